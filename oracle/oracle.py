@@ -1,0 +1,161 @@
+"""ctypes face of the ORACLE (oracle/liborc.so). TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product (gsdf_amd/) never imports, links or executes anything under oracle/.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class _Mesh(C.Structure):
+    _fields_ = [("tris", C.POINTER(C.c_float)), ("n_tris", C.c_uint64), ("cap", C.c_uint64), ("evals", C.c_uint64),
+                ("pruned", C.c_uint64), ("levels", C.c_int), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+                ("t_eval_s", C.c_double), ("t_march_s", C.c_double)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liborc.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_sdf_create.restype = C.c_void_p
+        L.orc_sdf_create.argtypes = [C.c_void_p]
+        L.orc_sdf_destroy.argtypes = [C.c_void_p]
+        L.orc_pool_create.restype = C.c_void_p
+        L.orc_pool_create.argtypes = [C.c_size_t]
+        L.orc_pool_destroy.argtypes = [C.c_void_p]
+        for f in (L.orc_eval3, L.orc_eval2):
+            f.restype = C.c_int
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_render_flat.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.POINTER(_Mesh)]
+        L.orc_render_octree.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.POINTER(_Mesh)]
+        L.orc_mesh_free.argtypes = [C.POINTER(_Mesh)]
+        L.orc_stl_size.restype = C.c_size_t
+        L.orc_stl_size.argtypes = [C.c_uint64]
+        L.orc_write_stl.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_march_cubes.restype = C.c_uint64
+        L.orc_march_cubes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p]
+        L.orc_normals_central_diff.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]
+        L.orc_mc_edge_table.restype = C.POINTER(C.c_uint16)
+        L.orc_mc_tri_table.restype = C.POINTER(C.c_int8)
+        _LIB = L
+    return _LIB
+
+
+class MeshResult:
+    def __init__(self, m):
+        n = int(m.n_tris)
+        self.tris = np.ctypeslib.as_array(m.tris, shape=(n, 3, 3)).copy() if n else np.zeros((0, 3, 3), np.float32)
+        self.n_tris = n
+        self.evals = int(m.evals)
+        self.pruned = int(m.pruned)
+        self.levels = int(m.levels)
+        self.grid = (int(m.nx), int(m.ny), int(m.nz))
+        self.t_eval_s = float(m.t_eval_s)
+        self.t_march_s = float(m.t_march_s)
+
+
+class OracleSDF:
+    """gleval.SDF3CPU / SDF2CPU restatement over a gsdf_tree (from gsdf_amd.builder.Shader.tree())."""
+
+    def __init__(self, tree, min_alloc=4096):
+        self._L = lib()
+        self._tree = tree
+        self._h = self._L.orc_sdf_create(C.byref(tree))
+        if not self._h:
+            raise ValueError("malformed tree")
+        self._pool = self._L.orc_pool_create(min_alloc)
+        self.bb = np.array(tree.bb[:], np.float32)
+        self.evals = 0
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.orc_sdf_destroy(self._h)
+                self._L.orc_pool_destroy(self._pool)
+                self._h = None
+        except Exception:
+            pass
+
+    def Bounds(self):
+        return self.bb
+
+    def Evaluate(self, pos, dist=None):
+        """pos: (n,3) or (n,2) float32. Returns dist (n,) float32 (written into `dist` if given)."""
+        pos = np.ascontiguousarray(pos, np.float32)
+        n = pos.shape[0]
+        if dist is None:
+            dist = np.empty(n, np.float32)
+        if dist.shape[0] != n:
+            raise ValueError("position and distance buffer length mismatch")
+        if n == 0:
+            raise ValueError("empty buffers")
+        f = self._L.orc_eval3 if pos.shape[1] == 3 else self._L.orc_eval2
+        err = f(self._h, self._pool, pos.ctypes.data, dist.ctypes.data, n)
+        if err:
+            raise RuntimeError(f"oracle eval error {err}")
+        self.evals += n
+        return dist
+
+    def render_flat(self, res, batch=4096, nthreads=1):
+        m = _Mesh()
+        err = self._L.orc_render_flat(self._h, np.float32(res), batch, nthreads, C.byref(m))
+        if err:
+            raise RuntimeError(f"oracle flat renderer error {err}")
+        r = MeshResult(m)
+        self._L.orc_mesh_free(C.byref(m))
+        return r
+
+    def render_octree(self, res, batch=4096, prune=True):
+        m = _Mesh()
+        err = self._L.orc_render_octree(self._h, np.float32(res), batch, int(prune), C.byref(m))
+        if err:
+            raise RuntimeError(f"oracle octree renderer error {err}")
+        r = MeshResult(m)
+        self._L.orc_mesh_free(C.byref(m))
+        return r
+
+    def normals_central_diff(self, pos, step):
+        pos = np.ascontiguousarray(pos, np.float32)
+        nrm = np.empty_like(pos)
+        err = self._L.orc_normals_central_diff(self._h, self._pool, pos.ctypes.data, nrm.ctypes.data, pos.shape[0], np.float32(step))
+        if err:
+            raise RuntimeError(f"oracle normals error {err}")
+        return nrm
+
+
+def write_stl(tris):
+    tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
+    L = lib()
+    buf = np.zeros(L.orc_stl_size(tris.shape[0]), np.uint8)
+    err = L.orc_write_stl(tris.ctypes.data, tris.shape[0], buf.ctypes.data)
+    if err:
+        raise ValueError("empty triangle slice" if err == -1 else "too many triangles")
+    return buf.tobytes()
+
+
+def march_cubes(pos, dist, res):
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 8, 3)
+    dist = np.ascontiguousarray(dist, np.float32).reshape(-1, 8)
+    n = pos.shape[0]
+    out = np.empty((5 * n, 3, 3), np.float32)
+    nt = lib().orc_march_cubes(pos.ctypes.data, dist.ctypes.data, n, np.float32(res), out.ctypes.data)
+    return out[:nt].copy()
+
+
+def mc_tables():
+    L = lib()
+    e = np.ctypeslib.as_array(L.orc_mc_edge_table(), shape=(256,)).copy()
+    t = np.ctypeslib.as_array(L.orc_mc_tri_table(), shape=(256, 16)).copy()
+    return e, t

@@ -1,0 +1,63 @@
+/*
+ * orc_eval.h -- ORACLE public interface (test infrastructure only).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything in oracle/.
+ */
+#ifndef ORC_EVAL_H
+#define ORC_EVAL_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../include/gsdf_program.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_sdf orc_sdf;
+typedef struct orc_pool orc_pool;
+
+orc_sdf* orc_sdf_create(const gsdf_tree* t); /* deep copy; NULL on malformed tree */
+void orc_sdf_destroy(orc_sdf* s);
+void orc_sdf_bounds(const orc_sdf* s, float bb[6]);
+int orc_sdf_root_is2d(const orc_sdf* s);
+
+orc_pool* orc_pool_create(size_t min_alloc); /* gleval.VecPool ; SetMinAllocationLen */
+void orc_pool_destroy(orc_pool* p);
+
+/* pos: n*3 floats (xyz AoS) / n*2 floats; dist: n floats. 0 on success. */
+int orc_eval3(const orc_sdf* s, orc_pool* vp, const float* pos, float* dist, size_t n);
+int orc_eval2(const orc_sdf* s, orc_pool* vp, const float* pos, float* dist, size_t n);
+
+/* ---- renderers (orc_render.c) ---- */
+typedef struct orc_mesh {
+  float* tris;     /* 9 floats per triangle, malloc'ed; free with orc_mesh_free */
+  uint64_t n_tris;
+  uint64_t cap;
+  uint64_t evals;  /* SDF evaluations performed */
+  uint64_t pruned; /* leaf cubes pruned (octree) */
+  int levels;      /* octree levels */
+  int nx, ny, nz;  /* flat grid cubes per axis */
+  double t_eval_s; /* seconds in SDF evaluation (flat: evalGrid) */
+  double t_march_s;
+} orc_mesh;
+void orc_mesh_free(orc_mesh* m);
+
+/* glrender.FlatRenderer (flatrenderer.go): batch = evalBufferSize, nthreads = numParallel. */
+int orc_render_flat(const orc_sdf* s, float res, int batch, int nthreads, orc_mesh* out);
+/* glrender.Octree (octreerenderer.go) with every Level>=3 cube centre-tested. prune=0 disables. */
+int orc_render_octree(const orc_sdf* s, float res, int batch, int prune, orc_mesh* out);
+/* glrender.WriteBinarySTL (stl.go:15-62): writes 84+50*n bytes into dst (caller sized). */
+size_t orc_stl_size(uint64_t n_tris);
+int orc_write_stl(const float* tris, uint64_t n_tris, uint8_t* dst);
+/* marchCubes on explicit cubes: pos 8*3*ncubes, dist 8*ncubes -> tris (cap 5*ncubes*9 floats). */
+uint64_t orc_march_cubes(const float* pos, const float* dist, uint64_t ncubes, float res, float* tris);
+/* gleval.NormalsCentralDiff (gleval/gleval.go:53-108) */
+int orc_normals_central_diff(const orc_sdf* s, orc_pool* vp, const float* pos, float* normals, size_t n, float step);
+/* table access for tests */
+const uint16_t* orc_mc_edge_table(void);
+const int8_t* orc_mc_tri_table(void); /* 256 x 16, -1 terminated */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

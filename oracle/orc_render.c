@@ -1,0 +1,400 @@
+/*
+ * orc_render.c -- ORACLE (test infrastructure only). CPU restatement of the reference meshers:
+ *   /root/reference/glrender/marchcubes.go:8-98        marchCubes, mcToTriangles, mcInterpolate
+ *   /root/reference/glrender/flatrenderer.go:36-256    FlatRenderer (Reset, evalGrid, evalKRange, ReadTriangles)
+ *   /root/reference/glrender/octreerenderer.go:71-284  Octree (Reset, makeICube, prune predicate, leaf corners)
+ *   /root/reference/glrender/stl.go:15-62              WriteBinarySTL
+ *   /root/reference/gleval/gleval.go:53-108            NormalsCentralDiff
+ * ms3.Octree / i3.Cube / ms3.Box are external (soypat/geometry, not vendored): restated from the
+ * call sites -- PARITY UNPINNED for those; pinned at count level by the reference's
+ * known answers (41072 sphere triangles, glrender_test.go:91; 423,852 npt-flange@400, README.md:116,130).
+ */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+
+#include "mc_tables.h"
+#include "orc_eval.h"
+#include "orc_math.h"
+
+typedef struct { float x, y, z; } V3;
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+const uint16_t* orc_mc_edge_table(void) { return ORC_MC_EDGE; }
+const int8_t* orc_mc_tri_table(void) { return &ORC_MC_TRI[0][0]; }
+
+void orc_mesh_free(orc_mesh* m) {
+  if (m && m->tris) { free(m->tris); m->tris = NULL; }
+}
+static void mesh_reserve(orc_mesh* m, uint64_t extra) {
+  if (m->n_tris + extra <= m->cap) return;
+  uint64_t nc = m->cap ? m->cap * 2 : 4096;
+  while (nc < m->n_tris + extra) nc *= 2;
+  m->tris = (float*)realloc(m->tris, nc * 9 * sizeof(float));
+  m->cap = nc;
+}
+
+/* ---------------- marching cubes (marchcubes.go) ---------------- */
+static const float GLRENDER_SQRT3 = 1.73205080757f; /* glrender.go:9 */
+
+/* marchcubes.go:76-98 */
+static V3 mc_interpolate(V3 p1, V3 p2, float v1, float v2, float x) {
+  const float eps = 1e-12f;
+  int c1 = go_absf(x - v1) < eps;
+  int c2 = go_absf(x - v2) < eps;
+  if (c1 && !c2) return p1;
+  if (c2 && !c1) return p2;
+  float t = 0.5f;
+  if (!c1 || !c2) t = (x - v1) / (v2 - v1);
+  V3 r = {p1.x + t * (p2.x - p1.x), p1.y + t * (p2.y - p1.y), p1.z + t * (p2.z - p1.z)};
+  return r;
+}
+
+/* marchcubes.go:34-73 ; dst must have room for 5 triangles (45 floats). */
+static int mc_to_triangles(float* dst, const V3 p[8], const float v[8], float x) {
+  int index = 0;
+  for (int i = 0; i < 8; i++)
+    if (v[i] < x) index |= 1 << i;
+  int edges = ORC_MC_EDGE[index];
+  if (edges == 0) return 0;
+  V3 pts[12];
+  for (int i = 0; i < 12; i++) {
+    if (edges & (1 << i)) {
+      int a = ORC_MC_PAIR[i][0], b = ORC_MC_PAIR[i][1];
+      pts[i] = mc_interpolate(p[a], p[b], v[a], v[b], x);
+    }
+  }
+  const int8_t* table = ORC_MC_TRI[index];
+  int nt = 0;
+  for (int i = 0; i < 16 && table[i] >= 0; i += 3) {
+    V3 a = pts[table[i + 2]], b = pts[table[i + 1]], c = pts[table[i + 0]];
+    float* t = dst + 9 * nt;
+    t[0] = a.x; t[1] = a.y; t[2] = a.z;
+    t[3] = b.x; t[4] = b.y; t[5] = b.z;
+    t[6] = c.x; t[7] = c.y; t[8] = c.z;
+    nt++;
+  }
+  return nt;
+}
+
+/* marchcubes.go:14-32 over explicit cubes. */
+uint64_t orc_march_cubes(const float* pos, const float* dist, uint64_t ncubes, float res, float* tris) {
+  float cubeDiag = 2 * GLRENDER_SQRT3 * res;
+  uint64_t nt = 0;
+  for (uint64_t c = 0; c < ncubes; c++) {
+    const float* d = dist + 8 * c;
+    if (go_absf(d[0]) <= cubeDiag) nt += mc_to_triangles(tris + 9 * nt, (const V3*)(pos + 24 * c), d, 0);
+  }
+  return nt;
+}
+
+/* ---------------- ms3.Box helpers [external, restated] ---------------- */
+typedef struct { V3 min, max; } Box3;
+static Box3 box_scale_centered(Box3 a, float sx, float sy, float sz) {
+  /* ScaleCentered(scale) = NewCenteredBox(a.Center(), MulElem(scale, a.Size())) */
+  V3 c = {0.5f * (a.min.x + a.max.x), 0.5f * (a.min.y + a.max.y), 0.5f * (a.min.z + a.max.z)};
+  V3 sz3 = {a.max.x - a.min.x, a.max.y - a.min.y, a.max.z - a.min.z};
+  V3 s = {go_maxf(sx, 0) * sz3.x, go_maxf(sy, 0) * sz3.y, go_maxf(sz, 0) * sz3.z};
+  V3 h = {0.5f * go_maxf(s.x, 0), 0.5f * go_maxf(s.y, 0), 0.5f * go_maxf(s.z, 0)};
+  Box3 r = {{c.x - h.x, c.y - h.y, c.z - h.z}, {c.x + h.x, c.y + h.y, c.z + h.z}};
+  return r;
+}
+
+/* ---------------- FlatRenderer (flatrenderer.go) ---------------- */
+typedef struct {
+  const orc_sdf* s;
+  float res;
+  V3 origin;
+  int nx, ny, nz;
+  float* grid;
+  int batch;
+  int k0, k1;
+  uint64_t evals;
+  int err;
+} flat_job;
+
+/* flatrenderer.go:146-182 evalKRange */
+static void* flat_eval_krange(void* arg) {
+  flat_job* j = (flat_job*)arg;
+  int bufSize = j->batch;
+  float* posbuf = (float*)malloc(sizeof(float) * 3 * bufSize);
+  float* distbuf = (float*)malloc(sizeof(float) * bufSize);
+  orc_pool* vp = orc_pool_create((size_t)bufSize);
+  size_t sz = (size_t)(j->nx + 1) * (j->ny + 1);
+  size_t batchStart = (size_t)j->k0 * sz;
+  int posIdx = 0;
+  for (int k = j->k0; k < j->k1 && !j->err; k++)
+    for (int jj = 0; jj <= j->ny && !j->err; jj++)
+      for (int i = 0; i <= j->nx; i++) {
+        posbuf[3 * posIdx + 0] = j->origin.x + (float)i * j->res;
+        posbuf[3 * posIdx + 1] = j->origin.y + (float)jj * j->res;
+        posbuf[3 * posIdx + 2] = j->origin.z + (float)k * j->res;
+        posIdx++;
+        if (posIdx == bufSize) {
+          j->err = orc_eval3(j->s, vp, posbuf, distbuf, (size_t)bufSize);
+          if (j->err) break;
+          memcpy(j->grid + batchStart, distbuf, sizeof(float) * bufSize);
+          j->evals += (uint64_t)bufSize;
+          batchStart += (size_t)bufSize;
+          posIdx = 0;
+        }
+      }
+  if (posIdx > 0 && !j->err) {
+    j->err = orc_eval3(j->s, vp, posbuf, distbuf, (size_t)posIdx);
+    if (!j->err) {
+      memcpy(j->grid + batchStart, distbuf, sizeof(float) * posIdx);
+      j->evals += (uint64_t)posIdx;
+    }
+  }
+  orc_pool_destroy(vp);
+  free(posbuf);
+  free(distbuf);
+  return NULL;
+}
+
+int orc_render_flat(const orc_sdf* s, float res, int batch, int nthreads, orc_mesh* out) {
+  memset(out, 0, sizeof(*out));
+  if (!(res > 0) || batch < 8 || nthreads < 1) return -1; /* flatrenderer.go:37-45 */
+  float bbf[6];
+  orc_sdf_bounds(s, bbf);
+  Box3 bb = {{bbf[0], bbf[1], bbf[2]}, {bbf[3], bbf[4], bbf[5]}};
+  bb = box_scale_centered(bb, 1.01f, 1.01f, 1.01f); /* :47-48 */
+  V3 sz = {bb.max.x - bb.min.x, bb.max.y - bb.min.y, bb.max.z - bb.min.z};
+  int nx = (int)go_ceilf(sz.x / res), ny = (int)go_ceilf(sz.y / res), nz = (int)go_ceilf(sz.z / res);
+  if (nx <= 0 || ny <= 0 || nz <= 0) return -2;
+  size_t gridSize = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
+  float* grid = (float*)malloc(sizeof(float) * gridSize);
+  if (!grid) return -5;
+  out->nx = nx; out->ny = ny; out->nz = nz;
+
+  /* evalGrid :103-141 */
+  double t0 = now_s();
+  int numG = nthreads;
+  if (numG > nz + 1) numG = nz + 1;
+  flat_job* jobs = (flat_job*)calloc((size_t)numG, sizeof(flat_job));
+  pthread_t* th = (pthread_t*)calloc((size_t)numG, sizeof(pthread_t));
+  for (int g = 0; g < numG; g++) {
+    flat_job* j = &jobs[g];
+    j->s = s; j->res = res; j->origin = bb.min; j->nx = nx; j->ny = ny; j->nz = nz;
+    j->grid = grid; j->batch = batch;
+    j->k0 = (int)((long long)g * (nz + 1) / numG);
+    j->k1 = (int)((long long)(g + 1) * (nz + 1) / numG);
+    if (numG == 1) flat_eval_krange(j);
+    else pthread_create(&th[g], NULL, flat_eval_krange, j);
+  }
+  int err = 0;
+  for (int g = 0; g < numG; g++) {
+    if (numG > 1) pthread_join(th[g], NULL);
+    if (jobs[g].err) err = jobs[g].err;
+    out->evals += jobs[g].evals;
+  }
+  free(jobs);
+  free(th);
+  out->t_eval_s = now_s() - t0;
+  if (err) { free(grid); return err; }
+
+  /* ReadTriangles :186-256 */
+  t0 = now_s();
+  size_t sy = (size_t)nx + 1;
+  size_t szz = sy * ((size_t)ny + 1);
+  float cubeDiag = 2 * GLRENDER_SQRT3 * res;
+  V3 o = bb.min;
+  for (int cz = 0; cz < nz; cz++)
+    for (int cy = 0; cy < ny; cy++)
+      for (int cx = 0; cx < nx; cx++) {
+        size_t base = (size_t)cx + (size_t)cy * sy + (size_t)cz * szz;
+        if (go_absf(grid[base]) > cubeDiag) continue;
+        float v[8] = {grid[base], grid[base + 1], grid[base + 1 + sy], grid[base + sy],
+                      grid[base + szz], grid[base + 1 + szz], grid[base + 1 + sy + szz], grid[base + sy + szz]};
+        float ox = o.x + (float)cx * res, oy = o.y + (float)cy * res, oz = o.z + (float)cz * res;
+        float r = res;
+        V3 p[8] = {{ox, oy, oz},         {ox + r, oy, oz},         {ox + r, oy + r, oz},         {ox, oy + r, oz},
+                   {ox, oy, oz + r},     {ox + r, oy, oz + r},     {ox + r, oy + r, oz + r},     {ox, oy + r, oz + r}};
+        mesh_reserve(out, 5);
+        out->n_tris += (uint64_t)mc_to_triangles(out->tris + 9 * out->n_tris, p, v, 0);
+      }
+  out->t_march_s = now_s() - t0;
+  free(grid);
+  return 0;
+}
+
+/* ---------------- Octree (octreerenderer.go) ---------------- */
+typedef struct { int32_t x, y, z; int32_t level; } Cube; /* x,y,z in leaf units; size = 2^(level-1) leaves */
+
+/* makeICube :222-235 */
+static int make_icube(Box3 bb, float res, int* levels) {
+  if (!(res > 0) || res != res || isinf(res)) return -1;
+  V3 sz = {bb.max.x - bb.min.x, bb.max.y - bb.min.y, bb.max.z - bb.min.z};
+  float longAxis = go_maxf(sz.x, go_maxf(sz.y, sz.z));
+  float l2 = go_log2f(longAxis / res);
+  int lv = (int)go_ceilf(l2) + 1;
+  if (lv <= 1) return -2;
+  *levels = lv;
+  return 0;
+}
+/* i3.Cube/ms3.Octree CubeSize, CubeOrigin [external]: size = float(2^(level-1))*res ;
+ * origin = Origin + size*float(levelIndex) with levelIndex = leafcoord >> (level-1). */
+static inline float cube_size(int level, float res) { return (float)(1 << (level - 1)) * res; }
+static inline V3 cube_origin(Cube c, V3 origin, float size) {
+  int sh = c.level - 1;
+  V3 r = {origin.x + size * (float)(c.x >> sh), origin.y + size * (float)(c.y >> sh), origin.z + size * (float)(c.z >> sh)};
+  return r;
+}
+
+typedef struct { Cube* v; size_t n, cap; } CubeVec;
+static void cv_push(CubeVec* cv, Cube c) {
+  if (cv->n == cv->cap) { cv->cap = cv->cap ? cv->cap * 2 : 1024; cv->v = (Cube*)realloc(cv->v, cv->cap * sizeof(Cube)); }
+  cv->v[cv->n++] = c;
+}
+
+int orc_render_octree(const orc_sdf* s, float res, int batch, int prune, orc_mesh* out) {
+  memset(out, 0, sizeof(*out));
+  if (batch < 64) return -1; /* :46-48 */
+  if (!(res > 0)) return -1;
+  float bbf[6];
+  orc_sdf_bounds(s, bbf);
+  Box3 bb = {{bbf[0], bbf[1], bbf[2]}, {bbf[3], bbf[4], bbf[5]}};
+  bb = box_scale_centered(bb, 1.01f, 1.01f, 1.01f); /* :79-80 */
+  int levels;
+  int err = make_icube(bb, res, &levels);
+  if (err) return err;
+  if (levels > 21) return -6;
+  out->levels = levels;
+  V3 origin = bb.min;
+  batch &= ~7;
+  float* posbuf = (float*)malloc(sizeof(float) * 3 * (size_t)batch);
+  float* distbuf = (float*)malloc(sizeof(float) * (size_t)batch);
+  orc_pool* vp = orc_pool_create((size_t)batch);
+  const float szMult = GLRENDER_SQRT3 / 2; /* :182 */
+
+  /* Level-synchronous descent. Every cube with Level >= minPrunableLvl(3) is centre-tested with the
+   * reference predicate (:270-273) -- a superset of the capacity-dependent subset the reference
+   * tests through DecomposeBFS (:140, table :94-105); identical surface for 1-Lipschitz fields. */
+  CubeVec cur = {0}, nxt = {0};
+  Cube top = {0, 0, 0, levels};
+  cv_push(&cur, top);
+  double t0 = now_s();
+  for (int level = levels; level >= 2; level--) {
+    nxt.n = 0;
+    if (level >= 3 && prune) {
+      float size = cube_size(level, res);
+      float maxDist = size * szMult;
+      for (size_t b0 = 0; b0 < cur.n; b0 += (size_t)batch) {
+        size_t nb = cur.n - b0 < (size_t)batch ? cur.n - b0 : (size_t)batch;
+        for (size_t i = 0; i < nb; i++) {
+          V3 o = cube_origin(cur.v[b0 + i], origin, size);
+          V3 mx = {o.x + size, o.y + size, o.z + size};
+          /* CubeCenter = box.Center() = Scale(0.5, Add(Min, Max)) [external] */
+          posbuf[3 * i] = 0.5f * (o.x + mx.x); posbuf[3 * i + 1] = 0.5f * (o.y + mx.y); posbuf[3 * i + 2] = 0.5f * (o.z + mx.z);
+        }
+        err = orc_eval3(s, vp, posbuf, distbuf, nb);
+        if (err) goto done;
+        out->evals += nb;
+        for (size_t i = 0; i < nb; i++) {
+          int prunable = go_absf(distbuf[i]) >= maxDist;
+          if (!prunable) {
+            Cube c = cur.v[b0 + i];
+            int h = 1 << (level - 2); /* child size in leaves */
+            /* children in corner order (i3.Cube octree decomposition [external]) */
+            const int ox[8] = {0, 1, 1, 0, 0, 1, 1, 0}, oy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, oz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+            for (int k = 0; k < 8; k++) { Cube ch = {c.x + ox[k] * h, c.y + oy[k] * h, c.z + oz[k] * h, level - 1}; cv_push(&nxt, ch); }
+          } else {
+            out->pruned += (uint64_t)1 << (3 * (level - 1)); /* DecomposesTo(1) = 8^(level-1) :279 */
+          }
+        }
+      }
+    } else {
+      for (size_t i = 0; i < cur.n; i++) {
+        Cube c = cur.v[i];
+        int h = 1 << (level - 2);
+        const int ox[8] = {0, 1, 1, 0, 0, 1, 1, 0}, oy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, oz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+        for (int k = 0; k < 8; k++) { Cube ch = {c.x + ox[k] * h, c.y + oy[k] * h, c.z + oz[k] * h, level - 1}; cv_push(&nxt, ch); }
+      }
+    }
+    CubeVec t = cur; cur = nxt; nxt = t;
+  }
+  /* cur = leaf cubes (level 1): 8 corners each (Box.Vertices order), evaluate + marchCubes :161-172 */
+  {
+    size_t cubesPerBatch = (size_t)batch / 8;
+    for (size_t b0 = 0; b0 < cur.n; b0 += cubesPerBatch) {
+      size_t nb = cur.n - b0 < cubesPerBatch ? cur.n - b0 : cubesPerBatch;
+      for (size_t i = 0; i < nb; i++) {
+        V3 o = cube_origin(cur.v[b0 + i], origin, res);
+        V3 m = {o.x + res, o.y + res, o.z + res};
+        float* p = posbuf + 24 * i;
+        p[0] = o.x; p[1] = o.y; p[2] = o.z;
+        p[3] = m.x; p[4] = o.y; p[5] = o.z;
+        p[6] = m.x; p[7] = m.y; p[8] = o.z;
+        p[9] = o.x; p[10] = m.y; p[11] = o.z;
+        p[12] = o.x; p[13] = o.y; p[14] = m.z;
+        p[15] = m.x; p[16] = o.y; p[17] = m.z;
+        p[18] = m.x; p[19] = m.y; p[20] = m.z;
+        p[21] = o.x; p[22] = m.y; p[23] = m.z;
+      }
+      err = orc_eval3(s, vp, posbuf, distbuf, nb * 8);
+      if (err) goto done;
+      out->evals += nb * 8;
+      mesh_reserve(out, 5 * nb);
+      out->n_tris += orc_march_cubes(posbuf, distbuf, nb, res, out->tris + 9 * out->n_tris);
+    }
+  }
+  out->t_eval_s = now_s() - t0;
+done:
+  free(cur.v); free(nxt.v);
+  orc_pool_destroy(vp);
+  free(posbuf); free(distbuf);
+  return err;
+}
+
+/* ---------------- STL (stl.go:15-62) ---------------- */
+size_t orc_stl_size(uint64_t n) { return 84 + 50 * (size_t)n; }
+static void put_f32(uint8_t* b, float f) { uint32_t u = orc_f32bits(f); b[0] = u; b[1] = u >> 8; b[2] = u >> 16; b[3] = u >> 24; }
+int orc_write_stl(const float* tris, uint64_t n, uint8_t* dst) {
+  if (n == 0) return -1;           /* "empty triangle slice" */
+  if (n > 0xffffffffull) return -2; /* exceeds STL design limits */
+  memset(dst, 0, 84);
+  uint32_t cnt = (uint32_t)n;
+  dst[80] = cnt; dst[81] = cnt >> 8; dst[82] = cnt >> 16; dst[83] = cnt >> 24;
+  for (uint64_t i = 0; i < n; i++) {
+    const float* t = tris + 9 * i;
+    uint8_t* b = dst + 84 + 50 * i;
+    /* ms3.Triangle.Normal() = Cross(t1-t0, t2-t0); Unit(v) = Scale(1/Norm(v), v) [external] */
+    V3 a = {t[3] - t[0], t[4] - t[1], t[5] - t[2]};
+    V3 c = {t[6] - t[0], t[7] - t[1], t[8] - t[2]};
+    V3 nrm = {a.y * c.z - a.z * c.y, a.z * c.x - a.x * c.z, a.x * c.y - a.y * c.x};
+    float inv = 1 / go_hypotf(nrm.x, go_hypotf(nrm.y, nrm.z));
+    put_f32(b, inv * nrm.x); put_f32(b + 4, inv * nrm.y); put_f32(b + 8, inv * nrm.z);
+    for (int k = 0; k < 9; k++) put_f32(b + 12 + 4 * k, t[k]);
+    b[48] = 0; b[49] = 0;
+  }
+  return 0;
+}
+
+/* ---------------- NormalsCentralDiff (gleval/gleval.go:53-108) ---------------- */
+int orc_normals_central_diff(const orc_sdf* s, orc_pool* vp, const float* pos, float* normals, size_t n, float step) {
+  step *= 0.5f;
+  if (!(step > 0)) return -1;
+  if (n == 0) return -1;
+  float* d1 = (float*)malloc(sizeof(float) * n);
+  float* d2 = (float*)malloc(sizeof(float) * n);
+  float* aux = (float*)malloc(sizeof(float) * 3 * n);
+  int err = 0;
+  for (int dim = 0; dim < 3 && !err; dim++) {
+    for (size_t i = 0; i < n; i++) { aux[3 * i] = pos[3 * i]; aux[3 * i + 1] = pos[3 * i + 1]; aux[3 * i + 2] = pos[3 * i + 2]; aux[3 * i + dim] = pos[3 * i + dim] + step; }
+    err = orc_eval3(s, vp, aux, d1, n);
+    if (err) break;
+    for (size_t i = 0; i < n; i++) { aux[3 * i] = pos[3 * i]; aux[3 * i + 1] = pos[3 * i + 1]; aux[3 * i + 2] = pos[3 * i + 2]; aux[3 * i + dim] = pos[3 * i + dim] - step; }
+    err = orc_eval3(s, vp, aux, d2, n);
+    if (err) break;
+    for (size_t i = 0; i < n; i++) normals[3 * i + dim] = d1[i] - d2[i];
+  }
+  free(d1); free(d2); free(aux);
+  return err;
+}
