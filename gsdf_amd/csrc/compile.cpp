@@ -1,0 +1,362 @@
+// compile.cpp -- lowers a gsdf tree blob to the device instruction stream (dev_ops.h).
+//
+// Every constant emitted here is computed with the same float32 operation sequence the reference's
+// Evaluate methods use for their loop-invariant values (cpu_evaluators.go, cited per case), so the
+// device sees bit-identical parameters. MUST be compiled with -ffp-contract=off.
+#include "compile.h"
+
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "../host/ms.hpp"
+#include "dev_ops.h"
+
+namespace gsdf_dev {
+namespace {
+
+constexpr float TRIBISECT = 0.8660254037844386467637231707529361834714026269051903140279034897f;
+constexpr float SQRT3 = 1.7320508075688772935274463415058723669428052538103806280558069794f;
+
+struct Ctx {
+  const gsdf_tree* t;
+  std::vector<uint32_t> code;
+  int slots = 0;      // currently allocated
+  int max_slots = 0;
+  size_t max_code;
+  std::vector<int8_t> clob;  // memo: -1 unknown, 0/1
+
+  int alloc(int n) {
+    int s = slots;
+    slots += n;
+    if (slots > max_slots) max_slots = slots;
+    if (slots > 0xffff) throw std::runtime_error("too many scratch slots");
+    return s;
+  }
+  void release(int n) { slots -= n; }
+  void op(uint32_t o, int slot = 0) {
+    if (code.size() > max_code) throw std::runtime_error("program too large after unrolling multi-evaluation nodes");
+    code.push_back(o | ((uint32_t)slot << 16));
+  }
+  void f(float v) { uint32_t u; std::memcpy(&u, &v, 4); code.push_back(u); }
+  void u(uint32_t v) { code.push_back(v); }
+  const gsdf_node& node(uint32_t i) const { return t->nodes[i]; }
+  uint32_t child(const gsdf_node& n, uint32_t k) const { return t->links[n.link_off + k]; }
+};
+
+// Does evaluating node i overwrite the position register?
+bool clobbers(Ctx& c, uint32_t i) {
+  if (c.clob[i] >= 0) return c.clob[i];
+  const gsdf_node& n = c.node(i);
+  bool r;
+  switch (n.op) {
+    case GSDF_OFFSET: case GSDF_OFFSET2D: case GSDF_ANNULUS2D:
+      r = clobbers(c, c.child(n, 0));
+      break;
+    case GSDF_UNION: case GSDF_INTERSECT: case GSDF_DIFF: case GSDF_XOR: case GSDF_SMOOTH_UNION:
+    case GSDF_SMOOTH_DIFF: case GSDF_SMOOTH_INTERSECT: case GSDF_UNION2D: case GSDF_INTERSECT2D:
+    case GSDF_DIFF2D: case GSDF_XOR2D: {
+      r = false;
+      for (uint32_t k = 0; k < n.nchild; k++) r = r || clobbers(c, c.child(n, k));
+      break;
+    }
+    default:
+      r = n.nchild > 0;  // every other operator rewrites P; primitives do not
+  }
+  c.clob[i] = r;
+  return r;
+}
+
+void gen(Ctx& c, uint32_t i, int depth);
+
+// n-ary / binary combine frame (cpu_evaluators.go:124-286, 821-912).
+void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int depth) {
+  bool is2d = gsdf_op_is2d(n.op);
+  bool need_save = false;
+  for (uint32_t k = 0; k + 1 < n.nchild; k++) need_save = need_save || clobbers(c, c.child(n, k));
+  int slotP = -1;
+  if (need_save) { slotP = c.alloc(is2d ? 2 : 3); c.op(is2d ? D_SAVEP2 : D_SAVEP3, slotP); }
+  int slotD = c.alloc(1);
+  bool dirty = false;
+  for (uint32_t k = 0; k < n.nchild; k++) {
+    if (k > 0 && dirty) { c.op(is2d ? D_LOADP2 : D_LOADP3, slotP); dirty = false; }
+    uint32_t ch = c.child(n, k);
+    gen(c, ch, depth + 1);
+    dirty = dirty || clobbers(c, ch);
+    if (k > 0) { c.op(comb, slotD); if (has_k) c.f(n.p[0]); }
+    if (k + 1 < n.nchild) c.op(D_SAVER, slotD);
+  }
+  c.release(1);
+  if (need_save) c.release(is2d ? 2 : 3);
+}
+
+void gen(Ctx& c, uint32_t i, int depth) {
+  if (depth > 256) throw std::runtime_error("tree too deep (cycle?)");
+  const gsdf_node& n = c.node(i);
+  const float* P = n.p;
+  auto need_children = [&](uint32_t k) { if (n.nchild != k) throw std::runtime_error("bad child count for op " + std::to_string(n.op)); };
+  auto child_dim = [&](bool want2d) {
+    for (uint32_t k = 0; k < n.nchild; k++)
+      if ((bool)gsdf_op_is2d(c.node(c.child(n, k)).op) != want2d) throw std::runtime_error("child dimension mismatch for op " + std::to_string(n.op));
+  };
+  switch (n.op) {
+    // ------------------------------- 3D primitives -------------------------------
+    case GSDF_SPHERE: c.op(D_SPHERE); c.f(P[0]); break;                                              // :20-26
+    case GSDF_BOX: c.op(D_BOX); c.f(0.5f * P[0]); c.f(0.5f * P[1]); c.f(0.5f * P[2]); c.f(P[3]); break;  // :28-36
+    case GSDF_BOXFRAME: {                                                                          // :38-57, primitives.go:292-297
+      float e = P[3];
+      c.op(D_BOXFRAME); c.f(e);
+      c.f(0.5f * P[0] + (-2 * e)); c.f(0.5f * P[1] + (-2 * e)); c.f(0.5f * P[2] + (-2 * e));
+      break;
+    }
+    case GSDF_TORUS: c.op(D_TORUS); c.f(P[0]); c.f(P[1]); break;                                   // :59-68
+    case GSDF_CYLINDER: {                                                                          // :70-88, primitives.go:147-149
+      float r = P[0], h = (P[1] - 2 * P[2]) / 2, round = P[2];
+      if (round == 0) { c.op(D_CYL0); c.f(r); c.f(h); }
+      else { c.op(D_CYLR); c.f(r); c.f(h); c.f(round); }
+      break;
+    }
+    case GSDF_HEX: c.op(D_HEX); c.f(P[0]); c.f(P[1]); c.f(0.57735f * P[0]); break;                  // :90-105
+    // ------------------------------- 3D booleans -------------------------------
+    case GSDF_UNION: if (n.nchild < 2) throw std::runtime_error("OpUnion must have at least 2 elements"); child_dim(false); gen_combine(c, n, D_COMBINE_MIN, false, depth); break;
+    case GSDF_INTERSECT: need_children(2); child_dim(false); gen_combine(c, n, D_COMBINE_MAX, false, depth); break;
+    case GSDF_DIFF: need_children(2); child_dim(false); gen_combine(c, n, D_COMBINE_DIFF, false, depth); break;
+    case GSDF_XOR: need_children(2); child_dim(false); gen_combine(c, n, D_COMBINE_XOR, false, depth); break;
+    case GSDF_SMOOTH_UNION: need_children(2); child_dim(false); gen_combine(c, n, D_COMBINE_SUNION, true, depth); break;
+    case GSDF_SMOOTH_DIFF: need_children(2); child_dim(false); gen_combine(c, n, D_COMBINE_SDIFF, true, depth); break;
+    case GSDF_SMOOTH_INTERSECT: need_children(2); child_dim(false); gen_combine(c, n, D_COMBINE_SINTER, true, depth); break;
+    // ------------------------------- 3D unary -------------------------------
+    case GSDF_SCALE: need_children(1); child_dim(false);                                           // :288-312
+      c.op(D_SCALE_PRE); c.f(1.f / P[0]); gen(c, c.child(n, 0), depth + 1); c.op(D_MULR); c.f(P[0]); break;
+    case GSDF_SYMMETRY: need_children(1); child_dim(false);                                        // :314-343
+      c.op(D_SYMMETRY); c.u((uint32_t)(int)P[0]); gen(c, c.child(n, 0), depth + 1); break;
+    case GSDF_ARRAY: {                                                                             // :345-397
+      need_children(1); child_dim(false);
+      int slotP = c.alloc(3), slotD = c.alloc(1);
+      c.op(D_SAVEP3, slotP);
+      c.op(D_SETSLOT, slotD); c.f(1e20f);
+      for (int k = 0; k < 2; k++) for (int j = 0; j < 2; j++) for (int ii = 0; ii < 2; ii++) {
+        c.op(D_ARRAY_PRE, slotP);
+        c.f((float)ii); c.f((float)j); c.f((float)k);
+        c.f(P[0]); c.f(P[1]); c.f(P[2]);
+        c.f(P[3] + -1); c.f(P[4] + -1); c.f(P[5] + -1);
+        gen(c, c.child(n, 0), depth + 1);
+        c.op(D_COMBINE_MIN, slotD);
+        if (!(k == 1 && j == 1 && ii == 1)) c.op(D_SAVER, slotD);
+      }
+      c.release(4);
+      break;
+    }
+    case GSDF_ELONGATE: {                                                                          // :399-426
+      need_children(1); child_dim(false);
+      int s = c.alloc(1);
+      c.op(D_ELONGATE_PRE, s); c.f(0.5f * P[0]); c.f(0.5f * P[1]); c.f(0.5f * P[2]);
+      gen(c, c.child(n, 0), depth + 1);
+      c.op(D_ADDR_SLOT, s);
+      c.release(1);
+      break;
+    }
+    case GSDF_SHELL: need_children(1); child_dim(false);                                           // :428-452
+      c.op(D_SCALE_PRE); c.f(1 / P[0]); gen(c, c.child(n, 0), depth + 1); c.op(D_SHELL_POST); c.f(P[0]); break;
+    case GSDF_OFFSET: need_children(1); child_dim(false);                                          // :454-468
+      gen(c, c.child(n, 0), depth + 1); c.op(D_ADDR); c.f(P[0]); break;
+    case GSDF_TRANSLATE: need_children(1); child_dim(false);                                       // :470-486
+      c.op(D_TRANSLATE); c.f(P[0]); c.f(P[1]); c.f(P[2]); gen(c, c.child(n, 0), depth + 1); break;
+    case GSDF_TRANSFORM: {                                                                         // :488-504
+      need_children(1); child_dim(false);
+      if (n.aux_len < 16) throw std::runtime_error("transform needs 16 aux floats");
+      c.op(D_TRANSFORM);
+      for (int k = 0; k < 12; k++) c.f(c.t->aux[n.aux_off + k]);
+      gen(c, c.child(n, 0), depth + 1);
+      break;
+    }
+    case GSDF_CIRCARRAY: case GSDF_CIRCARRAY2D: {                                                  // :1042-1143
+      need_children(1);
+      bool is2d = n.op == GSDF_CIRCARRAY2D;
+      child_dim(is2d);
+      int slotP = c.alloc(is2d ? 2 : 3), slotD = c.alloc(1);
+      if (!is2d) c.op(D_SAVEP3, slotP);  // keeps z at slotP+2; CIRC_PRE overwrites slotP..+1 with p0.xy
+      c.op(D_CIRC_PRE, slotP);
+      c.f((float)(2 * gsdf::kPi) / P[1]); c.f(P[1]); c.f((float)((int)P[0] - 1));
+      gen(c, c.child(n, 0), depth + 1);  // pos1 first
+      c.op(D_SAVER, slotD);
+      c.op(is2d ? D_LOADP2 : D_LOADP3, slotP);
+      gen(c, c.child(n, 0), depth + 1);  // pos0
+      c.op(D_COMBINE_MIN, slotD);
+      c.release(is2d ? 3 : 4);
+      break;
+    }
+    case GSDF_TWIST: need_children(1); child_dim(false);                                           // :1257-1274
+      c.op(D_TWIST); c.f(P[0]); gen(c, c.child(n, 0), depth + 1); break;
+    // ------------------------------- 2D -> 3D -------------------------------
+    case GSDF_EXTRUSION: {                                                                         // :506-531
+      need_children(1); child_dim(true);
+      int s = c.alloc(1);
+      c.op(D_EXTRUDE_PRE, s); c.f(P[0] / 2);
+      gen(c, c.child(n, 0), depth + 1);
+      c.op(D_EXTRUDE_POST, s);
+      c.release(1);
+      break;
+    }
+    case GSDF_REVOLUTION: need_children(1); child_dim(true);                                       // :533-549
+      c.op(D_REVOLVE_PRE); c.f(P[0]); gen(c, c.child(n, 0), depth + 1); break;
+    case GSDF_SCREW: {                                                                             // threads.go:141-181
+      need_children(1); child_dim(true);
+      int s = c.alloc(1);
+      c.op(D_SCREW_PRE, s);
+      c.f(P[0]); c.f(P[1]); c.f(P[2]); c.f(gsdf::tanf32(P[3])); c.f(P[0] / 2);
+      gen(c, c.child(n, 0), depth + 1);
+      c.op(D_MAXR_SLOT, s);
+      c.release(1);
+      break;
+    }
+    // ------------------------------- 2D primitives -------------------------------
+    case GSDF_LINE2D: {                                                                            // :551-562
+      float bax = P[2] - P[0], bay = P[3] - P[1];
+      c.op(D_LINE2D); c.f(P[0]); c.f(P[1]); c.f(bax); c.f(bay); c.f(bax * bax + bay * bay); c.f(P[4] / 2);
+      break;
+    }
+    case GSDF_ARC2D: {                                                                             // :564-579
+      float s, cs;
+      gsdf::sincosf32(P[1] / 2, s, cs);
+      c.op(D_ARC2D); c.f(P[0]); c.f(P[2] / 2); c.f(s); c.f(cs); c.f(P[0] * s); c.f(P[0] * cs);
+      break;
+    }
+    case GSDF_QUADBEZIER2D: {                                                                      // :581-593
+      float Ax = P[0], Ay = P[1], Bx = P[2], By = P[3], Cx = P[4], Cy = P[5];
+      float ax = Bx - Ax, ay = By - Ay;
+      float a2 = ax * ax + ay * ay;
+      float bx = Ax + (Cx - 2 * Bx), by = Ay + (Cy - 2 * By);
+      float cx = 2 * ax, cy = 2 * ay;
+      float kk = 1.f / (bx * bx + by * by);
+      float kx = kk * (ax * bx + ay * by);
+      float kx2 = kx * kx;
+      c.op(D_QUADBEZIER2D);
+      c.f(Ax); c.f(Ay); c.f(ax); c.f(ay); c.f(a2); c.f(bx); c.f(by); c.f(cx); c.f(cy); c.f(kk); c.f(kx); c.f(kx2); c.f(P[6] / 2);
+      break;
+    }
+    case GSDF_CIRCLE2D: c.op(D_CIRCLE2D); c.f(P[0]); break;                                        // :661-667
+    case GSDF_EQTRI2D: { float r = P[0] / SQRT3; c.op(D_EQTRI2D); c.f(r); c.f(r / SQRT3); break; }  // :669-683
+    case GSDF_RECT2D: c.op(D_RECT2D); c.f(0.5f * P[0]); c.f(0.5f * P[1]); break;                    // :685-692
+    case GSDF_DIAMOND2D: {                                                                         // :694-703
+      float bx = 0.5f * P[0], by = 0.5f * P[1];
+      c.op(D_DIAMOND2D); c.f(bx); c.f(by); c.f(bx * bx + by * by); c.f(0.5f * bx); c.f(0.5f * by); c.f(bx * by);
+      break;
+    }
+    case GSDF_X2D: c.op(D_X2D); c.f(P[0]); c.f(P[1]); break;                                       // :705-716
+    case GSDF_HEX2D: c.op(D_HEX2D); c.f(P[0]); c.f(0.577350269f * P[0]); break;                     // :718-729
+    case GSDF_OCT2D: c.op(D_OCT2D); c.f(P[0]); c.f(0.4142135623f * P[0]); break;                    // :731-748
+    case GSDF_ELLIPSE2D: c.op(D_ELLIPSE2D); c.f(P[0]); c.f(P[1]); break;                           // :750-791
+    case GSDF_POLY2D: {                                                                            // :793-818
+      uint32_t nv = n.aux_len / 2;
+      if (nv < 3) throw std::runtime_error("polygon needs at least 3 vertices");
+      const float* v = &c.t->aux[n.aux_off];
+      c.op(D_POLY2D); c.u(nv); c.f(v[0]); c.f(v[1]);
+      uint32_t jv = nv - 1;
+      for (uint32_t iv = 0; iv < nv; iv++) {
+        float v1x = v[2 * iv], v1y = v[2 * iv + 1], v2x = v[2 * jv], v2y = v[2 * jv + 1];
+        float ex = v2x - v1x, ey = v2y - v1y;
+        c.f(v1x); c.f(v1y); c.f(ex); c.f(ey); c.f(ex * ex + ey * ey); c.f(v2y);
+        jv = iv;
+      }
+      break;
+    }
+    case GSDF_LINES2D: {                                                                           // :1145-1160
+      uint32_t ns = n.aux_len / 4;
+      const float* sg = &c.t->aux[n.aux_off];
+      c.op(D_LINES2D); c.u(ns); c.f(P[0] / 2);
+      for (uint32_t k = 0; k < ns; k++) {
+        float ax = sg[4 * k], ay = sg[4 * k + 1], bax = sg[4 * k + 2] - ax, bay = sg[4 * k + 3] - ay;
+        c.f(ax); c.f(ay); c.f(bax); c.f(bay); c.f(bax * bax + bay * bay);
+      }
+      break;
+    }
+    // ------------------------------- 2D ops -------------------------------
+    case GSDF_UNION2D: if (n.nchild < 2) throw std::runtime_error("OpUnion2D must have at least 2 elements"); child_dim(true); gen_combine(c, n, D_COMBINE_MIN, false, depth); break;
+    case GSDF_INTERSECT2D: need_children(2); child_dim(true); gen_combine(c, n, D_COMBINE_MAX, false, depth); break;
+    case GSDF_DIFF2D: need_children(2); child_dim(true); gen_combine(c, n, D_COMBINE_DIFF, false, depth); break;
+    case GSDF_XOR2D: need_children(2); child_dim(true); gen_combine(c, n, D_COMBINE_XOR, false, depth); break;
+    case GSDF_ARRAY2D: {                                                                           // :914-962
+      need_children(1); child_dim(true);
+      int slotP = c.alloc(2), slotD = c.alloc(1);
+      c.op(D_SAVEP2, slotP);
+      c.op(D_SETSLOT, slotD); c.f(1e20f);
+      for (int j = 0; j < 2; j++) for (int ii = 0; ii < 2; ii++) {
+        c.op(D_ARRAY2D_PRE, slotP);
+        c.f((float)ii); c.f((float)j); c.f(P[0]); c.f(P[1]); c.f(P[2] + -1); c.f(P[3] + -1);
+        gen(c, c.child(n, 0), depth + 1);
+        c.op(D_COMBINE_MIN, slotD);
+        if (!(j == 1 && ii == 1)) c.op(D_SAVER, slotD);
+      }
+      c.release(3);
+      break;
+    }
+    case GSDF_OFFSET2D: need_children(1); child_dim(true); gen(c, c.child(n, 0), depth + 1); c.op(D_ADDR); c.f(P[0]); break;  // :964-978
+    case GSDF_TRANSLATE2D: need_children(1); child_dim(true);                                      // :980-996
+      c.op(D_TRANSLATE); c.f(P[0]); c.f(P[1]); c.f(0.f); gen(c, c.child(n, 0), depth + 1); break;
+    case GSDF_SYMMETRY2D: need_children(1); child_dim(true);                                       // :998-1024
+      c.op(D_SYMMETRY); c.u((uint32_t)(int)P[0] & 3u); gen(c, c.child(n, 0), depth + 1); break;
+    case GSDF_ANNULUS2D: need_children(1); child_dim(true); gen(c, c.child(n, 0), depth + 1); c.op(D_ANNULUS); c.f(P[0]); break;  // :1026-1040
+    case GSDF_TRANSLATEMULTI2D: {                                                                  // :1162-1184
+      need_children(1); child_dim(true);
+      uint32_t nd = n.aux_len / 2;
+      const float* d = &c.t->aux[n.aux_off];
+      int slotP = c.alloc(2), slotD = c.alloc(1);
+      c.op(D_SAVEP2, slotP);
+      c.op(D_SETSLOT, slotD); c.f(3.40282346638528859811704183484516925440e+38f);
+      if (nd == 0) { c.op(D_SETR); c.f(3.40282346638528859811704183484516925440e+38f); }
+      for (uint32_t k = 0; k < nd; k++) {
+        c.op(D_LOADP2_SUB, slotP); c.f(d[2 * k]); c.f(d[2 * k + 1]);
+        gen(c, c.child(n, 0), depth + 1);
+        c.op(D_COMBINE_MIN, slotD);
+        if (k + 1 < nd) c.op(D_SAVER, slotD);
+      }
+      c.release(3);
+      break;
+    }
+    case GSDF_ROTATION2D: need_children(1); child_dim(true);                                       // :1186-1203
+      c.op(D_ROT2D); c.f(P[0]); c.f(P[1]); c.f(P[2]); c.f(P[3]); gen(c, c.child(n, 0), depth + 1); break;
+    case GSDF_SCALE2D: need_children(1); child_dim(true);                                          // :1205-1226
+      c.op(D_SCALE_PRE); c.f(1.f / P[0]); gen(c, c.child(n, 0), depth + 1); c.op(D_MULR); c.f(P[0]); break;
+    case GSDF_ELONGATE2D: {                                                                        // :1228-1255
+      need_children(1); child_dim(true);
+      int s = c.alloc(1);
+      c.op(D_ELONGATE2D_PRE, s); c.f(0.5f * P[0]); c.f(0.5f * P[1]);
+      gen(c, c.child(n, 0), depth + 1);
+      c.op(D_ADDR_SLOT, s);
+      c.release(1);
+      break;
+    }
+    default:
+      throw std::runtime_error("unknown op " + std::to_string(n.op));
+  }
+}
+
+}  // namespace
+
+Program compile(const gsdf_tree& t, size_t max_code_words) {
+  if (!t.nodes || t.n_nodes == 0 || t.root >= t.n_nodes) throw std::runtime_error("malformed tree: bad root");
+  for (uint32_t i = 0; i < t.n_nodes; i++) {
+    const gsdf_node& nd = t.nodes[i];
+    if (nd.op == GSDF_OP_INVALID || nd.op >= GSDF_OP_COUNT) throw std::runtime_error("malformed tree: bad op");
+    if ((uint64_t)nd.link_off + nd.nchild > t.n_links) throw std::runtime_error("malformed tree: links out of range");
+    if ((uint64_t)nd.aux_off + nd.aux_len > t.n_aux) throw std::runtime_error("malformed tree: aux out of range");
+    for (uint32_t k = 0; k < nd.nchild; k++)
+      if (t.links[nd.link_off + k] >= t.n_nodes) throw std::runtime_error("malformed tree: child out of range");
+  }
+  Ctx c;
+  c.t = &t;
+  c.max_code = max_code_words;
+  c.clob.assign(t.n_nodes, -1);
+  gen(c, t.root, 0);
+  c.op(D_END);
+  Program p;
+  p.code = std::move(c.code);
+  p.nslots = c.max_slots;
+  p.is2d = gsdf_op_is2d(t.nodes[t.root].op);
+  std::memcpy(p.bb, t.bb, sizeof(p.bb));
+  return p;
+}
+
+}  // namespace gsdf_dev

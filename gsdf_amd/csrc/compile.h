@@ -1,0 +1,21 @@
+// compile.h -- host lowering of a gsdf tree blob to the device instruction stream.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/gsdf_program.h"
+
+namespace gsdf_dev {
+
+struct Program {
+  std::vector<uint32_t> code;  // dev_ops.h stream, terminated by D_END
+  int nslots = 0;              // LDS scratch slots per lane
+  bool is2d = false;           // root takes 2D positions
+  float bb[6] = {0};
+};
+
+// Throws std::runtime_error on malformed trees. max_code_words bounds unrolling blow-up.
+Program compile(const gsdf_tree& t, size_t max_code_words = (1u << 22));
+
+}  // namespace gsdf_dev

@@ -1,0 +1,196 @@
+// dev_math.h -- gfx950 device math for the SDF interpreter.
+//
+// float32 semantics of the reference's CPU evaluators (Go on amd64: IEEE single ops, never fused):
+// every expression below is a sequence of correctly rounded +,-,*,/,sqrt; compile with
+// -ffp-contract=off and without fast-math so hipcc keeps v_mul/v_add pairs (no v_fma contraction)
+// and its correctly rounded fp32 divide/sqrt expansions. Transcendentals follow the algorithms the
+// reference's math package uses (chewxy/math32 v1.11.1: float32(math.X(float64)) wrappers over Go's
+// Cephes-derived float64 routines for Atan2/Sin/Cos/Acos/Cbrt; float32 ports for Hypot/Sincos), so
+// distances are bit-identical to the CPU path for finite inputs. Not reproduced: Inf/NaN special
+// cases of hypot/atan2 (unreachable with finite positions) and math.Min/Max NaN propagation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dm {
+
+#define DM_INL __device__ __forceinline__
+
+DM_INL float absf(float x) { return __builtin_fabsf(x); }
+DM_INL float minf(float a, float b) { return __builtin_fminf(a, b); }  // v_min_f32: -0 < +0 like math.Min
+DM_INL float maxf(float a, float b) { return __builtin_fmaxf(a, b); }
+DM_INL float sqrtf_(float x) { return __builtin_sqrtf(x); }
+DM_INL float floorf_(float x) { return __builtin_floorf(x); }
+DM_INL float roundf_(float x) { return __builtin_roundf(x); }  // half away from zero == Go math.Round
+DM_INL float copysignf_(float x, float s) { return __builtin_copysignf(x, s); }
+DM_INL float signf(float a) { return a == 0.0f ? 0.0f : copysignf_(1.0f, a); }
+DM_INL float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+DM_INL float mixf(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+
+// math32.Hypot (float32 port of go/src/math/hypot.go)
+DM_INL float hypotf_(float p, float q) {
+  p = absf(p);
+  q = absf(q);
+  float hi = p < q ? q : p;
+  float lo = p < q ? p : q;
+  float r = lo / hi;
+  float v = hi * sqrtf_(1.0f + r * r);
+  return hi == 0.0f ? 0.0f : v;
+}
+DM_INL float norm3(float x, float y, float z) { return hypotf_(x, hypotf_(y, z)); }  // ms3.Norm
+DM_INL float norm2(float x, float y) { return hypotf_(x, y); }                       // ms2.Norm
+
+// math32.Sincos (float32 port of go/src/math/sincos.go)
+DM_INL void sincosf_(float x, float& s_out, float& c_out) {
+  const float PI4A = 7.85398125648498535156e-1f, PI4B = 3.77489470793079817668e-8f, PI4C = 2.69515142907905952645e-15f;
+  const float M4PI = 1.2732395447351628f;  // float32(4/Pi)
+  const float S0 = 1.58962301576546568060e-10f, S1 = -2.50507477628578072866e-8f, S2 = 2.75573136213857245213e-6f,
+              S3 = -1.98412698295895385996e-4f, S4 = 8.33333333332211858878e-3f, S5 = -1.66666666666666307295e-1f;
+  const float C0 = -1.13585365213876817300e-11f, C1 = 2.08757008419747316778e-9f, C2 = -2.75573141792967388112e-7f,
+              C3 = 2.48015872888517045348e-5f, C4 = -1.38888888888730564116e-3f, C5 = 4.16666666666665929218e-2f;
+  bool sinSign = x < 0.0f, cosSign = false;
+  float ax = absf(x);
+  uint32_t j = (uint32_t)(ax * M4PI);
+  float y = (float)j;
+  if (j & 1u) { j++; y += 1.0f; }
+  j &= 7u;
+  float z = ((ax - y * PI4A) - y * PI4B) - y * PI4C;
+  if (j > 3u) { j -= 4u; sinSign = !sinSign; cosSign = !cosSign; }
+  if (j > 1u) cosSign = !cosSign;
+  float zz = z * z;
+  float c = 1.0f - 0.5f * zz + zz * zz * ((((((C0 * zz) + C1) * zz + C2) * zz + C3) * zz + C4) * zz + C5);
+  float s = z + z * zz * ((((((S0 * zz) + S1) * zz + S2) * zz + S3) * zz + S4) * zz + S5);
+  bool sw = (j == 1u || j == 2u);
+  float s2 = sw ? c : s, c2 = sw ? s : c;
+  c2 = cosSign ? -c2 : c2;
+  s2 = sinSign ? -s2 : s2;
+  // x == 0: Go returns (x, 1)
+  s_out = x == 0.0f ? x : s2;
+  c_out = x == 0.0f ? 1.0f : c2;
+}
+
+// ---- float64 Go routines behind float32(math.X(float64(x))) ----
+#define DM_PI 3.14159265358979323846264338327950288
+
+DM_INL double xatan(double x) {
+  const double P0 = -8.750608600031904122785e-01, P1 = -1.615753718733365076637e+01, P2 = -7.500855792314704667340e+01,
+               P3 = -1.228866684490136173410e+02, P4 = -6.485021904942025371773e+01, Q0 = +2.485846490142306297962e+01,
+               Q1 = +1.650270098316988542046e+02, Q2 = +4.328810604912902668951e+02, Q3 = +4.853903996359136964868e+02,
+               Q4 = +1.945506571482613964425e+02;
+  double z = x * x;
+  z = z * ((((P0 * z + P1) * z + P2) * z + P3) * z + P4) / (((((z + Q0) * z + Q1) * z + Q2) * z + Q3) * z + Q4);
+  z = x * z + x;
+  return z;
+}
+DM_INL double satan(double x) {  // x >= 0
+  const double Morebits = 6.123233995736765886130e-17, Tan3pio8 = 2.41421356237309504880;
+  if (x <= 0.66) return xatan(x);
+  if (x > Tan3pio8) return DM_PI / 2 - xatan(1.0 / x) + Morebits;
+  return DM_PI / 4 + xatan((x - 1.0) / (x + 1.0)) + 0.5 * Morebits;
+}
+DM_INL double atan64(double x) {
+  if (x == 0.0) return x;
+  if (x > 0.0) return satan(x);
+  return -satan(-x);
+}
+// math.Atan2 (go/src/math/atan2.go), finite inputs.
+DM_INL float atan2f_(float yf, float xf) {
+  double y = (double)yf, x = (double)xf;
+  double r;
+  if (y == 0.0) {
+    r = (x >= 0.0 && !__builtin_signbit(x)) ? __builtin_copysign(0.0, y) : __builtin_copysign(DM_PI, y);
+  } else if (x == 0.0) {
+    r = __builtin_copysign(DM_PI / 2, y);
+  } else {
+    double q = atan64(y / x);
+    r = x < 0.0 ? (q <= 0.0 ? q + DM_PI : q - DM_PI) : q;
+  }
+  return (float)r;
+}
+
+DM_INL double trig_poly_sin(double z, double zz) {
+  return z + z * zz * ((((((1.58962301576546568060e-10 * zz) + -2.50507477628578072866e-8) * zz + 2.75573136213857245213e-6) * zz +
+                          -1.98412698295895385996e-4) * zz + 8.33333333332211858878e-3) * zz + -1.66666666666666307295e-1);
+}
+DM_INL double trig_poly_cos(double zz) {
+  return 1.0 - 0.5 * zz + zz * zz * ((((((-1.13585365213876817300e-11 * zz) + 2.08757008419747316778e-9) * zz + -2.75573141792967388112e-7) * zz +
+                                        2.48015872888517045348e-5) * zz + -1.38888888888730564116e-3) * zz + 4.16666666666665929218e-2);
+}
+// math.Cos / math.Sin (go/src/math/sin.go), |x| < 2^29.
+DM_INL float cosf_(float xf) {
+  double x = __builtin_fabs((double)xf);
+  bool sign = false;
+  uint64_t j = (uint64_t)(x * (4.0 / DM_PI));
+  double y = (double)j;
+  if (j & 1) { j++; y += 1.0; }
+  j &= 7;
+  double z = ((x - y * 7.85398125648498535156e-1) - y * 3.77489470793079817668e-8) - y * 2.69515142907905952645e-15;
+  if (j > 3) { j -= 4; sign = !sign; }
+  if (j > 1) sign = !sign;
+  double zz = z * z;
+  double r = (j == 1 || j == 2) ? trig_poly_sin(z, zz) : trig_poly_cos(zz);
+  return (float)(sign ? -r : r);
+}
+DM_INL float sinf_(float xf) {
+  double x = (double)xf;
+  if (x == 0.0) return xf;
+  bool sign = false;
+  if (x < 0.0) { x = -x; sign = true; }
+  uint64_t j = (uint64_t)(x * (4.0 / DM_PI));
+  double y = (double)j;
+  if (j & 1) { j++; y += 1.0; }
+  j &= 7;
+  double z = ((x - y * 7.85398125648498535156e-1) - y * 3.77489470793079817668e-8) - y * 2.69515142907905952645e-15;
+  if (j > 3) { sign = !sign; j -= 4; }
+  double zz = z * z;
+  double r = (j == 1 || j == 2) ? trig_poly_cos(zz) : trig_poly_sin(z, zz);
+  return (float)(sign ? -r : r);
+}
+// math.Acos = Pi/2 - Asin (go/src/math/asin.go)
+DM_INL float acosf_(float xf) {
+  double x = (double)xf;
+  double as;
+  if (x == 0.0) {
+    as = x;
+  } else {
+    bool sign = x < 0.0;
+    x = __builtin_fabs(x);
+    if (x > 1.0) return __builtin_nanf("");
+    double temp = __builtin_sqrt(1.0 - x * x);
+    if (x > 0.7) temp = DM_PI / 2 - satan(temp / x);
+    else temp = satan(x / temp);
+    as = sign ? -temp : temp;
+  }
+  return (float)(DM_PI / 2 - as);
+}
+// math.Cbrt (go/src/math/cbrt.go), x finite.
+DM_INL float cbrtf_(float xf) {
+  double x = (double)xf;
+  if (x == 0.0) return xf;
+  const double C = 5.42857142857142815906e-01, D = -7.05306122448979611050e-01, E = 1.41428571428571436819e+00,
+               F = 1.60714285714285720630e+00, G = 3.57142857142857150787e-01;
+  bool sign = x < 0.0;
+  x = __builtin_fabs(x);
+  double t = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(x) / 3ull + (715094163ull << 32)));
+  // float32 inputs converted to double are never double-subnormal: SmallestNormal branch unreachable.
+  double r = t * t / x;
+  double s = C + r * t;
+  t *= G + F / (s + E + D / s);
+  t = __longlong_as_double((long long)(((unsigned long long)__double_as_longlong(t) & (0xFFFFFFFFCull << 28)) + (1ull << 30)));
+  s = t * t;
+  r = x / s;
+  double w = t + t;
+  r = (r - t) / (w + r);
+  t = t + t * r;
+  return (float)(sign ? -t : t);
+}
+// math32.Pow(x, 1/3) for x >= 0 (gsdf.go:183): exp(yf*log(x)) -- see oracle note; agrees with the
+// CPU restatement to <= 1 ulp (ocml log/exp vs libm), quadbezier2d only.
+DM_INL float pow13f_(float x) {
+  if (x == 0.0f) return 0.0f;
+  const float yf = 0.3333333432674407958984375f;
+  float l = (float)__ocml_log_f64((double)x);
+  return (float)__ocml_exp_f64((double)(yf * l));
+}
+
+}  // namespace dm

@@ -1,0 +1,84 @@
+// dev_ops.h -- device instruction set of the gsdf_hip SDF interpreter (product-internal).
+//
+// A gsdf tree blob (include/gsdf_program.h) is lowered on the host (compile.cpp) to a straight-line
+// u32 instruction stream that every lane executes in lock step (wave-uniform control flow: the
+// program counter and every parameter live in SGPRs). Per-lane state is the current position
+// P (3 VGPRs), the current distance R (1 VGPR) and a per-lane scratch column in LDS
+// ("LDS-staged node stack", slot s of lane t at lds[s*blockDim + t], conflict-free).
+// Slots are allocated statically by the host compiler, so there is no stack pointer at run time.
+//
+// Encoding: word0 = opcode | slot<<16 ; then `nparam` 32-bit words (float bits / uints).
+#pragma once
+#include <stdint.h>
+
+enum DevOp : uint32_t {
+  D_END = 0,
+  // ---- 3D primitives: R = f(P)
+  D_SPHERE,    // r
+  D_BOX,       // hx hy hz round            (h = 0.5*dims)
+  D_BOXFRAME,  // e bx by bz
+  D_TORUS,     // R r
+  D_CYL0,      // r h'                       (round == 0 path)
+  D_CYLR,      // r h' round
+  D_HEX,       // h1 h2 clm
+  // ---- 2D primitives: R = f(P.xy)
+  D_LINE2D,    // ax ay bax bay dotba w
+  D_ARC2D,     // r t s c scrx scry
+  D_QUADBEZIER2D,  // Ax Ay ax ay a2 bx by cx cy kk kx kx2 thick
+  D_CIRCLE2D,  // r
+  D_EQTRI2D,   // r r/k
+  D_RECT2D,    // bx by
+  D_DIAMOND2D, // bx by dotbb hbx hby bxby
+  D_X2D,       // w r
+  D_HEX2D,     // r kzr
+  D_OCT2D,     // r kzr
+  D_ELLIPSE2D, // a b
+  D_POLY2D,    // nv v0x v0y then nv x {v1x v1y ex ey n2e v2y}
+  D_LINES2D,   // ns w then ns x {ax ay bax bay dotba}
+  // ---- position pre-ops: P = T(P)
+  D_TRANSLATE,     // tx ty tz
+  D_SCALE_PRE,     // inv
+  D_SYMMETRY,      // bits
+  D_TRANSFORM,     // m00 m01 m02 m03 m10 .. m23 (12)
+  D_TWIST,         // k
+  D_ROT2D,         // x00 x01 x10 x11
+  D_EXTRUDE_PRE,   // h/2            slot <- |z|-h/2
+  D_REVOLVE_PRE,   // off
+  D_SCREW_PRE,     // pitch lead L tanTaper halfpitch   slot <- |z|-L
+  D_ELONGATE_PRE,  // hx hy hz       slot <- min(max3(q),0)
+  D_ELONGATE2D_PRE,// hx hy          slot <- min(max2(q),0)
+  D_ARRAY_PRE,     // i j k sx sy sz nx ny nz   P = f(saved P at slot..slot+2)
+  D_ARRAY2D_PRE,   // i j sx sy nx ny           P = f(saved P at slot..slot+1)
+  D_CIRC_PRE,      // angle ncirc ninsm1 : P = p1 ; slot..slot+1 <- p0.xy (3D keeps z in place)
+  D_LOADP2_SUB,    // dx dy          P.xy = saved(slot..slot+1) - d
+  // ---- distance post-ops: R = g(R)
+  D_MULR,          // f
+  D_SHELL_POST,    // th
+  D_ADDR,          // off
+  D_ANNULUS,       // r
+  D_EXTRUDE_POST,  // (slot)
+  D_MAXR_SLOT,     // (slot)  R = max(R, lds[slot])
+  D_ADDR_SLOT,     // (slot)  R += lds[slot]
+  // ---- scratch
+  D_SAVEP3, D_LOADP3, D_SAVEP2, D_LOADP2, D_SAVER,  // (slot)
+  D_SETSLOT,       // value (slot)
+  D_SETR,          // value : R = value
+  // ---- combine: a = lds[slot] (first operand), b = R  ->  R
+  D_COMBINE_MIN, D_COMBINE_MAX, D_COMBINE_DIFF, D_COMBINE_XOR,
+  D_COMBINE_SUNION, D_COMBINE_SDIFF, D_COMBINE_SINTER,  // k
+  D_OP_COUNT
+};
+
+// Fixed parameter-word counts (D_POLY2D / D_LINES2D are variable: 3+6*nv / 2+5*ns).
+static const uint8_t kDevOpParams[D_OP_COUNT] = {
+    /*END*/ 0,
+    /*SPHERE*/ 1, /*BOX*/ 4, /*BOXFRAME*/ 4, /*TORUS*/ 2, /*CYL0*/ 2, /*CYLR*/ 3, /*HEX*/ 3,
+    /*LINE2D*/ 6, /*ARC2D*/ 6, /*QUADBEZIER*/ 13, /*CIRCLE*/ 1, /*EQTRI*/ 2, /*RECT*/ 2, /*DIAMOND*/ 6, /*X2D*/ 2,
+    /*HEX2D*/ 2, /*OCT2D*/ 2, /*ELLIPSE*/ 2, /*POLY*/ 3, /*LINES*/ 2,
+    /*TRANSLATE*/ 3, /*SCALE_PRE*/ 1, /*SYMMETRY*/ 1, /*TRANSFORM*/ 12, /*TWIST*/ 1, /*ROT2D*/ 4,
+    /*EXTRUDE_PRE*/ 1, /*REVOLVE_PRE*/ 1, /*SCREW_PRE*/ 5, /*ELONGATE_PRE*/ 3, /*ELONGATE2D_PRE*/ 2,
+    /*ARRAY_PRE*/ 9, /*ARRAY2D_PRE*/ 6, /*CIRC_PRE*/ 3, /*LOADP2_SUB*/ 2,
+    /*MULR*/ 1, /*SHELL_POST*/ 1, /*ADDR*/ 1, /*ANNULUS*/ 1, /*EXTRUDE_POST*/ 0, /*MAXR_SLOT*/ 0, /*ADDR_SLOT*/ 0,
+    /*SAVEP3*/ 0, /*LOADP3*/ 0, /*SAVEP2*/ 0, /*LOADP2*/ 0, /*SAVER*/ 0, /*SETSLOT*/ 1, /*SETR*/ 1,
+    /*MIN*/ 0, /*MAX*/ 0, /*DIFF*/ 0, /*XOR*/ 0, /*SUNION*/ 1, /*SDIFF*/ 1, /*SINTER*/ 1,
+};

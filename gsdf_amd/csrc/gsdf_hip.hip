@@ -1,0 +1,751 @@
+// gsdf_hip.hip -- gfx950 kernels + C ABI (include/gsdf_hip.h) of the MI355X SDF backend.
+//
+// Kernels (all wave64, 256-thread workgroups, grid-stride with wave-uniform trip counts so that the
+// interpreter's program counter stays scalar):
+//   eval_kernel<DIM>     dist[i] = SDF(pos[i])                      gleval SDF3/SDF2.Evaluate
+//   prune_kernel         octree level: centre sample, keep iff |d| < size*sqrt3/2, ballot+prefix
+//                        compaction of survivors                    glrender/octreerenderer.go:240-284
+//   leaf_first_kernel    leaf corner 0 + reject |d0| > 2*sqrt3*res, compaction of active leaves
+//                                                                   glrender/marchcubes.go:20-23
+//   leaf_march_kernel    remaining 7 corners + marching cubes with LDS tables, wave prefix-sum
+//                        triangle slot allocation                   glrender/marchcubes.go:34-98
+//   stl_kernel           50-byte STL records staged through LDS     glrender/stl.go:15-62
+//   normals_kernel       central differences                        gleval/gleval.go:53-108
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/gsdf_hip.h"
+#include "compile.h"
+#include "interp.h"
+#include "mc_tables.h"
+
+using gsdf_dev::code_ptr;
+using gsdf_dev::P3;
+
+#define BLOCK 256
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t _e = (expr);                                                                             \
+    if (_e != hipSuccess) return fail(GSDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+extern "C" const char* gsdf_hip_last_error(void) { return g_err.c_str(); }
+
+// ---------------------------------------------------------------------------------------------
+// device side
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ code_ptr as_code(const uint32_t* p) { return (code_ptr)(uintptr_t)p; }
+
+extern __shared__ __attribute__((aligned(16))) float g_smem[];
+
+template <int DIM>
+__global__ void __launch_bounds__(BLOCK) eval_kernel(const uint32_t* __restrict__ code_g, const float* __restrict__ pos,
+                                                     uint32_t stride_f, float* __restrict__ dist, uint64_t n) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {  // uniform trip count
+    const uint64_t i = base + threadIdx.x;
+    const bool valid = i < n;
+    P3 p = {0.f, 0.f, 0.f};
+    if (valid) {
+      const float* q = pos + i * stride_f;
+      p.x = q[0];
+      p.y = q[1];
+      if (DIM == 3) p.z = q[2];
+    }
+    float d = gsdf_dev::sdf_eval(code, p, lds, BLOCK);
+    if (valid) dist[i] = d;
+  }
+}
+
+// Octree cube: level-index coordinates (leaf coordinate >> (level-1)).
+struct __attribute__((aligned(8))) Cube {
+  uint16_t x, y, z, w;
+};
+
+struct MeshCounters {
+  unsigned long long n_out;     // survivors appended by the current prune level
+  unsigned long long n_active;  // active leaves
+  unsigned long long n_tris;
+  unsigned long long overflow;  // triangle buffer overflow flag
+};
+
+// wave64 compaction: returns the global slot for lanes with keep=true (others undefined).
+__device__ __forceinline__ unsigned long long wave_append(bool keep, unsigned long long* counter) {
+  const unsigned long long mask = __ballot(keep);
+  const unsigned int lane_prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+  unsigned long long base = 0;
+  if (mask != 0ull) {
+    const int leader = __builtin_ctzll(mask);
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, (unsigned long long)__builtin_popcountll(mask));
+    base = __shfl(base, leader, 64);
+  }
+  return base + lane_prefix;
+}
+
+// One octree level. expand=1: item i is child (i&7) of in[i>>3]; expand=0: item i is in[i].
+__global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ in,
+                                                      uint64_t n_items, int expand, int level, float ox, float oy, float oz,
+                                                      float res, int do_test, Cube* __restrict__ out,
+                                                      MeshCounters* __restrict__ ctr) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  const float size = (float)(1 << (level - 1)) * res;  // i3.Cube size at this level
+  const float maxDist = size * (1.73205080757f / 2);    // szDistMult = sqrt3/2 (octreerenderer.go:182)
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_items; base += step) {
+    const uint64_t i = base + threadIdx.x;
+    const bool valid = i < n_items;
+    Cube c = {0, 0, 0, 0};
+    if (valid) {
+      if (expand) {
+        const Cube pc = in[i >> 3];
+        const unsigned k = (unsigned)(i & 7);
+        // children in corner order: 0:(0,0,0) 1:(+x) 2:(+x,+y) 3:(+y) 4..7 same at +z
+        c.x = (uint16_t)(pc.x * 2 + ((k ^ (k >> 1)) & 1));
+        c.y = (uint16_t)(pc.y * 2 + ((k >> 1) & 1));
+        c.z = (uint16_t)(pc.z * 2 + ((k >> 2) & 1));
+      } else {
+        c = in[i];
+      }
+    }
+    bool keep = valid;
+    if (do_test) {
+      const float cx0 = ox + size * (float)c.x, cy0 = oy + size * (float)c.y, cz0 = oz + size * (float)c.z;
+      P3 p;  // CubeCenter = Scale(0.5, Add(min, max)), max = min + size
+      p.x = 0.5f * (cx0 + (cx0 + size));
+      p.y = 0.5f * (cy0 + (cy0 + size));
+      p.z = 0.5f * (cz0 + (cz0 + size));
+      const float d = gsdf_dev::sdf_eval(code, p, lds, BLOCK);
+      keep = valid && !(dm::absf(d) >= maxDist);
+    }
+    const unsigned long long slot = wave_append(keep, &ctr->n_out);
+    if (keep) out[slot] = c;
+  }
+}
+
+// Leaf phase A: corner 0 of every leaf of every surviving cube at level lq (lpc_shift = 3*(lq-1)).
+__global__ void __launch_bounds__(BLOCK) leaf_first_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
+                                                           uint64_t n_leaves, int lq, float ox, float oy, float oz, float res,
+                                                           Cube* __restrict__ act, float* __restrict__ act_d0,
+                                                           MeshCounters* __restrict__ ctr) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
+  const int sh = lq - 1;                            // leaves per axis = 1<<sh
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_leaves; base += step) {
+    const uint64_t i = base + threadIdx.x;
+    const bool valid = i < n_leaves;
+    Cube lf = {0, 0, 0, 0};
+    if (valid) {
+      const Cube pc = cubes[i >> (3 * sh)];
+      const unsigned l = (unsigned)(i & ((1u << (3 * sh)) - 1u));
+      const unsigned m = (1u << sh) - 1u;
+      lf.x = (uint16_t)((pc.x << sh) + (l & m));
+      lf.y = (uint16_t)((pc.y << sh) + ((l >> sh) & m));
+      lf.z = (uint16_t)((pc.z << sh) + ((l >> (2 * sh)) & m));
+    }
+    P3 p = {ox + res * (float)lf.x, oy + res * (float)lf.y, oz + res * (float)lf.z};
+    const float d0 = gsdf_dev::sdf_eval(code, p, lds, BLOCK);
+    const bool keep = valid && (dm::absf(d0) <= cubeDiag);
+    const unsigned long long slot = wave_append(keep, &ctr->n_active);
+    if (keep) {
+      act[slot] = lf;
+      act_d0[slot] = d0;
+    }
+  }
+}
+
+// mcInterpolate (marchcubes.go:76-98) with x = 0.
+__device__ __forceinline__ void mc_interp(float ax, float ay, float az, float bx, float by, float bz, float v1, float v2,
+                                          float& rx, float& ry, float& rz) {
+  const float eps = 1e-12f;
+  const bool c1 = dm::absf(0.f - v1) < eps, c2 = dm::absf(0.f - v2) < eps;
+  float t = 0.5f;
+  if (!c1 || !c2) t = (0.f - v1) / (v2 - v1);
+  float x = ax + t * (bx - ax), y = ay + t * (by - ay), z = az + t * (bz - az);
+  if (c1 && !c2) { x = ax; y = ay; z = az; }
+  if (c2 && !c1) { x = bx; y = by; z = bz; }
+  rx = x; ry = y; rz = z;
+}
+
+// Leaf phase B: corners 1..7 of each active leaf, marching cubes, triangle emission.
+// LDS: [nslots+8 floats per lane | triangle table 256 x 16 x i8]; edge pairs are immediate nibbles.
+__global__ void __launch_bounds__(BLOCK) leaf_march_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ act,
+                                                           const float* __restrict__ act_d0, uint64_t n_active, int nslots,
+                                                           float ox, float oy, float oz, float res, float* __restrict__ tris,
+                                                           uint64_t tri_cap, MeshCounters* __restrict__ ctr) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  float* vslot = lds + (size_t)nslots * BLOCK;  // 8 per-lane corner distances
+  int8_t* s_tri = (int8_t*)(g_smem + (size_t)(nslots + 8) * BLOCK);  // marching-cubes triangle table in LDS
+  for (int k = threadIdx.x; k < 256 * 16; k += BLOCK) s_tri[k] = GSDF_MC_TRI[k >> 4][k & 15];
+  __syncthreads();
+
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_active; base += step) {
+    const uint64_t i = base + threadIdx.x;
+    const bool valid = i < n_active;
+    Cube lf = {0, 0, 0, 0};
+    float d0 = 1.0f;
+    if (valid) { lf = act[i]; d0 = act_d0[i]; }
+    const float x0 = ox + res * (float)lf.x, y0 = oy + res * (float)lf.y, z0 = oz + res * (float)lf.z;
+    const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;  // Box max = origin + size
+    vslot[0] = d0;
+    unsigned index = d0 < 0.f ? 1u : 0u;
+#pragma unroll 1
+    for (unsigned c = 1; c < 8; c++) {
+      P3 p;
+      p.x = ((c ^ (c >> 1)) & 1u) ? x1 : x0;
+      p.y = ((c >> 1) & 1u) ? y1 : y0;
+      p.z = ((c >> 2) & 1u) ? z1 : z0;
+      const float d = gsdf_dev::sdf_eval(code, p, lds, BLOCK);
+      vslot[c * BLOCK] = d;
+      index |= (d < 0.f ? 1u : 0u) << c;
+    }
+    if (!valid) index = 0;
+    // count triangles for this cube
+    unsigned nt = 0;
+    {
+      const int8_t* row = s_tri + index * 16;
+      while (nt < 5 && row[3 * nt] >= 0) nt++;
+    }
+    // wave exclusive prefix sum of nt (Hillis-Steele over 64 lanes)
+    unsigned incl = nt;
+    const unsigned lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      unsigned v = __shfl_up(incl, off, 64);
+      if (lane >= (unsigned)off) incl += v;
+    }
+    const unsigned total = __shfl(incl, 63, 64);
+    unsigned long long wbase = 0;
+    if (total) {
+      if (lane == 0) wbase = atomicAdd(&ctr->n_tris, (unsigned long long)total);
+      wbase = __shfl(wbase, 0, 64);
+    }
+    if (nt) {
+      const unsigned long long first = wbase + (incl - nt);
+      if (first + nt > tri_cap) {
+        ctr->overflow = 1ull;
+      } else {
+        const int8_t* row = s_tri + index * 16;
+        float* dst = tris + first * 9;
+        for (unsigned t = 0; t < nt; t++) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const int e = row[3 * t + (2 - k)];  // reversed winding (marchcubes.go:64-68)
+            const unsigned a = GSDF_MC_PAIR_A(e), b = GSDF_MC_PAIR_B(e);
+            const float va = vslot[a * BLOCK], vb = vslot[b * BLOCK];
+            const float pax = ((a ^ (a >> 1)) & 1u) ? x1 : x0, pay = ((a >> 1) & 1u) ? y1 : y0, paz = ((a >> 2) & 1u) ? z1 : z0;
+            const float pbx = ((b ^ (b >> 1)) & 1u) ? x1 : x0, pby = ((b >> 1) & 1u) ? y1 : y0, pbz = ((b >> 2) & 1u) ? z1 : z0;
+            float rx, ry, rz;
+            mc_interp(pax, pay, paz, pbx, pby, pbz, va, vb, rx, ry, rz);
+            dst[9 * t + 3 * k + 0] = rx;
+            dst[9 * t + 3 * k + 1] = ry;
+            dst[9 * t + 3 * k + 2] = rz;
+          }
+        }
+      }
+    }
+  }
+}
+
+// STL records (stl.go:15-62): one wave stages 64 x 50-byte records in LDS, then stores dwords.
+__global__ void __launch_bounds__(BLOCK) stl_kernel(const float* __restrict__ tris, uint64_t n, uint8_t* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint8_t stage[BLOCK * 50];
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {
+    const uint64_t i = base + threadIdx.x;
+    if (i < n) {
+      const float* t = tris + 9 * i;
+      float v[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) v[k] = t[k];
+      // Unit(Cross(t1-t0, t2-t0)) with ms3.Norm = nested hypot
+      const float ax = v[3] - v[0], ay = v[4] - v[1], az = v[5] - v[2];
+      const float cx = v[6] - v[0], cy = v[7] - v[1], cz = v[8] - v[2];
+      const float nx = ay * cz - az * cy, ny = az * cx - ax * cz, nz = ax * cy - ay * cx;
+      const float inv = 1.0f / dm::norm3(nx, ny, nz);
+      uint16_t* rec = (uint16_t*)(stage + threadIdx.x * 50);
+      float f[12] = {inv * nx, inv * ny, inv * nz, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]};
+#pragma unroll
+      for (int k = 0; k < 12; k++) {
+        const uint32_t u = __float_as_uint(f[k]);
+        rec[2 * k] = (uint16_t)(u & 0xffffu);
+        rec[2 * k + 1] = (uint16_t)(u >> 16);
+      }
+      rec[24] = 0;
+    }
+    __syncthreads();
+    const uint64_t nrec = (n - base) < BLOCK ? (n - base) : BLOCK;
+    const uint64_t nbytes = nrec * 50;
+    uint8_t* o = out + 84 + base * 50;  // base is a multiple of 256 -> 4-byte aligned
+    const uint32_t* s32 = (const uint32_t*)stage;
+    uint32_t* o32 = (uint32_t*)o;
+    const uint64_t nwords = nbytes / 4;
+    for (uint64_t k = threadIdx.x; k < nwords; k += BLOCK) o32[k] = s32[k];
+    for (uint64_t k = nwords * 4 + threadIdx.x; k < nbytes; k += BLOCK) o[k] = stage[k];
+    __syncthreads();
+  }
+}
+
+// gleval.NormalsCentralDiff (gleval/gleval.go:53-108); h = step/2.
+__global__ void __launch_bounds__(BLOCK) normals_kernel(const uint32_t* __restrict__ code_g, const float* __restrict__ pos,
+                                                        float* __restrict__ nrm, uint64_t n, float h) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {
+    const uint64_t i = base + threadIdx.x;
+    const bool valid = i < n;
+    float px = 0, py = 0, pz = 0;
+    if (valid) { px = pos[3 * i]; py = pos[3 * i + 1]; pz = pos[3 * i + 2]; }
+    float out[3];
+#pragma unroll 1
+    for (int dim = 0; dim < 3; dim++) {
+      P3 a = {px + (dim == 0 ? h : 0.f), py + (dim == 1 ? h : 0.f), pz + (dim == 2 ? h : 0.f)};
+      P3 b = {px - (dim == 0 ? h : 0.f), py - (dim == 1 ? h : 0.f), pz - (dim == 2 ? h : 0.f)};
+      const float d1 = gsdf_dev::sdf_eval(code, a, lds, BLOCK);
+      const float d2 = gsdf_dev::sdf_eval(code, b, lds, BLOCK);
+      const float v = d1 - d2;
+      if (dim == 0) out[0] = v; else if (dim == 1) out[1] = v; else out[2] = v;
+    }
+    if (valid) { nrm[3 * i] = out[0]; nrm[3 * i + 1] = out[1]; nrm[3 * i + 2] = out[2]; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct gsdf_program {
+  gsdf_dev::Program prog;
+  int device = 0;
+  uint32_t* d_code = nullptr;
+  hipStream_t stream = nullptr;
+  uint64_t evals = 0;
+  // staging for the host-buffer API
+  void* d_pos = nullptr;
+  float* d_dist = nullptr;
+  size_t cap_pos_bytes = 0, cap_dist = 0;
+  int num_cu = 256;
+  size_t lds_bytes() const { return (size_t)(prog.nslots > 0 ? prog.nslots : 1) * BLOCK * sizeof(float); }
+};
+
+struct gsdf_mesh {
+  int device = 0;
+  float* d_tris = nullptr;
+  uint64_t cap = 0;
+  gsdf_mesh_stats st{};
+  hipStream_t stream = nullptr;
+};
+
+static unsigned grid_for(uint64_t n, int num_cu, int blocks_per_cu) {
+  uint64_t b = (n + BLOCK - 1) / BLOCK;
+  uint64_t mx = (uint64_t)num_cu * (uint64_t)blocks_per_cu;
+  if (b > mx) b = mx;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+extern "C" int gsdf_hip_init(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) return fail(GSDF_ERR_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+  if (device >= 0) {
+    if (device >= n) return fail(GSDF_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+  }
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_hip_program_create(const gsdf_tree* tree, gsdf_program** out) {
+  if (!tree || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  gsdf_program* p = new (std::nothrow) gsdf_program();
+  if (!p) return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory");
+  try {
+    p->prog = gsdf_dev::compile(*tree);
+  } catch (const std::exception& e) {
+    delete p;
+    return fail(GSDF_ERR_BAD_TREE, e.what());
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    delete p;
+    return fail(GSDF_ERR_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+  }
+  auto cleanup = [&](int code) { gsdf_hip_program_destroy(p); return code; };
+  if (hipGetDevice(&p->device) != hipSuccess) return cleanup(fail(GSDF_ERR_HIP, "hipGetDevice failed"));
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) p->num_cu = prop.multiProcessorCount;
+  if (p->lds_bytes() + 8 * BLOCK * 4 + 8192 > 160 * 1024) return cleanup(fail(GSDF_ERR_BAD_TREE, "tree needs more LDS scratch than one CU has"));
+  if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) return cleanup(fail(GSDF_ERR_HIP, "hipStreamCreate failed"));
+  size_t bytes = p->prog.code.size() * sizeof(uint32_t);
+  if (hipMalloc((void**)&p->d_code, bytes) != hipSuccess) return cleanup(fail(GSDF_ERR_HIP, "hipMalloc(program) failed"));
+  if (hipMemcpy(p->d_code, p->prog.code.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return cleanup(fail(GSDF_ERR_HIP, "hipMemcpy(program) failed"));
+  *out = p;
+  return GSDF_OK;
+}
+
+extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
+  if (!p) return;
+  if (p->d_code) (void)hipFree(p->d_code);
+  if (p->d_pos) (void)hipFree(p->d_pos);
+  if (p->d_dist) (void)hipFree(p->d_dist);
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+}
+
+extern "C" int gsdf_hip_program_bounds(const gsdf_program* p, float bb[6]) {
+  if (!p || !bb) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  std::memcpy(bb, p->prog.bb, sizeof(float) * 6);
+  return GSDF_OK;
+}
+extern "C" int gsdf_hip_program_is2d(const gsdf_program* p) { return p && p->prog.is2d ? 1 : 0; }
+extern "C" int gsdf_hip_program_info(const gsdf_program* p, uint32_t* code_words, uint32_t* lds_slots) {
+  if (!p) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  if (code_words) *code_words = (uint32_t)p->prog.code.size();
+  if (lds_slots) *lds_slots = (uint32_t)p->prog.nslots;
+  return GSDF_OK;
+}
+extern "C" uint64_t gsdf_hip_evaluations(const gsdf_program* p) { return p ? p->evals : 0; }
+
+static int eval_dev(gsdf_program* p, int dim, const void* d_pos, size_t stride_bytes, float* d_dist, size_t n, hipStream_t s) {
+  if (stride_bytes % 4 != 0 || stride_bytes < (size_t)dim * 4) return fail(GSDF_ERR_BAD_ARGUMENT, "bad position stride");
+  const unsigned grid = grid_for(n, p->num_cu, 8);
+  const uint32_t sf = (uint32_t)(stride_bytes / 4);
+  if (dim == 3)
+    hipLaunchKernelGGL(eval_kernel<3>, dim3(grid), dim3(BLOCK), p->lds_bytes(), s, p->d_code, (const float*)d_pos, sf, d_dist, (uint64_t)n);
+  else
+    hipLaunchKernelGGL(eval_kernel<2>, dim3(grid), dim3(BLOCK), p->lds_bytes(), s, p->d_code, (const float*)d_pos, sf, d_dist, (uint64_t)n);
+  HIP_TRY(hipGetLastError());
+  p->evals += n;
+  return GSDF_OK;
+}
+
+static int eval_host(gsdf_program* p, int dim, const void* pos, size_t stride, size_t n_pos, float* dist, size_t n_dist) {
+  if (!p) return fail(GSDF_ERR_BAD_ARGUMENT, "null program");
+  if (n_pos != n_dist) return fail(GSDF_ERR_LENGTH_MISMATCH, "position and distance buffer length mismatch");
+  if (n_pos == 0) return fail(GSDF_ERR_EMPTY_BUFFERS, "empty buffers");
+  if (!pos || !dist) return fail(GSDF_ERR_BAD_ARGUMENT, "null buffer");
+  if (p->prog.is2d != (dim == 2)) return fail(GSDF_ERR_DIMENSION, dim == 2 ? "program is 3D, eval2 called" : "program is 2D, eval3 called");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t pbytes = n_pos * stride;
+  if (pbytes > p->cap_pos_bytes) {
+    if (p->d_pos) (void)hipFree(p->d_pos);
+    p->d_pos = nullptr; p->cap_pos_bytes = 0;
+    HIP_TRY(hipMalloc(&p->d_pos, pbytes));
+    p->cap_pos_bytes = pbytes;
+  }
+  if (n_pos > p->cap_dist) {
+    if (p->d_dist) (void)hipFree(p->d_dist);
+    p->d_dist = nullptr; p->cap_dist = 0;
+    HIP_TRY(hipMalloc((void**)&p->d_dist, n_pos * sizeof(float)));
+    p->cap_dist = n_pos;
+  }
+  HIP_TRY(hipMemcpyAsync(p->d_pos, pos, pbytes, hipMemcpyHostToDevice, p->stream));
+  int rc = eval_dev(p, dim, p->d_pos, stride, p->d_dist, n_pos, p->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(dist, p->d_dist, n_pos * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_hip_eval3(gsdf_program* p, const void* pos, size_t stride, size_t n_pos, float* dist, size_t n_dist) {
+  return eval_host(p, 3, pos, stride, n_pos, dist, n_dist);
+}
+extern "C" int gsdf_hip_eval2(gsdf_program* p, const void* pos, size_t stride, size_t n_pos, float* dist, size_t n_dist) {
+  return eval_host(p, 2, pos, stride, n_pos, dist, n_dist);
+}
+extern "C" int gsdf_hip_eval3_dev(gsdf_program* p, const void* d_pos, size_t stride, float* d_dist, size_t n, void* stream) {
+  if (!p || !d_pos || !d_dist) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  if (n == 0) return fail(GSDF_ERR_EMPTY_BUFFERS, "empty buffers");
+  if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D, eval3 called");
+  return eval_dev(p, 3, d_pos, stride, d_dist, n, stream ? (hipStream_t)stream : p->stream);
+}
+extern "C" int gsdf_hip_eval2_dev(gsdf_program* p, const void* d_pos, size_t stride, float* d_dist, size_t n, void* stream) {
+  if (!p || !d_pos || !d_dist) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  if (n == 0) return fail(GSDF_ERR_EMPTY_BUFFERS, "empty buffers");
+  if (!p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 3D, eval2 called");
+  return eval_dev(p, 2, d_pos, stride, d_dist, n, stream ? (hipStream_t)stream : p->stream);
+}
+
+extern "C" int gsdf_hip_normals3(gsdf_program* p, const float* pos, float* normals, size_t n, float step) {
+  if (!p || !pos || !normals) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  step *= 0.5f;
+  if (!(step > 0)) return fail(GSDF_ERR_BAD_ARGUMENT, "invalid step");
+  if (n == 0) return fail(GSDF_ERR_EMPTY_BUFFERS, "empty buffers");
+  if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
+  HIP_TRY(hipSetDevice(p->device));
+  float *d_p = nullptr, *d_n = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_p, n * 12));
+  if (hipMalloc((void**)&d_n, n * 12) != hipSuccess) { (void)hipFree(d_p); return fail(GSDF_ERR_HIP, "hipMalloc failed"); }
+  int rc = GSDF_OK;
+  do {
+    if (hipMemcpyAsync(d_p, pos, n * 12, hipMemcpyHostToDevice, p->stream) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "H2D copy failed"); break; }
+    hipLaunchKernelGGL(normals_kernel, dim3(grid_for(n, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(), p->stream, p->d_code, d_p, d_n, (uint64_t)n, step);
+    if (hipGetLastError() != hipSuccess) { rc = fail(GSDF_ERR_HIP, "normals kernel launch failed"); break; }
+    if (hipMemcpyAsync(normals, d_n, n * 12, hipMemcpyDeviceToHost, p->stream) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "D2H copy failed"); break; }
+    if (hipStreamSynchronize(p->stream) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "stream sync failed"); break; }
+    p->evals += 6 * n;
+  } while (0);
+  (void)hipFree(d_p);
+  (void)hipFree(d_n);
+  return rc;
+}
+
+// ---- mesher -----------------------------------------------------------------------------------
+namespace {
+// ms3.Box.ScaleCentered(1.01) = NewCenteredBox(Center(), MulElem(scale, Size())) [external]; float32, unfused.
+void scale_centered(const float bb[6], float s, float mn[3], float mx[3]) {
+  for (int a = 0; a < 3; a++) {
+    const float c = 0.5f * (bb[a] + bb[a + 3]);
+    const float size = bb[a + 3] - bb[a];
+    float sz = fmaxf(s, 0.f) * size;
+    const float half = 0.5f * fmaxf(sz, 0.f);
+    mn[a] = c - half;
+    mx[a] = c + half;
+  }
+}
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+}  // namespace
+
+extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_opts* opts_in, gsdf_mesh** out) {
+  if (!p || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
+  if (!(res > 0) || std::isnan(res) || std::isinf(res)) return fail(GSDF_ERR_RESOLUTION, "invalid renderer cube resolution");
+  gsdf_mesh_opts opts{};
+  opts.prune = 1; opts.shard_rank = 0; opts.shard_count = 1;
+  if (opts_in) opts = *opts_in;
+  if (opts.shard_count < 1 || opts.shard_rank < 0 || opts.shard_rank >= opts.shard_count) return fail(GSDF_ERR_BAD_ARGUMENT, "bad shard rank/count");
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t s = opts.stream ? (hipStream_t)opts.stream : p->stream;
+
+  // Octree.Reset (octreerenderer.go:71-128) + makeICube (:222-235)
+  float mn[3], mx[3];
+  scale_centered(p->prog.bb, 1.01f, mn, mx);
+  const float longAxis = fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));
+  const float l2 = (float)std::log2((double)(longAxis / res));
+  const int levels = (int)std::ceil(l2) + 1;
+  if (levels <= 1) return fail(GSDF_ERR_RESOLUTION, "resolution not fine enough for marching cubes");
+  if (levels > 17) return fail(GSDF_ERR_RESOLUTION, "resolution too fine: more than 17 octree levels");
+  const float ox = mn[0], oy = mn[1], oz = mn[2];
+
+  gsdf_mesh* m = new (std::nothrow) gsdf_mesh();
+  if (!m) return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory");
+  m->device = p->device;
+  m->stream = s;
+  m->st.levels = levels;
+  m->st.res = res;
+  m->st.origin[0] = ox; m->st.origin[1] = oy; m->st.origin[2] = oz;
+  auto bail = [&](int code) { gsdf_hip_mesh_destroy(m); return code; };
+#define HIP_TRYM(expr)                                                                                          \
+  do {                                                                                                          \
+    hipError_t _e = (expr);                                                                                     \
+    if (_e != hipSuccess) return bail(fail(GSDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
+  } while (0)
+
+  DevBuf ctr_buf;
+  HIP_TRYM(ctr_buf.alloc(sizeof(MeshCounters)));
+  MeshCounters* d_ctr = (MeshCounters*)ctr_buf.p;
+  HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(MeshCounters), s));
+  hipEvent_t ev0, ev1, ev2, evm0, evm1;
+  HIP_TRYM(hipEventCreate(&ev0));
+  HIP_TRYM(hipEventCreate(&ev1));
+  HIP_TRYM(hipEventCreate(&ev2));
+  HIP_TRYM(hipEventCreate(&evm0));
+  HIP_TRYM(hipEventCreate(&evm1));
+  struct EvGuard { hipEvent_t e[5]; ~EvGuard() { for (auto x : e) (void)hipEventDestroy(x); } } evg{{ev0, ev1, ev2, evm0, evm1}};
+  bool marched = false;
+  HIP_TRYM(hipEventRecord(ev0, s));
+
+  // ---- level-synchronous descent from the top cube to level lq = min(levels, 3)
+  const int lq = levels < 3 ? levels : 3;
+  uint64_t evals = 0, pruned = 0;
+  DevBuf cur, nxt;
+  uint64_t n_cur = 1;
+  HIP_TRYM(cur.alloc(sizeof(Cube)));
+  {
+    Cube top = {0, 0, 0, 0};
+    HIP_TRYM(hipMemcpyAsync(cur.p, &top, sizeof(Cube), hipMemcpyHostToDevice, s));
+  }
+  const size_t lds = p->lds_bytes();
+  bool sharded = opts.shard_count == 1;
+  int shard_rc = GSDF_OK;
+  // multi-GPU: keep every shard_count-th brick (dealt round-robin over a coordinate-sorted list so
+  // that every rank derives the same partition without communicating).
+  auto deal = [&]() {
+    std::vector<Cube> h(n_cur);
+    if (n_cur && hipMemcpy(h.data(), cur.p, n_cur * sizeof(Cube), hipMemcpyDeviceToHost) != hipSuccess) { shard_rc = fail(GSDF_ERR_HIP, "D2H copy of bricks failed"); return; }
+    std::sort(h.begin(), h.end(), [](const Cube& a, const Cube& b) {
+      if (a.z != b.z) return a.z < b.z;
+      if (a.y != b.y) return a.y < b.y;
+      return a.x < b.x;
+    });
+    std::vector<Cube> mine;
+    for (uint64_t i = (uint64_t)opts.shard_rank; i < n_cur; i += (uint64_t)opts.shard_count) mine.push_back(h[i]);
+    n_cur = mine.size();
+    if (n_cur && hipMemcpy(cur.p, mine.data(), n_cur * sizeof(Cube), hipMemcpyHostToDevice) != hipSuccess) { shard_rc = fail(GSDF_ERR_HIP, "H2D copy of bricks failed"); return; }
+    sharded = true;
+  };
+  for (int level = levels; level >= lq; level--) {
+    const bool expand = level != levels;
+    const uint64_t n_items = expand ? n_cur * 8 : n_cur;
+    const int do_test = (level >= 3 && opts.prune) ? 1 : 0;
+    if (!expand && !do_test) continue;  // top cube kept as is
+    DevBuf o;
+    HIP_TRYM(o.alloc(n_items * sizeof(Cube)));
+    HIP_TRYM(hipMemsetAsync(&d_ctr->n_out, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(prune_kernel, dim3(grid_for(n_items, p->num_cu, 8)), dim3(BLOCK), lds, s, p->d_code, (const Cube*)cur.p,
+                       n_items, expand ? 1 : 0, level, ox, oy, oz, res, do_test, (Cube*)o.p, d_ctr);
+    HIP_TRYM(hipGetLastError());
+    unsigned long long n_out = 0;
+    HIP_TRYM(hipMemcpyAsync(&n_out, &d_ctr->n_out, sizeof(n_out), hipMemcpyDeviceToHost, s));
+    HIP_TRYM(hipStreamSynchronize(s));
+    if (do_test) {
+      evals += n_items;
+      pruned += (n_items - n_out) << (3 * (level - 1));  // DecomposesTo(1) = 8^(level-1)
+    }
+    std::swap(cur.p, o.p);
+    n_cur = n_out;
+    if (!sharded && (n_cur >= (uint64_t)64 * opts.shard_count || level == lq)) {
+      deal();
+      if (shard_rc) return bail(shard_rc);
+    }
+    if (n_cur == 0) break;
+  }
+  if (!sharded) {
+    deal();
+    if (shard_rc) return bail(shard_rc);
+  }
+  HIP_TRYM(hipEventRecord(ev1, s));
+
+  // ---- leaves
+  const uint64_t lpc = (uint64_t)1 << (3 * (lq - 1));
+  const uint64_t n_leaves = n_cur * lpc;
+  unsigned long long n_active = 0, n_tris = 0;
+  if (n_leaves) {
+    DevBuf act, act_d0;
+    HIP_TRYM(act.alloc(n_leaves * sizeof(Cube)));
+    HIP_TRYM(act_d0.alloc(n_leaves * sizeof(float)));
+    hipLaunchKernelGGL(leaf_first_kernel, dim3(grid_for(n_leaves, p->num_cu, 8)), dim3(BLOCK), lds, s, p->d_code, (const Cube*)cur.p,
+                       n_leaves, lq, ox, oy, oz, res, (Cube*)act.p, (float*)act_d0.p, d_ctr);
+    HIP_TRYM(hipGetLastError());
+    HIP_TRYM(hipMemcpyAsync(&n_active, &d_ctr->n_active, sizeof(n_active), hipMemcpyDeviceToHost, s));
+    HIP_TRYM(hipStreamSynchronize(s));
+    evals += n_leaves;
+    if (n_active) {
+      uint64_t cap = opts.max_tris ? opts.max_tris : n_active * 5;
+      HIP_TRYM(hipMalloc((void**)&m->d_tris, cap * 36));
+      m->cap = cap;
+      const size_t lds_m = (size_t)(p->prog.nslots + 8) * BLOCK * sizeof(float) + 512 + 4096;
+      HIP_TRYM(hipEventRecord(evm0, s));
+      hipLaunchKernelGGL(leaf_march_kernel, dim3(grid_for(n_active, p->num_cu, 8)), dim3(BLOCK), lds_m, s, p->d_code,
+                         (const Cube*)act.p, (const float*)act_d0.p, (uint64_t)n_active, p->prog.nslots, ox, oy, oz, res, m->d_tris,
+                         cap, d_ctr);
+      HIP_TRYM(hipGetLastError());
+      HIP_TRYM(hipEventRecord(evm1, s));
+      marched = true;
+      MeshCounters hc{};
+      HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));
+      HIP_TRYM(hipStreamSynchronize(s));
+      evals += 7 * n_active;
+      n_tris = hc.n_tris;
+      if (hc.overflow) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
+    }
+  }
+  HIP_TRYM(hipEventRecord(ev2, s));
+  HIP_TRYM(hipEventSynchronize(ev2));
+  float ms01 = 0, ms12 = 0;
+  HIP_TRYM(hipEventElapsedTime(&ms01, ev0, ev1));
+  HIP_TRYM(hipEventElapsedTime(&ms12, ev1, ev2));
+  m->st.n_tris = n_tris;
+  m->st.evals = evals;
+  m->st.pruned_leaves = pruned;
+  m->st.leaf_cubes = n_leaves;
+  m->st.active_leaves = n_active;
+  m->st.ms_prune = ms01;
+  m->st.ms_leaf = ms12;
+  m->st.ms_total = (double)ms01 + (double)ms12;
+  if (marched) {
+    float msm = 0;
+    HIP_TRYM(hipEventElapsedTime(&msm, evm0, evm1));
+    m->st.ms_march = msm;
+  }
+  p->evals += evals;
+  *out = m;
+  return GSDF_OK;
+#undef HIP_TRYM
+}
+
+extern "C" int gsdf_hip_mesh_stats_get(const gsdf_mesh* m, gsdf_mesh_stats* st) {
+  if (!m || !st) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *st = m->st;
+  return GSDF_OK;
+}
+extern "C" int gsdf_hip_mesh_read(const gsdf_mesh* m, uint64_t first, uint64_t count, float* dst) {
+  if (!m || (!dst && count)) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  if (first + count > m->st.n_tris) return fail(GSDF_ERR_BAD_ARGUMENT, "triangle range out of bounds");
+  if (count == 0) return GSDF_OK;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipMemcpy(dst, m->d_tris + first * 9, count * 36, hipMemcpyDeviceToHost));
+  return GSDF_OK;
+}
+extern "C" const float* gsdf_hip_mesh_dev_tris(const gsdf_mesh* m) { return m ? m->d_tris : nullptr; }
+
+extern "C" int gsdf_hip_mesh_stl(const gsdf_mesh* m, uint8_t* dst, size_t dst_cap) {
+  if (!m || !dst) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  const uint64_t n = m->st.n_tris;
+  if (n == 0) return fail(GSDF_ERR_EMPTY_BUFFERS, "empty triangle slice");
+  if (n > 0xffffffffull) return fail(GSDF_ERR_BAD_ARGUMENT, "amount of triangles in model exceeds STL design limits");
+  const size_t bytes = 84 + 50 * (size_t)n;
+  if (dst_cap < bytes) return fail(GSDF_ERR_SHORT_BUFFER, "short buffer");
+  HIP_TRY(hipSetDevice(m->device));
+  uint8_t* d_out = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_out, bytes + 4));
+  int rc = GSDF_OK;
+  do {
+    uint8_t hdr[84] = {0};
+    const uint32_t cnt = (uint32_t)n;
+    std::memcpy(hdr + 80, &cnt, 4);
+    if (hipMemcpyAsync(d_out, hdr, 84, hipMemcpyHostToDevice, m->stream) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "H2D header failed"); break; }
+    hipLaunchKernelGGL(stl_kernel, dim3(grid_for(n, 256, 8)), dim3(BLOCK), 0, m->stream, m->d_tris, n, d_out);
+    if (hipGetLastError() != hipSuccess) { rc = fail(GSDF_ERR_HIP, "stl kernel launch failed"); break; }
+    if (hipMemcpyAsync(dst, d_out, bytes, hipMemcpyDeviceToHost, m->stream) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "D2H stl failed"); break; }
+    if (hipStreamSynchronize(m->stream) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "stream sync failed"); break; }
+  } while (0);
+  (void)hipFree(d_out);
+  return rc;
+}
+
+extern "C" void gsdf_hip_mesh_destroy(gsdf_mesh* m) {
+  if (!m) return;
+  if (m->d_tris) (void)hipFree(m->d_tris);
+  delete m;
+}

@@ -1,0 +1,229 @@
+"""ctypes face of libgsdfhip.so (include/gsdf_hip.h): the MI355X HIP backend.
+
+Mirrors the reference seam: `SDF3HIP` stands where `gleval.SDF3Compute` does (gleval/gpu.go:56-103:
+Evaluate / Bounds / Evaluations, same error behaviour), `OctreeHIP` where `glrender.Octree` does
+(glrender/octreerenderer.go: ReadTriangles iterator + RenderAll), `write_binary_stl` where
+`glrender.WriteBinarySTL` does. There is NO CPU fallback: if the HIP library or a GPU is missing,
+construction raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+from ._ctypes_common import GsdfTree
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgsdfhip.so")
+_LIB = None
+
+ErrEmptyBuffers = "empty buffers"
+ErrMismatchBufferLength = "position and distance buffer length mismatch"
+
+# every symbol include/gsdf_hip.h declares
+SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "gsdf_hip_program_destroy",
+           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations",
+           "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3",
+           "gsdf_hip_mesh_octree", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
+           "gsdf_hip_mesh_stl", "gsdf_hip_mesh_destroy"]
+
+
+class MeshOpts(C.Structure):
+    _fields_ = [("prune", C.c_int), ("shard_rank", C.c_int), ("shard_count", C.c_int), ("max_tris", C.c_uint64),
+                ("stream", C.c_void_p)]
+
+
+class MeshStats(C.Structure):
+    _fields_ = [("n_tris", C.c_uint64), ("evals", C.c_uint64), ("pruned_leaves", C.c_uint64), ("leaf_cubes", C.c_uint64),
+                ("active_leaves", C.c_uint64), ("levels", C.c_int), ("origin", C.c_float * 3), ("res", C.c_float),
+                ("ms_total", C.c_double), ("ms_prune", C.c_double), ("ms_leaf", C.c_double), ("ms_march", C.c_double)]
+
+
+class HipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gsdf_hip error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def lib():
+    """Load libgsdfhip.so. Raises ImportError loudly if it was not built (never falls back)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: the HIP extension must be built "
+                              "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.gsdf_hip_last_error.restype = C.c_char_p
+        L.gsdf_hip_init.argtypes = [C.c_int]
+        L.gsdf_hip_program_create.argtypes = [C.POINTER(GsdfTree), C.POINTER(C.c_void_p)]
+        L.gsdf_hip_program_destroy.argtypes = [C.c_void_p]
+        L.gsdf_hip_program_destroy.restype = None
+        L.gsdf_hip_program_bounds.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.gsdf_hip_program_is2d.argtypes = [C.c_void_p]
+        L.gsdf_hip_program_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.gsdf_hip_evaluations.restype = C.c_uint64
+        L.gsdf_hip_evaluations.argtypes = [C.c_void_p]
+        for f in (L.gsdf_hip_eval3, L.gsdf_hip_eval2):
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t]
+        for f in (L.gsdf_hip_eval3_dev, L.gsdf_hip_eval2_dev):
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.gsdf_hip_normals3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]
+        L.gsdf_hip_mesh_octree.argtypes = [C.c_void_p, C.c_float, C.POINTER(MeshOpts), C.POINTER(C.c_void_p)]
+        L.gsdf_hip_mesh_stats_get.argtypes = [C.c_void_p, C.POINTER(MeshStats)]
+        L.gsdf_hip_mesh_read.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.gsdf_hip_mesh_dev_tris.restype = C.c_void_p
+        L.gsdf_hip_mesh_dev_tris.argtypes = [C.c_void_p]
+        L.gsdf_hip_mesh_stl.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.gsdf_hip_mesh_destroy.argtypes = [C.c_void_p]
+        L.gsdf_hip_mesh_destroy.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise HipError(rc, lib().gsdf_hip_last_error().decode())
+
+
+def init(device=-1):
+    """gleval.Init1x1GLFW analogue: make sure a HIP device is usable (raises otherwise)."""
+    _check(lib().gsdf_hip_init(device))
+
+
+class SDFHIP:
+    """gleval.SDF3 / SDF2 implemented by the HIP interpreter kernel for one flattened tree."""
+
+    def __init__(self, shader_or_tree, device=-1):
+        L = lib()
+        tree = shader_or_tree.tree() if hasattr(shader_or_tree, "tree") else shader_or_tree
+        self._tree = tree
+        if device >= 0:
+            _check(L.gsdf_hip_init(device))
+        h = C.c_void_p()
+        _check(L.gsdf_hip_program_create(C.byref(tree), C.byref(h)))
+        self._h = h
+        self.is2d = bool(L.gsdf_hip_program_is2d(h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gsdf_hip_program_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def Bounds(self):
+        bb = (C.c_float * 6)()
+        _check(lib().gsdf_hip_program_bounds(self._h, bb))
+        return np.array(bb[:], np.float32)
+
+    def Evaluations(self):
+        return int(lib().gsdf_hip_evaluations(self._h))
+
+    def info(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        _check(lib().gsdf_hip_program_info(self._h, C.byref(a), C.byref(b)))
+        return {"code_words": a.value, "lds_slots": b.value}
+
+    def Evaluate(self, pos, dist=None, userData=None):
+        """pos: (n,3)|(n,4)|(n,2) float32 host array (row stride = position stride); dist: (n,) float32."""
+        pos = np.asarray(pos, np.float32)
+        if pos.ndim != 2 or not pos.flags.c_contiguous:
+            pos = np.ascontiguousarray(pos.reshape(-1, 2 if self.is2d else 3))
+        n = pos.shape[0]
+        if dist is None:
+            dist = np.empty(n, np.float32)
+        f = lib().gsdf_hip_eval2 if self.is2d else lib().gsdf_hip_eval3
+        _check(f(self._h, pos.ctypes.data, pos.strides[0], n, dist.ctypes.data, dist.shape[0]))
+        return dist
+
+    def evaluate_dev(self, d_pos_ptr, stride_bytes, d_dist_ptr, n, stream=None):
+        """Device-resident evaluation on raw device pointers (e.g. torch tensors' data_ptr())."""
+        f = lib().gsdf_hip_eval2_dev if self.is2d else lib().gsdf_hip_eval3_dev
+        _check(f(self._h, d_pos_ptr, stride_bytes, d_dist_ptr, n, stream))
+
+    def normals(self, pos, step):
+        pos = np.ascontiguousarray(pos, np.float32)
+        out = np.empty_like(pos)
+        _check(lib().gsdf_hip_normals3(self._h, pos.ctypes.data, out.ctypes.data, pos.shape[0], step))
+        return out
+
+
+SDF3HIP = SDFHIP
+SDF2HIP = SDFHIP
+
+
+class OctreeHIP:
+    """glrender.Octree drop-in: octree pruning + marching cubes on device, triangles drained on demand.
+
+    NewOctreeRenderer(s, cubeResolution, evalBufferSize) -> OctreeHIP(sdf, res) ; the evaluation buffer
+    argument has no meaning here (positions are generated on device)."""
+
+    def __init__(self, sdf, res, evalBufferSize=64, prune=True, shard_rank=0, shard_count=1, max_tris=0, stream=None):
+        if evalBufferSize < 64:
+            raise ValueError("bad octree eval buffer size")
+        self.sdf = sdf
+        self._mesh = None
+        self._cursor = 0
+        self._opts = MeshOpts(int(prune), shard_rank, shard_count, max_tris, stream)
+        self.Reset(sdf, res)
+
+    def Reset(self, sdf, res):
+        self._free()
+        self.sdf = sdf
+        m = C.c_void_p()
+        _check(lib().gsdf_hip_mesh_octree(sdf._h, np.float32(res), C.byref(self._opts), C.byref(m)))
+        self._mesh = m
+        self._cursor = 0
+        st = MeshStats()
+        _check(lib().gsdf_hip_mesh_stats_get(m, C.byref(st)))
+        self.stats = st
+
+    def _free(self):
+        if getattr(self, "_mesh", None):
+            lib().gsdf_hip_mesh_destroy(self._mesh)
+            self._mesh = None
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass
+
+    def TotalPruned(self):
+        return int(self.stats.pruned_leaves)
+
+    def n_tris(self):
+        return int(self.stats.n_tris)
+
+    def dev_ptr(self):
+        return lib().gsdf_hip_mesh_dev_tris(self._mesh)
+
+    def ReadTriangles(self, dst, userData=None):
+        """dst: (k,3,3) float32. Returns (n, eof) like (n, io.EOF); needs len(dst) >= 5 (io.ErrShortBuffer)."""
+        if dst.shape[0] < 5:
+            raise BufferError("short buffer")
+        remaining = self.n_tris() - self._cursor
+        n = min(remaining, dst.shape[0])
+        if n:
+            _check(lib().gsdf_hip_mesh_read(self._mesh, self._cursor, n, dst.ctypes.data))
+        self._cursor += n
+        return n, self._cursor >= self.n_tris()
+
+    def RenderAll(self):
+        """glrender.RenderAll: all triangles as (n,3,3) float32."""
+        n = self.n_tris()
+        out = np.empty((n, 3, 3), np.float32)
+        if n:
+            _check(lib().gsdf_hip_mesh_read(self._mesh, 0, n, out.ctypes.data))
+        return out
+
+    def WriteBinarySTL(self):
+        """glrender.WriteBinarySTL of the device-resident triangles, records built on device."""
+        n = self.n_tris()
+        buf = np.empty(84 + 50 * n, np.uint8)
+        _check(lib().gsdf_hip_mesh_stl(self._mesh, buf.ctypes.data, buf.size))
+        return buf.tobytes()

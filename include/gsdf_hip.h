@@ -1,0 +1,116 @@
+/*
+ * gsdf_hip.h -- C ABI of libgsdfhip.so: the MI355X (gfx950) drop-in for the reference's GPU seam.
+ *
+ * What each entry point replaces in /root/reference (the cgo binding a maintainer would add is in
+ * INTEGRATION.md):
+ *   gsdf_hip_init              gleval.Init1x1GLFW                     gleval/gpu.go:21-32
+ *   gsdf_hip_program_create    gleval.NewComputeGPUSDF3 / ...SDF2     gleval/gpu.go:35-55,105-130
+ *                              (takes the flattened tree instead of GLSL text: glbuild.Programmer
+ *                               .WriteComputeSDF3, gsdfaux/gsdfaux.go:122-126)
+ *   gsdf_hip_program_bounds    (*SDF3Compute).Bounds                  gleval/gpu.go:75-77
+ *   gsdf_hip_evaluations       (*SDF3Compute).Evaluations             gleval/gpu.go:80
+ *   gsdf_hip_eval3 / _eval2    (*SDF3Compute).Evaluate / SDF2Compute  gleval/gpu.go:82-103,140-160
+ *                              + computeEvaluate                      gleval/gpu_cgo.go:194-258
+ *   gsdf_hip_eval3_dev         same, positions/distances already resident in HBM (no reference
+ *                              equivalent: the GL path re-uploads every call, gpu_cgo.go:238-257)
+ *   gsdf_hip_normals3          gleval.NormalsCentralDiff              gleval/gleval.go:53-108
+ *   gsdf_hip_mesh_octree       glrender.NewOctreeRenderer + RenderAll glrender/octreerenderer.go:43-178,
+ *                              (octree prune + marching cubes on device) glrender/marchcubes.go:14-98
+ *   gsdf_hip_mesh_read         (*Octree).ReadTriangles drain          glrender/octreerenderer.go:131-178
+ *   gsdf_hip_mesh_stl          glrender.WriteBinarySTL                glrender/stl.go:15-62
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative
+ * gsdf_status; gsdf_hip_last_error() gives the message for the calling thread. Buffers are borrowed
+ * for the duration of the call only (Go pointer rules: nothing is retained). A handle is not
+ * thread-safe (same as the reference's SDF3Compute, gpu.go:94-101); distinct handles are independent.
+ */
+#ifndef GSDF_HIP_H
+#define GSDF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "gsdf_program.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gsdf_status {
+  GSDF_OK = 0,
+  GSDF_ERR_EMPTY_BUFFERS = -1,   /* gleval.errEmptyBuffers (gleval/gleval.go:47) */
+  GSDF_ERR_LENGTH_MISMATCH = -2, /* gleval.errMismatchBufferLength (gleval/gleval.go:48) */
+  GSDF_ERR_BAD_ARGUMENT = -3,
+  GSDF_ERR_BAD_TREE = -4,
+  GSDF_ERR_HIP = -5,             /* HIP runtime error, message has hipGetErrorString */
+  GSDF_ERR_NO_DEVICE = -6,
+  GSDF_ERR_DIMENSION = -7,       /* 2D program given to a 3D entry point or vice versa */
+  GSDF_ERR_RESOLUTION = -8,      /* "invalid renderer cube resolution" / "resolution not fine enough" */
+  GSDF_ERR_SHORT_BUFFER = -9,    /* io.ErrShortBuffer */
+  GSDF_ERR_CAPACITY = -10        /* device triangle buffer capacity exceeded */
+} gsdf_status;
+
+typedef struct gsdf_program gsdf_program; /* compiled tree, resident on one GPU */
+typedef struct gsdf_mesh gsdf_mesh;       /* triangles produced on device, resident in HBM */
+
+const char* gsdf_hip_last_error(void);
+
+/* Select the HIP device for handles created by this thread afterwards. device < 0: keep current. */
+int gsdf_hip_init(int device);
+
+int gsdf_hip_program_create(const gsdf_tree* tree, gsdf_program** out);
+void gsdf_hip_program_destroy(gsdf_program* p);
+int gsdf_hip_program_bounds(const gsdf_program* p, float bb[6]);
+int gsdf_hip_program_is2d(const gsdf_program* p);
+/* Introspection for tests/benchmarks: lowered program size (32-bit words) and LDS slots per lane. */
+int gsdf_hip_program_info(const gsdf_program* p, uint32_t* code_words, uint32_t* lds_slots);
+uint64_t gsdf_hip_evaluations(const gsdf_program* p);
+
+/* Host-buffer evaluation (drop-in for SDF3Compute.Evaluate). pos_stride_bytes is the distance between
+ * consecutive positions: 12 for []ms3.Vec, 16 for std140 vec3 / ms3.Quat-aligned data; 8 for []ms2.Vec.
+ * n_pos/n_dist are the two slice lengths (mismatch and zero are reported like the reference does). */
+int gsdf_hip_eval3(gsdf_program* p, const void* pos, size_t pos_stride_bytes, size_t n_pos, float* dist, size_t n_dist);
+int gsdf_hip_eval2(gsdf_program* p, const void* pos, size_t pos_stride_bytes, size_t n_pos, float* dist, size_t n_dist);
+/* Device-resident evaluation: d_pos/d_dist are device pointers on the program's GPU; stream is a
+ * hipStream_t (NULL = the program's own stream). Asynchronous when stream != NULL. */
+int gsdf_hip_eval3_dev(gsdf_program* p, const void* d_pos, size_t pos_stride_bytes, float* d_dist, size_t n, void* stream);
+int gsdf_hip_eval2_dev(gsdf_program* p, const void* d_pos, size_t pos_stride_bytes, float* d_dist, size_t n, void* stream);
+/* Central-difference normals (not normalised), host buffers, 12-byte xyz in and out. */
+int gsdf_hip_normals3(gsdf_program* p, const float* pos, float* normals, size_t n, float step);
+
+typedef struct gsdf_mesh_opts {
+  int prune;          /* 1: octree centre-test pruning of every Level>=3 cube (default); 0: visit all leaves */
+  int shard_rank;     /* multi-GPU: this rank ... */
+  int shard_count;    /* ... of this many (1 = whole model). Bricks are dealt round-robin. */
+  uint64_t max_tris;  /* device triangle buffer capacity; 0 = size automatically */
+  void* stream;       /* hipStream_t to run on; NULL = the program's stream */
+} gsdf_mesh_opts;
+
+typedef struct gsdf_mesh_stats {
+  uint64_t n_tris;
+  uint64_t evals;          /* SDF evaluations performed on device for this mesh */
+  uint64_t pruned_leaves;  /* leaf cubes skipped by pruning (Octree.TotalPruned) */
+  uint64_t leaf_cubes;     /* leaf cubes visited */
+  uint64_t active_leaves;  /* leaf cubes that passed the |d(corner0)| <= 2*sqrt3*res test */
+  int levels;              /* octree levels (makeICube) */
+  float origin[3];         /* lattice origin (scaled bounds min) */
+  float res;
+  double ms_total;         /* device time for the whole mesh, HIP events */
+  double ms_prune;         /* pruning levels */
+  double ms_leaf;          /* leaf phase: corner-0 pass + march pass (incl. host gaps) */
+  double ms_march;         /* dominant kernel alone: leaf_march_kernel (7 corners + marching cubes) */
+} gsdf_mesh_stats;
+
+int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_opts* opts, gsdf_mesh** out);
+int gsdf_hip_mesh_stats_get(const gsdf_mesh* m, gsdf_mesh_stats* st);
+/* Copy triangles [first, first+count) to host memory: 9 floats (36 B) each = ms3.Triangle. */
+int gsdf_hip_mesh_read(const gsdf_mesh* m, uint64_t first, uint64_t count, float* dst);
+/* Device pointer to the triangle array (for RCCL gathers / further device work). */
+const float* gsdf_hip_mesh_dev_tris(const gsdf_mesh* m);
+/* Binary STL (84 + 50*n bytes) built on device into dst (host). dst_cap must be >= that size. */
+int gsdf_hip_mesh_stl(const gsdf_mesh* m, uint8_t* dst, size_t dst_cap);
+void gsdf_hip_mesh_destroy(gsdf_mesh* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
