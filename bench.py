@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: SDF evals/s + triangles/s, examples/npt-flange at resdiv 1600,
+octree pruning + marching cubes on device (BASELINE.json configs[1]).
+
+A "step" is one complete mesh of the model: every octree level, every leaf corner evaluation and all
+marching-cubes triangle emission, starting from the flattened tree resident in HBM and ending with
+the triangle buffer resident in HBM (N>1: + the RCCL gather of all ranks' triangles on every rank).
+Positions are generated on device from the lattice, so there is no host input to upload.
+
+  python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0). value = total SDF evaluations of all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(shader, resdiv, threads):
+    """Reference CPU path for this workload (gsdfaux.RenderShader3D without -gpu: FlatRenderer over the
+    batch-recursive evaluators, batch 4096, GOMAXPROCS-1 goroutines), restated in oracle/ (kind=port)."""
+    import numpy as np
+    from oracle.oracle import OracleSDF
+    res = np.float32(float(shader.Diagonal()) / resdiv)
+    sdf = OracleSDF(shader.tree())
+    t0 = time.perf_counter()
+    m = sdf.render_flat(res, 4096, threads)
+    dt = time.perf_counter() - t0
+    return {"value": m.evals / dt, "unit": "evals/s", "cores": threads, "kind": "port",
+            "sample": f"npt-flange resdiv {resdiv} flat lattice {m.grid[0]+1}x{m.grid[1]+1}x{m.grid[2]+1} = {m.evals} evals, "
+                      f"{m.n_tris} triangles in {dt:.2f}s (FlatRenderer+batch-recursive evaluators, batch 4096)",
+            "triangles_per_s": m.n_tris / dt, "eval_only_evals_per_s": m.evals / m.t_eval_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--resdiv", type=int, default=1600)
+    ap.add_argument("--scene", default="npt-flange")
+    ap.add_argument("--cpu-resdiv", type=int, default=800)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from gsdf_amd.builder import Builder
+    from gsdf_amd import hip
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    hip.init(dev.index)
+
+    bld = Builder()
+    shader = bld.Scene(args.scene)
+    res = np.float32(float(shader.Diagonal()) / args.resdiv)
+    sdf = hip.SDF3HIP(shader)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        oc = hip.OctreeHIP(sdf, res, shard_rank=rank, shard_count=world)
+        gathered = None
+        if dist is not None:
+            from gsdf_amd.gather import all_gatherv_triangles
+            gathered = all_gatherv_triangles(oc.dev_ptr(), oc.n_tris(), dev)
+        return oc, gathered
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    evals = tris = 0
+    march_ms = march_evals = march_tris = 0.0
+    last = None
+    for _ in range(args.steps):
+        oc, g = step()
+        st = oc.stats
+        evals += st.evals
+        tris += st.n_tris
+        march_ms += st.ms_march
+        march_evals += 7 * st.active_leaves
+        march_tris += st.n_tris
+        last = (oc, g)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    tot = torch.tensor([float(evals), float(tris), dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = tot.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax[2])
+    evals_all, tris_all = float(tot[0]), float(tot[1])
+
+    if rank == 0:
+        oc, g = last
+        st = oc.stats
+        # dominant kernel: leaf_march_kernel. ALGORITHMIC bytes per launch = 16 B per evaluation it performs
+        # (12 B position + 4 B distance; positions are generated on device but counted) + 36 B per triangle.
+        k_ms = march_ms / max(1, args.steps)
+        k_bytes = (march_evals * 16.0 + march_tris * 36.0) / max(1, args.steps)
+        achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "sdf_evals_per_s", "value": evals_all / dt, "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"examples/{args.scene} resdiv {args.resdiv}: octree prune + marching cubes on device "
+                                   f"(res {float(res):.7f}, {st.levels} levels)",
+                       "sharding": "octree bricks round-robin, RCCL all-gatherv of triangles" if world > 1 else "single GPU"},
+            "triangles_per_s": tris_all / dt,
+            "triangles_per_step": tris_all / args.steps, "evals_per_step": evals_all / args.steps,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "leaf_march_kernel", "kernel_ms": k_ms,
+                         "kernel_evals_per_s": (march_evals / max(1, args.steps)) / (k_ms * 1e-3) if k_ms > 0 else 0.0,
+                         "note": "path is fp32-VALU bound (SURVEY 8(d)): algorithmic HBM bytes are tiny by construction"},
+            "phase_ms_rank0": {"prune": st.ms_prune, "leaf": st.ms_leaf, "march_kernel": st.ms_march, "total_device": st.ms_total},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = max(1, (os.cpu_count() or 2) - 1)
+            out["cpu_baseline"] = cpu_baseline(shader, args.cpu_resdiv, threads)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,10 +5,9 @@
 //   eval_kernel<DIM>     dist[i] = SDF(pos[i])                      gleval SDF3/SDF2.Evaluate
 //   prune_kernel         octree level: centre sample, keep iff |d| < size*sqrt3/2, ballot+prefix
 //                        compaction of survivors                    glrender/octreerenderer.go:240-284
-//   leaf_first_kernel    leaf corner 0 + reject |d0| > 2*sqrt3*res, compaction of active leaves
-//                                                                   glrender/marchcubes.go:20-23
-//   leaf_march_kernel    remaining 7 corners + marching cubes with LDS tables, wave prefix-sum
-//                        triangle slot allocation                   glrender/marchcubes.go:34-98
+//   leaf_kernel          8 leaf corners (corner 0 first, reject |d0| > 2*sqrt3*res) + marching cubes
+//                        with the LDS triangle table, block prefix-sum slot allocation, triangles
+//                        staged in LDS and flushed coalesced          glrender/marchcubes.go:14-98
 //   stl_kernel           50-byte STL records staged through LDS     glrender/stl.go:15-62
 //   normals_kernel       central differences                        gleval/gleval.go:53-108
 #include <hip/hip_runtime.h>
@@ -142,39 +141,6 @@ __global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict
   }
 }
 
-// Leaf phase A: corner 0 of every leaf of every surviving cube at level lq (lpc_shift = 3*(lq-1)).
-__global__ void __launch_bounds__(BLOCK) leaf_first_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
-                                                           uint64_t n_leaves, int lq, float ox, float oy, float oz, float res,
-                                                           Cube* __restrict__ act, float* __restrict__ act_d0,
-                                                           MeshCounters* __restrict__ ctr) {
-  code_ptr code = as_code(code_g);
-  float* lds = g_smem + threadIdx.x;
-  const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
-  const int sh = lq - 1;                            // leaves per axis = 1<<sh
-  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_leaves; base += step) {
-    const uint64_t i = base + threadIdx.x;
-    const bool valid = i < n_leaves;
-    Cube lf = {0, 0, 0, 0};
-    if (valid) {
-      const Cube pc = cubes[i >> (3 * sh)];
-      const unsigned l = (unsigned)(i & ((1u << (3 * sh)) - 1u));
-      const unsigned m = (1u << sh) - 1u;
-      lf.x = (uint16_t)((pc.x << sh) + (l & m));
-      lf.y = (uint16_t)((pc.y << sh) + ((l >> sh) & m));
-      lf.z = (uint16_t)((pc.z << sh) + ((l >> (2 * sh)) & m));
-    }
-    P3 p = {ox + res * (float)lf.x, oy + res * (float)lf.y, oz + res * (float)lf.z};
-    const float d0 = gsdf_dev::sdf_eval(code, p, lds, BLOCK);
-    const bool keep = valid && (dm::absf(d0) <= cubeDiag);
-    const unsigned long long slot = wave_append(keep, &ctr->n_active);
-    if (keep) {
-      act[slot] = lf;
-      act_d0[slot] = d0;
-    }
-  }
-}
-
 // mcInterpolate (marchcubes.go:76-98) with x = 0.
 __device__ __forceinline__ void mc_interp(float ax, float ay, float az, float bx, float by, float bz, float v1, float v2,
                                           float& rx, float& ry, float& rz) {
@@ -188,32 +154,53 @@ __device__ __forceinline__ void mc_interp(float ax, float ay, float az, float bx
   rx = x; ry = y; rz = z;
 }
 
-// Leaf phase B: corners 1..7 of each active leaf, marching cubes, triangle emission.
-// LDS: [nslots+8 floats per lane | triangle table 256 x 16 x i8]; edge pairs are immediate nibbles.
-__global__ void __launch_bounds__(BLOCK) leaf_march_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ act,
-                                                           const float* __restrict__ act_d0, uint64_t n_active, int nslots,
-                                                           float ox, float oy, float oz, float res, float* __restrict__ tris,
-                                                           uint64_t tri_cap, MeshCounters* __restrict__ ctr) {
+#define TRI_STAGE 512  // triangles staged in LDS per workgroup before one coalesced flush (18 KB)
+
+// Leaf kernel: one lane per leaf cube of every surviving level-lq cube (64 leaves of a level-3 cube
+// = one wave). Corner 0 first; the wave runs the other 7 corners only if some lane passes the
+// reference's |d0| <= 2*sqrt3*res test (marchcubes.go:20-23). Marching cubes reads the triangle
+// table from LDS; triangles are staged in LDS and flushed with ONE global atomic per flush
+// (a single counter word saturates at ~88 atomics/us on MI355X, so per-wave appends do not scale).
+// LDS: [(nslots+8) floats per lane | tri table 256x16 i8 | TRI_STAGE*9 floats | 8 words].
+__global__ void __launch_bounds__(BLOCK) leaf_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
+                                                     uint64_t n_leaves, int lq, int nslots, float ox, float oy, float oz,
+                                                     float res, float* __restrict__ tris, uint64_t tri_cap,
+                                                     MeshCounters* __restrict__ ctr) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
   float* vslot = lds + (size_t)nslots * BLOCK;  // 8 per-lane corner distances
-  int8_t* s_tri = (int8_t*)(g_smem + (size_t)(nslots + 8) * BLOCK);  // marching-cubes triangle table in LDS
+  int8_t* s_tri = (int8_t*)(g_smem + (size_t)(nslots + 8) * BLOCK);
+  float* s_stage = (float*)(s_tri + 256 * 16);
+  unsigned* s_misc = (unsigned*)(s_stage + TRI_STAGE * 9);  // [0..3] wave sums, [4] staged count
+  unsigned long long* s_base = (unsigned long long*)(s_misc + 6);
   for (int k = threadIdx.x; k < 256 * 16; k += BLOCK) s_tri[k] = GSDF_MC_TRI[k >> 4][k & 15];
+  if (threadIdx.x == 0) s_misc[4] = 0;
   __syncthreads();
 
+  const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
+  const int sh = lq - 1;
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long my_active = 0;
   const uint64_t step = (uint64_t)gridDim.x * BLOCK;
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_active; base += step) {
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_leaves; base += step) {
     const uint64_t i = base + threadIdx.x;
-    const bool valid = i < n_active;
+    const bool valid = i < n_leaves;
     Cube lf = {0, 0, 0, 0};
-    float d0 = 1.0f;
-    if (valid) { lf = act[i]; d0 = act_d0[i]; }
+    if (valid) {
+      const Cube pc = cubes[i >> (3 * sh)];
+      const unsigned l = (unsigned)(i & ((1u << (3 * sh)) - 1u));
+      const unsigned m = (1u << sh) - 1u;
+      lf.x = (uint16_t)((pc.x << sh) + (l & m));
+      lf.y = (uint16_t)((pc.y << sh) + ((l >> sh) & m));
+      lf.z = (uint16_t)((pc.z << sh) + ((l >> (2 * sh)) & m));
+    }
     const float x0 = ox + res * (float)lf.x, y0 = oy + res * (float)lf.y, z0 = oz + res * (float)lf.z;
     const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;  // Box max = origin + size
-    vslot[0] = d0;
-    unsigned index = d0 < 0.f ? 1u : 0u;
+    // Single interpreter call site: corner 0 first, the remaining 7 only if some lane of the wave passes.
+    unsigned index = 0;
+    bool pass = false;
 #pragma unroll 1
-    for (unsigned c = 1; c < 8; c++) {
+    for (unsigned c = 0; c < 8; c++) {
       P3 p;
       p.x = ((c ^ (c >> 1)) & 1u) ? x1 : x0;
       p.y = ((c >> 1) & 1u) ? y1 : y0;
@@ -221,53 +208,95 @@ __global__ void __launch_bounds__(BLOCK) leaf_march_kernel(const uint32_t* __res
       const float d = gsdf_dev::sdf_eval(code, p, lds, BLOCK);
       vslot[c * BLOCK] = d;
       index |= (d < 0.f ? 1u : 0u) << c;
+      if (c == 0) {
+        pass = valid && (dm::absf(d) <= cubeDiag);
+        const unsigned long long pmask = __ballot(pass);
+        if (pmask == 0ull) break;  // wave-uniform
+        if (lane == 0) my_active += (unsigned long long)__builtin_popcountll(pmask);
+      }
     }
-    if (!valid) index = 0;
-    // count triangles for this cube
+    if (!pass) index = 0;
     unsigned nt = 0;
     {
       const int8_t* row = s_tri + index * 16;
       while (nt < 5 && row[3 * nt] >= 0) nt++;
     }
-    // wave exclusive prefix sum of nt (Hillis-Steele over 64 lanes)
+    // block exclusive scan of nt: wave scan + 4 wave totals through LDS
     unsigned incl = nt;
-    const unsigned lane = threadIdx.x & 63;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       unsigned v = __shfl_up(incl, off, 64);
       if (lane >= (unsigned)off) incl += v;
     }
-    const unsigned total = __shfl(incl, 63, 64);
-    unsigned long long wbase = 0;
-    if (total) {
-      if (lane == 0) wbase = atomicAdd(&ctr->n_tris, (unsigned long long)total);
-      wbase = __shfl(wbase, 0, 64);
+    if (lane == 63) s_misc[wave] = incl;
+    __syncthreads();  // (A)
+    const unsigned w0 = s_misc[0], w1 = s_misc[1], w2 = s_misc[2], w3 = s_misc[3];
+    const unsigned total = w0 + w1 + w2 + w3;
+    const unsigned wpre = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
+    unsigned cur = s_misc[4];
+    const bool direct = total > TRI_STAGE;  // block-uniform
+    unsigned long long gbase = 0;
+    if (!direct && cur + total > TRI_STAGE) {  // flush the stage first (block-uniform)
+      if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)cur);
+      __syncthreads();
+      const unsigned long long fb = *s_base;
+      if (fb + cur <= tri_cap) {
+        float* dst = tris + fb * 9;
+        for (unsigned k = threadIdx.x; k < cur * 9; k += BLOCK) dst[k] = s_stage[k];
+      } else if (threadIdx.x == 0) {
+        ctr->overflow = 1ull;
+      }
+      __syncthreads();
+      cur = 0;
+    }
+    if (direct) {
+      if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)total);
+      __syncthreads();
+      gbase = *s_base;
+      if (gbase + total > tri_cap) {
+        if (threadIdx.x == 0) ctr->overflow = 1ull;
+        nt = 0;
+      }
     }
     if (nt) {
-      const unsigned long long first = wbase + (incl - nt);
-      if (first + nt > tri_cap) {
-        ctr->overflow = 1ull;
-      } else {
-        const int8_t* row = s_tri + index * 16;
-        float* dst = tris + first * 9;
-        for (unsigned t = 0; t < nt; t++) {
+      const unsigned first = wpre + (incl - nt);
+      float* dst = direct ? (tris + (gbase + first) * 9) : (s_stage + (size_t)(cur + first) * 9);
+      const int8_t* row = s_tri + index * 16;
+      for (unsigned t = 0; t < nt; t++) {
 #pragma unroll
-          for (int k = 0; k < 3; k++) {
-            const int e = row[3 * t + (2 - k)];  // reversed winding (marchcubes.go:64-68)
-            const unsigned a = GSDF_MC_PAIR_A(e), b = GSDF_MC_PAIR_B(e);
-            const float va = vslot[a * BLOCK], vb = vslot[b * BLOCK];
-            const float pax = ((a ^ (a >> 1)) & 1u) ? x1 : x0, pay = ((a >> 1) & 1u) ? y1 : y0, paz = ((a >> 2) & 1u) ? z1 : z0;
-            const float pbx = ((b ^ (b >> 1)) & 1u) ? x1 : x0, pby = ((b >> 1) & 1u) ? y1 : y0, pbz = ((b >> 2) & 1u) ? z1 : z0;
-            float rx, ry, rz;
-            mc_interp(pax, pay, paz, pbx, pby, pbz, va, vb, rx, ry, rz);
-            dst[9 * t + 3 * k + 0] = rx;
-            dst[9 * t + 3 * k + 1] = ry;
-            dst[9 * t + 3 * k + 2] = rz;
-          }
+        for (int k = 0; k < 3; k++) {
+          const int e = row[3 * t + (2 - k)];  // reversed winding (marchcubes.go:64-68)
+          const unsigned a = GSDF_MC_PAIR_A(e), b = GSDF_MC_PAIR_B(e);
+          const float va = vslot[a * BLOCK], vb = vslot[b * BLOCK];
+          const float pax = ((a ^ (a >> 1)) & 1u) ? x1 : x0, pay = ((a >> 1) & 1u) ? y1 : y0, paz = ((a >> 2) & 1u) ? z1 : z0;
+          const float pbx = ((b ^ (b >> 1)) & 1u) ? x1 : x0, pby = ((b >> 1) & 1u) ? y1 : y0, pbz = ((b >> 2) & 1u) ? z1 : z0;
+          float rx, ry, rz;
+          mc_interp(pax, pay, paz, pbx, pby, pbz, va, vb, rx, ry, rz);
+          dst[9 * t + 3 * k + 0] = rx;
+          dst[9 * t + 3 * k + 1] = ry;
+          dst[9 * t + 3 * k + 2] = rz;
         }
       }
     }
+    __syncthreads();  // (B)
+    if (threadIdx.x == 0 && !direct) s_misc[4] = cur + total;
   }
+  __syncthreads();
+  {  // final flush
+    const unsigned cur = s_misc[4];
+    if (cur) {
+      if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)cur);
+      __syncthreads();
+      const unsigned long long fb = *s_base;
+      if (fb + cur <= tri_cap) {
+        float* dst = tris + fb * 9;
+        for (unsigned k = threadIdx.x; k < cur * 9; k += BLOCK) dst[k] = s_stage[k];
+      } else if (threadIdx.x == 0) {
+        ctr->overflow = 1ull;
+      }
+    }
+  }
+  if (lane == 0 && my_active) atomicAdd(&ctr->n_active, my_active);
 }
 
 // STL records (stl.go:15-62): one wave stages 64 x 50-byte records in LDS, then stores dwords.
@@ -348,6 +377,21 @@ struct gsdf_program {
   float* d_dist = nullptr;
   size_t cap_pos_bytes = 0, cap_dist = 0;
   int num_cu = 256;
+  // mesher workspace, grow-only, reused by every gsdf_hip_mesh_octree call on this handle
+  struct Arena {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+      if (bytes <= cap) return hipSuccess;
+      if (p) (void)hipFree(p);
+      p = nullptr; cap = 0;
+      size_t want = bytes + bytes / 4 + 4096;
+      hipError_t e = hipMalloc(&p, want);
+      if (e == hipSuccess) cap = want;
+      return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  } q0, q1, ctr;
   size_t lds_bytes() const { return (size_t)(prog.nslots > 0 ? prog.nslots : 1) * BLOCK * sizeof(float); }
 };
 
@@ -358,6 +402,37 @@ struct gsdf_mesh {
   gsdf_mesh_stats st{};
   hipStream_t stream = nullptr;
 };
+
+// Triangle buffers are recycled through a small per-process pool: hipMalloc/hipFree of the multi-GB
+// output buffer would otherwise dominate a mesh call.
+namespace {
+struct TriBuf { int device; float* p; uint64_t cap; };
+std::mutex g_pool_mu;
+std::vector<TriBuf> g_pool;
+float* pool_take(int device, uint64_t need, uint64_t* cap_out) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  int best = -1;
+  for (size_t i = 0; i < g_pool.size(); i++)
+    if (g_pool[i].device == device && g_pool[i].cap >= need && (best < 0 || g_pool[i].cap < g_pool[(size_t)best].cap)) best = (int)i;
+  if (best < 0) return nullptr;
+  TriBuf b = g_pool[(size_t)best];
+  g_pool.erase(g_pool.begin() + best);
+  *cap_out = b.cap;
+  return b.p;
+}
+void pool_give(int device, float* p, uint64_t cap) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (g_pool.size() >= 4) {  // drop the smallest
+    size_t sm = 0;
+    for (size_t i = 1; i < g_pool.size(); i++) if (g_pool[i].cap < g_pool[sm].cap) sm = i;
+    if (g_pool[sm].cap < cap) { (void)hipFree(g_pool[sm].p); g_pool[sm] = TriBuf{device, p, cap}; }
+    else (void)hipFree(p);
+    return;
+  }
+  g_pool.push_back(TriBuf{device, p, cap});
+}
+}  // namespace
 
 static unsigned grid_for(uint64_t n, int num_cu, int blocks_per_cu) {
   uint64_t b = (n + BLOCK - 1) / BLOCK;
@@ -413,6 +488,7 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (p->d_code) (void)hipFree(p->d_code);
   if (p->d_pos) (void)hipFree(p->d_pos);
   if (p->d_dist) (void)hipFree(p->d_dist);
+  p->q0.release(); p->q1.release(); p->ctr.release();
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
 }
@@ -515,6 +591,8 @@ extern "C" int gsdf_hip_normals3(gsdf_program* p, const float* pos, float* norma
   return rc;
 }
 
+extern "C" uint64_t gsdf_hip_shard_bricks(const uint16_t* cubes, uint64_t n, int rank, int count, uint16_t* out);
+
 // ---- mesher -----------------------------------------------------------------------------------
 namespace {
 // ms3.Box.ScaleCentered(1.01) = NewCenteredBox(Center(), MulElem(scale, Size())) [external]; float32, unfused.
@@ -571,29 +649,26 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     if (_e != hipSuccess) return bail(fail(GSDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
   } while (0)
 
-  DevBuf ctr_buf;
-  HIP_TRYM(ctr_buf.alloc(sizeof(MeshCounters)));
-  MeshCounters* d_ctr = (MeshCounters*)ctr_buf.p;
+  HIP_TRYM(p->ctr.ensure(sizeof(MeshCounters)));
+  MeshCounters* d_ctr = (MeshCounters*)p->ctr.p;
   HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(MeshCounters), s));
-  hipEvent_t ev0, ev1, ev2, evm0, evm1;
+  hipEvent_t ev0, ev1, ev2;
   HIP_TRYM(hipEventCreate(&ev0));
   HIP_TRYM(hipEventCreate(&ev1));
   HIP_TRYM(hipEventCreate(&ev2));
-  HIP_TRYM(hipEventCreate(&evm0));
-  HIP_TRYM(hipEventCreate(&evm1));
-  struct EvGuard { hipEvent_t e[5]; ~EvGuard() { for (auto x : e) (void)hipEventDestroy(x); } } evg{{ev0, ev1, ev2, evm0, evm1}};
-  bool marched = false;
+  struct EvGuard { hipEvent_t e[3]; ~EvGuard() { for (auto x : e) (void)hipEventDestroy(x); } } evg{{ev0, ev1, ev2}};
   HIP_TRYM(hipEventRecord(ev0, s));
 
   // ---- level-synchronous descent from the top cube to level lq = min(levels, 3)
   const int lq = levels < 3 ? levels : 3;
   uint64_t evals = 0, pruned = 0;
-  DevBuf cur, nxt;
+  gsdf_program::Arena* cur = &p->q0;
+  gsdf_program::Arena* nxt = &p->q1;
   uint64_t n_cur = 1;
-  HIP_TRYM(cur.alloc(sizeof(Cube)));
+  HIP_TRYM(cur->ensure(sizeof(Cube)));
   {
     Cube top = {0, 0, 0, 0};
-    HIP_TRYM(hipMemcpyAsync(cur.p, &top, sizeof(Cube), hipMemcpyHostToDevice, s));
+    HIP_TRYM(hipMemcpyAsync(cur->p, &top, sizeof(Cube), hipMemcpyHostToDevice, s));
   }
   const size_t lds = p->lds_bytes();
   bool sharded = opts.shard_count == 1;
@@ -602,16 +677,11 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   // that every rank derives the same partition without communicating).
   auto deal = [&]() {
     std::vector<Cube> h(n_cur);
-    if (n_cur && hipMemcpy(h.data(), cur.p, n_cur * sizeof(Cube), hipMemcpyDeviceToHost) != hipSuccess) { shard_rc = fail(GSDF_ERR_HIP, "D2H copy of bricks failed"); return; }
-    std::sort(h.begin(), h.end(), [](const Cube& a, const Cube& b) {
-      if (a.z != b.z) return a.z < b.z;
-      if (a.y != b.y) return a.y < b.y;
-      return a.x < b.x;
-    });
-    std::vector<Cube> mine;
-    for (uint64_t i = (uint64_t)opts.shard_rank; i < n_cur; i += (uint64_t)opts.shard_count) mine.push_back(h[i]);
-    n_cur = mine.size();
-    if (n_cur && hipMemcpy(cur.p, mine.data(), n_cur * sizeof(Cube), hipMemcpyHostToDevice) != hipSuccess) { shard_rc = fail(GSDF_ERR_HIP, "H2D copy of bricks failed"); return; }
+    if (n_cur && hipMemcpy(h.data(), cur->p, n_cur * sizeof(Cube), hipMemcpyDeviceToHost) != hipSuccess) { shard_rc = fail(GSDF_ERR_HIP, "D2H copy of bricks failed"); return; }
+    std::vector<Cube> mine(n_cur);
+    const uint64_t n_mine = gsdf_hip_shard_bricks((const uint16_t*)h.data(), n_cur, opts.shard_rank, opts.shard_count, (uint16_t*)mine.data());
+    n_cur = n_mine;
+    if (n_cur && hipMemcpy(cur->p, mine.data(), n_cur * sizeof(Cube), hipMemcpyHostToDevice) != hipSuccess) { shard_rc = fail(GSDF_ERR_HIP, "H2D copy of bricks failed"); return; }
     sharded = true;
   };
   for (int level = levels; level >= lq; level--) {
@@ -619,11 +689,10 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     const uint64_t n_items = expand ? n_cur * 8 : n_cur;
     const int do_test = (level >= 3 && opts.prune) ? 1 : 0;
     if (!expand && !do_test) continue;  // top cube kept as is
-    DevBuf o;
-    HIP_TRYM(o.alloc(n_items * sizeof(Cube)));
+    HIP_TRYM(nxt->ensure(n_items * sizeof(Cube)));
     HIP_TRYM(hipMemsetAsync(&d_ctr->n_out, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(prune_kernel, dim3(grid_for(n_items, p->num_cu, 8)), dim3(BLOCK), lds, s, p->d_code, (const Cube*)cur.p,
-                       n_items, expand ? 1 : 0, level, ox, oy, oz, res, do_test, (Cube*)o.p, d_ctr);
+    hipLaunchKernelGGL(prune_kernel, dim3(grid_for(n_items, p->num_cu, 8)), dim3(BLOCK), lds, s, p->d_code, (const Cube*)cur->p,
+                       n_items, expand ? 1 : 0, level, ox, oy, oz, res, do_test, (Cube*)nxt->p, d_ctr);
     HIP_TRYM(hipGetLastError());
     unsigned long long n_out = 0;
     HIP_TRYM(hipMemcpyAsync(&n_out, &d_ctr->n_out, sizeof(n_out), hipMemcpyDeviceToHost, s));
@@ -632,7 +701,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
       evals += n_items;
       pruned += (n_items - n_out) << (3 * (level - 1));  // DecomposesTo(1) = 8^(level-1)
     }
-    std::swap(cur.p, o.p);
+    std::swap(cur, nxt);
     n_cur = n_out;
     if (!sharded && (n_cur >= (uint64_t)64 * opts.shard_count || level == lq)) {
       deal();
@@ -651,33 +720,33 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   const uint64_t n_leaves = n_cur * lpc;
   unsigned long long n_active = 0, n_tris = 0;
   if (n_leaves) {
-    DevBuf act, act_d0;
-    HIP_TRYM(act.alloc(n_leaves * sizeof(Cube)));
-    HIP_TRYM(act_d0.alloc(n_leaves * sizeof(float)));
-    hipLaunchKernelGGL(leaf_first_kernel, dim3(grid_for(n_leaves, p->num_cu, 8)), dim3(BLOCK), lds, s, p->d_code, (const Cube*)cur.p,
-                       n_leaves, lq, ox, oy, oz, res, (Cube*)act.p, (float*)act_d0.p, d_ctr);
-    HIP_TRYM(hipGetLastError());
-    HIP_TRYM(hipMemcpyAsync(&n_active, &d_ctr->n_active, sizeof(n_active), hipMemcpyDeviceToHost, s));
-    HIP_TRYM(hipStreamSynchronize(s));
-    evals += n_leaves;
-    if (n_active) {
-      uint64_t cap = opts.max_tris ? opts.max_tris : n_active * 5;
-      HIP_TRYM(hipMalloc((void**)&m->d_tris, cap * 36));
-      m->cap = cap;
-      const size_t lds_m = (size_t)(p->prog.nslots + 8) * BLOCK * sizeof(float) + 512 + 4096;
-      HIP_TRYM(hipEventRecord(evm0, s));
-      hipLaunchKernelGGL(leaf_march_kernel, dim3(grid_for(n_active, p->num_cu, 8)), dim3(BLOCK), lds_m, s, p->d_code,
-                         (const Cube*)act.p, (const float*)act_d0.p, (uint64_t)n_active, p->prog.nslots, ox, oy, oz, res, m->d_tris,
-                         cap, d_ctr);
+    // capacity: caller's, else a pooled buffer, else one triangle per leaf; on overflow the kernel keeps
+    // counting, so the exact size is known and the leaf pass is repeated once with it.
+    uint64_t want = opts.max_tris ? opts.max_tris : (n_leaves < 4096 ? 4096 : n_leaves);
+    const size_t lds_m = (size_t)(p->prog.nslots + 8) * BLOCK * sizeof(float) + 4096 + TRI_STAGE * 36 + 64;
+    for (int attempt = 0; attempt < 2; attempt++) {
+      if (!m->d_tris) {
+        m->d_tris = pool_take(p->device, want, &m->cap);
+        if (!m->d_tris) {
+          HIP_TRYM(hipMalloc((void**)&m->d_tris, want * 36));
+          m->cap = want;
+        }
+      }
+      hipLaunchKernelGGL(leaf_kernel, dim3(grid_for(n_leaves, p->num_cu, 8)), dim3(BLOCK), lds_m, s, p->d_code, (const Cube*)cur->p,
+                         n_leaves, lq, p->prog.nslots, ox, oy, oz, res, m->d_tris, opts.max_tris ? opts.max_tris : m->cap, d_ctr);
       HIP_TRYM(hipGetLastError());
-      HIP_TRYM(hipEventRecord(evm1, s));
-      marched = true;
       MeshCounters hc{};
       HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));
       HIP_TRYM(hipStreamSynchronize(s));
-      evals += 7 * n_active;
+      n_active = hc.n_active;
       n_tris = hc.n_tris;
-      if (hc.overflow) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
+      evals += n_leaves + 7 * n_active;
+      if (!hc.overflow) break;
+      if (opts.max_tris || attempt == 1) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
+      pool_give(p->device, m->d_tris, m->cap);
+      m->d_tris = nullptr; m->cap = 0;
+      want = n_tris;
+      HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(MeshCounters), s));
     }
   }
   HIP_TRYM(hipEventRecord(ev2, s));
@@ -692,16 +761,29 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   m->st.active_leaves = n_active;
   m->st.ms_prune = ms01;
   m->st.ms_leaf = ms12;
+  m->st.ms_march = ms12;
   m->st.ms_total = (double)ms01 + (double)ms12;
-  if (marched) {
-    float msm = 0;
-    HIP_TRYM(hipEventElapsedTime(&msm, evm0, evm1));
-    m->st.ms_march = msm;
-  }
   p->evals += evals;
   *out = m;
   return GSDF_OK;
 #undef HIP_TRYM
+}
+
+// Pure host helper (no GPU): deterministic brick partition used for multi-GPU sharding. cubes/out are
+// arrays of 4 x u16 (x,y,z,pad). Returns the number of bricks of `rank`; every rank computes the same
+// partition from the same survivor set, so no communication is needed.
+extern "C" uint64_t gsdf_hip_shard_bricks(const uint16_t* cubes, uint64_t n, int rank, int count, uint16_t* out) {
+  if (!cubes || !out || count < 1 || rank < 0 || rank >= count) return 0;
+  std::vector<Cube> h(n);
+  std::memcpy(h.data(), cubes, n * sizeof(Cube));
+  std::sort(h.begin(), h.end(), [](const Cube& a, const Cube& b) {
+    if (a.z != b.z) return a.z < b.z;
+    if (a.y != b.y) return a.y < b.y;
+    return a.x < b.x;
+  });
+  uint64_t k = 0;
+  for (uint64_t i = (uint64_t)rank; i < n; i += (uint64_t)count) std::memcpy(out + 4 * (k++), &h[i], sizeof(Cube));
+  return k;
 }
 
 extern "C" int gsdf_hip_mesh_stats_get(const gsdf_mesh* m, gsdf_mesh_stats* st) {
@@ -746,6 +828,6 @@ extern "C" int gsdf_hip_mesh_stl(const gsdf_mesh* m, uint8_t* dst, size_t dst_ca
 
 extern "C" void gsdf_hip_mesh_destroy(gsdf_mesh* m) {
   if (!m) return;
-  if (m->d_tris) (void)hipFree(m->d_tris);
+  pool_give(m->device, m->d_tris, m->cap);
   delete m;
 }

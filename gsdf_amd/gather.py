@@ -1,0 +1,48 @@
+"""Variable-length gather of per-rank triangle buffers (RCCL over xGMI on GPUs, gloo on CPU in tests).
+
+The mesher shards octree bricks across ranks with no data-path communication; the only exchange is
+this final gather. RCCL has no all-gatherv: exchange the counts (one all_gather of
+world int64), pad every rank's payload to the maximum count and run ONE all_gather_into_tensor (one
+large collective; bricks are dealt round-robin so counts are balanced and padding is small), then
+compact on device.
+"""
+import torch
+import torch.distributed as dist
+
+
+class _DevArray:
+    """Zero-copy view of a raw device pointer for torch.as_tensor (CUDA array interface v2)."""
+
+    def __init__(self, ptr, nfloats):
+        self.__cuda_array_interface__ = {"shape": (int(nfloats),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+def tensor_from_dev_ptr(ptr, n_tris, device):
+    if n_tris == 0 or not ptr:
+        return torch.empty((0, 9), dtype=torch.float32, device=device)
+    return torch.as_tensor(_DevArray(ptr, n_tris * 9), device=device).view(n_tris, 9)
+
+
+def all_gatherv(local, group=None):
+    """local: (n_i, 9) float32 tensor on this rank's device. Returns ((sum n_i, 9) tensor, counts list),
+    rank-major order, identical on every rank."""
+    world = dist.get_world_size(group)
+    dev = local.device
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    counts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, n, group=group)
+    counts_l = [int(c) for c in counts.tolist()]
+    mx = max(counts_l)
+    if mx == 0:
+        return torch.empty((0, 9), dtype=torch.float32, device=dev), counts_l
+    send = torch.zeros((mx, 9), dtype=torch.float32, device=dev)
+    send[: local.shape[0]] = local
+    recv = torch.empty((world, mx, 9), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+    out = torch.cat([recv[r, : counts_l[r]] for r in range(world)], dim=0)
+    return out, counts_l
+
+
+def all_gatherv_triangles(dev_ptr, n_tris, device, group=None):
+    """Gather the device-resident triangle buffers of all ranks (OctreeHIP.dev_ptr()/n_tris())."""
+    return all_gatherv(tensor_from_dev_ptr(dev_ptr, n_tris, device), group)

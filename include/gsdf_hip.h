@@ -96,8 +96,8 @@ typedef struct gsdf_mesh_stats {
   float res;
   double ms_total;         /* device time for the whole mesh, HIP events */
   double ms_prune;         /* pruning levels */
-  double ms_leaf;          /* leaf phase: corner-0 pass + march pass (incl. host gaps) */
-  double ms_march;         /* dominant kernel alone: leaf_march_kernel (7 corners + marching cubes) */
+  double ms_leaf;          /* leaf phase */
+  double ms_march;         /* dominant kernel alone: leaf_kernel (8 corners + marching cubes), HIP events */
 } gsdf_mesh_stats;
 
 int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_opts* opts, gsdf_mesh** out);
@@ -109,6 +109,10 @@ const float* gsdf_hip_mesh_dev_tris(const gsdf_mesh* m);
 /* Binary STL (84 + 50*n bytes) built on device into dst (host). dst_cap must be >= that size. */
 int gsdf_hip_mesh_stl(const gsdf_mesh* m, uint8_t* dst, size_t dst_cap);
 void gsdf_hip_mesh_destroy(gsdf_mesh* m);
+
+/* Host-only helper (runs without a GPU): the deterministic brick partition gsdf_hip_mesh_octree uses for
+ * multi-GPU sharding. cubes/out: n x {u16 x, y, z, pad}. Returns the number of bricks given to `rank`. */
+uint64_t gsdf_hip_shard_bricks(const uint16_t* cubes, uint64_t n, int rank, int count, uint16_t* out);
 
 #ifdef __cplusplus
 }
