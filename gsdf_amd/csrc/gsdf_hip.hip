@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -54,24 +55,34 @@ __device__ __forceinline__ code_ptr as_code(const uint32_t* p) { return (code_pt
 
 extern __shared__ __attribute__((aligned(16))) float g_smem[];
 
-template <int DIM>
+// dist[i] = SDF(pos[i]). Each lane carries K points per interpreter pass (tile = K*BLOCK points,
+// point kp of lane t = tile + kp*BLOCK + t, so every load/store stays coalesced).
+template <int DIM, int K>
 __global__ void __launch_bounds__(BLOCK) eval_kernel(const uint32_t* __restrict__ code_g, const float* __restrict__ pos,
                                                      uint32_t stride_f, float* __restrict__ dist, uint64_t n) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
-  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {  // uniform trip count
-    const uint64_t i = base + threadIdx.x;
-    const bool valid = i < n;
-    P3 p = {0.f, 0.f, 0.f};
-    if (valid) {
-      const float* q = pos + i * stride_f;
-      p.x = q[0];
-      p.y = q[1];
-      if (DIM == 3) p.z = q[2];
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK * K;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK * K; base < n; base += step) {  // uniform trip count
+    P3 p[K];
+    float d[K];
+#pragma unroll
+    for (int kp = 0; kp < K; kp++) {
+      const uint64_t i = base + (uint64_t)kp * BLOCK + threadIdx.x;
+      p[kp] = P3{0.f, 0.f, 0.f};
+      if (i < n) {
+        const float* q = pos + i * stride_f;
+        p[kp].x = q[0];
+        p[kp].y = q[1];
+        if (DIM == 3) p[kp].z = q[2];
+      }
     }
-    float d = gsdf_dev::sdf_eval(code, p, lds, BLOCK);
-    if (valid) dist[i] = d;
+    gsdf_dev::sdf_eval<K>(code, p, d, lds, BLOCK);
+#pragma unroll
+    for (int kp = 0; kp < K; kp++) {
+      const uint64_t i = base + (uint64_t)kp * BLOCK + threadIdx.x;
+      if (i < n) dist[i] = d[kp];
+    }
   }
 }
 
@@ -85,6 +96,7 @@ struct MeshCounters {
   unsigned long long n_active;  // active leaves
   unsigned long long n_tris;
   unsigned long long overflow;  // triangle buffer overflow flag
+  unsigned long long n_cont;    // leaves whose wave went on to the remaining corners
 };
 
 // wave64 compaction: returns the global slot for lanes with keep=true (others undefined).
@@ -133,8 +145,10 @@ __global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict
       p.x = 0.5f * (cx0 + (cx0 + size));
       p.y = 0.5f * (cy0 + (cy0 + size));
       p.z = 0.5f * (cz0 + (cz0 + size));
-      const float d = gsdf_dev::sdf_eval(code, p, lds, BLOCK);
-      keep = valid && !(dm::absf(d) >= maxDist);
+      P3 pv[1] = {p};
+      float dv[1];
+      gsdf_dev::sdf_eval<1>(code, pv, dv, lds, BLOCK);
+      keep = valid && !(dm::absf(dv[0]) >= maxDist);
     }
     const unsigned long long slot = wave_append(keep, &ctr->n_out);
     if (keep) out[slot] = c;
@@ -162,14 +176,15 @@ __device__ __forceinline__ void mc_interp(float ax, float ay, float az, float bx
 // table from LDS; triangles are staged in LDS and flushed with ONE global atomic per flush
 // (a single counter word saturates at ~88 atomics/us on MI355X, so per-wave appends do not scale).
 // LDS: [(nslots+8) floats per lane | tri table 256x16 i8 | TRI_STAGE*9 floats | 8 words].
+template <int K>
 __global__ void __launch_bounds__(BLOCK) leaf_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
                                                      uint64_t n_leaves, int lq, int nslots, float ox, float oy, float oz,
                                                      float res, float* __restrict__ tris, uint64_t tri_cap,
                                                      MeshCounters* __restrict__ ctr) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
-  float* vslot = lds + (size_t)nslots * BLOCK;  // 8 per-lane corner distances
-  int8_t* s_tri = (int8_t*)(g_smem + (size_t)(nslots + 8) * BLOCK);
+  float* vslot = lds + (size_t)nslots * K * BLOCK;  // 8 per-lane corner distances
+  int8_t* s_tri = (int8_t*)(g_smem + (size_t)(nslots * K + 8) * BLOCK);
   float* s_stage = (float*)(s_tri + 256 * 16);
   unsigned* s_misc = (unsigned*)(s_stage + TRI_STAGE * 9);  // [0..3] wave sums, [4] staged count
   unsigned long long* s_base = (unsigned long long*)(s_misc + 6);
@@ -180,7 +195,7 @@ __global__ void __launch_bounds__(BLOCK) leaf_kernel(const uint32_t* __restrict_
   const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
   const int sh = lq - 1;
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned long long my_active = 0;
+  unsigned long long my_active = 0, my_cont = 0;
   const uint64_t step = (uint64_t)gridDim.x * BLOCK;
   for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_leaves; base += step) {
     const uint64_t i = base + threadIdx.x;
@@ -196,23 +211,36 @@ __global__ void __launch_bounds__(BLOCK) leaf_kernel(const uint32_t* __restrict_
     }
     const float x0 = ox + res * (float)lf.x, y0 = oy + res * (float)lf.y, z0 = oz + res * (float)lf.z;
     const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;  // Box max = origin + size
-    // Single interpreter call site: corner 0 first, the remaining 7 only if some lane of the wave passes.
+    // Single interpreter call site, K corners per pass (corner 0 is in the first pass); the wave goes on
+    // to the remaining corners only if some lane passes the reference's corner-0 test.
     unsigned index = 0;
     bool pass = false;
 #pragma unroll 1
-    for (unsigned c = 0; c < 8; c++) {
-      P3 p;
-      p.x = ((c ^ (c >> 1)) & 1u) ? x1 : x0;
-      p.y = ((c >> 1) & 1u) ? y1 : y0;
-      p.z = ((c >> 2) & 1u) ? z1 : z0;
-      const float d = gsdf_dev::sdf_eval(code, p, lds, BLOCK);
-      vslot[c * BLOCK] = d;
-      index |= (d < 0.f ? 1u : 0u) << c;
-      if (c == 0) {
-        pass = valid && (dm::absf(d) <= cubeDiag);
+    for (unsigned c0 = 0; c0 < 8; c0 += K) {
+      P3 pk[K];
+      float dk[K];
+#pragma unroll
+      for (int kp = 0; kp < K; kp++) {
+        const unsigned c = c0 + kp;
+        pk[kp].x = ((c ^ (c >> 1)) & 1u) ? x1 : x0;
+        pk[kp].y = ((c >> 1) & 1u) ? y1 : y0;
+        pk[kp].z = ((c >> 2) & 1u) ? z1 : z0;
+      }
+      gsdf_dev::sdf_eval<K>(code, pk, dk, lds, BLOCK);
+#pragma unroll
+      for (int kp = 0; kp < K; kp++) {
+        vslot[(c0 + kp) * BLOCK] = dk[kp];
+        index |= (dk[kp] < 0.f ? 1u : 0u) << (c0 + kp);
+      }
+      if (c0 == 0) {
+        pass = valid && (dm::absf(dk[0]) <= cubeDiag);
         const unsigned long long pmask = __ballot(pass);
         if (pmask == 0ull) break;  // wave-uniform
-        if (lane == 0) my_active += (unsigned long long)__builtin_popcountll(pmask);
+        const unsigned long long vmask = __ballot(valid);
+        if (lane == 0) {
+          my_active += (unsigned long long)__builtin_popcountll(pmask);
+          my_cont += (unsigned long long)__builtin_popcountll(vmask);
+        }
       }
     }
     if (!pass) index = 0;
@@ -296,7 +324,10 @@ __global__ void __launch_bounds__(BLOCK) leaf_kernel(const uint32_t* __restrict_
       }
     }
   }
-  if (lane == 0 && my_active) atomicAdd(&ctr->n_active, my_active);
+  if (lane == 0 && my_cont) {
+    atomicAdd(&ctr->n_active, my_active);
+    atomicAdd(&ctr->n_cont, my_cont);
+  }
 }
 
 // STL records (stl.go:15-62): one wave stages 64 x 50-byte records in LDS, then stores dwords.
@@ -354,9 +385,10 @@ __global__ void __launch_bounds__(BLOCK) normals_kernel(const uint32_t* __restri
     for (int dim = 0; dim < 3; dim++) {
       P3 a = {px + (dim == 0 ? h : 0.f), py + (dim == 1 ? h : 0.f), pz + (dim == 2 ? h : 0.f)};
       P3 b = {px - (dim == 0 ? h : 0.f), py - (dim == 1 ? h : 0.f), pz - (dim == 2 ? h : 0.f)};
-      const float d1 = gsdf_dev::sdf_eval(code, a, lds, BLOCK);
-      const float d2 = gsdf_dev::sdf_eval(code, b, lds, BLOCK);
-      const float v = d1 - d2;
+      P3 ab[2] = {a, b};
+      float dd[2];
+      gsdf_dev::sdf_eval<2>(code, ab, dd, lds, BLOCK);
+      const float v = dd[0] - dd[1];
       if (dim == 0) out[0] = v; else if (dim == 1) out[1] = v; else out[2] = v;
     }
     if (valid) { nrm[3 * i] = out[0]; nrm[3 * i + 1] = out[1]; nrm[3 * i + 2] = out[2]; }
@@ -392,7 +424,13 @@ struct gsdf_program {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
   } q0, q1, ctr;
-  size_t lds_bytes() const { return (size_t)(prog.nslots > 0 ? prog.nslots : 1) * BLOCK * sizeof(float); }
+  size_t lds_bytes(int k = 1) const { return (size_t)(prog.nslots > 0 ? prog.nslots : 1) * k * BLOCK * sizeof(float); }
+  // Points carried per lane: as many as keep >= 2 workgroups per CU resident (160 KB LDS per CU).
+  int batch_k() const {
+    static const int forced = [] { const char* e = getenv("GSDF_HIP_BATCH_K"); return e ? atoi(e) : 0; }();  // tuning knob
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    return prog.nslots <= 12 ? 4 : (prog.nslots <= 28 ? 2 : 1);
+  }
 };
 
 struct gsdf_mesh {
@@ -474,7 +512,7 @@ extern "C" int gsdf_hip_program_create(const gsdf_tree* tree, gsdf_program** out
   if (hipGetDevice(&p->device) != hipSuccess) return cleanup(fail(GSDF_ERR_HIP, "hipGetDevice failed"));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) p->num_cu = prop.multiProcessorCount;
-  if (p->lds_bytes() + 8 * BLOCK * 4 + 8192 > 160 * 1024) return cleanup(fail(GSDF_ERR_BAD_TREE, "tree needs more LDS scratch than one CU has"));
+  if (p->lds_bytes(p->batch_k()) + 8 * BLOCK * 4 + 4096 + TRI_STAGE * 36 + 64 > 160 * 1024) return cleanup(fail(GSDF_ERR_BAD_TREE, "tree needs more LDS scratch than one CU has"));
   if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) return cleanup(fail(GSDF_ERR_HIP, "hipStreamCreate failed"));
   size_t bytes = p->prog.code.size() * sizeof(uint32_t);
   if (hipMalloc((void**)&p->d_code, bytes) != hipSuccess) return cleanup(fail(GSDF_ERR_HIP, "hipMalloc(program) failed"));
@@ -509,12 +547,15 @@ extern "C" uint64_t gsdf_hip_evaluations(const gsdf_program* p) { return p ? p->
 
 static int eval_dev(gsdf_program* p, int dim, const void* d_pos, size_t stride_bytes, float* d_dist, size_t n, hipStream_t s) {
   if (stride_bytes % 4 != 0 || stride_bytes < (size_t)dim * 4) return fail(GSDF_ERR_BAD_ARGUMENT, "bad position stride");
-  const unsigned grid = grid_for(n, p->num_cu, 8);
+  const int k = p->batch_k();
+  const unsigned grid = grid_for((n + k - 1) / k, p->num_cu, 8);
   const uint32_t sf = (uint32_t)(stride_bytes / 4);
-  if (dim == 3)
-    hipLaunchKernelGGL(eval_kernel<3>, dim3(grid), dim3(BLOCK), p->lds_bytes(), s, p->d_code, (const float*)d_pos, sf, d_dist, (uint64_t)n);
-  else
-    hipLaunchKernelGGL(eval_kernel<2>, dim3(grid), dim3(BLOCK), p->lds_bytes(), s, p->d_code, (const float*)d_pos, sf, d_dist, (uint64_t)n);
+  const float* q = (const float*)d_pos;
+  const uint64_t nn = (uint64_t)n;
+#define LAUNCH_EVAL(D, KK) hipLaunchKernelGGL((eval_kernel<D, KK>), dim3(grid), dim3(BLOCK), p->lds_bytes(KK), s, p->d_code, q, sf, d_dist, nn)
+  if (dim == 3) { if (k == 4) LAUNCH_EVAL(3, 4); else if (k == 2) LAUNCH_EVAL(3, 2); else LAUNCH_EVAL(3, 1); }
+  else { if (k == 4) LAUNCH_EVAL(2, 4); else if (k == 2) LAUNCH_EVAL(2, 2); else LAUNCH_EVAL(2, 1); }
+#undef LAUNCH_EVAL
   HIP_TRY(hipGetLastError());
   p->evals += n;
   return GSDF_OK;
@@ -580,7 +621,7 @@ extern "C" int gsdf_hip_normals3(gsdf_program* p, const float* pos, float* norma
   int rc = GSDF_OK;
   do {
     if (hipMemcpyAsync(d_p, pos, n * 12, hipMemcpyHostToDevice, p->stream) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "H2D copy failed"); break; }
-    hipLaunchKernelGGL(normals_kernel, dim3(grid_for(n, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(), p->stream, p->d_code, d_p, d_n, (uint64_t)n, step);
+    hipLaunchKernelGGL(normals_kernel, dim3(grid_for(n, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(2), p->stream, p->d_code, d_p, d_n, (uint64_t)n, step);
     if (hipGetLastError() != hipSuccess) { rc = fail(GSDF_ERR_HIP, "normals kernel launch failed"); break; }
     if (hipMemcpyAsync(normals, d_n, n * 12, hipMemcpyDeviceToHost, p->stream) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "D2H copy failed"); break; }
     if (hipStreamSynchronize(p->stream) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "stream sync failed"); break; }
@@ -723,7 +764,8 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     // capacity: caller's, else a pooled buffer, else one triangle per leaf; on overflow the kernel keeps
     // counting, so the exact size is known and the leaf pass is repeated once with it.
     uint64_t want = opts.max_tris ? opts.max_tris : (n_leaves < 4096 ? 4096 : n_leaves);
-    const size_t lds_m = (size_t)(p->prog.nslots + 8) * BLOCK * sizeof(float) + 4096 + TRI_STAGE * 36 + 64;
+    const int lk = p->batch_k();
+    const size_t lds_m = (size_t)(p->prog.nslots * lk + 8) * BLOCK * sizeof(float) + 4096 + TRI_STAGE * 36 + 64;
     for (int attempt = 0; attempt < 2; attempt++) {
       if (!m->d_tris) {
         m->d_tris = pool_take(p->device, want, &m->cap);
@@ -732,15 +774,18 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
           m->cap = want;
         }
       }
-      hipLaunchKernelGGL(leaf_kernel, dim3(grid_for(n_leaves, p->num_cu, 8)), dim3(BLOCK), lds_m, s, p->d_code, (const Cube*)cur->p,
-                         n_leaves, lq, p->prog.nslots, ox, oy, oz, res, m->d_tris, opts.max_tris ? opts.max_tris : m->cap, d_ctr);
+#define LAUNCH_LEAF(KK)                                                                                                   \
+  hipLaunchKernelGGL((leaf_kernel<KK>), dim3(grid_for(n_leaves, p->num_cu, 8)), dim3(BLOCK), lds_m, s, p->d_code, (const Cube*)cur->p, \
+                     n_leaves, lq, p->prog.nslots, ox, oy, oz, res, m->d_tris, opts.max_tris ? opts.max_tris : m->cap, d_ctr)
+      if (lk == 4) LAUNCH_LEAF(4); else if (lk == 2) LAUNCH_LEAF(2); else LAUNCH_LEAF(1);
+#undef LAUNCH_LEAF
       HIP_TRYM(hipGetLastError());
       MeshCounters hc{};
       HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));
       HIP_TRYM(hipStreamSynchronize(s));
       n_active = hc.n_active;
       n_tris = hc.n_tris;
-      evals += n_leaves + 7 * n_active;
+      evals += n_leaves * (uint64_t)lk + (uint64_t)(8 - lk) * hc.n_cont;  // evaluations actually executed on leaf corners
       if (!hc.overflow) break;
       if (opts.max_tris || attempt == 1) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
       pool_give(p->device, m->d_tris, m->cap);

@@ -19,12 +19,18 @@ typedef const uint32_t __attribute__((address_space(4))) * code_ptr;  // constan
 
 struct P3 { float x, y, z; };
 
-#define LDSF(slot) lds[(slot) * nthreads]
+// Slot s of point k of this lane: one float per lane per (slot, k) -> conflict-free columns.
+#define LDSF(slot) lds[((slot) * K + kp) * nthreads]
+// Each instruction is applied to the K points this lane carries before the next dispatch: the decode,
+// the scalar parameter loads and the branch are paid once per K points, and the K independent
+// dependency chains hide VALU/transcendental latency at low occupancy.
+#define KLOOP _Pragma("unroll") for (int kp = 0; kp < K; ++kp)
 
-__device__ __forceinline__ float sdf_eval(code_ptr code, P3 p, float* __restrict__ lds /* already offset by tid */,
-                                          const uint32_t nthreads) {
+template <int K>
+__device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)[K],
+                                         float* __restrict__ lds /* already offset by tid */, const uint32_t nthreads) {
   using namespace dm;
-  float R = 0.0f;
+  KLOOP Rv[kp] = 0.0f;
   uint32_t pc = 0;
 #define PF(k) __uint_as_float(code[pc + 1 + (k)])
 #define PU(k) (code[pc + 1 + (k)])
@@ -37,456 +43,619 @@ __device__ __forceinline__ float sdf_eval(code_ptr code, P3 p, float* __restrict
     const uint32_t slot = w >> 16;
     switch (op) {
       case D_END:
-        return R;
+        return;
       // ------------------------------------------------ 3D primitives
       case D_SPHERE: {
-        R = norm3(p.x, p.y, p.z) - PF(0);
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          R = norm3(p.x, p.y, p.z) - PF(0);
+        }
         pc += 2;
         break;
       }
       case D_BOX: {
-        const float r = PF(3);
-        float qx = (absf(p.x) - PF(0)) + r, qy = (absf(p.y) - PF(1)) + r, qz = (absf(p.z) - PF(2)) + r;
-        R = norm3(maxf(qx, 0.f), maxf(qy, 0.f), maxf(qz, 0.f)) + minf(maxf(qx, maxf(qy, qz)), 0.0f) - r;
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float r = PF(3);
+          float qx = (absf(p.x) - PF(0)) + r, qy = (absf(p.y) - PF(1)) + r, qz = (absf(p.z) - PF(2)) + r;
+          R = norm3(maxf(qx, 0.f), maxf(qy, 0.f), maxf(qz, 0.f)) + minf(maxf(qx, maxf(qy, qz)), 0.0f) - r;
+        }
         pc += 5;
         break;
       }
       case D_BOXFRAME: {
-        const float e = PF(0);
-        float px = absf(p.x) - PF(1), py = absf(p.y) - PF(2), pz = absf(p.z) - PF(3);
-        float qx = absf(px + e) + (-e), qy = absf(py + e) + (-e), qz = absf(pz + e) + (-e);
-        float s1 = minf(0.f, maxf(px, maxf(qy, qz)));
-        float n1 = norm3(maxf(px, 0.f), maxf(qy, 0.f), maxf(qz, 0.f)) + s1;
-        float s2 = minf(0.f, maxf(qx, maxf(py, qz)));
-        float n2 = norm3(maxf(qx, 0.f), maxf(py, 0.f), maxf(qz, 0.f)) + s2;
-        float s3 = minf(0.f, maxf(qx, maxf(qy, pz)));
-        float n3 = norm3(maxf(qx, 0.f), maxf(qy, 0.f), maxf(pz, 0.f)) + s3;
-        R = minf(n1, minf(n2, n3));
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float e = PF(0);
+          float px = absf(p.x) - PF(1), py = absf(p.y) - PF(2), pz = absf(p.z) - PF(3);
+          float qx = absf(px + e) + (-e), qy = absf(py + e) + (-e), qz = absf(pz + e) + (-e);
+          float s1 = minf(0.f, maxf(px, maxf(qy, qz)));
+          float n1 = norm3(maxf(px, 0.f), maxf(qy, 0.f), maxf(qz, 0.f)) + s1;
+          float s2 = minf(0.f, maxf(qx, maxf(py, qz)));
+          float n2 = norm3(maxf(qx, 0.f), maxf(py, 0.f), maxf(qz, 0.f)) + s2;
+          float s3 = minf(0.f, maxf(qx, maxf(qy, pz)));
+          float n3 = norm3(maxf(qx, 0.f), maxf(qy, 0.f), maxf(pz, 0.f)) + s3;
+          R = minf(n1, minf(n2, n3));
+        }
         pc += 5;
         break;
       }
       case D_TORUS: {
-        float qx = hypotf_(p.x, p.y) - PF(0);
-        R = norm2(qx, p.z) - PF(1);
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          float qx = hypotf_(p.x, p.y) - PF(0);
+          R = norm2(qx, p.z) - PF(1);
+        }
         pc += 3;
         break;
       }
       case D_CYL0: {
-        float dx = hypotf_(p.x, p.y) - PF(0);
-        float dy = absf(p.z) - PF(1);
-        R = minf(0.f, maxf(dx, dy)) + hypotf_(maxf(0.f, dx), maxf(0.f, dy));
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          float dx = hypotf_(p.x, p.y) - PF(0);
+          float dy = absf(p.z) - PF(1);
+          R = minf(0.f, maxf(dx, dy)) + hypotf_(maxf(0.f, dx), maxf(0.f, dy));
+        }
         pc += 3;
         break;
       }
       case D_CYLR: {
-        const float round = PF(2);
-        float dx = hypotf_(p.x, p.y) - PF(0) + round;
-        float dy = absf(p.z) - PF(1);
-        R = minf(maxf(dx, dy), 0.f) + hypotf_(maxf(dx, 0.f), maxf(dy, 0.f)) - round;
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float round = PF(2);
+          float dx = hypotf_(p.x, p.y) - PF(0) + round;
+          float dy = absf(p.z) - PF(1);
+          R = minf(maxf(dx, dy), 0.f) + hypotf_(maxf(dx, 0.f), maxf(dy, 0.f)) - round;
+        }
         pc += 4;
         break;
       }
       case D_HEX: {
-        const float k1 = -0.8660254037844386f, k2 = 0.5f, twok1 = -1.7320508075688772f;
-        const float h1 = PF(0), h2 = PF(1), clm = PF(2);
-        float px = absf(p.x), py = absf(p.y), pz = absf(p.z);
-        float pm = minf(k1 * px + k2 * py, 0.f);
-        px -= twok1 * pm;
-        py -= 1.0f * pm;
-        float d1 = hypotf_(px - clampf(px, -clm, clm), py - h1) * signf(py - h1);
-        float d2 = pz - h2;
-        R = minf(maxf(d1, d2), 0.f) + hypotf_(maxf(d1, 0.f), maxf(d2, 0.f));
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float k1 = -0.8660254037844386f, k2 = 0.5f, twok1 = -1.7320508075688772f;
+          const float h1 = PF(0), h2 = PF(1), clm = PF(2);
+          float px = absf(p.x), py = absf(p.y), pz = absf(p.z);
+          float pm = minf(k1 * px + k2 * py, 0.f);
+          px -= twok1 * pm;
+          py -= 1.0f * pm;
+          float d1 = hypotf_(px - clampf(px, -clm, clm), py - h1) * signf(py - h1);
+          float d2 = pz - h2;
+          R = minf(maxf(d1, d2), 0.f) + hypotf_(maxf(d1, 0.f), maxf(d2, 0.f));
+        }
         pc += 4;
         break;
       }
       // ------------------------------------------------ 2D primitives
       case D_LINE2D: {
-        const float bax = PF(2), bay = PF(3);
-        float pax = p.x - PF(0), pay = p.y - PF(1);
-        float h = clampf((pax * bax + pay * bay) / PF(4), 0.f, 1.f);
-        R = norm2(pax - h * bax, pay - h * bay) - PF(5);
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float bax = PF(2), bay = PF(3);
+          float pax = p.x - PF(0), pay = p.y - PF(1);
+          float h = clampf((pax * bax + pay * bay) / PF(4), 0.f, 1.f);
+          R = norm2(pax - h * bax, pay - h * bay) - PF(5);
+        }
         pc += 7;
         break;
       }
       case D_ARC2D: {
-        const float r = PF(0), t = PF(1), s = PF(2), c = PF(3);
-        float px = absf(p.x), py = p.y;
-        float a = norm2(px - PF(4), py - PF(5)) - t;
-        float b = absf(norm2(px, py) - r) - t;
-        R = (c * px > s * py) ? a : b;
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float r = PF(0), t = PF(1), s = PF(2), c = PF(3);
+          float px = absf(p.x), py = p.y;
+          float a = norm2(px - PF(4), py - PF(5)) - t;
+          float b = absf(norm2(px, py) - r) - t;
+          R = (c * px > s * py) ? a : b;
+        }
         pc += 7;
         break;
       }
       case D_QUADBEZIER2D: {
-        const float Ax = PF(0), Ay = PF(1), ax = PF(2), ay = PF(3), a2 = PF(4), bx = PF(5), by = PF(6), cx = PF(7),
-                    cy = PF(8), kk = PF(9), kx = PF(10), kx2 = PF(11), thick = PF(12);
-        float dx = Ax - p.x, dy = Ay - p.y;
-        float ky = kk * (2.f * a2 + (dx * bx + dy * by)) / 3.f;
-        float kz = kk * (dx * ax + dy * ay);
-        float g = ky - kx2;
-        float q = kx * (2.f * kx2 - 3.f * ky) + kz;
-        float g3 = g * g * g;
-        float q2 = q * q;
-        float h = q2 + 4.f * g3;
-        float res;
-        if (h >= 0.f) {
-          h = sqrtf_(h);
-          float xx = 0.5f * (h + -q), xy = 0.5f * (-h + -q);
-          if (absf(g) < 0.001f) {
-            float k = (1.0f - g3 / q2) * g3 / q;
-            xx = k;
-            xy = -k - q;
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float Ax = PF(0), Ay = PF(1), ax = PF(2), ay = PF(3), a2 = PF(4), bx = PF(5), by = PF(6), cx = PF(7),
+                      cy = PF(8), kk = PF(9), kx = PF(10), kx2 = PF(11), thick = PF(12);
+          float dx = Ax - p.x, dy = Ay - p.y;
+          float ky = kk * (2.f * a2 + (dx * bx + dy * by)) / 3.f;
+          float kz = kk * (dx * ax + dy * ay);
+          float g = ky - kx2;
+          float q = kx * (2.f * kx2 - 3.f * ky) + kz;
+          float g3 = g * g * g;
+          float q2 = q * q;
+          float h = q2 + 4.f * g3;
+          float res;
+          if (h >= 0.f) {
+            h = sqrtf_(h);
+            float xx = 0.5f * (h + -q), xy = 0.5f * (-h + -q);
+            if (absf(g) < 0.001f) {
+              float k = (1.0f - g3 / q2) * g3 / q;
+              xx = k;
+              xy = -k - q;
+            }
+            float uvx = signf(xx) * pow13f_(absf(xx)), uvy = signf(xy) * pow13f_(absf(xy));
+            float t = uvx + uvy;
+            t -= (t * (t * t + 3.0f * g) + q) / (3.0f * t * t + 3.0f * g);
+            t = clampf(t - kx, 0.f, 1.f);
+            float wx = dx + t * (cx + t * bx), wy = dy + t * (cy + t * by);
+            res = wx * wx + wy * wy;
+          } else {
+            float z = sqrtf_(-g);
+            float v = q / (2.f * g * z);
+            v = sqrtf_(0.5f + 0.5f * v);
+            float m = v * (v * (v * (v * -0.008972f + 0.039071f) - 0.107074f) + 0.576975f) + 0.5f;
+            float nn = sqrtf_(1.f - m * m);
+            nn *= 1.7320508075688772f;
+            float tx = clampf((m + m) * z - kx, 0.f, 1.f);
+            float ty = clampf((-nn - m) * z - kx, 0.f, 1.f);
+            float qxx = dx + tx * (cx + tx * bx), qxy = dy + tx * (cy + tx * by);
+            float qyx = dx + ty * (cx + ty * bx), qyy = dy + ty * (cy + ty * by);
+            float ddx = qxx * qxx + qxy * qxy, ddy = qyx * qyx + qyy * qyy;
+            res = ddx < ddy ? ddx : ddy;
           }
-          float uvx = signf(xx) * pow13f_(absf(xx)), uvy = signf(xy) * pow13f_(absf(xy));
-          float t = uvx + uvy;
-          t -= (t * (t * t + 3.0f * g) + q) / (3.0f * t * t + 3.0f * g);
-          t = clampf(t - kx, 0.f, 1.f);
-          float wx = dx + t * (cx + t * bx), wy = dy + t * (cy + t * by);
-          res = wx * wx + wy * wy;
-        } else {
-          float z = sqrtf_(-g);
-          float v = q / (2.f * g * z);
-          v = sqrtf_(0.5f + 0.5f * v);
-          float m = v * (v * (v * (v * -0.008972f + 0.039071f) - 0.107074f) + 0.576975f) + 0.5f;
-          float nn = sqrtf_(1.f - m * m);
-          nn *= 1.7320508075688772f;
-          float tx = clampf((m + m) * z - kx, 0.f, 1.f);
-          float ty = clampf((-nn - m) * z - kx, 0.f, 1.f);
-          float qxx = dx + tx * (cx + tx * bx), qxy = dy + tx * (cy + tx * by);
-          float qyx = dx + ty * (cx + ty * bx), qyy = dy + ty * (cy + ty * by);
-          float ddx = qxx * qxx + qxy * qxy, ddy = qyx * qyx + qyy * qyy;
-          res = ddx < ddy ? ddx : ddy;
+          R = sqrtf_(res) - thick;
         }
-        R = sqrtf_(res) - thick;
         pc += 14;
         break;
       }
       case D_CIRCLE2D: {
-        R = norm2(p.x, p.y) - PF(0);
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          R = norm2(p.x, p.y) - PF(0);
+        }
         pc += 2;
         break;
       }
       case D_EQTRI2D: {
-        const float k = 1.7320508075688772f;
-        const float r = PF(0);
-        float px = absf(p.x) - r, py = p.y + PF(1);
-        if (px + k * py > 0.f) {
-          float tx = px - k * py, ty = -k * px - py;
-          px = 0.5f * tx;
-          py = 0.5f * ty;
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float k = 1.7320508075688772f;
+          const float r = PF(0);
+          float px = absf(p.x) - r, py = p.y + PF(1);
+          if (px + k * py > 0.f) {
+            float tx = px - k * py, ty = -k * px - py;
+            px = 0.5f * tx;
+            py = 0.5f * ty;
+          }
+          px -= clampf(px, -2.f * r, 0.f);
+          R = -norm2(px, py) * signf(py);
         }
-        px -= clampf(px, -2.f * r, 0.f);
-        R = -norm2(px, py) * signf(py);
         pc += 3;
         break;
       }
       case D_RECT2D: {
-        float dx = absf(p.x) - PF(0), dy = absf(p.y) - PF(1);
-        R = norm2(maxf(dx, 0.f), maxf(dy, 0.f)) + minf(0.f, maxf(dx, dy));
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          float dx = absf(p.x) - PF(0), dy = absf(p.y) - PF(1);
+          R = norm2(maxf(dx, 0.f), maxf(dy, 0.f)) + minf(0.f, maxf(dx, dy));
+        }
         pc += 3;
         break;
       }
       case D_DIAMOND2D: {
-        const float bx = PF(0), by = PF(1);
-        float px = absf(p.x), py = absf(p.y);
-        float tx = bx - 2.f * px, ty = by - 2.f * py;
-        float h = clampf((tx * bx - ty * by) / PF(2), -1.f, 1.f);
-        float d = norm2(px - PF(3) * (1.f - h), py - PF(4) * (1.f + h));
-        R = d * signf(px * by + py * bx - PF(5));
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float bx = PF(0), by = PF(1);
+          float px = absf(p.x), py = absf(p.y);
+          float tx = bx - 2.f * px, ty = by - 2.f * py;
+          float h = clampf((tx * bx - ty * by) / PF(2), -1.f, 1.f);
+          float d = norm2(px - PF(3) * (1.f - h), py - PF(4) * (1.f + h));
+          R = d * signf(px * by + py * bx - PF(5));
+        }
         pc += 7;
         break;
       }
       case D_X2D: {
-        float px = absf(p.x), py = absf(p.y);
-        float sub = 0.5f * minf(px + py, PF(0));
-        R = norm2(px - sub, py - sub) - PF(1);
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          float px = absf(p.x), py = absf(p.y);
+          float sub = 0.5f * minf(px + py, PF(0));
+          R = norm2(px - sub, py - sub) - PF(1);
+        }
         pc += 3;
         break;
       }
       case D_HEX2D: {
-        const float kx = -0.8660254037844386f, ky = 0.5f;
-        const float r = PF(0), kzr = PF(1);
-        float px = absf(p.x), py = absf(p.y);
-        float f = 2.f * minf(kx * px + ky * py, 0.f);
-        px = px - f * kx;
-        py = py - f * ky;
-        px = px - clampf(px, -kzr, kzr);
-        py = py - r;
-        R = signf(py) * norm2(px, py);
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float kx = -0.8660254037844386f, ky = 0.5f;
+          const float r = PF(0), kzr = PF(1);
+          float px = absf(p.x), py = absf(p.y);
+          float f = 2.f * minf(kx * px + ky * py, 0.f);
+          px = px - f * kx;
+          py = py - f * ky;
+          px = px - clampf(px, -kzr, kzr);
+          py = py - r;
+          R = signf(py) * norm2(px, py);
+        }
         pc += 3;
         break;
       }
       case D_OCT2D: {
-        const float kx = -0.9238795325f, ky = 0.3826834323f;
-        const float r = PF(0), kzr = PF(1);
-        float px = absf(p.x), py = absf(p.y);
-        float f1 = 2.f * minf(kx * px + ky * py, 0.f);
-        px = px - f1 * kx;
-        py = py - f1 * ky;
-        float f2 = 2.f * minf((-kx) * px + ky * py, 0.f);
-        px = px - f2 * (-kx);
-        py = py - f2 * ky;
-        px = px - clampf(px, -kzr, kzr);
-        py = py - r;
-        R = signf(py) * norm2(px, py);
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float kx = -0.9238795325f, ky = 0.3826834323f;
+          const float r = PF(0), kzr = PF(1);
+          float px = absf(p.x), py = absf(p.y);
+          float f1 = 2.f * minf(kx * px + ky * py, 0.f);
+          px = px - f1 * kx;
+          py = py - f1 * ky;
+          float f2 = 2.f * minf((-kx) * px + ky * py, 0.f);
+          px = px - f2 * (-kx);
+          py = py - f2 * ky;
+          px = px - clampf(px, -kzr, kzr);
+          py = py - r;
+          R = signf(py) * norm2(px, py);
+        }
         pc += 3;
         break;
       }
       case D_ELLIPSE2D: {
-        float a = PF(0), b = PF(1);
-        float px = absf(p.x), py = absf(p.y);
-        if (px > py) { float t = px; px = py; py = t; t = a; a = b; b = t; }
-        float l = b * b - a * a;
-        float m = a * px / l;
-        float m2 = m * m;
-        float nn = b * py / l;
-        float n2 = nn * nn;
-        float c = (m2 + n2 - 1.f) / 3.f;
-        float c3 = c * c * c;
-        float q = c3 + 2.f * m2 * n2;
-        float d = c3 + m2 * n2;
-        float g = m + m * n2;
-        float co;
-        if (d < 0.f) {
-          float h = acosf_(q / c3) / 3.f;
-          float sh, ch;
-          sincosf_(h, sh, ch);
-          float t = 1.7320508075688772f * sh;
-          float rx = sqrtf_(-c * (ch + t + 2.f) + m2);
-          float ry = sqrtf_(-c * (ch - t + 2.f) + m2);
-          co = (ry + signf(l) * rx + absf(g) / (rx * ry) - m) / 2.f;
-        } else {
-          float h = 2.f * m * nn * sqrtf_(d);
-          float sv = signf(q + h) * cbrtf_(absf(q + h));
-          float u = signf(q - h) * cbrtf_(absf(q - h));
-          float rx = -sv - u - 4.f * c + 2.f * m2;
-          float ry = 1.7320508075688772f * (sv - u);
-          float rm = hypotf_(rx, ry);
-          co = (ry / sqrtf_(rm - rx) + 2.f * g / rm - m) / 2.f;
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          float a = PF(0), b = PF(1);
+          float px = absf(p.x), py = absf(p.y);
+          if (px > py) { float t = px; px = py; py = t; t = a; a = b; b = t; }
+          float l = b * b - a * a;
+          float m = a * px / l;
+          float m2 = m * m;
+          float nn = b * py / l;
+          float n2 = nn * nn;
+          float c = (m2 + n2 - 1.f) / 3.f;
+          float c3 = c * c * c;
+          float q = c3 + 2.f * m2 * n2;
+          float d = c3 + m2 * n2;
+          float g = m + m * n2;
+          float co;
+          if (d < 0.f) {
+            float h = acosf_(q / c3) / 3.f;
+            float sh, ch;
+            sincosf_(h, sh, ch);
+            float t = 1.7320508075688772f * sh;
+            float rx = sqrtf_(-c * (ch + t + 2.f) + m2);
+            float ry = sqrtf_(-c * (ch - t + 2.f) + m2);
+            co = (ry + signf(l) * rx + absf(g) / (rx * ry) - m) / 2.f;
+          } else {
+            float h = 2.f * m * nn * sqrtf_(d);
+            float sv = signf(q + h) * cbrtf_(absf(q + h));
+            float u = signf(q - h) * cbrtf_(absf(q - h));
+            float rx = -sv - u - 4.f * c + 2.f * m2;
+            float ry = 1.7320508075688772f * (sv - u);
+            float rm = hypotf_(rx, ry);
+            co = (ry / sqrtf_(rm - rx) + 2.f * g / rm - m) / 2.f;
+          }
+          float rx2 = a * co, ry2 = b * sqrtf_(1.f - co * co);
+          R = norm2(rx2 - px, ry2 - py) * signf(py - ry2);
         }
-        float rx2 = a * co, ry2 = b * sqrtf_(1.f - co * co);
-        R = norm2(rx2 - px, ry2 - py) * signf(py - ry2);
         pc += 3;
         break;
       }
       case D_POLY2D: {
+        // vertex-major: each edge's six scalars are fetched once and applied to the K points.
         const uint32_t nv = PU(0);
-        float wx0 = p.x - PF(1), wy0 = p.y - PF(2);
-        float d = wx0 * wx0 + wy0 * wy0;
-        bool neg = false;
+        const float v0x = PF(1), v0y = PF(2);
+        float d[K];
+        bool neg[K];
+        KLOOP {
+          float wx0 = pv[kp].x - v0x, wy0 = pv[kp].y - v0y;
+          d[kp] = wx0 * wx0 + wy0 * wy0;
+          neg[kp] = false;
+        }
         uint32_t q = pc + 4;
         for (uint32_t iv = 0; iv < nv; iv++, q += 6) {
           const float v1x = __uint_as_float(code[q]), v1y = __uint_as_float(code[q + 1]), ex = __uint_as_float(code[q + 2]),
                       ey = __uint_as_float(code[q + 3]), n2e = __uint_as_float(code[q + 4]), v2y = __uint_as_float(code[q + 5]);
-          float wx = p.x - v1x, wy = p.y - v1y;
-          float t = clampf((wx * ex + wy * ey) / n2e, 0.f, 1.f);
-          float bx = wx - t * ex, by = wy - t * ey;
-          d = minf(d, bx * bx + by * by);
-          bool b1 = p.y >= v1y, b2 = p.y < v2y, b3 = ex * wy > ey * wx;
-          bool flip = (b1 && b2 && b3) || (!b1 && !b2 && !b3);
-          neg = neg != flip;
+          KLOOP {
+            const float px = pv[kp].x, py = pv[kp].y;
+            float wx = px - v1x, wy = py - v1y;
+            float t = clampf((wx * ex + wy * ey) / n2e, 0.f, 1.f);
+            float bx = wx - t * ex, by = wy - t * ey;
+            d[kp] = minf(d[kp], bx * bx + by * by);
+            bool b1 = py >= v1y, b2 = py < v2y, b3 = ex * wy > ey * wx;
+            bool flip = (b1 && b2 && b3) || (!b1 && !b2 && !b3);
+            neg[kp] = neg[kp] != flip;
+          }
         }
-        float sd = sqrtf_(d);
-        R = neg ? -sd : sd;  // s * sqrt(d), s = +-1
+        KLOOP {
+          float sd = sqrtf_(d[kp]);
+          Rv[kp] = neg[kp] ? -sd : sd;  // s * sqrt(d), s = +-1
+        }
         pc = q;
         break;
       }
       case D_LINES2D: {
         const uint32_t ns = PU(0);
         const float w2 = PF(1);
-        float d = 1e23f;
+        float d[K];
+        KLOOP d[kp] = 1e23f;
         uint32_t q = pc + 3;
-        for (uint32_t k = 0; k < ns; k++, q += 5) {
+        for (uint32_t sg = 0; sg < ns; sg++, q += 5) {
           const float ax = __uint_as_float(code[q]), ay = __uint_as_float(code[q + 1]), bax = __uint_as_float(code[q + 2]),
                       bay = __uint_as_float(code[q + 3]), dotba = __uint_as_float(code[q + 4]);
-          float pax = p.x - ax, pay = p.y - ay;
-          float h = clampf((pax * bax + pay * bay) / dotba, 0.f, 1.f);
-          float rx = pax - h * bax, ry = pay - h * bay;
-          d = minf(d, rx * rx + ry * ry);
+          KLOOP {
+            float pax = pv[kp].x - ax, pay = pv[kp].y - ay;
+            float h = clampf((pax * bax + pay * bay) / dotba, 0.f, 1.f);
+            float rx = pax - h * bax, ry = pay - h * bay;
+            d[kp] = minf(d[kp], rx * rx + ry * ry);
+          }
         }
-        R = sqrtf_(d) - w2;
+        KLOOP Rv[kp] = sqrtf_(d[kp]) - w2;
         pc = q;
         break;
       }
       // ------------------------------------------------ position pre-ops
       case D_TRANSLATE: {
-        p.x = p.x - PF(0); p.y = p.y - PF(1); p.z = p.z - PF(2);
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          p.x = p.x - PF(0); p.y = p.y - PF(1); p.z = p.z - PF(2);
+        }
         pc += 4;
         break;
       }
       case D_SCALE_PRE: {
-        const float f = PF(0);
-        p.x = f * p.x; p.y = f * p.y; p.z = f * p.z;
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float f = PF(0);
+          p.x = f * p.x; p.y = f * p.y; p.z = f * p.z;
+        }
         pc += 2;
         break;
       }
       case D_SYMMETRY: {
-        const uint32_t bits = PU(0);
-        if (bits & 1u) p.x = absf(p.x);
-        if (bits & 2u) p.y = absf(p.y);
-        if (bits & 4u) p.z = absf(p.z);
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const uint32_t bits = PU(0);
+          if (bits & 1u) p.x = absf(p.x);
+          if (bits & 2u) p.y = absf(p.y);
+          if (bits & 4u) p.z = absf(p.z);
+        }
         pc += 2;
         break;
       }
       case D_TRANSFORM: {
-        float x = PF(0) * p.x + PF(1) * p.y + PF(2) * p.z + PF(3);
-        float y = PF(4) * p.x + PF(5) * p.y + PF(6) * p.z + PF(7);
-        float z = PF(8) * p.x + PF(9) * p.y + PF(10) * p.z + PF(11);
-        p.x = x; p.y = y; p.z = z;
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          float x = PF(0) * p.x + PF(1) * p.y + PF(2) * p.z + PF(3);
+          float y = PF(4) * p.x + PF(5) * p.y + PF(6) * p.z + PF(7);
+          float z = PF(8) * p.x + PF(9) * p.y + PF(10) * p.z + PF(11);
+          p.x = x; p.y = y; p.z = z;
+        }
         pc += 13;
         break;
       }
       case D_TWIST: {
-        const float k = PF(0);
-        float c = cosf_(k * p.z), s = sinf_(k * p.z);
-        float x = c * p.x - s * p.y, y = s * p.x + c * p.y;
-        p.x = x; p.y = y;
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float k = PF(0);
+          float c = cosf_(k * p.z), s = sinf_(k * p.z);
+          float x = c * p.x - s * p.y, y = s * p.x + c * p.y;
+          p.x = x; p.y = y;
+        }
         pc += 2;
         break;
       }
       case D_ROT2D: {
-        float x = PF(0) * p.x + PF(1) * p.y, y = PF(2) * p.x + PF(3) * p.y;
-        p.x = x; p.y = y;
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          float x = PF(0) * p.x + PF(1) * p.y, y = PF(2) * p.x + PF(3) * p.y;
+          p.x = x; p.y = y;
+        }
         pc += 5;
         break;
       }
       case D_EXTRUDE_PRE: {
-        LDSF(slot) = absf(p.z) - PF(0);
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          LDSF(slot) = absf(p.z) - PF(0);
+        }
         pc += 2;
         break;
       }
       case D_REVOLVE_PRE: {
-        float x = hypotf_(p.x, p.z) - PF(0);
-        p.x = x;  // p.y stays
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          float x = hypotf_(p.x, p.z) - PF(0);
+          p.x = x;  // p.y stays
+        }
         pc += 2;
         break;
       }
       case D_SCREW_PRE: {
-        const float pitch = PF(0), lead = PF(1), L = PF(2), tanTaper = PF(3), halfp = PF(4);
-        float y0 = hypotf_(p.x, p.y);
-        y0 += p.z * tanTaper;
-        float theta = atan2f_(p.y, p.x);
-        float z = p.z + lead * theta / 6.2831853071795862f;
-        float x = z + halfp;
-        float t = x / pitch;
-        float x0 = pitch * (t - floorf_(t)) - halfp;
-        LDSF(slot) = absf(p.z) - L;
-        p.x = x0; p.y = y0;
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float pitch = PF(0), lead = PF(1), L = PF(2), tanTaper = PF(3), halfp = PF(4);
+          float y0 = hypotf_(p.x, p.y);
+          y0 += p.z * tanTaper;
+          float theta = atan2f_(p.y, p.x);
+          float z = p.z + lead * theta / 6.2831853071795862f;
+          float x = z + halfp;
+          float t = x / pitch;
+          float x0 = pitch * (t - floorf_(t)) - halfp;
+          LDSF(slot) = absf(p.z) - L;
+          p.x = x0; p.y = y0;
+        }
         pc += 6;
         break;
       }
       case D_ELONGATE_PRE: {
-        float qx = absf(p.x) - PF(0), qy = absf(p.y) - PF(1), qz = absf(p.z) - PF(2);
-        LDSF(slot) = minf(maxf(qx, maxf(qy, qz)), 0.f);
-        p.x = maxf(qx, 0.f); p.y = maxf(qy, 0.f); p.z = maxf(qz, 0.f);
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          float qx = absf(p.x) - PF(0), qy = absf(p.y) - PF(1), qz = absf(p.z) - PF(2);
+          LDSF(slot) = minf(maxf(qx, maxf(qy, qz)), 0.f);
+          p.x = maxf(qx, 0.f); p.y = maxf(qy, 0.f); p.z = maxf(qz, 0.f);
+        }
         pc += 4;
         break;
       }
       case D_ELONGATE2D_PRE: {
-        float qx = absf(p.x) - PF(0), qy = absf(p.y) - PF(1);
-        LDSF(slot) = minf(maxf(qx, qy), 0.f);
-        p.x = maxf(qx, 0.f); p.y = maxf(qy, 0.f);
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          float qx = absf(p.x) - PF(0), qy = absf(p.y) - PF(1);
+          LDSF(slot) = minf(maxf(qx, qy), 0.f);
+          p.x = maxf(qx, 0.f); p.y = maxf(qy, 0.f);
+        }
         pc += 3;
         break;
       }
       case D_ARRAY_PRE: {
-        float ox = LDSF(slot), oy = LDSF(slot + 1), oz = LDSF(slot + 2);
-        const float sx = PF(3), sy = PF(4), sz = PF(5);
-        float idx = roundf_(ox / sx), idy = roundf_(oy / sy), idz = roundf_(oz / sz);
-        float o_x = signf(ox - sx * idx), o_y = signf(oy - sy * idy), o_z = signf(oz - sz * idz);
-        float rx = clampf(idx + PF(0) * o_x, 0.f, PF(6));
-        float ry = clampf(idy + PF(1) * o_y, 0.f, PF(7));
-        float rz = clampf(idz + PF(2) * o_z, 0.f, PF(8));
-        p.x = ox - sx * rx; p.y = oy - sy * ry; p.z = oz - sz * rz;
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          float ox = LDSF(slot), oy = LDSF(slot + 1), oz = LDSF(slot + 2);
+          const float sx = PF(3), sy = PF(4), sz = PF(5);
+          float idx = roundf_(ox / sx), idy = roundf_(oy / sy), idz = roundf_(oz / sz);
+          float o_x = signf(ox - sx * idx), o_y = signf(oy - sy * idy), o_z = signf(oz - sz * idz);
+          float rx = clampf(idx + PF(0) * o_x, 0.f, PF(6));
+          float ry = clampf(idy + PF(1) * o_y, 0.f, PF(7));
+          float rz = clampf(idz + PF(2) * o_z, 0.f, PF(8));
+          p.x = ox - sx * rx; p.y = oy - sy * ry; p.z = oz - sz * rz;
+        }
         pc += 10;
         break;
       }
       case D_ARRAY2D_PRE: {
-        float ox = LDSF(slot), oy = LDSF(slot + 1);
-        const float sx = PF(2), sy = PF(3);
-        float idx = roundf_(ox / sx), idy = roundf_(oy / sy);
-        float o_x = signf(ox - sx * idx), o_y = signf(oy - sy * idy);
-        float rx = clampf(idx + PF(0) * o_x, 0.f, PF(4));
-        float ry = clampf(idy + PF(1) * o_y, 0.f, PF(5));
-        p.x = ox - sx * rx; p.y = oy - sy * ry;
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          float ox = LDSF(slot), oy = LDSF(slot + 1);
+          const float sx = PF(2), sy = PF(3);
+          float idx = roundf_(ox / sx), idy = roundf_(oy / sy);
+          float o_x = signf(ox - sx * idx), o_y = signf(oy - sy * idy);
+          float rx = clampf(idx + PF(0) * o_x, 0.f, PF(4));
+          float ry = clampf(idy + PF(1) * o_y, 0.f, PF(5));
+          p.x = ox - sx * rx; p.y = oy - sy * ry;
+        }
         pc += 7;
         break;
       }
       case D_CIRC_PRE: {
-        const float angle = PF(0), ncirc = PF(1), ninsm1 = PF(2);
-        float pangle = atan2f_(p.y, p.x);
-        float id = floorf_(pangle / angle);
-        if (id < 0.f) id += ncirc;
-        float i0, i1;
-        if (id >= ninsm1) { i0 = ninsm1; i1 = 0.f; } else { i0 = id; i1 = id + 1.f; }
-        float s0, c0, s1, c1;
-        sincosf_(angle * i0, s0, c0);
-        sincosf_(angle * i1, s1, c1);
-        LDSF(slot) = c0 * p.x + s0 * p.y;
-        LDSF(slot + 1) = (-s0) * p.x + c0 * p.y;
-        float x1 = c1 * p.x + s1 * p.y, y1 = (-s1) * p.x + c1 * p.y;
-        p.x = x1; p.y = y1;
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float angle = PF(0), ncirc = PF(1), ninsm1 = PF(2);
+          float pangle = atan2f_(p.y, p.x);
+          float id = floorf_(pangle / angle);
+          if (id < 0.f) id += ncirc;
+          float i0, i1;
+          if (id >= ninsm1) { i0 = ninsm1; i1 = 0.f; } else { i0 = id; i1 = id + 1.f; }
+          float s0, c0, s1, c1;
+          sincosf_(angle * i0, s0, c0);
+          sincosf_(angle * i1, s1, c1);
+          LDSF(slot) = c0 * p.x + s0 * p.y;
+          LDSF(slot + 1) = (-s0) * p.x + c0 * p.y;
+          float x1 = c1 * p.x + s1 * p.y, y1 = (-s1) * p.x + c1 * p.y;
+          p.x = x1; p.y = y1;
+        }
         pc += 4;
         break;
       }
       case D_LOADP2_SUB: {
-        p.x = LDSF(slot) - PF(0);
-        p.y = LDSF(slot + 1) - PF(1);
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          p.x = LDSF(slot) - PF(0);
+          p.y = LDSF(slot + 1) - PF(1);
+        }
         pc += 3;
         break;
       }
       // ------------------------------------------------ distance post-ops
-      case D_MULR: R = R * PF(0); pc += 2; break;
-      case D_SHELL_POST: { const float th = PF(0); R = th * (absf(R) - th); pc += 2; break; }
-      case D_ADDR: R = R + PF(0); pc += 2; break;
-      case D_ANNULUS: R = absf(R) - PF(0); pc += 2; break;
+      case D_MULR: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = R * PF(0); } pc += 2; break; }
+      case D_SHELL_POST: { const float th = PF(0); KLOOP { float& R = Rv[kp]; R = th * (absf(R) - th); } pc += 2; break; }
+      case D_ADDR: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = R + PF(0); } pc += 2; break; }
+      case D_ANNULUS: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = absf(R) - PF(0); } pc += 2; break; }
       case D_EXTRUDE_POST: {
-        float wy = LDSF(slot);
-        R = minf(0.f, maxf(R, wy)) + hypotf_(maxf(R, 0.f), maxf(wy, 0.f));
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          float wy = LDSF(slot);
+          R = minf(0.f, maxf(R, wy)) + hypotf_(maxf(R, 0.f), maxf(wy, 0.f));
+        }
         pc += 1;
         break;
       }
-      case D_MAXR_SLOT: R = maxf(R, LDSF(slot)); pc += 1; break;
-      case D_ADDR_SLOT: R = R + LDSF(slot); pc += 1; break;
+      case D_MAXR_SLOT: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = maxf(R, LDSF(slot)); } pc += 1; break; }
+      case D_ADDR_SLOT: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = R + LDSF(slot); } pc += 1; break; }
       // ------------------------------------------------ scratch
-      case D_SAVEP3: LDSF(slot) = p.x; LDSF(slot + 1) = p.y; LDSF(slot + 2) = p.z; pc += 1; break;
-      case D_LOADP3: p.x = LDSF(slot); p.y = LDSF(slot + 1); p.z = LDSF(slot + 2); pc += 1; break;
-      case D_SAVEP2: LDSF(slot) = p.x; LDSF(slot + 1) = p.y; pc += 1; break;
-      case D_LOADP2: p.x = LDSF(slot); p.y = LDSF(slot + 1); pc += 1; break;
-      case D_SAVER: LDSF(slot) = R; pc += 1; break;
-      case D_SETSLOT: LDSF(slot) = PF(0); pc += 2; break;
-      case D_SETR: R = PF(0); pc += 2; break;
+      case D_SAVEP3: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; LDSF(slot) = p.x; LDSF(slot + 1) = p.y; LDSF(slot + 2) = p.z; } pc += 1; break; }
+      case D_LOADP3: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; p.x = LDSF(slot); p.y = LDSF(slot + 1); p.z = LDSF(slot + 2); } pc += 1; break; }
+      case D_SAVEP2: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; LDSF(slot) = p.x; LDSF(slot + 1) = p.y; } pc += 1; break; }
+      case D_LOADP2: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; p.x = LDSF(slot); p.y = LDSF(slot + 1); } pc += 1; break; }
+      case D_SAVER: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; LDSF(slot) = R; } pc += 1; break; }
+      case D_SETSLOT: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; LDSF(slot) = PF(0); } pc += 2; break; }
+      case D_SETR: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = PF(0); } pc += 2; break; }
       // ------------------------------------------------ combine (a = saved first operand, b = R)
-      case D_COMBINE_MIN: R = minf(LDSF(slot), R); pc += 1; break;
-      case D_COMBINE_MAX: R = maxf(LDSF(slot), R); pc += 1; break;
-      case D_COMBINE_DIFF: R = maxf(LDSF(slot), -R); pc += 1; break;
-      case D_COMBINE_XOR: { float a = LDSF(slot), b = R; R = maxf(minf(a, b), -maxf(a, b)); pc += 1; break; }
+      case D_COMBINE_MIN: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = minf(LDSF(slot), R); } pc += 1; break; }
+      case D_COMBINE_MAX: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = maxf(LDSF(slot), R); } pc += 1; break; }
+      case D_COMBINE_DIFF: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = maxf(LDSF(slot), -R); } pc += 1; break; }
+      case D_COMBINE_XOR: { KLOOP { float& R = Rv[kp]; float a = LDSF(slot), b = R; R = maxf(minf(a, b), -maxf(a, b)); } pc += 1; break; }
       case D_COMBINE_SUNION: {
-        const float k = PF(0);
-        float a = LDSF(slot), b = R;
-        float h = clampf(0.5f + 0.5f * (b - a) / k, 0.f, 1.f);
-        R = mixf(b, a, h) - k * h * (1.f - h);
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float k = PF(0);
+          float a = LDSF(slot), b = R;
+          float h = clampf(0.5f + 0.5f * (b - a) / k, 0.f, 1.f);
+          R = mixf(b, a, h) - k * h * (1.f - h);
+        }
         pc += 2;
         break;
       }
       case D_COMBINE_SDIFF: {
-        const float k = PF(0);
-        float a = LDSF(slot), b = R;
-        float h = clampf(0.5f - 0.5f * (b + a) / k, 0.f, 1.f);
-        R = mixf(a, -b, h) + k * h * (1.f - h);
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float k = PF(0);
+          float a = LDSF(slot), b = R;
+          float h = clampf(0.5f - 0.5f * (b + a) / k, 0.f, 1.f);
+          R = mixf(a, -b, h) + k * h * (1.f - h);
+        }
         pc += 2;
         break;
       }
       case D_COMBINE_SINTER: {
-        const float k = PF(0);
-        float a = LDSF(slot), b = R;
-        float h = clampf(0.5f - 0.5f * (b - a) / k, 0.f, 1.f);
-        R = mixf(b, a, h) + k * h * (1.f - h);
+        KLOOP {
+          P3& p = pv[kp];
+          float& R = Rv[kp];
+          const float k = PF(0);
+          float a = LDSF(slot), b = R;
+          float h = clampf(0.5f - 0.5f * (b - a) / k, 0.f, 1.f);
+          R = mixf(b, a, h) + k * h * (1.f - h);
+        }
         pc += 2;
         break;
       }
       default:
-        return __builtin_nanf("");
+        KLOOP Rv[kp] = __builtin_nanf("");
+        return;
     }
   }
 #undef PF
@@ -494,5 +663,6 @@ __device__ __forceinline__ float sdf_eval(code_ptr code, P3 p, float* __restrict
 }
 
 #undef LDSF
+#undef KLOOP
 
 }  // namespace gsdf_dev

@@ -47,6 +47,7 @@ def lib():
         L.orc_march_cubes.restype = C.c_uint64
         L.orc_march_cubes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p]
         L.orc_normals_central_diff.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]
+        L.orc_math_apply.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.orc_mc_edge_table.restype = C.POINTER(C.c_uint16)
         L.orc_mc_tri_table.restype = C.POINTER(C.c_int8)
         _LIB = L
@@ -159,3 +160,16 @@ def mc_tables():
     e = np.ctypeslib.as_array(L.orc_mc_edge_table(), shape=(256,)).copy()
     t = np.ctypeslib.as_array(L.orc_mc_tri_table(), shape=(256, 16)).copy()
     return e, t
+
+
+MATH_FN = {"hypot": 0, "atan2": 1, "sin": 2, "cos": 3, "acos": 4, "cbrt": 5, "sincos_s": 6, "sincos_c": 7,
+           "min": 8, "max": 9, "pow13": 10, "round": 11, "floor": 12}
+
+
+def math_apply(name, x, y=None):
+    """Apply one of the oracle's math32 restatements elementwise (float32 in, float32 out)."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), np.float32)
+    out = np.empty_like(x)
+    lib().orc_math_apply(MATH_FN[name], x.ctypes.data, y.ctypes.data, out.ctypes.data, x.size)
+    return out

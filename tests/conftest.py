@@ -1,0 +1,30 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_libs():
+    """Build the native pieces once if a fresh checkout has none (CPU-only: hipcc cross-compiles)."""
+    need = [os.path.join(ROOT, "gsdf_amd", "host", "libgsdfhost.so"), os.path.join(ROOT, "gsdf_amd", "csrc", "libgsdfhip.so"),
+            os.path.join(ROOT, "oracle", "liborc.so")]
+    if not all(os.path.exists(p) for p in need):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "__graft_entry__.py")])
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    from gsdf_amd import hip
+    hip.init(0)  # raises loudly when no device / no library: GPU tests must never fall back
+    return hip

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz -- self-derived golden vectors.
+
+The reference is Go and cannot be built or imported in this container (no Go toolchain, external
+modules not vendored), and it ships no numeric golden files. These fixtures are
+therefore produced by the oracle (oracle/liborc.so), which itself is pinned against the reference's
+published known answers (tests/test_oracle_golden.py: 41072, 423,852, 6,711,685, res 0.21679485).
+They freeze those results so that both the oracle (CPU suite) and the HIP path (GPU suite) are
+checked against committed DATA: positions in, distances / triangle digests out.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import corpus  # noqa: E402
+from oracle.oracle import OracleSDF  # noqa: E402
+
+
+def tri_digest(tris):
+    t = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
+    t = t[np.lexsort(t.view(np.uint32).T[::-1])]
+    return hashlib.sha256(t.tobytes()).hexdigest()
+
+
+def main():
+    data = {}
+    for fn in (corpus.shapes3d, corpus.shapes2d):
+        _, shapes = fn()
+        for name, sh in shapes:
+            pos = corpus.sample_points(sh, n_grid=5, n_rand=160, seed=11)
+            d = OracleSDF(sh.tree()).Evaluate(pos)
+            data["pos_" + name] = pos
+            data["dist_" + name] = d
+    np.savez_compressed(os.path.join(HERE, "corpus_distances.npz"), **data)
+    # mesh digests (count + sha256 of the sorted triangle bytes)
+    meshes = {}
+    from gsdf_amd.builder import Builder
+    b = Builder()
+    cases = [("sphere_r1_res1_33", b.NewSphere(1.0), np.float32(1.0 / 33)),
+             ("npt_flange_resdiv100", b.Scene("npt-flange"), None), ("npt_flange_resdiv400", b.Scene("npt-flange"), None),
+             ("bolt_resdiv150", b.Scene("bolt"), None), ("knurled_cylinder_resdiv120", b.Scene("knurled-cylinder"), None)]
+    if "--full" in sys.argv:
+        cases.append(("npt_flange_resdiv1600", b.Scene("npt-flange"), None))
+    for name, sh, res in cases:
+        if res is None:
+            res = np.float32(float(sh.Diagonal()) / int(name.rsplit("resdiv", 1)[1]))
+        m = OracleSDF(sh.tree()).render_octree(res, 4096, True)
+        meshes[name] = {"res_bits": int(np.float32(res).view(np.uint32)), "res": float(res), "n_tris": m.n_tris,
+                        "levels": m.levels, "sha256_sorted": tri_digest(m.tris)}
+        print(name, meshes[name])
+    path = os.path.join(HERE, "mesh_digests.json")
+    old = {}
+    if os.path.exists(path):
+        old = json.load(open(path))
+    old.update(meshes)
+    json.dump(old, open(path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

