@@ -39,6 +39,20 @@ def cpu_baseline(shader, resdiv, threads):
             "triangles_per_s": m.n_tris / dt, "eval_only_evals_per_s": m.evals / m.t_eval_s}
 
 
+def pmc_traffic_gb():
+    """HBM bytes per leaf_kernel launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_pmc_summary.json: 2*FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE, KB -> GB)."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not fs:
+        return None
+    try:
+        d = json.load(open(fs[-1]))
+        return d["leaf_kernel"]["hbm_traffic_gb_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,7 +60,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--resdiv", type=int, default=1600)
     ap.add_argument("--scene", default="npt-flange")
-    ap.add_argument("--cpu-resdiv", type=int, default=800)
+    ap.add_argument("--cpu-resdiv", type=int, default=0, help="resdiv of the bounded CPU sample (0 = pick ~10-30 s of CPU work from the core count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -104,7 +118,7 @@ def main():
         evals += st.evals
         tris += st.n_tris
         march_ms += st.ms_march
-        march_evals += 7 * st.active_leaves
+        march_evals += st.evals_leaf
         march_tris += st.n_tris
         last = (oc, g)
     barrier()
@@ -121,7 +135,7 @@ def main():
     if rank == 0:
         oc, g = last
         st = oc.stats
-        # dominant kernel: leaf_march_kernel. ALGORITHMIC bytes per launch = 16 B per evaluation it performs
+        # dominant kernel: leaf_kernel. ALGORITHMIC bytes per launch = 16 B per evaluation it performs
         # (12 B position + 4 B distance; positions are generated on device but counted) + 36 B per triangle.
         k_ms = march_ms / max(1, args.steps)
         k_bytes = (march_evals * 16.0 + march_tris * 36.0) / max(1, args.steps)
@@ -137,15 +151,17 @@ def main():
             "triangles_per_s": tris_all / dt,
             "triangles_per_step": tris_all / args.steps, "evals_per_step": evals_all / args.steps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "leaf_march_kernel", "kernel_ms": k_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_gb(),
+                         "kernel": "leaf_kernel<4>", "kernel_ms": k_ms,
                          "kernel_evals_per_s": (march_evals / max(1, args.steps)) / (k_ms * 1e-3) if k_ms > 0 else 0.0,
                          "note": "path is fp32-VALU bound (SURVEY 8(d)): algorithmic HBM bytes are tiny by construction"},
             "phase_ms_rank0": {"prune": st.ms_prune, "leaf": st.ms_leaf, "march_kernel": st.ms_march, "total_device": st.ms_total},
         }
         if world == 1 and not args.no_cpu_baseline:
-            threads = max(1, (os.cpu_count() or 2) - 1)
-            out["cpu_baseline"] = cpu_baseline(shader, args.cpu_resdiv, threads)
+            threads = max(1, (os.cpu_count() or 2) - 1)  # GOMAXPROCS-1 (gsdfaux/gsdfaux.go:162-164)
+            # bounded sample of the SAME workload: full resdiv 1600 lattice (420 M evals) on big hosts, coarser on small ones
+            cpu_rd = args.cpu_resdiv or (args.resdiv if threads >= 64 else (1000 if threads >= 16 else 600))
+            out["cpu_baseline"] = cpu_baseline(shader, cpu_rd, threads)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

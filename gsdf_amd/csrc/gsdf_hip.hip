@@ -755,6 +755,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     if (shard_rc) return bail(shard_rc);
   }
   HIP_TRYM(hipEventRecord(ev1, s));
+  const uint64_t evals_prune = evals;
 
   // ---- leaves
   const uint64_t lpc = (uint64_t)1 << (3 * (lq - 1));
@@ -801,6 +802,8 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   HIP_TRYM(hipEventElapsedTime(&ms12, ev1, ev2));
   m->st.n_tris = n_tris;
   m->st.evals = evals;
+  m->st.evals_prune = evals_prune;
+  m->st.evals_leaf = evals - evals_prune;
   m->st.pruned_leaves = pruned;
   m->st.leaf_cubes = n_leaves;
   m->st.active_leaves = n_active;

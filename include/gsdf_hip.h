@@ -98,6 +98,8 @@ typedef struct gsdf_mesh_stats {
   double ms_prune;         /* pruning levels */
   double ms_leaf;          /* leaf phase */
   double ms_march;         /* dominant kernel alone: leaf_kernel (8 corners + marching cubes), HIP events */
+  uint64_t evals_prune;    /* evaluations done by the pruning levels (cube centres) */
+  uint64_t evals_leaf;     /* evaluations done by leaf_kernel (leaf corners) */
 } gsdf_mesh_stats;
 
 int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_opts* opts, gsdf_mesh** out);
