@@ -91,12 +91,16 @@ struct __attribute__((aligned(8))) Cube {
   uint16_t x, y, z, w;
 };
 
+#define MAX_LEVELS 24
 struct MeshCounters {
-  unsigned long long n_out;     // survivors appended by the current prune level
-  unsigned long long n_active;  // active leaves
+  unsigned long long n_level[MAX_LEVELS];  // [L]: cubes of level L handed to the next stage (survivors kept by this rank)
+  unsigned long long n_items[MAX_LEVELS];  // [L]: candidate cubes centre-tested at level L (0 if the level was not tested)
+  unsigned long long n_pass[MAX_LEVELS];   // [L]: candidates that passed the prune predicate (before shard filter)
+  unsigned long long n_active;             // leaves passing the corner-0 test
   unsigned long long n_tris;
-  unsigned long long overflow;  // triangle buffer overflow flag
-  unsigned long long n_cont;    // leaves whose wave went on to the remaining corners
+  unsigned long long overflow;             // triangle buffer overflow flag
+  unsigned long long n_cont;               // leaves whose wave went on to the remaining corners
+  unsigned long long q_overflow;           // cube queue capacity exceeded
 };
 
 // wave64 compaction: returns the global slot for lanes with keep=true (others undefined).
@@ -112,31 +116,49 @@ __device__ __forceinline__ unsigned long long wave_append(bool keep, unsigned lo
   return base + lane_prefix;
 }
 
-// One octree level. expand=1: item i is child (i&7) of in[i>>3]; expand=0: item i is in[i].
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// Owner rank of a brick for multi-GPU sharding: a pure function of the brick coordinates, so every
+// rank derives the same partition with no communication and no ordering dependence.
+__host__ __device__ __forceinline__ unsigned brick_owner(unsigned x, unsigned y, unsigned z, unsigned count) {
+  unsigned h = (x * 73856093u) ^ (y * 19349663u) ^ (z * 83492791u);
+  h ^= h >> 15;
+  h *= 0x2c1b3c6du;
+  h ^= h >> 12;
+  return h % count;
+}
+
+// One octree level, chained on the stream with NO host round trip: the candidate count is read from the
+// previous level's survivor counter in device memory. expand=1: item i is child (i&7) of in[i>>3];
+// expand=0: the single top cube. Survivors are compacted into `out` (ballot + mbcnt prefix + one
+// atomic per wave; queues are small, the leaf kernel is where atomics had to go).
 __global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ in,
-                                                      uint64_t n_items, int expand, int level, float ox, float oy, float oz,
-                                                      float res, int do_test, Cube* __restrict__ out,
+                                                      int expand, int level, float ox, float oy, float oz, float res,
+                                                      int do_test, Cube* __restrict__ out, unsigned long long out_cap,
+                                                      int shard_here, unsigned shard_rank, unsigned shard_count,
                                                       MeshCounters* __restrict__ ctr) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
+  const unsigned long long n_items = expand ? uniform_u64(ctr->n_level[level + 1]) * 8ull : 1ull;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_items[level] = do_test ? n_items : 0ull;
   const float size = (float)(1 << (level - 1)) * res;  // i3.Cube size at this level
   const float maxDist = size * (1.73205080757f / 2);    // szDistMult = sqrt3/2 (octreerenderer.go:182)
   const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  unsigned long long my_pass = 0;
   for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_items; base += step) {
     const uint64_t i = base + threadIdx.x;
     const bool valid = i < n_items;
     Cube c = {0, 0, 0, 0};
-    if (valid) {
-      if (expand) {
-        const Cube pc = in[i >> 3];
-        const unsigned k = (unsigned)(i & 7);
-        // children in corner order: 0:(0,0,0) 1:(+x) 2:(+x,+y) 3:(+y) 4..7 same at +z
-        c.x = (uint16_t)(pc.x * 2 + ((k ^ (k >> 1)) & 1));
-        c.y = (uint16_t)(pc.y * 2 + ((k >> 1) & 1));
-        c.z = (uint16_t)(pc.z * 2 + ((k >> 2) & 1));
-      } else {
-        c = in[i];
-      }
+    if (valid && expand) {
+      const Cube pc = in[i >> 3];
+      const unsigned k = (unsigned)(i & 7);
+      // children in corner order: 0:(0,0,0) 1:(+x) 2:(+x,+y) 3:(+y) 4..7 same at +z
+      c.x = (uint16_t)(pc.x * 2 + ((k ^ (k >> 1)) & 1));
+      c.y = (uint16_t)(pc.y * 2 + ((k >> 1) & 1));
+      c.z = (uint16_t)(pc.z * 2 + ((k >> 2) & 1));
     }
     bool keep = valid;
     if (do_test) {
@@ -150,9 +172,16 @@ __global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict
       gsdf_dev::sdf_eval<1>(code, pv, dv, lds, BLOCK);
       keep = valid && !(dm::absf(dv[0]) >= maxDist);
     }
-    const unsigned long long slot = wave_append(keep, &ctr->n_out);
-    if (keep) out[slot] = c;
+    const unsigned long long pm = __ballot(keep);
+    if ((threadIdx.x & 63) == 0) my_pass += (unsigned long long)__builtin_popcountll(pm);
+    if (shard_here) keep = keep && (brick_owner(c.x, c.y, c.z, shard_count) == shard_rank);
+    const unsigned long long slot = wave_append(keep, &ctr->n_level[level]);
+    if (keep) {
+      if (slot < out_cap) out[slot] = c;
+      else ctr->q_overflow = 1ull;
+    }
   }
+  if ((threadIdx.x & 63) == 0 && my_pass) atomicAdd(&ctr->n_pass[level], my_pass);
 }
 
 // mcInterpolate (marchcubes.go:76-98) with x = 0.
@@ -178,7 +207,7 @@ __device__ __forceinline__ void mc_interp(float ax, float ay, float az, float bx
 // LDS: [(nslots+8) floats per lane | tri table 256x16 i8 | TRI_STAGE*9 floats | 8 words].
 template <int K>
 __global__ void __launch_bounds__(BLOCK) leaf_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
-                                                     uint64_t n_leaves, int lq, int nslots, float ox, float oy, float oz,
+                                                     unsigned long long cube_cap, int lq, int nslots, float ox, float oy, float oz,
                                                      float res, float* __restrict__ tris, uint64_t tri_cap,
                                                      MeshCounters* __restrict__ ctr) {
   code_ptr code = as_code(code_g);
@@ -194,6 +223,9 @@ __global__ void __launch_bounds__(BLOCK) leaf_kernel(const uint32_t* __restrict_
 
   const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
   const int sh = lq - 1;
+  unsigned long long n_cubes = uniform_u64(ctr->n_level[lq]);  // survivors of the last prune level (device-side count)
+  if (n_cubes > cube_cap) n_cubes = cube_cap;                  // queue overflowed: host reruns with larger queues
+  const uint64_t n_leaves = n_cubes << (3 * sh);
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long my_active = 0, my_cont = 0;
   const uint64_t step = (uint64_t)gridDim.x * BLOCK;
@@ -424,6 +456,8 @@ struct gsdf_program {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
   } q0, q1, ctr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  uint64_t last_tris = 0;  // triangle count of the previous mesh on this handle: sizes the next output buffer
   size_t lds_bytes(int k = 1) const { return (size_t)(prog.nslots > 0 ? prog.nslots : 1) * k * BLOCK * sizeof(float); }
   // Points carried per lane: as many as keep >= 2 workgroups per CU resident (160 KB LDS per CU).
   int batch_k() const {
@@ -527,6 +561,7 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (p->d_pos) (void)hipFree(p->d_pos);
   if (p->d_dist) (void)hipFree(p->d_dist);
   p->q0.release(); p->q1.release(); p->ctr.release();
+  for (auto e : p->ev) if (e) (void)hipEventDestroy(e);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
 }
@@ -632,8 +667,6 @@ extern "C" int gsdf_hip_normals3(gsdf_program* p, const float* pos, float* norma
   return rc;
 }
 
-extern "C" uint64_t gsdf_hip_shard_bricks(const uint16_t* cubes, uint64_t n, int rank, int count, uint16_t* out);
-
 // ---- mesher -----------------------------------------------------------------------------------
 namespace {
 // ms3.Box.ScaleCentered(1.01) = NewCenteredBox(Center(), MulElem(scale, Size())) [external]; float32, unfused.
@@ -692,146 +725,116 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
 
   HIP_TRYM(p->ctr.ensure(sizeof(MeshCounters)));
   MeshCounters* d_ctr = (MeshCounters*)p->ctr.p;
-  HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(MeshCounters), s));
-  hipEvent_t ev0, ev1, ev2;
-  HIP_TRYM(hipEventCreate(&ev0));
-  HIP_TRYM(hipEventCreate(&ev1));
-  HIP_TRYM(hipEventCreate(&ev2));
-  struct EvGuard { hipEvent_t e[3]; ~EvGuard() { for (auto x : e) (void)hipEventDestroy(x); } } evg{{ev0, ev1, ev2}};
-  HIP_TRYM(hipEventRecord(ev0, s));
+  for (auto& e : p->ev)
+    if (!e) HIP_TRYM(hipEventCreate(&e));
+  hipEvent_t ev0 = p->ev[0], ev1 = p->ev[1], ev2 = p->ev[2];
 
-  // ---- level-synchronous descent from the top cube to level lq = min(levels, 3)
+  // ---- level-synchronous descent from the top cube to level lq = min(levels, 3). The whole chain
+  // (memset, one prune launch per level, the leaf kernel) is enqueued without a host round trip: each
+  // kernel reads its input count from the previous level's counter in device memory.
   const int lq = levels < 3 ? levels : 3;
-  uint64_t evals = 0, pruned = 0;
-  gsdf_program::Arena* cur = &p->q0;
-  gsdf_program::Arena* nxt = &p->q1;
-  uint64_t n_cur = 1;
-  HIP_TRYM(cur->ensure(sizeof(Cube)));
-  {
-    Cube top = {0, 0, 0, 0};
-    HIP_TRYM(hipMemcpyAsync(cur->p, &top, sizeof(Cube), hipMemcpyHostToDevice, s));
-  }
-  const size_t lds = p->lds_bytes();
-  bool sharded = opts.shard_count == 1;
-  int shard_rc = GSDF_OK;
-  // multi-GPU: keep every shard_count-th brick (dealt round-robin over a coordinate-sorted list so
-  // that every rank derives the same partition without communicating).
-  auto deal = [&]() {
-    std::vector<Cube> h(n_cur);
-    if (n_cur && hipMemcpy(h.data(), cur->p, n_cur * sizeof(Cube), hipMemcpyDeviceToHost) != hipSuccess) { shard_rc = fail(GSDF_ERR_HIP, "D2H copy of bricks failed"); return; }
-    std::vector<Cube> mine(n_cur);
-    const uint64_t n_mine = gsdf_hip_shard_bricks((const uint16_t*)h.data(), n_cur, opts.shard_rank, opts.shard_count, (uint16_t*)mine.data());
-    n_cur = n_mine;
-    if (n_cur && hipMemcpy(cur->p, mine.data(), n_cur * sizeof(Cube), hipMemcpyHostToDevice) != hipSuccess) { shard_rc = fail(GSDF_ERR_HIP, "H2D copy of bricks failed"); return; }
-    sharded = true;
-  };
-  for (int level = levels; level >= lq; level--) {
-    const bool expand = level != levels;
-    const uint64_t n_items = expand ? n_cur * 8 : n_cur;
-    const int do_test = (level >= 3 && opts.prune) ? 1 : 0;
-    if (!expand && !do_test) continue;  // top cube kept as is
-    HIP_TRYM(nxt->ensure(n_items * sizeof(Cube)));
-    HIP_TRYM(hipMemsetAsync(&d_ctr->n_out, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(prune_kernel, dim3(grid_for(n_items, p->num_cu, 8)), dim3(BLOCK), lds, s, p->d_code, (const Cube*)cur->p,
-                       n_items, expand ? 1 : 0, level, ox, oy, oz, res, do_test, (Cube*)nxt->p, d_ctr);
-    HIP_TRYM(hipGetLastError());
-    unsigned long long n_out = 0;
-    HIP_TRYM(hipMemcpyAsync(&n_out, &d_ctr->n_out, sizeof(n_out), hipMemcpyDeviceToHost, s));
-    HIP_TRYM(hipStreamSynchronize(s));
-    if (do_test) {
-      evals += n_items;
-      pruned += (n_items - n_out) << (3 * (level - 1));  // DecomposesTo(1) = 8^(level-1)
-    }
-    std::swap(cur, nxt);
-    n_cur = n_out;
-    if (!sharded && (n_cur >= (uint64_t)64 * opts.shard_count || level == lq)) {
-      deal();
-      if (shard_rc) return bail(shard_rc);
-    }
-    if (n_cur == 0) break;
-  }
-  if (!sharded) {
-    deal();
-    if (shard_rc) return bail(shard_rc);
-  }
-  HIP_TRYM(hipEventRecord(ev1, s));
-  const uint64_t evals_prune = evals;
-
-  // ---- leaves
-  const uint64_t lpc = (uint64_t)1 << (3 * (lq - 1));
-  const uint64_t n_leaves = n_cur * lpc;
-  unsigned long long n_active = 0, n_tris = 0;
-  if (n_leaves) {
-    // capacity: caller's, else a pooled buffer, else one triangle per leaf; on overflow the kernel keeps
-    // counting, so the exact size is known and the leaf pass is repeated once with it.
-    uint64_t want = opts.max_tris ? opts.max_tris : (n_leaves < 4096 ? 4096 : n_leaves);
-    const int lk = p->batch_k();
-    const size_t lds_m = (size_t)(p->prog.nslots * lk + 8) * BLOCK * sizeof(float) + 4096 + TRI_STAGE * 36 + 64;
-    for (int attempt = 0; attempt < 2; attempt++) {
+  // multi-GPU: bricks of level ls are dealt to ranks by a hash of their coordinates (brick_owner).
+  const int ls = levels < lq + 2 ? levels : lq + 2;
+  const size_t lds = p->lds_bytes(1);
+  const int lk = p->batch_k();
+  const size_t lds_m = (size_t)(p->prog.nslots * lk + 8) * BLOCK * sizeof(float) + 4096 + TRI_STAGE * 36 + 64;
+  uint64_t qcap = p->q0.cap / sizeof(Cube);
+  if (qcap < (1u << 20)) qcap = 1u << 20;  // 1 M cubes (8 MB) per queue to start with
+  uint64_t want = opts.max_tris;
+  MeshCounters hc{};
+  float ms01 = 0, ms12 = 0;
+  for (int attempt = 0;; attempt++) {
+    HIP_TRYM(p->q0.ensure(qcap * sizeof(Cube)));
+    HIP_TRYM(p->q1.ensure(qcap * sizeof(Cube)));
+    const uint64_t cap0 = p->q0.cap / sizeof(Cube), cap1 = p->q1.cap / sizeof(Cube);
+    gsdf_program::Arena* q[2] = {&p->q0, &p->q1};
+    const uint64_t capq[2] = {cap0, cap1};
+    // triangle buffer: caller's size, else a pooled buffer, else a guess that is corrected by one exact rerun
+    if (!m->d_tris) {
+      uint64_t need = want ? want : (p->last_tris ? p->last_tris + p->last_tris / 16 + 1024 : (uint64_t)1 << 20);
+      m->d_tris = pool_take(p->device, need, &m->cap);
       if (!m->d_tris) {
-        m->d_tris = pool_take(p->device, want, &m->cap);
-        if (!m->d_tris) {
-          HIP_TRYM(hipMalloc((void**)&m->d_tris, want * 36));
-          m->cap = want;
-        }
+        HIP_TRYM(hipMalloc((void**)&m->d_tris, need * 36));
+        m->cap = need;
       }
-#define LAUNCH_LEAF(KK)                                                                                                   \
-  hipLaunchKernelGGL((leaf_kernel<KK>), dim3(grid_for(n_leaves, p->num_cu, 8)), dim3(BLOCK), lds_m, s, p->d_code, (const Cube*)cur->p, \
-                     n_leaves, lq, p->prog.nslots, ox, oy, oz, res, m->d_tris, opts.max_tris ? opts.max_tris : m->cap, d_ctr)
+    }
+    HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(MeshCounters), s));
+    HIP_TRYM(hipEventRecord(ev0, s));
+    for (int level = levels; level >= lq; level--) {
+      const int expand = level != levels;
+      const int do_test = (level >= 3 && opts.prune) ? 1 : 0;
+      // upper bound of candidates at this level (for the grid only): 8^(levels-level), capped by the queue
+      uint64_t bound = (levels - level) * 3 >= 40 ? UINT64_MAX : ((uint64_t)1 << (3 * (levels - level)));
+      if (bound > capq[(level + 1) & 1] * 8) bound = capq[(level + 1) & 1] * 8;
+      hipLaunchKernelGGL(prune_kernel, dim3(grid_for(bound, p->num_cu, 8)), dim3(BLOCK), lds, s, p->d_code,
+                         (const Cube*)q[(level + 1) & 1]->p, expand, level, ox, oy, oz, res, do_test, (Cube*)q[level & 1]->p,
+                         (unsigned long long)capq[level & 1], (opts.shard_count > 1 && level == ls) ? 1 : 0,
+                         (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr);
+      HIP_TRYM(hipGetLastError());
+    }
+    HIP_TRYM(hipEventRecord(ev1, s));
+    {
+      uint64_t bound = capq[lq & 1] << (3 * (lq - 1));
+      const uint64_t full = (levels - lq) * 3 >= 40 ? UINT64_MAX : ((uint64_t)1 << (3 * (levels - 1)));
+      if (bound > full) bound = full;
+      const unsigned long long tcap = opts.max_tris ? opts.max_tris : m->cap;
+#define LAUNCH_LEAF(KK)                                                                                               \
+  hipLaunchKernelGGL((leaf_kernel<KK>), dim3(grid_for(bound, p->num_cu, 8)), dim3(BLOCK), lds_m, s, p->d_code,          \
+                     (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res,  \
+                     m->d_tris, tcap, d_ctr)
       if (lk == 4) LAUNCH_LEAF(4); else if (lk == 2) LAUNCH_LEAF(2); else LAUNCH_LEAF(1);
 #undef LAUNCH_LEAF
       HIP_TRYM(hipGetLastError());
-      MeshCounters hc{};
-      HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));
-      HIP_TRYM(hipStreamSynchronize(s));
-      n_active = hc.n_active;
-      n_tris = hc.n_tris;
-      evals += n_leaves * (uint64_t)lk + (uint64_t)(8 - lk) * hc.n_cont;  // evaluations actually executed on leaf corners
-      if (!hc.overflow) break;
-      if (opts.max_tris || attempt == 1) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
+    }
+    HIP_TRYM(hipEventRecord(ev2, s));
+    HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));
+    HIP_TRYM(hipStreamSynchronize(s));
+    if (hc.q_overflow) {  // a cube queue was too small: double and redo (exact: nothing was dropped silently)
+      if (attempt >= 8) return bail(fail(GSDF_ERR_CAPACITY, "octree queue capacity exceeded"));
+      qcap *= 4;
+      continue;
+    }
+    if (hc.overflow) {  // triangle buffer too small: the kernel kept counting, so the exact size is known
+      if (opts.max_tris) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
+      if (attempt >= 8) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
       pool_give(p->device, m->d_tris, m->cap);
       m->d_tris = nullptr; m->cap = 0;
-      want = n_tris;
-      HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(MeshCounters), s));
+      want = hc.n_tris + hc.n_tris / 16 + 1024;
+      continue;
     }
+    break;
   }
-  HIP_TRYM(hipEventRecord(ev2, s));
-  HIP_TRYM(hipEventSynchronize(ev2));
-  float ms01 = 0, ms12 = 0;
   HIP_TRYM(hipEventElapsedTime(&ms01, ev0, ev1));
   HIP_TRYM(hipEventElapsedTime(&ms12, ev1, ev2));
-  m->st.n_tris = n_tris;
-  m->st.evals = evals;
+  uint64_t evals_prune = 0, pruned = 0;
+  for (int level = levels; level >= lq; level--) {
+    evals_prune += hc.n_items[level];
+    if (hc.n_items[level]) pruned += (hc.n_items[level] - hc.n_pass[level]) << (3 * (level - 1));  // DecomposesTo(1) = 8^(level-1)
+  }
+  const uint64_t n_leaves = hc.n_level[lq] << (3 * (lq - 1));
+  const uint64_t evals_leaf = n_leaves * (uint64_t)lk + (uint64_t)(8 - lk) * hc.n_cont;  // evaluations actually executed
+  m->st.n_tris = hc.n_tris;
+  m->st.evals = evals_prune + evals_leaf;
   m->st.evals_prune = evals_prune;
-  m->st.evals_leaf = evals - evals_prune;
+  m->st.evals_leaf = evals_leaf;
   m->st.pruned_leaves = pruned;
   m->st.leaf_cubes = n_leaves;
-  m->st.active_leaves = n_active;
+  m->st.active_leaves = hc.n_active;
   m->st.ms_prune = ms01;
   m->st.ms_leaf = ms12;
   m->st.ms_march = ms12;
   m->st.ms_total = (double)ms01 + (double)ms12;
-  p->evals += evals;
+  p->evals += m->st.evals;
+  p->last_tris = hc.n_tris;
   *out = m;
   return GSDF_OK;
 #undef HIP_TRYM
 }
 
-// Pure host helper (no GPU): deterministic brick partition used for multi-GPU sharding. cubes/out are
-// arrays of 4 x u16 (x,y,z,pad). Returns the number of bricks of `rank`; every rank computes the same
-// partition from the same survivor set, so no communication is needed.
-extern "C" uint64_t gsdf_hip_shard_bricks(const uint16_t* cubes, uint64_t n, int rank, int count, uint16_t* out) {
-  if (!cubes || !out || count < 1 || rank < 0 || rank >= count) return 0;
-  std::vector<Cube> h(n);
-  std::memcpy(h.data(), cubes, n * sizeof(Cube));
-  std::sort(h.begin(), h.end(), [](const Cube& a, const Cube& b) {
-    if (a.z != b.z) return a.z < b.z;
-    if (a.y != b.y) return a.y < b.y;
-    return a.x < b.x;
-  });
-  uint64_t k = 0;
-  for (uint64_t i = (uint64_t)rank; i < n; i += (uint64_t)count) std::memcpy(out + 4 * (k++), &h[i], sizeof(Cube));
-  return k;
+// Pure host helper (no GPU): owner rank of the brick (x,y,z) under the multi-GPU partition that
+// gsdf_hip_mesh_octree applies on device (same function, SURVEY 8(e): no data-path collective).
+extern "C" uint32_t gsdf_hip_brick_owner(uint32_t x, uint32_t y, uint32_t z, uint32_t count) {
+  return count ? brick_owner(x, y, z, count) : 0;
 }
 
 extern "C" int gsdf_hip_mesh_stats_get(const gsdf_mesh* m, gsdf_mesh_stats* st) {

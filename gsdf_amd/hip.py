@@ -24,7 +24,7 @@ SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "g
            "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations",
            "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3",
            "gsdf_hip_mesh_octree", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
-           "gsdf_hip_mesh_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_shard_bricks"]
+           "gsdf_hip_mesh_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner"]
 
 
 class MeshOpts(C.Structure):
@@ -77,8 +77,8 @@ def lib():
         L.gsdf_hip_mesh_stl.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.gsdf_hip_mesh_destroy.argtypes = [C.c_void_p]
         L.gsdf_hip_mesh_destroy.restype = None
-        L.gsdf_hip_shard_bricks.restype = C.c_uint64
-        L.gsdf_hip_shard_bricks.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
+        L.gsdf_hip_brick_owner.restype = C.c_uint32
+        L.gsdf_hip_brick_owner.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         _LIB = L
     return _LIB
 

@@ -112,9 +112,9 @@ const float* gsdf_hip_mesh_dev_tris(const gsdf_mesh* m);
 int gsdf_hip_mesh_stl(const gsdf_mesh* m, uint8_t* dst, size_t dst_cap);
 void gsdf_hip_mesh_destroy(gsdf_mesh* m);
 
-/* Host-only helper (runs without a GPU): the deterministic brick partition gsdf_hip_mesh_octree uses for
- * multi-GPU sharding. cubes/out: n x {u16 x, y, z, pad}. Returns the number of bricks given to `rank`. */
-uint64_t gsdf_hip_shard_bricks(const uint16_t* cubes, uint64_t n, int rank, int count, uint16_t* out);
+/* Host-only helper (runs without a GPU): owner rank of octree brick (x,y,z) under the multi-GPU partition
+ * gsdf_hip_mesh_octree applies on device -- a pure function of the coordinates, so ranks never communicate. */
+uint32_t gsdf_hip_brick_owner(uint32_t x, uint32_t y, uint32_t z, uint32_t count);
 
 #ifdef __cplusplus
 }

@@ -58,22 +58,17 @@ def test_no_gpu_is_reported_not_hidden():
     assert e.value.code in (-6, -5)  # GSDF_ERR_NO_DEVICE / HIP error: never a silent CPU fallback
 
 
-def test_shard_bricks_partition_is_exact_and_deterministic():
+def test_brick_owner_partition_is_balanced_and_total():
+    """Multi-GPU partition (host-visible twin of the device function): every brick has exactly one owner,
+    ownership depends only on the coordinates, and the deal is balanced."""
     L = hip.lib()
-    rng = np.random.default_rng(0)
-    cubes = np.zeros((1000, 4), np.uint16)
-    cubes[:, :3] = rng.integers(0, 512, (1000, 3))
-    cubes = np.unique(cubes, axis=0)
-    n = cubes.shape[0]
-    for world in (1, 2, 3, 8):
-        parts = []
-        for r in range(world):
-            out = np.zeros_like(cubes)
-            perm = rng.permutation(n)  # every rank sees the survivor list in a different order
-            shuffled = np.ascontiguousarray(cubes[perm])
-            k = L.gsdf_hip_shard_bricks(shuffled.ctypes.data, n, r, world, out.ctypes.data)
-            parts.append(out[:k])
-            assert abs(k - n / world) <= 1  # balanced
-        allc = np.concatenate(parts)
-        assert allc.shape[0] == n and np.unique(allc, axis=0).shape[0] == n  # disjoint and complete
-    assert L.gsdf_hip_shard_bricks(cubes.ctypes.data, n, 3, 2, cubes.ctypes.data) == 0  # bad rank
+    coords = [(x, y, z) for x in range(24) for y in range(24) for z in range(8)]
+    for world in (1, 2, 3, 4, 8):
+        owners = np.array([L.gsdf_hip_brick_owner(x, y, z, world) for x, y, z in coords])
+        assert owners.min() >= 0 and owners.max() < world
+        counts = np.bincount(owners, minlength=world)
+        assert counts.sum() == len(coords)
+        assert counts.max() < 1.25 * len(coords) / world and counts.min() > 0.75 * len(coords) / world
+        again = np.array([L.gsdf_hip_brick_owner(x, y, z, world) for x, y, z in coords])
+        assert (owners == again).all()
+    assert L.gsdf_hip_brick_owner(1, 2, 3, 0) == 0
