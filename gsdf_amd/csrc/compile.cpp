@@ -26,6 +26,17 @@ struct Ctx {
   int max_slots = 0;
   size_t max_code;
   std::vector<int8_t> clob;  // memo: -1 unknown, 0/1
+  // Static tracking of "which P.xy value is live" so that hypot(P.x,P.y) can be shared by sibling
+  // primitives (three cylinders and the screw of npt-flange all see the same x,y): every instruction
+  // that rewrites x or y starts a new version; saved positions remember theirs.
+  uint32_t xyver = 1, next_ver = 2, hxyver = 0;
+  std::vector<uint32_t> slotver = std::vector<uint32_t>(1 << 16, 0);
+  void bump() { xyver = next_ver++; }
+  uint32_t hxy_flag() {  // call when emitting a consumer of hypot(P.x,P.y)
+    uint32_t f = (hxyver == xyver) ? D_FLAG_HXY : 0u;
+    hxyver = xyver;
+    return f;
+  }
 
   int alloc(int n) {
     int s = slots;
@@ -70,21 +81,33 @@ bool clobbers(Ctx& c, uint32_t i) {
 
 void gen(Ctx& c, uint32_t i, int depth);
 
-// n-ary / binary combine frame (cpu_evaluators.go:124-286, 821-912).
+// n-ary / binary combine frame (cpu_evaluators.go:124-286, 821-912). Children that do not rewrite the
+// position are evaluated first (min/max are order-independent; for the asymmetric binary ops the
+// combine gets D_FLAG_SWAP), so the position only has to be saved when two or more children rewrite it.
 void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int depth) {
   bool is2d = gsdf_op_is2d(n.op);
+  std::vector<uint32_t> order;
+  for (uint32_t k = 0; k < n.nchild; k++) if (!clobbers(c, c.child(n, k))) order.push_back(k);
+  for (uint32_t k = 0; k < n.nchild; k++) if (clobbers(c, c.child(n, k))) order.push_back(k);
+  const bool asym = comb == D_COMBINE_DIFF || comb == D_COMBINE_SUNION || comb == D_COMBINE_SDIFF || comb == D_COMBINE_SINTER;
+  const bool swapped = n.nchild == 2 && order[0] != 0;
+  if (n.nchild != 2 && asym) throw std::runtime_error("asymmetric combine needs exactly 2 children");
   bool need_save = false;
-  for (uint32_t k = 0; k + 1 < n.nchild; k++) need_save = need_save || clobbers(c, c.child(n, k));
+  for (uint32_t k = 0; k + 1 < n.nchild; k++) need_save = need_save || clobbers(c, c.child(n, order[k]));
   int slotP = -1;
-  if (need_save) { slotP = c.alloc(is2d ? 2 : 3); c.op(is2d ? D_SAVEP2 : D_SAVEP3, slotP); }
+  if (need_save) {
+    slotP = c.alloc(is2d ? 2 : 3);
+    c.op(is2d ? D_SAVEP2 : D_SAVEP3, slotP);
+    c.slotver[(size_t)slotP] = c.xyver;
+  }
   int slotD = c.alloc(1);
   bool dirty = false;
   for (uint32_t k = 0; k < n.nchild; k++) {
-    if (k > 0 && dirty) { c.op(is2d ? D_LOADP2 : D_LOADP3, slotP); dirty = false; }
-    uint32_t ch = c.child(n, k);
+    if (k > 0 && dirty) { c.op(is2d ? D_LOADP2 : D_LOADP3, slotP); c.xyver = c.slotver[(size_t)slotP]; dirty = false; }
+    uint32_t ch = c.child(n, order[k]);
     gen(c, ch, depth + 1);
     dirty = dirty || clobbers(c, ch);
-    if (k > 0) { c.op(comb, slotD); if (has_k) c.f(n.p[0]); }
+    if (k > 0) { c.op(comb | ((asym && swapped) ? D_FLAG_SWAP : 0u), slotD); if (has_k) c.f(n.p[0]); }
     if (k + 1 < n.nchild) c.op(D_SAVER, slotD);
   }
   c.release(1);
@@ -110,11 +133,11 @@ void gen(Ctx& c, uint32_t i, int depth) {
       c.f(0.5f * P[0] + (-2 * e)); c.f(0.5f * P[1] + (-2 * e)); c.f(0.5f * P[2] + (-2 * e));
       break;
     }
-    case GSDF_TORUS: c.op(D_TORUS); c.f(P[0]); c.f(P[1]); break;                                   // :59-68
+    case GSDF_TORUS: c.op(D_TORUS | c.hxy_flag()); c.f(P[0]); c.f(P[1]); break;                                   // :59-68
     case GSDF_CYLINDER: {                                                                          // :70-88, primitives.go:147-149
       float r = P[0], h = (P[1] - 2 * P[2]) / 2, round = P[2];
-      if (round == 0) { c.op(D_CYL0); c.f(r); c.f(h); }
-      else { c.op(D_CYLR); c.f(r); c.f(h); c.f(round); }
+      if (round == 0) { c.op(D_CYL0 | c.hxy_flag()); c.f(r); c.f(h); }
+      else { c.op(D_CYLR | c.hxy_flag()); c.f(r); c.f(h); c.f(round); }
       break;
     }
     case GSDF_HEX: c.op(D_HEX); c.f(P[0]); c.f(P[1]); c.f(0.57735f * P[0]); break;                  // :90-105
@@ -128,9 +151,9 @@ void gen(Ctx& c, uint32_t i, int depth) {
     case GSDF_SMOOTH_INTERSECT: need_children(2); child_dim(false); gen_combine(c, n, D_COMBINE_SINTER, true, depth); break;
     // ------------------------------- 3D unary -------------------------------
     case GSDF_SCALE: need_children(1); child_dim(false);                                           // :288-312
-      c.op(D_SCALE_PRE); c.f(1.f / P[0]); gen(c, c.child(n, 0), depth + 1); c.op(D_MULR); c.f(P[0]); break;
+      c.op(D_SCALE_PRE); c.f(1.f / P[0]); c.bump(); gen(c, c.child(n, 0), depth + 1); c.op(D_MULR); c.f(P[0]); break;
     case GSDF_SYMMETRY: need_children(1); child_dim(false);                                        // :314-343
-      c.op(D_SYMMETRY); c.u((uint32_t)(int)P[0]); gen(c, c.child(n, 0), depth + 1); break;
+      c.op(D_SYMMETRY); c.u((uint32_t)(int)P[0]); if ((int)P[0] & 3) c.bump(); gen(c, c.child(n, 0), depth + 1); break;
     case GSDF_ARRAY: {                                                                             // :345-397
       need_children(1); child_dim(false);
       int slotP = c.alloc(3), slotD = c.alloc(1);
@@ -138,6 +161,7 @@ void gen(Ctx& c, uint32_t i, int depth) {
       c.op(D_SETSLOT, slotD); c.f(1e20f);
       for (int k = 0; k < 2; k++) for (int j = 0; j < 2; j++) for (int ii = 0; ii < 2; ii++) {
         c.op(D_ARRAY_PRE, slotP);
+        c.bump();
         c.f((float)ii); c.f((float)j); c.f((float)k);
         c.f(P[0]); c.f(P[1]); c.f(P[2]);
         c.f(P[3] + -1); c.f(P[4] + -1); c.f(P[5] + -1);
@@ -152,22 +176,26 @@ void gen(Ctx& c, uint32_t i, int depth) {
       need_children(1); child_dim(false);
       int s = c.alloc(1);
       c.op(D_ELONGATE_PRE, s); c.f(0.5f * P[0]); c.f(0.5f * P[1]); c.f(0.5f * P[2]);
+      c.bump();
       gen(c, c.child(n, 0), depth + 1);
       c.op(D_ADDR_SLOT, s);
       c.release(1);
       break;
     }
     case GSDF_SHELL: need_children(1); child_dim(false);                                           // :428-452
-      c.op(D_SCALE_PRE); c.f(1 / P[0]); gen(c, c.child(n, 0), depth + 1); c.op(D_SHELL_POST); c.f(P[0]); break;
+      c.op(D_SCALE_PRE); c.f(1 / P[0]); c.bump(); gen(c, c.child(n, 0), depth + 1); c.op(D_SHELL_POST); c.f(P[0]); break;
     case GSDF_OFFSET: need_children(1); child_dim(false);                                          // :454-468
       gen(c, c.child(n, 0), depth + 1); c.op(D_ADDR); c.f(P[0]); break;
     case GSDF_TRANSLATE: need_children(1); child_dim(false);                                       // :470-486
-      c.op(D_TRANSLATE); c.f(P[0]); c.f(P[1]); c.f(P[2]); gen(c, c.child(n, 0), depth + 1); break;
+      c.op(D_TRANSLATE); c.f(P[0]); c.f(P[1]); c.f(P[2]);
+      if (!(P[0] == 0.f && P[1] == 0.f)) c.bump();  // x - 0.0f == x bitwise: a z-only translate keeps hypot(x,y)
+      gen(c, c.child(n, 0), depth + 1); break;
     case GSDF_TRANSFORM: {                                                                         // :488-504
       need_children(1); child_dim(false);
       if (n.aux_len < 16) throw std::runtime_error("transform needs 16 aux floats");
       c.op(D_TRANSFORM);
       for (int k = 0; k < 12; k++) c.f(c.t->aux[n.aux_off + k]);
+      c.bump();
       gen(c, c.child(n, 0), depth + 1);
       break;
     }
@@ -178,17 +206,21 @@ void gen(Ctx& c, uint32_t i, int depth) {
       int slotP = c.alloc(is2d ? 2 : 3), slotD = c.alloc(1);
       if (!is2d) c.op(D_SAVEP3, slotP);  // keeps z at slotP+2; CIRC_PRE overwrites slotP..+1 with p0.xy
       c.op(D_CIRC_PRE, slotP);
+      c.bump();
+      c.slotver[(size_t)slotP] = c.xyver;  // p0
+      c.bump();                              // P = p1
       c.f((float)(2 * gsdf::kPi) / P[1]); c.f(P[1]); c.f((float)((int)P[0] - 1));
       gen(c, c.child(n, 0), depth + 1);  // pos1 first
       c.op(D_SAVER, slotD);
       c.op(is2d ? D_LOADP2 : D_LOADP3, slotP);
+      c.xyver = c.slotver[(size_t)slotP];
       gen(c, c.child(n, 0), depth + 1);  // pos0
       c.op(D_COMBINE_MIN, slotD);
       c.release(is2d ? 3 : 4);
       break;
     }
     case GSDF_TWIST: need_children(1); child_dim(false);                                           // :1257-1274
-      c.op(D_TWIST); c.f(P[0]); gen(c, c.child(n, 0), depth + 1); break;
+      c.op(D_TWIST); c.f(P[0]); c.bump(); gen(c, c.child(n, 0), depth + 1); break;
     // ------------------------------- 2D -> 3D -------------------------------
     case GSDF_EXTRUSION: {                                                                         // :506-531
       need_children(1); child_dim(true);
@@ -200,11 +232,12 @@ void gen(Ctx& c, uint32_t i, int depth) {
       break;
     }
     case GSDF_REVOLUTION: need_children(1); child_dim(true);                                       // :533-549
-      c.op(D_REVOLVE_PRE); c.f(P[0]); gen(c, c.child(n, 0), depth + 1); break;
+      c.op(D_REVOLVE_PRE); c.f(P[0]); c.bump(); gen(c, c.child(n, 0), depth + 1); break;
     case GSDF_SCREW: {                                                                             // threads.go:141-181
       need_children(1); child_dim(true);
       int s = c.alloc(1);
-      c.op(D_SCREW_PRE, s);
+      c.op(D_SCREW_PRE | c.hxy_flag(), s);
+      c.bump();
       c.f(P[0]); c.f(P[1]); c.f(P[2]); c.f(gsdf::tanf32(P[3])); c.f(P[0] / 2);
       gen(c, c.child(n, 0), depth + 1);
       c.op(D_MAXR_SLOT, s);
@@ -236,7 +269,7 @@ void gen(Ctx& c, uint32_t i, int depth) {
       c.f(Ax); c.f(Ay); c.f(ax); c.f(ay); c.f(a2); c.f(bx); c.f(by); c.f(cx); c.f(cy); c.f(kk); c.f(kx); c.f(kx2); c.f(P[6] / 2);
       break;
     }
-    case GSDF_CIRCLE2D: c.op(D_CIRCLE2D); c.f(P[0]); break;                                        // :661-667
+    case GSDF_CIRCLE2D: c.op(D_CIRCLE2D | c.hxy_flag()); c.f(P[0]); break;                                        // :661-667
     case GSDF_EQTRI2D: { float r = P[0] / SQRT3; c.op(D_EQTRI2D); c.f(r); c.f(r / SQRT3); break; }  // :669-683
     case GSDF_RECT2D: c.op(D_RECT2D); c.f(0.5f * P[0]); c.f(0.5f * P[1]); break;                    // :685-692
     case GSDF_DIAMOND2D: {                                                                         // :694-703
@@ -284,6 +317,7 @@ void gen(Ctx& c, uint32_t i, int depth) {
       c.op(D_SETSLOT, slotD); c.f(1e20f);
       for (int j = 0; j < 2; j++) for (int ii = 0; ii < 2; ii++) {
         c.op(D_ARRAY2D_PRE, slotP);
+        c.bump();
         c.f((float)ii); c.f((float)j); c.f(P[0]); c.f(P[1]); c.f(P[2] + -1); c.f(P[3] + -1);
         gen(c, c.child(n, 0), depth + 1);
         c.op(D_COMBINE_MIN, slotD);
@@ -294,9 +328,9 @@ void gen(Ctx& c, uint32_t i, int depth) {
     }
     case GSDF_OFFSET2D: need_children(1); child_dim(true); gen(c, c.child(n, 0), depth + 1); c.op(D_ADDR); c.f(P[0]); break;  // :964-978
     case GSDF_TRANSLATE2D: need_children(1); child_dim(true);                                      // :980-996
-      c.op(D_TRANSLATE); c.f(P[0]); c.f(P[1]); c.f(0.f); gen(c, c.child(n, 0), depth + 1); break;
+      c.op(D_TRANSLATE); c.f(P[0]); c.f(P[1]); c.f(0.f); if (!(P[0] == 0.f && P[1] == 0.f)) c.bump(); gen(c, c.child(n, 0), depth + 1); break;
     case GSDF_SYMMETRY2D: need_children(1); child_dim(true);                                       // :998-1024
-      c.op(D_SYMMETRY); c.u((uint32_t)(int)P[0] & 3u); gen(c, c.child(n, 0), depth + 1); break;
+      c.op(D_SYMMETRY); c.u((uint32_t)(int)P[0] & 3u); if ((int)P[0] & 3) c.bump(); gen(c, c.child(n, 0), depth + 1); break;
     case GSDF_ANNULUS2D: need_children(1); child_dim(true); gen(c, c.child(n, 0), depth + 1); c.op(D_ANNULUS); c.f(P[0]); break;  // :1026-1040
     case GSDF_TRANSLATEMULTI2D: {                                                                  // :1162-1184
       need_children(1); child_dim(true);
@@ -308,6 +342,7 @@ void gen(Ctx& c, uint32_t i, int depth) {
       if (nd == 0) { c.op(D_SETR); c.f(3.40282346638528859811704183484516925440e+38f); }
       for (uint32_t k = 0; k < nd; k++) {
         c.op(D_LOADP2_SUB, slotP); c.f(d[2 * k]); c.f(d[2 * k + 1]);
+        c.bump();
         gen(c, c.child(n, 0), depth + 1);
         c.op(D_COMBINE_MIN, slotD);
         if (k + 1 < nd) c.op(D_SAVER, slotD);
@@ -316,13 +351,14 @@ void gen(Ctx& c, uint32_t i, int depth) {
       break;
     }
     case GSDF_ROTATION2D: need_children(1); child_dim(true);                                       // :1186-1203
-      c.op(D_ROT2D); c.f(P[0]); c.f(P[1]); c.f(P[2]); c.f(P[3]); gen(c, c.child(n, 0), depth + 1); break;
+      c.op(D_ROT2D); c.f(P[0]); c.f(P[1]); c.f(P[2]); c.f(P[3]); c.bump(); gen(c, c.child(n, 0), depth + 1); break;
     case GSDF_SCALE2D: need_children(1); child_dim(true);                                          // :1205-1226
-      c.op(D_SCALE_PRE); c.f(1.f / P[0]); gen(c, c.child(n, 0), depth + 1); c.op(D_MULR); c.f(P[0]); break;
+      c.op(D_SCALE_PRE); c.f(1.f / P[0]); c.bump(); gen(c, c.child(n, 0), depth + 1); c.op(D_MULR); c.f(P[0]); break;
     case GSDF_ELONGATE2D: {                                                                        // :1228-1255
       need_children(1); child_dim(true);
       int s = c.alloc(1);
       c.op(D_ELONGATE2D_PRE, s); c.f(0.5f * P[0]); c.f(0.5f * P[1]);
+      c.bump();
       gen(c, c.child(n, 0), depth + 1);
       c.op(D_ADDR_SLOT, s);
       c.release(1);

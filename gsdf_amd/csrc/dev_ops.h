@@ -7,9 +7,17 @@
 // ("LDS-staged node stack", slot s of lane t at lds[s*blockDim + t], conflict-free).
 // Slots are allocated statically by the host compiler, so there is no stack pointer at run time.
 //
-// Encoding: word0 = opcode | slot<<16 ; then `nparam` 32-bit words (float bits / uints).
+// Encoding: word0 = opcode (bits 0-13) | flags (bits 14-15) | slot<<16 ; then `nparam` 32-bit words.
+//   D_FLAG_HXY  (bit 14): hypot(P.x,P.y) of every point is already in the per-point `hxy` register (the host
+//                compiler proved P.xy unchanged since it was last computed): reuse instead of recomputing.
+//   D_FLAG_SWAP (bit 15): combine with operand roles exchanged (the second child was evaluated first so that
+//                the position did not have to be saved and restored).
 #pragma once
 #include <stdint.h>
+
+#define D_OP_MASK 0x3fffu
+#define D_FLAG_HXY 0x4000u
+#define D_FLAG_SWAP 0x8000u
 
 enum DevOp : uint32_t {
   D_END = 0,

@@ -555,6 +555,23 @@ extern "C" int gsdf_hip_program_create(const gsdf_tree* tree, gsdf_program** out
   return GSDF_OK;
 }
 
+// Host-only (no GPU): lower a tree to the device instruction stream, for inspection/tests.
+extern "C" int gsdf_hip_lower(const gsdf_tree* tree, uint32_t* code_out, uint32_t code_cap, uint32_t* code_words, uint32_t* lds_slots) {
+  if (!tree) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  try {
+    gsdf_dev::Program pr = gsdf_dev::compile(*tree);
+    if (code_words) *code_words = (uint32_t)pr.code.size();
+    if (lds_slots) *lds_slots = (uint32_t)pr.nslots;
+    if (code_out) {
+      if (code_cap < pr.code.size()) return fail(GSDF_ERR_SHORT_BUFFER, "short buffer");
+      std::memcpy(code_out, pr.code.data(), pr.code.size() * sizeof(uint32_t));
+    }
+    return GSDF_OK;
+  } catch (const std::exception& e) {
+    return fail(GSDF_ERR_BAD_TREE, e.what());
+  }
+}
+
 extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (!p) return;
   if (p->d_code) (void)hipFree(p->d_code);

@@ -31,6 +31,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
                                          float* __restrict__ lds /* already offset by tid */, const uint32_t nthreads) {
   using namespace dm;
   KLOOP Rv[kp] = 0.0f;
+  float hxy[K];  // hypot(P.x, P.y) cache shared by sibling primitives (validity is tracked by the host compiler)
+  KLOOP hxy[kp] = 0.0f;
   uint32_t pc = 0;
 #define PF(k) __uint_as_float(code[pc + 1 + (k)])
 #define PU(k) (code[pc + 1 + (k)])
@@ -39,8 +41,10 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
     // that opcode/parameter fetches are scalar loads (s_load_dword*) and parameters are scalar operands.
     pc = __builtin_amdgcn_readfirstlane(pc);
     const uint32_t w = code[pc];
-    const uint32_t op = w & 0xffffu;
+    const uint32_t op = w & D_OP_MASK;
     const uint32_t slot = w >> 16;
+    const bool use_hxy = (w & D_FLAG_HXY) != 0u;   // wave-uniform
+    const bool swap_ab = (w & D_FLAG_SWAP) != 0u;  // wave-uniform
     switch (op) {
       case D_END:
         return;
@@ -87,7 +91,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         KLOOP {
           P3& p = pv[kp];
           float& R = Rv[kp];
-          float qx = hypotf_(p.x, p.y) - PF(0);
+          if (!use_hxy) hxy[kp] = hypotf_(p.x, p.y);
+          float qx = hxy[kp] - PF(0);
           R = norm2(qx, p.z) - PF(1);
         }
         pc += 3;
@@ -97,7 +102,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         KLOOP {
           P3& p = pv[kp];
           float& R = Rv[kp];
-          float dx = hypotf_(p.x, p.y) - PF(0);
+          if (!use_hxy) hxy[kp] = hypotf_(p.x, p.y);
+          float dx = hxy[kp] - PF(0);
           float dy = absf(p.z) - PF(1);
           R = minf(0.f, maxf(dx, dy)) + hypotf_(maxf(0.f, dx), maxf(0.f, dy));
         }
@@ -109,7 +115,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
           P3& p = pv[kp];
           float& R = Rv[kp];
           const float round = PF(2);
-          float dx = hypotf_(p.x, p.y) - PF(0) + round;
+          if (!use_hxy) hxy[kp] = hypotf_(p.x, p.y);
+          float dx = hxy[kp] - PF(0) + round;
           float dy = absf(p.z) - PF(1);
           R = minf(maxf(dx, dy), 0.f) + hypotf_(maxf(dx, 0.f), maxf(dy, 0.f)) - round;
         }
@@ -211,7 +218,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         KLOOP {
           P3& p = pv[kp];
           float& R = Rv[kp];
-          R = norm2(p.x, p.y) - PF(0);
+          if (!use_hxy) hxy[kp] = hypotf_(p.x, p.y);
+          R = hxy[kp] - PF(0);
         }
         pc += 2;
         break;
@@ -490,7 +498,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
           P3& p = pv[kp];
           float& R = Rv[kp];
           const float pitch = PF(0), lead = PF(1), L = PF(2), tanTaper = PF(3), halfp = PF(4);
-          float y0 = hypotf_(p.x, p.y);
+          if (!use_hxy) hxy[kp] = hypotf_(p.x, p.y);
+          float y0 = hxy[kp];
           y0 += p.z * tanTaper;
           float theta = atan2f_(p.y, p.x);
           float z = p.z + lead * theta / 6.2831853071795862f;
@@ -615,7 +624,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       // ------------------------------------------------ combine (a = saved first operand, b = R)
       case D_COMBINE_MIN: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = minf(LDSF(slot), R); } pc += 1; break; }
       case D_COMBINE_MAX: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = maxf(LDSF(slot), R); } pc += 1; break; }
-      case D_COMBINE_DIFF: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = maxf(LDSF(slot), -R); } pc += 1; break; }
+      case D_COMBINE_DIFF: { KLOOP { float& R = Rv[kp]; float a = LDSF(slot), b = R; if (swap_ab) { float t = a; a = b; b = t; } R = maxf(a, -b); } pc += 1; break; }
       case D_COMBINE_XOR: { KLOOP { float& R = Rv[kp]; float a = LDSF(slot), b = R; R = maxf(minf(a, b), -maxf(a, b)); } pc += 1; break; }
       case D_COMBINE_SUNION: {
         KLOOP {
@@ -623,6 +632,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
           float& R = Rv[kp];
           const float k = PF(0);
           float a = LDSF(slot), b = R;
+          if (swap_ab) { float t = a; a = b; b = t; }
           float h = clampf(0.5f + 0.5f * (b - a) / k, 0.f, 1.f);
           R = mixf(b, a, h) - k * h * (1.f - h);
         }
@@ -635,6 +645,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
           float& R = Rv[kp];
           const float k = PF(0);
           float a = LDSF(slot), b = R;
+          if (swap_ab) { float t = a; a = b; b = t; }
           float h = clampf(0.5f - 0.5f * (b + a) / k, 0.f, 1.f);
           R = mixf(a, -b, h) + k * h * (1.f - h);
         }
@@ -647,6 +658,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
           float& R = Rv[kp];
           const float k = PF(0);
           float a = LDSF(slot), b = R;
+          if (swap_ab) { float t = a; a = b; b = t; }
           float h = clampf(0.5f - 0.5f * (b - a) / k, 0.f, 1.f);
           R = mixf(b, a, h) + k * h * (1.f - h);
         }

@@ -21,7 +21,7 @@ ErrMismatchBufferLength = "position and distance buffer length mismatch"
 
 # every symbol include/gsdf_hip.h declares
 SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "gsdf_hip_program_destroy",
-           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations",
+           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower",
            "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3",
            "gsdf_hip_mesh_octree", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
            "gsdf_hip_mesh_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner"]
@@ -62,6 +62,7 @@ def lib():
         L.gsdf_hip_program_bounds.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.gsdf_hip_program_is2d.argtypes = [C.c_void_p]
         L.gsdf_hip_program_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.gsdf_hip_lower.argtypes = [C.POINTER(GsdfTree), C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.gsdf_hip_evaluations.restype = C.c_uint64
         L.gsdf_hip_evaluations.argtypes = [C.c_void_p]
         for f in (L.gsdf_hip_eval3, L.gsdf_hip_eval2):
@@ -86,6 +87,16 @@ def lib():
 def _check(rc):
     if rc != 0:
         raise HipError(rc, lib().gsdf_hip_last_error().decode())
+
+
+def lower(shader_or_tree):
+    """Host-only lowering of a tree to the device instruction stream: (uint32 code array, lds_slots)."""
+    tree = shader_or_tree.tree() if hasattr(shader_or_tree, "tree") else shader_or_tree
+    n, sl = C.c_uint32(), C.c_uint32()
+    _check(lib().gsdf_hip_lower(C.byref(tree), None, 0, C.byref(n), C.byref(sl)))
+    code = np.zeros(n.value, np.uint32)
+    _check(lib().gsdf_hip_lower(C.byref(tree), code.ctypes.data, n.value, C.byref(n), C.byref(sl)))
+    return code, sl.value
 
 
 def init(device=-1):

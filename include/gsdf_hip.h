@@ -64,6 +64,9 @@ int gsdf_hip_program_is2d(const gsdf_program* p);
 /* Introspection for tests/benchmarks: lowered program size (32-bit words) and LDS slots per lane. */
 int gsdf_hip_program_info(const gsdf_program* p, uint32_t* code_words, uint32_t* lds_slots);
 uint64_t gsdf_hip_evaluations(const gsdf_program* p);
+/* Host-only (runs without a GPU): lower a tree to the device instruction stream (gsdf_amd/csrc/dev_ops.h) for
+ * inspection. code_out may be NULL to query the size. */
+int gsdf_hip_lower(const gsdf_tree* tree, uint32_t* code_out, uint32_t code_cap, uint32_t* code_words, uint32_t* lds_slots);
 
 /* Host-buffer evaluation (drop-in for SDF3Compute.Evaluate). pos_stride_bytes is the distance between
  * consecutive positions: 12 for []ms3.Vec, 16 for std140 vec3 / ms3.Quat-aligned data; 8 for []ms2.Vec.
