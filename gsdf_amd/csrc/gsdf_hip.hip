@@ -362,6 +362,298 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
   }
 }
 
+// =================================================================================================
+// Dual contouring on device (glrender/dual_contour.go, dual_contour_vertexplacement.go).
+// The reference keeps a map[i3.Vec]int over a full BFS decomposition; here the lattice is a dense
+// int32 index grid in HBM (levels <= 11 -> <= 4.3 GB, trivial against 288 GB), so neighbour lookups
+// are single loads and every stage is one lane per cube / per active edge.
+// =================================================================================================
+struct DCCounters {
+  unsigned long long n_cubes, n_edges, n_tris, q_overflow, t_overflow;
+};
+
+// Stage 1 (Reset :26-83): evaluate every cube origin; keep iff |d| < 2*size (octreePrunea szMult=2, origin).
+template <int K>
+__global__ void __launch_bounds__(BLOCK, 3) dc_origin_kernel(const uint32_t* __restrict__ code_g, int nshift, float ox, float oy,
+                                                             float oz, float res, int* __restrict__ grid, Cube* __restrict__ cubes,
+                                                             unsigned long long cube_cap, DCCounters* __restrict__ ctr) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  const unsigned long long ncell = 1ull << (3 * nshift);
+  const unsigned mask = (1u << nshift) - 1u;
+  const float maxDist = res * 2;
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK * K;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK * K; base < ncell; base += step) {
+    P3 p[K];
+    float d[K];
+#pragma unroll
+    for (int kp = 0; kp < K; kp++) {
+      const uint64_t c = base + (uint64_t)kp * BLOCK + threadIdx.x;
+      const unsigned x = (unsigned)c & mask, y = (unsigned)(c >> nshift) & mask, z = (unsigned)(c >> (2 * nshift)) & mask;
+      p[kp] = P3{ox + res * (float)x, oy + res * (float)y, oz + res * (float)z};  // CubeOrigin, size = res
+    }
+    gsdf_dev::sdf_eval<K>(code, p, d, lds, BLOCK);
+#pragma unroll
+    for (int kp = 0; kp < K; kp++) {
+      const uint64_t c = base + (uint64_t)kp * BLOCK + threadIdx.x;
+      const bool valid = c < ncell;
+      const bool keep = valid && !(dm::absf(d[kp]) >= maxDist);
+      const unsigned long long slot = wave_append(keep, &ctr->n_cubes);
+      if (keep) {
+        if (slot < cube_cap) {
+          const unsigned x = (unsigned)c & mask, y = (unsigned)(c >> nshift) & mask, z = (unsigned)(c >> (2 * nshift)) & mask;
+          cubes[slot] = Cube{(uint16_t)x, (uint16_t)y, (uint16_t)z, 0};
+          grid[c] = (int)slot;
+        } else {
+          ctr->q_overflow = 1ull;
+          grid[c] = -1;
+        }
+      } else if (valid) {
+        grid[c] = -1;
+      }
+    }
+  }
+}
+
+// Stage 2 (RenderAll :85-108): origin, +x, +y, +z distances of every kept cube (one 4-point pass per
+// lane); default FinalVertex = cube origin; active edges (sign BIT differs, :261-269) are compacted.
+__global__ void __launch_bounds__(BLOCK, 3) dc_edges_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
+                                                            unsigned long long cube_cap, float ox, float oy, float oz, float res,
+                                                            float4* __restrict__ dists, float* __restrict__ fv,
+                                                            unsigned* __restrict__ edges, unsigned long long edge_cap,
+                                                            DCCounters* __restrict__ ctr) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  unsigned long long n = uniform_u64(ctr->n_cubes);
+  if (n > cube_cap) n = cube_cap;
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {
+    const uint64_t i = base + threadIdx.x;
+    const bool valid = i < n;
+    Cube c = {0, 0, 0, 0};
+    if (valid) c = cubes[i];
+    const float x0 = ox + res * (float)c.x, y0 = oy + res * (float)c.y, z0 = oz + res * (float)c.z;
+    P3 p[4] = {{x0, y0, z0}, {x0 + res, y0 + 0.f, z0 + 0.f}, {x0 + 0.f, y0 + res, z0 + 0.f}, {x0 + 0.f, y0 + 0.f, z0 + res}};
+    float d[4];
+    gsdf_dev::sdf_eval<4>(code, p, d, lds, BLOCK);
+    if (valid) {
+      dists[i] = make_float4(d[0], d[1], d[2], d[3]);
+      fv[3 * i] = x0; fv[3 * i + 1] = y0; fv[3 * i + 2] = z0;
+    }
+    const unsigned s0 = __float_as_uint(d[0]) >> 31;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const bool act = valid && ((__float_as_uint(d[1 + a]) >> 31) != s0);
+      const unsigned long long slot = wave_append(act, &ctr->n_edges);
+      if (act) {
+        if (slot < edge_cap) edges[slot] = ((unsigned)i << 2) | (unsigned)a;
+        else ctr->q_overflow = 1ull;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float dc_isect(float o, float e) { return -o / (e - o); }
+
+// Stage 3 (PlaceVertices :28-50 + gleval.NormalsCentralDiff): raw central-difference normals at the
+// linear intersection of every ACTIVE edge (inactive edges' normals are never read by the reference).
+__global__ void __launch_bounds__(BLOCK, 3) dc_normals_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
+                                                              const float4* __restrict__ dists, const unsigned* __restrict__ edges,
+                                                              unsigned long long edge_cap, float ox, float oy, float oz, float res,
+                                                              float h, float* __restrict__ nrm, DCCounters* __restrict__ ctr) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  unsigned long long n = uniform_u64(ctr->n_edges);
+  if (n > edge_cap) n = edge_cap;
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {
+    const uint64_t i = base + threadIdx.x;
+    const bool valid = i < n;
+    float px = 0, py = 0, pz = 0;
+    unsigned e = 0;
+    if (valid) {
+      e = edges[i];
+      const unsigned ci = e >> 2, a = e & 3u;
+      const Cube c = cubes[ci];
+      const float4 d = dists[ci];
+      const float t = res * dc_isect(d.x, a == 0 ? d.y : (a == 1 ? d.z : d.w));
+      px = (ox + res * (float)c.x) + (a == 0 ? t : 0.f);
+      py = (oy + res * (float)c.y) + (a == 1 ? t : 0.f);
+      pz = (oz + res * (float)c.z) + (a == 2 ? t : 0.f);
+    }
+    float out[3];
+#pragma unroll 1
+    for (int dim = 0; dim < 3; dim++) {
+      P3 ab[2] = {{px + (dim == 0 ? h : 0.f), py + (dim == 1 ? h : 0.f), pz + (dim == 2 ? h : 0.f)},
+                  {px - (dim == 0 ? h : 0.f), py - (dim == 1 ? h : 0.f), pz - (dim == 2 ? h : 0.f)}};
+      float dd[2];
+      gsdf_dev::sdf_eval<2>(code, ab, dd, lds, BLOCK);
+      const float v = dd[0] - dd[1];
+      if (dim == 0) out[0] = v; else if (dim == 1) out[1] = v; else out[2] = v;
+    }
+    if (valid) {
+      const size_t o = ((size_t)(e >> 2) * 3 + (e & 3u)) * 3;
+      nrm[o] = out[0]; nrm[o + 1] = out[1]; nrm[o + 2] = out[2];
+    }
+  }
+}
+
+#define DC_ROWS 18  // <= 3 own + 12 contributed (own edges appear again among them) + 3 regularisation rows
+#define DC_BLOCK 64
+// Stage 4 (PlaceVertices :52-141, leastSquaresMGS64 :152-223): per cube, rows = own active edges, then the
+// edges of the (up to 12) contributing cubes in lattice order (z,y,x) and axis order, 3 regularisation rows;
+// float64 modified Gram-Schmidt with the rows staged in LDS ([row][col][lane]; zero rows are exact no-ops).
+__global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restrict__ cubes, unsigned long long cube_cap,
+                                                            const float4* __restrict__ dists, const int* __restrict__ grid,
+                                                            const float* __restrict__ nrm, int nshift, float ox, float oy, float oz,
+                                                            float res, float sqrtLambda, float* __restrict__ fv,
+                                                            DCCounters* __restrict__ ctr) {
+  __shared__ double sQ[DC_ROWS][3][DC_BLOCK];
+  __shared__ double sB[DC_ROWS][DC_BLOCK];
+  unsigned long long n = uniform_u64(ctr->n_cubes);
+  if (n > cube_cap) n = cube_cap;
+  const int nn = 1 << nshift;
+  const unsigned t = threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * DC_BLOCK;
+  for (uint64_t base = (uint64_t)blockIdx.x * DC_BLOCK; base < n; base += step) {
+    const uint64_t i = base + t;
+    if (i >= n) continue;  // no block-level sync below: each lane owns column t of the LDS arrays
+    const Cube c = cubes[i];
+    const float cox = ox + res * (float)c.x, coy = oy + res * (float)c.y, coz = oz + res * (float)c.z;
+    const float invRes = 1.0f / res;
+    int nr = 0, nnb = 0;
+    float mx = 0.f, my = 0.f, mz = 0.f;
+    auto add_row = [&](float bx, float by, float bz, float nx, float ny, float nz) {
+      const float qx = invRes * (bx - cox), qy = invRes * (by - coy), qz = invRes * (bz - coz);
+      sQ[nr][0][t] = (double)nx; sQ[nr][1][t] = (double)ny; sQ[nr][2][t] = (double)nz;
+      sB[nr][t] = (double)(nx * qx + ny * qy + nz * qz);
+      mx = mx + bx; my = my + by; mz = mz + bz;
+      nr++;
+    };
+    auto edge_row = [&](unsigned ci, int a) {
+      const Cube u = cubes[ci];
+      const float4 d = dists[ci];
+      const float tt = res * dc_isect(d.x, a == 0 ? d.y : (a == 1 ? d.z : d.w));
+      const float ux = ox + res * (float)u.x, uy = oy + res * (float)u.y, uz = oz + res * (float)u.z;
+      const size_t o = ((size_t)ci * 3 + (size_t)a) * 3;
+      add_row(ux + (a == 0 ? tt : 0.f), uy + (a == 1 ? tt : 0.f), uz + (a == 2 ? tt : 0.f), nrm[o], nrm[o + 1], nrm[o + 2]);
+    };
+    // neighbour records first decide whether this cube is placed at all (len(cube.Neighbors) == 0 -> skip)
+    unsigned contrib[12];
+    unsigned char caxis[12];
+    for (int dz = 0; dz < 2; dz++)
+      for (int dy = 0; dy < 2; dy++)
+        for (int dx = 0; dx < 2; dx++) {
+          const int ux = c.x + dx, uy = c.y + dy, uz = c.z + dz;
+          if (ux >= nn || uy >= nn || uz >= nn) continue;
+          const int ui = grid[((size_t)uz * nn + uy) * nn + ux];
+          if (ui < 0) continue;
+          const float4 d = dists[ui];
+          const unsigned s0 = __float_as_uint(d.x) >> 31;
+          if (dx == 0 && ((__float_as_uint(d.y) >> 31) != s0)) { contrib[nnb] = (unsigned)ui; caxis[nnb++] = 0; }
+          if (dy == 0 && ((__float_as_uint(d.z) >> 31) != s0)) { contrib[nnb] = (unsigned)ui; caxis[nnb++] = 1; }
+          if (dz == 0 && ((__float_as_uint(d.w) >> 31) != s0)) { contrib[nnb] = (unsigned)ui; caxis[nnb++] = 2; }
+        }
+    if (nnb == 0) continue;
+    {
+      const float4 d = dists[i];
+      const unsigned s0 = __float_as_uint(d.x) >> 31;
+      if ((__float_as_uint(d.y) >> 31) != s0) edge_row((unsigned)i, 0);
+      if ((__float_as_uint(d.z) >> 31) != s0) edge_row((unsigned)i, 1);
+      if ((__float_as_uint(d.w) >> 31) != s0) edge_row((unsigned)i, 2);
+    }
+    for (int k = 0; k < nnb; k++) edge_row(contrib[k], caxis[k]);
+    const float im = 1.f / (float)nr;
+    const float bsx = invRes * (im * mx - cox), bsy = invRes * (im * my - coy), bsz = invRes * (im * mz - coz);
+    sQ[nr][0][t] = (double)sqrtLambda; sQ[nr][1][t] = 0.0; sQ[nr][2][t] = 0.0; sB[nr][t] = (double)(sqrtLambda * bsx); nr++;
+    sQ[nr][0][t] = 0.0; sQ[nr][1][t] = (double)sqrtLambda; sQ[nr][2][t] = 0.0; sB[nr][t] = (double)(sqrtLambda * bsy); nr++;
+    sQ[nr][0][t] = 0.0; sQ[nr][1][t] = 0.0; sQ[nr][2][t] = (double)sqrtLambda; sB[nr][t] = (double)(sqrtLambda * bsz); nr++;
+    const int K = nr;
+    double R[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int j = 0; j < 3; j++) {
+      for (int ii = 0; ii < j; ii++) {
+        double dot = 0;
+        for (int k = 0; k < K; k++) dot += sQ[k][ii][t] * sQ[k][j][t];
+        R[ii][j] = dot;
+        for (int k = 0; k < K; k++) sQ[k][j][t] -= dot * sQ[k][ii][t];
+      }
+      double nsq = 0;
+      for (int k = 0; k < K; k++) nsq += sQ[k][j][t] * sQ[k][j][t];
+      const double norm = __builtin_sqrt(nsq);
+      R[j][j] = norm;
+      if (norm > 1e-14) {
+        const double inv = 1.0 / norm;
+        for (int k = 0; k < K; k++) sQ[k][j][t] *= inv;
+      }
+    }
+    double Qtb[3] = {0, 0, 0};
+    for (int j = 0; j < 3; j++)
+      for (int k = 0; k < K; k++) Qtb[j] += sQ[k][j][t] * sB[k][t];
+    double x[3];
+    for (int ii = 2; ii >= 0; ii--) {
+      x[ii] = Qtb[ii];
+      for (int k = ii + 1; k < 3; k++) x[ii] -= R[ii][k] * x[k];
+      if (R[ii][ii] > 1e-14) x[ii] /= R[ii][ii];
+      else x[ii] = 0;
+    }
+    const float xf = dm::clampf((float)x[0], -0.1f, 1.1f), yf = dm::clampf((float)x[1], -0.1f, 1.1f), zf = dm::clampf((float)x[2], -0.1f, 1.1f);
+    fv[3 * i] = res * xf + cox; fv[3 * i + 1] = res * yf + coy; fv[3 * i + 2] = res * zf + coz;
+  }
+}
+
+// Stage 5 (RenderAll :143-219): one quad (2 triangles) per active edge whose 4 surrounding cubes exist.
+__global__ void __launch_bounds__(BLOCK) dc_quads_kernel(const Cube* __restrict__ cubes, const float4* __restrict__ dists,
+                                                         const unsigned* __restrict__ edges, unsigned long long edge_cap,
+                                                         const int* __restrict__ grid, const float* __restrict__ fv, int nshift,
+                                                         float* __restrict__ tris, unsigned long long tri_cap,
+                                                         DCCounters* __restrict__ ctr) {
+  unsigned long long n = uniform_u64(ctr->n_edges);
+  if (n > edge_cap) n = edge_cap;
+  const int nn = 1 << nshift;
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {
+    const uint64_t i = base + threadIdx.x;
+    bool ok = i < n;
+    int q[4] = {-1, -1, -1, -1};
+    bool flip = false;
+    if (ok) {
+      const unsigned e = edges[i];
+      const unsigned ci = e >> 2, a = e & 3u;
+      const Cube c = cubes[ci];
+      const float4 d = dists[ci];
+      flip = ((a == 0 ? d.y : (a == 1 ? d.z : d.w)) - d.x) < 0.f;
+      // EdgeNeighborsX/Y/Z (:271-287): offsets in cube units
+      const int off[3][4][3] = {{{0, -1, -1}, {0, 0, -1}, {0, 0, 0}, {0, -1, 0}},
+                                {{-1, 0, -1}, {-1, 0, 0}, {0, 0, 0}, {0, 0, -1}},
+                                {{-1, -1, 0}, {0, -1, 0}, {0, 0, 0}, {-1, 0, 0}}};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int x = c.x + off[a][k][0], y = c.y + off[a][k][1], z = c.z + off[a][k][2];
+        int idx = -1;
+        if (x >= 0 && y >= 0 && z >= 0 && x < nn && y < nn && z < nn) idx = grid[((size_t)z * nn + y) * nn + x];
+        q[k] = idx;
+        ok = ok && idx >= 0;
+      }
+    }
+    const unsigned long long slot = wave_append(ok, &ctr->n_tris);
+    if (ok) {
+      if (2 * slot + 2 <= tri_cap) {
+        int o[4] = {q[0], q[1], q[2], q[3]};
+        if (flip) { o[0] = q[3]; o[1] = q[2]; o[2] = q[1]; o[3] = q[0]; }
+        float* dst = tris + 18 * slot;
+        const int order[6] = {0, 1, 2, 2, 3, 0};
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const float* v = fv + 3 * (size_t)o[order[k]];
+          dst[3 * k] = v[0]; dst[3 * k + 1] = v[1]; dst[3 * k + 2] = v[2];
+        }
+      } else {
+        ctr->t_overflow = 1ull;
+      }
+    }
+  }
+}
+
 // STL records (stl.go:15-62): one wave stages 64 x 50-byte records in LDS, then stores dwords.
 __global__ void __launch_bounds__(BLOCK) stl_kernel(const float* __restrict__ tris, uint64_t n, uint8_t* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) uint8_t stage[BLOCK * 50];
@@ -847,6 +1139,110 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   m->st.ms_total = (double)ms01 + (double)ms12;
   p->evals += m->st.evals;
   p->last_tris = hc.n_tris;
+  *out = m;
+  return GSDF_OK;
+#undef HIP_TRYM
+}
+
+// glrender.DualContourRenderer.Reset + RenderAll with DualContourLeastSquares on device.
+extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chiseled, void* stream, gsdf_mesh** out) {
+  if (!p || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
+  if (!(res > 0) || std::isnan(res) || std::isinf(res)) return fail(GSDF_ERR_RESOLUTION, "invalid renderer cube resolution");
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  // Reset (dual_contour.go:26-41): bounds shifted by -res/2, makeICube
+  const float sub = res / 2;
+  float mn[3], mx[3];
+  for (int a = 0; a < 3; a++) { mn[a] = p->prog.bb[a] + -sub; mx[a] = p->prog.bb[a + 3] + -sub; }
+  const float longAxis = fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));
+  const int levels = (int)std::ceil((float)std::log2((double)(longAxis / res))) + 1;
+  if (levels <= 1) return fail(GSDF_ERR_RESOLUTION, "resolution not fine enough for marching cubes");
+  if (levels > 11) return fail(GSDF_ERR_RESOLUTION, "dual contouring lattice too large: more than 11 octree levels");
+  const int nshift = levels - 1;
+  const uint64_t ncell = (uint64_t)1 << (3 * nshift);
+  const float ox = mn[0], oy = mn[1], oz = mn[2];
+
+  gsdf_mesh* m = new (std::nothrow) gsdf_mesh();
+  if (!m) return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory");
+  m->device = p->device; m->stream = s;
+  m->st.levels = levels; m->st.res = res;
+  m->st.origin[0] = ox; m->st.origin[1] = oy; m->st.origin[2] = oz;
+  auto bail = [&](int code) { gsdf_hip_mesh_destroy(m); return code; };
+#define HIP_TRYM(expr)                                                                                          \
+  do {                                                                                                          \
+    hipError_t _e = (expr);                                                                                     \
+    if (_e != hipSuccess) return bail(fail(GSDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
+  } while (0)
+  for (auto& e : p->ev)
+    if (!e) HIP_TRYM(hipEventCreate(&e));
+  DevBuf grid, ctrb, distb, fvb, nrmb, edgeb;
+  HIP_TRYM(grid.alloc(ncell * sizeof(int)));
+  HIP_TRYM(ctrb.alloc(sizeof(DCCounters)));
+  DCCounters* d_ctr = (DCCounters*)ctrb.p;
+  const int lk = p->batch_k();
+  uint64_t ccap = 1u << 20;
+  DCCounters hc{};
+  const float h = (chiseled ? (float)1e-4 : (float)2e-8) * 0.5f;  // NormalsCentralDiff: step *= 0.5
+  const float sqrtLambda = chiseled ? (float)(std::sqrt(1e-5) * 1e-4) : (float)std::sqrt(1e-5);
+  for (int attempt = 0;; attempt++) {
+    if (ccap > ncell) ccap = ncell;
+    const uint64_t ecap = 3 * ccap, tcap = 2 * ecap;
+    HIP_TRYM(p->q0.ensure(ccap * sizeof(Cube)));
+    DevBuf d2, f2, n2, e2;
+    HIP_TRYM(d2.alloc(ccap * sizeof(float4)));
+    HIP_TRYM(f2.alloc(ccap * 12));
+    HIP_TRYM(n2.alloc(ccap * 36));
+    HIP_TRYM(e2.alloc(ecap * sizeof(unsigned)));
+    if (!m->d_tris || m->cap < tcap) {
+      pool_give(p->device, m->d_tris, m->cap);
+      m->d_tris = pool_take(p->device, tcap, &m->cap);
+      if (!m->d_tris) { HIP_TRYM(hipMalloc((void**)&m->d_tris, tcap * 36)); m->cap = tcap; }
+    }
+    HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(DCCounters), s));
+    HIP_TRYM(hipEventRecord(p->ev[0], s));
+    const unsigned g1 = grid_for((ncell + lk - 1) / lk, p->num_cu, 8);
+#define LAUNCH_O(KK) hipLaunchKernelGGL((dc_origin_kernel<KK>), dim3(g1), dim3(BLOCK), p->lds_bytes(KK), s, p->d_code, nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, d_ctr)
+    if (lk == 4) LAUNCH_O(4); else if (lk == 2) LAUNCH_O(2); else LAUNCH_O(1);
+#undef LAUNCH_O
+    HIP_TRYM(hipGetLastError());
+    if (p->lds_bytes(4) > 150 * 1024) return bail(fail(GSDF_ERR_BAD_TREE, "tree needs too much LDS scratch for the dual contouring edge pass"));
+    hipLaunchKernelGGL(dc_edges_kernel, dim3(grid_for(ccap, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(4), s, p->d_code, (const Cube*)p->q0.p,
+                       (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, d_ctr);
+    HIP_TRYM(hipGetLastError());
+    hipLaunchKernelGGL(dc_normals_kernel, dim3(grid_for(ecap, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(2), s, p->d_code, (const Cube*)p->q0.p,
+                       (const float4*)d2.p, (const unsigned*)e2.p, (unsigned long long)ecap, ox, oy, oz, res, h, (float*)n2.p, d_ctr);
+    HIP_TRYM(hipGetLastError());
+    hipLaunchKernelGGL(dc_place_kernel, dim3(grid_for(ccap * 4, p->num_cu, 16)), dim3(DC_BLOCK), 0, s, (const Cube*)p->q0.p,
+                       (unsigned long long)ccap, (const float4*)d2.p, (const int*)grid.p, (const float*)n2.p, nshift, ox, oy, oz, res,
+                       sqrtLambda, (float*)f2.p, d_ctr);
+    HIP_TRYM(hipGetLastError());
+    hipLaunchKernelGGL(dc_quads_kernel, dim3(grid_for(ecap, p->num_cu, 8)), dim3(BLOCK), 0, s, (const Cube*)p->q0.p, (const float4*)d2.p,
+                       (const unsigned*)e2.p, (unsigned long long)ecap, (const int*)grid.p, (const float*)f2.p, nshift, m->d_tris,
+                       (unsigned long long)m->cap, d_ctr);
+    HIP_TRYM(hipGetLastError());
+    HIP_TRYM(hipEventRecord(p->ev[1], s));
+    HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));
+    HIP_TRYM(hipStreamSynchronize(s));
+    if (hc.q_overflow || hc.t_overflow) {
+      if (attempt >= 8 || ccap >= ncell) return bail(fail(GSDF_ERR_CAPACITY, "dual contouring queue capacity exceeded"));
+      ccap *= 8;
+      continue;
+    }
+    break;
+  }
+  float ms = 0;
+  HIP_TRYM(hipEventElapsedTime(&ms, p->ev[0], p->ev[1]));
+  m->st.n_tris = 2 * hc.n_tris;  // quads -> 2 triangles
+  m->st.evals = ncell + 4 * hc.n_cubes + 6 * hc.n_edges;
+  m->st.evals_prune = ncell;
+  m->st.evals_leaf = 4 * hc.n_cubes + 6 * hc.n_edges;
+  m->st.pruned_leaves = ncell - hc.n_cubes;
+  m->st.leaf_cubes = hc.n_cubes;
+  m->st.active_leaves = hc.n_edges;
+  m->st.ms_total = ms;
+  p->evals += m->st.evals;
   *out = m;
   return GSDF_OK;
 #undef HIP_TRYM

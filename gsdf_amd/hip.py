@@ -23,7 +23,7 @@ ErrMismatchBufferLength = "position and distance buffer length mismatch"
 SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "gsdf_hip_program_destroy",
            "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower",
            "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3",
-           "gsdf_hip_mesh_octree", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
+           "gsdf_hip_mesh_octree", "gsdf_hip_mesh_dualcontour", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
            "gsdf_hip_mesh_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner"]
 
 
@@ -71,6 +71,7 @@ def lib():
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         L.gsdf_hip_normals3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]
         L.gsdf_hip_mesh_octree.argtypes = [C.c_void_p, C.c_float, C.POINTER(MeshOpts), C.POINTER(C.c_void_p)]
+        L.gsdf_hip_mesh_dualcontour.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.gsdf_hip_mesh_stats_get.argtypes = [C.c_void_p, C.POINTER(MeshStats)]
         L.gsdf_hip_mesh_read.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         L.gsdf_hip_mesh_dev_tris.restype = C.c_void_p
@@ -241,3 +242,26 @@ class OctreeHIP:
         buf = np.empty(84 + 50 * n, np.uint8)
         _check(lib().gsdf_hip_mesh_stl(self._mesh, buf.ctypes.data, buf.size))
         return buf.tobytes()
+
+
+class DualContourHIP(OctreeHIP):
+    """glrender.DualContourRenderer with DualContourLeastSquares on device (Reset + RenderAll)."""
+
+    def __init__(self, sdf, res, chiseled=False, stream=None):
+        self.sdf = sdf
+        self._mesh = None
+        self._cursor = 0
+        self._chiseled = bool(chiseled)
+        self._stream = stream
+        self.Reset(sdf, res)
+
+    def Reset(self, sdf, res):
+        self._free()
+        self.sdf = sdf
+        m = C.c_void_p()
+        _check(lib().gsdf_hip_mesh_dualcontour(sdf._h, np.float32(res), int(self._chiseled), self._stream, C.byref(m)))
+        self._mesh = m
+        self._cursor = 0
+        st = MeshStats()
+        _check(lib().gsdf_hip_mesh_stats_get(m, C.byref(st)))
+        self.stats = st

@@ -16,6 +16,8 @@
  *   gsdf_hip_normals3          gleval.NormalsCentralDiff              gleval/gleval.go:53-108
  *   gsdf_hip_mesh_octree       glrender.NewOctreeRenderer + RenderAll glrender/octreerenderer.go:43-178,
  *                              (octree prune + marching cubes on device) glrender/marchcubes.go:14-98
+ *   gsdf_hip_mesh_dualcontour  glrender.DualContourRenderer.Reset/RenderAll + DualContourLeastSquares
+ *                                                                      glrender/dual_contour.go:26-219, dual_contour_vertexplacement.go:26-223
  *   gsdf_hip_mesh_read         (*Octree).ReadTriangles drain          glrender/octreerenderer.go:131-178
  *   gsdf_hip_mesh_stl          glrender.WriteBinarySTL                glrender/stl.go:15-62
  *
@@ -106,6 +108,9 @@ typedef struct gsdf_mesh_stats {
 } gsdf_mesh_stats;
 
 int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_opts* opts, gsdf_mesh** out);
+/* Dual contouring (least-squares vertex placement; chiseled = DualContourLeastSquares.Chiseled). The result is a
+ * gsdf_mesh like the octree mesher's (stats: leaf_cubes = kept cubes, active_leaves = active edges). */
+int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chiseled, void* stream, gsdf_mesh** out);
 int gsdf_hip_mesh_stats_get(const gsdf_mesh* m, gsdf_mesh_stats* st);
 /* Copy triangles [first, first+count) to host memory: 9 floats (36 B) each = ms3.Triangle. */
 int gsdf_hip_mesh_read(const gsdf_mesh* m, uint64_t first, uint64_t count, float* dst);

@@ -40,6 +40,8 @@ def lib():
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.orc_render_flat.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.POINTER(_Mesh)]
         L.orc_render_octree.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.POINTER(_Mesh)]
+        L.orc_render_dualcontour.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(_Mesh)]
+        L.orc_lsq_mgs64.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_mesh_free.argtypes = [C.POINTER(_Mesh)]
         L.orc_stl_size.restype = C.c_size_t
         L.orc_stl_size.argtypes = [C.c_uint64]
@@ -127,6 +129,15 @@ class OracleSDF:
         self._L.orc_mesh_free(C.byref(m))
         return r
 
+    def render_dualcontour(self, res, chiseled=False):
+        m = _Mesh()
+        err = self._L.orc_render_dualcontour(self._h, np.float32(res), int(chiseled), C.byref(m))
+        if err:
+            raise RuntimeError(f"oracle dual contour renderer error {err}")
+        r = MeshResult(m)
+        self._L.orc_mesh_free(C.byref(m))
+        return r
+
     def normals_central_diff(self, pos, step):
         pos = np.ascontiguousarray(pos, np.float32)
         nrm = np.empty_like(pos)
@@ -173,3 +184,12 @@ def math_apply(name, x, y=None):
     out = np.empty_like(x)
     lib().orc_math_apply(MATH_FN[name], x.ctypes.data, y.ctypes.data, out.ctypes.data, x.size)
     return out
+
+
+def lsq_mgs64(A, b):
+    """leastSquaresMGS64 (dual_contour_vertexplacement.go:152-223): float32 rows in, float32[3] out."""
+    A = np.ascontiguousarray(A, np.float32).reshape(-1, 3)
+    b = np.ascontiguousarray(b, np.float32)
+    x = np.zeros(3, np.float32)
+    lib().orc_lsq_mgs64(A.ctypes.data, b.ctypes.data, A.shape[0], x.ctypes.data)
+    return x

@@ -146,3 +146,35 @@ def test_full_size_npt_flange_resdiv1600(gpu):
     # every vertex lies on a leaf-cube edge of the lattice: within res of the surface
     d = OracleSDF(s.tree()).Evaluate(t.reshape(-1, 3)[::997])
     assert np.abs(d).max() < float(res)
+
+
+# ---------------- dual contouring on device ----------------
+@pytest.mark.parametrize("chiseled", [False, True])
+def test_dualcontour_identical_to_oracle(gpu, chiseled):
+    b = Builder()
+    cases = [(b.NewSphere(1.0), 1.0 / 8), (b.NewBox(2, 2, 2, 0), 2.0 / 8), (b.Scene("bolt"), 0.5), (b.Scene("npt-flange"), 0.9),
+             (b.Scene("knurled-cylinder"), 0.8)]
+    for sh, res in cases:
+        res = np.float32(res)
+        dc = gpu.DualContourHIP(gpu.SDF3HIP(sh), res, chiseled=chiseled)
+        ref = OracleSDF(sh.tree()).render_dualcontour(res, chiseled)
+        assert dc.stats.levels == ref.levels
+        assert dc.n_tris() == ref.n_tris, (sh, dc.n_tris(), ref.n_tris)
+        tg, tc = _sorted(dc.RenderAll()), _sorted(ref.tris)
+        assert (tg.view(np.uint32) == tc.view(np.uint32)).all(), sh   # float64 QR reproduced bit for bit
+        assert dc.stats.evals == ref.evals
+
+
+def test_dualcontour_reference_tolerances(gpu):
+    # glrender/dual_contour_test.go:140-295 on the device output
+    b = Builder()
+    for sh, res in ((b.NewSphere(1.0), 1.0 / 8), (b.NewBox(2, 2, 2, 0), 2.0 / 8)):
+        dc = gpu.DualContourHIP(gpu.SDF3HIP(sh), np.float32(res))
+        v = np.unique(dc.RenderAll().reshape(-1, 3), axis=0)
+        d = np.abs(gpu.SDF3HIP(sh).Evaluate(v))
+        assert d.max() <= 1.5 * res and d.mean() <= 1.5 * res / 4
+    fine = gpu.DualContourHIP(gpu.SDF3HIP(b.Scene("npt-flange")), np.float32(0.25))  # 9 levels: 16.7 M lattice cells
+    assert fine.n_tris() > 100000 and fine.stats.levels == 9
+    assert len(fine.WriteBinarySTL()) == 84 + 50 * fine.n_tris()
+    with pytest.raises(gpu.HipError):
+        gpu.DualContourHIP(gpu.SDF3HIP(b.NewSphere(1)), np.float32(0.0005))  # > 11 levels

@@ -170,3 +170,55 @@ def test_normals_central_diff():
     n = sdf.normals_central_diff(p, 1e-3)
     u = n / np.linalg.norm(n, axis=1, keepdims=True)
     np.testing.assert_allclose(u, p / np.linalg.norm(p, axis=1, keepdims=True), atol=2e-3)
+
+
+# ---------------- dual contouring (glrender/dual_contour_test.go) ----------------
+def test_qef_solver_kats():
+    # TestQEFSolver (:20-78): three orthogonal planes meet at (0.5,0.5,0.5)
+    A = np.eye(3, dtype=np.float32)
+    b = np.float32([0.5, 0.5, 0.5])
+    np.testing.assert_allclose(oracle.lsq_mgs64(A, b), [0.5, 0.5, 0.5], atol=1e-4)
+    # TestQEFSolverDiagonalPlanes (:81-136): planes through (1,1,1), solved relative to cube origin (.5,.5,.5)
+    n = np.float32([[1, 1, 0], [0, 1, 1], [1, 0, 1]]) / np.float32(np.sqrt(2))
+    q = np.float32([0.5, 0.5, 0.5])
+    x = oracle.lsq_mgs64(n, n @ q)
+    np.testing.assert_allclose(x + 0.5, [1, 1, 1], atol=1e-3)
+    # rank-deficient system: fewer than 3 rows returns zero (K < 3), degenerate columns give 0 not NaN
+    assert (oracle.lsq_mgs64(np.float32([[1, 0, 0], [1, 0, 0]]), np.float32([1, 1])) == 0).all()
+    x = oracle.lsq_mgs64(np.float32([[1, 0, 0], [1, 0, 0], [0, 1, 0]]), np.float32([1, 1, 2]))
+    assert np.isfinite(x).all() and abs(x[0] - 1) < 1e-6 and abs(x[1] - 2) < 1e-6 and x[2] == 0
+
+
+def _dc_surface_stats(shader, res, chiseled=False):
+    m = OracleSDF(shader.tree()).render_dualcontour(np.float32(res), chiseled)
+    v = np.unique(m.tris.reshape(-1, 3), axis=0)
+    d = np.abs(OracleSDF(shader.tree()).Evaluate(v))
+    return m, float(d.max()), float(d.mean())
+
+
+def test_dualcontour_sphere_vertices_on_surface():
+    # TestDualContourSphereVerticesOnSurface (:140-220): r=1, res=1/8: max <= 1.5 res, avg <= 0.375 res
+    b = Builder()
+    res = 1.0 / 8
+    m, mx, avg = _dc_surface_stats(b.NewSphere(1.0), res)
+    assert m.n_tris > 0 and m.n_tris % 2 == 0
+    assert mx <= 1.5 * res and avg <= 1.5 * res / 4
+
+
+def test_dualcontour_box_vertices_on_surface():
+    # TestDualContourBoxVerticesOnSurface (:224-295): 2x2x2 box, res = 2/8
+    b = Builder()
+    res = 2.0 / 8
+    m, mx, avg = _dc_surface_stats(b.NewBox(2, 2, 2, 0), res)
+    assert m.n_tris > 0
+    assert mx <= 1.5 * res and avg <= 1.5 * res / 4
+    # chiseled placement recovers the sharp box edges almost exactly
+    _, mxc, _ = _dc_surface_stats(b.NewBox(2, 2, 2, 0), res, chiseled=True)
+    assert mxc < 1e-3
+
+
+def test_dualcontour_bolt_renders():
+    # TestDualRender (glrender_test.go:22-53): the M3 bolt at res 0.5 produces triangles
+    b = Builder()
+    m = OracleSDF(b.Scene("bolt").tree()).render_dualcontour(np.float32(0.5))
+    assert m.n_tris > 0 and np.isfinite(m.tris).all()
