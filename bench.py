@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--scene", default="npt-flange")
     ap.add_argument("--cpu-resdiv", type=int, default=0, help="resdiv of the bounded CPU sample (0 = pick ~10-30 s of CPU work from the core count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--share-corners", action="store_true", help="evaluate each bitwise-distinct lattice corner of a brick once (same triangles, fewer evals)")
     args = ap.parse_args()
 
     import numpy as np
@@ -98,7 +99,7 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        oc = hip.OctreeHIP(sdf, res, shard_rank=rank, shard_count=world)
+        oc = hip.OctreeHIP(sdf, res, shard_rank=rank, shard_count=world, share_corners=args.share_corners)
         gathered = None
         if dist is not None:
             from gsdf_amd.gather import all_gatherv_triangles
@@ -147,7 +148,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"examples/{args.scene} resdiv {args.resdiv}: octree prune + marching cubes on device "
                                    f"(res {float(res):.7f}, {st.levels} levels)",
-                       "sharding": "octree bricks round-robin, RCCL all-gatherv of triangles" if world > 1 else "single GPU"},
+                       "sharding": "octree bricks by coordinate hash, RCCL all-gatherv of triangles" if world > 1 else "single GPU",
+                       "leaf_corners": "shared (distinct lattice points once)" if args.share_corners else "8 per leaf (as the reference)"},
             "triangles_per_s": tris_all / dt,
             "triangles_per_step": tris_all / args.steps, "evals_per_step": evals_all / args.steps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -101,6 +101,7 @@ struct MeshCounters {
   unsigned long long overflow;             // triangle buffer overflow flag
   unsigned long long n_cont;               // leaves whose wave went on to the remaining corners
   unsigned long long q_overflow;           // cube queue capacity exceeded
+  unsigned long long n_points;             // lattice points evaluated by leaf_brick_kernel
 };
 
 // wave64 compaction: returns the global slot for lanes with keep=true (others undefined).
@@ -199,6 +200,100 @@ __device__ __forceinline__ void mc_interp(float ax, float ay, float az, float bx
 
 #define TRI_STAGE 256  // triangles staged in LDS per workgroup before one coalesced flush (9 KB)
 
+// Marching cubes of one leaf per lane + block-wide triangle emission (shared by both leaf kernels).
+// vslot: the lane's 8 corner distances in its LDS column; index: the 8-bit inside mask (0 = no triangles).
+// Block-uniform control flow: every thread of the workgroup must call this the same number of times.
+template <typename CornerDist>
+__device__ __forceinline__ void mc_emit_block(unsigned index, float x0, float y0, float z0, float x1, float y1, float z1,
+                                              CornerDist vdist, const int8_t* s_tri, float* s_stage, unsigned* s_misc,
+                                              unsigned long long* s_base, float* __restrict__ tris, uint64_t tri_cap,
+                                              MeshCounters* __restrict__ ctr) {
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned nt = 0;
+  {
+    const int8_t* row = s_tri + index * 16;
+    while (nt < 5 && row[3 * nt] >= 0) nt++;
+  }
+  // block exclusive scan of nt: wave scan + 4 wave totals through LDS
+  unsigned incl = nt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned v = __shfl_up(incl, off, 64);
+    if (lane >= (unsigned)off) incl += v;
+  }
+  if (lane == 63) s_misc[wave] = incl;
+  __syncthreads();  // (A)
+  const unsigned w0 = s_misc[0], w1 = s_misc[1], w2 = s_misc[2], w3 = s_misc[3];
+  const unsigned total = w0 + w1 + w2 + w3;
+  const unsigned wpre = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
+  unsigned cur = s_misc[4];
+  const bool direct = total > TRI_STAGE;  // block-uniform
+  unsigned long long gbase = 0;
+  if (!direct && cur + total > TRI_STAGE) {  // flush the stage first (block-uniform)
+    if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)cur);
+    __syncthreads();
+    const unsigned long long fb = *s_base;
+    if (fb + cur <= tri_cap) {
+      float* dst = tris + fb * 9;
+      for (unsigned k = threadIdx.x; k < cur * 9; k += BLOCK) dst[k] = s_stage[k];
+    } else if (threadIdx.x == 0) {
+      ctr->overflow = 1ull;
+    }
+    __syncthreads();
+    cur = 0;
+  }
+  if (direct) {
+    if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)total);
+    __syncthreads();
+    gbase = *s_base;
+    if (gbase + total > tri_cap) {
+      if (threadIdx.x == 0) ctr->overflow = 1ull;
+      nt = 0;
+    }
+  }
+  if (nt) {
+    const unsigned first = wpre + (incl - nt);
+    float* dst = direct ? (tris + (gbase + first) * 9) : (s_stage + (size_t)(cur + first) * 9);
+    const int8_t* row = s_tri + index * 16;
+    for (unsigned t = 0; t < nt; t++) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int e = row[3 * t + (2 - k)];  // reversed winding (marchcubes.go:64-68)
+        const unsigned a = GSDF_MC_PAIR_A(e), b = GSDF_MC_PAIR_B(e);
+        const float va = vdist(a), vb = vdist(b);
+        const float pax = ((a ^ (a >> 1)) & 1u) ? x1 : x0, pay = ((a >> 1) & 1u) ? y1 : y0, paz = ((a >> 2) & 1u) ? z1 : z0;
+        const float pbx = ((b ^ (b >> 1)) & 1u) ? x1 : x0, pby = ((b >> 1) & 1u) ? y1 : y0, pbz = ((b >> 2) & 1u) ? z1 : z0;
+        float rx, ry, rz;
+        mc_interp(pax, pay, paz, pbx, pby, pbz, va, vb, rx, ry, rz);
+        dst[9 * t + 3 * k + 0] = rx;
+        dst[9 * t + 3 * k + 1] = ry;
+        dst[9 * t + 3 * k + 2] = rz;
+      }
+    }
+  }
+  __syncthreads();  // (B)
+  if (threadIdx.x == 0 && !direct) s_misc[4] = cur + total;
+}
+
+// Final flush of the LDS triangle stage (all threads of the workgroup).
+__device__ __forceinline__ void mc_final_flush(float* s_stage, unsigned* s_misc, unsigned long long* s_base,
+                                               float* __restrict__ tris, uint64_t tri_cap, MeshCounters* __restrict__ ctr) {
+  __syncthreads();
+  const unsigned cur = s_misc[4];
+  if (cur) {
+    if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)cur);
+    __syncthreads();
+    const unsigned long long fb = *s_base;
+    if (fb + cur <= tri_cap) {
+      float* dst = tris + fb * 9;
+      for (unsigned k = threadIdx.x; k < cur * 9; k += BLOCK) dst[k] = s_stage[k];
+    } else if (threadIdx.x == 0) {
+      ctr->overflow = 1ull;
+    }
+  }
+}
+
+
 // Leaf kernel: one lane per leaf cube of every surviving level-lq cube (64 leaves of a level-3 cube
 // = one wave). Corner 0 first; the wave runs the other 7 corners only if some lane passes the
 // reference's |d0| <= 2*sqrt3*res test (marchcubes.go:20-23). Marching cubes reads the triangle
@@ -276,89 +371,126 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
       }
     }
     if (!pass) index = 0;
-    unsigned nt = 0;
-    {
-      const int8_t* row = s_tri + index * 16;
-      while (nt < 5 && row[3 * nt] >= 0) nt++;
-    }
-    // block exclusive scan of nt: wave scan + 4 wave totals through LDS
-    unsigned incl = nt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      unsigned v = __shfl_up(incl, off, 64);
-      if (lane >= (unsigned)off) incl += v;
-    }
-    if (lane == 63) s_misc[wave] = incl;
-    __syncthreads();  // (A)
-    const unsigned w0 = s_misc[0], w1 = s_misc[1], w2 = s_misc[2], w3 = s_misc[3];
-    const unsigned total = w0 + w1 + w2 + w3;
-    const unsigned wpre = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
-    unsigned cur = s_misc[4];
-    const bool direct = total > TRI_STAGE;  // block-uniform
-    unsigned long long gbase = 0;
-    if (!direct && cur + total > TRI_STAGE) {  // flush the stage first (block-uniform)
-      if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)cur);
-      __syncthreads();
-      const unsigned long long fb = *s_base;
-      if (fb + cur <= tri_cap) {
-        float* dst = tris + fb * 9;
-        for (unsigned k = threadIdx.x; k < cur * 9; k += BLOCK) dst[k] = s_stage[k];
-      } else if (threadIdx.x == 0) {
-        ctr->overflow = 1ull;
-      }
-      __syncthreads();
-      cur = 0;
-    }
-    if (direct) {
-      if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)total);
-      __syncthreads();
-      gbase = *s_base;
-      if (gbase + total > tri_cap) {
-        if (threadIdx.x == 0) ctr->overflow = 1ull;
-        nt = 0;
-      }
-    }
-    if (nt) {
-      const unsigned first = wpre + (incl - nt);
-      float* dst = direct ? (tris + (gbase + first) * 9) : (s_stage + (size_t)(cur + first) * 9);
-      const int8_t* row = s_tri + index * 16;
-      for (unsigned t = 0; t < nt; t++) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const int e = row[3 * t + (2 - k)];  // reversed winding (marchcubes.go:64-68)
-          const unsigned a = GSDF_MC_PAIR_A(e), b = GSDF_MC_PAIR_B(e);
-          const float va = vslot[a * BLOCK], vb = vslot[b * BLOCK];
-          const float pax = ((a ^ (a >> 1)) & 1u) ? x1 : x0, pay = ((a >> 1) & 1u) ? y1 : y0, paz = ((a >> 2) & 1u) ? z1 : z0;
-          const float pbx = ((b ^ (b >> 1)) & 1u) ? x1 : x0, pby = ((b >> 1) & 1u) ? y1 : y0, pbz = ((b >> 2) & 1u) ? z1 : z0;
-          float rx, ry, rz;
-          mc_interp(pax, pay, paz, pbx, pby, pbz, va, vb, rx, ry, rz);
-          dst[9 * t + 3 * k + 0] = rx;
-          dst[9 * t + 3 * k + 1] = ry;
-          dst[9 * t + 3 * k + 2] = rz;
-        }
-      }
-    }
-    __syncthreads();  // (B)
-    if (threadIdx.x == 0 && !direct) s_misc[4] = cur + total;
+    mc_emit_block(index, x0, y0, z0, x1, y1, z1, [&](unsigned cc) { return vslot[cc * BLOCK]; }, s_tri, s_stage, s_misc, s_base, tris,
+                  tri_cap, ctr);
   }
-  __syncthreads();
-  {  // final flush
-    const unsigned cur = s_misc[4];
-    if (cur) {
-      if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)cur);
-      __syncthreads();
-      const unsigned long long fb = *s_base;
-      if (fb + cur <= tri_cap) {
-        float* dst = tris + fb * 9;
-        for (unsigned k = threadIdx.x; k < cur * 9; k += BLOCK) dst[k] = s_stage[k];
-      } else if (threadIdx.x == 0) {
-        ctr->overflow = 1ull;
-      }
-    }
-  }
+  mc_final_flush(s_stage, s_misc, s_base, tris, tri_cap, ctr);
   if (lane == 0 && my_cont) {
     atomicAdd(&ctr->n_active, my_active);
     atomicAdd(&ctr->n_cont, my_cont);
+  }
+}
+
+// Leaf kernel with exact corner sharing (level-3 bricks: one wave = one brick of 4x4x4 leaves).
+// The reference evaluates 8 corners per leaf: 512 evaluations per brick. Neighbouring leaves share lattice
+// planes, but the two coordinate expressions of a plane -- A(i) = O + res*i (min corner of leaf i) and
+// B(i) = A(i-1) + res (max corner of leaf i-1) -- are only sometimes the same float (64-73 % of planes at
+// resdiv 1600). Per axis the brick therefore has 5..8 bitwise-distinct coordinates (A0, {B1,A1}, {B2,A2},
+// {B3,A3}, B4 with equal pairs merged); every distinct point is evaluated ONCE (typically ~6x6x6 = 216
+// instead of 512: one 4-points-per-lane pass instead of two) and each leaf corner reads the value of
+// exactly the coordinates the reference would have evaluated, so distances, signs and triangles stay
+// bit-identical.
+// LDS: [nslots*K floats per lane | tri table | triangle stage | misc | 4 x 512 distances | 4 x 24 coordinates].
+template <int K, int WAVES>
+__global__ void __launch_bounds__(BLOCK, WAVES) leaf_brick_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
+                                                                  unsigned long long cube_cap, int nslots, float ox, float oy, float oz,
+                                                                  float res, float* __restrict__ tris, uint64_t tri_cap,
+                                                                  MeshCounters* __restrict__ ctr) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  int8_t* s_tri = (int8_t*)(g_smem + (size_t)(nslots * K) * BLOCK);
+  float* s_stage = (float*)(s_tri + 256 * 16);
+  unsigned* s_misc = (unsigned*)(s_stage + TRI_STAGE * 9);
+  unsigned long long* s_base = (unsigned long long*)(s_misc + 6);
+  float* s_D = (float*)(s_base + 1);
+  float* s_val = s_D + 4 * 512;
+  for (int k = threadIdx.x; k < 256 * 16; k += BLOCK) s_tri[k] = GSDF_MC_TRI[k >> 4][k & 15];
+  if (threadIdx.x == 0) s_misc[4] = 0;
+  __syncthreads();
+
+  const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
+  unsigned long long n_cubes = uniform_u64(ctr->n_level[3]);
+  if (n_cubes > cube_cap) n_cubes = cube_cap;
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* D = s_D + wave * 512;
+  float* val = s_val + wave * 24;
+  const float org[3] = {ox, oy, oz};
+  unsigned long long my_active = 0, my_points = 0;
+  const uint64_t step = (uint64_t)gridDim.x * 4;
+  for (uint64_t base = (uint64_t)blockIdx.x * 4; base < n_cubes; base += step) {  // block-uniform trip count
+    const uint64_t brick = base + wave;
+    const bool bvalid = brick < n_cubes;
+    Cube pc = {0, 0, 0, 0};
+    if (bvalid) pc = cubes[brick];
+    const unsigned pidx[3] = {pc.x, pc.y, pc.z};
+    // per-axis mismatch bits m_p (p = 1..3): plane p has two distinct floats
+    unsigned mb[3], nax[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+      const unsigned i0 = pidx[ax] * 4u;
+      float A[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) A[k] = org[ax] + res * (float)(i0 + k);  // CubeOrigin of leaf i0+k
+      unsigned m = 0;
+#pragma unroll
+      for (int k = 1; k < 4; k++) m |= ((A[k - 1] + res) != A[k] ? 1u : 0u) << (k - 1);
+      mb[ax] = m;
+      nax[ax] = 5u + __builtin_popcount(m);
+    }
+    if (lane < 12) {  // coordinate table: lane (axis, a) writes A_a and B_{a+1} at their distinct-value slots
+      const unsigned ax = lane >> 2, a = lane & 3u;
+      const float Aa = org[ax] + res * (float)(pidx[ax] * 4u + a);
+      const unsigned u = a + __builtin_popcount(mb[ax] & ((1u << a) - 1u));
+      val[ax * 8 + u] = Aa;
+      val[ax * 8 + u + 1] = Aa + res;  // Box max = origin + size
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned nx = nax[0], ny = nax[1], nxy = nax[0] * nax[1], N = nxy * nax[2];
+    const float inx = 1.0f / (float)nx, inxy = 1.0f / (float)nxy;
+    if (bvalid && lane == 0) my_points += N;
+#pragma unroll 1
+    for (unsigned t0 = 0; t0 < N; t0 += 64 * K) {  // wave-uniform: 1 pass when N <= 256
+      P3 pk[K];
+      float dk[K];
+#pragma unroll
+      for (int kp = 0; kp < K; kp++) {
+        unsigned t = t0 + kp * 64 + lane;
+        if (t >= N) t = N - 1;  // idle slots re-evaluate the last point (result discarded)
+        const unsigned uz = (unsigned)(((float)t + 0.5f) * inxy);
+        const unsigned r = t - uz * nxy;
+        const unsigned uy = (unsigned)(((float)r + 0.5f) * inx);
+        const unsigned ux = r - uy * nx;
+        pk[kp] = P3{val[ux], val[8 + uy], val[16 + uz]};
+      }
+      gsdf_dev::sdf_eval<K>(code, pk, dk, lds, BLOCK);
+#pragma unroll
+      for (int kp = 0; kp < K; kp++) {
+        const unsigned t = t0 + kp * 64 + lane;
+        if (t < N) D[t] = dk[kp];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // this lane's leaf (a,b,c) and its corner 0 index in the distinct-point lattice
+    const unsigned la = lane & 3u, lb = (lane >> 2) & 3u, lc = lane >> 4;
+    const unsigned ux0 = la + __builtin_popcount(mb[0] & ((1u << la) - 1u));
+    const unsigned uy0 = lb + __builtin_popcount(mb[1] & ((1u << lb) - 1u));
+    const unsigned uz0 = lc + __builtin_popcount(mb[2] & ((1u << lc) - 1u));
+    const unsigned tb = ux0 + nx * uy0 + nxy * uz0;
+    auto vdist = [&](unsigned cc) { return D[tb + ((cc ^ (cc >> 1)) & 1u) + nx * ((cc >> 1) & 1u) + nxy * ((cc >> 2) & 1u)]; };
+    const float x0 = val[ux0], x1 = val[ux0 + 1], y0 = val[8 + uy0], y1 = val[8 + uy0 + 1], z0 = val[16 + uz0], z1 = val[16 + uz0 + 1];
+    unsigned index = 0;
+#pragma unroll
+    for (unsigned cc = 0; cc < 8; cc++) index |= (vdist(cc) < 0.f ? 1u : 0u) << cc;
+    const bool pass = bvalid && (dm::absf(vdist(0)) <= cubeDiag);
+    const unsigned long long pmask = __ballot(pass);
+    if (lane == 0) my_active += (unsigned long long)__builtin_popcountll(pmask);
+    if (!pass) index = 0;
+    mc_emit_block(index, x0, y0, z0, x1, y1, z1, vdist, s_tri, s_stage, s_misc, s_base, tris, tri_cap, ctr);
+  }
+  mc_final_flush(s_stage, s_misc, s_base, tris, tri_cap, ctr);
+  if (lane == 0 && my_points) {
+    atomicAdd(&ctr->n_active, my_active);
+    atomicAdd(&ctr->n_points, my_points);
   }
 }
 
@@ -1002,7 +1134,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
   if (!(res > 0) || std::isnan(res) || std::isinf(res)) return fail(GSDF_ERR_RESOLUTION, "invalid renderer cube resolution");
   gsdf_mesh_opts opts{};
-  opts.prune = 1; opts.shard_rank = 0; opts.shard_count = 1;
+  opts.prune = 1; opts.shard_rank = 0; opts.shard_count = 1; opts.share_corners = 0;
   if (opts_in) opts = *opts_in;
   if (opts.shard_count < 1 || opts.shard_rank < 0 || opts.shard_rank >= opts.shard_count) return fail(GSDF_ERR_BAD_ARGUMENT, "bad shard rank/count");
   HIP_TRY(hipSetDevice(p->device));
@@ -1051,6 +1183,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   if (qcap < (1u << 20)) qcap = 1u << 20;  // 1 M cubes (8 MB) per queue to start with
   uint64_t want = opts.max_tris;
   MeshCounters hc{};
+  bool used_brick = false;
   float ms01 = 0, ms12 = 0;
   for (int attempt = 0;; attempt++) {
     HIP_TRYM(p->q0.ensure(qcap * sizeof(Cube)));
@@ -1092,6 +1225,14 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
                      (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res,  \
                      m->d_tris, tcap, d_ctr)
       static const int forced_w = [] { const char* e = getenv("GSDF_HIP_LEAF_WAVES"); return e ? atoi(e) : 0; }();  // tuning knob
+      if (lq == 3 && lk == 4 && opts.share_corners) {
+        // exact corner sharing: one wave per level-3 brick
+        const size_t lds_b = (size_t)(p->prog.nslots * 4) * BLOCK * sizeof(float) + 4096 + TRI_STAGE * 36 + 32 + 4 * 512 * 4 + 4 * 24 * 4;
+        hipLaunchKernelGGL((leaf_brick_kernel<4, 3>), dim3(grid_for(capq[lq & 1] * 64 < bound ? capq[lq & 1] * 64 : bound, p->num_cu, 8)),
+                           dim3(BLOCK), lds_b, s, p->d_code, (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1],
+                           p->prog.nslots, ox, oy, oz, res, m->d_tris, tcap, d_ctr);
+        used_brick = true;
+      } else
       // K=4 at 3 waves/SIMD (168 VGPRs, a few spills) measured 17% faster than 2 waves/SIMD (203 VGPRs, none)
       if (lk == 4) { if (forced_w == 2) LAUNCH_LEAF(4, 2); else LAUNCH_LEAF(4, 3); }
       else if (lk == 2) { if (forced_w == 4) LAUNCH_LEAF(2, 4); else LAUNCH_LEAF(2, 3); }
@@ -1125,7 +1266,8 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     if (hc.n_items[level]) pruned += (hc.n_items[level] - hc.n_pass[level]) << (3 * (level - 1));  // DecomposesTo(1) = 8^(level-1)
   }
   const uint64_t n_leaves = hc.n_level[lq] << (3 * (lq - 1));
-  const uint64_t evals_leaf = n_leaves * (uint64_t)lk + (uint64_t)(8 - lk) * hc.n_cont;  // evaluations actually executed
+  const uint64_t evals_leaf = used_brick ? hc.n_points  // distinct lattice points evaluated once each
+                                         : n_leaves * (uint64_t)lk + (uint64_t)(8 - lk) * hc.n_cont;  // evaluations actually executed
   m->st.n_tris = hc.n_tris;
   m->st.evals = evals_prune + evals_leaf;
   m->st.evals_prune = evals_prune;

@@ -29,7 +29,7 @@ SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "g
 
 class MeshOpts(C.Structure):
     _fields_ = [("prune", C.c_int), ("shard_rank", C.c_int), ("shard_count", C.c_int), ("max_tris", C.c_uint64),
-                ("stream", C.c_void_p)]
+                ("stream", C.c_void_p), ("share_corners", C.c_int)]
 
 
 class MeshStats(C.Structure):
@@ -177,13 +177,14 @@ class OctreeHIP:
     NewOctreeRenderer(s, cubeResolution, evalBufferSize) -> OctreeHIP(sdf, res) ; the evaluation buffer
     argument has no meaning here (positions are generated on device)."""
 
-    def __init__(self, sdf, res, evalBufferSize=64, prune=True, shard_rank=0, shard_count=1, max_tris=0, stream=None):
+    def __init__(self, sdf, res, evalBufferSize=64, prune=True, shard_rank=0, shard_count=1, max_tris=0, stream=None,
+                 share_corners=False):
         if evalBufferSize < 64:
             raise ValueError("bad octree eval buffer size")
         self.sdf = sdf
         self._mesh = None
         self._cursor = 0
-        self._opts = MeshOpts(int(prune), shard_rank, shard_count, max_tris, stream)
+        self._opts = MeshOpts(int(prune), shard_rank, shard_count, max_tris, stream, int(share_corners))
         self.Reset(sdf, res)
 
     def Reset(self, sdf, res):

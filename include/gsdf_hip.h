@@ -88,6 +88,9 @@ typedef struct gsdf_mesh_opts {
   int shard_count;    /* ... of this many (1 = whole model). Bricks are dealt round-robin. */
   uint64_t max_tris;  /* device triangle buffer capacity; 0 = size automatically */
   void* stream;       /* hipStream_t to run on; NULL = the program's stream */
+  int share_corners;  /* 0 (default): every leaf evaluates its own 8 corners like the reference (8 evals/leaf);
+                         1: each bitwise-distinct lattice point of a 4x4x4-leaf brick is evaluated once (identical
+                         triangles, ~1.5x fewer evaluations, ~9% less time at npt-flange resdiv 1600) */
 } gsdf_mesh_opts;
 
 typedef struct gsdf_mesh_stats {

@@ -49,6 +49,9 @@ def test_scene_mesh_identical_to_oracle(gpu, scene, key):
     ref = OracleSDF(s.tree()).render_octree(res, 4096, True)
     assert (tg.view(np.uint32) == _sorted(ref.tris).view(np.uint32)).all()
     assert oc.TotalPruned() == ref.pruned                    # Octree.TotalPruned
+    shared = gpu.OctreeHIP(sdf, res, share_corners=True)   # exact corner sharing: same triangles, fewer evaluations
+    assert (_sorted(shared.RenderAll()).view(np.uint32) == tg.view(np.uint32)).all()
+    assert shared.stats.evals < oc.stats.evals
     # pruning must not change the surface (flat renderer == octree renderer in the reference's README)
     if key != "npt_flange_resdiv400":
         assert gpu.OctreeHIP(sdf, res, prune=False).n_tris() == g["n_tris"]
@@ -138,7 +141,7 @@ def test_full_size_npt_flange_resdiv1600(gpu):
     assert oc.stats.levels == 12 and oc.n_tris() == g["n_tris"]
     t = oc.RenderAll()
     assert _digest(t) == g["sha256_sorted"]
-    oc2 = gpu.OctreeHIP(sdf, res)
+    oc2 = gpu.OctreeHIP(sdf, res, share_corners=True)
     assert oc2.n_tris() == oc.n_tris() and _digest(oc2.RenderAll()) == g["sha256_sorted"]   # idempotent / deterministic set
     halves = [gpu.OctreeHIP(sdf, res, shard_rank=r, shard_count=2) for r in range(2)]
     assert sum(h.n_tris() for h in halves) == g["n_tris"]
