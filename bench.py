@@ -53,6 +53,50 @@ def pmc_traffic_gb():
         return None
 
 
+def eval_mode(args, torch, np, hip, shader, sdf, res, dev):
+    """M1: dist[i] = SDF(pos[i]) over the FlatRenderer lattice (flatrenderer.go:153-160 order), positions and distances
+    resident in HBM, 2^24 points per launch. Algorithmic traffic 16 B/eval (12 B position + 4 B distance)."""
+    bb = shader.Bounds().astype(np.float64)
+    c, h = (bb[:3] + bb[3:]) / 2, (bb[3:] - bb[:3]) / 2 * 1.01
+    mn = (c - h).astype(np.float32)
+    nx, ny, nz = [int(np.ceil(np.float32(2 * h[a]) / res)) + 1 for a in range(3)]
+    n = 1 << (26 if args.scene == "sphere" else 24)
+    total = nx * ny * nz
+    idx = torch.arange(n, device=dev, dtype=torch.int64)
+    pos = torch.empty((n, 3), device=dev, dtype=torch.float32)
+    dist = torch.empty(n, device=dev, dtype=torch.float32)
+
+    def fill(chunk):
+        g = (idx + chunk * n) % total
+        pos[:, 0] = mn[0] + (g % nx).to(torch.float32) * float(res)
+        pos[:, 1] = mn[1] + ((g // nx) % ny).to(torch.float32) * float(res)
+        pos[:, 2] = mn[2] + (g // (nx * ny)).to(torch.float32) * float(res)
+    fill(0)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = torch.cuda.Stream(device=dev)  # a real (non-null) stream: kernels and events must share it
+    torch.cuda.synchronize()
+    with torch.cuda.stream(ts):
+        for _ in range(args.warmup):
+            sdf.evaluate_dev(pos.data_ptr(), 12, dist.data_ptr(), n, ts.cuda_stream)
+        ts.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(ts)
+        for k in range(args.steps):
+            sdf.evaluate_dev(pos.data_ptr(), 12, dist.data_ptr(), n, ts.cuda_stream)
+        ev1.record(ts)
+        ts.synchronize()
+    dt = time.perf_counter() - t0
+    k_ms = ev0.elapsed_time(ev1) / args.steps
+    achieved = n * 16.0 / (k_ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "sdf_evals_per_s", "value": n * args.steps / dt, "unit": "evals/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"Evaluate micro-benchmark: {args.scene}, {n} HBM-resident lattice points per launch (lattice {nx}x{ny}x{nz} at resdiv {args.resdiv})"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "eval_kernel<3,K>", "kernel_ms": k_ms}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,6 +106,9 @@ def main():
     ap.add_argument("--scene", default="npt-flange")
     ap.add_argument("--cpu-resdiv", type=int, default=0, help="resdiv of the bounded CPU sample (0 = pick ~10-30 s of CPU work from the core count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["mesh", "eval"], default="mesh",
+                    help="mesh (default, BASELINE configs[1]) or eval: the gleval.SDF3.Evaluate micro-benchmark (SURVEY 8(d) M1) on "
+                         "HBM-resident positions: 2^24-point chunks of the flat lattice of the scene at --resdiv")
     ap.add_argument("--share-corners", action="store_true", help="evaluate each bitwise-distinct lattice corner of a brick once (same triangles, fewer evals)")
     args = ap.parse_args()
 
@@ -88,9 +135,12 @@ def main():
     hip.init(dev.index)
 
     bld = Builder()
-    shader = bld.Scene(args.scene)
+    shader = bld.NewSphere(1.0) if args.scene == "sphere" else bld.Scene(args.scene)
     res = np.float32(float(shader.Diagonal()) / args.resdiv)
     sdf = hip.SDF3HIP(shader)
+
+    if args.mode == "eval":
+        return eval_mode(args, torch, np, hip, shader, sdf, res, dev)
 
     def barrier():
         torch.cuda.synchronize()
