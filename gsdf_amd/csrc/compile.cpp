@@ -286,11 +286,12 @@ void gen(Ctx& c, uint32_t i, int depth) {
       if (nv < 3) throw std::runtime_error("polygon needs at least 3 vertices");
       const float* v = &c.t->aux[n.aux_off];
       c.op(D_POLY2D); c.u(nv); c.f(v[0]); c.f(v[1]);
+      while (c.code.size() % 8 != 0) c.u(0);  // edge records: 8 dwords, 32-byte aligned (two s_load_dwordx4 each)
       uint32_t jv = nv - 1;
       for (uint32_t iv = 0; iv < nv; iv++) {
         float v1x = v[2 * iv], v1y = v[2 * iv + 1], v2x = v[2 * jv], v2y = v[2 * jv + 1];
         float ex = v2x - v1x, ey = v2y - v1y;
-        c.f(v1x); c.f(v1y); c.f(ex); c.f(ey); c.f(ex * ex + ey * ey); c.f(v2y);
+        c.f(v1x); c.f(v1y); c.f(ex); c.f(ey); c.f(ex * ex + ey * ey); c.f(v2y); c.u(0); c.u(0);
         jv = iv;
       }
       break;

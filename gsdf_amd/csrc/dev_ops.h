@@ -41,7 +41,7 @@ enum DevOp : uint32_t {
   D_HEX2D,     // r kzr
   D_OCT2D,     // r kzr
   D_ELLIPSE2D, // a b
-  D_POLY2D,    // nv v0x v0y then nv x {v1x v1y ex ey n2e v2y}
+  D_POLY2D,    // nv v0x v0y, pad to an 8-dword boundary, then nv x {v1x v1y ex ey n2e v2y 0 0}
   D_LINES2D,   // ns w then ns x {ax ay bax bay dotba}
   // ---- position pre-ops: P = T(P)
   D_TRANSLATE,     // tx ty tz
@@ -77,7 +77,7 @@ enum DevOp : uint32_t {
   D_OP_COUNT
 };
 
-// Fixed parameter-word counts (D_POLY2D / D_LINES2D are variable: 3+6*nv / 2+5*ns).
+// Fixed parameter-word counts (D_POLY2D / D_LINES2D are variable: 3 + pad + 8*nv / 2+5*ns).
 static const uint8_t kDevOpParams[D_OP_COUNT] = {
     /*END*/ 0,
     /*SPHERE*/ 1, /*BOX*/ 4, /*BOXFRAME*/ 4, /*TORUS*/ 2, /*CYL0*/ 2, /*CYLR*/ 3, /*HEX*/ 3,

@@ -16,6 +16,8 @@
 namespace gsdf_dev {
 
 typedef const uint32_t __attribute__((address_space(4))) * code_ptr;  // constant AS -> s_load
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const v4f __attribute__((address_space(4))) * f4ptr;
 
 struct P3 { float x, y, z; };
 
@@ -366,18 +368,22 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
           d[kp] = wx0 * wx0 + wy0 * wy0;
           neg[kp] = false;
         }
-        uint32_t q = pc + 4;
-        for (uint32_t iv = 0; iv < nv; iv++, q += 6) {
-          const float v1x = __uint_as_float(code[q]), v1y = __uint_as_float(code[q + 1]), ex = __uint_as_float(code[q + 2]),
-                      ey = __uint_as_float(code[q + 3]), n2e = __uint_as_float(code[q + 4]), v2y = __uint_as_float(code[q + 5]);
+        // edge records are 8 dwords {v1x v1y ex ey |e|^2 v2y - -}, 32-byte aligned in the stream: two s_load_dwordx4
+        uint32_t q = (pc + 4u + 7u) & ~7u;
+        for (uint32_t iv = 0; iv < nv; iv++, q += 8) {
+          const f4ptr er = (f4ptr)(code + q);
+          const v4f e0 = er[0], e1 = er[1];
+          const float v1x = e0.x, v1y = e0.y, ex = e0.z, ey = e0.w, n2e = e1.x, v2y = e1.y;
           KLOOP {
             const float px = pv[kp].x, py = pv[kp].y;
             float wx = px - v1x, wy = py - v1y;
-            float t = clampf((wx * ex + wy * ey) / n2e, 0.f, 1.f);
+            // clamp(v,0,1) as med3: differs from the reference's if-chain only in the sign of a zero t, which
+            // cannot reach d (t only scales e before the square)
+            float t = __builtin_amdgcn_fmed3f((wx * ex + wy * ey) / n2e, 0.f, 1.f);
             float bx = wx - t * ex, by = wy - t * ey;
             d[kp] = minf(d[kp], bx * bx + by * by);
             bool b1 = py >= v1y, b2 = py < v2y, b3 = ex * wy > ey * wx;
-            bool flip = (b1 && b2 && b3) || (!b1 && !b2 && !b3);
+            bool flip = (b1 == b2) && (b2 == b3);  // all three true or all three false
             neg[kp] = neg[kp] != flip;
           }
         }
