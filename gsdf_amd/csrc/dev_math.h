@@ -82,16 +82,27 @@ DM_INL double xatan(double x) {
   z = x * z + x;
   return z;
 }
+// satan (go/src/math/atan.go), x >= 0. The three argument ranges are folded into ONE xatan evaluation by
+// selecting the reduced argument first (x/1, 1/x or (x-1)/(x+1)): lanes of a wave fall into all three
+// ranges, so the branchy form executes xatan three times. Same operations per lane, same results:
+//   x <= 0.66        : xatan(x)                          = (0 + z) + 0
+//   x > tan(3pi/8)   : Pi/2 - xatan(1/x) + Morebits      = (Pi/2 - z) + Morebits
+//   otherwise        : Pi/4 + xatan((x-1)/(x+1)) + 0.5*Morebits
 DM_INL double satan(double x) {  // x >= 0
   const double Morebits = 6.123233995736765886130e-17, Tan3pio8 = 2.41421356237309504880;
-  if (x <= 0.66) return xatan(x);
-  if (x > Tan3pio8) return DM_PI / 2 - xatan(1.0 / x) + Morebits;
-  return DM_PI / 4 + xatan((x - 1.0) / (x + 1.0)) + 0.5 * Morebits;
+  const bool lo = x <= 0.66, hi = x > Tan3pio8;
+  const double num = lo ? x : (hi ? 1.0 : x - 1.0);
+  const double den = lo ? 1.0 : (hi ? x : x + 1.0);
+  const double z = xatan(num / den);  // x/1.0 == x exactly
+  const double c0 = lo ? 0.0 : (hi ? DM_PI / 2 : DM_PI / 4);
+  const double c1 = lo ? 0.0 : (hi ? Morebits : 0.5 * Morebits);
+  const double t = hi ? c0 - z : c0 + z;  // 0 + z == z exactly (z > 0 for x > 0; satan(0) is never called)
+  return t + c1;
 }
 DM_INL double atan64(double x) {
   if (x == 0.0) return x;
-  if (x > 0.0) return satan(x);
-  return -satan(-x);
+  const double r = satan(__builtin_fabs(x));
+  return x > 0.0 ? r : -r;
 }
 // math.Atan2 (go/src/math/atan2.go), finite inputs.
 DM_INL float atan2f_(float yf, float xf) {
@@ -145,6 +156,26 @@ DM_INL float sinf_(float xf) {
   double zz = z * z;
   double r = (j == 1 || j == 2) ? trig_poly_cos(zz) : trig_poly_sin(z, zz);
   return (float)(sign ? -r : r);
+}
+// math.Cos(x) and math.Sin(x) of the same argument (twist, cpu_evaluators.go:1269-1270): both routines perform the
+// identical Cody-Waite reduction and pick between the same two polynomials, so they are evaluated once.
+DM_INL void cossinf_(float xf, float& c_out, float& s_out) {
+  const double xs = (double)xf;
+  double x = __builtin_fabs(xs);
+  uint64_t j = (uint64_t)(x * (4.0 / DM_PI));
+  double y = (double)j;
+  if (j & 1) { j++; y += 1.0; }
+  j &= 7;
+  const double z = ((x - y * 7.85398125648498535156e-1) - y * 3.77489470793079817668e-8) - y * 2.69515142907905952645e-15;
+  bool csign = false, ssign = xs < 0.0;
+  if (j > 3) { j -= 4; csign = !csign; ssign = !ssign; }
+  if (j > 1) csign = !csign;
+  const double zz = z * z;
+  const double ps = trig_poly_sin(z, zz), pc = trig_poly_cos(zz);
+  const bool sw = (j == 1 || j == 2);
+  const double c = sw ? ps : pc, sn = sw ? pc : ps;
+  c_out = (float)(csign ? -c : c);
+  s_out = xs == 0.0 ? xf : (float)(ssign ? -sn : sn);  // Sin(+-0) = +-0
 }
 // math.Acos = Pi/2 - Asin (go/src/math/asin.go)
 DM_INL float acosf_(float xf) {

@@ -463,7 +463,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
           P3& p = pv[kp];
           float& R = Rv[kp];
           const float k = PF(0);
-          float c = cosf_(k * p.z), s = sinf_(k * p.z);
+          float c, s;
+          cossinf_(k * p.z, c, s);
           float x = c * p.x - s * p.y, y = s * p.x + c * p.y;
           p.x = x; p.y = y;
         }
