@@ -181,3 +181,15 @@ def test_dualcontour_reference_tolerances(gpu):
     assert len(fine.WriteBinarySTL()) == 84 + 50 * fine.n_tris()
     with pytest.raises(gpu.HipError):
         gpu.DualContourHIP(gpu.SDF3HIP(b.NewSphere(1)), np.float32(0.0005))  # > 11 levels
+
+
+def test_zero_copy_device_view_for_gather(gpu):
+    """gsdf_amd.gather wraps the device triangle buffer without a copy (what the RCCL gather sends)."""
+    import torch
+    from gsdf_amd.gather import tensor_from_dev_ptr
+    b = Builder()
+    oc = gpu.OctreeHIP(gpu.SDF3HIP(b.NewSphere(1.0)), np.float32(1 / 16))
+    t = tensor_from_dev_ptr(oc.dev_ptr(), oc.n_tris(), torch.device("cuda", 0))
+    assert t.shape == (oc.n_tris(), 9) and t.data_ptr() == oc.dev_ptr()
+    assert (t.cpu().numpy().reshape(-1, 3, 3) == oc.RenderAll()).all()
+    assert tensor_from_dev_ptr(0, 0, torch.device("cuda", 0)).shape == (0, 9)

@@ -1,0 +1,110 @@
+"""Host lowering (gsdf_amd/csrc/compile.cpp) checked without a GPU through gsdf_hip_lower: instruction
+stream shape, LDS slot allocation, the position-save elision and the hypot(x,y) sharing flags."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import corpus
+from gsdf_amd import hip
+from gsdf_amd.builder import Builder
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_HDR = open(os.path.join(ROOT, "gsdf_amd", "csrc", "dev_ops.h")).read()
+_ENUM = _HDR[_HDR.index("enum DevOp"):_HDR.index("D_OP_COUNT")]
+NAMES = [n for n in dict.fromkeys(re.findall(r"\b(D_[A-Z0-9_]+)\b", _ENUM))]
+NPAR = [int(x) for x in re.findall(r"\*/\s*(\d+)", re.search(r"kDevOpParams\[D_OP_COUNT\] = \{(.*?)\};", _HDR, re.S).group(1))]
+FLAG_HXY, FLAG_SWAP, OP_MASK = 0x4000, 0x8000, 0x3FFF
+
+
+def decode(code):
+    out, pc = [], 0
+    while pc < len(code):
+        w = int(code[pc])
+        op = w & OP_MASK
+        name, n = NAMES[op], NPAR[op]
+        if name == "D_POLY2D":
+            nv = int(code[pc + 1])
+            n = ((pc + 4 + 7) & ~7) - (pc + 1) + 8 * nv
+        elif name == "D_LINES2D":
+            n = 2 + 5 * int(code[pc + 1])
+        out.append((name, bool(w & FLAG_HXY), bool(w & FLAG_SWAP), w >> 16, pc))
+        pc += 1 + n
+        if name == "D_END":
+            break
+    assert pc == len(code)
+    return out
+
+
+def test_opcode_table_is_consistent():
+    assert len(NAMES) == len(NPAR)
+    assert NAMES[0] == "D_END"
+
+
+def test_npt_flange_program():
+    b = Builder()
+    code, slots = hip.lower(b.Scene("npt-flange"))
+    ins = decode(code)
+    names = [i[0] for i in ins]
+    assert names[0] == "D_SCALE_PRE" and names[-2:] == ["D_MULR", "D_END"]
+    assert names.count("D_POLY2D") == 1 and names.count("D_SCREW_PRE") == 1
+    assert names.count("D_CYL0") + names.count("D_CYLR") == 3
+    # the hole cylinder is evaluated first (position-preserving), so the root difference needs no position save
+    assert names.count("D_SAVEP3") == 1 and names.count("D_LOADP3") == 1
+    assert [i for i in ins if i[0] == "D_COMBINE_DIFF"][-1][2] is True     # swapped operands
+    # hypot(x,y) is computed once and reused by the other two cylinders and the screw (z-only translate keeps it)
+    users = [i for i in ins if i[0] in ("D_CYL0", "D_CYLR", "D_SCREW_PRE")]
+    assert [u[1] for u in users].count(False) == 1 and [u[1] for u in users].count(True) == 3
+    assert slots == 7
+    # polygon edge records start on a 32-byte boundary
+    poly = [i for i in ins if i[0] == "D_POLY2D"][0]
+    assert ((poly[4] + 4 + 7) & ~7) % 8 == 0
+
+
+def test_hxy_not_reused_across_xy_changes():
+    b = Builder()
+    c = b.NewCylinder(1, 2, 0)
+    s = b.Union(c, b.Translate(c, 0.5, 0, 0), b.Translate(c, 0, 0, 3))
+    ins = decode(hip.lower(s)[0])
+    cyls = [i for i in ins if i[0] == "D_CYL0"]
+    assert len(cyls) == 3
+    # order: non-clobbering child first; the z-only translate may reuse, the x translate may not
+    flags = {}
+    prev = None
+    for i in ins:
+        if i[0] == "D_TRANSLATE":
+            prev = i
+        if i[0] == "D_CYL0":
+            flags[prev[4] if prev else -1] = i[1]
+    assert list(flags.values()).count(True) <= 1
+    for name, sh in corpus.shapes3d()[1] + corpus.shapes2d()[1]:
+        decode(hip.lower(sh)[0])  # every corpus program decodes cleanly to D_END
+
+
+def test_multi_evaluation_nodes_are_unrolled():
+    b = Builder()
+    box = b.NewBox(1, 1, 1, 0)
+    arr = b.Array(box, 2, 2, 2, 3, 3, 3)
+    names = [i[0] for i in decode(hip.lower(arr)[0])]
+    assert names.count("D_ARRAY_PRE") == 8 and names.count("D_BOX") == 8 and names.count("D_COMBINE_MIN") == 8
+    circ = b.CircularArray(b.Translate(box, 2, 0, 0), 5, 7)
+    names = [i[0] for i in decode(hip.lower(circ)[0])]
+    assert names.count("D_CIRC_PRE") == 1 and names.count("D_BOX") == 2
+    k = b.Scene("knurled-cylinder")
+    names = [i[0] for i in decode(hip.lower(k)[0])]
+    assert names.count("D_TWIST") == 2 and names.count("D_CIRC_PRE") == 2 and names.count("D_BOX") == 4  # shared subtree re-emitted
+
+
+def test_bad_trees_raise():
+    from gsdf_amd._ctypes_common import GsdfNode, GsdfTree, OP
+    import ctypes as C
+    nodes = (GsdfNode * 2)()
+    nodes[0].op = OP["SPHERE"]
+    nodes[1].op = OP["EXTRUSION"]  # extrusion of a 3D child
+    nodes[1].nchild = 1
+    links = (C.c_uint32 * 1)(0)
+    t = GsdfTree(nodes, 2, links, 1, None, 0, 1)
+    with pytest.raises(hip.HipError) as e:
+        hip.lower(t)
+    assert e.value.code == -4 and "dimension" in e.value.msg
