@@ -14,6 +14,24 @@
 #include "dev_ops.h"
 
 namespace gsdf_dev {
+
+// r = RN(1/d) for the device's div_by_uniform, or 0 when d is unsuitable (the device then uses the IEEE
+// expansion). The candidate from double arithmetic is checked against its float neighbours with the exact
+// residual 1 - d*r (d*r has <= 48 significant bits: exact in long double), so r is the correctly rounded
+// reciprocal, not a double-rounded one.
+float recip_for(float d) {
+  const float a = std::fabs(d);
+  if (!(a >= 9.313225746154785e-10f && a <= 1073741824.0f)) return 0.f;  // outside [2^-30, 2^30], zero, NaN
+  float best = (float)(1.0 / (double)d);
+  long double berr = fabsl(1.0L - (long double)d * (long double)best);
+  const float cand[2] = {std::nextafterf(best, INFINITY), std::nextafterf(best, -INFINITY)};
+  for (float c : cand) {
+    long double err = fabsl(1.0L - (long double)d * (long double)c);
+    if (err < berr) { berr = err; best = c; }
+  }
+  return best;
+}
+
 namespace {
 
 constexpr float TRIBISECT = 0.8660254037844386467637231707529361834714026269051903140279034897f;
@@ -285,13 +303,24 @@ void gen(Ctx& c, uint32_t i, int depth) {
       uint32_t nv = n.aux_len / 2;
       if (nv < 3) throw std::runtime_error("polygon needs at least 3 vertices");
       const float* v = &c.t->aux[n.aux_off];
-      c.op(D_POLY2D); c.u(nv); c.f(v[0]); c.f(v[1]);
+      // all edge divisors eligible for the exact reciprocal form? (bit 31 of the vertex-count word)
+      bool all_recip = true;
+      {
+        uint32_t jv0 = nv - 1;
+        for (uint32_t iv = 0; iv < nv; iv++) {
+          float ex = v[2 * jv0] - v[2 * iv], ey = v[2 * jv0 + 1] - v[2 * iv + 1];
+          if (recip_for(ex * ex + ey * ey) == 0.f) all_recip = false;
+          jv0 = iv;
+        }
+      }
+      c.op(D_POLY2D); c.u(nv | (all_recip ? 0x80000000u : 0u)); c.f(v[0]); c.f(v[1]);
       while (c.code.size() % 8 != 0) c.u(0);  // edge records: 8 dwords, 32-byte aligned (two s_load_dwordx4 each)
       uint32_t jv = nv - 1;
       for (uint32_t iv = 0; iv < nv; iv++) {
         float v1x = v[2 * iv], v1y = v[2 * iv + 1], v2x = v[2 * jv], v2y = v[2 * jv + 1];
         float ex = v2x - v1x, ey = v2y - v1y;
-        c.f(v1x); c.f(v1y); c.f(ex); c.f(ey); c.f(ex * ex + ey * ey); c.f(v2y); c.u(0); c.u(0);
+        const float n2e = ex * ex + ey * ey;
+        c.f(v1x); c.f(v1y); c.f(ex); c.f(ey); c.f(n2e); c.f(v2y); c.f(recip_for(n2e)); c.u(0);
         jv = iv;
       }
       break;

@@ -15,6 +15,9 @@ struct Program {
   float bb[6] = {0};
 };
 
+// RN(1/d) for the device's exact division by a wave-uniform divisor, 0 if d is not eligible.
+float recip_for(float d);
+
 // Throws std::runtime_error on malformed trees. max_code_words bounds unrolling blow-up.
 Program compile(const gsdf_tree& t, size_t max_code_words = (1u << 22));
 

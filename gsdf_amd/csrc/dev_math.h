@@ -27,6 +27,28 @@ DM_INL float signf(float a) { return a == 0.0f ? 0.0f : copysignf_(1.0f, a); }
 DM_INL float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 DM_INL float mixf(float x, float y, float a) { return x * (1.0f - a) + y * a; }
 
+// Correctly rounded n/d for a WAVE-UNIFORM divisor d whose correctly rounded reciprocal r = RN(1/d) was
+// computed on the host (compile.cpp: recip_for): q0 = RN(n*r), two Markstein corrections
+// q <- RN(q + RN(n - d*q)*r) with the residual exact by FMA. After the first correction q is a faithful
+// rounding of n/d, so the second yields RN(n/d) (Markstein 1990; Muller et al., Handbook of FP Arithmetic,
+// ch. 4: y = RN(1/b), q faithful, r = a - b*q exact  =>  RN(q + r*y) = RN(a/b)), provided nothing
+// under/overflows: callers guard |n| in [2^-90, 2^90] (divisors are restricted to [2^-30, 2^30] by the
+// host) and fall back to the IEEE expansion for the whole wave otherwise (also for n == 0, whose zero
+// sign the FMA chain does not preserve). 5 full-rate VALU ops instead of ~10 + a quarter-rate v_rcp.
+// Exhaustively checked against v_div for every float32 numerator: tests/test_gpu_eval.py (div selftest).
+DM_INL float div_by_uniform(float n, float d, float r) {
+  float q = n * r;
+  float e = __builtin_fmaf(-d, q, n);
+  q = __builtin_fmaf(e, r, q);
+  e = __builtin_fmaf(-d, q, n);
+  q = __builtin_fmaf(e, r, q);
+  return q;
+}
+DM_INL bool div_fast_ok(float n) {
+  const float a = absf(n);
+  return a >= 8.0779357e-28f /* 2^-90 */ && a <= 1.2379400e+27f /* 2^90 */;
+}
+
 // math32.Hypot (float32 port of go/src/math/hypot.go)
 DM_INL float hypotf_(float p, float q) {
   p = absf(p);

@@ -41,7 +41,7 @@ enum DevOp : uint32_t {
   D_HEX2D,     // r kzr
   D_OCT2D,     // r kzr
   D_ELLIPSE2D, // a b
-  D_POLY2D,    // nv v0x v0y, pad to an 8-dword boundary, then nv x {v1x v1y ex ey n2e v2y 0 0}
+  D_POLY2D,    // nv v0x v0y, pad to an 8-dword boundary, then nv x {v1x v1y ex ey n2e v2y RN(1/n2e)|0 0}
   D_LINES2D,   // ns w then ns x {ax ay bax bay dotba}
   // ---- position pre-ops: P = T(P)
   D_TRANSLATE,     // tx ty tz

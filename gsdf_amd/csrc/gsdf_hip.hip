@@ -786,6 +786,21 @@ __global__ void __launch_bounds__(BLOCK) dc_quads_kernel(const Cube* __restrict_
   }
 }
 
+// Exhaustive self-test of dm::div_by_uniform: every float32 numerator against the IEEE division.
+__global__ void __launch_bounds__(BLOCK) div_selftest_kernel(float d, float r, unsigned long long* __restrict__ bad,
+                                                             unsigned long long* __restrict__ fast_count) {
+  unsigned long long nb = 0, nf = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < (1ull << 32); i += (unsigned long long)gridDim.x * BLOCK) {
+    const float n = __uint_as_float((unsigned)i);
+    if (!dm::div_fast_ok(n)) continue;  // the interpreter takes the IEEE path for these
+    nf++;
+    const float a = dm::div_by_uniform(n, d, r), b = n / d;
+    if (__float_as_uint(a) != __float_as_uint(b)) nb++;
+  }
+  if (nb) atomicAdd(bad, nb);
+  atomicAdd(fast_count, nf);
+}
+
 // STL records (stl.go:15-62): one wave stages 64 x 50-byte records in LDS, then stores dwords.
 __global__ void __launch_bounds__(BLOCK) stl_kernel(const float* __restrict__ tris, uint64_t n, uint8_t* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) uint8_t stage[BLOCK * 50];
@@ -977,6 +992,29 @@ extern "C" int gsdf_hip_program_create(const gsdf_tree* tree, gsdf_program** out
   if (hipMemcpy(p->d_code, p->prog.code.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return cleanup(fail(GSDF_ERR_HIP, "hipMemcpy(program) failed"));
   *out = p;
   return GSDF_OK;
+}
+
+// Test hook: runs dm::div_by_uniform(n, d, RN(1/d)) for all 2^32 numerators n on the GPU and counts results that
+// differ from n / d among the numerators the interpreter would send down the fast path.
+extern "C" int gsdf_hip_selftest_div(float d, uint64_t* mismatches, uint64_t* fast_path_numerators, float* recip) {
+  const float r = gsdf_dev::recip_for(d);
+  if (recip) *recip = r;
+  if (mismatches) *mismatches = 0;
+  if (fast_path_numerators) *fast_path_numerators = 0;
+  if (r == 0.f) return GSDF_OK;  // divisor not eligible: the device always uses the IEEE expansion
+  unsigned long long* d_c = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_c, 16));
+  int rc = GSDF_OK;
+  do {
+    if (hipMemset(d_c, 0, 16) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "memset failed"); break; }
+    hipLaunchKernelGGL(div_selftest_kernel, dim3(4096), dim3(BLOCK), 0, nullptr, d, r, d_c, d_c + 1);
+    unsigned long long h[2] = {0, 0};
+    if (hipMemcpy(h, d_c, 16, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "selftest kernel failed"); break; }
+    if (mismatches) *mismatches = h[0];
+    if (fast_path_numerators) *fast_path_numerators = h[1];
+  } while (0);
+  (void)hipFree(d_c);
+  return rc;
 }
 
 // Host-only (no GPU): lower a tree to the device instruction stream, for inspection/tests.

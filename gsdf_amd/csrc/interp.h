@@ -28,6 +28,54 @@ struct P3 { float x, y, z; };
 // dependency chains hide VALU/transcendental latency at low occupancy.
 #define KLOOP _Pragma("unroll") for (int kp = 0; kp < K; ++kp)
 
+// poly2D (cpu_evaluators.go:793-818), vertex-major: each edge record (8 dwords {v1x v1y ex ey |e|^2 v2y 1/|e|^2 -},
+// 32-byte aligned: two s_load_dwordx4) is fetched once and applied to the K points. FAST divides by the
+// wave-uniform |e|^2 with the host's correctly rounded reciprocal (dm::div_by_uniform) and tracks the
+// smallest/largest |numerator|; it returns false (wave-uniform) if some lane left the proven-exact range.
+template <int K, bool FAST>
+__device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t nv, float v0x, float v0y, const P3 (&pv)[K],
+                                           float (&d)[K], bool (&neg)[K]) {
+  using namespace dm;
+  float nmin[K], nmax[K];
+  KLOOP {
+    float wx0 = pv[kp].x - v0x, wy0 = pv[kp].y - v0y;
+    d[kp] = wx0 * wx0 + wy0 * wy0;
+    neg[kp] = false;
+    nmin[kp] = 1.0f;
+    nmax[kp] = 1.0f;
+  }
+  for (uint32_t iv = 0; iv < nv; iv++, q += 8) {
+    const f4ptr er = (f4ptr)(code + q);
+    const v4f e0 = er[0], e1 = er[1];
+    const float v1x = e0.x, v1y = e0.y, ex = e0.z, ey = e0.w, n2e = e1.x, v2y = e1.y, rn2e = e1.z;
+    KLOOP {
+      const float px = pv[kp].x, py = pv[kp].y;
+      const float wx = px - v1x, wy = py - v1y;
+      const float num = wx * ex + wy * ey;
+      float quo;
+      if (FAST) {
+        quo = div_by_uniform(num, n2e, rn2e);
+        nmin[kp] = minf(nmin[kp], absf(num));
+        nmax[kp] = maxf(nmax[kp], absf(num));
+      } else {
+        quo = num / n2e;
+      }
+      // clamp(v,0,1) as med3: differs from the reference's if-chain only in the sign of a zero t, which cannot
+      // reach d (t only scales e before the square)
+      const float t = __builtin_amdgcn_fmed3f(quo, 0.f, 1.f);
+      const float bx = wx - t * ex, by = wy - t * ey;
+      d[kp] = minf(d[kp], bx * bx + by * by);
+      const bool b1 = py >= v1y, b2 = py < v2y, b3 = ex * wy > ey * wx;
+      const bool flip = (b1 == b2) && (b2 == b3);  // all three true or all three false
+      neg[kp] = neg[kp] != flip;
+    }
+  }
+  if (!FAST) return true;
+  bool ok = true;
+  KLOOP ok = ok && nmin[kp] >= 8.0779357e-28f /* 2^-90 */ && nmax[kp] <= 1.2379400e+27f /* 2^90 */;
+  return __all(ok);
+}
+
 template <int K>
 __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)[K],
                                          float* __restrict__ lds /* already offset by tid */, const uint32_t nthreads) {
@@ -358,40 +406,22 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       case D_POLY2D: {
-        // vertex-major: each edge's six scalars are fetched once and applied to the K points.
-        const uint32_t nv = PU(0);
+        // See poly_edges below. Pass with the exact reciprocal division first; only if some lane's numerator left
+        // the range where that form is proven exact, redo the polygon with the IEEE expansion (identical bits).
+        const uint32_t hdr = PU(0);
+        const uint32_t nv = hdr & 0x7fffffffu;
         const float v0x = PF(1), v0y = PF(2);
+        const uint32_t q0 = (pc + 4u + 7u) & ~7u;
         float d[K];
         bool neg[K];
-        KLOOP {
-          float wx0 = pv[kp].x - v0x, wy0 = pv[kp].y - v0y;
-          d[kp] = wx0 * wx0 + wy0 * wy0;
-          neg[kp] = false;
-        }
-        // edge records are 8 dwords {v1x v1y ex ey |e|^2 v2y - -}, 32-byte aligned in the stream: two s_load_dwordx4
-        uint32_t q = (pc + 4u + 7u) & ~7u;
-        for (uint32_t iv = 0; iv < nv; iv++, q += 8) {
-          const f4ptr er = (f4ptr)(code + q);
-          const v4f e0 = er[0], e1 = er[1];
-          const float v1x = e0.x, v1y = e0.y, ex = e0.z, ey = e0.w, n2e = e1.x, v2y = e1.y;
-          KLOOP {
-            const float px = pv[kp].x, py = pv[kp].y;
-            float wx = px - v1x, wy = py - v1y;
-            // clamp(v,0,1) as med3: differs from the reference's if-chain only in the sign of a zero t, which
-            // cannot reach d (t only scales e before the square)
-            float t = __builtin_amdgcn_fmed3f((wx * ex + wy * ey) / n2e, 0.f, 1.f);
-            float bx = wx - t * ex, by = wy - t * ey;
-            d[kp] = minf(d[kp], bx * bx + by * by);
-            bool b1 = py >= v1y, b2 = py < v2y, b3 = ex * wy > ey * wx;
-            bool flip = (b1 == b2) && (b2 == b3);  // all three true or all three false
-            neg[kp] = neg[kp] != flip;
-          }
-        }
+        bool done = false;
+        if (hdr >> 31) done = poly_edges<K, true>(code, q0, nv, v0x, v0y, pv, d, neg);
+        if (!done) poly_edges<K, false>(code, q0, nv, v0x, v0y, pv, d, neg);
         KLOOP {
           float sd = sqrtf_(d[kp]);
           Rv[kp] = neg[kp] ? -sd : sd;  // s * sqrt(d), s = +-1
         }
-        pc = q;
+        pc = q0 + 8u * nv;
         break;
       }
       case D_LINES2D: {

@@ -66,6 +66,9 @@ int gsdf_hip_program_is2d(const gsdf_program* p);
 /* Introspection for tests/benchmarks: lowered program size (32-bit words) and LDS slots per lane. */
 int gsdf_hip_program_info(const gsdf_program* p, uint32_t* code_words, uint32_t* lds_slots);
 uint64_t gsdf_hip_evaluations(const gsdf_program* p);
+/* Test hook (needs a GPU): exhaustive check of the interpreter's exact division by a wave-uniform divisor d against
+ * the IEEE division, over all 2^32 numerators. recip receives RN(1/d) (0: d not eligible, nothing to check). */
+int gsdf_hip_selftest_div(float d, uint64_t* mismatches, uint64_t* fast_path_numerators, float* recip);
 /* Host-only (runs without a GPU): lower a tree to the device instruction stream (gsdf_amd/csrc/dev_ops.h) for
  * inspection. code_out may be NULL to query the size. */
 int gsdf_hip_lower(const gsdf_tree* tree, uint32_t* code_out, uint32_t code_cap, uint32_t* code_words, uint32_t* lds_slots);

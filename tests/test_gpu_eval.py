@@ -137,3 +137,32 @@ def test_many_handles_and_big_union(gpu):
     hs = [gpu.SDF3HIP(p) for p in parts[:8]]
     for h, p in zip(hs, parts):
         assert _mismatch(h.Evaluate(pos), OracleSDF(p.tree()).Evaluate(pos)) == 0
+
+
+def test_exact_division_by_uniform_divisor_exhaustive(gpu):
+    """dm::div_by_uniform (interp.h polygon loop) == IEEE division for EVERY float32 numerator the fast path
+    accepts, for every polygon divisor |e|^2 of the benchmark scenes and a few adversarial divisors."""
+    import ctypes as C
+    from gsdf_amd._ctypes_common import OP
+    b = Builder()
+    divisors = set()
+    for sc in ("npt-flange", "bolt", "knurled-cylinder"):
+        t = b.Scene(sc).tree()
+        for i in range(t.n_nodes):
+            nd = t.nodes[i]
+            if nd.op == OP["POLY2D"]:
+                v = np.array([t.aux[nd.aux_off + k] for k in range(nd.aux_len)], np.float32).reshape(-1, 2)
+                e = np.roll(v, 1, axis=0) - v
+                divisors.update(np.float32(e[:, 0] * e[:, 0] + e[:, 1] * e[:, 1]).tolist())
+    divisors.update([1.0, 3.0, 0.1, 7.0, 1.9999999, 1.0000001, 6.2831855, 1e-9, 1e9, float(np.float32(2.0) ** -30)])
+    assert len(divisors) > 20
+    checked = 0
+    for d in sorted(divisors):
+        bad, nfast, r = C.c_uint64(), C.c_uint64(), C.c_float()
+        rc = gpu.lib().gsdf_hip_selftest_div(np.float32(d), C.byref(bad), C.byref(nfast), C.byref(r))
+        assert rc == 0
+        if r.value == 0.0:
+            continue  # not eligible: interpreter uses the IEEE expansion
+        assert nfast.value > 2_000_000_000 and bad.value == 0, (d, bad.value)
+        checked += 1
+    assert checked >= 20

@@ -25,7 +25,7 @@ def decode(code):
         op = w & OP_MASK
         name, n = NAMES[op], NPAR[op]
         if name == "D_POLY2D":
-            nv = int(code[pc + 1])
+            nv = int(code[pc + 1]) & 0x7FFFFFFF
             n = ((pc + 4 + 7) & ~7) - (pc + 1) + 8 * nv
         elif name == "D_LINES2D":
             n = 2 + 5 * int(code[pc + 1])
