@@ -786,6 +786,39 @@ __global__ void __launch_bounds__(BLOCK) dc_quads_kernel(const Cube* __restrict_
   }
 }
 
+// glrender.ImageRendererSDF2.Render (image.go:76-118) with the default black/white/red conversion (:52-61):
+// pixel (i,j) samples (xmin + i*dx, ymax - j*dy); dist gets the raw distances, rgba the converted pixels.
+template <int K>
+__global__ void __launch_bounds__(BLOCK, 3) image2_kernel(const uint32_t* __restrict__ code_g, int w, int h, float xmin, float ymax,
+                                                          float dx, float dy, float* __restrict__ dist, uint32_t* __restrict__ rgba) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  const uint64_t n = (uint64_t)w * (uint64_t)h;
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK * K;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK * K; base < n; base += step) {
+    P3 p[K];
+    float d[K];
+#pragma unroll
+    for (int kp = 0; kp < K; kp++) {
+      uint64_t i = base + (uint64_t)kp * BLOCK + threadIdx.x;
+      if (i >= n) i = n - 1;
+      const unsigned px = (unsigned)(i % (uint64_t)w), py = (unsigned)(i / (uint64_t)w);
+      p[kp] = P3{(float)px * dx + xmin, ymax - (float)py * dy, 0.f};
+    }
+    gsdf_dev::sdf_eval<K>(code, p, d, lds, BLOCK);
+#pragma unroll
+    for (int kp = 0; kp < K; kp++) {
+      const uint64_t i = base + (uint64_t)kp * BLOCK + threadIdx.x;
+      if (i < n) {
+        const float v = d[kp];
+        if (dist) dist[i] = v;
+        const bool bad = (v != v) || (dm::absf(v) == __builtin_inff());
+        if (rgba) rgba[i] = bad ? 0xff0000ffu : (v > 0.f ? 0xffffffffu : 0xff000000u);  // R,G,B,A bytes little-endian
+      }
+    }
+  }
+}
+
 // Exhaustive self-test of dm::div_by_uniform: every float32 numerator against the IEEE division.
 __global__ void __launch_bounds__(BLOCK) div_selftest_kernel(float d, float r, unsigned long long* __restrict__ bad,
                                                              unsigned long long* __restrict__ fast_count) {
@@ -1322,6 +1355,33 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   *out = m;
   return GSDF_OK;
 #undef HIP_TRYM
+}
+
+// glrender.ImageRendererSDF2.Render for a 2D program: w x h pixels over Bounds(); host outputs (either may be NULL).
+extern "C" int gsdf_hip_image2(gsdf_program* p, int w, int h, float* dist_out, uint8_t* rgba_out) {
+  if (!p) return fail(GSDF_ERR_BAD_ARGUMENT, "null program");
+  if (!p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 3D, image2 called");
+  if (w <= 0 || h <= 0) return fail(GSDF_ERR_BAD_ARGUMENT, "bad image size");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t n = (size_t)w * (size_t)h;
+  // image.go:82-88: dx = sz.X/dxi ; bb.Min += (dx/2, dy/2) ; y = bb.Max.Y - j*dy ; x = i*dx + bb.Min.X
+  const float szx = p->prog.bb[3] - p->prog.bb[0], szy = p->prog.bb[4] - p->prog.bb[1];
+  const float dx = szx / (float)w, dy = szy / (float)h;
+  const float xmin = p->prog.bb[0] + dx / 2, ymax = p->prog.bb[4];
+  DevBuf dd, dc;
+  HIP_TRY(dd.alloc(n * 4));
+  HIP_TRY(dc.alloc(n * 4));
+  const int k = p->batch_k();
+  const unsigned grid = grid_for((n + k - 1) / k, p->num_cu, 8);
+#define LAUNCH_IMG(KK) hipLaunchKernelGGL((image2_kernel<KK>), dim3(grid), dim3(BLOCK), p->lds_bytes(KK), p->stream, p->d_code, w, h, xmin, ymax, dx, dy, (float*)dd.p, (uint32_t*)dc.p)
+  if (k == 4) LAUNCH_IMG(4); else if (k == 2) LAUNCH_IMG(2); else LAUNCH_IMG(1);
+#undef LAUNCH_IMG
+  HIP_TRY(hipGetLastError());
+  if (dist_out) HIP_TRY(hipMemcpyAsync(dist_out, dd.p, n * 4, hipMemcpyDeviceToHost, p->stream));
+  if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, dc.p, n * 4, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->evals += n;
+  return GSDF_OK;
 }
 
 // glrender.DualContourRenderer.Reset + RenderAll with DualContourLeastSquares on device.

@@ -22,7 +22,7 @@ ErrMismatchBufferLength = "position and distance buffer length mismatch"
 # every symbol include/gsdf_hip.h declares
 SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "gsdf_hip_program_destroy",
            "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_selftest_div",
-           "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3",
+           "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3", "gsdf_hip_image2",
            "gsdf_hip_mesh_octree", "gsdf_hip_mesh_dualcontour", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
            "gsdf_hip_mesh_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner"]
 
@@ -71,6 +71,7 @@ def lib():
         for f in (L.gsdf_hip_eval3_dev, L.gsdf_hip_eval2_dev):
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         L.gsdf_hip_normals3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]
+        L.gsdf_hip_image2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.gsdf_hip_mesh_octree.argtypes = [C.c_void_p, C.c_float, C.POINTER(MeshOpts), C.POINTER(C.c_void_p)]
         L.gsdf_hip_mesh_dualcontour.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.gsdf_hip_mesh_stats_get.argtypes = [C.c_void_p, C.POINTER(MeshStats)]
@@ -160,6 +161,13 @@ class SDFHIP:
         """Device-resident evaluation on raw device pointers (e.g. torch tensors' data_ptr())."""
         f = lib().gsdf_hip_eval2_dev if self.is2d else lib().gsdf_hip_eval3_dev
         _check(f(self._h, d_pos_ptr, stride_bytes, d_dist_ptr, n, stream))
+
+    def render_image(self, w, h):
+        """glrender.ImageRendererSDF2.Render with the default conversion: (dist (h,w) float32, rgba (h,w,4) uint8)."""
+        dist = np.empty((h, w), np.float32)
+        rgba = np.empty((h, w, 4), np.uint8)
+        _check(lib().gsdf_hip_image2(self._h, w, h, dist.ctypes.data, rgba.ctypes.data))
+        return dist, rgba
 
     def normals(self, pos, step):
         pos = np.ascontiguousarray(pos, np.float32)

@@ -14,6 +14,7 @@
  *   gsdf_hip_eval3_dev         same, positions/distances already resident in HBM (no reference
  *                              equivalent: the GL path re-uploads every call, gpu_cgo.go:238-257)
  *   gsdf_hip_normals3          gleval.NormalsCentralDiff              gleval/gleval.go:53-108
+ *   gsdf_hip_image2            glrender.ImageRendererSDF2.Render (default conversion)  glrender/image.go:46-118
  *   gsdf_hip_mesh_octree       glrender.NewOctreeRenderer + RenderAll glrender/octreerenderer.go:43-178,
  *                              (octree prune + marching cubes on device) glrender/marchcubes.go:14-98
  *   gsdf_hip_mesh_dualcontour  glrender.DualContourRenderer.Reset/RenderAll + DualContourLeastSquares
@@ -84,6 +85,10 @@ int gsdf_hip_eval3_dev(gsdf_program* p, const void* d_pos, size_t pos_stride_byt
 int gsdf_hip_eval2_dev(gsdf_program* p, const void* d_pos, size_t pos_stride_bytes, float* d_dist, size_t n, void* stream);
 /* Central-difference normals (not normalised), host buffers, 12-byte xyz in and out. */
 int gsdf_hip_normals3(gsdf_program* p, const float* pos, float* normals, size_t n, float step);
+
+/* ImageRendererSDF2.Render of a 2D program over its Bounds(): dist_out (w*h floats, row 0 = top) and/or rgba_out
+ * (w*h*4 bytes: black inside, white outside, red for NaN/Inf -- the renderer's default conversion). */
+int gsdf_hip_image2(gsdf_program* p, int w, int h, float* dist_out, uint8_t* rgba_out);
 
 typedef struct gsdf_mesh_opts {
   int prune;          /* 1: octree centre-test pruning of every Level>=3 cube (default); 0: visit all leaves */

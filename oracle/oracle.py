@@ -138,6 +138,26 @@ class OracleSDF:
         self._L.orc_mesh_free(C.byref(m))
         return r
 
+    def render_image(self, w, h):
+        """glrender.ImageRendererSDF2.Render (image.go:76-118) + default conversion (:52-61), row by row."""
+        bb = self.bb.astype(np.float32)
+        f = np.float32
+        dx, dy = f((bb[3] - bb[0]) / f(w)), f((bb[4] - bb[1]) / f(h))
+        xmin = f(bb[0] + f(dx / f(2)))
+        dist = np.empty((h, w), np.float32)
+        for j in range(h):
+            y = f(bb[4] - f(f(j) * dy))
+            pos = np.empty((w, 2), np.float32)
+            pos[:, 0] = (np.arange(w, dtype=np.float32) * dx).astype(np.float32) + xmin
+            pos[:, 1] = y
+            dist[j] = self.Evaluate(pos)
+        rgba = np.zeros((h, w, 4), np.uint8)
+        rgba[..., 3] = 255
+        rgba[dist > 0, :3] = 255
+        bad = ~np.isfinite(dist)
+        rgba[bad] = (255, 0, 0, 255)
+        return dist, rgba
+
     def normals_central_diff(self, pos, step):
         pos = np.ascontiguousarray(pos, np.float32)
         nrm = np.empty_like(pos)

@@ -166,3 +166,17 @@ def test_exact_division_by_uniform_divisor_exhaustive(gpu):
         assert nfast.value > 2_000_000_000 and bad.value == 0, (d, bad.value)
         checked += 1
     assert checked >= 20
+
+
+def test_image_renderer_sdf2(gpu):
+    """glrender.ImageRendererSDF2 (image.go:76-118): pixel lattice, row 0 on top, default black/white conversion."""
+    _, shapes = corpus.shapes2d()
+    for name, sh in shapes[:12]:
+        for (w, h) in ((64, 48), (257, 131)):
+            dg, cg = gpu.SDF2HIP(sh).render_image(w, h)
+            dc, cc = OracleSDF(sh.tree()).render_image(w, h)
+            assert _mismatch(dg.ravel(), dc.ravel()) == 0, (name, w, h)
+            assert (cg == cc).all()
+    b = Builder()
+    with pytest.raises(gpu.HipError):
+        gpu.SDF3HIP(b.NewSphere(1)).render_image(8, 8)  # 3D program
