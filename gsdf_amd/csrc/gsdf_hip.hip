@@ -508,14 +508,17 @@ struct DCCounters {
 template <int K>
 __global__ void __launch_bounds__(BLOCK, 3) dc_origin_kernel(const uint32_t* __restrict__ code_g, int nshift, float ox, float oy,
                                                              float oz, float res, int* __restrict__ grid, Cube* __restrict__ cubes,
-                                                             unsigned long long cube_cap, DCCounters* __restrict__ ctr) {
+                                                             unsigned long long cube_cap, unsigned zlo, unsigned zhi,
+                                                             DCCounters* __restrict__ ctr) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
-  const unsigned long long ncell = 1ull << (3 * nshift);
+  // multi-GPU: this rank evaluates the z-slab [zlo, zhi) of the lattice (its own slab plus a one-cube halo)
+  const unsigned long long cell0 = (unsigned long long)zlo << (2 * nshift);
+  const unsigned long long ncell = (unsigned long long)zhi << (2 * nshift);
   const unsigned mask = (1u << nshift) - 1u;
   const float maxDist = res * 2;
   const uint64_t step = (uint64_t)gridDim.x * BLOCK * K;
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK * K; base < ncell; base += step) {
+  for (uint64_t base = cell0 + (uint64_t)blockIdx.x * BLOCK * K; base < ncell; base += step) {
     P3 p[K];
     float d[K];
 #pragma unroll
@@ -638,7 +641,7 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_normals_kernel(const uint32_t* __
 __global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restrict__ cubes, unsigned long long cube_cap,
                                                             const float4* __restrict__ dists, const int* __restrict__ grid,
                                                             const float* __restrict__ nrm, int nshift, float ox, float oy, float oz,
-                                                            float res, float sqrtLambda, float* __restrict__ fv,
+                                                            float res, float sqrtLambda, float* __restrict__ fv, unsigned zplace_hi,
                                                             DCCounters* __restrict__ ctr) {
   __shared__ double sQ[DC_ROWS][3][DC_BLOCK];
   __shared__ double sB[DC_ROWS][DC_BLOCK];
@@ -651,6 +654,7 @@ __global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restri
     const uint64_t i = base + t;
     if (i >= n) continue;  // no block-level sync below: each lane owns column t of the LDS arrays
     const Cube c = cubes[i];
+    if (c.z >= zplace_hi) continue;  // top halo layer: only its distances/normals are needed
     const float cox = ox + res * (float)c.x, coy = oy + res * (float)c.y, coz = oz + res * (float)c.z;
     const float invRes = 1.0f / res;
     int nr = 0, nnb = 0;
@@ -737,8 +741,8 @@ __global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restri
 __global__ void __launch_bounds__(BLOCK) dc_quads_kernel(const Cube* __restrict__ cubes, const float4* __restrict__ dists,
                                                          const unsigned* __restrict__ edges, unsigned long long edge_cap,
                                                          const int* __restrict__ grid, const float* __restrict__ fv, int nshift,
-                                                         float* __restrict__ tris, unsigned long long tri_cap,
-                                                         DCCounters* __restrict__ ctr) {
+                                                         unsigned zown_lo, unsigned zown_hi, float* __restrict__ tris,
+                                                         unsigned long long tri_cap, DCCounters* __restrict__ ctr) {
   unsigned long long n = uniform_u64(ctr->n_edges);
   if (n > edge_cap) n = edge_cap;
   const int nn = 1 << nshift;
@@ -753,6 +757,7 @@ __global__ void __launch_bounds__(BLOCK) dc_quads_kernel(const Cube* __restrict_
       const unsigned ci = e >> 2, a = e & 3u;
       const Cube c = cubes[ci];
       const float4 d = dists[ci];
+      ok = ok && c.z >= zown_lo && c.z < zown_hi;  // quads are emitted by the rank that owns the edge's cube
       flip = ((a == 0 ? d.y : (a == 1 ? d.z : d.w)) - d.x) < 0.f;
       // EdgeNeighborsX/Y/Z (:271-287): offsets in cube units
       const int off[3][4][3] = {{{0, -1, -1}, {0, 0, -1}, {0, 0, 0}, {0, -1, 0}},
@@ -1385,11 +1390,13 @@ extern "C" int gsdf_hip_image2(gsdf_program* p, int w, int h, float* dist_out, u
 }
 
 // glrender.DualContourRenderer.Reset + RenderAll with DualContourLeastSquares on device.
-extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chiseled, void* stream, gsdf_mesh** out) {
+extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chiseled, int shard_rank, int shard_count, void* stream,
+                                         gsdf_mesh** out) {
   if (!p || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
   *out = nullptr;
   if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
   if (!(res > 0) || std::isnan(res) || std::isinf(res)) return fail(GSDF_ERR_RESOLUTION, "invalid renderer cube resolution");
+  if (shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return fail(GSDF_ERR_BAD_ARGUMENT, "bad shard rank/count");
   HIP_TRY(hipSetDevice(p->device));
   hipStream_t s = stream ? (hipStream_t)stream : p->stream;
   // Reset (dual_contour.go:26-41): bounds shifted by -res/2, makeICube
@@ -1403,6 +1410,14 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
   const int nshift = levels - 1;
   const uint64_t ncell = (uint64_t)1 << (3 * nshift);
   const float ox = mn[0], oy = mn[1], oz = mn[2];
+  // multi-GPU: z-slabs. A rank owns the quads of cubes with z in [zown_lo, zown_hi); their vertices need the cubes of
+  // [zown_lo-1, zown_hi) placed, which in turn need the distances and normals of [zown_lo-1, zown_hi+1). Every stage is
+  // a pure function of the lattice cell, so the halo is recomputed instead of exchanged (no data-path collective).
+  const unsigned nz = 1u << nshift;
+  const unsigned zown_lo = (unsigned)(((uint64_t)nz * (uint64_t)shard_rank) / (uint64_t)shard_count);
+  const unsigned zown_hi = (unsigned)(((uint64_t)nz * (uint64_t)(shard_rank + 1)) / (uint64_t)shard_count);
+  const unsigned zlo = zown_lo > 0 ? zown_lo - 1 : 0, zhi = zown_hi < nz ? zown_hi + 1 : nz;
+  const uint64_t nslab = (uint64_t)(zhi - zlo) << (2 * nshift);
 
   gsdf_mesh* m = new (std::nothrow) gsdf_mesh();
   if (!m) return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory");
@@ -1427,7 +1442,7 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
   const float h = (chiseled ? (float)1e-4 : (float)2e-8) * 0.5f;  // NormalsCentralDiff: step *= 0.5
   const float sqrtLambda = chiseled ? (float)(std::sqrt(1e-5) * 1e-4) : (float)std::sqrt(1e-5);
   for (int attempt = 0;; attempt++) {
-    if (ccap > ncell) ccap = ncell;
+    if (ccap > nslab) ccap = nslab;
     const uint64_t ecap = 3 * ccap, tcap = 2 * ecap;
     HIP_TRYM(p->q0.ensure(ccap * sizeof(Cube)));
     DevBuf d2, f2, n2, e2;
@@ -1441,9 +1456,10 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
       if (!m->d_tris) { HIP_TRYM(hipMalloc((void**)&m->d_tris, tcap * 36)); m->cap = tcap; }
     }
     HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(DCCounters), s));
+    if (shard_count > 1) HIP_TRYM(hipMemsetAsync(grid.p, 0xff, ncell * sizeof(int), s));  // cells outside the slab read as empty
     HIP_TRYM(hipEventRecord(p->ev[0], s));
-    const unsigned g1 = grid_for((ncell + lk - 1) / lk, p->num_cu, 8);
-#define LAUNCH_O(KK) hipLaunchKernelGGL((dc_origin_kernel<KK>), dim3(g1), dim3(BLOCK), p->lds_bytes(KK), s, p->d_code, nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, d_ctr)
+    const unsigned g1 = grid_for((nslab + lk - 1) / lk, p->num_cu, 8);
+#define LAUNCH_O(KK) hipLaunchKernelGGL((dc_origin_kernel<KK>), dim3(g1), dim3(BLOCK), p->lds_bytes(KK), s, p->d_code, nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, zlo, zhi, d_ctr)
     if (lk == 4) LAUNCH_O(4); else if (lk == 2) LAUNCH_O(2); else LAUNCH_O(1);
 #undef LAUNCH_O
     HIP_TRYM(hipGetLastError());
@@ -1456,17 +1472,17 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     HIP_TRYM(hipGetLastError());
     hipLaunchKernelGGL(dc_place_kernel, dim3(grid_for(ccap * 4, p->num_cu, 16)), dim3(DC_BLOCK), 0, s, (const Cube*)p->q0.p,
                        (unsigned long long)ccap, (const float4*)d2.p, (const int*)grid.p, (const float*)n2.p, nshift, ox, oy, oz, res,
-                       sqrtLambda, (float*)f2.p, d_ctr);
+                       sqrtLambda, (float*)f2.p, zown_hi, d_ctr);
     HIP_TRYM(hipGetLastError());
     hipLaunchKernelGGL(dc_quads_kernel, dim3(grid_for(ecap, p->num_cu, 8)), dim3(BLOCK), 0, s, (const Cube*)p->q0.p, (const float4*)d2.p,
-                       (const unsigned*)e2.p, (unsigned long long)ecap, (const int*)grid.p, (const float*)f2.p, nshift, m->d_tris,
-                       (unsigned long long)m->cap, d_ctr);
+                       (const unsigned*)e2.p, (unsigned long long)ecap, (const int*)grid.p, (const float*)f2.p, nshift, zown_lo, zown_hi,
+                       m->d_tris, (unsigned long long)m->cap, d_ctr);
     HIP_TRYM(hipGetLastError());
     HIP_TRYM(hipEventRecord(p->ev[1], s));
     HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));
     HIP_TRYM(hipStreamSynchronize(s));
     if (hc.q_overflow || hc.t_overflow) {
-      if (attempt >= 8 || ccap >= ncell) return bail(fail(GSDF_ERR_CAPACITY, "dual contouring queue capacity exceeded"));
+      if (attempt >= 8 || ccap >= nslab) return bail(fail(GSDF_ERR_CAPACITY, "dual contouring queue capacity exceeded"));
       ccap *= 8;
       continue;
     }
@@ -1475,10 +1491,10 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
   float ms = 0;
   HIP_TRYM(hipEventElapsedTime(&ms, p->ev[0], p->ev[1]));
   m->st.n_tris = 2 * hc.n_tris;  // quads -> 2 triangles
-  m->st.evals = ncell + 4 * hc.n_cubes + 6 * hc.n_edges;
-  m->st.evals_prune = ncell;
+  m->st.evals = nslab + 4 * hc.n_cubes + 6 * hc.n_edges;
+  m->st.evals_prune = nslab;
   m->st.evals_leaf = 4 * hc.n_cubes + 6 * hc.n_edges;
-  m->st.pruned_leaves = ncell - hc.n_cubes;
+  m->st.pruned_leaves = nslab - hc.n_cubes;
   m->st.leaf_cubes = hc.n_cubes;
   m->st.active_leaves = hc.n_edges;
   m->st.ms_total = ms;

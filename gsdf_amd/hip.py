@@ -73,7 +73,7 @@ def lib():
         L.gsdf_hip_normals3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]
         L.gsdf_hip_image2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.gsdf_hip_mesh_octree.argtypes = [C.c_void_p, C.c_float, C.POINTER(MeshOpts), C.POINTER(C.c_void_p)]
-        L.gsdf_hip_mesh_dualcontour.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.gsdf_hip_mesh_dualcontour.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.gsdf_hip_mesh_stats_get.argtypes = [C.c_void_p, C.POINTER(MeshStats)]
         L.gsdf_hip_mesh_read.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         L.gsdf_hip_mesh_dev_tris.restype = C.c_void_p
@@ -257,7 +257,8 @@ class OctreeHIP:
 class DualContourHIP(OctreeHIP):
     """glrender.DualContourRenderer with DualContourLeastSquares on device (Reset + RenderAll)."""
 
-    def __init__(self, sdf, res, chiseled=False, stream=None):
+    def __init__(self, sdf, res, chiseled=False, stream=None, shard_rank=0, shard_count=1):
+        self._shard = (shard_rank, shard_count)
         self.sdf = sdf
         self._mesh = None
         self._cursor = 0
@@ -269,7 +270,8 @@ class DualContourHIP(OctreeHIP):
         self._free()
         self.sdf = sdf
         m = C.c_void_p()
-        _check(lib().gsdf_hip_mesh_dualcontour(sdf._h, np.float32(res), int(self._chiseled), self._stream, C.byref(m)))
+        _check(lib().gsdf_hip_mesh_dualcontour(sdf._h, np.float32(res), int(self._chiseled), self._shard[0], self._shard[1],
+                                               self._stream, C.byref(m)))
         self._mesh = m
         self._cursor = 0
         st = MeshStats()

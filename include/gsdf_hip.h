@@ -120,8 +120,10 @@ typedef struct gsdf_mesh_stats {
 
 int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_opts* opts, gsdf_mesh** out);
 /* Dual contouring (least-squares vertex placement; chiseled = DualContourLeastSquares.Chiseled). The result is a
- * gsdf_mesh like the octree mesher's (stats: leaf_cubes = kept cubes, active_leaves = active edges). */
-int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chiseled, void* stream, gsdf_mesh** out);
+ * gsdf_mesh like the octree mesher's (stats: leaf_cubes = kept cubes, active_leaves = active edges). Multi-GPU: rank
+ * shard_rank of shard_count emits the quads of its z-slab of the lattice (one-cube halo recomputed, nothing exchanged). */
+int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chiseled, int shard_rank, int shard_count, void* stream,
+                              gsdf_mesh** out);
 int gsdf_hip_mesh_stats_get(const gsdf_mesh* m, gsdf_mesh_stats* st);
 /* Copy triangles [first, first+count) to host memory: 9 floats (36 B) each = ms3.Triangle. */
 int gsdf_hip_mesh_read(const gsdf_mesh* m, uint64_t first, uint64_t count, float* dst);

@@ -193,3 +193,14 @@ def test_zero_copy_device_view_for_gather(gpu):
     assert t.shape == (oc.n_tris(), 9) and t.data_ptr() == oc.dev_ptr()
     assert (t.cpu().numpy().reshape(-1, 3, 3) == oc.RenderAll()).all()
     assert tensor_from_dev_ptr(0, 0, torch.device("cuda", 0)).shape == (0, 9)
+
+
+def test_dualcontour_sharded_union_equals_whole(gpu):
+    b = Builder()
+    for sh, res in ((b.Scene("bolt"), 0.25), (b.Scene("npt-flange"), 0.5)):
+        sdf = gpu.SDF3HIP(sh)
+        whole = _sorted(gpu.DualContourHIP(sdf, np.float32(res)).RenderAll())
+        for world in (2, 3, 8):
+            parts = [gpu.DualContourHIP(sdf, np.float32(res), shard_rank=r, shard_count=world) for r in range(world)]
+            u = _sorted(np.concatenate([p.RenderAll() for p in parts]))
+            assert u.shape == whole.shape and (u.view(np.uint32) == whole.view(np.uint32)).all(), (world, u.shape, whole.shape)
