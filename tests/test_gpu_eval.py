@@ -180,3 +180,22 @@ def test_image_renderer_sdf2(gpu):
     b = Builder()
     with pytest.raises(gpu.HipError):
         gpu.SDF3HIP(b.NewSphere(1)).render_image(8, 8)  # 3D program
+
+
+def test_large_batch_and_special_values(gpu):
+    b = Builder()
+    s = b.Scene("npt-flange")
+    sdf = gpu.SDF3HIP(s)
+    n = (1 << 22) + 3
+    rng = np.random.default_rng(11)
+    pos = (rng.standard_normal((n, 3)) * 20).astype(np.float32)
+    pos[:64] = 0.0                                   # the axis: atan2(0,0), hypot(0,0)
+    pos[64:128, :2] = 0.0                            # on the screw axis at various z
+    pos[128:192, 1] = 0.0                            # y == 0: atan2(+-0, x)
+    pos[192:256, 1] = -0.0
+    pos[256:320, 0] = 0.0
+    d = sdf.Evaluate(pos)
+    ref = OracleSDF(s.tree())
+    idx = np.concatenate([np.arange(4096), rng.integers(0, n, 200000)])
+    assert _mismatch(d[idx], ref.Evaluate(pos[idx])) == 0
+    assert np.isfinite(d).all()

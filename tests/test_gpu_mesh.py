@@ -204,3 +204,38 @@ def test_dualcontour_sharded_union_equals_whole(gpu):
             parts = [gpu.DualContourHIP(sdf, np.float32(res), shard_rank=r, shard_count=world) for r in range(world)]
             u = _sorted(np.concatenate([p.RenderAll() for p in parts]))
             assert u.shape == whole.shape and (u.view(np.uint32) == whole.view(np.uint32)).all(), (world, u.shape, whole.shape)
+
+
+def test_empty_and_degenerate_meshes(gpu):
+    b = Builder()
+    # a surface-free field inside the bounds: an offset sphere whose zero set is outside its (reference) Bounds()
+    far = b.Offset(b.NewSphere(1.0), 10.0)      # d = |p| - 1 + 10 > 0 everywhere
+    sdf = gpu.SDF3HIP(far)
+    oc = gpu.OctreeHIP(sdf, np.float32(0.5))
+    assert oc.n_tris() == 0 and oc.RenderAll().shape == (0, 3, 3)
+    n, eof = oc.ReadTriangles(np.zeros((8, 3, 3), np.float32))
+    assert n == 0 and eof
+    with pytest.raises(gpu.HipError) as e:
+        oc.WriteBinarySTL()                      # "empty triangle slice" (stl.go:16-18)
+    assert e.value.code == -1
+    assert OracleSDF(far.tree()).render_octree(np.float32(0.5)).n_tris == 0
+    dc = gpu.DualContourHIP(sdf, np.float32(0.5))
+    assert dc.n_tris() == 0
+    # the coarsest legal octree: 2 levels (resolution just fine enough)
+    s = b.NewSphere(1.0)
+    o2 = gpu.OctreeHIP(gpu.SDF3HIP(s), np.float32(1.2))
+    r2 = OracleSDF(s.tree()).render_octree(np.float32(1.2))
+    assert o2.stats.levels == 2 == r2.levels and o2.n_tris() == r2.n_tris
+
+
+def test_repeated_resets_reuse_buffers_and_stay_exact(gpu):
+    b = Builder()
+    s = b.Scene("npt-flange")
+    sdf = gpu.SDF3HIP(s)
+    oc = gpu.OctreeHIP(sdf, np.float32(float(s.Diagonal()) / 100))
+    first = _digest(oc.RenderAll())
+    for div in (160, 100, 220, 100):            # Octree.Reset with a new resolution (octreerenderer.go:71)
+        oc.Reset(sdf, np.float32(float(s.Diagonal()) / div))
+        if div == 100:
+            assert _digest(oc.RenderAll()) == first
+    assert sdf.Evaluations() > 0
