@@ -207,4 +207,4 @@ class Builder:
     def HexHead(self, r, h, round_neg, round_pos): return self._call("threads.HexHead", [r, h], [int(round_neg), int(round_pos)])
     def KnurledHead(self, r, h, pitch): return self._call("threads.KnurledHead", [r, h, pitch])
     # ---- benchmark scenes (examples/*)
-    def Scene(self, name, *fargs): return self._call("scene." + name, list(fargs))
+    def Scene(self, name, *fargs, ints=()): return self._call("scene." + name, list(fargs), list(ints))

@@ -291,5 +291,37 @@ inline Shader3D KnurledCylinder(Builder& bld, float diameter = 20) {
   return obj;
 }
 
+// Synthetic stand-in for BASELINE.json configs[4] (forge/textsdf multi-glyph plate): forge/textsdf needs
+// golang.org/x/image/font/sfnt (TTF parsing, 26.6 fixed-point scaling, kerning), which is external to the reference
+// and is not restated. The computational shape is reproduced instead: a wide Union2D of translated glyph polygons
+// (outlines with holes via Difference2D, like font.go:214-337), extruded and united with a base plate
+// (examples/ui-text/uitext.go:30-42 pattern).
+inline Shader3D GlyphPlate(Builder& bld, int nglyphs = 24) {
+  auto poly = [&](std::initializer_list<Vec2> v) { return bld.NewPolygon(std::vector<Vec2>(v)); };
+  // block letters on a 6 x 10 cell
+  Shader2D G = poly({{0, 0}, {6, 0}, {6, 5}, {3, 5}, {3, 3.5f}, {4.5f, 3.5f}, {4.5f, 1.5f}, {1.5f, 1.5f}, {1.5f, 8.5f}, {6, 8.5f}, {6, 10}, {0, 10}});
+  Shader2D S = poly({{0, 0}, {6, 0}, {6, 5.75f}, {1.5f, 5.75f}, {1.5f, 8.5f}, {6, 8.5f}, {6, 10}, {0, 10}, {0, 4.25f}, {4.5f, 4.25f}, {4.5f, 1.5f}, {0, 1.5f}});
+  Shader2D Dout = poly({{0, 0}, {4, 0}, {6, 2}, {6, 8}, {4, 10}, {0, 10}});
+  Shader2D Din = poly({{1.5f, 1.5f}, {3.4f, 1.5f}, {4.5f, 2.6f}, {4.5f, 7.4f}, {3.4f, 8.5f}, {1.5f, 8.5f}});
+  Shader2D D = bld.Difference2D(Dout, Din);
+  Shader2D F = poly({{0, 0}, {1.5f, 0}, {1.5f, 4.25f}, {4.5f, 4.25f}, {4.5f, 5.75f}, {1.5f, 5.75f}, {1.5f, 8.5f}, {6, 8.5f}, {6, 10}, {0, 10}});
+  Shader2D glyphs[4] = {G, S, D, F};
+  std::vector<Shader2D> line;
+  const float advance = 7.5f;
+  const int per_row = 12;
+  for (int i = 0; i < nglyphs; i++) {
+    const float x = advance * (float)(i % per_row), y = -13.0f * (float)(i / per_row);
+    line.push_back(bld.Translate2D(glyphs[i % 4], x, y));
+  }
+  Shader2D text = line.size() == 1 ? line[0] : bld.Union2D(line);
+  Shader3D text3 = bld.Extrude(text, 2.0f);
+  Box3 tb = bld.Bounds(text3);
+  Vec3 sz = tb.Size();
+  Shader3D plate = bld.NewBox(sz.X + 4, sz.Y + 4, 1.0f, 0.25f);
+  Vec3 c = tb.Center();
+  plate = bld.Translate(plate, c.X, c.Y, -1.25f);
+  return bld.Union(text3, plate);
+}
+
 }  // namespace scenes
 }  // namespace gsdf

@@ -80,6 +80,7 @@ def shapes3d(bld=None):
     out.append(("scene_npt_flange", b.Scene("npt-flange")))
     out.append(("scene_bolt", b.Scene("bolt")))
     out.append(("scene_knurled_cylinder", b.Scene("knurled-cylinder")))
+    out.append(("scene_glyph_plate", b.Scene("glyph-plate")))
     return b, out
 
 

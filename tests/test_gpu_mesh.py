@@ -239,3 +239,22 @@ def test_repeated_resets_reuse_buffers_and_stay_exact(gpu):
         if div == 100:
             assert _digest(oc.RenderAll()) == first
     assert sdf.Evaluations() > 0
+
+
+def test_glyph_plate_wide_union(gpu):
+    """Config-5-shaped workload (wide 2D union -> extrude -> plate): octree + dual contouring vs the oracle."""
+    b = Builder()
+    s = b.Scene("glyph-plate")
+    sdf = gpu.SDF3HIP(s)
+    ref = OracleSDF(s.tree())
+    res = np.float32(float(s.Diagonal()) / 150)
+    oc = gpu.OctreeHIP(sdf, res)
+    r = ref.render_octree(res)
+    assert oc.n_tris() == r.n_tris
+    assert (_sorted(oc.RenderAll()).view(np.uint32) == _sorted(r.tris).view(np.uint32)).all()
+    dc = gpu.DualContourHIP(sdf, np.float32(1.5))
+    rd = ref.render_dualcontour(np.float32(1.5))
+    assert dc.n_tris() == rd.n_tris
+    assert (_sorted(dc.RenderAll()).view(np.uint32) == _sorted(rd.tris).view(np.uint32)).all()
+    fine = gpu.DualContourHIP(sdf, np.float32(0.25))   # 10 levels: 134 M lattice cells, the reference's practical limit
+    assert fine.stats.levels == 10 and fine.n_tris() > 200000
