@@ -49,6 +49,20 @@ DM_INL bool div_fast_ok(float n) {
   return a >= 8.0779357e-28f /* 2^-90 */ && a <= 1.2379400e+27f /* 2^90 */;
 }
 
+// Correctly rounded sqrt for s in [1, 2] (hypot's 1 + q*q with q in [0,1]): hipcc's generic expansion of sqrtf
+// spends 7 of its 16 instructions on denormal pre-scaling and zero/inf class handling that cannot apply here. What
+// remains is its own fix-up: v_sqrt_f32 is within 1 ulp; compare the residuals of the neighbours r-1ulp / r+1ulp
+// (exact by FMA) and step if needed. Checked against sqrtf for every float in [1, 2] on the GPU
+// (test_sqrt_unit_range_exhaustive).
+DM_INL float sqrt_1to2(float s) {
+  float r = __builtin_amdgcn_sqrtf(s);
+  const float rm = __uint_as_float(__float_as_uint(r) - 1u), rp = __uint_as_float(__float_as_uint(r) + 1u);
+  const float em = __builtin_fmaf(-rm, r, s), ep = __builtin_fmaf(-rp, r, s);
+  r = em <= 0.0f ? rm : r;
+  r = ep > 0.0f ? rp : r;
+  return r;
+}
+
 // math32.Hypot (float32 port of go/src/math/hypot.go)
 DM_INL float hypotf_(float p, float q) {
   p = absf(p);
@@ -56,7 +70,7 @@ DM_INL float hypotf_(float p, float q) {
   float hi = p < q ? q : p;
   float lo = p < q ? p : q;
   float r = lo / hi;
-  float v = hi * sqrtf_(1.0f + r * r);
+  float v = hi * sqrt_1to2(1.0f + r * r);  // r in [0,1] (NaN only for 0/0, discarded below)
   return hi == 0.0f ? 0.0f : v;
 }
 DM_INL float norm3(float x, float y, float z) { return hypotf_(x, hypotf_(y, z)); }  // ms3.Norm

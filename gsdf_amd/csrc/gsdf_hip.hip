@@ -824,6 +824,16 @@ __global__ void __launch_bounds__(BLOCK, 3) image2_kernel(const uint32_t* __rest
   }
 }
 
+// Exhaustive self-test of dm::sqrt_1to2 over every float in [1, 2].
+__global__ void __launch_bounds__(BLOCK) sqrt_selftest_kernel(unsigned long long* __restrict__ bad) {
+  unsigned long long nb = 0;
+  for (unsigned i = 0x3f800000u + blockIdx.x * BLOCK + threadIdx.x; i <= 0x40000000u; i += gridDim.x * BLOCK) {
+    const float s = __uint_as_float(i);
+    if (__float_as_uint(dm::sqrt_1to2(s)) != __float_as_uint(__builtin_sqrtf(s))) nb++;
+  }
+  if (nb) atomicAdd(bad, nb);
+}
+
 // Exhaustive self-test of dm::div_by_uniform: every float32 numerator against the IEEE division.
 __global__ void __launch_bounds__(BLOCK) div_selftest_kernel(float d, float r, unsigned long long* __restrict__ bad,
                                                              unsigned long long* __restrict__ fast_count) {
@@ -1052,6 +1062,22 @@ extern "C" int gsdf_hip_selftest_div(float d, uint64_t* mismatches, uint64_t* fa
     if (fast_path_numerators) *fast_path_numerators = h[1];
   } while (0);
   (void)hipFree(d_c);
+  return rc;
+}
+
+// Test hook: dm::sqrt_1to2 against sqrtf for all 8,388,609 floats in [1, 2].
+extern "C" int gsdf_hip_selftest_sqrt(uint64_t* mismatches) {
+  unsigned long long* d_c = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_c, 8));
+  int rc = GSDF_OK;
+  unsigned long long h = 0;
+  if (hipMemset(d_c, 0, 8) != hipSuccess) rc = fail(GSDF_ERR_HIP, "memset failed");
+  if (!rc) {
+    hipLaunchKernelGGL(sqrt_selftest_kernel, dim3(1024), dim3(BLOCK), 0, nullptr, d_c);
+    if (hipMemcpy(&h, d_c, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(GSDF_ERR_HIP, "selftest kernel failed");
+  }
+  (void)hipFree(d_c);
+  if (mismatches) *mismatches = h;
   return rc;
 }
 

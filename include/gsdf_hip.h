@@ -70,6 +70,8 @@ uint64_t gsdf_hip_evaluations(const gsdf_program* p);
 /* Test hook (needs a GPU): exhaustive check of the interpreter's exact division by a wave-uniform divisor d against
  * the IEEE division, over all 2^32 numerators. recip receives RN(1/d) (0: d not eligible, nothing to check). */
 int gsdf_hip_selftest_div(float d, uint64_t* mismatches, uint64_t* fast_path_numerators, float* recip);
+/* Test hook (needs a GPU): the interpreter's sqrt for hypot's [1,2] argument range against sqrtf, all floats in range. */
+int gsdf_hip_selftest_sqrt(uint64_t* mismatches);
 /* Host-only (runs without a GPU): lower a tree to the device instruction stream (gsdf_amd/csrc/dev_ops.h) for
  * inspection. code_out may be NULL to query the size. */
 int gsdf_hip_lower(const gsdf_tree* tree, uint32_t* code_out, uint32_t code_cap, uint32_t* code_words, uint32_t* lds_slots);

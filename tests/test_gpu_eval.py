@@ -199,3 +199,10 @@ def test_large_batch_and_special_values(gpu):
     idx = np.concatenate([np.arange(4096), rng.integers(0, n, 200000)])
     assert _mismatch(d[idx], ref.Evaluate(pos[idx])) == 0
     assert np.isfinite(d).all()
+
+
+def test_sqrt_unit_range_exhaustive(gpu):
+    import ctypes as C
+    bad = C.c_uint64(1)
+    assert gpu.lib().gsdf_hip_selftest_sqrt(C.byref(bad)) == 0
+    assert bad.value == 0
