@@ -34,7 +34,6 @@ float recip_for(float d) {
 
 namespace {
 
-constexpr float TRIBISECT = 0.8660254037844386467637231707529361834714026269051903140279034897f;
 constexpr float SQRT3 = 1.7320508075688772935274463415058723669428052538103806280558069794f;
 
 struct Ctx {

@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
   unsigned long long n_cubes = uniform_u64(ctr->n_level[lq]);  // survivors of the last prune level (device-side count)
   if (n_cubes > cube_cap) n_cubes = cube_cap;                  // queue overflowed: host reruns with larger queues
   const uint64_t n_leaves = n_cubes << (3 * sh);
-  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned lane = threadIdx.x & 63;
   unsigned long long my_active = 0, my_cont = 0;
   const uint64_t step = (uint64_t)gridDim.x * BLOCK;
   for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_leaves; base += step) {
@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_brick_kernel(const uint32_t
       val[ax * 8 + u + 1] = Aa + res;  // Box max = origin + size
     }
     __builtin_amdgcn_wave_barrier();
-    const unsigned nx = nax[0], ny = nax[1], nxy = nax[0] * nax[1], N = nxy * nax[2];
+    const unsigned nx = nax[0], nxy = nax[0] * nax[1], N = nxy * nax[2];
     const float inx = 1.0f / (float)nx, inxy = 1.0f / (float)nxy;
     if (bvalid && lane == 0) my_points += N;
 #pragma unroll 1

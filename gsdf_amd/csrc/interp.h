@@ -101,8 +101,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       // ------------------------------------------------ 3D primitives
       case D_SPHERE: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           R = norm3(p.x, p.y, p.z) - PF(0);
         }
         pc += 2;
@@ -110,8 +110,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_BOX: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float r = PF(3);
           float qx = (absf(p.x) - PF(0)) + r, qy = (absf(p.y) - PF(1)) + r, qz = (absf(p.z) - PF(2)) + r;
           R = norm3(maxf(qx, 0.f), maxf(qy, 0.f), maxf(qz, 0.f)) + minf(maxf(qx, maxf(qy, qz)), 0.0f) - r;
@@ -121,8 +121,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_BOXFRAME: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float e = PF(0);
           float px = absf(p.x) - PF(1), py = absf(p.y) - PF(2), pz = absf(p.z) - PF(3);
           float qx = absf(px + e) + (-e), qy = absf(py + e) + (-e), qz = absf(pz + e) + (-e);
@@ -139,8 +139,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_TORUS: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           if (!use_hxy) hxy[kp] = hypotf_(p.x, p.y);
           float qx = hxy[kp] - PF(0);
           R = norm2(qx, p.z) - PF(1);
@@ -150,8 +150,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_CYL0: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           if (!use_hxy) hxy[kp] = hypotf_(p.x, p.y);
           float dx = hxy[kp] - PF(0);
           float dy = absf(p.z) - PF(1);
@@ -162,8 +162,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_CYLR: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float round = PF(2);
           if (!use_hxy) hxy[kp] = hypotf_(p.x, p.y);
           float dx = hxy[kp] - PF(0) + round;
@@ -175,8 +175,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_HEX: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float k1 = -0.8660254037844386f, k2 = 0.5f, twok1 = -1.7320508075688772f;
           const float h1 = PF(0), h2 = PF(1), clm = PF(2);
           float px = absf(p.x), py = absf(p.y), pz = absf(p.z);
@@ -193,8 +193,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       // ------------------------------------------------ 2D primitives
       case D_LINE2D: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float bax = PF(2), bay = PF(3);
           float pax = p.x - PF(0), pay = p.y - PF(1);
           float h = clampf((pax * bax + pay * bay) / PF(4), 0.f, 1.f);
@@ -205,8 +205,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_ARC2D: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float r = PF(0), t = PF(1), s = PF(2), c = PF(3);
           float px = absf(p.x), py = p.y;
           float a = norm2(px - PF(4), py - PF(5)) - t;
@@ -218,8 +218,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_QUADBEZIER2D: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float Ax = PF(0), Ay = PF(1), ax = PF(2), ay = PF(3), a2 = PF(4), bx = PF(5), by = PF(6), cx = PF(7),
                       cy = PF(8), kk = PF(9), kx = PF(10), kx2 = PF(11), thick = PF(12);
           float dx = Ax - p.x, dy = Ay - p.y;
@@ -266,8 +266,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_CIRCLE2D: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           if (!use_hxy) hxy[kp] = hypotf_(p.x, p.y);
           R = hxy[kp] - PF(0);
         }
@@ -276,8 +276,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_EQTRI2D: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float k = 1.7320508075688772f;
           const float r = PF(0);
           float px = absf(p.x) - r, py = p.y + PF(1);
@@ -294,8 +294,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_RECT2D: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           float dx = absf(p.x) - PF(0), dy = absf(p.y) - PF(1);
           R = norm2(maxf(dx, 0.f), maxf(dy, 0.f)) + minf(0.f, maxf(dx, dy));
         }
@@ -304,8 +304,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_DIAMOND2D: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float bx = PF(0), by = PF(1);
           float px = absf(p.x), py = absf(p.y);
           float tx = bx - 2.f * px, ty = by - 2.f * py;
@@ -318,8 +318,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_X2D: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           float px = absf(p.x), py = absf(p.y);
           float sub = 0.5f * minf(px + py, PF(0));
           R = norm2(px - sub, py - sub) - PF(1);
@@ -329,8 +329,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_HEX2D: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float kx = -0.8660254037844386f, ky = 0.5f;
           const float r = PF(0), kzr = PF(1);
           float px = absf(p.x), py = absf(p.y);
@@ -346,8 +346,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_OCT2D: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float kx = -0.9238795325f, ky = 0.3826834323f;
           const float r = PF(0), kzr = PF(1);
           float px = absf(p.x), py = absf(p.y);
@@ -366,8 +366,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_ELLIPSE2D: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           float a = PF(0), b = PF(1);
           float px = absf(p.x), py = absf(p.y);
           if (px > py) { float t = px; px = py; py = t; t = a; a = b; b = t; }
@@ -447,8 +447,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       // ------------------------------------------------ position pre-ops
       case D_TRANSLATE: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           p.x = p.x - PF(0); p.y = p.y - PF(1); p.z = p.z - PF(2);
         }
         pc += 4;
@@ -456,8 +456,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_SCALE_PRE: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float f = PF(0);
           p.x = f * p.x; p.y = f * p.y; p.z = f * p.z;
         }
@@ -466,8 +466,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_SYMMETRY: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const uint32_t bits = PU(0);
           if (bits & 1u) p.x = absf(p.x);
           if (bits & 2u) p.y = absf(p.y);
@@ -478,8 +478,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_TRANSFORM: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           float x = PF(0) * p.x + PF(1) * p.y + PF(2) * p.z + PF(3);
           float y = PF(4) * p.x + PF(5) * p.y + PF(6) * p.z + PF(7);
           float z = PF(8) * p.x + PF(9) * p.y + PF(10) * p.z + PF(11);
@@ -490,8 +490,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_TWIST: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float k = PF(0);
           float c, s;
           cossinf_(k * p.z, c, s);
@@ -503,8 +503,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_ROT2D: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           float x = PF(0) * p.x + PF(1) * p.y, y = PF(2) * p.x + PF(3) * p.y;
           p.x = x; p.y = y;
         }
@@ -513,8 +513,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_EXTRUDE_PRE: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           LDSF(slot) = absf(p.z) - PF(0);
         }
         pc += 2;
@@ -522,8 +522,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_REVOLVE_PRE: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           float x = hypotf_(p.x, p.z) - PF(0);
           p.x = x;  // p.y stays
         }
@@ -532,8 +532,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_SCREW_PRE: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float pitch = PF(0), lead = PF(1), L = PF(2), tanTaper = PF(3), halfp = PF(4);
           if (!use_hxy) hxy[kp] = hypotf_(p.x, p.y);
           float y0 = hxy[kp];
@@ -551,8 +551,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_ELONGATE_PRE: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           float qx = absf(p.x) - PF(0), qy = absf(p.y) - PF(1), qz = absf(p.z) - PF(2);
           LDSF(slot) = minf(maxf(qx, maxf(qy, qz)), 0.f);
           p.x = maxf(qx, 0.f); p.y = maxf(qy, 0.f); p.z = maxf(qz, 0.f);
@@ -562,8 +562,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_ELONGATE2D_PRE: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           float qx = absf(p.x) - PF(0), qy = absf(p.y) - PF(1);
           LDSF(slot) = minf(maxf(qx, qy), 0.f);
           p.x = maxf(qx, 0.f); p.y = maxf(qy, 0.f);
@@ -573,8 +573,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_ARRAY_PRE: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           float ox = LDSF(slot), oy = LDSF(slot + 1), oz = LDSF(slot + 2);
           const float sx = PF(3), sy = PF(4), sz = PF(5);
           float idx = roundf_(ox / sx), idy = roundf_(oy / sy), idz = roundf_(oz / sz);
@@ -589,8 +589,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_ARRAY2D_PRE: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           float ox = LDSF(slot), oy = LDSF(slot + 1);
           const float sx = PF(2), sy = PF(3);
           float idx = roundf_(ox / sx), idy = roundf_(oy / sy);
@@ -604,8 +604,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_CIRC_PRE: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float angle = PF(0), ncirc = PF(1), ninsm1 = PF(2);
           float pangle = atan2f_(p.y, p.x);
           float id = floorf_(pangle / angle);
@@ -625,8 +625,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_LOADP2_SUB: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           p.x = LDSF(slot) - PF(0);
           p.y = LDSF(slot + 1) - PF(1);
         }
@@ -640,8 +640,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       case D_ANNULUS: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = absf(R) - PF(0); } pc += 2; break; }
       case D_EXTRUDE_POST: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           float wy = LDSF(slot);
           R = minf(0.f, maxf(R, wy)) + hypotf_(maxf(R, 0.f), maxf(wy, 0.f));
         }
@@ -665,8 +665,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       case D_COMBINE_XOR: { KLOOP { float& R = Rv[kp]; float a = LDSF(slot), b = R; R = maxf(minf(a, b), -maxf(a, b)); } pc += 1; break; }
       case D_COMBINE_SUNION: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float k = PF(0);
           float a = LDSF(slot), b = R;
           if (swap_ab) { float t = a; a = b; b = t; }
@@ -678,8 +678,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_COMBINE_SDIFF: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float k = PF(0);
           float a = LDSF(slot), b = R;
           if (swap_ab) { float t = a; a = b; b = t; }
@@ -691,8 +691,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_COMBINE_SINTER: {
         KLOOP {
-          P3& p = pv[kp];
-          float& R = Rv[kp];
+          [[maybe_unused]] P3& p = pv[kp];
+          [[maybe_unused]] float& R = Rv[kp];
           const float k = PF(0);
           float a = LDSF(slot), b = R;
           if (swap_ab) { float t = a; a = b; b = t; }
