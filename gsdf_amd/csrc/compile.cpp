@@ -49,6 +49,32 @@ struct Ctx {
   uint32_t xyver = 1, next_ver = 2, hxyver = 0;
   std::vector<uint32_t> slotver = std::vector<uint32_t>(1 << 16, 0);
   void bump() { xyver = next_ver++; }
+  // Full-position version (x, y and z): a new one after every position-rewriting instruction (see op()).
+  // Saved positions that are still live are remembered with their versions, so a combine that needs the
+  // position it was entered with does not store a second copy of a value some enclosing frame already
+  // holds (deep CSG trees otherwise spend most of their LDS slots on copies of the root position, and the
+  // slot count decides how many points per lane the interpreter can batch).
+  uint32_t pver = 1;
+  std::vector<uint32_t> slotpver = std::vector<uint32_t>(1 << 16, 0);
+  struct Saved { int slot; bool is2d; };
+  std::vector<Saved> live;
+  int find_saved(bool is2d) const {
+    for (size_t k = live.size(); k-- > 0;) {
+      const Saved& s = live[k];
+      if (is2d ? (slotver[(size_t)s.slot] == xyver) : (!s.is2d && slotpver[(size_t)s.slot] == pver)) return s.slot;
+    }
+    return -1;
+  }
+  void mark_saved(int slot, bool is2d) {
+    slotver[(size_t)slot] = xyver;
+    slotpver[(size_t)slot] = pver;
+    live.push_back({slot, is2d});
+  }
+  void load_saved(int slot, bool is2d) {
+    op(is2d ? D_LOADP2 : D_LOADP3, slot);
+    xyver = slotver[(size_t)slot];
+    pver = is2d ? next_ver++ : slotpver[(size_t)slot];  // LOADP2 leaves z as it was: treat as a new position
+  }
   uint32_t hxy_flag() {  // call when emitting a consumer of hypot(P.x,P.y)
     uint32_t f = (hxyver == xyver) ? D_FLAG_HXY : 0u;
     hxyver = xyver;
@@ -66,6 +92,8 @@ struct Ctx {
   void op(uint32_t o, int slot = 0) {
     if (code.size() > max_code) throw std::runtime_error("program too large after unrolling multi-evaluation nodes");
     code.push_back(o | ((uint32_t)slot << 16));
+    const uint32_t base = o & D_OP_MASK;
+    if (base >= D_TRANSLATE && base <= D_LOADP2_SUB) pver = next_ver++;
   }
   void f(float v) { uint32_t u; std::memcpy(&u, &v, 4); code.push_back(u); }
   void u(uint32_t v) { code.push_back(v); }
@@ -112,15 +140,20 @@ void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int dept
   bool need_save = false;
   for (uint32_t k = 0; k + 1 < n.nchild; k++) need_save = need_save || clobbers(c, c.child(n, order[k]));
   int slotP = -1;
+  bool own_save = false;
   if (need_save) {
-    slotP = c.alloc(is2d ? 2 : 3);
-    c.op(is2d ? D_SAVEP2 : D_SAVEP3, slotP);
-    c.slotver[(size_t)slotP] = c.xyver;
+    slotP = c.find_saved(is2d);  // an enclosing frame already holds exactly this position
+    if (slotP < 0) {
+      own_save = true;
+      slotP = c.alloc(is2d ? 2 : 3);
+      c.op(is2d ? D_SAVEP2 : D_SAVEP3, slotP);
+      c.mark_saved(slotP, is2d);
+    }
   }
   int slotD = c.alloc(1);
   bool dirty = false;
   for (uint32_t k = 0; k < n.nchild; k++) {
-    if (k > 0 && dirty) { c.op(is2d ? D_LOADP2 : D_LOADP3, slotP); c.xyver = c.slotver[(size_t)slotP]; dirty = false; }
+    if (k > 0 && dirty) { c.load_saved(slotP, is2d); dirty = false; }
     uint32_t ch = c.child(n, order[k]);
     gen(c, ch, depth + 1);
     dirty = dirty || clobbers(c, ch);
@@ -128,7 +161,7 @@ void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int dept
     if (k + 1 < n.nchild) c.op(D_SAVER, slotD);
   }
   c.release(1);
-  if (need_save) c.release(is2d ? 2 : 3);
+  if (own_save) { c.live.pop_back(); c.release(is2d ? 2 : 3); }
 }
 
 void gen(Ctx& c, uint32_t i, int depth) {
@@ -225,14 +258,17 @@ void gen(Ctx& c, uint32_t i, int depth) {
       c.op(D_CIRC_PRE, slotP);
       c.bump();
       c.slotver[(size_t)slotP] = c.xyver;  // p0
+      c.slotpver[(size_t)slotP] = c.next_ver++;
+      c.live.push_back({slotP, is2d});       // frames of the second pass find p0 here
       c.bump();                              // P = p1
       c.f((float)(2 * gsdf::kPi) / P[1]); c.f(P[1]); c.f((float)((int)P[0] - 1));
       gen(c, c.child(n, 0), depth + 1);  // pos1 first
       c.op(D_SAVER, slotD);
-      c.op(is2d ? D_LOADP2 : D_LOADP3, slotP);
-      c.xyver = c.slotver[(size_t)slotP];
+      c.load_saved(slotP, is2d);
+      if (is2d) c.slotpver[(size_t)slotP] = c.pver;
       gen(c, c.child(n, 0), depth + 1);  // pos0
       c.op(D_COMBINE_MIN, slotD);
+      c.live.pop_back();
       c.release(is2d ? 3 : 4);
       break;
     }

@@ -62,6 +62,29 @@ def test_npt_flange_program():
     assert ((poly[4] + 4 + 7) & ~7) % 8 == 0
 
 
+def test_saved_positions_are_not_duplicated():
+    """A frame that needs the position an enclosing frame already saved reuses that slot: the deep example
+    trees keep one copy of the root position (bolt 13 -> 7 slots, knurled-cylinder 18 -> 12: 4 points per lane)."""
+    b = Builder()
+    for scene, max_slots, saves in (("bolt", 7, 1), ("knurled-cylinder", 12, 3)):
+        code, slots = hip.lower(b.Scene(scene))
+        ins = decode(code)
+        assert slots <= max_slots, (scene, slots)
+        assert [i[0] for i in ins].count("D_SAVEP3") == saves, scene
+        # every load reads a slot that some earlier instruction saved
+        saved = set()
+        for name, _, _, slot, _ in ins:
+            if name in ("D_SAVEP3", "D_SAVEP2"):
+                saved.add(slot)
+            if name in ("D_LOADP3", "D_LOADP2"):
+                assert slot in saved, (scene, slot)
+    # a position rewritten between two frames is saved again (different value)
+    sh = b.Union(b.Translate(b.Union(b.Translate(b.NewSphere(1), 1, 0, 0), b.Translate(b.NewSphere(1), 0, 1, 0)), 0, 0, 1),
+                 b.Translate(b.NewSphere(1), 0, 0, 2))
+    names = [i[0] for i in decode(hip.lower(sh)[0])]
+    assert names.count("D_SAVEP3") == 2
+
+
 def test_hxy_not_reused_across_xy_changes():
     b = Builder()
     c = b.NewCylinder(1, 2, 0)

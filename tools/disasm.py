@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""List the lowered device program of a scene (host-only, no GPU needed): tools/disasm.py npt-flange"""
+import os, re, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gsdf_amd.builder import Builder
+from gsdf_amd import hip
+
+src = open(os.path.join(os.path.dirname(__file__), "..", "gsdf_amd", "csrc", "dev_ops.h")).read()
+body = src[src.index("enum DevOp"):src.index("D_OP_COUNT")]
+body = re.sub(r"//[^\n]*", "", body)
+names = re.findall(r"\bD_[A-Z0-9_]+", body)
+tab = src[src.index("kDevOpParams[D_OP_COUNT]"):]
+tab = re.sub(r"/\*.*?\*/", "", tab[tab.index("{") + 1:tab.index("}")])
+nparams = [int(x) for x in re.findall(r"\d+", tab)]
+assert len(names) == len(nparams), (len(names), len(nparams))
+
+def listing(code):
+    pc, out = 0, []
+    f = code.view(np.float32)
+    while True:
+        w = int(code[pc]); op = w & 0x3fff; slot = w >> 16
+        fl = ("|HXY" if w & 0x4000 else "") + ("|SWAP" if w & 0x8000 else "")
+        name = names[op]
+        if name == "D_POLY2D":
+            nv = int(code[pc + 1]) & 0x7fffffff
+            q0 = (pc + 4 + 7) & ~7
+            out.append(f"{pc:5d} {name}{fl} slot={slot} nv={nv} fast={int(code[pc+1])>>31}")
+            pc = q0 + 8 * nv
+        elif name == "D_LINES2D":
+            ns = int(code[pc + 1]); out.append(f"{pc:5d} {name}{fl} ns={ns}"); pc += 3 + 5 * ns
+        else:
+            n = nparams[op]
+            out.append(f"{pc:5d} {name}{fl} slot={slot} " + " ".join(f"{f[pc+1+i]:.6g}" for i in range(n)))
+            pc += 1 + n
+        if name == "D_END":
+            break
+    return out
+
+if __name__ == "__main__":
+    sh = Builder().Scene(sys.argv[1] if len(sys.argv) > 1 else "npt-flange")
+    code, slots = hip.lower(sh)
+    print(f"{len(code)} words, {slots} LDS slots")
+    print("\n".join(listing(code)))
