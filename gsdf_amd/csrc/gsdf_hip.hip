@@ -1336,7 +1336,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
         used_brick = true;
       } else
       // K=4 at 3 waves/SIMD (168 VGPRs, a few spills) measured 17% faster than 2 waves/SIMD (203 VGPRs, none)
-      if (lk == 4) { if (forced_w == 2) LAUNCH_LEAF(4, 2); else LAUNCH_LEAF(4, 3); }
+      if (lk == 4) { if (forced_w == 2) LAUNCH_LEAF(4, 2); else if (forced_w == 4) LAUNCH_LEAF(4, 4); else LAUNCH_LEAF(4, 3); }
       else if (lk == 2) { if (forced_w == 4) LAUNCH_LEAF(2, 4); else LAUNCH_LEAF(2, 3); }
       else LAUNCH_LEAF(1, 4);
 #undef LAUNCH_LEAF

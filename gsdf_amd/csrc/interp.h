@@ -36,13 +36,13 @@ template <int K, bool FAST>
 __device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t nv, float v0x, float v0y, const P3 (&pv)[K],
                                            float (&d)[K], bool (&neg)[K]) {
   using namespace dm;
-  float nmin[K], nmax[K];
+  // The numerator range guard is shared by the K points of the lane (only a wave-wide verdict is needed):
+  // consecutive updates fold into v_min3_f32 / v_max3_f32.
+  float nmin = 1.0f, nmax = 1.0f;
   KLOOP {
     float wx0 = pv[kp].x - v0x, wy0 = pv[kp].y - v0y;
     d[kp] = wx0 * wx0 + wy0 * wy0;
     neg[kp] = false;
-    nmin[kp] = 1.0f;
-    nmax[kp] = 1.0f;
   }
   for (uint32_t iv = 0; iv < nv; iv++, q += 8) {
     const f4ptr er = (f4ptr)(code + q);
@@ -55,8 +55,8 @@ __device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t n
       float quo;
       if (FAST) {
         quo = div_by_uniform(num, n2e, rn2e);
-        nmin[kp] = minf(nmin[kp], absf(num));
-        nmax[kp] = maxf(nmax[kp], absf(num));
+        nmin = minf(nmin, absf(num));
+        nmax = maxf(nmax, absf(num));
       } else {
         quo = num / n2e;
       }
@@ -71,9 +71,7 @@ __device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t n
     }
   }
   if (!FAST) return true;
-  bool ok = true;
-  KLOOP ok = ok && nmin[kp] >= 8.0779357e-28f /* 2^-90 */ && nmax[kp] <= 1.2379400e+27f /* 2^90 */;
-  return __all(ok);
+  return __all(nmin >= 8.0779357e-28f /* 2^-90 */ && nmax <= 1.2379400e+27f /* 2^90 */);
 }
 
 template <int K>
