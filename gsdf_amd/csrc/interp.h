@@ -39,10 +39,13 @@ __device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t n
   // The numerator range guard is shared by the K points of the lane (only a wave-wide verdict is needed):
   // consecutive updates fold into v_min3_f32 / v_max3_f32.
   float nmin = 1.0f, nmax = 1.0f;
+  // Winding parity as wave-wide lane masks in SGPRs: the three edge predicates are v_cmp results already, so
+  // "all three equal" and the parity update are 4 scalar ops per point with no per-lane select.
+  uint64_t negm[K];
   KLOOP {
     float wx0 = pv[kp].x - v0x, wy0 = pv[kp].y - v0y;
     d[kp] = wx0 * wx0 + wy0 * wy0;
-    neg[kp] = false;
+    negm[kp] = 0;
   }
   for (uint32_t iv = 0; iv < nv; iv++, q += 8) {
     const f4ptr er = (f4ptr)(code + q);
@@ -65,11 +68,12 @@ __device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t n
       const float t = __builtin_amdgcn_fmed3f(quo, 0.f, 1.f);
       const float bx = wx - t * ex, by = wy - t * ey;
       d[kp] = minf(d[kp], bx * bx + by * by);
-      const bool b1 = py >= v1y, b2 = py < v2y, b3 = ex * wy > ey * wx;
-      const bool flip = (b1 == b2) && (b2 == b3);  // all three true or all three false
-      neg[kp] = neg[kp] != flip;
+      const uint64_t b1 = __builtin_amdgcn_ballot_w64(py >= v1y), b2 = __builtin_amdgcn_ballot_w64(py < v2y),
+                     b3 = __builtin_amdgcn_ballot_w64(ex * wy > ey * wx);
+      negm[kp] ^= ~((b1 ^ b2) | (b2 ^ b3));  // flip where all three are true or all three are false
     }
   }
+  KLOOP neg[kp] = __builtin_amdgcn_inverse_ballot_w64(negm[kp]);  // the mask is the per-lane predicate
   if (!FAST) return true;
   return __all(nmin >= 8.0779357e-28f /* 2^-90 */ && nmax <= 1.2379400e+27f /* 2^90 */);
 }
