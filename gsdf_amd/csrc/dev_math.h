@@ -55,23 +55,30 @@ DM_INL bool div_fast_ok(float n) {
 // (exact by FMA) and step if needed. Checked against sqrtf for every float in [1, 2] on the GPU
 // (test_sqrt_unit_range_exhaustive).
 DM_INL float sqrt_1to2(float s) {
-  float r = __builtin_amdgcn_sqrtf(s);
-  const float rm = __uint_as_float(__float_as_uint(r) - 1u), rp = __uint_as_float(__float_as_uint(r) + 1u);
-  const float em = __builtin_fmaf(-rm, r, s), ep = __builtin_fmaf(-rp, r, s);
-  r = em <= 0.0f ? rm : r;
-  r = ep > 0.0f ? rp : r;
-  return r;
+  // r in [1, sqrt 2]: ulp(r) = 2^-23 throughout. With e = s - r*r (FMA; exact wherever the decision is close, see
+  // below) the correctly rounded root is r+1ulp iff s > (r + 2^-24)^2 and r-1ulp iff s < (r - 2^-24)^2. e, r*2^-23
+  // and s are multiples of 2^-46, so the 2^-48 term of the squares cannot decide: the tests reduce to
+  // e > r*2^-23 and e <= -r*2^-23. |e| near r*2^-23 < 2^-22 has at most 24 significant bits (exact); larger |e|
+  // is rounded but stays on its side of the threshold. One residual instead of two neighbour products, and the
+  // +-1 ulp steps are carry-in adds on the bit pattern.
+  const float r = __builtin_amdgcn_sqrtf(s);
+  const float t = r * 1.1920928955078125e-07f;  // r * 2^-23
+  const float e = __builtin_fmaf(-r, r, s);
+  uint32_t u = __float_as_uint(r);
+  u += (e > t) ? 1u : 0u;
+  u -= (e <= -t) ? 1u : 0u;
+  return __uint_as_float(u);
 }
 
 // math32.Hypot (float32 port of go/src/math/hypot.go)
 DM_INL float hypotf_(float p, float q) {
   p = absf(p);
   q = absf(q);
-  float hi = p < q ? q : p;
-  float lo = p < q ? p : q;
-  float r = lo / hi;
-  float v = hi * sqrt_1to2(1.0f + r * r);  // r in [0,1] (NaN only for 0/0, discarded below)
-  return hi == 0.0f ? 0.0f : v;
+  // "if p < q swap" as max/min (identical for non-NaN magnitudes); "if p == 0 return 0" by dividing by at least the
+  // smallest subnormal: hi > 0 is unchanged by the max, hi == 0 gives 0/tiny = 0 and 0 * sqrt(1) = 0.
+  const float hi = maxf(p, q), lo = minf(p, q);
+  const float r = lo / maxf(hi, 1.401298464324817e-45f);
+  return hi * sqrt_1to2(1.0f + r * r);  // r in [0,1]
 }
 DM_INL float norm3(float x, float y, float z) { return hypotf_(x, hypotf_(y, z)); }  // ms3.Norm
 DM_INL float norm2(float x, float y) { return hypotf_(x, y); }                       // ms2.Norm
