@@ -56,6 +56,22 @@ struct Ctx {
   // slot count decides how many points per lane the interpreter can batch).
   uint32_t pver = 1;
   std::vector<uint32_t> slotpver = std::vector<uint32_t>(1 << 16, 0);
+  // Which ENTRY coordinates (bit 0 x, bit 1 y, bit 2 z) each component of the current position depends on: lets
+  // the mesher's leaf kernels share f(P.x,P.y) / g(P.z) between cube corners that enter with equal x,y / equal z
+  // (D_FLAG_SHXY / D_FLAG_SHZ in dev_ops.h). Conservative: anything not known to be component-wise sets all bits.
+  uint8_t dep[3] = {1, 2, 4};
+  std::vector<uint32_t> slotdep = std::vector<uint32_t>(1 << 16, 0x070707u);
+  uint32_t shxy_flag() const { return ((dep[0] | dep[1]) & 4) ? 0u : D_FLAG_SHXY; }
+  uint32_t shz_flag() const { return (dep[2] & 3) ? 0u : D_FLAG_SHZ; }
+  void dep_after(uint32_t base) {
+    switch (base) {
+      case D_TRANSLATE: case D_SCALE_PRE: case D_SYMMETRY: case D_ELONGATE_PRE: case D_ELONGATE2D_PRE: case D_EXTRUDE_PRE:
+        break;  // component-wise (or position untouched)
+      case D_ROT2D: case D_CIRC_PRE: dep[0] = dep[1] = (uint8_t)(dep[0] | dep[1]); break;
+      case D_TWIST: dep[0] = dep[1] = (uint8_t)(dep[0] | dep[1] | dep[2]); break;
+      default: dep[0] = dep[1] = dep[2] = 7; break;
+    }
+  }
   struct Saved { int slot; bool is2d; };
   std::vector<Saved> live;
   int find_saved(bool is2d) const {
@@ -68,12 +84,16 @@ struct Ctx {
   void mark_saved(int slot, bool is2d) {
     slotver[(size_t)slot] = xyver;
     slotpver[(size_t)slot] = pver;
+    slotdep[(size_t)slot] = dep[0] | (dep[1] << 8) | (dep[2] << 16);
     live.push_back({slot, is2d});
   }
   void load_saved(int slot, bool is2d) {
     op(is2d ? D_LOADP2 : D_LOADP3, slot);
     xyver = slotver[(size_t)slot];
     pver = is2d ? next_ver++ : slotpver[(size_t)slot];  // LOADP2 leaves z as it was: treat as a new position
+    const uint32_t d = slotdep[(size_t)slot];
+    dep[0] = (uint8_t)d; dep[1] = (uint8_t)(d >> 8);
+    if (!is2d) dep[2] = (uint8_t)(d >> 16);
   }
   uint32_t hxy_flag() {  // call when emitting a consumer of hypot(P.x,P.y)
     uint32_t f = (hxyver == xyver) ? D_FLAG_HXY : 0u;
@@ -93,7 +113,7 @@ struct Ctx {
     if (code.size() > max_code) throw std::runtime_error("program too large after unrolling multi-evaluation nodes");
     code.push_back(o | ((uint32_t)slot << 16));
     const uint32_t base = o & D_OP_MASK;
-    if (base >= D_TRANSLATE && base <= D_LOADP2_SUB) pver = next_ver++;
+    if (base >= D_TRANSLATE && base <= D_LOADP2_SUB) { pver = next_ver++; dep_after(base); }
   }
   void f(float v) { uint32_t u; std::memcpy(&u, &v, 4); code.push_back(u); }
   void u(uint32_t v) { code.push_back(v); }
@@ -183,11 +203,11 @@ void gen(Ctx& c, uint32_t i, int depth) {
       c.f(0.5f * P[0] + (-2 * e)); c.f(0.5f * P[1] + (-2 * e)); c.f(0.5f * P[2] + (-2 * e));
       break;
     }
-    case GSDF_TORUS: c.op(D_TORUS | c.hxy_flag()); c.f(P[0]); c.f(P[1]); break;                                   // :59-68
+    case GSDF_TORUS: c.op(D_TORUS | c.hxy_flag() | c.shxy_flag()); c.f(P[0]); c.f(P[1]); break;                                   // :59-68
     case GSDF_CYLINDER: {                                                                          // :70-88, primitives.go:147-149
       float r = P[0], h = (P[1] - 2 * P[2]) / 2, round = P[2];
-      if (round == 0) { c.op(D_CYL0 | c.hxy_flag()); c.f(r); c.f(h); }
-      else { c.op(D_CYLR | c.hxy_flag()); c.f(r); c.f(h); c.f(round); }
+      if (round == 0) { c.op(D_CYL0 | c.hxy_flag() | c.shxy_flag()); c.f(r); c.f(h); }
+      else { c.op(D_CYLR | c.hxy_flag() | c.shxy_flag()); c.f(r); c.f(h); c.f(round); }
       break;
     }
     case GSDF_HEX: c.op(D_HEX); c.f(P[0]); c.f(P[1]); c.f(0.57735f * P[0]); break;                  // :90-105
@@ -255,10 +275,11 @@ void gen(Ctx& c, uint32_t i, int depth) {
       child_dim(is2d);
       int slotP = c.alloc(is2d ? 2 : 3), slotD = c.alloc(1);
       if (!is2d) c.op(D_SAVEP3, slotP);  // keeps z at slotP+2; CIRC_PRE overwrites slotP..+1 with p0.xy
-      c.op(D_CIRC_PRE, slotP);
+      c.op(D_CIRC_PRE | c.shxy_flag(), slotP);
       c.bump();
       c.slotver[(size_t)slotP] = c.xyver;  // p0
       c.slotpver[(size_t)slotP] = c.next_ver++;
+      c.slotdep[(size_t)slotP] = c.dep[0] | (c.dep[1] << 8) | (c.dep[2] << 16);  // p0: same dependencies as p1
       c.live.push_back({slotP, is2d});       // frames of the second pass find p0 here
       c.bump();                              // P = p1
       c.f((float)(2 * gsdf::kPi) / P[1]); c.f(P[1]); c.f((float)((int)P[0] - 1));
@@ -273,7 +294,7 @@ void gen(Ctx& c, uint32_t i, int depth) {
       break;
     }
     case GSDF_TWIST: need_children(1); child_dim(false);                                           // :1257-1274
-      c.op(D_TWIST); c.f(P[0]); c.bump(); gen(c, c.child(n, 0), depth + 1); break;
+      c.op(D_TWIST | c.shz_flag()); c.f(P[0]); c.bump(); gen(c, c.child(n, 0), depth + 1); break;
     // ------------------------------- 2D -> 3D -------------------------------
     case GSDF_EXTRUSION: {                                                                         // :506-531
       need_children(1); child_dim(true);
@@ -289,7 +310,7 @@ void gen(Ctx& c, uint32_t i, int depth) {
     case GSDF_SCREW: {                                                                             // threads.go:141-181
       need_children(1); child_dim(true);
       int s = c.alloc(1);
-      c.op(D_SCREW_PRE | c.hxy_flag(), s);
+      c.op(D_SCREW_PRE | c.hxy_flag() | c.shxy_flag(), s);
       c.bump();
       c.f(P[0]); c.f(P[1]); c.f(P[2]); c.f(gsdf::tanf32(P[3])); c.f(P[0] / 2);
       gen(c, c.child(n, 0), depth + 1);
@@ -322,7 +343,7 @@ void gen(Ctx& c, uint32_t i, int depth) {
       c.f(Ax); c.f(Ay); c.f(ax); c.f(ay); c.f(a2); c.f(bx); c.f(by); c.f(cx); c.f(cy); c.f(kk); c.f(kx); c.f(kx2); c.f(P[6] / 2);
       break;
     }
-    case GSDF_CIRCLE2D: c.op(D_CIRCLE2D | c.hxy_flag()); c.f(P[0]); break;                                        // :661-667
+    case GSDF_CIRCLE2D: c.op(D_CIRCLE2D | c.hxy_flag() | c.shxy_flag()); c.f(P[0]); break;                                        // :661-667
     case GSDF_EQTRI2D: { float r = P[0] / SQRT3; c.op(D_EQTRI2D); c.f(r); c.f(r / SQRT3); break; }  // :669-683
     case GSDF_RECT2D: c.op(D_RECT2D); c.f(0.5f * P[0]); c.f(0.5f * P[1]); break;                    // :685-692
     case GSDF_DIAMOND2D: {                                                                         // :694-703

@@ -7,15 +7,23 @@
 // ("LDS-staged node stack", slot s of lane t at lds[s*blockDim + t], conflict-free).
 // Slots are allocated statically by the host compiler, so there is no stack pointer at run time.
 //
-// Encoding: word0 = opcode (bits 0-13) | flags (bits 14-15) | slot<<16 ; then `nparam` 32-bit words.
+// Encoding: word0 = opcode (bits 0-11) | flags (bits 12-15) | slot<<16 ; then `nparam` 32-bit words.
 //   D_FLAG_HXY  (bit 14): hypot(P.x,P.y) of every point is already in the per-point `hxy` register (the host
 //                compiler proved P.xy unchanged since it was last computed): reuse instead of recomputing.
+//   D_FLAG_SHXY (bit 13): P.x and P.y are functions of the ENTRY x,y only (no z has been mixed in), and
+//   D_FLAG_SHZ  (bit 12): P.z is a function of the entry z only. The mesher's leaf kernels feed the interpreter
+//                the corners of one leaf cube in the order {0,4,1,5 | 3,7,2,6}: points 2j and 2j+1 enter with the
+//                same x,y and (4 points per lane) points j and j+2 with the same z, so the flagged instruction's
+//                f(P.x,P.y) (hypot, atan2) resp. g(P.z) (twist sin/cos) is computed once per pair and copied --
+//                same inputs, same operations, same bits. Ignored by every other kernel (arbitrary positions).
 //   D_FLAG_SWAP (bit 15): combine with operand roles exchanged (the second child was evaluated first so that
 //                the position did not have to be saved and restored).
 #pragma once
 #include <stdint.h>
 
-#define D_OP_MASK 0x3fffu
+#define D_OP_MASK 0x0fffu
+#define D_FLAG_SHZ 0x1000u
+#define D_FLAG_SHXY 0x2000u
 #define D_FLAG_HXY 0x4000u
 #define D_FLAG_SWAP 0x8000u
 

@@ -346,18 +346,21 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
     for (unsigned c0 = 0; c0 < 8; c0 += K) {
       P3 pk[K];
       float dk[K];
+      // Corner order {0,4,1,5 | 3,7,2,6}: consecutive points share x,y and (K = 4) points j, j+2 share z, which is
+      // what the interpreter's PAIRED mode needs to compute hypot/atan2(x,y) and twist sin/cos(z) once per pair.
 #pragma unroll
       for (int kp = 0; kp < K; kp++) {
-        const unsigned c = c0 + kp;
+        const unsigned c = (0x62735140u >> (4u * (c0 + kp))) & 7u;
         pk[kp].x = ((c ^ (c >> 1)) & 1u) ? x1 : x0;
         pk[kp].y = ((c >> 1) & 1u) ? y1 : y0;
         pk[kp].z = ((c >> 2) & 1u) ? z1 : z0;
       }
-      gsdf_dev::sdf_eval<K>(code, pk, dk, lds, BLOCK);
+      gsdf_dev::sdf_eval<K, true>(code, pk, dk, lds, BLOCK);
 #pragma unroll
       for (int kp = 0; kp < K; kp++) {
-        vslot[(c0 + kp) * BLOCK] = dk[kp];
-        index |= (dk[kp] < 0.f ? 1u : 0u) << (c0 + kp);
+        const unsigned c = (0x62735140u >> (4u * (c0 + kp))) & 7u;
+        vslot[c * BLOCK] = dk[kp];
+        index |= (dk[kp] < 0.f ? 1u : 0u) << c;
       }
       if (c0 == 0) {
         pass = valid && (dm::absf(dk[0]) <= cubeDiag);

@@ -78,7 +78,11 @@ __device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t n
   return __all(nmin >= 8.0779357e-28f /* 2^-90 */ && nmax <= 1.2379400e+27f /* 2^90 */);
 }
 
-template <int K>
+// PAIRED (the mesher's leaf kernels only): the caller passes the corners of one leaf cube in the order
+// {0,4,1,5 | 3,7,2,6}, i.e. points 2j and 2j+1 enter with bitwise equal x,y and (K = 4) points j and j+2 with equal z.
+// Instructions the host compiler flagged D_FLAG_SHXY / D_FLAG_SHZ then compute their f(P.x,P.y) / g(P.z) once per
+// pair and copy it: same inputs, same operation sequence, same bits as evaluating every corner separately.
+template <int K, bool PAIRED = false>
 __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)[K],
                                          float* __restrict__ lds /* already offset by tid */, const uint32_t nthreads) {
   using namespace dm;
@@ -97,6 +101,15 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
     const uint32_t slot = w >> 16;
     const bool use_hxy = (w & D_FLAG_HXY) != 0u;   // wave-uniform
     const bool swap_ab = (w & D_FLAG_SWAP) != 0u;  // wave-uniform
+    const bool sh_xy = PAIRED && K >= 2 && (w & D_FLAG_SHXY) != 0u;
+    const bool sh_z = PAIRED && K >= 4 && (w & D_FLAG_SHZ) != 0u;
+// hypot(P.x,P.y) of every point into hxy[] unless the cache is valid; odd points copy their pair's value when shared
+#define ENSURE_HXY()                                                                   \
+  if (!use_hxy) {                                                                      \
+    KLOOP if (!(kp & 1)) hxy[kp] = hypotf_(pv[kp].x, pv[kp].y);                         \
+    if (sh_xy) { KLOOP if (kp & 1) hxy[kp] = hxy[kp ? kp - 1 : 0]; }                    \
+    else { KLOOP if (kp & 1) hxy[kp] = hypotf_(pv[kp].x, pv[kp].y); }                   \
+  }
     switch (op) {
       case D_END:
         return;
@@ -140,10 +153,10 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       case D_TORUS: {
+        ENSURE_HXY();
         KLOOP {
           [[maybe_unused]] P3& p = pv[kp];
           [[maybe_unused]] float& R = Rv[kp];
-          if (!use_hxy) hxy[kp] = hypotf_(p.x, p.y);
           float qx = hxy[kp] - PF(0);
           R = norm2(qx, p.z) - PF(1);
         }
@@ -151,10 +164,10 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       case D_CYL0: {
+        ENSURE_HXY();
         KLOOP {
           [[maybe_unused]] P3& p = pv[kp];
           [[maybe_unused]] float& R = Rv[kp];
-          if (!use_hxy) hxy[kp] = hypotf_(p.x, p.y);
           float dx = hxy[kp] - PF(0);
           float dy = absf(p.z) - PF(1);
           R = minf(0.f, maxf(dx, dy)) + hypotf_(maxf(0.f, dx), maxf(0.f, dy));
@@ -163,11 +176,11 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       case D_CYLR: {
+        ENSURE_HXY();
         KLOOP {
           [[maybe_unused]] P3& p = pv[kp];
           [[maybe_unused]] float& R = Rv[kp];
           const float round = PF(2);
-          if (!use_hxy) hxy[kp] = hypotf_(p.x, p.y);
           float dx = hxy[kp] - PF(0) + round;
           float dy = absf(p.z) - PF(1);
           R = minf(maxf(dx, dy), 0.f) + hypotf_(maxf(dx, 0.f), maxf(dy, 0.f)) - round;
@@ -267,10 +280,10 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       case D_CIRCLE2D: {
+        ENSURE_HXY();
         KLOOP {
           [[maybe_unused]] P3& p = pv[kp];
           [[maybe_unused]] float& R = Rv[kp];
-          if (!use_hxy) hxy[kp] = hypotf_(p.x, p.y);
           R = hxy[kp] - PF(0);
         }
         pc += 2;
@@ -491,12 +504,17 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       case D_TWIST: {
+        float tc[K], ts[K];  // cos/sin(k * P.z): a function of z only
+        {
+          const float k = PF(0);
+          KLOOP if (kp < (K + 1) / 2) cossinf_(k * pv[kp].z, tc[kp], ts[kp]);
+          if (sh_z) { KLOOP if (kp >= (K + 1) / 2) { tc[kp] = tc[kp - K / 2]; ts[kp] = ts[kp - K / 2]; } }
+          else { KLOOP if (kp >= (K + 1) / 2) cossinf_(k * pv[kp].z, tc[kp], ts[kp]); }
+        }
         KLOOP {
           [[maybe_unused]] P3& p = pv[kp];
           [[maybe_unused]] float& R = Rv[kp];
-          const float k = PF(0);
-          float c, s;
-          cossinf_(k * p.z, c, s);
+          const float c = tc[kp], s = ts[kp];
           float x = c * p.x - s * p.y, y = s * p.x + c * p.y;
           p.x = x; p.y = y;
         }
@@ -533,14 +551,18 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       case D_SCREW_PRE: {
+        float th[K];  // atan2(P.y, P.x): a function of x,y only
+        KLOOP if (!(kp & 1)) th[kp] = atan2f_(pv[kp].y, pv[kp].x);
+        if (sh_xy) { KLOOP if (kp & 1) th[kp] = th[kp ? kp - 1 : 0]; }
+        else { KLOOP if (kp & 1) th[kp] = atan2f_(pv[kp].y, pv[kp].x); }
+        ENSURE_HXY();
         KLOOP {
           [[maybe_unused]] P3& p = pv[kp];
           [[maybe_unused]] float& R = Rv[kp];
           const float pitch = PF(0), lead = PF(1), L = PF(2), tanTaper = PF(3), halfp = PF(4);
-          if (!use_hxy) hxy[kp] = hypotf_(p.x, p.y);
           float y0 = hxy[kp];
           y0 += p.z * tanTaper;
-          float theta = atan2f_(p.y, p.x);
+          const float theta = th[kp];
           float z = p.z + lead * theta / 6.2831853071795862f;
           float x = z + halfp;
           float t = x / pitch;
@@ -605,11 +627,15 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       case D_CIRC_PRE: {
+        float th[K];
+        KLOOP if (!(kp & 1)) th[kp] = atan2f_(pv[kp].y, pv[kp].x);
+        if (sh_xy) { KLOOP if (kp & 1) th[kp] = th[kp ? kp - 1 : 0]; }
+        else { KLOOP if (kp & 1) th[kp] = atan2f_(pv[kp].y, pv[kp].x); }
         KLOOP {
           [[maybe_unused]] P3& p = pv[kp];
           [[maybe_unused]] float& R = Rv[kp];
           const float angle = PF(0), ncirc = PF(1), ninsm1 = PF(2);
-          float pangle = atan2f_(p.y, p.x);
+          const float pangle = th[kp];
           float id = floorf_(pangle / angle);
           if (id < 0.f) id += ncirc;
           float i0, i1;
@@ -711,6 +737,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
   }
 #undef PF
 #undef PU
+#undef ENSURE_HXY
 }
 
 #undef LDSF

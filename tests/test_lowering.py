@@ -15,7 +15,7 @@ _HDR = open(os.path.join(ROOT, "gsdf_amd", "csrc", "dev_ops.h")).read()
 _ENUM = _HDR[_HDR.index("enum DevOp"):_HDR.index("D_OP_COUNT")]
 NAMES = [n for n in dict.fromkeys(re.findall(r"\b(D_[A-Z0-9_]+)\b", _ENUM))]
 NPAR = [int(x) for x in re.findall(r"\*/\s*(\d+)", re.search(r"kDevOpParams\[D_OP_COUNT\] = \{(.*?)\};", _HDR, re.S).group(1))]
-FLAG_HXY, FLAG_SWAP, OP_MASK = 0x4000, 0x8000, 0x3FFF
+FLAG_SHZ, FLAG_SHXY, FLAG_HXY, FLAG_SWAP, OP_MASK = 0x1000, 0x2000, 0x4000, 0x8000, 0x0FFF
 
 
 def decode(code):
@@ -83,6 +83,32 @@ def test_saved_positions_are_not_duplicated():
                  b.Translate(b.NewSphere(1), 0, 0, 2))
     names = [i[0] for i in decode(hip.lower(sh)[0])]
     assert names.count("D_SAVEP3") == 2
+
+
+def flags_of(code):
+    out, pc = [], 0
+    for name, _, _, _, at in decode(code):
+        out.append((name, bool(int(code[at]) & FLAG_SHXY), bool(int(code[at]) & FLAG_SHZ)))
+    return out
+
+
+def test_corner_pair_sharing_flags():
+    """D_FLAG_SHXY / D_FLAG_SHZ: set only while P.xy (resp. P.z) is still a function of the entry x,y (entry z)."""
+    b = Builder()
+    fl = flags_of(hip.lower(b.Scene("npt-flange"))[0])
+    # scale and z-translate are component-wise: all three cylinders and the screw may share hypot/atan2 between z-pairs
+    assert [f[1] for f in fl if f[0] in ("D_CYL0", "D_CYLR", "D_SCREW_PRE")] == [True] * 4
+    fl = flags_of(hip.lower(b.Scene("knurled-cylinder"))[0])
+    assert [f[2] for f in fl if f[0] == "D_TWIST"] == [True, True]          # twist angle depends on entry z only
+    assert [f[1] for f in fl if f[0] == "D_CIRC_PRE"] == [False, False]     # after the twist x,y depend on z
+    assert [f[1] for f in fl if f[0] in ("D_CYL0", "D_CYLR")][:2] == [True, True]
+    fl = flags_of(hip.lower(b.Scene("bolt"))[0])
+    assert not any(f[1] or f[2] for f in fl)                                # a general rotation comes first
+    # a rotation about z keeps z-only and xy-only dependencies apart; a second saved/restored branch gets its own
+    sh = b.Union(b.Translate(b.Rotate(b.NewCylinder(1, 2, 0), 0.3, (0, 0, 1)), 0.5, 0, 0), b.Translate(b.NewCylinder(1, 2, 0), 0, 0, 1))
+    fl = flags_of(hip.lower(sh)[0])
+    cyl = [f for f in fl if f[0] == "D_CYL0"]
+    assert len(cyl) == 2 and cyl[0][1] != cyl[1][1]  # the transformed branch (4x4 matrix) is not shareable, the other is
 
 
 def test_hxy_not_reused_across_xy_changes():

@@ -19,8 +19,8 @@ def listing(code):
     pc, out = 0, []
     f = code.view(np.float32)
     while True:
-        w = int(code[pc]); op = w & 0x3fff; slot = w >> 16
-        fl = ("|HXY" if w & 0x4000 else "") + ("|SWAP" if w & 0x8000 else "")
+        w = int(code[pc]); op = w & 0x0fff; slot = w >> 16
+        fl = ("|HXY" if w & 0x4000 else "") + ("|SWAP" if w & 0x8000 else "") + ("|SHXY" if w & 0x2000 else "") + ("|SHZ" if w & 0x1000 else "")
         name = names[op]
         if name == "D_POLY2D":
             nv = int(code[pc + 1]) & 0x7fffffff
