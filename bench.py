@@ -39,18 +39,35 @@ def cpu_baseline(shader, resdiv, threads):
             "triangles_per_s": m.n_tris / dt, "eval_only_evals_per_s": m.evals / m.t_eval_s}
 
 
-def pmc_traffic_gb():
-    """HBM bytes per leaf_kernel launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/*_pmc_summary.json: 2*FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE, KB -> GB)."""
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, one wave64 VALU op per 2 cycles, 2.4 GHz
+
+
+def pmc_summary():
+    """Latest committed rocprofv3 PMC summary of this same command (profiles/*_pmc_summary.json)."""
     import glob
     fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     if not fs:
-        return None
+        return {}
     try:
-        d = json.load(open(fs[-1]))
-        return d["leaf_kernel"]["hbm_traffic_gb_per_launch"]
+        return json.load(open(fs[-1])).get("leaf_kernel", {})
     except Exception:
+        return {}
+
+
+def pmc_traffic_gb():
+    """HBM bytes per leaf_kernel launch: 2*FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE, KB -> GB."""
+    return pmc_summary().get("hbm_traffic_gb_per_launch")
+
+
+def valu_roofline(kernel_evals_per_s):
+    """The binding roofline of this path: VALU issue. Instructions per evaluation come from the PMC pass
+    (SQ_INSTS_VALU x 64 lanes / evaluations per launch), the rate from the live kernel timing."""
+    per_eval = pmc_summary().get("valu_lane_instr_per_eval")
+    if not per_eval:
         return None
+    ach = per_eval * kernel_evals_per_s
+    return {"lane_instr_per_eval": per_eval, "achieved": ach / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-instr/s",
+            "frac": ach / VALU_PEAK_LANE_OPS}
 
 
 def eval_mode(args, torch, np, hip, shader, sdf, res, dev):
@@ -191,6 +208,7 @@ def main():
         k_ms = march_ms / max(1, args.steps)
         k_bytes = (march_evals * 16.0 + march_tris * 36.0) / max(1, args.steps)
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        kernel_rate = (march_evals / max(1, args.steps)) / (k_ms * 1e-3) if k_ms > 0 else 0.0
         out = {
             "metric": "sdf_evals_per_s", "value": evals_all / dt, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -205,8 +223,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_gb(),
                          "kernel": "leaf_kernel<4>", "kernel_ms": k_ms,
-                         "kernel_evals_per_s": (march_evals / max(1, args.steps)) / (k_ms * 1e-3) if k_ms > 0 else 0.0,
-                         "note": "path is fp32-VALU bound (SURVEY 8(d)): algorithmic HBM bytes are tiny by construction"},
+                         "kernel_evals_per_s": kernel_rate, "valu": valu_roofline(kernel_rate),
+                         "note": "path is fp32-VALU bound (SURVEY 8(d)): algorithmic HBM bytes are tiny by construction; "
+                                 "'valu' prices the same kernel against the VALU issue peak"},
             "phase_ms_rank0": {"prune": st.ms_prune, "leaf": st.ms_leaf, "march_kernel": st.ms_march, "total_device": st.ms_total},
         }
         if world == 1 and not args.no_cpu_baseline:

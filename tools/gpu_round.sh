@@ -14,7 +14,20 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU 
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_wait -- $BENCH > $OUT/pmc_wait.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
-find $OUT -name "*.csv" | head -30
+timeout 600 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_IFETCH SQ_INSTS_BRANCH SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 --output-format csv -d $OUT/pmc_mix -- $BENCH > $OUT/pmc_mix.log 2>&1
+cd $GRAFT_REPO_ROOT
+python - "$OUT" <<'PY'
+import json, subprocess, sys
+out = sys.argv[1]
+b = json.loads(open(out + "/bench.json").read().strip().splitlines()[-1])
+ev = b["evals_per_step"] - 0  # leaf + prune evaluations; prune share is < 1 %
+kms = b["roofline"]["kernel_ms"]
+s = subprocess.check_output([sys.executable, "tools/pmc_summarize.py", out, "--evals-per-launch", str(ev), "--kernel-ms", str(kms),
+                             "--workload", b["config"]["workload"]])
+open(out + "/pmc_summary.json", "wb").write(s)
+print(s.decode()[:1500])
+PY
+find $OUT -name "*stats.csv" | head
 # keep only small summaries (gpurun_out merge limit)
 find $OUT -name "*kernel_trace.csv" -size +4M -delete
 find $OUT -name "*counter_collection.csv" -size +16M -delete
