@@ -198,7 +198,7 @@ __device__ __forceinline__ void mc_interp(float ax, float ay, float az, float bx
   rx = x; ry = y; rz = z;
 }
 
-#define TRI_STAGE 256  // triangles staged in LDS per workgroup before one coalesced flush (9 KB)
+#define TRI_STAGE 128  // triangles staged in LDS per workgroup before one coalesced flush (4.5 KB: lets 4 workgroups of a 7-slot program share a CU)
 
 // Marching cubes of one leaf per lane + block-wide triangle emission (shared by both leaf kernels).
 // vslot: the lane's 8 corner distances in its LDS column; index: the 8-bit inside mask (0 = no triangles).
@@ -299,7 +299,9 @@ __device__ __forceinline__ void mc_final_flush(float* s_stage, unsigned* s_misc,
 // reference's |d0| <= 2*sqrt3*res test (marchcubes.go:20-23). Marching cubes reads the triangle
 // table from LDS; triangles are staged in LDS and flushed with ONE global atomic per flush
 // (a single counter word saturates at ~88 atomics/us on MI355X, so per-wave appends do not scale).
-// LDS: [(nslots+8) floats per lane | tri table 256x16 i8 | TRI_STAGE*9 floats | 8 words].
+// LDS: [max(nslots*K, 8) floats per lane | tri table 256x16 i8 | TRI_STAGE*9 floats | 8 words]. The lane's 8 corner
+// distances reuse the interpreter's slot columns: the distances of the earlier passes ride in registers until the
+// last pass has finished with the slots, then all 8 are stored for marching cubes' dynamically indexed reads.
 template <int K, int WAVES>
 __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
                                                      unsigned long long cube_cap, int lq, int nslots, float ox, float oy, float oz,
@@ -307,8 +309,8 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
                                                      MeshCounters* __restrict__ ctr) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
-  float* vslot = lds + (size_t)nslots * K * BLOCK;  // 8 per-lane corner distances
-  int8_t* s_tri = (int8_t*)(g_smem + (size_t)(nslots * K + 8) * BLOCK);
+  float* vslot = lds;  // 8 per-lane corner distances, written after the last interpreter pass (aliases the slots)
+  int8_t* s_tri = (int8_t*)(g_smem + (size_t)(nslots * K > 8 ? nslots * K : 8) * BLOCK);
   float* s_stage = (float*)(s_tri + 256 * 16);
   unsigned* s_misc = (unsigned*)(s_stage + TRI_STAGE * 9);  // [0..3] wave sums, [4] staged count
   unsigned long long* s_base = (unsigned long long*)(s_misc + 6);
@@ -342,6 +344,9 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
     // to the remaining corners only if some lane passes the reference's corner-0 test.
     unsigned index = 0;
     bool pass = false;
+    float dall[8];  // distances in evaluation order; shifted so that the final contents sit at static positions
+#pragma unroll
+    for (int j = 0; j < 8; j++) dall[j] = 0.f;
 #pragma unroll 1
     for (unsigned c0 = 0; c0 < 8; c0 += K) {
       P3 pk[K];
@@ -357,9 +362,11 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
       }
       gsdf_dev::sdf_eval<K, true>(code, pk, dk, lds, BLOCK);
 #pragma unroll
+      for (int j = 0; j < 8 - K; j++) dall[j] = dall[j + K];  // static shift register: no dynamic register index
+#pragma unroll
       for (int kp = 0; kp < K; kp++) {
         const unsigned c = (0x62735140u >> (4u * (c0 + kp))) & 7u;
-        vslot[c * BLOCK] = dk[kp];
+        dall[8 - K + kp] = dk[kp];
         index |= (dk[kp] < 0.f ? 1u : 0u) << c;
       }
       if (c0 == 0) {
@@ -374,6 +381,9 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
       }
     }
     if (!pass) index = 0;
+    // after the last pass dall[j] is the distance of corner order[j] (an early exit leaves index == 0: nothing is read)
+#pragma unroll
+    for (int j = 0; j < 8; j++) vslot[((0x62735140u >> (4u * j)) & 7u) * BLOCK] = dall[j];
     mc_emit_block(index, x0, y0, z0, x1, y1, z1, [&](unsigned cc) { return vslot[cc * BLOCK]; }, s_tri, s_stage, s_misc, s_base, tris,
                   tri_cap, ctr);
   }
@@ -1282,8 +1292,10 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   // multi-GPU: bricks of level ls are dealt to ranks by a hash of their coordinates (brick_owner).
   const int ls = levels < lq + 2 ? levels : lq + 2;
   const size_t lds = p->lds_bytes(1);
-  const int lk = p->batch_k();
-  const size_t lds_m = (size_t)(p->prog.nslots * lk + 8) * BLOCK * sizeof(float) + 4096 + TRI_STAGE * 36 + 64;
+  // leaf kernel batching: K = 4 while 3 workgroups still fit the CU's LDS (<= 11 slots); 12..15 slots run K = 2 at 4
+  // waves/SIMD instead of K = 4 at 2 (knurled-cylinder: 23.3 vs 23.8 ms)
+  const int lk = (p->batch_k() == 4 && p->prog.nslots > 11) ? 2 : p->batch_k();
+  const size_t lds_m = (size_t)(p->prog.nslots * lk > 8 ? p->prog.nslots * lk : 8) * BLOCK * sizeof(float) + 4096 + TRI_STAGE * 36 + 64;
   uint64_t qcap = p->q0.cap / sizeof(Cube);
   if (qcap < (1u << 20)) qcap = 1u << 20;  // 1 M cubes (8 MB) per queue to start with
   uint64_t want = opts.max_tris;
@@ -1338,10 +1350,16 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
                            p->prog.nslots, ox, oy, oz, res, m->d_tris, tcap, d_ctr);
         used_brick = true;
       } else
-      // K=4 at 3 waves/SIMD (168 VGPRs, a few spills) measured 17% faster than 2 waves/SIMD (203 VGPRs, none)
-      if (lk == 4) { if (forced_w == 2) LAUNCH_LEAF(4, 2); else if (forced_w == 4) LAUNCH_LEAF(4, 4); else LAUNCH_LEAF(4, 3); }
-      else if (lk == 2) { if (forced_w == 4) LAUNCH_LEAF(2, 4); else LAUNCH_LEAF(2, 3); }
-      else LAUNCH_LEAF(1, 4);
+      {
+        // Occupancy: a 4th wave per SIMD is worth more than the ~30 VGPRs it costs (flange 3.28 -> 2.95 ms; the
+        // spills are the leaf's corner coordinates parked around the interpreter), but only if 4 workgroups fit the
+        // CU's 160 KB of LDS; otherwise 3 waves/SIMD with the larger register budget.
+        const bool fit4 = 4 * lds_m <= 160 * 1024;
+        const int ww = forced_w ? forced_w : (fit4 ? 4 : 3);
+        if (lk == 4) { if (ww == 2) LAUNCH_LEAF(4, 2); else if (ww == 4) LAUNCH_LEAF(4, 4); else LAUNCH_LEAF(4, 3); }
+        else if (lk == 2) { if (ww == 4) LAUNCH_LEAF(2, 4); else LAUNCH_LEAF(2, 3); }
+        else LAUNCH_LEAF(1, 4);
+      }
 #undef LAUNCH_LEAF
       HIP_TRYM(hipGetLastError());
     }
