@@ -97,7 +97,9 @@ struct MeshCounters {
   unsigned long long n_items[MAX_LEVELS];  // [L]: candidate cubes centre-tested at level L (0 if the level was not tested)
   unsigned long long n_pass[MAX_LEVELS];   // [L]: candidates that passed the prune predicate (before shard filter)
   unsigned long long n_active;             // leaves passing the corner-0 test
+  unsigned long long pad0[16];             // the triangle append counter gets a cache line (L2 atomic unit) of its own
   unsigned long long n_tris;
+  unsigned long long pad1[15];
   unsigned long long overflow;             // triangle buffer overflow flag
   unsigned long long n_cont;               // leaves whose wave went on to the remaining corners
   unsigned long long q_overflow;           // cube queue capacity exceeded
@@ -134,22 +136,43 @@ __host__ __device__ __forceinline__ unsigned brick_owner(unsigned x, unsigned y,
 
 // One octree level, chained on the stream with NO host round trip: the candidate count is read from the
 // previous level's survivor counter in device memory. expand=1: item i is child (i&7) of in[i>>3];
-// expand=0: the single top cube. Survivors are compacted into `out` (ballot + mbcnt prefix + one
-// atomic per wave; queues are small, the leaf kernel is where atomics had to go).
+// expand=0: the single top cube. Survivors are compacted block-wide (ballot + mbcnt prefix per wave, 4 wave totals
+// through LDS) into an LDS stage of PRUNE_STAGE cubes and appended to `out` with ONE global atomic per flush: a
+// single counter word takes ~88 atomics/us on MI355X, so the per-wave appends of the first version bounded the two
+// big levels (8940 waves at level 3 = 100 us of a 124 us kernel).
+// LDS: [nslots floats per lane | PRUNE_STAGE cubes | 4 wave totals | base].
+#define PRUNE_STAGE 1024
 __global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ in,
-                                                      int expand, int level, float ox, float oy, float oz, float res,
+                                                      int expand, int level, int nslots, float ox, float oy, float oz, float res,
                                                       int do_test, Cube* __restrict__ out, unsigned long long out_cap,
                                                       int shard_here, unsigned shard_rank, unsigned shard_count,
                                                       MeshCounters* __restrict__ ctr) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
+  Cube* s_q = (Cube*)(g_smem + (size_t)(nslots > 0 ? nslots : 1) * BLOCK);
+  unsigned* s_w = (unsigned*)(s_q + PRUNE_STAGE);  // [0..3] wave totals, [4..7] per-wave "passed the test" counts
+  unsigned long long* s_base = (unsigned long long*)(s_w + 8);
   const unsigned long long n_items = expand ? uniform_u64(ctr->n_level[level + 1]) * 8ull : 1ull;
   if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_items[level] = do_test ? n_items : 0ull;
   const float size = (float)(1 << (level - 1)) * res;  // i3.Cube size at this level
   const float maxDist = size * (1.73205080757f / 2);    // szDistMult = sqrt3/2 (octreerenderer.go:182)
   const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long my_pass = 0;
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_items; base += step) {
+  unsigned cur = 0;  // cubes staged so far (block-uniform: every thread derives it from the same LDS totals)
+  auto flush = [&]() {  // block-uniform
+    if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_level[level], (unsigned long long)cur);
+    __syncthreads();
+    const unsigned long long fb = *s_base;
+    if (fb + cur <= out_cap) {
+      for (unsigned k = threadIdx.x; k < cur; k += BLOCK) out[fb + k] = s_q[k];
+    } else if (threadIdx.x == 0) {
+      ctr->q_overflow = 1ull;
+    }
+    __syncthreads();
+    cur = 0;
+  };
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_items; base += step) {  // block-uniform trip count
     const uint64_t i = base + threadIdx.x;
     const bool valid = i < n_items;
     Cube c = {0, 0, 0, 0};
@@ -174,15 +197,29 @@ __global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict
       keep = valid && !(dm::absf(dv[0]) >= maxDist);
     }
     const unsigned long long pm = __ballot(keep);
-    if ((threadIdx.x & 63) == 0) my_pass += (unsigned long long)__builtin_popcountll(pm);
+    if (lane == 0) my_pass += (unsigned long long)__builtin_popcountll(pm);
     if (shard_here) keep = keep && (brick_owner(c.x, c.y, c.z, shard_count) == shard_rank);
-    const unsigned long long slot = wave_append(keep, &ctr->n_level[level]);
-    if (keep) {
-      if (slot < out_cap) out[slot] = c;
-      else ctr->q_overflow = 1ull;
-    }
+    const unsigned long long km = __ballot(keep);
+    const unsigned lane_prefix = __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
+    if (lane == 0) s_w[wave] = (unsigned)__builtin_popcountll(km);
+    __syncthreads();
+    const unsigned w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+    const unsigned total = w0 + w1 + w2 + w3;
+    const unsigned wpre = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
+    if (cur + total > PRUNE_STAGE) flush();  // total <= 256 always fits afterwards
+    if (keep) s_q[cur + wpre + lane_prefix] = c;
+    cur += total;
+    __syncthreads();  // s_w is rewritten next iteration; s_q complete before a flush reads it
   }
-  if ((threadIdx.x & 63) == 0 && my_pass) atomicAdd(&ctr->n_pass[level], my_pass);
+  if (cur) flush();
+  // statistics: one atomic per workgroup (the kernel cannot retire before its atomics do: 4 per workgroup on one
+  // word were 46 us of the level-3 launch)
+  if (lane == 0) s_w[4 + wave] = (unsigned)my_pass;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = (unsigned long long)s_w[4] + s_w[5] + s_w[6] + s_w[7];
+    if (t) atomicAdd(&ctr->n_pass[level], t);
+  }
 }
 
 // mcInterpolate (marchcubes.go:76-98) with x = 0.
@@ -388,9 +425,15 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
                   tri_cap, ctr);
   }
   mc_final_flush(s_stage, s_misc, s_base, tris, tri_cap, ctr);
-  if (lane == 0 && my_cont) {
-    atomicAdd(&ctr->n_active, my_active);
-    atomicAdd(&ctr->n_cont, my_cont);
+  // statistics: two atomics per workgroup, not per wave (they share the L2 atomic unit with the triangle appends)
+  __syncthreads();
+  unsigned* s_stat = (unsigned*)s_stage;
+  if (lane == 0) { s_stat[2 * (threadIdx.x >> 6)] = (unsigned)my_active; s_stat[2 * (threadIdx.x >> 6) + 1] = (unsigned)my_cont; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long a = (unsigned long long)s_stat[0] + s_stat[2] + s_stat[4] + s_stat[6];
+    const unsigned long long c = (unsigned long long)s_stat[1] + s_stat[3] + s_stat[5] + s_stat[7];
+    if (c) { atomicAdd(&ctr->n_active, a); atomicAdd(&ctr->n_cont, c); }
   }
 }
 
@@ -1291,7 +1334,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   const int lq = levels < 3 ? levels : 3;
   // multi-GPU: bricks of level ls are dealt to ranks by a hash of their coordinates (brick_owner).
   const int ls = levels < lq + 2 ? levels : lq + 2;
-  const size_t lds = p->lds_bytes(1);
+  const size_t lds_prune = p->lds_bytes(1) + PRUNE_STAGE * sizeof(Cube) + 64;
   // leaf kernel batching: K = 4 while 3 workgroups still fit the CU's LDS (<= 11 slots); 12..15 slots run K = 2 at 4
   // waves/SIMD instead of K = 4 at 2 (knurled-cylinder: 23.3 vs 23.8 ms)
   const int lk = (p->batch_k() == 4 && p->prog.nslots > 11) ? 2 : p->batch_k();
@@ -1325,8 +1368,8 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
       // upper bound of candidates at this level (for the grid only): 8^(levels-level), capped by the queue
       uint64_t bound = (levels - level) * 3 >= 40 ? UINT64_MAX : ((uint64_t)1 << (3 * (levels - level)));
       if (bound > capq[(level + 1) & 1] * 8) bound = capq[(level + 1) & 1] * 8;
-      hipLaunchKernelGGL(prune_kernel, dim3(grid_for(bound, p->num_cu, 8)), dim3(BLOCK), lds, s, p->d_code,
-                         (const Cube*)q[(level + 1) & 1]->p, expand, level, ox, oy, oz, res, do_test, (Cube*)q[level & 1]->p,
+      hipLaunchKernelGGL(prune_kernel, dim3(grid_for(bound, p->num_cu, 4)), dim3(BLOCK), lds_prune, s, p->d_code,
+                         (const Cube*)q[(level + 1) & 1]->p, expand, level, p->prog.nslots, ox, oy, oz, res, do_test, (Cube*)q[level & 1]->p,
                          (unsigned long long)capq[level & 1], (opts.shard_count > 1 && level == ls) ? 1 : 0,
                          (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr);
       HIP_TRYM(hipGetLastError());
