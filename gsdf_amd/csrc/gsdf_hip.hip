@@ -562,12 +562,15 @@ struct DCCounters {
 
 // Stage 1 (Reset :26-83): evaluate every cube origin; keep iff |d| < 2*size (octreePrunea szMult=2, origin).
 template <int K>
-__global__ void __launch_bounds__(BLOCK, 3) dc_origin_kernel(const uint32_t* __restrict__ code_g, int nshift, float ox, float oy,
+__global__ void __launch_bounds__(BLOCK, 3) dc_origin_kernel(const uint32_t* __restrict__ code_g, int nslots, int nshift, float ox, float oy,
                                                              float oz, float res, int* __restrict__ grid, Cube* __restrict__ cubes,
                                                              unsigned long long cube_cap, unsigned zlo, unsigned zhi,
                                                              DCCounters* __restrict__ ctr) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
+  unsigned* s_w = (unsigned*)(g_smem + (size_t)(nslots > 0 ? nslots : 1) * K * BLOCK);  // 4 wave totals
+  unsigned long long* s_base = (unsigned long long*)(s_w + 4);
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // multi-GPU: this rank evaluates the z-slab [zlo, zhi) of the lattice (its own slab plus a one-cube halo)
   const unsigned long long cell0 = (unsigned long long)zlo << (2 * nshift);
   const unsigned long long ncell = (unsigned long long)zhi << (2 * nshift);
@@ -584,13 +587,35 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_origin_kernel(const uint32_t* __r
       p[kp] = P3{ox + res * (float)x, oy + res * (float)y, oz + res * (float)z};  // CubeOrigin, size = res
     }
     gsdf_dev::sdf_eval<K>(code, p, d, lds, BLOCK);
+    // Block-wide append: ONE global atomic per workgroup pass (K*256 cells) instead of one per wave and point --
+    // at ~88 atomics/us on a single word the per-wave form was a co-bottleneck for cheap trees (1e9 cells / 64).
+    bool keep[K];
+    unsigned mine = 0;
+#pragma unroll
+    for (int kp = 0; kp < K; kp++) {
+      const uint64_t c = base + (uint64_t)kp * BLOCK + threadIdx.x;
+      keep[kp] = c < ncell && !(dm::absf(d[kp]) >= maxDist);
+      mine += keep[kp] ? 1u : 0u;
+    }
+    unsigned incl = mine;  // wave inclusive scan of per-lane counts
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned v = __shfl_up(incl, off, 64);
+      if (lane >= (unsigned)off) incl += v;
+    }
+    __syncthreads();  // previous pass finished reading s_w / s_base
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    const unsigned w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+    const unsigned total = w0 + w1 + w2 + w3;
+    if (threadIdx.x == 0 && total) *s_base = atomicAdd(&ctr->n_cubes, (unsigned long long)total);
+    __syncthreads();
+    unsigned long long slot = (total ? *s_base : 0ull) + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + (incl - mine);
 #pragma unroll
     for (int kp = 0; kp < K; kp++) {
       const uint64_t c = base + (uint64_t)kp * BLOCK + threadIdx.x;
       const bool valid = c < ncell;
-      const bool keep = valid && !(dm::absf(d[kp]) >= maxDist);
-      const unsigned long long slot = wave_append(keep, &ctr->n_cubes);
-      if (keep) {
+      if (keep[kp]) {
         if (slot < cube_cap) {
           const unsigned x = (unsigned)c & mask, y = (unsigned)(c >> nshift) & mask, z = (unsigned)(c >> (2 * nshift)) & mask;
           cubes[slot] = Cube{(uint16_t)x, (uint16_t)y, (uint16_t)z, 0};
@@ -599,6 +624,7 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_origin_kernel(const uint32_t* __r
           ctr->q_overflow = 1ull;
           grid[c] = -1;
         }
+        slot++;
       } else if (valid) {
         grid[c] = -1;
       }
@@ -998,9 +1024,10 @@ struct gsdf_program {
       return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-  } q0, q1, ctr;
+  } q0, q1, ctr, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge;  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   uint64_t last_tris = 0;  // triangle count of the previous mesh on this handle: sizes the next output buffer
+  uint64_t last_dc_cubes = 0;  // kept cubes of the previous dual contouring pass: sizes the next queues
   size_t lds_bytes(int k = 1) const { return (size_t)(prog.nslots > 0 ? prog.nslots : 1) * k * BLOCK * sizeof(float); }
   // Points carried per lane: as many as keep >= 2 workgroups per CU resident (160 KB LDS per CU).
   int batch_k() const {
@@ -1160,6 +1187,7 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (p->d_pos) (void)hipFree(p->d_pos);
   if (p->d_dist) (void)hipFree(p->d_dist);
   p->q0.release(); p->q1.release(); p->ctr.release();
+  p->dc_grid.release(); p->dc_dist.release(); p->dc_fv.release(); p->dc_nrm.release(); p->dc_edge.release();
   for (auto e : p->ev) if (e) (void)hipEventDestroy(e);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
@@ -1522,12 +1550,17 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
   } while (0)
   for (auto& e : p->ev)
     if (!e) HIP_TRYM(hipEventCreate(&e));
-  DevBuf grid, ctrb, distb, fvb, nrmb, edgeb;
-  HIP_TRYM(grid.alloc(ncell * sizeof(int)));
-  HIP_TRYM(ctrb.alloc(sizeof(DCCounters)));
-  DCCounters* d_ctr = (DCCounters*)ctrb.p;
+  // Workspace lives in the program handle (grow-only): the index grid alone is 4.3 GB at 1024^3 cells, and a
+  // hipMalloc/hipFree pair of that size per mesh cost more wall time than the whole device pass.
+  gsdf_program::Arena &grid = p->dc_grid, &d2 = p->dc_dist, &f2 = p->dc_fv, &n2 = p->dc_nrm, &e2 = p->dc_edge;
+  HIP_TRYM(grid.ensure(ncell * sizeof(int)));
+  HIP_TRYM(p->ctr.ensure(sizeof(MeshCounters) > sizeof(DCCounters) ? sizeof(MeshCounters) : sizeof(DCCounters)));
+  DCCounters* d_ctr = (DCCounters*)p->ctr.p;
   const int lk = p->batch_k();
-  uint64_t ccap = 1u << 20;
+  // Kept cubes hug the surface: ~ c * n^2 of the n^3 lattice. Start from the previous pass on this handle, else from
+  // 12 n^2 (an overflow repeats the full-lattice origin pass, so be generous: 84 B per cube).
+  uint64_t ccap = p->last_dc_cubes ? p->last_dc_cubes + p->last_dc_cubes / 8 + 4096 : (uint64_t)12 << (2 * nshift);
+  if (ccap < (1u << 20)) ccap = 1u << 20;
   DCCounters hc{};
   const float h = (chiseled ? (float)1e-4 : (float)2e-8) * 0.5f;  // NormalsCentralDiff: step *= 0.5
   const float sqrtLambda = chiseled ? (float)(std::sqrt(1e-5) * 1e-4) : (float)std::sqrt(1e-5);
@@ -1535,11 +1568,10 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     if (ccap > nslab) ccap = nslab;
     const uint64_t ecap = 3 * ccap, tcap = 2 * ecap;
     HIP_TRYM(p->q0.ensure(ccap * sizeof(Cube)));
-    DevBuf d2, f2, n2, e2;
-    HIP_TRYM(d2.alloc(ccap * sizeof(float4)));
-    HIP_TRYM(f2.alloc(ccap * 12));
-    HIP_TRYM(n2.alloc(ccap * 36));
-    HIP_TRYM(e2.alloc(ecap * sizeof(unsigned)));
+    HIP_TRYM(d2.ensure(ccap * sizeof(float4)));
+    HIP_TRYM(f2.ensure(ccap * 12));
+    HIP_TRYM(n2.ensure(ccap * 36));
+    HIP_TRYM(e2.ensure(ecap * sizeof(unsigned)));
     if (!m->d_tris || m->cap < tcap) {
       pool_give(p->device, m->d_tris, m->cap);
       m->d_tris = pool_take(p->device, tcap, &m->cap);
@@ -1549,7 +1581,7 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     if (shard_count > 1) HIP_TRYM(hipMemsetAsync(grid.p, 0xff, ncell * sizeof(int), s));  // cells outside the slab read as empty
     HIP_TRYM(hipEventRecord(p->ev[0], s));
     const unsigned g1 = grid_for((nslab + lk - 1) / lk, p->num_cu, 8);
-#define LAUNCH_O(KK) hipLaunchKernelGGL((dc_origin_kernel<KK>), dim3(g1), dim3(BLOCK), p->lds_bytes(KK), s, p->d_code, nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, zlo, zhi, d_ctr)
+#define LAUNCH_O(KK) hipLaunchKernelGGL((dc_origin_kernel<KK>), dim3(g1), dim3(BLOCK), p->lds_bytes(KK) + 32, s, p->d_code, p->prog.nslots, nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, zlo, zhi, d_ctr)
     if (lk == 4) LAUNCH_O(4); else if (lk == 2) LAUNCH_O(2); else LAUNCH_O(1);
 #undef LAUNCH_O
     HIP_TRYM(hipGetLastError());
@@ -1573,13 +1605,15 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     HIP_TRYM(hipStreamSynchronize(s));
     if (hc.q_overflow || hc.t_overflow) {
       if (attempt >= 8 || ccap >= nslab) return bail(fail(GSDF_ERR_CAPACITY, "dual contouring queue capacity exceeded"));
-      ccap *= 8;
+      // the origin pass keeps counting past the capacity, so the exact number of kept cubes is known
+      ccap = hc.n_cubes > ccap ? hc.n_cubes + hc.n_cubes / 16 + 4096 : ccap * 2;
       continue;
     }
     break;
   }
   float ms = 0;
   HIP_TRYM(hipEventElapsedTime(&ms, p->ev[0], p->ev[1]));
+  p->last_dc_cubes = hc.n_cubes;
   m->st.n_tris = 2 * hc.n_tris;  // quads -> 2 triangles
   m->st.evals = nslab + 4 * hc.n_cubes + 6 * hc.n_edges;
   m->st.evals_prune = nslab;
