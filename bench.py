@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--mode", choices=["mesh", "eval"], default="mesh",
                     help="mesh (default, BASELINE configs[1]) or eval: the gleval.SDF3.Evaluate micro-benchmark (SURVEY 8(d) M1) on "
                          "HBM-resident positions: 2^24-point chunks of the flat lattice of the scene at --resdiv")
+    ap.add_argument("--interpreter", action="store_true", help="run the generic interpreter kernels instead of kernels specialised for the tree")
     ap.add_argument("--share-corners", action="store_true", help="evaluate each bitwise-distinct lattice corner of a brick once (same triangles, fewer evals)")
     args = ap.parse_args()
 
@@ -155,6 +156,10 @@ def main():
     shader = bld.NewSphere(1.0) if args.scene == "sphere" else bld.Scene(args.scene)
     res = np.float32(float(shader.Diagonal()) / args.resdiv)
     sdf = hip.SDF3HIP(shader)
+    if not args.interpreter:
+        # per-tree kernel build (hiprtc), outside the timed region: the analogue of the reference compiling its GLSL
+        # compute shader for the tree (gleval/gpu.go:35-54). --interpreter keeps the generic interpreter kernels.
+        sdf.specialize()
 
     if args.mode == "eval":
         return eval_mode(args, torch, np, hip, shader, sdf, res, dev)
@@ -217,7 +222,9 @@ def main():
             "config": {"workload": f"examples/{args.scene} resdiv {args.resdiv}: octree prune + marching cubes on device "
                                    f"(res {float(res):.7f}, {st.levels} levels)",
                        "sharding": "octree bricks by coordinate hash, RCCL all-gatherv of triangles" if world > 1 else "single GPU",
-                       "leaf_corners": "shared (distinct lattice points once)" if args.share_corners else "8 per leaf (as the reference)"},
+                       "leaf_corners": "shared (distinct lattice points once)" if args.share_corners else "8 per leaf (as the reference)",
+                       "evaluator": ("interpreter kernels" if args.interpreter else
+                                     "kernels specialised for the tree at setup (hiprtc, %.1f s, untimed)" % sdf.info()["specialize_s"])},
             "triangles_per_s": tris_all / dt,
             "triangles_per_step": tris_all / args.steps, "evals_per_step": evals_all / args.steps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -9,8 +9,19 @@
 // distances are bit-identical to the CPU path for finite inputs. Not reproduced: Inf/NaN special
 // cases of hypot/atan2 (unreachable with finite positions) and math.Min/Max NaN propagation.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else  // hiprtc: no host headers; the fixed-width types are all the device code needs from them
+typedef signed char int8_t;
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+typedef unsigned long uintptr_t;
+#endif
 
 namespace dm {
 

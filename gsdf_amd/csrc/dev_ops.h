@@ -19,7 +19,9 @@
 //   D_FLAG_SWAP (bit 15): combine with operand roles exchanged (the second child was evaluated first so that
 //                the position did not have to be saved and restored).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 #define D_OP_MASK 0x0fffu
 #define D_FLAG_SHZ 0x1000u

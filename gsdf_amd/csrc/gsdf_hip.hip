@@ -1,18 +1,10 @@
 // gsdf_hip.hip -- gfx950 kernels + C ABI (include/gsdf_hip.h) of the MI355X SDF backend.
 //
-// Kernels (all wave64, 256-thread workgroups, grid-stride with wave-uniform trip counts so that the
-// interpreter's program counter stays scalar):
-//   eval_kernel<DIM>     dist[i] = SDF(pos[i])                      gleval SDF3/SDF2.Evaluate
-//   prune_kernel         octree level: centre sample, keep iff |d| < size*sqrt3/2, ballot+prefix
-//                        compaction of survivors                    glrender/octreerenderer.go:240-284
-//   leaf_kernel          8 leaf corners (corner 0 first, reject |d0| > 2*sqrt3*res) + marching cubes
-//                        with the LDS triangle table, block prefix-sum slot allocation, triangles
-//                        staged in LDS and flushed coalesced          glrender/marchcubes.go:14-98
-//   stl_kernel           50-byte STL records staged through LDS     glrender/stl.go:15-62
-//   normals_kernel       central differences                        gleval/gleval.go:53-108
+// The kernels live in kernels.h (device code only, also compiled at run time by hiprtc for specialised programs).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -24,13 +16,7 @@
 
 #include "../../include/gsdf_hip.h"
 #include "compile.h"
-#include "interp.h"
-#include "mc_tables.h"
-
-using gsdf_dev::code_ptr;
-using gsdf_dev::P3;
-
-#define BLOCK 256
+#include "specialize.h"
 
 // ---------------------------------------------------------------------------------------------
 // error plumbing
@@ -48,953 +34,7 @@ static int fail(int code, const std::string& msg) {
 
 extern "C" const char* gsdf_hip_last_error(void) { return g_err.c_str(); }
 
-// ---------------------------------------------------------------------------------------------
-// device side
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ code_ptr as_code(const uint32_t* p) { return (code_ptr)(uintptr_t)p; }
-
-extern __shared__ __attribute__((aligned(16))) float g_smem[];
-
-// dist[i] = SDF(pos[i]). Each lane carries K points per interpreter pass (tile = K*BLOCK points,
-// point kp of lane t = tile + kp*BLOCK + t, so every load/store stays coalesced).
-template <int DIM, int K>
-__global__ void __launch_bounds__(BLOCK, (K == 1 ? 4 : 3)) eval_kernel(const uint32_t* __restrict__ code_g, const float* __restrict__ pos,
-                                                     uint32_t stride_f, float* __restrict__ dist, uint64_t n) {
-  code_ptr code = as_code(code_g);
-  float* lds = g_smem + threadIdx.x;
-  const uint64_t step = (uint64_t)gridDim.x * BLOCK * K;
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK * K; base < n; base += step) {  // uniform trip count
-    P3 p[K];
-    float d[K];
-#pragma unroll
-    for (int kp = 0; kp < K; kp++) {
-      const uint64_t i = base + (uint64_t)kp * BLOCK + threadIdx.x;
-      p[kp] = P3{0.f, 0.f, 0.f};
-      if (i < n) {
-        const float* q = pos + i * stride_f;
-        p[kp].x = q[0];
-        p[kp].y = q[1];
-        if (DIM == 3) p[kp].z = q[2];
-      }
-    }
-    gsdf_dev::sdf_eval<K>(code, p, d, lds, BLOCK);
-#pragma unroll
-    for (int kp = 0; kp < K; kp++) {
-      const uint64_t i = base + (uint64_t)kp * BLOCK + threadIdx.x;
-      if (i < n) dist[i] = d[kp];
-    }
-  }
-}
-
-// Octree cube: level-index coordinates (leaf coordinate >> (level-1)).
-struct __attribute__((aligned(8))) Cube {
-  uint16_t x, y, z, w;
-};
-
-#define MAX_LEVELS 24
-struct MeshCounters {
-  unsigned long long n_level[MAX_LEVELS];  // [L]: cubes of level L handed to the next stage (survivors kept by this rank)
-  unsigned long long n_items[MAX_LEVELS];  // [L]: candidate cubes centre-tested at level L (0 if the level was not tested)
-  unsigned long long n_pass[MAX_LEVELS];   // [L]: candidates that passed the prune predicate (before shard filter)
-  unsigned long long n_active;             // leaves passing the corner-0 test
-  unsigned long long pad0[16];             // the triangle append counter gets a cache line (L2 atomic unit) of its own
-  unsigned long long n_tris;
-  unsigned long long pad1[15];
-  unsigned long long overflow;             // triangle buffer overflow flag
-  unsigned long long n_cont;               // leaves whose wave went on to the remaining corners
-  unsigned long long q_overflow;           // cube queue capacity exceeded
-  unsigned long long n_points;             // lattice points evaluated by leaf_brick_kernel
-};
-
-// wave64 compaction: returns the global slot for lanes with keep=true (others undefined).
-__device__ __forceinline__ unsigned long long wave_append(bool keep, unsigned long long* counter) {
-  const unsigned long long mask = __ballot(keep);
-  const unsigned int lane_prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
-  unsigned long long base = 0;
-  if (mask != 0ull) {
-    const int leader = __builtin_ctzll(mask);
-    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, (unsigned long long)__builtin_popcountll(mask));
-    base = __shfl(base, leader, 64);
-  }
-  return base + lane_prefix;
-}
-
-__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return ((unsigned long long)hi << 32) | lo;
-}
-
-// Owner rank of a brick for multi-GPU sharding: a pure function of the brick coordinates, so every
-// rank derives the same partition with no communication and no ordering dependence.
-__host__ __device__ __forceinline__ unsigned brick_owner(unsigned x, unsigned y, unsigned z, unsigned count) {
-  unsigned h = (x * 73856093u) ^ (y * 19349663u) ^ (z * 83492791u);
-  h ^= h >> 15;
-  h *= 0x2c1b3c6du;
-  h ^= h >> 12;
-  return h % count;
-}
-
-// One octree level, chained on the stream with NO host round trip: the candidate count is read from the
-// previous level's survivor counter in device memory. expand=1: item i is child (i&7) of in[i>>3];
-// expand=0: the single top cube. Survivors are compacted block-wide (ballot + mbcnt prefix per wave, 4 wave totals
-// through LDS) into an LDS stage of PRUNE_STAGE cubes and appended to `out` with ONE global atomic per flush: a
-// single counter word takes ~88 atomics/us on MI355X, so the per-wave appends of the first version bounded the two
-// big levels (8940 waves at level 3 = 100 us of a 124 us kernel).
-// LDS: [nslots floats per lane | PRUNE_STAGE cubes | 4 wave totals | base].
-#define PRUNE_STAGE 1024
-__global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ in,
-                                                      int expand, int level, int nslots, float ox, float oy, float oz, float res,
-                                                      int do_test, Cube* __restrict__ out, unsigned long long out_cap,
-                                                      int shard_here, unsigned shard_rank, unsigned shard_count,
-                                                      MeshCounters* __restrict__ ctr) {
-  code_ptr code = as_code(code_g);
-  float* lds = g_smem + threadIdx.x;
-  Cube* s_q = (Cube*)(g_smem + (size_t)(nslots > 0 ? nslots : 1) * BLOCK);
-  unsigned* s_w = (unsigned*)(s_q + PRUNE_STAGE);  // [0..3] wave totals, [4..7] per-wave "passed the test" counts
-  unsigned long long* s_base = (unsigned long long*)(s_w + 8);
-  const unsigned long long n_items = expand ? uniform_u64(ctr->n_level[level + 1]) * 8ull : 1ull;
-  if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_items[level] = do_test ? n_items : 0ull;
-  const float size = (float)(1 << (level - 1)) * res;  // i3.Cube size at this level
-  const float maxDist = size * (1.73205080757f / 2);    // szDistMult = sqrt3/2 (octreerenderer.go:182)
-  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
-  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned long long my_pass = 0;
-  unsigned cur = 0;  // cubes staged so far (block-uniform: every thread derives it from the same LDS totals)
-  auto flush = [&]() {  // block-uniform
-    if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_level[level], (unsigned long long)cur);
-    __syncthreads();
-    const unsigned long long fb = *s_base;
-    if (fb + cur <= out_cap) {
-      for (unsigned k = threadIdx.x; k < cur; k += BLOCK) out[fb + k] = s_q[k];
-    } else if (threadIdx.x == 0) {
-      ctr->q_overflow = 1ull;
-    }
-    __syncthreads();
-    cur = 0;
-  };
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_items; base += step) {  // block-uniform trip count
-    const uint64_t i = base + threadIdx.x;
-    const bool valid = i < n_items;
-    Cube c = {0, 0, 0, 0};
-    if (valid && expand) {
-      const Cube pc = in[i >> 3];
-      const unsigned k = (unsigned)(i & 7);
-      // children in corner order: 0:(0,0,0) 1:(+x) 2:(+x,+y) 3:(+y) 4..7 same at +z
-      c.x = (uint16_t)(pc.x * 2 + ((k ^ (k >> 1)) & 1));
-      c.y = (uint16_t)(pc.y * 2 + ((k >> 1) & 1));
-      c.z = (uint16_t)(pc.z * 2 + ((k >> 2) & 1));
-    }
-    bool keep = valid;
-    if (do_test) {
-      const float cx0 = ox + size * (float)c.x, cy0 = oy + size * (float)c.y, cz0 = oz + size * (float)c.z;
-      P3 p;  // CubeCenter = Scale(0.5, Add(min, max)), max = min + size
-      p.x = 0.5f * (cx0 + (cx0 + size));
-      p.y = 0.5f * (cy0 + (cy0 + size));
-      p.z = 0.5f * (cz0 + (cz0 + size));
-      P3 pv[1] = {p};
-      float dv[1];
-      gsdf_dev::sdf_eval<1>(code, pv, dv, lds, BLOCK);
-      keep = valid && !(dm::absf(dv[0]) >= maxDist);
-    }
-    const unsigned long long pm = __ballot(keep);
-    if (lane == 0) my_pass += (unsigned long long)__builtin_popcountll(pm);
-    if (shard_here) keep = keep && (brick_owner(c.x, c.y, c.z, shard_count) == shard_rank);
-    const unsigned long long km = __ballot(keep);
-    const unsigned lane_prefix = __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
-    if (lane == 0) s_w[wave] = (unsigned)__builtin_popcountll(km);
-    __syncthreads();
-    const unsigned w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
-    const unsigned total = w0 + w1 + w2 + w3;
-    const unsigned wpre = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
-    if (cur + total > PRUNE_STAGE) flush();  // total <= 256 always fits afterwards
-    if (keep) s_q[cur + wpre + lane_prefix] = c;
-    cur += total;
-    __syncthreads();  // s_w is rewritten next iteration; s_q complete before a flush reads it
-  }
-  if (cur) flush();
-  // statistics: one atomic per workgroup (the kernel cannot retire before its atomics do: 4 per workgroup on one
-  // word were 46 us of the level-3 launch)
-  if (lane == 0) s_w[4 + wave] = (unsigned)my_pass;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned long long t = (unsigned long long)s_w[4] + s_w[5] + s_w[6] + s_w[7];
-    if (t) atomicAdd(&ctr->n_pass[level], t);
-  }
-}
-
-// mcInterpolate (marchcubes.go:76-98) with x = 0.
-__device__ __forceinline__ void mc_interp(float ax, float ay, float az, float bx, float by, float bz, float v1, float v2,
-                                          float& rx, float& ry, float& rz) {
-  const float eps = 1e-12f;
-  const bool c1 = dm::absf(0.f - v1) < eps, c2 = dm::absf(0.f - v2) < eps;
-  float t = 0.5f;
-  if (!c1 || !c2) t = (0.f - v1) / (v2 - v1);
-  float x = ax + t * (bx - ax), y = ay + t * (by - ay), z = az + t * (bz - az);
-  if (c1 && !c2) { x = ax; y = ay; z = az; }
-  if (c2 && !c1) { x = bx; y = by; z = bz; }
-  rx = x; ry = y; rz = z;
-}
-
-#define TRI_STAGE 128  // triangles staged in LDS per workgroup before one coalesced flush (4.5 KB: lets 4 workgroups of a 7-slot program share a CU)
-
-// Marching cubes of one leaf per lane + block-wide triangle emission (shared by both leaf kernels).
-// vslot: the lane's 8 corner distances in its LDS column; index: the 8-bit inside mask (0 = no triangles).
-// Block-uniform control flow: every thread of the workgroup must call this the same number of times.
-template <typename CornerDist>
-__device__ __forceinline__ void mc_emit_block(unsigned index, float x0, float y0, float z0, float x1, float y1, float z1,
-                                              CornerDist vdist, const int8_t* s_tri, float* s_stage, unsigned* s_misc,
-                                              unsigned long long* s_base, float* __restrict__ tris, uint64_t tri_cap,
-                                              MeshCounters* __restrict__ ctr) {
-  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned nt = 0;
-  {
-    const int8_t* row = s_tri + index * 16;
-    while (nt < 5 && row[3 * nt] >= 0) nt++;
-  }
-  // block exclusive scan of nt: wave scan + 4 wave totals through LDS
-  unsigned incl = nt;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    unsigned v = __shfl_up(incl, off, 64);
-    if (lane >= (unsigned)off) incl += v;
-  }
-  if (lane == 63) s_misc[wave] = incl;
-  __syncthreads();  // (A)
-  const unsigned w0 = s_misc[0], w1 = s_misc[1], w2 = s_misc[2], w3 = s_misc[3];
-  const unsigned total = w0 + w1 + w2 + w3;
-  const unsigned wpre = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
-  unsigned cur = s_misc[4];
-  const bool direct = total > TRI_STAGE;  // block-uniform
-  unsigned long long gbase = 0;
-  if (!direct && cur + total > TRI_STAGE) {  // flush the stage first (block-uniform)
-    if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)cur);
-    __syncthreads();
-    const unsigned long long fb = *s_base;
-    if (fb + cur <= tri_cap) {
-      float* dst = tris + fb * 9;
-      for (unsigned k = threadIdx.x; k < cur * 9; k += BLOCK) dst[k] = s_stage[k];
-    } else if (threadIdx.x == 0) {
-      ctr->overflow = 1ull;
-    }
-    __syncthreads();
-    cur = 0;
-  }
-  if (direct) {
-    if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)total);
-    __syncthreads();
-    gbase = *s_base;
-    if (gbase + total > tri_cap) {
-      if (threadIdx.x == 0) ctr->overflow = 1ull;
-      nt = 0;
-    }
-  }
-  if (nt) {
-    const unsigned first = wpre + (incl - nt);
-    float* dst = direct ? (tris + (gbase + first) * 9) : (s_stage + (size_t)(cur + first) * 9);
-    const int8_t* row = s_tri + index * 16;
-    for (unsigned t = 0; t < nt; t++) {
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const int e = row[3 * t + (2 - k)];  // reversed winding (marchcubes.go:64-68)
-        const unsigned a = GSDF_MC_PAIR_A(e), b = GSDF_MC_PAIR_B(e);
-        const float va = vdist(a), vb = vdist(b);
-        const float pax = ((a ^ (a >> 1)) & 1u) ? x1 : x0, pay = ((a >> 1) & 1u) ? y1 : y0, paz = ((a >> 2) & 1u) ? z1 : z0;
-        const float pbx = ((b ^ (b >> 1)) & 1u) ? x1 : x0, pby = ((b >> 1) & 1u) ? y1 : y0, pbz = ((b >> 2) & 1u) ? z1 : z0;
-        float rx, ry, rz;
-        mc_interp(pax, pay, paz, pbx, pby, pbz, va, vb, rx, ry, rz);
-        dst[9 * t + 3 * k + 0] = rx;
-        dst[9 * t + 3 * k + 1] = ry;
-        dst[9 * t + 3 * k + 2] = rz;
-      }
-    }
-  }
-  __syncthreads();  // (B)
-  if (threadIdx.x == 0 && !direct) s_misc[4] = cur + total;
-}
-
-// Final flush of the LDS triangle stage (all threads of the workgroup).
-__device__ __forceinline__ void mc_final_flush(float* s_stage, unsigned* s_misc, unsigned long long* s_base,
-                                               float* __restrict__ tris, uint64_t tri_cap, MeshCounters* __restrict__ ctr) {
-  __syncthreads();
-  const unsigned cur = s_misc[4];
-  if (cur) {
-    if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)cur);
-    __syncthreads();
-    const unsigned long long fb = *s_base;
-    if (fb + cur <= tri_cap) {
-      float* dst = tris + fb * 9;
-      for (unsigned k = threadIdx.x; k < cur * 9; k += BLOCK) dst[k] = s_stage[k];
-    } else if (threadIdx.x == 0) {
-      ctr->overflow = 1ull;
-    }
-  }
-}
-
-
-// Leaf kernel: one lane per leaf cube of every surviving level-lq cube (64 leaves of a level-3 cube
-// = one wave). Corner 0 first; the wave runs the other 7 corners only if some lane passes the
-// reference's |d0| <= 2*sqrt3*res test (marchcubes.go:20-23). Marching cubes reads the triangle
-// table from LDS; triangles are staged in LDS and flushed with ONE global atomic per flush
-// (a single counter word saturates at ~88 atomics/us on MI355X, so per-wave appends do not scale).
-// LDS: [max(nslots*K, 8) floats per lane | tri table 256x16 i8 | TRI_STAGE*9 floats | 8 words]. The lane's 8 corner
-// distances reuse the interpreter's slot columns: the distances of the earlier passes ride in registers until the
-// last pass has finished with the slots, then all 8 are stored for marching cubes' dynamically indexed reads.
-template <int K, int WAVES>
-__global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
-                                                     unsigned long long cube_cap, int lq, int nslots, float ox, float oy, float oz,
-                                                     float res, float* __restrict__ tris, uint64_t tri_cap,
-                                                     MeshCounters* __restrict__ ctr) {
-  code_ptr code = as_code(code_g);
-  float* lds = g_smem + threadIdx.x;
-  float* vslot = lds;  // 8 per-lane corner distances, written after the last interpreter pass (aliases the slots)
-  int8_t* s_tri = (int8_t*)(g_smem + (size_t)(nslots * K > 8 ? nslots * K : 8) * BLOCK);
-  float* s_stage = (float*)(s_tri + 256 * 16);
-  unsigned* s_misc = (unsigned*)(s_stage + TRI_STAGE * 9);  // [0..3] wave sums, [4] staged count
-  unsigned long long* s_base = (unsigned long long*)(s_misc + 6);
-  for (int k = threadIdx.x; k < 256 * 16; k += BLOCK) s_tri[k] = GSDF_MC_TRI[k >> 4][k & 15];
-  if (threadIdx.x == 0) s_misc[4] = 0;
-  __syncthreads();
-
-  const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
-  const int sh = lq - 1;
-  unsigned long long n_cubes = uniform_u64(ctr->n_level[lq]);  // survivors of the last prune level (device-side count)
-  if (n_cubes > cube_cap) n_cubes = cube_cap;                  // queue overflowed: host reruns with larger queues
-  const uint64_t n_leaves = n_cubes << (3 * sh);
-  const unsigned lane = threadIdx.x & 63;
-  unsigned long long my_active = 0, my_cont = 0;
-  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_leaves; base += step) {
-    const uint64_t i = base + threadIdx.x;
-    const bool valid = i < n_leaves;
-    Cube lf = {0, 0, 0, 0};
-    if (valid) {
-      const Cube pc = cubes[i >> (3 * sh)];
-      const unsigned l = (unsigned)(i & ((1u << (3 * sh)) - 1u));
-      const unsigned m = (1u << sh) - 1u;
-      lf.x = (uint16_t)((pc.x << sh) + (l & m));
-      lf.y = (uint16_t)((pc.y << sh) + ((l >> sh) & m));
-      lf.z = (uint16_t)((pc.z << sh) + ((l >> (2 * sh)) & m));
-    }
-    const float x0 = ox + res * (float)lf.x, y0 = oy + res * (float)lf.y, z0 = oz + res * (float)lf.z;
-    const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;  // Box max = origin + size
-    // Single interpreter call site, K corners per pass (corner 0 is in the first pass); the wave goes on
-    // to the remaining corners only if some lane passes the reference's corner-0 test.
-    unsigned index = 0;
-    bool pass = false;
-    float dall[8];  // distances in evaluation order; shifted so that the final contents sit at static positions
-#pragma unroll
-    for (int j = 0; j < 8; j++) dall[j] = 0.f;
-#pragma unroll 1
-    for (unsigned c0 = 0; c0 < 8; c0 += K) {
-      P3 pk[K];
-      float dk[K];
-      // Corner order {0,4,1,5 | 3,7,2,6}: consecutive points share x,y and (K = 4) points j, j+2 share z, which is
-      // what the interpreter's PAIRED mode needs to compute hypot/atan2(x,y) and twist sin/cos(z) once per pair.
-#pragma unroll
-      for (int kp = 0; kp < K; kp++) {
-        const unsigned c = (0x62735140u >> (4u * (c0 + kp))) & 7u;
-        pk[kp].x = ((c ^ (c >> 1)) & 1u) ? x1 : x0;
-        pk[kp].y = ((c >> 1) & 1u) ? y1 : y0;
-        pk[kp].z = ((c >> 2) & 1u) ? z1 : z0;
-      }
-      gsdf_dev::sdf_eval<K, true>(code, pk, dk, lds, BLOCK);
-#pragma unroll
-      for (int j = 0; j < 8 - K; j++) dall[j] = dall[j + K];  // static shift register: no dynamic register index
-#pragma unroll
-      for (int kp = 0; kp < K; kp++) {
-        const unsigned c = (0x62735140u >> (4u * (c0 + kp))) & 7u;
-        dall[8 - K + kp] = dk[kp];
-        index |= (dk[kp] < 0.f ? 1u : 0u) << c;
-      }
-      if (c0 == 0) {
-        pass = valid && (dm::absf(dk[0]) <= cubeDiag);
-        const unsigned long long pmask = __ballot(pass);
-        if (pmask == 0ull) break;  // wave-uniform
-        const unsigned long long vmask = __ballot(valid);
-        if (lane == 0) {
-          my_active += (unsigned long long)__builtin_popcountll(pmask);
-          my_cont += (unsigned long long)__builtin_popcountll(vmask);
-        }
-      }
-    }
-    if (!pass) index = 0;
-    // after the last pass dall[j] is the distance of corner order[j] (an early exit leaves index == 0: nothing is read)
-#pragma unroll
-    for (int j = 0; j < 8; j++) vslot[((0x62735140u >> (4u * j)) & 7u) * BLOCK] = dall[j];
-    mc_emit_block(index, x0, y0, z0, x1, y1, z1, [&](unsigned cc) { return vslot[cc * BLOCK]; }, s_tri, s_stage, s_misc, s_base, tris,
-                  tri_cap, ctr);
-  }
-  mc_final_flush(s_stage, s_misc, s_base, tris, tri_cap, ctr);
-  // statistics: two atomics per workgroup, not per wave (they share the L2 atomic unit with the triangle appends)
-  __syncthreads();
-  unsigned* s_stat = (unsigned*)s_stage;
-  if (lane == 0) { s_stat[2 * (threadIdx.x >> 6)] = (unsigned)my_active; s_stat[2 * (threadIdx.x >> 6) + 1] = (unsigned)my_cont; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned long long a = (unsigned long long)s_stat[0] + s_stat[2] + s_stat[4] + s_stat[6];
-    const unsigned long long c = (unsigned long long)s_stat[1] + s_stat[3] + s_stat[5] + s_stat[7];
-    if (c) { atomicAdd(&ctr->n_active, a); atomicAdd(&ctr->n_cont, c); }
-  }
-}
-
-// Leaf kernel with exact corner sharing (level-3 bricks: one wave = one brick of 4x4x4 leaves).
-// The reference evaluates 8 corners per leaf: 512 evaluations per brick. Neighbouring leaves share lattice
-// planes, but the two coordinate expressions of a plane -- A(i) = O + res*i (min corner of leaf i) and
-// B(i) = A(i-1) + res (max corner of leaf i-1) -- are only sometimes the same float (64-73 % of planes at
-// resdiv 1600). Per axis the brick therefore has 5..8 bitwise-distinct coordinates (A0, {B1,A1}, {B2,A2},
-// {B3,A3}, B4 with equal pairs merged); every distinct point is evaluated ONCE (typically ~6x6x6 = 216
-// instead of 512: one 4-points-per-lane pass instead of two) and each leaf corner reads the value of
-// exactly the coordinates the reference would have evaluated, so distances, signs and triangles stay
-// bit-identical.
-// LDS: [nslots*K floats per lane | tri table | triangle stage | misc | 4 x 512 distances | 4 x 24 coordinates].
-template <int K, int WAVES>
-__global__ void __launch_bounds__(BLOCK, WAVES) leaf_brick_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
-                                                                  unsigned long long cube_cap, int nslots, float ox, float oy, float oz,
-                                                                  float res, float* __restrict__ tris, uint64_t tri_cap,
-                                                                  MeshCounters* __restrict__ ctr) {
-  code_ptr code = as_code(code_g);
-  float* lds = g_smem + threadIdx.x;
-  int8_t* s_tri = (int8_t*)(g_smem + (size_t)(nslots * K) * BLOCK);
-  float* s_stage = (float*)(s_tri + 256 * 16);
-  unsigned* s_misc = (unsigned*)(s_stage + TRI_STAGE * 9);
-  unsigned long long* s_base = (unsigned long long*)(s_misc + 6);
-  float* s_D = (float*)(s_base + 1);
-  float* s_val = s_D + 4 * 512;
-  for (int k = threadIdx.x; k < 256 * 16; k += BLOCK) s_tri[k] = GSDF_MC_TRI[k >> 4][k & 15];
-  if (threadIdx.x == 0) s_misc[4] = 0;
-  __syncthreads();
-
-  const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
-  unsigned long long n_cubes = uniform_u64(ctr->n_level[3]);
-  if (n_cubes > cube_cap) n_cubes = cube_cap;
-  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* D = s_D + wave * 512;
-  float* val = s_val + wave * 24;
-  const float org[3] = {ox, oy, oz};
-  unsigned long long my_active = 0, my_points = 0;
-  const uint64_t step = (uint64_t)gridDim.x * 4;
-  for (uint64_t base = (uint64_t)blockIdx.x * 4; base < n_cubes; base += step) {  // block-uniform trip count
-    const uint64_t brick = base + wave;
-    const bool bvalid = brick < n_cubes;
-    Cube pc = {0, 0, 0, 0};
-    if (bvalid) pc = cubes[brick];
-    const unsigned pidx[3] = {pc.x, pc.y, pc.z};
-    // per-axis mismatch bits m_p (p = 1..3): plane p has two distinct floats
-    unsigned mb[3], nax[3];
-#pragma unroll
-    for (int ax = 0; ax < 3; ax++) {
-      const unsigned i0 = pidx[ax] * 4u;
-      float A[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) A[k] = org[ax] + res * (float)(i0 + k);  // CubeOrigin of leaf i0+k
-      unsigned m = 0;
-#pragma unroll
-      for (int k = 1; k < 4; k++) m |= ((A[k - 1] + res) != A[k] ? 1u : 0u) << (k - 1);
-      mb[ax] = m;
-      nax[ax] = 5u + __builtin_popcount(m);
-    }
-    if (lane < 12) {  // coordinate table: lane (axis, a) writes A_a and B_{a+1} at their distinct-value slots
-      const unsigned ax = lane >> 2, a = lane & 3u;
-      const float Aa = org[ax] + res * (float)(pidx[ax] * 4u + a);
-      const unsigned u = a + __builtin_popcount(mb[ax] & ((1u << a) - 1u));
-      val[ax * 8 + u] = Aa;
-      val[ax * 8 + u + 1] = Aa + res;  // Box max = origin + size
-    }
-    __builtin_amdgcn_wave_barrier();
-    const unsigned nx = nax[0], nxy = nax[0] * nax[1], N = nxy * nax[2];
-    const float inx = 1.0f / (float)nx, inxy = 1.0f / (float)nxy;
-    if (bvalid && lane == 0) my_points += N;
-#pragma unroll 1
-    for (unsigned t0 = 0; t0 < N; t0 += 64 * K) {  // wave-uniform: 1 pass when N <= 256
-      P3 pk[K];
-      float dk[K];
-#pragma unroll
-      for (int kp = 0; kp < K; kp++) {
-        unsigned t = t0 + kp * 64 + lane;
-        if (t >= N) t = N - 1;  // idle slots re-evaluate the last point (result discarded)
-        const unsigned uz = (unsigned)(((float)t + 0.5f) * inxy);
-        const unsigned r = t - uz * nxy;
-        const unsigned uy = (unsigned)(((float)r + 0.5f) * inx);
-        const unsigned ux = r - uy * nx;
-        pk[kp] = P3{val[ux], val[8 + uy], val[16 + uz]};
-      }
-      gsdf_dev::sdf_eval<K>(code, pk, dk, lds, BLOCK);
-#pragma unroll
-      for (int kp = 0; kp < K; kp++) {
-        const unsigned t = t0 + kp * 64 + lane;
-        if (t < N) D[t] = dk[kp];
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // this lane's leaf (a,b,c) and its corner 0 index in the distinct-point lattice
-    const unsigned la = lane & 3u, lb = (lane >> 2) & 3u, lc = lane >> 4;
-    const unsigned ux0 = la + __builtin_popcount(mb[0] & ((1u << la) - 1u));
-    const unsigned uy0 = lb + __builtin_popcount(mb[1] & ((1u << lb) - 1u));
-    const unsigned uz0 = lc + __builtin_popcount(mb[2] & ((1u << lc) - 1u));
-    const unsigned tb = ux0 + nx * uy0 + nxy * uz0;
-    auto vdist = [&](unsigned cc) { return D[tb + ((cc ^ (cc >> 1)) & 1u) + nx * ((cc >> 1) & 1u) + nxy * ((cc >> 2) & 1u)]; };
-    const float x0 = val[ux0], x1 = val[ux0 + 1], y0 = val[8 + uy0], y1 = val[8 + uy0 + 1], z0 = val[16 + uz0], z1 = val[16 + uz0 + 1];
-    unsigned index = 0;
-#pragma unroll
-    for (unsigned cc = 0; cc < 8; cc++) index |= (vdist(cc) < 0.f ? 1u : 0u) << cc;
-    const bool pass = bvalid && (dm::absf(vdist(0)) <= cubeDiag);
-    const unsigned long long pmask = __ballot(pass);
-    if (lane == 0) my_active += (unsigned long long)__builtin_popcountll(pmask);
-    if (!pass) index = 0;
-    mc_emit_block(index, x0, y0, z0, x1, y1, z1, vdist, s_tri, s_stage, s_misc, s_base, tris, tri_cap, ctr);
-  }
-  mc_final_flush(s_stage, s_misc, s_base, tris, tri_cap, ctr);
-  if (lane == 0 && my_points) {
-    atomicAdd(&ctr->n_active, my_active);
-    atomicAdd(&ctr->n_points, my_points);
-  }
-}
-
-// =================================================================================================
-// Dual contouring on device (glrender/dual_contour.go, dual_contour_vertexplacement.go).
-// The reference keeps a map[i3.Vec]int over a full BFS decomposition; here the lattice is a dense
-// int32 index grid in HBM (levels <= 11 -> <= 4.3 GB, trivial against 288 GB), so neighbour lookups
-// are single loads and every stage is one lane per cube / per active edge.
-// =================================================================================================
-struct DCCounters {
-  unsigned long long n_cubes, n_edges, n_tris, q_overflow, t_overflow;
-};
-
-// Stage 1 (Reset :26-83): evaluate every cube origin; keep iff |d| < 2*size (octreePrunea szMult=2, origin).
-template <int K>
-__global__ void __launch_bounds__(BLOCK, 3) dc_origin_kernel(const uint32_t* __restrict__ code_g, int nslots, int nshift, float ox, float oy,
-                                                             float oz, float res, int* __restrict__ grid, Cube* __restrict__ cubes,
-                                                             unsigned long long cube_cap, unsigned zlo, unsigned zhi,
-                                                             DCCounters* __restrict__ ctr) {
-  code_ptr code = as_code(code_g);
-  float* lds = g_smem + threadIdx.x;
-  unsigned* s_w = (unsigned*)(g_smem + (size_t)(nslots > 0 ? nslots : 1) * K * BLOCK);  // 4 wave totals
-  unsigned long long* s_base = (unsigned long long*)(s_w + 4);
-  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // multi-GPU: this rank evaluates the z-slab [zlo, zhi) of the lattice (its own slab plus a one-cube halo)
-  const unsigned long long cell0 = (unsigned long long)zlo << (2 * nshift);
-  const unsigned long long ncell = (unsigned long long)zhi << (2 * nshift);
-  const unsigned mask = (1u << nshift) - 1u;
-  const float maxDist = res * 2;
-  const uint64_t step = (uint64_t)gridDim.x * BLOCK * K;
-  for (uint64_t base = cell0 + (uint64_t)blockIdx.x * BLOCK * K; base < ncell; base += step) {
-    P3 p[K];
-    float d[K];
-#pragma unroll
-    for (int kp = 0; kp < K; kp++) {
-      const uint64_t c = base + (uint64_t)kp * BLOCK + threadIdx.x;
-      const unsigned x = (unsigned)c & mask, y = (unsigned)(c >> nshift) & mask, z = (unsigned)(c >> (2 * nshift)) & mask;
-      p[kp] = P3{ox + res * (float)x, oy + res * (float)y, oz + res * (float)z};  // CubeOrigin, size = res
-    }
-    gsdf_dev::sdf_eval<K>(code, p, d, lds, BLOCK);
-    // Block-wide append: ONE global atomic per workgroup pass (K*256 cells) instead of one per wave and point --
-    // at ~88 atomics/us on a single word the per-wave form was a co-bottleneck for cheap trees (1e9 cells / 64).
-    bool keep[K];
-    unsigned mine = 0;
-#pragma unroll
-    for (int kp = 0; kp < K; kp++) {
-      const uint64_t c = base + (uint64_t)kp * BLOCK + threadIdx.x;
-      keep[kp] = c < ncell && !(dm::absf(d[kp]) >= maxDist);
-      mine += keep[kp] ? 1u : 0u;
-    }
-    unsigned incl = mine;  // wave inclusive scan of per-lane counts
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned v = __shfl_up(incl, off, 64);
-      if (lane >= (unsigned)off) incl += v;
-    }
-    __syncthreads();  // previous pass finished reading s_w / s_base
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    const unsigned w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
-    const unsigned total = w0 + w1 + w2 + w3;
-    if (threadIdx.x == 0 && total) *s_base = atomicAdd(&ctr->n_cubes, (unsigned long long)total);
-    __syncthreads();
-    unsigned long long slot = (total ? *s_base : 0ull) + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + (incl - mine);
-#pragma unroll
-    for (int kp = 0; kp < K; kp++) {
-      const uint64_t c = base + (uint64_t)kp * BLOCK + threadIdx.x;
-      const bool valid = c < ncell;
-      if (keep[kp]) {
-        if (slot < cube_cap) {
-          const unsigned x = (unsigned)c & mask, y = (unsigned)(c >> nshift) & mask, z = (unsigned)(c >> (2 * nshift)) & mask;
-          cubes[slot] = Cube{(uint16_t)x, (uint16_t)y, (uint16_t)z, 0};
-          grid[c] = (int)slot;
-        } else {
-          ctr->q_overflow = 1ull;
-          grid[c] = -1;
-        }
-        slot++;
-      } else if (valid) {
-        grid[c] = -1;
-      }
-    }
-  }
-}
-
-// Stage 2 (RenderAll :85-108): origin, +x, +y, +z distances of every kept cube (one 4-point pass per
-// lane); default FinalVertex = cube origin; active edges (sign BIT differs, :261-269) are compacted.
-__global__ void __launch_bounds__(BLOCK, 3) dc_edges_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
-                                                            unsigned long long cube_cap, float ox, float oy, float oz, float res,
-                                                            float4* __restrict__ dists, float* __restrict__ fv,
-                                                            unsigned* __restrict__ edges, unsigned long long edge_cap,
-                                                            DCCounters* __restrict__ ctr) {
-  code_ptr code = as_code(code_g);
-  float* lds = g_smem + threadIdx.x;
-  unsigned long long n = uniform_u64(ctr->n_cubes);
-  if (n > cube_cap) n = cube_cap;
-  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {
-    const uint64_t i = base + threadIdx.x;
-    const bool valid = i < n;
-    Cube c = {0, 0, 0, 0};
-    if (valid) c = cubes[i];
-    const float x0 = ox + res * (float)c.x, y0 = oy + res * (float)c.y, z0 = oz + res * (float)c.z;
-    P3 p[4] = {{x0, y0, z0}, {x0 + res, y0 + 0.f, z0 + 0.f}, {x0 + 0.f, y0 + res, z0 + 0.f}, {x0 + 0.f, y0 + 0.f, z0 + res}};
-    float d[4];
-    gsdf_dev::sdf_eval<4>(code, p, d, lds, BLOCK);
-    if (valid) {
-      dists[i] = make_float4(d[0], d[1], d[2], d[3]);
-      fv[3 * i] = x0; fv[3 * i + 1] = y0; fv[3 * i + 2] = z0;
-    }
-    const unsigned s0 = __float_as_uint(d[0]) >> 31;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      const bool act = valid && ((__float_as_uint(d[1 + a]) >> 31) != s0);
-      const unsigned long long slot = wave_append(act, &ctr->n_edges);
-      if (act) {
-        if (slot < edge_cap) edges[slot] = ((unsigned)i << 2) | (unsigned)a;
-        else ctr->q_overflow = 1ull;
-      }
-    }
-  }
-}
-
-__device__ __forceinline__ float dc_isect(float o, float e) { return -o / (e - o); }
-
-// Stage 3 (PlaceVertices :28-50 + gleval.NormalsCentralDiff): raw central-difference normals at the
-// linear intersection of every ACTIVE edge (inactive edges' normals are never read by the reference).
-__global__ void __launch_bounds__(BLOCK, 3) dc_normals_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
-                                                              const float4* __restrict__ dists, const unsigned* __restrict__ edges,
-                                                              unsigned long long edge_cap, float ox, float oy, float oz, float res,
-                                                              float h, float* __restrict__ nrm, DCCounters* __restrict__ ctr) {
-  code_ptr code = as_code(code_g);
-  float* lds = g_smem + threadIdx.x;
-  unsigned long long n = uniform_u64(ctr->n_edges);
-  if (n > edge_cap) n = edge_cap;
-  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {
-    const uint64_t i = base + threadIdx.x;
-    const bool valid = i < n;
-    float px = 0, py = 0, pz = 0;
-    unsigned e = 0;
-    if (valid) {
-      e = edges[i];
-      const unsigned ci = e >> 2, a = e & 3u;
-      const Cube c = cubes[ci];
-      const float4 d = dists[ci];
-      const float t = res * dc_isect(d.x, a == 0 ? d.y : (a == 1 ? d.z : d.w));
-      px = (ox + res * (float)c.x) + (a == 0 ? t : 0.f);
-      py = (oy + res * (float)c.y) + (a == 1 ? t : 0.f);
-      pz = (oz + res * (float)c.z) + (a == 2 ? t : 0.f);
-    }
-    float out[3];
-#pragma unroll 1
-    for (int dim = 0; dim < 3; dim++) {
-      P3 ab[2] = {{px + (dim == 0 ? h : 0.f), py + (dim == 1 ? h : 0.f), pz + (dim == 2 ? h : 0.f)},
-                  {px - (dim == 0 ? h : 0.f), py - (dim == 1 ? h : 0.f), pz - (dim == 2 ? h : 0.f)}};
-      float dd[2];
-      gsdf_dev::sdf_eval<2>(code, ab, dd, lds, BLOCK);
-      const float v = dd[0] - dd[1];
-      if (dim == 0) out[0] = v; else if (dim == 1) out[1] = v; else out[2] = v;
-    }
-    if (valid) {
-      const size_t o = ((size_t)(e >> 2) * 3 + (e & 3u)) * 3;
-      nrm[o] = out[0]; nrm[o + 1] = out[1]; nrm[o + 2] = out[2];
-    }
-  }
-}
-
-#define DC_ROWS 18  // <= 3 own + 12 contributed (own edges appear again among them) + 3 regularisation rows
-#define DC_BLOCK 64
-// Stage 4 (PlaceVertices :52-141, leastSquaresMGS64 :152-223): per cube, rows = own active edges, then the
-// edges of the (up to 12) contributing cubes in lattice order (z,y,x) and axis order, 3 regularisation rows;
-// float64 modified Gram-Schmidt with the rows staged in LDS ([row][col][lane]; zero rows are exact no-ops).
-__global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restrict__ cubes, unsigned long long cube_cap,
-                                                            const float4* __restrict__ dists, const int* __restrict__ grid,
-                                                            const float* __restrict__ nrm, int nshift, float ox, float oy, float oz,
-                                                            float res, float sqrtLambda, float* __restrict__ fv, unsigned zplace_hi,
-                                                            DCCounters* __restrict__ ctr) {
-  __shared__ double sQ[DC_ROWS][3][DC_BLOCK];
-  __shared__ double sB[DC_ROWS][DC_BLOCK];
-  unsigned long long n = uniform_u64(ctr->n_cubes);
-  if (n > cube_cap) n = cube_cap;
-  const int nn = 1 << nshift;
-  const unsigned t = threadIdx.x;
-  const uint64_t step = (uint64_t)gridDim.x * DC_BLOCK;
-  for (uint64_t base = (uint64_t)blockIdx.x * DC_BLOCK; base < n; base += step) {
-    const uint64_t i = base + t;
-    if (i >= n) continue;  // no block-level sync below: each lane owns column t of the LDS arrays
-    const Cube c = cubes[i];
-    if (c.z >= zplace_hi) continue;  // top halo layer: only its distances/normals are needed
-    const float cox = ox + res * (float)c.x, coy = oy + res * (float)c.y, coz = oz + res * (float)c.z;
-    const float invRes = 1.0f / res;
-    int nr = 0, nnb = 0;
-    float mx = 0.f, my = 0.f, mz = 0.f;
-    auto add_row = [&](float bx, float by, float bz, float nx, float ny, float nz) {
-      const float qx = invRes * (bx - cox), qy = invRes * (by - coy), qz = invRes * (bz - coz);
-      sQ[nr][0][t] = (double)nx; sQ[nr][1][t] = (double)ny; sQ[nr][2][t] = (double)nz;
-      sB[nr][t] = (double)(nx * qx + ny * qy + nz * qz);
-      mx = mx + bx; my = my + by; mz = mz + bz;
-      nr++;
-    };
-    auto edge_row = [&](unsigned ci, int a) {
-      const Cube u = cubes[ci];
-      const float4 d = dists[ci];
-      const float tt = res * dc_isect(d.x, a == 0 ? d.y : (a == 1 ? d.z : d.w));
-      const float ux = ox + res * (float)u.x, uy = oy + res * (float)u.y, uz = oz + res * (float)u.z;
-      const size_t o = ((size_t)ci * 3 + (size_t)a) * 3;
-      add_row(ux + (a == 0 ? tt : 0.f), uy + (a == 1 ? tt : 0.f), uz + (a == 2 ? tt : 0.f), nrm[o], nrm[o + 1], nrm[o + 2]);
-    };
-    // neighbour records first decide whether this cube is placed at all (len(cube.Neighbors) == 0 -> skip)
-    unsigned contrib[12];
-    unsigned char caxis[12];
-    for (int dz = 0; dz < 2; dz++)
-      for (int dy = 0; dy < 2; dy++)
-        for (int dx = 0; dx < 2; dx++) {
-          const int ux = c.x + dx, uy = c.y + dy, uz = c.z + dz;
-          if (ux >= nn || uy >= nn || uz >= nn) continue;
-          const int ui = grid[((size_t)uz * nn + uy) * nn + ux];
-          if (ui < 0) continue;
-          const float4 d = dists[ui];
-          const unsigned s0 = __float_as_uint(d.x) >> 31;
-          if (dx == 0 && ((__float_as_uint(d.y) >> 31) != s0)) { contrib[nnb] = (unsigned)ui; caxis[nnb++] = 0; }
-          if (dy == 0 && ((__float_as_uint(d.z) >> 31) != s0)) { contrib[nnb] = (unsigned)ui; caxis[nnb++] = 1; }
-          if (dz == 0 && ((__float_as_uint(d.w) >> 31) != s0)) { contrib[nnb] = (unsigned)ui; caxis[nnb++] = 2; }
-        }
-    if (nnb == 0) continue;
-    {
-      const float4 d = dists[i];
-      const unsigned s0 = __float_as_uint(d.x) >> 31;
-      if ((__float_as_uint(d.y) >> 31) != s0) edge_row((unsigned)i, 0);
-      if ((__float_as_uint(d.z) >> 31) != s0) edge_row((unsigned)i, 1);
-      if ((__float_as_uint(d.w) >> 31) != s0) edge_row((unsigned)i, 2);
-    }
-    for (int k = 0; k < nnb; k++) edge_row(contrib[k], caxis[k]);
-    const float im = 1.f / (float)nr;
-    const float bsx = invRes * (im * mx - cox), bsy = invRes * (im * my - coy), bsz = invRes * (im * mz - coz);
-    sQ[nr][0][t] = (double)sqrtLambda; sQ[nr][1][t] = 0.0; sQ[nr][2][t] = 0.0; sB[nr][t] = (double)(sqrtLambda * bsx); nr++;
-    sQ[nr][0][t] = 0.0; sQ[nr][1][t] = (double)sqrtLambda; sQ[nr][2][t] = 0.0; sB[nr][t] = (double)(sqrtLambda * bsy); nr++;
-    sQ[nr][0][t] = 0.0; sQ[nr][1][t] = 0.0; sQ[nr][2][t] = (double)sqrtLambda; sB[nr][t] = (double)(sqrtLambda * bsz); nr++;
-    const int K = nr;
-    double R[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    for (int j = 0; j < 3; j++) {
-      for (int ii = 0; ii < j; ii++) {
-        double dot = 0;
-        for (int k = 0; k < K; k++) dot += sQ[k][ii][t] * sQ[k][j][t];
-        R[ii][j] = dot;
-        for (int k = 0; k < K; k++) sQ[k][j][t] -= dot * sQ[k][ii][t];
-      }
-      double nsq = 0;
-      for (int k = 0; k < K; k++) nsq += sQ[k][j][t] * sQ[k][j][t];
-      const double norm = __builtin_sqrt(nsq);
-      R[j][j] = norm;
-      if (norm > 1e-14) {
-        const double inv = 1.0 / norm;
-        for (int k = 0; k < K; k++) sQ[k][j][t] *= inv;
-      }
-    }
-    double Qtb[3] = {0, 0, 0};
-    for (int j = 0; j < 3; j++)
-      for (int k = 0; k < K; k++) Qtb[j] += sQ[k][j][t] * sB[k][t];
-    double x[3];
-    for (int ii = 2; ii >= 0; ii--) {
-      x[ii] = Qtb[ii];
-      for (int k = ii + 1; k < 3; k++) x[ii] -= R[ii][k] * x[k];
-      if (R[ii][ii] > 1e-14) x[ii] /= R[ii][ii];
-      else x[ii] = 0;
-    }
-    const float xf = dm::clampf((float)x[0], -0.1f, 1.1f), yf = dm::clampf((float)x[1], -0.1f, 1.1f), zf = dm::clampf((float)x[2], -0.1f, 1.1f);
-    fv[3 * i] = res * xf + cox; fv[3 * i + 1] = res * yf + coy; fv[3 * i + 2] = res * zf + coz;
-  }
-}
-
-// Stage 5 (RenderAll :143-219): one quad (2 triangles) per active edge whose 4 surrounding cubes exist.
-__global__ void __launch_bounds__(BLOCK) dc_quads_kernel(const Cube* __restrict__ cubes, const float4* __restrict__ dists,
-                                                         const unsigned* __restrict__ edges, unsigned long long edge_cap,
-                                                         const int* __restrict__ grid, const float* __restrict__ fv, int nshift,
-                                                         unsigned zown_lo, unsigned zown_hi, float* __restrict__ tris,
-                                                         unsigned long long tri_cap, DCCounters* __restrict__ ctr) {
-  unsigned long long n = uniform_u64(ctr->n_edges);
-  if (n > edge_cap) n = edge_cap;
-  const int nn = 1 << nshift;
-  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {
-    const uint64_t i = base + threadIdx.x;
-    bool ok = i < n;
-    int q[4] = {-1, -1, -1, -1};
-    bool flip = false;
-    if (ok) {
-      const unsigned e = edges[i];
-      const unsigned ci = e >> 2, a = e & 3u;
-      const Cube c = cubes[ci];
-      const float4 d = dists[ci];
-      ok = ok && c.z >= zown_lo && c.z < zown_hi;  // quads are emitted by the rank that owns the edge's cube
-      flip = ((a == 0 ? d.y : (a == 1 ? d.z : d.w)) - d.x) < 0.f;
-      // EdgeNeighborsX/Y/Z (:271-287): offsets in cube units
-      const int off[3][4][3] = {{{0, -1, -1}, {0, 0, -1}, {0, 0, 0}, {0, -1, 0}},
-                                {{-1, 0, -1}, {-1, 0, 0}, {0, 0, 0}, {0, 0, -1}},
-                                {{-1, -1, 0}, {0, -1, 0}, {0, 0, 0}, {-1, 0, 0}}};
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int x = c.x + off[a][k][0], y = c.y + off[a][k][1], z = c.z + off[a][k][2];
-        int idx = -1;
-        if (x >= 0 && y >= 0 && z >= 0 && x < nn && y < nn && z < nn) idx = grid[((size_t)z * nn + y) * nn + x];
-        q[k] = idx;
-        ok = ok && idx >= 0;
-      }
-    }
-    const unsigned long long slot = wave_append(ok, &ctr->n_tris);
-    if (ok) {
-      if (2 * slot + 2 <= tri_cap) {
-        int o[4] = {q[0], q[1], q[2], q[3]};
-        if (flip) { o[0] = q[3]; o[1] = q[2]; o[2] = q[1]; o[3] = q[0]; }
-        float* dst = tris + 18 * slot;
-        const int order[6] = {0, 1, 2, 2, 3, 0};
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-          const float* v = fv + 3 * (size_t)o[order[k]];
-          dst[3 * k] = v[0]; dst[3 * k + 1] = v[1]; dst[3 * k + 2] = v[2];
-        }
-      } else {
-        ctr->t_overflow = 1ull;
-      }
-    }
-  }
-}
-
-// glrender.ImageRendererSDF2.Render (image.go:76-118) with the default black/white/red conversion (:52-61):
-// pixel (i,j) samples (xmin + i*dx, ymax - j*dy); dist gets the raw distances, rgba the converted pixels.
-template <int K>
-__global__ void __launch_bounds__(BLOCK, 3) image2_kernel(const uint32_t* __restrict__ code_g, int w, int h, float xmin, float ymax,
-                                                          float dx, float dy, float* __restrict__ dist, uint32_t* __restrict__ rgba) {
-  code_ptr code = as_code(code_g);
-  float* lds = g_smem + threadIdx.x;
-  const uint64_t n = (uint64_t)w * (uint64_t)h;
-  const uint64_t step = (uint64_t)gridDim.x * BLOCK * K;
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK * K; base < n; base += step) {
-    P3 p[K];
-    float d[K];
-#pragma unroll
-    for (int kp = 0; kp < K; kp++) {
-      uint64_t i = base + (uint64_t)kp * BLOCK + threadIdx.x;
-      if (i >= n) i = n - 1;
-      const unsigned px = (unsigned)(i % (uint64_t)w), py = (unsigned)(i / (uint64_t)w);
-      p[kp] = P3{(float)px * dx + xmin, ymax - (float)py * dy, 0.f};
-    }
-    gsdf_dev::sdf_eval<K>(code, p, d, lds, BLOCK);
-#pragma unroll
-    for (int kp = 0; kp < K; kp++) {
-      const uint64_t i = base + (uint64_t)kp * BLOCK + threadIdx.x;
-      if (i < n) {
-        const float v = d[kp];
-        if (dist) dist[i] = v;
-        const bool bad = (v != v) || (dm::absf(v) == __builtin_inff());
-        if (rgba) rgba[i] = bad ? 0xff0000ffu : (v > 0.f ? 0xffffffffu : 0xff000000u);  // R,G,B,A bytes little-endian
-      }
-    }
-  }
-}
-
-// Exhaustive self-test of dm::sqrt_1to2 over every float in [1, 2].
-__global__ void __launch_bounds__(BLOCK) sqrt_selftest_kernel(unsigned long long* __restrict__ bad) {
-  unsigned long long nb = 0;
-  for (unsigned i = 0x3f800000u + blockIdx.x * BLOCK + threadIdx.x; i <= 0x40000000u; i += gridDim.x * BLOCK) {
-    const float s = __uint_as_float(i);
-    if (__float_as_uint(dm::sqrt_1to2(s)) != __float_as_uint(__builtin_sqrtf(s))) nb++;
-  }
-  if (nb) atomicAdd(bad, nb);
-}
-
-// Exhaustive self-test of dm::div_by_uniform: every float32 numerator against the IEEE division.
-__global__ void __launch_bounds__(BLOCK) div_selftest_kernel(float d, float r, unsigned long long* __restrict__ bad,
-                                                             unsigned long long* __restrict__ fast_count) {
-  unsigned long long nb = 0, nf = 0;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < (1ull << 32); i += (unsigned long long)gridDim.x * BLOCK) {
-    const float n = __uint_as_float((unsigned)i);
-    if (!dm::div_fast_ok(n)) continue;  // the interpreter takes the IEEE path for these
-    nf++;
-    const float a = dm::div_by_uniform(n, d, r), b = n / d;
-    if (__float_as_uint(a) != __float_as_uint(b)) nb++;
-  }
-  if (nb) atomicAdd(bad, nb);
-  atomicAdd(fast_count, nf);
-}
-
-// STL records (stl.go:15-62): one wave stages 64 x 50-byte records in LDS, then stores dwords.
-__global__ void __launch_bounds__(BLOCK) stl_kernel(const float* __restrict__ tris, uint64_t n, uint8_t* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) uint8_t stage[BLOCK * 50];
-  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {
-    const uint64_t i = base + threadIdx.x;
-    if (i < n) {
-      const float* t = tris + 9 * i;
-      float v[9];
-#pragma unroll
-      for (int k = 0; k < 9; k++) v[k] = t[k];
-      // Unit(Cross(t1-t0, t2-t0)) with ms3.Norm = nested hypot
-      const float ax = v[3] - v[0], ay = v[4] - v[1], az = v[5] - v[2];
-      const float cx = v[6] - v[0], cy = v[7] - v[1], cz = v[8] - v[2];
-      const float nx = ay * cz - az * cy, ny = az * cx - ax * cz, nz = ax * cy - ay * cx;
-      const float inv = 1.0f / dm::norm3(nx, ny, nz);
-      uint16_t* rec = (uint16_t*)(stage + threadIdx.x * 50);
-      float f[12] = {inv * nx, inv * ny, inv * nz, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]};
-#pragma unroll
-      for (int k = 0; k < 12; k++) {
-        const uint32_t u = __float_as_uint(f[k]);
-        rec[2 * k] = (uint16_t)(u & 0xffffu);
-        rec[2 * k + 1] = (uint16_t)(u >> 16);
-      }
-      rec[24] = 0;
-    }
-    __syncthreads();
-    const uint64_t nrec = (n - base) < BLOCK ? (n - base) : BLOCK;
-    const uint64_t nbytes = nrec * 50;
-    uint8_t* o = out + 84 + base * 50;  // base is a multiple of 256 -> 4-byte aligned
-    const uint32_t* s32 = (const uint32_t*)stage;
-    uint32_t* o32 = (uint32_t*)o;
-    const uint64_t nwords = nbytes / 4;
-    for (uint64_t k = threadIdx.x; k < nwords; k += BLOCK) o32[k] = s32[k];
-    for (uint64_t k = nwords * 4 + threadIdx.x; k < nbytes; k += BLOCK) o[k] = stage[k];
-    __syncthreads();
-  }
-}
-
-// gleval.NormalsCentralDiff (gleval/gleval.go:53-108); h = step/2.
-__global__ void __launch_bounds__(BLOCK) normals_kernel(const uint32_t* __restrict__ code_g, const float* __restrict__ pos,
-                                                        float* __restrict__ nrm, uint64_t n, float h) {
-  code_ptr code = as_code(code_g);
-  float* lds = g_smem + threadIdx.x;
-  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {
-    const uint64_t i = base + threadIdx.x;
-    const bool valid = i < n;
-    float px = 0, py = 0, pz = 0;
-    if (valid) { px = pos[3 * i]; py = pos[3 * i + 1]; pz = pos[3 * i + 2]; }
-    float out[3];
-#pragma unroll 1
-    for (int dim = 0; dim < 3; dim++) {
-      P3 a = {px + (dim == 0 ? h : 0.f), py + (dim == 1 ? h : 0.f), pz + (dim == 2 ? h : 0.f)};
-      P3 b = {px - (dim == 0 ? h : 0.f), py - (dim == 1 ? h : 0.f), pz - (dim == 2 ? h : 0.f)};
-      P3 ab[2] = {a, b};
-      float dd[2];
-      gsdf_dev::sdf_eval<2>(code, ab, dd, lds, BLOCK);
-      const float v = dd[0] - dd[1];
-      if (dim == 0) out[0] = v; else if (dim == 1) out[1] = v; else out[2] = v;
-    }
-    if (valid) { nrm[3 * i] = out[0]; nrm[3 * i + 1] = out[1]; nrm[3 * i + 2] = out[2]; }
-  }
-}
+#include "kernels.h"
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -1028,6 +68,15 @@ struct gsdf_program {
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   uint64_t last_tris = 0;  // triangle count of the previous mesh on this handle: sizes the next output buffer
   uint64_t last_dc_cubes = 0;  // kept cubes of the previous dual contouring pass: sizes the next queues
+  // run-time specialised kernels for this program (gsdf_hip_program_specialize): hiprtc module, else interpreter
+  hipModule_t spec_mod = nullptr;
+  hipFunction_t f_eval = nullptr, f_prune = nullptr, f_leaf = nullptr;
+  int spec_eval_k = 0, spec_leaf_k = 0, spec_leaf_w = 0;
+  double spec_compile_s = 0;
+  // leaf kernel batching: K = 4 while 3 workgroups still fit the CU's LDS (<= 11 slots); 12..15 slots run K = 2 at 4
+  // waves/SIMD instead of K = 4 at 2 (knurled-cylinder: 23.3 vs 23.8 ms). A 4th wave per SIMD is worth more than the
+  // ~30 VGPRs it costs (flange 3.28 -> 2.95 ms), but only if 4 workgroups fit the CU's 160 KB of LDS.
+  void leaf_config(int* k, int* w, size_t* lds) const;
   size_t lds_bytes(int k = 1) const { return (size_t)(prog.nslots > 0 ? prog.nslots : 1) * k * BLOCK * sizeof(float); }
   // Points carried per lane: as many as keep >= 2 workgroups per CU resident (160 KB LDS per CU).
   int batch_k() const {
@@ -1036,6 +85,25 @@ struct gsdf_program {
     return prog.nslots <= 12 ? 4 : (prog.nslots <= 28 ? 2 : 1);
   }
 };
+
+void gsdf_program::leaf_config(int* k, int* w, size_t* lds) const {
+  static const int forced_w = [] { const char* e = getenv("GSDF_HIP_LEAF_WAVES"); return e ? atoi(e) : 0; }();  // tuning knob
+  const int ns = prog.nslots;
+  const int lk = (batch_k() == 4 && ns > 11) ? 2 : batch_k();
+  const size_t lds_m = (size_t)(ns * lk > 8 ? ns * lk : 8) * BLOCK * sizeof(float) + 4096 + TRI_STAGE * 36 + 64;
+  int ww = forced_w ? forced_w : (4 * lds_m <= 160 * 1024 ? 4 : 3);
+  if (lk == 4) { if (ww != 2 && ww != 4) ww = 3; }
+  else if (lk == 2) { if (ww != 4) ww = 3; }
+  else ww = 4;
+  *k = lk; *w = ww; *lds = lds_m;
+}
+
+// hipModuleLaunchKernel with typed arguments (the specialised kernels take exactly the ahead-of-time kernels' parameters)
+template <typename... A>
+static hipError_t launch_fn(hipFunction_t f, unsigned grid, unsigned block, size_t lds, hipStream_t s, A... a) {
+  void* args[] = {(void*)&a...};
+  return hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, (unsigned)lds, s, args, nullptr);
+}
 
 struct gsdf_mesh {
   int device = 0;
@@ -1164,6 +232,87 @@ extern "C" int gsdf_hip_selftest_sqrt(uint64_t* mismatches) {
   return rc;
 }
 
+// Compile and load kernels specialised for this handle's program (specialize.cpp): eval, prune and leaf kernels of
+// the configuration the mesher would pick. Afterwards gsdf_hip_eval*/gsdf_hip_mesh_octree launch them instead of the
+// interpreter kernels; results are bit-identical (same statements, same compiler flags). Idempotent.
+extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
+  if (!p) return fail(GSDF_ERR_BAD_ARGUMENT, "null program");
+  if (p->spec_mod) return GSDF_OK;
+  HIP_TRY(hipSetDevice(p->device));
+  hipDeviceProp_t pr;
+  HIP_TRY(hipGetDeviceProperties(&pr, p->device));
+  std::string arch = pr.gcnArchName;
+  if (arch.find(':') != std::string::npos) arch = arch.substr(0, arch.find(':'));
+  int lk, lw;
+  size_t lds_m;
+  p->leaf_config(&lk, &lw, &lds_m);
+  const int ek = p->batch_k();
+  std::vector<std::string> names;
+  names.push_back(std::string("eval_kernel<") + (p->prog.is2d ? "2" : "3") + ", " + std::to_string(ek) + ">");
+  if (!p->prog.is2d) {
+    names.push_back("prune_kernel");
+    names.push_back("leaf_kernel<" + std::to_string(lk) + ", " + std::to_string(lw) + ">");
+  }
+  std::vector<char> co;
+  std::vector<std::string> low;
+  std::string log;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (!gsdf_dev::spec_compile(p->prog, arch, names, co, low, log)) return fail(GSDF_ERR_HIP, "specialised build failed:\n" + log);
+  p->spec_compile_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  hipModule_t mod = nullptr;
+  HIP_TRY(hipModuleLoadData(&mod, co.data()));
+  hipFunction_t fe = nullptr, fp = nullptr, fl = nullptr;
+  hipError_t e = hipModuleGetFunction(&fe, mod, low[0].c_str());
+  if (e == hipSuccess && !p->prog.is2d) e = hipModuleGetFunction(&fp, mod, low[1].c_str());
+  if (e == hipSuccess && !p->prog.is2d) e = hipModuleGetFunction(&fl, mod, low[2].c_str());
+  if (e != hipSuccess) {
+    (void)hipModuleUnload(mod);
+    return fail(GSDF_ERR_HIP, std::string("hipModuleGetFunction: ") + hipGetErrorString(e));
+  }
+  p->spec_mod = mod;
+  p->f_eval = fe; p->f_prune = fp; p->f_leaf = fl;
+  p->spec_eval_k = ek; p->spec_leaf_k = lk; p->spec_leaf_w = lw;
+  return GSDF_OK;
+}
+/* 1 if the handle runs specialised kernels; compile_seconds (optional) = what the build took */
+extern "C" int gsdf_hip_program_is_specialized(const gsdf_program* p, double* compile_seconds) {
+  if (compile_seconds) *compile_seconds = p ? p->spec_compile_s : 0.0;
+  return p && p->spec_mod ? 1 : 0;
+}
+
+// Host-only (no GPU): the generated evaluator source of a tree's specialised build, and a hiprtc compile of the
+// specialised kernels for gfx950 that stops before loading them (proves the generated code builds).
+extern "C" int gsdf_hip_specialize_source(const gsdf_tree* tree, char* dst, size_t dst_cap, size_t* len) {
+  if (!tree) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  try {
+    const std::string s = gsdf_dev::spec_source(gsdf_dev::compile(*tree));
+    if (len) *len = s.size();
+    if (dst) {
+      if (dst_cap < s.size() + 1) return fail(GSDF_ERR_SHORT_BUFFER, "short buffer");
+      std::memcpy(dst, s.c_str(), s.size() + 1);
+    }
+    return GSDF_OK;
+  } catch (const std::exception& e) {
+    return fail(GSDF_ERR_BAD_TREE, e.what());
+  }
+}
+extern "C" int gsdf_hip_specialize_check(const gsdf_tree* tree, size_t* code_object_bytes) {
+  if (!tree) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  try {
+    const gsdf_dev::Program pr = gsdf_dev::compile(*tree);
+    std::vector<char> co;
+    std::vector<std::string> low;
+    std::string log;
+    const std::vector<std::string> names = pr.is2d ? std::vector<std::string>{"eval_kernel<2, 4>"}
+                                                   : std::vector<std::string>{"eval_kernel<3, 4>", "prune_kernel", "leaf_kernel<4, 4>"};
+    if (!gsdf_dev::spec_compile(pr, "gfx950", names, co, low, log)) return fail(GSDF_ERR_HIP, "specialised build failed:\n" + log);
+    if (code_object_bytes) *code_object_bytes = co.size();
+    return GSDF_OK;
+  } catch (const std::exception& e) {
+    return fail(GSDF_ERR_BAD_TREE, e.what());
+  }
+}
+
 // Host-only (no GPU): lower a tree to the device instruction stream, for inspection/tests.
 extern "C" int gsdf_hip_lower(const gsdf_tree* tree, uint32_t* code_out, uint32_t code_cap, uint32_t* code_words, uint32_t* lds_slots) {
   if (!tree) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
@@ -1186,6 +335,7 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (p->d_code) (void)hipFree(p->d_code);
   if (p->d_pos) (void)hipFree(p->d_pos);
   if (p->d_dist) (void)hipFree(p->d_dist);
+  if (p->spec_mod) (void)hipModuleUnload(p->spec_mod);
   p->q0.release(); p->q1.release(); p->ctr.release();
   p->dc_grid.release(); p->dc_dist.release(); p->dc_fv.release(); p->dc_nrm.release(); p->dc_edge.release();
   for (auto e : p->ev) if (e) (void)hipEventDestroy(e);
@@ -1215,6 +365,9 @@ static int eval_dev(gsdf_program* p, int dim, const void* d_pos, size_t stride_b
   const float* q = (const float*)d_pos;
   const uint64_t nn = (uint64_t)n;
 #define LAUNCH_EVAL(D, KK) hipLaunchKernelGGL((eval_kernel<D, KK>), dim3(grid), dim3(BLOCK), p->lds_bytes(KK), s, p->d_code, q, sf, d_dist, nn)
+  if (p->f_eval && p->spec_eval_k == k) {
+    HIP_TRY(launch_fn(p->f_eval, grid, BLOCK, p->lds_bytes(k), s, (const uint32_t*)p->d_code, q, sf, d_dist, nn));
+  } else
   if (dim == 3) { if (k == 4) LAUNCH_EVAL(3, 4); else if (k == 2) LAUNCH_EVAL(3, 2); else LAUNCH_EVAL(3, 1); }
   else { if (k == 4) LAUNCH_EVAL(2, 4); else if (k == 2) LAUNCH_EVAL(2, 2); else LAUNCH_EVAL(2, 1); }
 #undef LAUNCH_EVAL
@@ -1363,10 +516,9 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   // multi-GPU: bricks of level ls are dealt to ranks by a hash of their coordinates (brick_owner).
   const int ls = levels < lq + 2 ? levels : lq + 2;
   const size_t lds_prune = p->lds_bytes(1) + PRUNE_STAGE * sizeof(Cube) + 64;
-  // leaf kernel batching: K = 4 while 3 workgroups still fit the CU's LDS (<= 11 slots); 12..15 slots run K = 2 at 4
-  // waves/SIMD instead of K = 4 at 2 (knurled-cylinder: 23.3 vs 23.8 ms)
-  const int lk = (p->batch_k() == 4 && p->prog.nslots > 11) ? 2 : p->batch_k();
-  const size_t lds_m = (size_t)(p->prog.nslots * lk > 8 ? p->prog.nslots * lk : 8) * BLOCK * sizeof(float) + 4096 + TRI_STAGE * 36 + 64;
+  int lk, lw;
+  size_t lds_m;
+  p->leaf_config(&lk, &lw, &lds_m);
   uint64_t qcap = p->q0.cap / sizeof(Cube);
   if (qcap < (1u << 20)) qcap = 1u << 20;  // 1 M cubes (8 MB) per queue to start with
   uint64_t want = opts.max_tris;
@@ -1396,6 +548,12 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
       // upper bound of candidates at this level (for the grid only): 8^(levels-level), capped by the queue
       uint64_t bound = (levels - level) * 3 >= 40 ? UINT64_MAX : ((uint64_t)1 << (3 * (levels - level)));
       if (bound > capq[(level + 1) & 1] * 8) bound = capq[(level + 1) & 1] * 8;
+      if (p->f_prune) {
+        HIP_TRYM(launch_fn(p->f_prune, grid_for(bound, p->num_cu, 4), BLOCK, lds_prune, s, (const uint32_t*)p->d_code,
+                           (const Cube*)q[(level + 1) & 1]->p, (int)expand, (int)level, (int)p->prog.nslots, ox, oy, oz, res, (int)do_test,
+                           (Cube*)q[level & 1]->p, (unsigned long long)capq[level & 1], (int)((opts.shard_count > 1 && level == ls) ? 1 : 0),
+                           (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr));
+      } else
       hipLaunchKernelGGL(prune_kernel, dim3(grid_for(bound, p->num_cu, 4)), dim3(BLOCK), lds_prune, s, p->d_code,
                          (const Cube*)q[(level + 1) & 1]->p, expand, level, p->prog.nslots, ox, oy, oz, res, do_test, (Cube*)q[level & 1]->p,
                          (unsigned long long)capq[level & 1], (opts.shard_count > 1 && level == ls) ? 1 : 0,
@@ -1412,7 +570,6 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   hipLaunchKernelGGL((leaf_kernel<KK, WW>), dim3(grid_for(bound, p->num_cu, 8)), dim3(BLOCK), lds_m, s, p->d_code,      \
                      (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res,  \
                      m->d_tris, tcap, d_ctr)
-      static const int forced_w = [] { const char* e = getenv("GSDF_HIP_LEAF_WAVES"); return e ? atoi(e) : 0; }();  // tuning knob
       if (lq == 3 && lk == 4 && opts.share_corners) {
         // exact corner sharing: one wave per level-3 brick
         const size_t lds_b = (size_t)(p->prog.nslots * 4) * BLOCK * sizeof(float) + 4096 + TRI_STAGE * 36 + 32 + 4 * 512 * 4 + 4 * 24 * 4;
@@ -1420,15 +577,13 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
                            dim3(BLOCK), lds_b, s, p->d_code, (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1],
                            p->prog.nslots, ox, oy, oz, res, m->d_tris, tcap, d_ctr);
         used_brick = true;
-      } else
-      {
-        // Occupancy: a 4th wave per SIMD is worth more than the ~30 VGPRs it costs (flange 3.28 -> 2.95 ms; the
-        // spills are the leaf's corner coordinates parked around the interpreter), but only if 4 workgroups fit the
-        // CU's 160 KB of LDS; otherwise 3 waves/SIMD with the larger register budget.
-        const bool fit4 = 4 * lds_m <= 160 * 1024;
-        const int ww = forced_w ? forced_w : (fit4 ? 4 : 3);
-        if (lk == 4) { if (ww == 2) LAUNCH_LEAF(4, 2); else if (ww == 4) LAUNCH_LEAF(4, 4); else LAUNCH_LEAF(4, 3); }
-        else if (lk == 2) { if (ww == 4) LAUNCH_LEAF(2, 4); else LAUNCH_LEAF(2, 3); }
+      } else if (p->f_leaf && p->spec_leaf_k == lk && p->spec_leaf_w == lw) {
+        HIP_TRYM(launch_fn(p->f_leaf, grid_for(bound, p->num_cu, 8), BLOCK, lds_m, s, (const uint32_t*)p->d_code, (const Cube*)q[lq & 1]->p,
+                           (unsigned long long)capq[lq & 1], (int)lq, (int)p->prog.nslots, ox, oy, oz, res, m->d_tris,
+                           (unsigned long)tcap, d_ctr));
+      } else {
+        if (lk == 4) { if (lw == 2) LAUNCH_LEAF(4, 2); else if (lw == 4) LAUNCH_LEAF(4, 4); else LAUNCH_LEAF(4, 3); }
+        else if (lk == 2) { if (lw == 4) LAUNCH_LEAF(2, 4); else LAUNCH_LEAF(2, 3); }
         else LAUNCH_LEAF(1, 4);
       }
 #undef LAUNCH_LEAF

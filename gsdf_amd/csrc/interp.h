@@ -8,7 +8,9 @@
 //
 // Formula order per opcode follows /root/reference/cpu_evaluators.go (line cites in compile.cpp).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 
 #include "dev_math.h"
 #include "dev_ops.h"
@@ -73,15 +75,28 @@ __device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t n
       negm[kp] ^= ~((b1 ^ b2) | (b2 ^ b3));  // flip where all three are true or all three are false
     }
   }
-  KLOOP neg[kp] = __builtin_amdgcn_inverse_ballot_w64(negm[kp]);  // the mask is the per-lane predicate
+  {  // the mask is the per-lane predicate (shift/and rather than the inverse-ballot builtin: the run-time compiler
+     // of a process that loaded an older ROCm first, e.g. PyTorch's bundled one, does not have it)
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    KLOOP neg[kp] = ((negm[kp] >> lane) & 1ull) != 0ull;
+  }
   if (!FAST) return true;
   return __all(nmin >= 8.0779357e-28f /* 2^-90 */ && nmax <= 1.2379400e+27f /* 2^90 */);
 }
+
+// hypot(P.x,P.y) of every point into hxy[] unless the cache is valid; odd points copy their pair's value when shared
+#define ENSURE_HXY()                                                                   \
+  if (!use_hxy) {                                                                      \
+    KLOOP if (!(kp & 1)) hxy[kp] = hypotf_(pv[kp].x, pv[kp].y);                         \
+    if (sh_xy) { KLOOP if (kp & 1) hxy[kp] = hxy[kp ? kp - 1 : 0]; }                    \
+    else { KLOOP if (kp & 1) hxy[kp] = hypotf_(pv[kp].x, pv[kp].y); }                   \
+  }
 
 // PAIRED (the mesher's leaf kernels only): the caller passes the corners of one leaf cube in the order
 // {0,4,1,5 | 3,7,2,6}, i.e. points 2j and 2j+1 enter with bitwise equal x,y and (K = 4) points j and j+2 with equal z.
 // Instructions the host compiler flagged D_FLAG_SHXY / D_FLAG_SHZ then compute their f(P.x,P.y) / g(P.z) once per
 // pair and copy it: same inputs, same operation sequence, same bits as evaluating every corner separately.
+#ifndef GSDF_SPECIALIZED
 template <int K, bool PAIRED = false>
 __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)[K],
                                          float* __restrict__ lds /* already offset by tid */, const uint32_t nthreads) {
@@ -103,13 +118,6 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
     const bool swap_ab = (w & D_FLAG_SWAP) != 0u;  // wave-uniform
     const bool sh_xy = PAIRED && K >= 2 && (w & D_FLAG_SHXY) != 0u;
     const bool sh_z = PAIRED && K >= 4 && (w & D_FLAG_SHZ) != 0u;
-// hypot(P.x,P.y) of every point into hxy[] unless the cache is valid; odd points copy their pair's value when shared
-#define ENSURE_HXY()                                                                   \
-  if (!use_hxy) {                                                                      \
-    KLOOP if (!(kp & 1)) hxy[kp] = hypotf_(pv[kp].x, pv[kp].y);                         \
-    if (sh_xy) { KLOOP if (kp & 1) hxy[kp] = hxy[kp ? kp - 1 : 0]; }                    \
-    else { KLOOP if (kp & 1) hxy[kp] = hypotf_(pv[kp].x, pv[kp].y); }                   \
-  }
     switch (op) {
       case D_END:
         return;
@@ -737,9 +745,17 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
   }
 #undef PF
 #undef PU
-#undef ENSURE_HXY
 }
+#else
+// Run-time specialisation (hiprtc): sdf_eval<K, PAIRED> for ONE lowered program, generated by specialize.cpp from the
+// case bodies above -- the same statements in program order, with the instruction word, its flags, the slot number and
+// every parameter as literals, so there is no fetch/decode, no dispatch branch and no dead flag test left.
+}  // namespace gsdf_dev
+#include "gsdf_spec_gen.h"
+namespace gsdf_dev {
+#endif
 
+#undef ENSURE_HXY
 #undef LDSF
 #undef KLOOP
 

@@ -21,7 +21,7 @@ ErrMismatchBufferLength = "position and distance buffer length mismatch"
 
 # every symbol include/gsdf_hip.h declares
 SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "gsdf_hip_program_destroy",
-           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt",
+           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_program_specialize", "gsdf_hip_program_is_specialized", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
            "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3", "gsdf_hip_image2",
            "gsdf_hip_mesh_octree", "gsdf_hip_mesh_dualcontour", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
            "gsdf_hip_mesh_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner"]
@@ -65,6 +65,10 @@ def lib():
         L.gsdf_hip_lower.argtypes = [C.POINTER(GsdfTree), C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.gsdf_hip_selftest_div.argtypes = [C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
         L.gsdf_hip_selftest_sqrt.argtypes = [C.POINTER(C.c_uint64)]
+        L.gsdf_hip_program_specialize.argtypes = [C.c_void_p]
+        L.gsdf_hip_program_is_specialized.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.gsdf_hip_specialize_source.argtypes = [C.POINTER(GsdfTree), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.gsdf_hip_specialize_check.argtypes = [C.POINTER(GsdfTree), C.POINTER(C.c_size_t)]
         L.gsdf_hip_evaluations.restype = C.c_uint64
         L.gsdf_hip_evaluations.argtypes = [C.c_void_p]
         for f in (L.gsdf_hip_eval3, L.gsdf_hip_eval2):
@@ -144,7 +148,14 @@ class SDFHIP:
     def info(self):
         a, b = C.c_uint32(), C.c_uint32()
         _check(lib().gsdf_hip_program_info(self._h, C.byref(a), C.byref(b)))
-        return {"code_words": a.value, "lds_slots": b.value}
+        t = C.c_double()
+        sp = lib().gsdf_hip_program_is_specialized(self._h, C.byref(t))
+        return {"code_words": a.value, "lds_slots": b.value, "specialized": bool(sp), "specialize_s": t.value}
+
+    def specialize(self):
+        """Build (hiprtc) and switch to kernels specialised for this tree: same bits, no fetch/decode. Returns self."""
+        _check(lib().gsdf_hip_program_specialize(self._h))
+        return self
 
     def Evaluate(self, pos, dist=None, userData=None):
         """pos: (n,3)|(n,4)|(n,2) float32 host array (row stride = position stride); dist: (n,) float32."""

@@ -72,6 +72,17 @@ uint64_t gsdf_hip_evaluations(const gsdf_program* p);
 int gsdf_hip_selftest_div(float d, uint64_t* mismatches, uint64_t* fast_path_numerators, float* recip);
 /* Test hook (needs a GPU): the interpreter's sqrt for hypot's [1,2] argument range against sqrtf, all floats in range. */
 int gsdf_hip_selftest_sqrt(uint64_t* mismatches);
+/* Run-time specialisation (no reference counterpart; the reference's GPU path compiles GLSL per tree at
+ * gleval/gpu.go:35-54, this is the same step for the HIP backend): builds, with hiprtc, eval / prune / leaf kernels in
+ * which this program's instructions are laid out straight-line with literal parameters, and makes the handle launch
+ * them. Same statements and compiler flags as the interpreter, so results stay bit-identical; costs a few seconds
+ * once per handle. Without it (or if hiprtc is unavailable: GSDF_ERR_HIP) the handle runs the interpreter kernels. */
+int gsdf_hip_program_specialize(gsdf_program* p);
+int gsdf_hip_program_is_specialized(const gsdf_program* p, double* compile_seconds);
+/* Host-only (run without a GPU): text of the generated evaluator, and a gfx950 hiprtc build of the specialised kernels
+ * that stops before loading them. dst may be NULL to query the length. */
+int gsdf_hip_specialize_source(const gsdf_tree* tree, char* dst, size_t dst_cap, size_t* len);
+int gsdf_hip_specialize_check(const gsdf_tree* tree, size_t* code_object_bytes);
 /* Host-only (runs without a GPU): lower a tree to the device instruction stream (gsdf_amd/csrc/dev_ops.h) for
  * inspection. code_out may be NULL to query the size. */
 int gsdf_hip_lower(const gsdf_tree* tree, uint32_t* code_out, uint32_t code_cap, uint32_t* code_words, uint32_t* lds_slots);

@@ -1,0 +1,91 @@
+"""GPU parity of the run-time specialised kernels (gsdf_hip_program_specialize): bit-identical to the oracle and
+to the interpreter kernels on every node type, on the golden vectors and on the meshes."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import corpus
+from gsdf_amd.builder import Builder
+from oracle.oracle import OracleSDF
+
+pytestmark = pytest.mark.gpu
+GOLDDIR = os.path.join(os.path.dirname(__file__), "golden")
+GOLD = json.load(open(os.path.join(GOLDDIR, "mesh_digests.json")))
+
+
+def _mismatch(a, b):
+    return int(((a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))).sum())
+
+
+def _sorted(t):
+    t = np.ascontiguousarray(t, np.float32).reshape(-1, 9)
+    return t[np.lexsort(t.view(np.uint32).T[::-1])]
+
+
+@pytest.mark.parametrize("which", ["3d", "2d"])
+def test_corpus_specialised_bit_exact(gpu, which):
+    """All 53 node types: specialised Evaluate == oracle == committed golden distances, bit for bit."""
+    gold = np.load(os.path.join(GOLDDIR, "corpus_distances.npz"))
+    _, shapes = (corpus.shapes3d if which == "3d" else corpus.shapes2d)()
+    for name, sh in shapes:
+        sdf = gpu.SDFHIP(sh).specialize()
+        assert sdf.info()["specialized"]
+        pos = corpus.sample_points(sh)
+        assert _mismatch(sdf.Evaluate(pos), OracleSDF(sh.tree()).Evaluate(pos)) == 0, name
+        assert _mismatch(sdf.Evaluate(gold["pos_" + name]), gold["dist_" + name]) == 0, name
+
+
+@pytest.mark.parametrize("scene,key", [("npt-flange", "npt_flange_resdiv400"), ("bolt", "bolt_resdiv150"),
+                                       ("knurled-cylinder", "knurled_cylinder_resdiv120")])
+def test_specialised_mesh_identical(gpu, scene, key):
+    s = Builder().Scene(scene)
+    g = GOLD[key]
+    res = np.uint32(g["res_bits"]).view(np.float32)
+    sdf = gpu.SDF3HIP(s).specialize()
+    oc = gpu.OctreeHIP(sdf, res)
+    assert oc.n_tris() == g["n_tris"]                       # npt-flange@400: 423,852 (README.md:116,130)
+    tg = _sorted(oc.RenderAll())
+    assert hashlib.sha256(tg.tobytes()).hexdigest() == g["sha256_sorted"]
+    ref = OracleSDF(s.tree()).render_octree(res, 4096, True)
+    assert oc.TotalPruned() == ref.pruned
+    # sharded and unpruned runs go through the same specialised kernels
+    parts = [gpu.OctreeHIP(sdf, res, shard_rank=r, shard_count=3).RenderAll() for r in range(3)]
+    assert (_sorted(np.concatenate(parts)).view(np.uint32) == tg.view(np.uint32)).all()
+    if key != "npt_flange_resdiv400":
+        assert gpu.OctreeHIP(sdf, res, prune=False).n_tris() == g["n_tris"]
+    # the corner-sharing kernel (interpreter build) still works on a specialised handle
+    assert (_sorted(gpu.OctreeHIP(sdf, res, share_corners=True).RenderAll()).view(np.uint32) == tg.view(np.uint32)).all()
+
+
+def test_specialised_full_size_npt_flange(gpu):
+    """BASELINE.json configs[1] through the specialised kernels: count + digest of the sorted triangle set."""
+    s = Builder().Scene("npt-flange")
+    g = GOLD["npt_flange_resdiv1600"]
+    res = np.uint32(g["res_bits"]).view(np.float32)
+    sdf = gpu.SDF3HIP(s).specialize()
+    oc = gpu.OctreeHIP(sdf, res)
+    assert oc.n_tris() == g["n_tris"]
+    assert hashlib.sha256(_sorted(oc.RenderAll()).tobytes()).hexdigest() == g["sha256_sorted"]
+
+
+def test_specialise_is_idempotent_and_counts_evaluations(gpu):
+    s = Builder().Scene("npt-flange")
+    sdf = gpu.SDF3HIP(s)
+    assert not sdf.info()["specialized"]
+    rng = np.random.default_rng(3)
+    bb = s.Bounds()
+    pos = (bb[:3] + rng.random((5000, 3), np.float32) * (bb[3:] - bb[:3])).astype(np.float32)
+    d0 = sdf.Evaluate(pos)
+    sdf.specialize().specialize()
+    info = sdf.info()
+    assert info["specialized"] and info["specialize_s"] > 0
+    assert _mismatch(sdf.Evaluate(pos), d0) == 0
+    assert sdf.Evaluations() == 10000
+    # dual contouring and normals keep using the interpreter kernels of the same handle
+    res = np.float32(float(s.Diagonal()) / 60)
+    a = gpu.DualContourHIP(sdf, res).RenderAll()
+    b = gpu.DualContourHIP(gpu.SDF3HIP(s), res).RenderAll()
+    assert (_sorted(a).view(np.uint32) == _sorted(b).view(np.uint32)).all()
