@@ -69,8 +69,10 @@ struct gsdf_program {
   uint64_t last_tris = 0;  // triangle count of the previous mesh on this handle: sizes the next output buffer
   uint64_t last_dc_cubes = 0;  // kept cubes of the previous dual contouring pass: sizes the next queues
   // run-time specialised kernels for this program (gsdf_hip_program_specialize): hiprtc module, else interpreter
-  hipModule_t spec_mod = nullptr;
+  hipModule_t spec_mod = nullptr, spec_mod2 = nullptr;  // spec_mod2: second group, built on first use (see spec_aux)
   hipFunction_t f_eval = nullptr, f_prune = nullptr, f_leaf = nullptr;
+  hipFunction_t f_dc_origin = nullptr, f_dc_edges = nullptr, f_dc_normals = nullptr, f_normals = nullptr, f_image = nullptr;
+  bool spec_aux_tried = false;
   int spec_eval_k = 0, spec_leaf_k = 0, spec_leaf_w = 0;
   double spec_compile_s = 0;
   // leaf kernel batching: K = 4 while 3 workgroups still fit the CU's LDS (<= 11 slots); 12..15 slots run K = 2 at 4
@@ -232,6 +234,53 @@ extern "C" int gsdf_hip_selftest_sqrt(uint64_t* mismatches) {
   return rc;
 }
 
+static std::string device_arch(int device) {
+  hipDeviceProp_t pr;
+  if (hipGetDeviceProperties(&pr, device) != hipSuccess) return "gfx950";
+  std::string arch = pr.gcnArchName;
+  if (arch.find(':') != std::string::npos) arch = arch.substr(0, arch.find(':'));
+  return arch;
+}
+
+// hiprtc build + module load of `names` for the handle's program; fns receives one function per name.
+static int spec_build(gsdf_program* p, const std::vector<std::string>& names, hipModule_t* mod_out, std::vector<hipFunction_t>& fns, double* secs) {
+  std::vector<char> co;
+  std::vector<std::string> low;
+  std::string log;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (!gsdf_dev::spec_compile(p->prog, device_arch(p->device), names, co, low, log)) return fail(GSDF_ERR_HIP, "specialised build failed:\n" + log);
+  if (secs) *secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  hipModule_t mod = nullptr;
+  HIP_TRY(hipModuleLoadData(&mod, co.data()));
+  fns.assign(names.size(), nullptr);
+  for (size_t i = 0; i < names.size(); i++) {
+    hipError_t e = hipModuleGetFunction(&fns[i], mod, low[i].c_str());
+    if (e != hipSuccess) {
+      (void)hipModuleUnload(mod);
+      return fail(GSDF_ERR_HIP, std::string("hipModuleGetFunction: ") + hipGetErrorString(e));
+    }
+  }
+  *mod_out = mod;
+  return GSDF_OK;
+}
+
+// Second group of a specialised handle, built the first time one of these entry points runs: the evaluating kernels of
+// dual contouring, central-difference normals and the 2-D image renderer. Failure leaves the interpreter kernels in use.
+static void spec_aux(gsdf_program* p) {
+  if (!p->spec_mod || p->spec_aux_tried) return;
+  p->spec_aux_tried = true;
+  const std::string k = std::to_string(p->batch_k());
+  std::vector<hipFunction_t> f;
+  if (p->prog.is2d) {
+    if (spec_build(p, {"image2_kernel<" + k + ">"}, &p->spec_mod2, f, &p->spec_compile_s) == GSDF_OK) p->f_image = f[0];
+  } else {
+    if (spec_build(p, {"dc_origin_kernel<" + k + ">", "dc_edges_kernel", "dc_normals_kernel", "normals_kernel"}, &p->spec_mod2, f,
+                   &p->spec_compile_s) == GSDF_OK) {
+      p->f_dc_origin = f[0]; p->f_dc_edges = f[1]; p->f_dc_normals = f[2]; p->f_normals = f[3];
+    }
+  }
+}
+
 // Compile and load kernels specialised for this handle's program (specialize.cpp): eval, prune and leaf kernels of
 // the configuration the mesher would pick. Afterwards gsdf_hip_eval*/gsdf_hip_mesh_octree launch them instead of the
 // interpreter kernels; results are bit-identical (same statements, same compiler flags). Idempotent.
@@ -239,10 +288,6 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
   if (!p) return fail(GSDF_ERR_BAD_ARGUMENT, "null program");
   if (p->spec_mod) return GSDF_OK;
   HIP_TRY(hipSetDevice(p->device));
-  hipDeviceProp_t pr;
-  HIP_TRY(hipGetDeviceProperties(&pr, p->device));
-  std::string arch = pr.gcnArchName;
-  if (arch.find(':') != std::string::npos) arch = arch.substr(0, arch.find(':'));
   int lk, lw;
   size_t lds_m;
   p->leaf_config(&lk, &lw, &lds_m);
@@ -253,24 +298,13 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
     names.push_back("prune_kernel");
     names.push_back("leaf_kernel<" + std::to_string(lk) + ", " + std::to_string(lw) + ">");
   }
-  std::vector<char> co;
-  std::vector<std::string> low;
-  std::string log;
-  const auto t0 = std::chrono::steady_clock::now();
-  if (!gsdf_dev::spec_compile(p->prog, arch, names, co, low, log)) return fail(GSDF_ERR_HIP, "specialised build failed:\n" + log);
-  p->spec_compile_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::vector<hipFunction_t> f;
   hipModule_t mod = nullptr;
-  HIP_TRY(hipModuleLoadData(&mod, co.data()));
-  hipFunction_t fe = nullptr, fp = nullptr, fl = nullptr;
-  hipError_t e = hipModuleGetFunction(&fe, mod, low[0].c_str());
-  if (e == hipSuccess && !p->prog.is2d) e = hipModuleGetFunction(&fp, mod, low[1].c_str());
-  if (e == hipSuccess && !p->prog.is2d) e = hipModuleGetFunction(&fl, mod, low[2].c_str());
-  if (e != hipSuccess) {
-    (void)hipModuleUnload(mod);
-    return fail(GSDF_ERR_HIP, std::string("hipModuleGetFunction: ") + hipGetErrorString(e));
-  }
+  const int rc = spec_build(p, names, &mod, f, &p->spec_compile_s);
+  if (rc != GSDF_OK) return rc;
   p->spec_mod = mod;
-  p->f_eval = fe; p->f_prune = fp; p->f_leaf = fl;
+  p->f_eval = f[0];
+  if (!p->prog.is2d) { p->f_prune = f[1]; p->f_leaf = f[2]; }
   p->spec_eval_k = ek; p->spec_leaf_k = lk; p->spec_leaf_w = lw;
   return GSDF_OK;
 }
@@ -336,6 +370,7 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (p->d_pos) (void)hipFree(p->d_pos);
   if (p->d_dist) (void)hipFree(p->d_dist);
   if (p->spec_mod) (void)hipModuleUnload(p->spec_mod);
+  if (p->spec_mod2) (void)hipModuleUnload(p->spec_mod2);
   p->q0.release(); p->q1.release(); p->ctr.release();
   p->dc_grid.release(); p->dc_dist.release(); p->dc_fv.release(); p->dc_nrm.release(); p->dc_edge.release();
   for (auto e : p->ev) if (e) (void)hipEventDestroy(e);
@@ -436,6 +471,11 @@ extern "C" int gsdf_hip_normals3(gsdf_program* p, const float* pos, float* norma
   int rc = GSDF_OK;
   do {
     if (hipMemcpyAsync(d_p, pos, n * 12, hipMemcpyHostToDevice, p->stream) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "H2D copy failed"); break; }
+    spec_aux(p);
+    if (p->f_normals) {
+      if (launch_fn(p->f_normals, grid_for(n, p->num_cu, 8), BLOCK, p->lds_bytes(2), p->stream, (const uint32_t*)p->d_code, (const float*)d_p, (float*)d_n,
+                    (uint64_t)n, (float)step) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "kernel launch failed"); break; }
+    } else
     hipLaunchKernelGGL(normals_kernel, dim3(grid_for(n, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(2), p->stream, p->d_code, d_p, d_n, (uint64_t)n, step);
     if (hipGetLastError() != hipSuccess) { rc = fail(GSDF_ERR_HIP, "normals kernel launch failed"); break; }
     if (hipMemcpyAsync(normals, d_n, n * 12, hipMemcpyDeviceToHost, p->stream) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "D2H copy failed"); break; }
@@ -652,6 +692,9 @@ extern "C" int gsdf_hip_image2(gsdf_program* p, int w, int h, float* dist_out, u
   const int k = p->batch_k();
   const unsigned grid = grid_for((n + k - 1) / k, p->num_cu, 8);
 #define LAUNCH_IMG(KK) hipLaunchKernelGGL((image2_kernel<KK>), dim3(grid), dim3(BLOCK), p->lds_bytes(KK), p->stream, p->d_code, w, h, xmin, ymax, dx, dy, (float*)dd.p, (uint32_t*)dc.p)
+  spec_aux(p);
+  if (p->f_image) HIP_TRY(launch_fn(p->f_image, grid, BLOCK, p->lds_bytes(k), p->stream, (const uint32_t*)p->d_code, (int)w, (int)h, xmin, ymax, dx, dy, (float*)dd.p, (uint32_t*)dc.p));
+  else
   if (k == 4) LAUNCH_IMG(4); else if (k == 2) LAUNCH_IMG(2); else LAUNCH_IMG(1);
 #undef LAUNCH_IMG
   HIP_TRY(hipGetLastError());
@@ -737,13 +780,22 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     HIP_TRYM(hipEventRecord(p->ev[0], s));
     const unsigned g1 = grid_for((nslab + lk - 1) / lk, p->num_cu, 8);
 #define LAUNCH_O(KK) hipLaunchKernelGGL((dc_origin_kernel<KK>), dim3(g1), dim3(BLOCK), p->lds_bytes(KK) + 32, s, p->d_code, p->prog.nslots, nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, zlo, zhi, d_ctr)
+    spec_aux(p);
+    if (p->f_dc_origin) HIP_TRYM(launch_fn(p->f_dc_origin, g1, BLOCK, p->lds_bytes(lk) + 32, s, (const uint32_t*)p->d_code, (int)p->prog.nslots, (int)nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, (unsigned)zlo, (unsigned)zhi, d_ctr));
+    else
     if (lk == 4) LAUNCH_O(4); else if (lk == 2) LAUNCH_O(2); else LAUNCH_O(1);
 #undef LAUNCH_O
     HIP_TRYM(hipGetLastError());
     if (p->lds_bytes(4) > 150 * 1024) return bail(fail(GSDF_ERR_BAD_TREE, "tree needs too much LDS scratch for the dual contouring edge pass"));
+    if (p->f_dc_edges) HIP_TRYM(launch_fn(p->f_dc_edges, grid_for(ccap, p->num_cu, 8), BLOCK, p->lds_bytes(4), s, (const uint32_t*)p->d_code, (const Cube*)p->q0.p,
+                       (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, d_ctr));
+    else
     hipLaunchKernelGGL(dc_edges_kernel, dim3(grid_for(ccap, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(4), s, p->d_code, (const Cube*)p->q0.p,
                        (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, d_ctr);
     HIP_TRYM(hipGetLastError());
+    if (p->f_dc_normals) HIP_TRYM(launch_fn(p->f_dc_normals, grid_for(ecap, p->num_cu, 8), BLOCK, p->lds_bytes(2), s, (const uint32_t*)p->d_code, (const Cube*)p->q0.p,
+                       (const float4*)d2.p, (const unsigned*)e2.p, (unsigned long long)ecap, ox, oy, oz, res, h, (float*)n2.p, d_ctr));
+    else
     hipLaunchKernelGGL(dc_normals_kernel, dim3(grid_for(ecap, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(2), s, p->d_code, (const Cube*)p->q0.p,
                        (const float4*)d2.p, (const unsigned*)e2.p, (unsigned long long)ecap, ox, oy, oz, res, h, (float*)n2.p, d_ctr);
     HIP_TRYM(hipGetLastError());

@@ -84,8 +84,26 @@ def test_specialise_is_idempotent_and_counts_evaluations(gpu):
     assert info["specialized"] and info["specialize_s"] > 0
     assert _mismatch(sdf.Evaluate(pos), d0) == 0
     assert sdf.Evaluations() == 10000
-    # dual contouring and normals keep using the interpreter kernels of the same handle
+
+
+def test_specialised_dualcontour_normals_image(gpu):
+    """The second kernel group of a specialised handle (built on first use): dual contouring, central-difference
+    normals and the 2-D image renderer give the interpreter's bits."""
+    b = Builder()
+    s = b.Scene("npt-flange")
+    spec, plain = gpu.SDF3HIP(s).specialize(), gpu.SDF3HIP(s)
     res = np.float32(float(s.Diagonal()) / 60)
-    a = gpu.DualContourHIP(sdf, res).RenderAll()
-    b = gpu.DualContourHIP(gpu.SDF3HIP(s), res).RenderAll()
-    assert (_sorted(a).view(np.uint32) == _sorted(b).view(np.uint32)).all()
+    for chis in (False, True):
+        a = gpu.DualContourHIP(spec, res, chiseled=chis).RenderAll()
+        c = gpu.DualContourHIP(plain, res, chiseled=chis).RenderAll()
+        assert a.shape == c.shape and (_sorted(a).view(np.uint32) == _sorted(c).view(np.uint32)).all()
+    ref = OracleSDF(s.tree()).render_dualcontour(res, False)
+    assert (_sorted(gpu.DualContourHIP(spec, res).RenderAll()).view(np.uint32) == _sorted(ref.tris).view(np.uint32)).all()
+    rng = np.random.default_rng(11)
+    bb = s.Bounds()
+    pos = (bb[:3] + rng.random((4000, 3), np.float32) * (bb[3:] - bb[:3])).astype(np.float32)
+    assert _mismatch(spec.normals(pos, 1e-3), plain.normals(pos, 1e-3)) == 0
+    sh2 = b.Union2D(b.NewCircle(1.0), b.Translate2D(b.NewRectangle(1.0, 2.0), 0.5, 0.25))
+    s2, p2 = gpu.SDF2HIP(sh2).specialize(), gpu.SDF2HIP(sh2)
+    ia, ib = s2.render_image(96, 64), p2.render_image(96, 64)
+    assert all((np.asarray(x).view(np.uint8) == np.asarray(y).view(np.uint8)).all() for x, y in zip(ia, ib))
