@@ -560,7 +560,14 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   size_t lds_m;
   p->leaf_config(&lk, &lw, &lds_m);
   uint64_t qcap = p->q0.cap / sizeof(Cube);
-  if (qcap < (1u << 20)) qcap = 1u << 20;  // 1 M cubes (8 MB) per queue to start with
+  {
+    // 1 M cubes (8 MB) per queue to start with; GSDF_HIP_QCAP_MIN lowers it so that tests can drive the
+    // overflow -> grow -> rerun path (the arenas only ever grow, so a handle that already meshed keeps its size)
+    const char* e = getenv("GSDF_HIP_QCAP_MIN");
+    const uint64_t qmin = e ? (uint64_t)strtoull(e, nullptr, 10) : ((uint64_t)1 << 20);
+    if (qcap < qmin) qcap = qmin;
+    if (qcap < 64) qcap = 64;
+  }
   uint64_t want = opts.max_tris;
   MeshCounters hc{};
   bool used_brick = false;

@@ -258,3 +258,19 @@ def test_glyph_plate_wide_union(gpu):
     assert (_sorted(dc.RenderAll()).view(np.uint32) == _sorted(rd.tris).view(np.uint32)).all()
     fine = gpu.DualContourHIP(sdf, np.float32(0.25))   # 10 levels: 134 M lattice cells, the reference's practical limit
     assert fine.stats.levels == 10 and fine.n_tris() > 200000
+
+
+def test_cube_queue_overflow_grows_and_reruns(gpu, monkeypatch):
+    """A survivor queue that is too small is detected on device (nothing is dropped silently), grown and the pass
+    repeated: same mesh as with ample queues. Exercises the LDS-staged block append of prune_kernel at its capacity."""
+    s = Builder().Scene("npt-flange")
+    g = GOLD["npt_flange_resdiv400"]
+    res = np.uint32(g["res_bits"]).view(np.float32)
+    monkeypatch.setenv("GSDF_HIP_QCAP_MIN", "100")           # level 3 has 17 K survivors at this resolution
+    for spec in (False, True):
+        sdf = gpu.SDF3HIP(s)                                 # fresh handle: arenas start empty
+        if spec:
+            sdf.specialize()
+        oc = gpu.OctreeHIP(sdf, res)
+        assert oc.n_tris() == g["n_tris"]
+        assert _digest(oc.RenderAll()) == g["sha256_sorted"]
