@@ -12,6 +12,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/gsdf_hip.h"
@@ -892,4 +893,93 @@ extern "C" void gsdf_hip_mesh_destroy(gsdf_mesh* m) {
   if (!m) return;
   pool_give(m->device, m->d_tris, m->cap);
   delete m;
+}
+
+// ---- gleval.BlockCachedSDF3 (gleval/gleval.go:110-218) over a HIP program ---------------------------------------
+// Host-side wrapper, as in the reference: a lossy cache keyed by the lattice cell of the position
+// (int(mul * (p - bb.Min)) per axis, mul = 1/res); misses are evaluated in ONE batch by the wrapped evaluator.
+struct gsdf_blockcache {
+  gsdf_program* sdf = nullptr;
+  float mul[3] = {0, 0, 0};
+  struct Key { long long x, y, z; bool operator==(const Key& o) const { return x == o.x && y == o.y && z == o.z; } };
+  struct Hash {
+    size_t operator()(const Key& k) const {
+      unsigned long long h = (unsigned long long)k.x * 0x9E3779B97F4A7C15ull;
+      h ^= (unsigned long long)k.y + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+      h ^= (unsigned long long)k.z + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+      return (size_t)h;
+    }
+  };
+  std::unordered_map<Key, float, Hash> m;
+  std::vector<float> posbuf, distbuf;
+  std::vector<size_t> idxbuf;
+  uint64_t hits = 0, evals = 0;
+};
+
+extern "C" int gsdf_hip_blockcache_reset(gsdf_blockcache* c, gsdf_program* sdf, float resx, float resy, float resz) {
+  if (!c || !sdf) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  if (resx <= 0 || resy <= 0 || resz <= 0 || std::isnan(resx) || std::isnan(resy) || std::isnan(resz))
+    return fail(GSDF_ERR_RESOLUTION, "invalid resolution for BlockCachedSDF3");  // gleval.go:127-129
+  if (sdf->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
+  c->m.clear();
+  c->sdf = sdf;
+  c->mul[0] = 1.0f / resx; c->mul[1] = 1.0f / resy; c->mul[2] = 1.0f / resz;  // DivElem({1,1,1}, res)
+  c->posbuf.clear(); c->distbuf.clear(); c->idxbuf.clear();
+  c->hits = 0; c->evals = 0;  // Reset also resets the statistics (gleval.go:124)
+  return GSDF_OK;
+}
+extern "C" int gsdf_hip_blockcache_create(gsdf_program* sdf, float resx, float resy, float resz, gsdf_blockcache** out) {
+  if (!out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  gsdf_blockcache* c = new (std::nothrow) gsdf_blockcache();
+  if (!c) return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory");
+  const int rc = gsdf_hip_blockcache_reset(c, sdf, resx, resy, resz);
+  if (rc) { delete c; return rc; }
+  *out = c;
+  return GSDF_OK;
+}
+extern "C" void gsdf_hip_blockcache_destroy(gsdf_blockcache* c) { delete c; }
+extern "C" uint64_t gsdf_hip_blockcache_hits(const gsdf_blockcache* c) { return c ? c->hits : 0; }
+extern "C" uint64_t gsdf_hip_blockcache_evaluations(const gsdf_blockcache* c) { return c ? c->evals : 0; }
+
+// (*BlockCachedSDF3).Evaluate (gleval.go:154-211). pos: n x 3 float32 with the given byte stride (12 or 16).
+extern "C" int gsdf_hip_blockcache_eval3(gsdf_blockcache* c, const void* pos, size_t stride, size_t n_pos, float* dist, size_t n_dist) {
+  if (!c || !c->sdf) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  if (n_pos != n_dist) return fail(GSDF_ERR_LENGTH_MISMATCH, "position and distance buffer length mismatch");
+  if (n_pos == 0) return fail(GSDF_ERR_EMPTY_BUFFERS, "empty buffers");
+  if (!pos || !dist) return fail(GSDF_ERR_BAD_ARGUMENT, "null buffer");
+  if (stride % 4 != 0 || stride < 12) return fail(GSDF_ERR_BAD_ARGUMENT, "bad position stride");
+  const float* bbmin = c->sdf->prog.bb;
+  auto key_of = [&](const float* p) {
+    // tp = MulElem(mul, Sub(p, bb.Min)); int(tp.X) truncates toward zero (Go float->int conversion)
+    gsdf_blockcache::Key k;
+    k.x = (long long)(c->mul[0] * (p[0] - bbmin[0]));
+    k.y = (long long)(c->mul[1] * (p[1] - bbmin[1]));
+    k.z = (long long)(c->mul[2] * (p[2] - bbmin[2]));
+    return k;
+  };
+  c->posbuf.clear();
+  c->idxbuf.clear();
+  const char* base = (const char*)pos;
+  for (size_t i = 0; i < n_pos; i++) {
+    const float* p = (const float*)(base + i * stride);
+    auto it = c->m.find(key_of(p));
+    if (it != c->m.end()) {
+      dist[i] = it->second;
+    } else {
+      c->posbuf.insert(c->posbuf.end(), p, p + 3);
+      c->idxbuf.push_back(i);
+    }
+  }
+  const size_t nseek = c->idxbuf.size();
+  if (nseek > 0) {
+    c->distbuf.resize(nseek);
+    const int rc = gsdf_hip_eval3(c->sdf, c->posbuf.data(), 12, nseek, c->distbuf.data(), nseek);
+    if (rc) return rc;
+    for (size_t i = 0; i < nseek; i++) c->m[key_of(&c->posbuf[3 * i])] = c->distbuf[i];  // later entries of a cell overwrite
+    for (size_t i = 0; i < nseek; i++) dist[c->idxbuf[i]] = c->distbuf[i];
+  }
+  c->evals += n_pos;
+  c->hits += n_pos - nseek;
+  return GSDF_OK;
 }

@@ -21,7 +21,7 @@ ErrMismatchBufferLength = "position and distance buffer length mismatch"
 
 # every symbol include/gsdf_hip.h declares
 SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "gsdf_hip_program_destroy",
-           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_program_specialize", "gsdf_hip_program_is_specialized", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
+           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_blockcache_create", "gsdf_hip_blockcache_reset", "gsdf_hip_blockcache_eval3", "gsdf_hip_blockcache_hits", "gsdf_hip_blockcache_evaluations", "gsdf_hip_blockcache_destroy", "gsdf_hip_program_specialize", "gsdf_hip_program_is_specialized", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
            "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3", "gsdf_hip_image2",
            "gsdf_hip_mesh_octree", "gsdf_hip_mesh_dualcontour", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
            "gsdf_hip_mesh_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner"]
@@ -65,6 +65,15 @@ def lib():
         L.gsdf_hip_lower.argtypes = [C.POINTER(GsdfTree), C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.gsdf_hip_selftest_div.argtypes = [C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
         L.gsdf_hip_selftest_sqrt.argtypes = [C.POINTER(C.c_uint64)]
+        L.gsdf_hip_blockcache_create.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_void_p)]
+        L.gsdf_hip_blockcache_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.gsdf_hip_blockcache_eval3.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.gsdf_hip_blockcache_hits.restype = C.c_uint64
+        L.gsdf_hip_blockcache_hits.argtypes = [C.c_void_p]
+        L.gsdf_hip_blockcache_evaluations.restype = C.c_uint64
+        L.gsdf_hip_blockcache_evaluations.argtypes = [C.c_void_p]
+        L.gsdf_hip_blockcache_destroy.restype = None
+        L.gsdf_hip_blockcache_destroy.argtypes = [C.c_void_p]
         L.gsdf_hip_program_specialize.argtypes = [C.c_void_p]
         L.gsdf_hip_program_is_specialized.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.gsdf_hip_specialize_source.argtypes = [C.POINTER(GsdfTree), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -190,6 +199,44 @@ class SDFHIP:
 
 SDF3HIP = SDFHIP
 SDF2HIP = SDFHIP
+
+
+class BlockCachedSDF3HIP:
+    """gleval.BlockCachedSDF3 (gleval/gleval.go:110-218) in front of a HIP evaluator: Reset / Evaluate / CacheHits /
+    Evaluations / Bounds with the reference's semantics (lossy per-cell cache, misses evaluated in one batch)."""
+
+    def __init__(self, sdf, resX, resY, resZ):
+        self._h = C.c_void_p()
+        self.sdf = sdf
+        _check(lib().gsdf_hip_blockcache_create(sdf._h, resX, resY, resZ, C.byref(self._h)))
+
+    def Reset(self, sdf, resX, resY, resZ):
+        _check(lib().gsdf_hip_blockcache_reset(self._h, sdf._h, resX, resY, resZ))
+        self.sdf = sdf
+
+    def Evaluate(self, pos, dist=None, userData=None):
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        if dist is None:
+            dist = np.empty(pos.shape[0], np.float32)
+        _check(lib().gsdf_hip_blockcache_eval3(self._h, pos.ctypes.data, 12, pos.shape[0], dist.ctypes.data, dist.shape[0]))
+        return dist
+
+    def CacheHits(self):
+        return int(lib().gsdf_hip_blockcache_hits(self._h))
+
+    def Evaluations(self):
+        return int(lib().gsdf_hip_blockcache_evaluations(self._h))
+
+    def Bounds(self):
+        return self.sdf.Bounds()
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().gsdf_hip_blockcache_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 class OctreeHIP:

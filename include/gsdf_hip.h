@@ -87,6 +87,17 @@ int gsdf_hip_specialize_check(const gsdf_tree* tree, size_t* code_object_bytes);
  * inspection. code_out may be NULL to query the size. */
 int gsdf_hip_lower(const gsdf_tree* tree, uint32_t* code_out, uint32_t code_cap, uint32_t* code_words, uint32_t* lds_slots);
 
+/* gleval.BlockCachedSDF3 (gleval/gleval.go:110-218): host-side lossy cache in front of a 3-D program, keyed by the
+ * lattice cell int(mul*(p - bb.Min)), mul = 1/res per axis; misses go to the program in one batch. reset = Reset
+ * (also clears the statistics), hits = CacheHits, evaluations = Evaluations (cached ones included). */
+typedef struct gsdf_blockcache gsdf_blockcache;
+int gsdf_hip_blockcache_create(gsdf_program* sdf, float resx, float resy, float resz, gsdf_blockcache** out);
+int gsdf_hip_blockcache_reset(gsdf_blockcache* c, gsdf_program* sdf, float resx, float resy, float resz);
+int gsdf_hip_blockcache_eval3(gsdf_blockcache* c, const void* pos, size_t pos_stride_bytes, size_t n_pos, float* dist, size_t n_dist);
+uint64_t gsdf_hip_blockcache_hits(const gsdf_blockcache* c);
+uint64_t gsdf_hip_blockcache_evaluations(const gsdf_blockcache* c);
+void gsdf_hip_blockcache_destroy(gsdf_blockcache* c);
+
 /* Host-buffer evaluation (drop-in for SDF3Compute.Evaluate). pos_stride_bytes is the distance between
  * consecutive positions: 12 for []ms3.Vec, 16 for std140 vec3 / ms3.Quat-aligned data; 8 for []ms2.Vec.
  * n_pos/n_dist are the two slice lengths (mismatch and zero are reported like the reference does). */

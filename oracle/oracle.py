@@ -213,3 +213,51 @@ def lsq_mgs64(A, b):
     x = np.zeros(3, np.float32)
     lib().orc_lsq_mgs64(A.ctypes.data, b.ctypes.data, A.shape[0], x.ctypes.data)
     return x
+
+
+class OracleBlockCachedSDF3:
+    """gleval.BlockCachedSDF3 (gleval/gleval.go:110-218) restated over OracleSDF -- pure-Python loops, small cases only
+    (test infrastructure like the rest of oracle/)."""
+
+    def __init__(self, sdf, resX, resY, resZ):
+        self.m = {}
+        self.Reset(sdf, resX, resY, resZ)
+
+    def Reset(self, sdf, resX, resY, resZ):                      # :126-146
+        if resX <= 0 or resY <= 0 or resZ <= 0:
+            raise ValueError("invalid resolution for BlockCachedSDF3")
+        self.m.clear()
+        self.sdf = sdf
+        one = np.float32(1)
+        self.mul = np.array([one / np.float32(resX), one / np.float32(resY), one / np.float32(resZ)], np.float32)
+        self.hits = 0
+        self.evals = 0
+
+    def _key(self, p, bbmin):
+        tp = self.mul * (p - bbmin)                              # MulElem(mul, Sub(p, bb.Min)) in float32
+        return (int(tp[0]), int(tp[1]), int(tp[2]))              # Go int(float32): truncation toward zero
+
+    def Evaluate(self, pos):                                     # :154-211
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        if pos.shape[0] == 0:
+            raise ValueError("empty buffers")
+        bbmin = np.asarray(self.sdf.Bounds(), np.float32)[:3]
+        dist = np.empty(pos.shape[0], np.float32)
+        seek, idx = [], []
+        for i in range(pos.shape[0]):
+            k = self._key(pos[i], bbmin)
+            if k in self.m:
+                dist[i] = self.m[k]
+            else:
+                seek.append(pos[i])
+                idx.append(i)
+        if idx:
+            sp = np.array(seek, np.float32)
+            sd = self.sdf.Evaluate(sp)
+            for i in range(len(idx)):
+                self.m[self._key(sp[i], bbmin)] = sd[i]
+            for i, d in enumerate(sd):
+                dist[idx[i]] = d
+        self.evals += pos.shape[0]
+        self.hits += pos.shape[0] - len(idx)
+        return dist

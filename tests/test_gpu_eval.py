@@ -206,3 +206,38 @@ def test_sqrt_unit_range_exhaustive(gpu):
     bad = C.c_uint64(1)
     assert gpu.lib().gsdf_hip_selftest_sqrt(C.byref(bad)) == 0
     assert bad.value == 0
+
+
+def test_block_cached_sdf3_like_reference(gpu):
+    """gleval.BlockCachedSDF3 (gleval.go:110-218) in front of the HIP evaluator: distances, CacheHits and Evaluations
+    equal the restated reference wrapper over the oracle, including the lossy-cache behaviour (a cell answers with the
+    distance of the LAST position evaluated in it) and Reset clearing the statistics."""
+    from oracle.oracle import OracleBlockCachedSDF3
+    b = Builder()
+    s = b.Scene("npt-flange")
+    sdf = gpu.SDF3HIP(s)
+    ref = OracleSDF(s.tree())
+    rx, ry, rz = 0.5, 0.75, 0.25
+    cg = gpu.BlockCachedSDF3HIP(sdf, rx, ry, rz)
+    co = OracleBlockCachedSDF3(ref, rx, ry, rz)
+    rng = np.random.default_rng(17)
+    bb = s.Bounds()
+    for rnd in range(4):
+        n = 3000
+        pos = (bb[:3] + rng.random((n, 3), np.float32) * (bb[3:] - bb[:3]) * np.float32(0.3)).astype(np.float32)
+        pos[::7] = pos[1::7][: pos[::7].shape[0]]           # exact repeats inside one batch: both are misses, both evaluated
+        if rnd == 2:
+            pos[:50] -= np.float32(5.0)                       # outside the bounds: negative cell indices (truncation toward zero)
+        dg, do = cg.Evaluate(pos), co.Evaluate(pos)
+        assert _mismatch(dg, do) == 0, rnd
+        assert cg.CacheHits() == co.hits and cg.Evaluations() == co.evals, rnd
+    assert cg.CacheHits() > 0
+    cg.Reset(sdf, 1.0, 1.0, 1.0)
+    assert cg.CacheHits() == 0 and cg.Evaluations() == 0
+    assert np.array_equal(cg.Bounds(), sdf.Bounds())
+    with pytest.raises(gpu.HipError) as e:
+        cg.Reset(sdf, 0.0, 1.0, 1.0)
+    assert e.value.msg == "invalid resolution for BlockCachedSDF3"
+    with pytest.raises(gpu.HipError) as e:
+        cg.Evaluate(np.zeros((0, 3), np.float32))
+    assert e.value.msg == "empty buffers"

@@ -222,3 +222,23 @@ def test_dualcontour_bolt_renders():
     b = Builder()
     m = OracleSDF(b.Scene("bolt").tree()).render_dualcontour(np.float32(0.5))
     assert m.n_tris > 0 and np.isfinite(m.tris).all()
+
+
+def test_block_cached_wrapper_semantics():
+    """gleval.BlockCachedSDF3 restatement (oracle.OracleBlockCachedSDF3): lossy per-cell cache, statistics, Reset."""
+    from gsdf_amd.builder import Builder
+    from oracle.oracle import OracleBlockCachedSDF3, OracleSDF
+    b = Builder()
+    sdf = OracleSDF(b.NewSphere(1.0).tree())
+    c = OracleBlockCachedSDF3(sdf, 0.5, 0.5, 0.5)
+    p = np.array([[0.1, 0.1, 0.1], [0.2, 0.2, 0.2], [0.9, 0.9, 0.9]], np.float32)   # first two share a cell
+    d1 = c.Evaluate(p)
+    assert np.array_equal(d1, sdf.Evaluate(p)) and c.hits == 0 and c.evals == 3      # same-batch duplicates are both misses
+    d2 = c.Evaluate(p[:1])
+    assert c.hits == 1 and c.evals == 4
+    assert d2[0] == d1[1]                                                            # the cell answers with the LAST distance stored
+    c.Reset(sdf, 1.0, 1.0, 1.0)
+    assert c.hits == 0 and c.evals == 0 and not c.m
+    import pytest
+    with pytest.raises(ValueError):
+        c.Reset(sdf, 0.0, 1.0, 1.0)
