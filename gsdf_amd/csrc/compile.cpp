@@ -177,7 +177,7 @@ void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int dept
     uint32_t ch = c.child(n, order[k]);
     gen(c, ch, depth + 1);
     dirty = dirty || clobbers(c, ch);
-    if (k > 0) { c.op(comb | ((asym && swapped) ? D_FLAG_SWAP : 0u), slotD); if (has_k) c.f(n.p[0]); }
+    if (k > 0) { c.op(comb | ((asym && swapped) ? D_FLAG_SWAP : 0u), slotD); if (has_k) { c.f(n.p[0]); c.f(recip_for(n.p[0])); } }
     if (k + 1 < n.nchild) c.op(D_SAVER, slotD);
   }
   c.release(1);
@@ -312,7 +312,7 @@ void gen(Ctx& c, uint32_t i, int depth) {
       int s = c.alloc(1);
       c.op(D_SCREW_PRE | c.hxy_flag() | c.shxy_flag(), s);
       c.bump();
-      c.f(P[0]); c.f(P[1]); c.f(P[2]); c.f(gsdf::tanf32(P[3])); c.f(P[0] / 2);
+      c.f(P[0]); c.f(P[1]); c.f(P[2]); c.f(gsdf::tanf32(P[3])); c.f(P[0] / 2); c.f(recip_for(P[0]));
       gen(c, c.child(n, 0), depth + 1);
       c.op(D_MAXR_SLOT, s);
       c.release(1);

@@ -55,6 +55,27 @@ DM_INL float div_by_uniform(float n, float d, float r) {
   q = __builtin_fmaf(e, r, q);
   return q;
 }
+// K numerators of one lane by a wave-uniform divisor: the exact reciprocal form when the host supplied RN(1/d)
+// (r != 0) and every numerator of the wave is in the proven range, else the IEEE expansion for the whole wave
+// (wave-uniform branch; identical bits either way).
+template <int K>
+DM_INL void div_uniform_k(const float (&n)[K], float d, float r, float (&q)[K]) {
+  bool fast = r != 0.0f;
+  if (fast) {
+    float nmin = 1.0f, nmax = 1.0f;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      q[k] = div_by_uniform(n[k], d, r);
+      nmin = minf(nmin, absf(n[k]));
+      nmax = maxf(nmax, absf(n[k]));
+    }
+    fast = __all(nmin >= 8.0779357e-28f /* 2^-90 */ && nmax <= 1.2379400e+27f /* 2^90 */) != 0;
+  }
+  if (!fast) {
+#pragma unroll
+    for (int k = 0; k < K; k++) q[k] = n[k] / d;
+  }
+}
 DM_INL bool div_fast_ok(float n) {
   const float a = absf(n);
   return a >= 8.0779357e-28f /* 2^-90 */ && a <= 1.2379400e+27f /* 2^90 */;

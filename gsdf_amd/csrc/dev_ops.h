@@ -62,7 +62,7 @@ enum DevOp : uint32_t {
   D_ROT2D,         // x00 x01 x10 x11
   D_EXTRUDE_PRE,   // h/2            slot <- |z|-h/2
   D_REVOLVE_PRE,   // off
-  D_SCREW_PRE,     // pitch lead L tanTaper halfpitch   slot <- |z|-L
+  D_SCREW_PRE,     // pitch lead L tanTaper halfpitch RN(1/pitch)|0   slot <- |z|-L
   D_ELONGATE_PRE,  // hx hy hz       slot <- min(max3(q),0)
   D_ELONGATE2D_PRE,// hx hy          slot <- min(max2(q),0)
   D_ARRAY_PRE,     // i j k sx sy sz nx ny nz   P = f(saved P at slot..slot+2)
@@ -83,7 +83,7 @@ enum DevOp : uint32_t {
   D_SETR,          // value : R = value
   // ---- combine: a = lds[slot] (first operand), b = R  ->  R
   D_COMBINE_MIN, D_COMBINE_MAX, D_COMBINE_DIFF, D_COMBINE_XOR,
-  D_COMBINE_SUNION, D_COMBINE_SDIFF, D_COMBINE_SINTER,  // k
+  D_COMBINE_SUNION, D_COMBINE_SDIFF, D_COMBINE_SINTER,  // k RN(1/k)|0
   D_OP_COUNT
 };
 
@@ -94,9 +94,9 @@ static const uint8_t kDevOpParams[D_OP_COUNT] = {
     /*LINE2D*/ 6, /*ARC2D*/ 6, /*QUADBEZIER*/ 13, /*CIRCLE*/ 1, /*EQTRI*/ 2, /*RECT*/ 2, /*DIAMOND*/ 6, /*X2D*/ 2,
     /*HEX2D*/ 2, /*OCT2D*/ 2, /*ELLIPSE*/ 2, /*POLY*/ 3, /*LINES*/ 2,
     /*TRANSLATE*/ 3, /*SCALE_PRE*/ 1, /*SYMMETRY*/ 1, /*TRANSFORM*/ 12, /*TWIST*/ 1, /*ROT2D*/ 4,
-    /*EXTRUDE_PRE*/ 1, /*REVOLVE_PRE*/ 1, /*SCREW_PRE*/ 5, /*ELONGATE_PRE*/ 3, /*ELONGATE2D_PRE*/ 2,
+    /*EXTRUDE_PRE*/ 1, /*REVOLVE_PRE*/ 1, /*SCREW_PRE*/ 6, /*ELONGATE_PRE*/ 3, /*ELONGATE2D_PRE*/ 2,
     /*ARRAY_PRE*/ 9, /*ARRAY2D_PRE*/ 6, /*CIRC_PRE*/ 3, /*LOADP2_SUB*/ 2,
     /*MULR*/ 1, /*SHELL_POST*/ 1, /*ADDR*/ 1, /*ANNULUS*/ 1, /*EXTRUDE_POST*/ 0, /*MAXR_SLOT*/ 0, /*ADDR_SLOT*/ 0,
     /*SAVEP3*/ 0, /*LOADP3*/ 0, /*SAVEP2*/ 0, /*LOADP2*/ 0, /*SAVER*/ 0, /*SETSLOT*/ 1, /*SETR*/ 1,
-    /*MIN*/ 0, /*MAX*/ 0, /*DIFF*/ 0, /*XOR*/ 0, /*SUNION*/ 1, /*SDIFF*/ 1, /*SINTER*/ 1,
+    /*MIN*/ 0, /*MAX*/ 0, /*DIFF*/ 0, /*XOR*/ 0, /*SUNION*/ 2, /*SDIFF*/ 2, /*SINTER*/ 2,
 };

@@ -564,21 +564,25 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         if (sh_xy) { KLOOP if (kp & 1) th[kp] = th[kp ? kp - 1 : 0]; }
         else { KLOOP if (kp & 1) th[kp] = atan2f_(pv[kp].y, pv[kp].x); }
         ENSURE_HXY();
-        KLOOP {
-          [[maybe_unused]] P3& p = pv[kp];
-          [[maybe_unused]] float& R = Rv[kp];
-          const float pitch = PF(0), lead = PF(1), L = PF(2), tanTaper = PF(3), halfp = PF(4);
-          float y0 = hxy[kp];
-          y0 += p.z * tanTaper;
-          const float theta = th[kp];
-          float z = p.z + lead * theta / 6.2831853071795862f;
-          float x = z + halfp;
-          float t = x / pitch;
-          float x0 = pitch * (t - floorf_(t)) - halfp;
-          LDSF(slot) = absf(p.z) - L;
-          p.x = x0; p.y = y0;
+        {
+          // z' = z + lead*theta/2pi ; sawTooth(z', pitch): both divisors are wave-uniform -> exact reciprocal form
+          const float pitch = PF(0), lead = PF(1), L = PF(2), tanTaper = PF(3), halfp = PF(4), rpitch = PF(5);
+          const float twopi = 6.2831853071795862f, rtwopi = 0.15915493667125702f;  // RN(1/float32(2pi)) = 0x3e22f983
+          float n1[K], q1[K], xs[K], t[K];
+          KLOOP n1[kp] = lead * th[kp];
+          div_uniform_k<K>(n1, twopi, rtwopi, q1);
+          KLOOP xs[kp] = (pv[kp].z + q1[kp]) + halfp;
+          div_uniform_k<K>(xs, pitch, rpitch, t);
+          KLOOP {
+            [[maybe_unused]] P3& p = pv[kp];
+            float y0 = hxy[kp];
+            y0 += p.z * tanTaper;
+            float x0 = pitch * (t[kp] - floorf_(t[kp])) - halfp;
+            LDSF(slot) = absf(p.z) - L;
+            p.x = x0; p.y = y0;
+          }
         }
-        pc += 6;
+        pc += 7;
         break;
       }
       case D_ELONGATE_PRE: {
@@ -700,42 +704,66 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       case D_COMBINE_DIFF: { KLOOP { float& R = Rv[kp]; float a = LDSF(slot), b = R; if (swap_ab) { float t = a; a = b; b = t; } R = maxf(a, -b); } pc += 1; break; }
       case D_COMBINE_XOR: { KLOOP { float& R = Rv[kp]; float a = LDSF(slot), b = R; R = maxf(minf(a, b), -maxf(a, b)); } pc += 1; break; }
       case D_COMBINE_SUNION: {
-        KLOOP {
-          [[maybe_unused]] P3& p = pv[kp];
-          [[maybe_unused]] float& R = Rv[kp];
-          const float k = PF(0);
-          float a = LDSF(slot), b = R;
-          if (swap_ab) { float t = a; a = b; b = t; }
-          float h = clampf(0.5f + 0.5f * (b - a) / k, 0.f, 1.f);
-          R = mixf(b, a, h) - k * h * (1.f - h);
+        {
+          const float k = PF(0), rk = PF(1);  // (0.5*(b -+ a)) / k by a wave-uniform k: exact reciprocal form
+          float av[K], bv[K], num[K], q[K];
+          KLOOP {
+            float a = LDSF(slot), b = Rv[kp];
+            if (swap_ab) { float t = a; a = b; b = t; }
+            av[kp] = a; bv[kp] = b;
+            num[kp] = 0.5f * (b - a);
+          }
+          div_uniform_k<K>(num, k, rk, q);
+          KLOOP {
+            float& R = Rv[kp];
+            const float a = av[kp], b = bv[kp];
+            float h = clampf(0.5f + q[kp], 0.f, 1.f);
+            R = mixf(b, a, h) - k * h * (1.f - h);
+          }
         }
-        pc += 2;
+        pc += 3;
         break;
       }
       case D_COMBINE_SDIFF: {
-        KLOOP {
-          [[maybe_unused]] P3& p = pv[kp];
-          [[maybe_unused]] float& R = Rv[kp];
-          const float k = PF(0);
-          float a = LDSF(slot), b = R;
-          if (swap_ab) { float t = a; a = b; b = t; }
-          float h = clampf(0.5f - 0.5f * (b + a) / k, 0.f, 1.f);
-          R = mixf(a, -b, h) + k * h * (1.f - h);
+        {
+          const float k = PF(0), rk = PF(1);  // (0.5*(b -+ a)) / k by a wave-uniform k: exact reciprocal form
+          float av[K], bv[K], num[K], q[K];
+          KLOOP {
+            float a = LDSF(slot), b = Rv[kp];
+            if (swap_ab) { float t = a; a = b; b = t; }
+            av[kp] = a; bv[kp] = b;
+            num[kp] = 0.5f * (b + a);
+          }
+          div_uniform_k<K>(num, k, rk, q);
+          KLOOP {
+            float& R = Rv[kp];
+            const float a = av[kp], b = bv[kp];
+            float h = clampf(0.5f - q[kp], 0.f, 1.f);
+            R = mixf(a, -b, h) + k * h * (1.f - h);
+          }
         }
-        pc += 2;
+        pc += 3;
         break;
       }
       case D_COMBINE_SINTER: {
-        KLOOP {
-          [[maybe_unused]] P3& p = pv[kp];
-          [[maybe_unused]] float& R = Rv[kp];
-          const float k = PF(0);
-          float a = LDSF(slot), b = R;
-          if (swap_ab) { float t = a; a = b; b = t; }
-          float h = clampf(0.5f - 0.5f * (b - a) / k, 0.f, 1.f);
-          R = mixf(b, a, h) + k * h * (1.f - h);
+        {
+          const float k = PF(0), rk = PF(1);  // (0.5*(b -+ a)) / k by a wave-uniform k: exact reciprocal form
+          float av[K], bv[K], num[K], q[K];
+          KLOOP {
+            float a = LDSF(slot), b = Rv[kp];
+            if (swap_ab) { float t = a; a = b; b = t; }
+            av[kp] = a; bv[kp] = b;
+            num[kp] = 0.5f * (b - a);
+          }
+          div_uniform_k<K>(num, k, rk, q);
+          KLOOP {
+            float& R = Rv[kp];
+            const float a = av[kp], b = bv[kp];
+            float h = clampf(0.5f - q[kp], 0.f, 1.f);
+            R = mixf(b, a, h) + k * h * (1.f - h);
+          }
         }
-        pc += 2;
+        pc += 3;
         break;
       }
       default:

@@ -154,7 +154,12 @@ def test_exact_division_by_uniform_divisor_exhaustive(gpu):
                 v = np.array([t.aux[nd.aux_off + k] for k in range(nd.aux_len)], np.float32).reshape(-1, 2)
                 e = np.roll(v, 1, axis=0) - v
                 divisors.update(np.float32(e[:, 0] * e[:, 0] + e[:, 1] * e[:, 1]).tolist())
+            if nd.op == OP["SCREW"]:
+                divisors.add(float(nd.p[0]))                      # sawTooth: x / pitch
+            if nd.op in (OP["SMOOTH_UNION"], OP["SMOOTH_DIFF"], OP["SMOOTH_INTERSECT"]):
+                divisors.add(float(nd.p[0]))                      # (0.5*(b -+ a)) / k
     divisors.update([1.0, 3.0, 0.1, 7.0, 1.9999999, 1.0000001, 6.2831855, 1e-9, 1e9, float(np.float32(2.0) ** -30)])
+    divisors.add(float(np.float32(6.2831853071795862)))          # screw: lead*theta / 2pi
     assert len(divisors) > 20
     checked = 0
     for d in sorted(divisors):
