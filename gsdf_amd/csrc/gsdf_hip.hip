@@ -598,12 +598,14 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
       if (bound > capq[(level + 1) & 1] * 8) bound = capq[(level + 1) & 1] * 8;
       if (p->f_prune) {
         HIP_TRYM(launch_fn(p->f_prune, grid_for(bound, p->num_cu, 4), BLOCK, lds_prune, s, (const uint32_t*)p->d_code,
-                           (const Cube*)q[(level + 1) & 1]->p, (int)expand, (int)level, (int)p->prog.nslots, ox, oy, oz, res, (int)do_test,
+                           (const Cube*)q[(level + 1) & 1]->p, (unsigned long long)capq[(level + 1) & 1], (int)expand, (int)level,
+                           (int)p->prog.nslots, ox, oy, oz, res, (int)do_test,
                            (Cube*)q[level & 1]->p, (unsigned long long)capq[level & 1], (int)((opts.shard_count > 1 && level == ls) ? 1 : 0),
                            (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr));
       } else
       hipLaunchKernelGGL(prune_kernel, dim3(grid_for(bound, p->num_cu, 4)), dim3(BLOCK), lds_prune, s, p->d_code,
-                         (const Cube*)q[(level + 1) & 1]->p, expand, level, p->prog.nslots, ox, oy, oz, res, do_test, (Cube*)q[level & 1]->p,
+                         (const Cube*)q[(level + 1) & 1]->p, (unsigned long long)capq[(level + 1) & 1], expand, level, p->prog.nslots, ox, oy,
+                         oz, res, do_test, (Cube*)q[level & 1]->p,
                          (unsigned long long)capq[level & 1], (opts.shard_count > 1 && level == ls) ? 1 : 0,
                          (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr);
       HIP_TRYM(hipGetLastError());

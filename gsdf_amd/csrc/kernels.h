@@ -120,7 +120,8 @@ __host__ __device__ __forceinline__ unsigned brick_owner(unsigned x, unsigned y,
 // LDS: [nslots floats per lane | PRUNE_STAGE cubes | 4 wave totals | base].
 #define PRUNE_STAGE 1024
 __global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ in,
-                                                      int expand, int level, int nslots, float ox, float oy, float oz, float res,
+                                                      unsigned long long in_cap, int expand, int level, int nslots, float ox,
+                                                      float oy, float oz, float res,
                                                       int do_test, Cube* __restrict__ out, unsigned long long out_cap,
                                                       int shard_here, unsigned shard_rank, unsigned shard_count,
                                                       MeshCounters* __restrict__ ctr) {
@@ -129,7 +130,11 @@ __global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict
   Cube* s_q = (Cube*)(g_smem + (size_t)(nslots > 0 ? nslots : 1) * BLOCK);
   unsigned* s_w = (unsigned*)(s_q + PRUNE_STAGE);  // [0..3] wave totals, [4..7] per-wave "passed the test" counts
   unsigned long long* s_base = (unsigned long long*)(s_w + 8);
-  const unsigned long long n_items = expand ? uniform_u64(ctr->n_level[level + 1]) * 8ull : 1ull;
+  // the previous level counts every survivor, also those its queue had no room for (the host then grows the queues
+  // and reruns): never read past what was stored
+  unsigned long long n_in = expand ? uniform_u64(ctr->n_level[level + 1]) : 0ull;
+  if (n_in > in_cap) n_in = in_cap;
+  const unsigned long long n_items = expand ? n_in * 8ull : 1ull;
   if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_items[level] = do_test ? n_items : 0ull;
   const float size = (float)(1 << (level - 1)) * res;  // i3.Cube size at this level
   const float maxDist = size * (1.73205080757f / 2);    // szDistMult = sqrt3/2 (octreerenderer.go:182)
