@@ -170,7 +170,9 @@ void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int dept
       c.mark_saved(slotP, is2d);
     }
   }
-  int slotD = c.alloc(1);
+  // The partial result gets its slot only when the first child is done: while that child (in left-deep trees, the
+  // whole rest of the tree) runs, this frame holds no distance slot.
+  int slotD = -1;
   bool dirty = false;
   for (uint32_t k = 0; k < n.nchild; k++) {
     if (k > 0 && dirty) { c.load_saved(slotP, is2d); dirty = false; }
@@ -178,9 +180,12 @@ void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int dept
     gen(c, ch, depth + 1);
     dirty = dirty || clobbers(c, ch);
     if (k > 0) { c.op(comb | ((asym && swapped) ? D_FLAG_SWAP : 0u), slotD); if (has_k) { c.f(n.p[0]); c.f(recip_for(n.p[0])); } }
-    if (k + 1 < n.nchild) c.op(D_SAVER, slotD);
+    if (k + 1 < n.nchild) {
+      if (slotD < 0) slotD = c.alloc(1);
+      c.op(D_SAVER, slotD);
+    }
   }
-  c.release(1);
+  if (slotD >= 0) c.release(1);
   if (own_save) { c.live.pop_back(); c.release(is2d ? 2 : 3); }
 }
 

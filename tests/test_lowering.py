@@ -56,7 +56,7 @@ def test_npt_flange_program():
     # hypot(x,y) is computed once and reused by the other two cylinders and the screw (z-only translate keeps it)
     users = [i for i in ins if i[0] in ("D_CYL0", "D_CYLR", "D_SCREW_PRE")]
     assert [u[1] for u in users].count(False) == 1 and [u[1] for u in users].count(True) == 3
-    assert slots == 7
+    assert slots == 6   # 1 root distance + 3 saved position + 2 nested partial results
     # polygon edge records start on a 32-byte boundary
     poly = [i for i in ins if i[0] == "D_POLY2D"][0]
     assert ((poly[4] + 4 + 7) & ~7) % 8 == 0
@@ -64,9 +64,9 @@ def test_npt_flange_program():
 
 def test_saved_positions_are_not_duplicated():
     """A frame that needs the position an enclosing frame already saved reuses that slot: the deep example
-    trees keep one copy of the root position (bolt 13 -> 7 slots, knurled-cylinder 18 -> 12: 4 points per lane)."""
+    trees keep one copy of the root position (bolt 13 -> 6 slots, knurled-cylinder 18 -> 10: 4 points per lane)."""
     b = Builder()
-    for scene, max_slots, saves in (("bolt", 7, 1), ("knurled-cylinder", 12, 3)):
+    for scene, max_slots, saves in (("bolt", 6, 1), ("knurled-cylinder", 10, 3)):
         code, slots = hip.lower(b.Scene(scene))
         ins = decode(code)
         assert slots <= max_slots, (scene, slots)
