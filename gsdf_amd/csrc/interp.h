@@ -84,13 +84,33 @@ __device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t n
   return __all(nmin >= 8.0779357e-28f /* 2^-90 */ && nmax <= 1.2379400e+27f /* 2^90 */);
 }
 
-// hypot(P.x,P.y) of every point into hxy[] unless the cache is valid; odd points copy their pair's value when shared
-#define ENSURE_HXY()                                                                   \
-  if (!use_hxy) {                                                                      \
-    KLOOP if (!(kp & 1)) hxy[kp] = hypotf_(pv[kp].x, pv[kp].y);                         \
-    if (sh_xy) { KLOOP if (kp & 1) hxy[kp] = hxy[kp ? kp - 1 : 0]; }                    \
-    else { KLOOP if (kp & 1) hxy[kp] = hypotf_(pv[kp].x, pv[kp].y); }                   \
+// f(P.x, P.y) of the K points of a lane for the instructions flagged D_FLAG_SHXY (hypot, atan2).
+//   not shared : every point on its own;
+//   paired     : points 2j / 2j+1 entered with equal x,y -> even points compute, odd points copy;
+//   brick      : (K = 4, one wave = the 4x4x4 leaves of one level-3 cube, lane = x + 4y + 16z) the four lanes of an
+//                x,y column hold the same two x,y pairs, so lanes with even z evaluate pair 0, lanes with odd z pair 1
+//                -- ONE evaluation per lane instead of two -- and every lane fetches both results from the z = 0 / z = 1
+//                lanes of its column (ds_bpermute). Same inputs, same operations, same bits.
+template <int K, typename F>
+__device__ __forceinline__ void xy_shared(const P3 (&pv)[K], float (&out)[K], bool shared, bool brick, F f) {
+  if (K == 4 && shared && brick) {
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const bool odd = ((lane >> 4) & 1u) != 0u;
+    const float sx = odd ? pv[K > 2 ? 2 : 0].x : pv[0].x, sy = odd ? pv[K > 2 ? 2 : 0].y : pv[0].y;
+    const float v = f(sx, sy);
+    const float v0 = __shfl(v, (int)(lane & 15u), 64), v1 = __shfl(v, (int)((lane & 15u) + 16u), 64);
+    out[0] = v0; out[K > 1 ? 1 : 0] = v0;
+    out[K > 2 ? 2 : 0] = v1; out[K > 3 ? 3 : 0] = v1;
+    return;
   }
+  KLOOP if (!(kp & 1)) out[kp] = f(pv[kp].x, pv[kp].y);
+  if (shared) { KLOOP if (kp & 1) out[kp] = out[kp ? kp - 1 : 0]; }
+  else { KLOOP if (kp & 1) out[kp] = f(pv[kp].x, pv[kp].y); }
+}
+
+// hypot(P.x,P.y) of every point into hxy[] unless the cache is valid
+#define ENSURE_HXY() \
+  if (!use_hxy) xy_shared<K>(pv, hxy, sh_xy, brick, [](float x, float y) { return dm::hypotf_(x, y); })
 
 // PAIRED (the mesher's leaf kernels only): the caller passes the corners of one leaf cube in the order
 // {0,4,1,5 | 3,7,2,6}, i.e. points 2j and 2j+1 enter with bitwise equal x,y and (K = 4) points j and j+2 with equal z.
@@ -99,7 +119,8 @@ __device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t n
 #ifndef GSDF_SPECIALIZED
 template <int K, bool PAIRED = false>
 __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)[K],
-                                         float* __restrict__ lds /* already offset by tid */, const uint32_t nthreads) {
+                                         float* __restrict__ lds /* already offset by tid */, const uint32_t nthreads,
+                                         const bool brick = false /* wave-uniform; see xy_shared */) {
   using namespace dm;
   KLOOP Rv[kp] = 0.0f;
   float hxy[K];  // hypot(P.x, P.y) cache shared by sibling primitives (validity is tracked by the host compiler)
@@ -560,9 +581,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_SCREW_PRE: {
         float th[K];  // atan2(P.y, P.x): a function of x,y only
-        KLOOP if (!(kp & 1)) th[kp] = atan2f_(pv[kp].y, pv[kp].x);
-        if (sh_xy) { KLOOP if (kp & 1) th[kp] = th[kp ? kp - 1 : 0]; }
-        else { KLOOP if (kp & 1) th[kp] = atan2f_(pv[kp].y, pv[kp].x); }
+        xy_shared<K>(pv, th, sh_xy, brick, [](float x, float y) { return dm::atan2f_(y, x); });
         ENSURE_HXY();
         {
           // z' = z + lead*theta/2pi ; sawTooth(z', pitch): both divisors are wave-uniform -> exact reciprocal form
@@ -639,10 +658,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       case D_CIRC_PRE: {
-        float th[K];
-        KLOOP if (!(kp & 1)) th[kp] = atan2f_(pv[kp].y, pv[kp].x);
-        if (sh_xy) { KLOOP if (kp & 1) th[kp] = th[kp ? kp - 1 : 0]; }
-        else { KLOOP if (kp & 1) th[kp] = atan2f_(pv[kp].y, pv[kp].x); }
+        float th[K];  // atan2(P.y, P.x): a function of x,y only
+        xy_shared<K>(pv, th, sh_xy, brick, [](float x, float y) { return dm::atan2f_(y, x); });
         KLOOP {
           [[maybe_unused]] P3& p = pv[kp];
           [[maybe_unused]] float& R = Rv[kp];

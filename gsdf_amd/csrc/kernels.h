@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
         pk[kp].y = ((c >> 1) & 1u) ? y1 : y0;
         pk[kp].z = ((c >> 2) & 1u) ? z1 : z0;
       }
-      gsdf_dev::sdf_eval<K, true>(code, pk, dk, lds, BLOCK);
+      gsdf_dev::sdf_eval<K, true>(code, pk, dk, lds, BLOCK, /*brick=*/sh == 2);  // lq == 3: one wave = one 4x4x4 brick
 #pragma unroll
       for (int j = 0; j < 8 - K; j++) dall[j] = dall[j + K];  // static shift register: no dynamic register index
 #pragma unroll
