@@ -94,3 +94,23 @@ def random_shapes(seed, count, depth=3):
         except ShapeError:
             continue
     return b, out
+
+
+def random_shapes2d(seed, count, depth=3):
+    """`count` random 2-D shapes the builder accepts."""
+    r = np.random.default_rng(seed)
+    b = Builder()
+    out = []
+    tries = 0
+    while len(out) < count and tries < 20 * count:
+        tries += 1
+        try:
+            sh = _shape2(b, r, depth)
+            bb = np.asarray(sh.Bounds(), np.float32)      # 2-D bounds come as (minx, miny, 0, maxx, maxy, 0)
+            ext = bb[[3, 4]] - bb[[0, 1]]
+            if not np.isfinite(bb).all() or ext.max() > 50 or ext.min() <= 0:
+                continue
+            out.append(sh)
+        except ShapeError:
+            continue
+    return b, out

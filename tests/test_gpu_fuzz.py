@@ -51,3 +51,45 @@ def test_random_trees_distances_and_meshes(gpu, seed):
             assert (_sorted(oc.RenderAll()).view(np.uint32) == _sorted(m.tris).view(np.uint32)).all(), (seed, k)
             meshed += 1
     assert meshed >= 8
+
+
+def test_random_2d_trees(gpu):
+    _, shapes = fuzz_trees.random_shapes2d(7, 24, depth=3)
+    assert len(shapes) == 24
+    rng = np.random.default_rng(70)
+    for k, sh in enumerate(shapes):
+        bb = np.asarray(sh.Bounds(), np.float32)
+        lo, hi = bb[[0, 1]], bb[[3, 4]]
+        c, h = (lo + hi) / 2, (hi - lo) / 2 * np.float32(1.2)
+        pos = (c + (rng.random((5000, 2), np.float32) * 2 - 1) * h).astype(np.float32)
+        pos = np.concatenate([pos, np.float32(0.125) * rng.integers(-12, 13, (1000, 2)).astype(np.float32)])
+        dref = OracleSDF(sh.tree()).Evaluate(pos)
+        sdf = gpu.SDF2HIP(sh)
+        assert _mismatch(sdf.Evaluate(pos), dref) == 0, (k, "interpreter")
+        if k % 4 == 0:
+            assert _mismatch(sdf.specialize().Evaluate(pos), dref) == 0, (k, "specialised")
+
+
+def test_random_trees_dual_contouring_and_normals(gpu):
+    """Dual contouring (all five stages incl. the fp64 QR) and central-difference normals of random trees."""
+    _, shapes = fuzz_trees.random_shapes(11, 8, depth=3)
+    rng = np.random.default_rng(110)
+    done = 0
+    for k, sh in enumerate(shapes):
+        ref = OracleSDF(sh.tree())
+        sdf = gpu.SDF3HIP(sh)
+        if k % 2 == 0:
+            sdf.specialize()
+        res = np.float32(float(sh.Diagonal()) / 40)
+        try:
+            m = ref.render_dualcontour(res, False)
+        except Exception:
+            continue                                  # lattice too large / degenerate for the oracle's renderer
+        a = gpu.DualContourHIP(sdf, res).RenderAll()
+        assert a.shape[0] == m.n_tris, (k, a.shape[0], m.n_tris)
+        if m.n_tris:
+            assert (_sorted(a).view(np.uint32) == _sorted(m.tris).view(np.uint32)).all(), k
+            done += 1
+        pos = _points(sh, rng, 2000)
+        assert _mismatch(sdf.normals(pos, 1e-3), ref.normals_central_diff(pos, 1e-3)) == 0, k
+    assert done >= 4
