@@ -146,6 +146,61 @@ bool clobbers(Ctx& c, uint32_t i) {
 
 void gen(Ctx& c, uint32_t i, int depth);
 
+// Bounding box (min xyz, max xyz; z ignored for 2-D nodes) of a subtree whose field is at least the Euclidean distance
+// to that box: exact-distance primitives under translation, union, and as the first operand of a difference or an
+// intersection (max(a, .) >= a). Everything else -- smoothing, scaling, domain repetition, approximate primitives --
+// answers false: no claim, the child is always evaluated.
+bool exact_box(Ctx& c, uint32_t i, float bb[6], int depth = 0) {
+  if (depth > 64) return false;
+  const gsdf_node& n = c.node(i);
+  const float* P = n.p;
+  auto set = [&](float x0, float y0, float z0, float x1, float y1, float z1) {
+    bb[0] = x0; bb[1] = y0; bb[2] = z0; bb[3] = x1; bb[4] = y1; bb[5] = z1;
+    return true;
+  };
+  switch (n.op) {
+    case GSDF_SPHERE: return set(-P[0], -P[0], -P[0], P[0], P[0], P[0]);
+    case GSDF_BOX: return set(-0.5f * P[0], -0.5f * P[1], -0.5f * P[2], 0.5f * P[0], 0.5f * P[1], 0.5f * P[2]);
+    case GSDF_CYLINDER: return set(-P[0], -P[0], -0.5f * P[1], P[0], P[0], 0.5f * P[1]);
+    case GSDF_CIRCLE2D: return set(-P[0], -P[0], 0, P[0], P[0], 0);
+    case GSDF_RECT2D: return set(-0.5f * P[0], -0.5f * P[1], 0, 0.5f * P[0], 0.5f * P[1], 0);
+    case GSDF_POLY2D: {
+      const uint32_t nv = n.aux_len / 2;
+      if (nv < 3) return false;
+      const float* v = &c.t->aux[n.aux_off];
+      float x0 = v[0], y0 = v[1], x1 = v[0], y1 = v[1];
+      for (uint32_t k = 1; k < nv; k++) {
+        x0 = std::fmin(x0, v[2 * k]); x1 = std::fmax(x1, v[2 * k]);
+        y0 = std::fmin(y0, v[2 * k + 1]); y1 = std::fmax(y1, v[2 * k + 1]);
+      }
+      return set(x0, y0, 0, x1, y1, 0);
+    }
+    case GSDF_TRANSLATE: case GSDF_TRANSLATE2D: {
+      if (n.nchild != 1 || !exact_box(c, c.child(n, 0), bb, depth + 1)) return false;
+      const float tz = n.op == GSDF_TRANSLATE ? P[2] : 0.f;
+      bb[0] += P[0]; bb[3] += P[0]; bb[1] += P[1]; bb[4] += P[1]; bb[2] += tz; bb[5] += tz;
+      return true;
+    }
+    case GSDF_UNION: case GSDF_UNION2D: {
+      float a[6];
+      for (uint32_t k = 0; k < n.nchild; k++) {
+        if (!exact_box(c, c.child(n, k), a, depth + 1)) return false;
+        if (k == 0) std::memcpy(bb, a, sizeof a);
+        else for (int j = 0; j < 3; j++) { bb[j] = std::fmin(bb[j], a[j]); bb[j + 3] = std::fmax(bb[j + 3], a[j + 3]); }
+      }
+      return n.nchild > 0;
+    }
+    case GSDF_DIFF: case GSDF_DIFF2D: case GSDF_INTERSECT: case GSDF_INTERSECT2D:
+      return n.nchild == 2 && exact_box(c, c.child(n, 0), bb, depth + 1);
+    case GSDF_EXTRUSION: {  // exact for an exact 2-D child: min(0,max(d,|z|-h/2)) + |max((d,|z|-h/2),0)|
+      if (n.nchild != 1 || !exact_box(c, c.child(n, 0), bb, depth + 1)) return false;
+      bb[2] = -0.5f * P[0]; bb[5] = 0.5f * P[0];
+      return true;
+    }
+    default: return false;
+  }
+}
+
 // n-ary / binary combine frame (cpu_evaluators.go:124-286, 821-912). Children that do not rewrite the
 // position are evaluated first (min/max are order-independent; for the asymmetric binary ops the
 // combine gets D_FLAG_SWAP), so the position only has to be saved when two or more children rewrite it.
@@ -177,9 +232,20 @@ void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int dept
   for (uint32_t k = 0; k < n.nchild; k++) {
     if (k > 0 && dirty) { c.load_saved(slotP, is2d); dirty = false; }
     uint32_t ch = c.child(n, order[k]);
+    // wide union: a child that provably cannot lower the running minimum for any point of the wave is skipped
+    long skip_at = -1;
+    float cb[6];
+    if (comb == D_COMBINE_MIN && n.nchild >= 4 && k > 0 && exact_box(c, ch, cb)) {
+      c.op(is2d ? D_SKIPFAR2D : D_SKIPFAR3D, slotD);
+      if (is2d) { c.f(cb[0]); c.f(cb[1]); c.f(cb[3]); c.f(cb[4]); }
+      else { for (int j = 0; j < 6; j++) c.f(cb[j]); }
+      skip_at = (long)c.code.size();
+      c.u(0);  // patched below: words from this instruction to the one after the child's D_COMBINE_MIN
+    }
     gen(c, ch, depth + 1);
     dirty = dirty || clobbers(c, ch);
     if (k > 0) { c.op(comb | ((asym && swapped) ? D_FLAG_SWAP : 0u), slotD); if (has_k) { c.f(n.p[0]); c.f(recip_for(n.p[0])); } }
+    if (skip_at >= 0) c.code[(size_t)skip_at] = (uint32_t)(c.code.size() - ((size_t)skip_at - (is2d ? 5 : 7)));
     if (k + 1 < n.nchild) {
       if (slotD < 0) slotD = c.alloc(1);
       c.op(D_SAVER, slotD);
@@ -482,6 +548,7 @@ Program compile(const gsdf_tree& t, size_t max_code_words) {
   p.code = std::move(c.code);
   p.nslots = c.max_slots;
   p.is2d = gsdf_op_is2d(t.nodes[t.root].op);
+  p.has_exact_bb = exact_box(c, t.root, p.exact_bb);
   std::memcpy(p.bb, t.bb, sizeof(p.bb));
   return p;
 }

@@ -13,6 +13,11 @@ struct Program {
   int nslots = 0;              // LDS scratch slots per lane
   bool is2d = false;           // root takes 2D positions
   float bb[6] = {0};
+  // Set when the whole field is known to be >= the Euclidean distance to `exact_bb` (exact-distance primitives under
+  // translation / union / difference, see compile.cpp: exact_box): lets a renderer decide "farther than r from the
+  // surface" for lattice points outside that box by more than r without evaluating them.
+  bool has_exact_bb = false;
+  float exact_bb[6] = {0};
 };
 
 // RN(1/d) for the device's exact division by a wave-uniform divisor, 0 if d is not eligible.

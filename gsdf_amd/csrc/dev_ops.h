@@ -8,6 +8,7 @@
 // Slots are allocated statically by the host compiler, so there is no stack pointer at run time.
 //
 // Encoding: word0 = opcode (bits 0-11) | flags (bits 12-15) | slot<<16 ; then `nparam` 32-bit words.
+// The stream is straight-line except for D_SKIPFAR*, a forward wave-uniform skip.
 //   D_FLAG_HXY  (bit 14): hypot(P.x,P.y) of every point is already in the per-point `hxy` register (the host
 //                compiler proved P.xy unchanged since it was last computed): reuse instead of recomputing.
 //   D_FLAG_SHXY (bit 13): P.x and P.y are functions of the ENTRY x,y only (no z has been mixed in), and
@@ -84,6 +85,13 @@ enum DevOp : uint32_t {
   // ---- combine: a = lds[slot] (first operand), b = R  ->  R
   D_COMBINE_MIN, D_COMBINE_MAX, D_COMBINE_DIFF, D_COMBINE_XOR,
   D_COMBINE_SUNION, D_COMBINE_SDIFF, D_COMBINE_SINTER,  // k RN(1/k)|0
+  // ---- wide unions: skip a child that cannot lower the running minimum. a = lds[slot] is the minimum so far, the
+  //      child's field is >= its Euclidean distance to the child's bounding box (exact-distance subtrees only, see
+  //      compile.cpp: exact_box). If EVERY point of the wave lies outside the box by more than a (plus a 1e-3 relative
+  //      margin, a thousand times the rounding of either side), min(a, child) == a for all of them: R = a and the
+  //      program counter advances by `skip` words past the child and its D_COMBINE_MIN. Wave-uniform branch.
+  D_SKIPFAR2D,  // minx miny maxx maxy skip
+  D_SKIPFAR3D,  // minx miny minz maxx maxy maxz skip
   D_OP_COUNT
 };
 
@@ -99,4 +107,5 @@ static const uint8_t kDevOpParams[D_OP_COUNT] = {
     /*MULR*/ 1, /*SHELL_POST*/ 1, /*ADDR*/ 1, /*ANNULUS*/ 1, /*EXTRUDE_POST*/ 0, /*MAXR_SLOT*/ 0, /*ADDR_SLOT*/ 0,
     /*SAVEP3*/ 0, /*LOADP3*/ 0, /*SAVEP2*/ 0, /*LOADP2*/ 0, /*SAVER*/ 0, /*SETSLOT*/ 1, /*SETR*/ 1,
     /*MIN*/ 0, /*MAX*/ 0, /*DIFF*/ 0, /*XOR*/ 0, /*SUNION*/ 2, /*SDIFF*/ 2, /*SINTER*/ 2,
+    /*SKIPFAR2D*/ 5, /*SKIPFAR3D*/ 7,
 };

@@ -789,9 +789,11 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     if (shard_count > 1) HIP_TRYM(hipMemsetAsync(grid.p, 0xff, ncell * sizeof(int), s));  // cells outside the slab read as empty
     HIP_TRYM(hipEventRecord(p->ev[0], s));
     const unsigned g1 = grid_for((nslab + lk - 1) / lk, p->num_cu, 8);
-#define LAUNCH_O(KK) hipLaunchKernelGGL((dc_origin_kernel<KK>), dim3(g1), dim3(BLOCK), p->lds_bytes(KK) + 32, s, p->d_code, p->prog.nslots, nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, zlo, zhi, d_ctr)
+#define LAUNCH_O(KK) hipLaunchKernelGGL((dc_origin_kernel<KK>), dim3(g1), dim3(BLOCK), p->lds_bytes(KK) + 32, s, p->d_code, p->prog.nslots, nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, zlo, zhi, ub, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], d_ctr)
     spec_aux(p);
-    if (p->f_dc_origin) HIP_TRYM(launch_fn(p->f_dc_origin, g1, BLOCK, p->lds_bytes(lk) + 32, s, (const uint32_t*)p->d_code, (int)p->prog.nslots, (int)nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, (unsigned)zlo, (unsigned)zhi, d_ctr));
+    const int ub = p->prog.has_exact_bb ? 1 : 0;
+    const float* eb = p->prog.exact_bb;
+    if (p->f_dc_origin) HIP_TRYM(launch_fn(p->f_dc_origin, g1, BLOCK, p->lds_bytes(lk) + 32, s, (const uint32_t*)p->d_code, (int)p->prog.nslots, (int)nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, (unsigned)zlo, (unsigned)zhi, ub, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], d_ctr));
     else
     if (lk == 4) LAUNCH_O(4); else if (lk == 2) LAUNCH_O(2); else LAUNCH_O(1);
 #undef LAUNCH_O
@@ -832,8 +834,8 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
   HIP_TRYM(hipEventElapsedTime(&ms, p->ev[0], p->ev[1]));
   p->last_dc_cubes = hc.n_cubes;
   m->st.n_tris = 2 * hc.n_tris;  // quads -> 2 triangles
-  m->st.evals = nslab + 4 * hc.n_cubes + 6 * hc.n_edges;
-  m->st.evals_prune = nslab;
+  m->st.evals = hc.n_origin_evals + 4 * hc.n_cubes + 6 * hc.n_edges;
+  m->st.evals_prune = hc.n_origin_evals;  // of the nslab lattice cells; the rest lay outside the exact box by > 2 res
   m->st.evals_leaf = 4 * hc.n_cubes + 6 * hc.n_edges;
   m->st.pruned_leaves = nslab - hc.n_cubes;
   m->st.leaf_cubes = hc.n_cubes;

@@ -112,6 +112,23 @@ __device__ __forceinline__ void xy_shared(const P3 (&pv)[K], float (&out)[K], bo
 #define ENSURE_HXY() \
   if (!use_hxy) xy_shared<K>(pv, hxy, sh_xy, brick, [](float x, float y) { return dm::hypotf_(x, y); })
 
+// D_SKIPFAR*: true (wave-uniform) if every point of the wave is outside the box [mn, mx] by more than the running
+// minimum `a` of the union, with margin: then no point's min(a, child) can differ from a (the child's field is at least
+// the distance to its box; the Chebyshev distance used here is a lower bound of the Euclidean one). Inside the box
+// (L <= 0) there is no bound: never skip.
+template <int K, int DIM>
+__device__ __forceinline__ bool all_far(const P3 (&pv)[K], const float (&a)[K], float mnx, float mny, float mnz, float mxx, float mxy,
+                                        float mxz) {
+  using namespace dm;
+  bool far = true;
+  KLOOP {
+    float L = maxf(maxf(mnx - pv[kp].x, pv[kp].x - mxx), maxf(mny - pv[kp].y, pv[kp].y - mxy));
+    if (DIM == 3) L = maxf(L, maxf(mnz - pv[kp].z, pv[kp].z - mxz));
+    far = far && (L > 0.0f) && (L > a[kp] + 1e-3f * (L + absf(a[kp])));
+  }
+  return __all(far) != 0;
+}
+
 // PAIRED (the mesher's leaf kernels only): the caller passes the corners of one leaf cube in the order
 // {0,4,1,5 | 3,7,2,6}, i.e. points 2j and 2j+1 enter with bitwise equal x,y and (K = 4) points j and j+2 with equal z.
 // Instructions the host compiler flagged D_FLAG_SHXY / D_FLAG_SHZ then compute their f(P.x,P.y) / g(P.z) once per
@@ -781,6 +798,28 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
           }
         }
         pc += 3;
+        break;
+      }
+      case D_SKIPFAR2D: {
+        float a[K];
+        KLOOP a[kp] = LDSF(slot);
+        if (all_far<K, 2>(pv, a, PF(0), PF(1), 0.f, PF(2), PF(3), 0.f)) {
+          KLOOP Rv[kp] = a[kp];
+          pc += PU(4);
+        } else {
+          pc += 6;
+        }
+        break;
+      }
+      case D_SKIPFAR3D: {
+        float a[K];
+        KLOOP a[kp] = LDSF(slot);
+        if (all_far<K, 3>(pv, a, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5))) {
+          KLOOP Rv[kp] = a[kp];
+          pc += PU(6);
+        } else {
+          pc += 8;
+        }
         break;
       }
       default:

@@ -540,6 +540,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_brick_kernel(const uint32_t
 // =================================================================================================
 struct DCCounters {
   unsigned long long n_cubes, n_edges, n_tris, q_overflow, t_overflow;
+  unsigned long long n_origin_evals;  // lattice cells whose origin was actually evaluated (the rest were outside the exact box)
 };
 
 // Stage 1 (Reset :26-83): evaluate every cube origin; keep iff |d| < 2*size (octreePrunea szMult=2, origin).
@@ -547,36 +548,65 @@ template <int K>
 __global__ void __launch_bounds__(BLOCK, 3) dc_origin_kernel(const uint32_t* __restrict__ code_g, int nslots, int nshift, float ox, float oy,
                                                              float oz, float res, int* __restrict__ grid, Cube* __restrict__ cubes,
                                                              unsigned long long cube_cap, unsigned zlo, unsigned zhi,
-                                                             DCCounters* __restrict__ ctr) {
+                                                             int use_box, float bx0, float by0, float bz0, float bx1, float by1,
+                                                             float bz1, DCCounters* __restrict__ ctr) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
   unsigned* s_w = (unsigned*)(g_smem + (size_t)(nslots > 0 ? nslots : 1) * K * BLOCK);  // 4 wave totals
   unsigned long long* s_base = (unsigned long long*)(s_w + 4);
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // multi-GPU: this rank evaluates the z-slab [zlo, zhi) of the lattice (its own slab plus a one-cube halo)
-  const unsigned long long cell0 = (unsigned long long)zlo << (2 * nshift);
-  const unsigned long long ncell = (unsigned long long)zhi << (2 * nshift);
-  const unsigned mask = (1u << nshift) - 1u;
+  // multi-GPU: this rank evaluates the z-slab [zlo, zhi) of the lattice (its own slab plus a one-cube halo).
+  // Work tile = a compact 8 x 8 x 4K brick of cells (a wave = one 8x8 patch at K z-levels), not a K*256-long row:
+  // spatially coherent waves are what lets D_SKIPFAR* drop the far children of a wide union for the whole wave.
+  const unsigned n = 1u << nshift;
+  const unsigned bxn = (n + 7u) >> 3;
+  const unsigned bzn = (zhi - zlo + 4u * K - 1u) / (4u * K);
+  const uint64_t ntiles = (uint64_t)bxn * bxn * bzn;
   const float maxDist = res * 2;
-  const uint64_t step = (uint64_t)gridDim.x * BLOCK * K;
-  for (uint64_t base = cell0 + (uint64_t)blockIdx.x * BLOCK * K; base < ncell; base += step) {
+  unsigned long long my_evals = 0;
+  for (uint64_t T = blockIdx.x; T < ntiles; T += gridDim.x) {  // block-uniform trip count
+    const unsigned tx = (unsigned)(T % bxn), ty = (unsigned)((T / bxn) % bxn), tz = (unsigned)(T / ((uint64_t)bxn * bxn));
     P3 p[K];
     float d[K];
+    unsigned cx[K], cy[K], cz[K];
+    bool valid[K];
 #pragma unroll
     for (int kp = 0; kp < K; kp++) {
-      const uint64_t c = base + (uint64_t)kp * BLOCK + threadIdx.x;
-      const unsigned x = (unsigned)c & mask, y = (unsigned)(c >> nshift) & mask, z = (unsigned)(c >> (2 * nshift)) & mask;
-      p[kp] = P3{ox + res * (float)x, oy + res * (float)y, oz + res * (float)z};  // CubeOrigin, size = res
+      const unsigned j = (unsigned)kp * BLOCK + threadIdx.x;
+      cx[kp] = tx * 8u + (j & 7u);
+      cy[kp] = ty * 8u + ((j >> 3) & 7u);
+      cz[kp] = zlo + tz * (4u * K) + (j >> 6);
+      valid[kp] = cx[kp] < n && cy[kp] < n && cz[kp] < zhi;
+      p[kp] = P3{ox + res * (float)cx[kp], oy + res * (float)cy[kp], oz + res * (float)cz[kp]};  // CubeOrigin, size = res
     }
-    gsdf_dev::sdf_eval<K>(code, p, d, lds, BLOCK);
+    // Trees whose field is >= the distance to a known box (use_box): a wave whose cells all lie outside that box by
+    // more than the keep radius needs no evaluation -- |d| >= distance to the box > 2*res decides "not kept" exactly.
+    // (The reference sweeps its cubic lattice unconditionally; a long thin part fills a few percent of it.)
+    bool far = use_box != 0;
+#pragma unroll
+    for (int kp = 0; kp < K; kp++) {
+      const float L = dm::maxf(dm::maxf(dm::maxf(bx0 - p[kp].x, p[kp].x - bx1), dm::maxf(by0 - p[kp].y, p[kp].y - by1)),
+                               dm::maxf(bz0 - p[kp].z, p[kp].z - bz1));
+      far = far && (!valid[kp] || L > maxDist * 1.001f);
+    }
+    if (__all(far)) {
+#pragma unroll
+      for (int kp = 0; kp < K; kp++) d[kp] = 3.0e38f;
+    } else {
+      gsdf_dev::sdf_eval<K>(code, p, d, lds, BLOCK);
+#pragma unroll
+      for (int kp = 0; kp < K; kp++) {  // count the lattice cells (tiles overhang the lattice edge)
+        const unsigned long long vm = __ballot(valid[kp]);
+        if (lane == 0) my_evals += (unsigned long long)__builtin_popcountll(vm);
+      }
+    }
     // Block-wide append: ONE global atomic per workgroup pass (K*256 cells) instead of one per wave and point --
     // at ~88 atomics/us on a single word the per-wave form was a co-bottleneck for cheap trees (1e9 cells / 64).
     bool keep[K];
     unsigned mine = 0;
 #pragma unroll
     for (int kp = 0; kp < K; kp++) {
-      const uint64_t c = base + (uint64_t)kp * BLOCK + threadIdx.x;
-      keep[kp] = c < ncell && !(dm::absf(d[kp]) >= maxDist);
+      keep[kp] = valid[kp] && !(dm::absf(d[kp]) >= maxDist);
       mine += keep[kp] ? 1u : 0u;
     }
     unsigned incl = mine;  // wave inclusive scan of per-lane counts
@@ -595,23 +625,22 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_origin_kernel(const uint32_t* __r
     unsigned long long slot = (total ? *s_base : 0ull) + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + (incl - mine);
 #pragma unroll
     for (int kp = 0; kp < K; kp++) {
-      const uint64_t c = base + (uint64_t)kp * BLOCK + threadIdx.x;
-      const bool valid = c < ncell;
+      const uint64_t c = (uint64_t)cx[kp] + ((uint64_t)cy[kp] << nshift) + ((uint64_t)cz[kp] << (2 * nshift));
       if (keep[kp]) {
         if (slot < cube_cap) {
-          const unsigned x = (unsigned)c & mask, y = (unsigned)(c >> nshift) & mask, z = (unsigned)(c >> (2 * nshift)) & mask;
-          cubes[slot] = Cube{(uint16_t)x, (uint16_t)y, (uint16_t)z, 0};
+          cubes[slot] = Cube{(uint16_t)cx[kp], (uint16_t)cy[kp], (uint16_t)cz[kp], 0};
           grid[c] = (int)slot;
         } else {
           ctr->q_overflow = 1ull;
           grid[c] = -1;
         }
         slot++;
-      } else if (valid) {
+      } else if (valid[kp]) {
         grid[c] = -1;
       }
     }
   }
+  if (lane == 0 && my_evals) atomicAdd(&ctr->n_origin_evals, my_evals);
 }
 
 // Stage 2 (RenderAll :85-108): origin, +x, +y, +z distances of every kept cube (one 4-point pass per

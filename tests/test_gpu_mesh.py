@@ -157,7 +157,7 @@ def test_dualcontour_identical_to_oracle(gpu, chiseled):
     b = Builder()
     cases = [(b.NewSphere(1.0), 1.0 / 8), (b.NewBox(2, 2, 2, 0), 2.0 / 8), (b.Scene("bolt"), 0.5), (b.Scene("npt-flange"), 0.9),
              (b.Scene("knurled-cylinder"), 0.8)]
-    for sh, res in cases:
+    for k, (sh, res) in enumerate(cases):
         res = np.float32(res)
         dc = gpu.DualContourHIP(gpu.SDF3HIP(sh), res, chiseled=chiseled)
         ref = OracleSDF(sh.tree()).render_dualcontour(res, chiseled)
@@ -165,7 +165,10 @@ def test_dualcontour_identical_to_oracle(gpu, chiseled):
         assert dc.n_tris() == ref.n_tris, (sh, dc.n_tris(), ref.n_tris)
         tg, tc = _sorted(dc.RenderAll()), _sorted(ref.tris)
         assert (tg.view(np.uint32) == tc.view(np.uint32)).all(), sh   # float64 QR reproduced bit for bit
-        assert dc.stats.evals == ref.evals
+        # the reference sweeps the whole cubic lattice; for trees with an exact bounding box (sphere, box) the device
+        # skips lattice cells farther than 2*res outside that box -- same kept cubes, fewer evaluations
+        exact = sh.Bounds() is not None and k < 2
+        assert (dc.stats.evals <= ref.evals) if exact else (dc.stats.evals == ref.evals), (k, dc.stats.evals, ref.evals)
 
 
 def test_dualcontour_reference_tolerances(gpu):
@@ -274,3 +277,21 @@ def test_cube_queue_overflow_grows_and_reruns(gpu, monkeypatch):
         oc = gpu.OctreeHIP(sdf, res)
         assert oc.n_tris() == g["n_tris"]
         assert _digest(oc.RenderAll()) == g["sha256_sorted"]
+
+
+def test_dualcontour_exact_box_early_out(gpu):
+    """A long thin exact-distance part fills a few percent of the reference's cubic lattice: cells farther than 2*res
+    outside the part's box are decided without evaluation -- identical mesh, a fraction of the evaluations. The same
+    tree also exercises the far-child skip of wide unions (D_SKIPFAR*)."""
+    b = Builder()
+    s = b.Scene("glyph-plate")
+    res = np.float32(float(s.Diagonal()) / 96)
+    ref = OracleSDF(s.tree()).render_dualcontour(res, False)
+    for spec in (False, True):
+        sdf = gpu.SDF3HIP(s)
+        if spec:
+            sdf.specialize()
+        dc = gpu.DualContourHIP(sdf, res)
+        assert dc.n_tris() == ref.n_tris
+        assert (_sorted(dc.RenderAll()).view(np.uint32) == _sorted(ref.tris).view(np.uint32)).all()
+        assert dc.stats.evals < ref.evals // 4, (dc.stats.evals, ref.evals)
