@@ -40,8 +40,11 @@ def _shape2(b, r, depth):
     if depth <= 0 or r.random() < 0.3:
         return _prim2(b, r)
     u = lambda lo, hi: float(r.uniform(lo, hi))
-    k = r.integers(0, 9)
+    k = r.integers(0, 10)
     a = _shape2(b, r, depth - 1)
+    if k == 9:                                                                   # wide 2-D union (text-plate shape)
+        parts = [a] + [b.Translate2D(_shape2(b, r, max(0, depth - 2)), u(-4, 4), u(-4, 4)) for _ in range(int(r.integers(3, 6)))]
+        return b.Union2D(*parts)
     if k == 0: return b.Union2D(a, _shape2(b, r, depth - 1))
     if k == 1: return b.Difference2D(a, _shape2(b, r, depth - 1))
     if k == 2: return b.Intersection2D(a, b.Translate2D(_shape2(b, r, depth - 1), u(-0.2, 0.2), u(-0.2, 0.2)))
@@ -57,8 +60,11 @@ def _shape3(b, r, depth):
     if depth <= 0 or r.random() < 0.1:
         return _prim3(b, r)
     u = lambda lo, hi: float(r.uniform(lo, hi))
-    k = r.integers(0, 16)
+    k = r.integers(0, 18)
     a = _shape3(b, r, depth - 1)
+    if k >= 16:                                                                  # wide union: exercises the far-child skip
+        parts = [a] + [b.Translate(_shape3(b, r, max(0, depth - 2)), u(-4, 4), u(-4, 4), u(-2, 2)) for _ in range(int(r.integers(3, 6)))]
+        return b.Union(*parts)
     if k == 0: return b.Union(a, _shape3(b, r, depth - 1))
     if k == 1: return b.Union(a, _shape3(b, r, depth - 1), _shape3(b, r, depth - 2))
     if k == 2: return b.Difference(a, b.Translate(_shape3(b, r, depth - 1), u(-0.3, 0.3), u(-0.3, 0.3), u(-0.3, 0.3)))

@@ -111,6 +111,38 @@ def test_corner_pair_sharing_flags():
     assert len(cyl) == 2 and cyl[0][1] != cyl[1][1]  # the transformed branch (4x4 matrix) is not shareable, the other is
 
 
+def test_far_child_skip_in_wide_unions():
+    """D_SKIPFAR*: emitted in unions of >= 4 children for children with an exact bounding box; the skip lands on the
+    instruction after the child's D_COMBINE_MIN; the box is the child's (translated polygon bounds)."""
+    b = Builder()
+    code, _ = hip.lower(b.Scene("glyph-plate"))
+    ins = decode(code)
+    starts = {i[4] for i in ins}
+    f = code.view(np.float32)
+    skips = [i for i in ins if i[0] == "D_SKIPFAR2D"]
+    assert len(skips) == 23                                  # 24 glyphs: every child but the first
+    for name, _, _, slot, pc in skips:
+        target = pc + int(code[pc + 5])
+        assert target in starts                              # lands on an instruction boundary ...
+        prev = max(p for p in starts if p < target)
+        assert [i[0] for i in ins if i[4] == prev] == ["D_COMBINE_MIN"]   # ... right after the child's combine
+        assert [i[3] for i in ins if i[4] == prev] == [slot]              # same running-minimum slot
+        x0, y0, x1, y1 = f[pc + 1:pc + 5]
+        assert x1 - x0 == 6.0 and y1 - y0 == 10.0            # glyph cell of the scene (threads.hpp: 6 x 10)
+    # children without an exact-distance guarantee are never skipped: smoothing, scaling, approximate primitives
+    def mk(child):
+        return b.Union2D(b.NewCircle(1), b.Translate2D(b.NewCircle(1), 3, 0), b.Translate2D(b.NewCircle(1), 6, 0), child)
+    names = lambda sh: [i[0] for i in decode(hip.lower(sh)[0])]
+    assert names(mk(b.Translate2D(b.NewCircle(1), 9, 0))).count("D_SKIPFAR2D") == 3
+    assert names(mk(b.Translate2D(b.NewEllipse(1, 0.5), 9, 0))).count("D_SKIPFAR2D") == 2
+    assert names(mk(b.Scale2D(b.NewCircle(1), 2.0))).count("D_SKIPFAR2D") == 2
+    assert names(b.Union2D(b.NewCircle(1), b.Translate2D(b.NewCircle(1), 3, 0), b.Translate2D(b.NewCircle(1), 6, 0))).count("D_SKIPFAR2D") == 0
+    # 3-D: extruded exact shapes and boxes qualify
+    sh3 = b.Union(b.NewSphere(1), b.Translate(b.NewBox(1, 1, 1, 0), 3, 0, 0), b.Translate(b.Extrude(b.NewRectangle(1, 1), 1), 6, 0, 0),
+                  b.Translate(b.NewTorus(1, 0.2), 9, 0, 0))
+    assert names(sh3).count("D_SKIPFAR3D") == 2              # box and extrusion; the torus makes no claim
+
+
 def test_hxy_not_reused_across_xy_changes():
     b = Builder()
     c = b.NewCylinder(1, 2, 0)
