@@ -234,7 +234,8 @@ def main():
             "triangles_per_s": tris_all / dt,
             "triangles_per_step": tris_all / args.steps, "evals_per_step": evals_all / args.steps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_gb(),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_gb(), "traffic_unit": "GB per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
+                         "algorithmic_gb_per_launch": k_bytes / 1e9,
                          "kernel": "leaf_kernel<4>", "kernel_ms": k_ms,
                          "kernel_evals_per_s": kernel_rate, "valu": valu_roofline(kernel_rate),
                          "note": "path is fp32-VALU bound (SURVEY 8(d)): algorithmic HBM bytes are tiny by construction; "
