@@ -206,5 +206,25 @@ class Builder:
     def BoltISO(self, D, P, ext, style, total, shank): return self._call("threads.Bolt.ISO", [D, P, total, shank], [int(ext), style])
     def HexHead(self, r, h, round_neg, round_pos): return self._call("threads.HexHead", [r, h], [int(round_neg), int(round_pos)])
     def KnurledHead(self, r, h, pitch): return self._call("threads.KnurledHead", [r, h, pitch])
+    # ---- forge/textsdf (font.go): one line of text set in a TrueType font, as a 2-D shape
+    def TextLine(self, ttf_bytes, text, reltol=0.0):
+        """textsdf.Font{}.LoadTTFBytes(ttf); Configure(FontConfig{RelativeGlyphTolerance: reltol}); TextLine(text)."""
+        buf = (C.c_uint8 * len(ttf_bytes)).from_buffer_copy(ttf_bytes)
+        self._lib.gsdfb_textsdf_line.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_float, C.c_void_p, C.c_void_p]
+        r = self._lib.gsdfb_textsdf_line(self._h, buf, len(ttf_bytes), text.encode("utf-8"), reltol, None, None)
+        if r < 0:
+            raise ShapeError(self._lib.gsdfb_last_error().decode())
+        return Shader(self, r)
+
+    def TextMetrics(self, ttf_bytes, two_chars):
+        """(AdvanceWidth(c0), Kern(c0, c1)) of textsdf.Font for the first two characters."""
+        buf = (C.c_uint8 * len(ttf_bytes)).from_buffer_copy(ttf_bytes)
+        adv, kern = C.c_float(), C.c_float()
+        self._lib.gsdfb_textsdf_line.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_float, C.c_void_p, C.c_void_p]
+        r = self._lib.gsdfb_textsdf_line(self._h, buf, len(ttf_bytes), two_chars.encode("utf-8"), 0.0, C.byref(adv), C.byref(kern))
+        if r < 0:
+            raise ShapeError(self._lib.gsdfb_last_error().decode())
+        return adv.value, kern.value
+
     # ---- benchmark scenes (examples/*)
     def Scene(self, name, *fargs, ints=()): return self._call("scene." + name, list(fargs), list(ints))

@@ -7,6 +7,7 @@
 #include <string>
 
 #include "builder.hpp"
+#include "textsdf.hpp"
 #include "threads.hpp"
 
 using namespace gsdf;
@@ -133,6 +134,29 @@ int gsdfb_op(void* hv, const char* name, const float* f, int nf, const int* i, i
     if (n == "scene.knurled-cylinder") return scenes::KnurledCylinder(b, nf > 0 ? f[0] : 20.f).id;
     g_err = "unknown builder method: " + n;
     return -1;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+// forge/textsdf: Font.LoadTTFBytes + Configure(RelativeGlyphTolerance) + TextLine(text) on this builder
+// (font.go:39-137). Returns the 2-D node id of the line, or -1 with gsdfb_last_error() set (the reference's error
+// texts: "no text provided", "char ... not graphic", "invalid RelativeGlyphTolerance", sfnt parse errors).
+// advance_out / kern_out (optional): Font.AdvanceWidth / Font.Kern of the first (two) runes, for tests.
+int gsdfb_textsdf_line(void* hv, const uint8_t* ttf, size_t ttf_len, const char* utf8, float reltol, float* advance_out, float* kern_out) {
+  Builder& b = ((Handle*)hv)->b;
+  try {
+    if (!ttf || !utf8) throw std::invalid_argument("null argument");
+    textsdf::Font f(b);
+    textsdf::FontConfig cfg;
+    cfg.RelativeGlyphTolerance = reltol;
+    f.Configure(cfg);
+    f.LoadTTFBytes(ttf, ttf_len);
+    const std::string s(utf8);
+    if (advance_out && !s.empty()) *advance_out = f.AdvanceWidth((unsigned char)s[0]);
+    if (kern_out && s.size() > 1) *kern_out = f.Kern((unsigned char)s[0], (unsigned char)s[1]);
+    return f.TextLine(s).id;
   } catch (const std::exception& e) {
     g_err = e.what();
     return -1;

@@ -295,3 +295,43 @@ def test_dualcontour_exact_box_early_out(gpu):
         assert dc.n_tris() == ref.n_tris
         assert (_sorted(dc.RenderAll()).view(np.uint32) == _sorted(ref.tris).view(np.uint32)).all()
         assert dc.stats.evals < ref.evals // 4, (dc.stats.evals, ref.evals)
+
+
+def _text_plate(b, text="gsdf MI355X"):
+    """BASELINE config 5's tree shape from the reference's own font: forge/textsdf line -> extrude -> union with a plate."""
+    ttf = open(os.path.join(os.path.dirname(__file__), "golden", "iso-3098.ttf"), "rb").read()
+    t2 = b.TextLine(ttf, text)
+    bb = t2.Bounds()
+    t3 = b.Extrude(t2, 0.12)
+    w, h = float(bb[3] - bb[0]), float(bb[4] - bb[1])
+    plate = b.Translate(b.NewBox(w + 0.3, h + 0.3, 0.06, 0.01), float(bb[0] + bb[3]) / 2, float(bb[1] + bb[4]) / 2, -0.08)
+    return b.Union(t3, plate)
+
+
+def test_text_plate_from_reference_font(gpu):
+    """forge/textsdf (host mirror) -> HIP evaluator / octree mesher / dual contouring, bit-identical to the oracle on
+    the same tree, interpreter and specialised kernels. Wide 2-D union of translated glyph polygons (far-child skip)."""
+    b = Builder()
+    s = _text_plate(b)
+    ref = OracleSDF(s.tree())
+    rng = np.random.default_rng(23)
+    bb = s.Bounds()
+    pos = (bb[:3] + rng.random((40000, 3), np.float32) * (bb[3:] - bb[:3])).astype(np.float32)
+    dref = ref.Evaluate(pos)
+    res = np.float32(float(s.Diagonal()) / 160)
+    mo = ref.render_octree(res, 4096, True)
+    md = ref.render_dualcontour(np.float32(float(s.Diagonal()) / 96), False)
+    assert mo.n_tris > 20000 and md.n_tris > 5000
+    for spec in (False, True):
+        sdf = gpu.SDF3HIP(s)
+        if spec:
+            sdf.specialize()
+        d = sdf.Evaluate(pos)
+        assert int((d.view(np.uint32) != dref.view(np.uint32)).sum()) == 0
+        oc = gpu.OctreeHIP(sdf, res)
+        assert oc.n_tris() == mo.n_tris
+        assert (_sorted(oc.RenderAll()).view(np.uint32) == _sorted(mo.tris).view(np.uint32)).all()
+        dc = gpu.DualContourHIP(sdf, np.float32(float(s.Diagonal()) / 96))
+        assert dc.n_tris() == md.n_tris
+        assert (_sorted(dc.RenderAll()).view(np.uint32) == _sorted(md.tris).view(np.uint32)).all()
+        assert dc.stats.evals < md.evals // 4                # the exact-box early-out applies: text + box are exact fields
