@@ -150,7 +150,12 @@ void gen(Ctx& c, uint32_t i, int depth);
 // to that box: exact-distance primitives under translation, union, and as the first operand of a difference or an
 // intersection (max(a, .) >= a). Everything else -- smoothing, scaling, domain repetition, approximate primitives --
 // answers false: no claim, the child is always evaluated.
-bool exact_box(Ctx& c, uint32_t i, float bb[6], int depth = 0) {
+// *solid (optional): additionally the shape is known to be non-empty inside the box, so the field is also <= the
+// distance to the box's farthest corner (the upper bound D_UBOUND* uses). A difference or intersection may be empty.
+bool exact_box(Ctx& c, uint32_t i, float bb[6], int depth = 0, bool* solid = nullptr) {
+  bool dummy = true;
+  if (!solid) solid = &dummy;
+  if (depth == 0) *solid = true;
   if (depth > 64) return false;
   const gsdf_node& n = c.node(i);
   const float* P = n.p;
@@ -176,7 +181,7 @@ bool exact_box(Ctx& c, uint32_t i, float bb[6], int depth = 0) {
       return set(x0, y0, 0, x1, y1, 0);
     }
     case GSDF_TRANSLATE: case GSDF_TRANSLATE2D: {
-      if (n.nchild != 1 || !exact_box(c, c.child(n, 0), bb, depth + 1)) return false;
+      if (n.nchild != 1 || !exact_box(c, c.child(n, 0), bb, depth + 1, solid)) return false;
       const float tz = n.op == GSDF_TRANSLATE ? P[2] : 0.f;
       bb[0] += P[0]; bb[3] += P[0]; bb[1] += P[1]; bb[4] += P[1]; bb[2] += tz; bb[5] += tz;
       return true;
@@ -184,16 +189,17 @@ bool exact_box(Ctx& c, uint32_t i, float bb[6], int depth = 0) {
     case GSDF_UNION: case GSDF_UNION2D: {
       float a[6];
       for (uint32_t k = 0; k < n.nchild; k++) {
-        if (!exact_box(c, c.child(n, k), a, depth + 1)) return false;
+        if (!exact_box(c, c.child(n, k), a, depth + 1, solid)) return false;
         if (k == 0) std::memcpy(bb, a, sizeof a);
         else for (int j = 0; j < 3; j++) { bb[j] = std::fmin(bb[j], a[j]); bb[j + 3] = std::fmax(bb[j + 3], a[j + 3]); }
       }
       return n.nchild > 0;
     }
     case GSDF_DIFF: case GSDF_DIFF2D: case GSDF_INTERSECT: case GSDF_INTERSECT2D:
-      return n.nchild == 2 && exact_box(c, c.child(n, 0), bb, depth + 1);
+      *solid = false;  // what is left after the cut may be anywhere in the box, or nothing
+      return n.nchild == 2 && exact_box(c, c.child(n, 0), bb, depth + 1, solid);
     case GSDF_EXTRUSION: {  // exact for an exact 2-D child: min(0,max(d,|z|-h/2)) + |max((d,|z|-h/2),0)|
-      if (n.nchild != 1 || !exact_box(c, c.child(n, 0), bb, depth + 1)) return false;
+      if (n.nchild != 1 || !exact_box(c, c.child(n, 0), bb, depth + 1, solid)) return false;
       bb[2] = -0.5f * P[0]; bb[5] = 0.5f * P[0];
       return true;
     }
@@ -225,9 +231,30 @@ void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int dept
       c.mark_saved(slotP, is2d);
     }
   }
+  // Wide union with >= 3 exact-boxed children: start the running minimum at an upper bound of the union (D_UBOUND*),
+  // so that far children are skipped from the first one on, wherever the point is.
+  std::vector<float> ub;
+  if (comb == D_COMBINE_MIN && n.nchild >= 4) {
+    float cb[6];
+    for (uint32_t k = 0; k < n.nchild; k++) {
+      bool solid = true;
+      if (exact_box(c, c.child(n, k), cb, 0, &solid) && solid) {
+        if (is2d) { ub.push_back(cb[0]); ub.push_back(cb[1]); ub.push_back(cb[3]); ub.push_back(cb[4]); }
+        else for (int j = 0; j < 6; j++) ub.push_back(cb[j]);
+      }
+    }
+    if (ub.size() < (size_t)(is2d ? 12 : 18)) ub.clear();
+  }
+  const bool bounded = !ub.empty();
   // The partial result gets its slot only when the first child is done: while that child (in left-deep trees, the
   // whole rest of the tree) runs, this frame holds no distance slot.
   int slotD = -1;
+  if (bounded) {
+    slotD = c.alloc(1);
+    c.op(is2d ? D_UBOUND2D : D_UBOUND3D, slotD);
+    c.u((uint32_t)(ub.size() / (is2d ? 4 : 6)));
+    for (float v : ub) c.f(v);
+  }
   bool dirty = false;
   for (uint32_t k = 0; k < n.nchild; k++) {
     if (k > 0 && dirty) { c.load_saved(slotP, is2d); dirty = false; }
@@ -235,16 +262,19 @@ void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int dept
     // wide union: a child that provably cannot lower the running minimum for any point of the wave is skipped
     long skip_at = -1;
     float cb[6];
-    if (comb == D_COMBINE_MIN && n.nchild >= 4 && k > 0 && exact_box(c, ch, cb)) {
+    if (comb == D_COMBINE_MIN && n.nchild >= 4 && (k > 0 || bounded) && exact_box(c, ch, cb)) {
       c.op(is2d ? D_SKIPFAR2D : D_SKIPFAR3D, slotD);
       if (is2d) { c.f(cb[0]); c.f(cb[1]); c.f(cb[3]); c.f(cb[4]); }
       else { for (int j = 0; j < 6; j++) c.f(cb[j]); }
       skip_at = (long)c.code.size();
       c.u(0);  // patched below: words from this instruction to the one after the child's D_COMBINE_MIN
     }
+    const uint32_t hxy_before = c.hxyver;
     gen(c, ch, depth + 1);
+    // a child that may be skipped at run time may not have refreshed the hypot(x,y) register: forget what it cached
+    if (skip_at >= 0 && c.hxyver != hxy_before) c.hxyver = 0;
     dirty = dirty || clobbers(c, ch);
-    if (k > 0) { c.op(comb | ((asym && swapped) ? D_FLAG_SWAP : 0u), slotD); if (has_k) { c.f(n.p[0]); c.f(recip_for(n.p[0])); } }
+    if (k > 0 || bounded) { c.op(comb | ((asym && swapped) ? D_FLAG_SWAP : 0u), slotD); if (has_k) { c.f(n.p[0]); c.f(recip_for(n.p[0])); } }
     if (skip_at >= 0) c.code[(size_t)skip_at] = (uint32_t)(c.code.size() - ((size_t)skip_at - (is2d ? 5 : 7)));
     if (k + 1 < n.nchild) {
       if (slotD < 0) slotD = c.alloc(1);

@@ -92,10 +92,16 @@ enum DevOp : uint32_t {
   //      program counter advances by `skip` words past the child and its D_COMBINE_MIN. Wave-uniform branch.
   D_SKIPFAR2D,  // minx miny maxx maxy skip
   D_SKIPFAR3D,  // minx miny minz maxx maxy maxz skip
+  //      D_UBOUND* opens such a union: lds[slot] <- (1 + 1e-3) * min over the listed boxes of the distance to the box's
+  //      FARTHEST corner -- an upper bound of that child's field (the shape lies inside its box), hence of the union.
+  //      Starting the running minimum there lets D_SKIPFAR* drop far children from the first one on; the bound never
+  //      reaches the result (it is >= the nearest child's value, which is always evaluated: its L <= bound).
+  D_UBOUND2D,   // nb then nb x {minx miny maxx maxy}
+  D_UBOUND3D,   // nb then nb x {minx miny minz maxx maxy maxz}
   D_OP_COUNT
 };
 
-// Fixed parameter-word counts (D_POLY2D / D_LINES2D are variable: 3 + pad + 8*nv / 2+5*ns).
+// Fixed parameter-word counts (variable: D_POLY2D 3 + pad + 8*nv, D_LINES2D 2 + 5*ns, D_UBOUND2D/3D 1 + 4*nb / 1 + 6*nb).
 static const uint8_t kDevOpParams[D_OP_COUNT] = {
     /*END*/ 0,
     /*SPHERE*/ 1, /*BOX*/ 4, /*BOXFRAME*/ 4, /*TORUS*/ 2, /*CYL0*/ 2, /*CYLR*/ 3, /*HEX*/ 3,
@@ -107,5 +113,5 @@ static const uint8_t kDevOpParams[D_OP_COUNT] = {
     /*MULR*/ 1, /*SHELL_POST*/ 1, /*ADDR*/ 1, /*ANNULUS*/ 1, /*EXTRUDE_POST*/ 0, /*MAXR_SLOT*/ 0, /*ADDR_SLOT*/ 0,
     /*SAVEP3*/ 0, /*LOADP3*/ 0, /*SAVEP2*/ 0, /*LOADP2*/ 0, /*SAVER*/ 0, /*SETSLOT*/ 1, /*SETR*/ 1,
     /*MIN*/ 0, /*MAX*/ 0, /*DIFF*/ 0, /*XOR*/ 0, /*SUNION*/ 2, /*SDIFF*/ 2, /*SINTER*/ 2,
-    /*SKIPFAR2D*/ 5, /*SKIPFAR3D*/ 7,
+    /*SKIPFAR2D*/ 5, /*SKIPFAR3D*/ 7, /*UBOUND2D*/ 1, /*UBOUND3D*/ 1,
 };

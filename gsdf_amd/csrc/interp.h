@@ -800,6 +800,42 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         pc += 3;
         break;
       }
+      case D_UBOUND2D: {
+        // running minimum of a wide union <- upper bound: (1 + 1e-3) * min over boxes of the distance to the far corner
+        const uint32_t nb = PU(0);
+        float m2[K];
+        KLOOP m2[kp] = 3.0e38f;
+        uint32_t q = pc + 2;
+        for (uint32_t ib = 0; ib < nb; ib++, q += 4) {
+          const float x0 = __uint_as_float(code[q]), y0 = __uint_as_float(code[q + 1]), x1 = __uint_as_float(code[q + 2]),
+                      y1 = __uint_as_float(code[q + 3]);
+          KLOOP {
+            const float dx = maxf(absf(pv[kp].x - x0), absf(pv[kp].x - x1)), dy = maxf(absf(pv[kp].y - y0), absf(pv[kp].y - y1));
+            m2[kp] = minf(m2[kp], dx * dx + dy * dy);
+          }
+        }
+        KLOOP LDSF(slot) = 1.001f * sqrtf_(m2[kp]) + 1e-30f;
+        pc = q;
+        break;
+      }
+      case D_UBOUND3D: {
+        const uint32_t nb = PU(0);
+        float m2[K];
+        KLOOP m2[kp] = 3.0e38f;
+        uint32_t q = pc + 2;
+        for (uint32_t ib = 0; ib < nb; ib++, q += 6) {
+          const float x0 = __uint_as_float(code[q]), y0 = __uint_as_float(code[q + 1]), z0 = __uint_as_float(code[q + 2]),
+                      x1 = __uint_as_float(code[q + 3]), y1 = __uint_as_float(code[q + 4]), z1 = __uint_as_float(code[q + 5]);
+          KLOOP {
+            const float dx = maxf(absf(pv[kp].x - x0), absf(pv[kp].x - x1)), dy = maxf(absf(pv[kp].y - y0), absf(pv[kp].y - y1)),
+                        dz = maxf(absf(pv[kp].z - z0), absf(pv[kp].z - z1));
+            m2[kp] = minf(m2[kp], dx * dx + dy * dy + dz * dz);
+          }
+        }
+        KLOOP LDSF(slot) = 1.001f * sqrtf_(m2[kp]) + 1e-30f;
+        pc = q;
+        break;
+      }
       case D_SKIPFAR2D: {
         float a[K];
         KLOOP a[kp] = LDSF(slot);

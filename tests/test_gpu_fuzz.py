@@ -27,7 +27,7 @@ def _points(sh, rng, n=6000):
     return np.concatenate([p, g]).astype(np.float32)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_trees_distances_and_meshes(gpu, seed):
     _, shapes = fuzz_trees.random_shapes(seed, 14, depth=4)
     assert len(shapes) == 14

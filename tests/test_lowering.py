@@ -13,7 +13,7 @@ from gsdf_amd.builder import Builder
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _HDR = open(os.path.join(ROOT, "gsdf_amd", "csrc", "dev_ops.h")).read()
 _ENUM = _HDR[_HDR.index("enum DevOp"):_HDR.index("D_OP_COUNT")]
-NAMES = [n for n in dict.fromkeys(re.findall(r"\b(D_[A-Z0-9_]+)\b", _ENUM))]
+NAMES = [n for n in dict.fromkeys(re.findall(r"\b(D_[A-Z0-9_]+)\b", re.sub(r"//[^\n]*", "", _ENUM)))]
 NPAR = [int(x) for x in re.findall(r"\*/\s*(\d+)", re.search(r"kDevOpParams\[D_OP_COUNT\] = \{(.*?)\};", _HDR, re.S).group(1))]
 FLAG_SHZ, FLAG_SHXY, FLAG_HXY, FLAG_SWAP, OP_MASK = 0x1000, 0x2000, 0x4000, 0x8000, 0x0FFF
 
@@ -29,6 +29,8 @@ def decode(code):
             n = ((pc + 4 + 7) & ~7) - (pc + 1) + 8 * nv
         elif name == "D_LINES2D":
             n = 2 + 5 * int(code[pc + 1])
+        elif name in ("D_UBOUND2D", "D_UBOUND3D"):
+            n = 1 + (4 if name == "D_UBOUND2D" else 6) * int(code[pc + 1])
         out.append((name, bool(w & FLAG_HXY), bool(w & FLAG_SWAP), w >> 16, pc))
         pc += 1 + n
         if name == "D_END":
@@ -112,16 +114,22 @@ def test_corner_pair_sharing_flags():
 
 
 def test_far_child_skip_in_wide_unions():
-    """D_SKIPFAR*: emitted in unions of >= 4 children for children with an exact bounding box; the skip lands on the
-    instruction after the child's D_COMBINE_MIN; the box is the child's (translated polygon bounds)."""
+    """Wide unions (>= 4 children) of exact-boxed children: D_UBOUND* starts the running minimum at an upper bound of the
+    union, every boxed child is preceded by D_SKIPFAR* whose skip lands on the instruction after the child's
+    D_COMBINE_MIN; the boxes are the children's (translated polygon bounds)."""
     b = Builder()
     code, _ = hip.lower(b.Scene("glyph-plate"))
     ins = decode(code)
     starts = {i[4] for i in ins}
     f = code.view(np.float32)
+    ub = [i for i in ins if i[0] == "D_UBOUND2D"]
+    nb = int(code[ub[0][4] + 1])
+    assert len(ub) == 1 and nb == 18                         # the 6 "D" glyphs are differences: lower bound only, no upper bound
+    ub_boxes = {tuple(f[ub[0][4] + 2 + 4 * k: ub[0][4] + 6 + 4 * k]) for k in range(nb)}
     skips = [i for i in ins if i[0] == "D_SKIPFAR2D"]
-    assert len(skips) == 23                                  # 24 glyphs: every child but the first
-    for name, _, _, slot, pc in skips:
+    assert len(skips) == 24                                  # every glyph, the first one included
+    for k, (name, _, _, slot, pc) in enumerate(skips):
+        assert slot == ub[0][3]                              # all test against the slot the bound was stored in
         target = pc + int(code[pc + 5])
         assert target in starts                              # lands on an instruction boundary ...
         prev = max(p for p in starts if p < target)
@@ -129,18 +137,29 @@ def test_far_child_skip_in_wide_unions():
         assert [i[3] for i in ins if i[4] == prev] == [slot]              # same running-minimum slot
         x0, y0, x1, y1 = f[pc + 1:pc + 5]
         assert x1 - x0 == 6.0 and y1 - y0 == 10.0            # glyph cell of the scene (threads.hpp: 6 x 10)
+        assert ((x0, y0, x1, y1) in ub_boxes) == (k % 4 != 2)  # the bound lists the boxes of the solid glyphs (G, S, F)
     # children without an exact-distance guarantee are never skipped: smoothing, scaling, approximate primitives
     def mk(child):
         return b.Union2D(b.NewCircle(1), b.Translate2D(b.NewCircle(1), 3, 0), b.Translate2D(b.NewCircle(1), 6, 0), child)
     names = lambda sh: [i[0] for i in decode(hip.lower(sh)[0])]
-    assert names(mk(b.Translate2D(b.NewCircle(1), 9, 0))).count("D_SKIPFAR2D") == 3
-    assert names(mk(b.Translate2D(b.NewEllipse(1, 0.5), 9, 0))).count("D_SKIPFAR2D") == 2
-    assert names(mk(b.Scale2D(b.NewCircle(1), 2.0))).count("D_SKIPFAR2D") == 2
-    assert names(b.Union2D(b.NewCircle(1), b.Translate2D(b.NewCircle(1), 3, 0), b.Translate2D(b.NewCircle(1), 6, 0))).count("D_SKIPFAR2D") == 0
+    assert names(mk(b.Translate2D(b.NewCircle(1), 9, 0))).count("D_SKIPFAR2D") == 4
+    assert names(mk(b.Translate2D(b.NewEllipse(1, 0.5), 9, 0))).count("D_SKIPFAR2D") == 3
+    assert names(mk(b.Scale2D(b.NewCircle(1), 2.0))).count("D_SKIPFAR2D") == 3
+    three = names(b.Union2D(b.NewCircle(1), b.Translate2D(b.NewCircle(1), 3, 0), b.Translate2D(b.NewCircle(1), 6, 0)))
+    assert three.count("D_SKIPFAR2D") == 0 and three.count("D_UBOUND2D") == 0
+    # fewer than three boxed children: no upper bound, the first child is always evaluated
+    two = names(b.Union2D(b.NewCircle(1), b.Translate2D(b.NewCircle(1), 3, 0), b.NewEllipse(1, 0.5), b.NewEllipse(2, 0.5)))
+    assert two.count("D_UBOUND2D") == 0 and two.count("D_SKIPFAR2D") == 1
+    # a difference may be empty: it can be skipped (lower bound) but contributes no upper bound
+    dd = b.Union2D(b.NewCircle(1), b.Translate2D(b.NewCircle(1), 3, 0), b.Translate2D(b.NewCircle(1), 6, 0),
+                   b.Translate2D(b.Difference2D(b.NewCircle(1), b.NewCircle(2)), 9, 0))
+    cdd = hip.lower(dd)[0]
+    idd = decode(cdd)
+    assert [i[0] for i in idd].count("D_SKIPFAR2D") == 4 and int(cdd[[i[4] for i in idd if i[0] == "D_UBOUND2D"][0] + 1]) == 3
     # 3-D: extruded exact shapes and boxes qualify
     sh3 = b.Union(b.NewSphere(1), b.Translate(b.NewBox(1, 1, 1, 0), 3, 0, 0), b.Translate(b.Extrude(b.NewRectangle(1, 1), 1), 6, 0, 0),
                   b.Translate(b.NewTorus(1, 0.2), 9, 0, 0))
-    assert names(sh3).count("D_SKIPFAR3D") == 2              # box and extrusion; the torus makes no claim
+    assert names(sh3).count("D_SKIPFAR3D") == 3 and names(sh3).count("D_UBOUND3D") == 1   # the torus makes no claim
 
 
 def test_hxy_not_reused_across_xy_changes():

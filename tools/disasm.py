@@ -27,6 +27,8 @@ def listing(code):
             q0 = (pc + 4 + 7) & ~7
             out.append(f"{pc:5d} {name}{fl} slot={slot} nv={nv} fast={int(code[pc+1])>>31}")
             pc = q0 + 8 * nv
+        elif name in ("D_UBOUND2D", "D_UBOUND3D"):
+            nb = int(code[pc + 1]); out.append(f"{pc:5d} {name}{fl} slot={slot} boxes={nb}"); pc += 2 + (4 if name == "D_UBOUND2D" else 6) * nb
         elif name == "D_LINES2D":
             ns = int(code[pc + 1]); out.append(f"{pc:5d} {name}{fl} ns={ns}"); pc += 3 + 5 * ns
         else:
