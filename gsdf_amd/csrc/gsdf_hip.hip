@@ -789,11 +789,27 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     if (shard_count > 1) HIP_TRYM(hipMemsetAsync(grid.p, 0xff, ncell * sizeof(int), s));  // cells outside the slab read as empty
     HIP_TRYM(hipEventRecord(p->ev[0], s));
     const unsigned g1 = grid_for((nslab + lk - 1) / lk, p->num_cu, 8);
-#define LAUNCH_O(KK) hipLaunchKernelGGL((dc_origin_kernel<KK>), dim3(g1), dim3(BLOCK), p->lds_bytes(KK) + 32, s, p->d_code, p->prog.nslots, nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, zlo, zhi, ub, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], d_ctr)
+#define LAUNCH_O(KK) hipLaunchKernelGGL((dc_origin_kernel<KK>), dim3(g1), dim3(BLOCK), p->lds_bytes(KK) + 32, s, p->d_code, p->prog.nslots, nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, zlo, zhi, ub, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], t0[0], t0[1], t0[2], tn[0], tn[1], tn[2], d_ctr)
     spec_aux(p);
     const int ub = p->prog.has_exact_bb ? 1 : 0;
     const float* eb = p->prog.exact_bb;
-    if (p->f_dc_origin) HIP_TRYM(launch_fn(p->f_dc_origin, g1, BLOCK, p->lds_bytes(lk) + 32, s, (const uint32_t*)p->d_code, (int)p->prog.nslots, (int)nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, (unsigned)zlo, (unsigned)zhi, ub, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], d_ctr));
+    // tile range of the origin sweep (8 x 8 x 4K cells per tile, z tiles counted from zlo)
+    const unsigned ncell1 = 1u << nshift, tzk = 4u * (unsigned)lk;
+    unsigned t0[3] = {0, 0, 0}, tn[3] = {(ncell1 + 7u) >> 3, (ncell1 + 7u) >> 3, (zhi - zlo + tzk - 1u) / tzk};
+    if (ub) {
+      const float org[3] = {ox, oy, oz}, grow = res * 2 * 1.001f + 2 * res;
+      const unsigned lo_lim[3] = {0, 0, zlo}, hi_lim[3] = {ncell1, ncell1, zhi}, tsz[3] = {8, 8, tzk};
+      for (int a = 0; a < 3; a++) {
+        double c0 = std::floor(((double)eb[a] - grow - org[a]) / res) - 1, c1 = std::ceil(((double)eb[a + 3] + grow - org[a]) / res) + 2;
+        if (c0 < lo_lim[a]) c0 = lo_lim[a];
+        if (c1 > hi_lim[a]) c1 = hi_lim[a];
+        if (c1 <= c0) { c0 = lo_lim[a]; c1 = lo_lim[a]; }  // nothing of the box in this slab
+        const unsigned first = ((unsigned)c0 - lo_lim[a]) / tsz[a], last = ((unsigned)c1 - lo_lim[a] + tsz[a] - 1) / tsz[a];
+        t0[a] = first;
+        tn[a] = last > first ? last - first : 0;
+      }
+    }
+    if (p->f_dc_origin) HIP_TRYM(launch_fn(p->f_dc_origin, g1, BLOCK, p->lds_bytes(lk) + 32, s, (const uint32_t*)p->d_code, (int)p->prog.nslots, (int)nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, (unsigned)zlo, (unsigned)zhi, ub, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], t0[0], t0[1], t0[2], tn[0], tn[1], tn[2], d_ctr));
     else
     if (lk == 4) LAUNCH_O(4); else if (lk == 2) LAUNCH_O(2); else LAUNCH_O(1);
 #undef LAUNCH_O

@@ -549,7 +549,8 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_origin_kernel(const uint32_t* __r
                                                              float oz, float res, int* __restrict__ grid, Cube* __restrict__ cubes,
                                                              unsigned long long cube_cap, unsigned zlo, unsigned zhi,
                                                              int use_box, float bx0, float by0, float bz0, float bx1, float by1,
-                                                             float bz1, DCCounters* __restrict__ ctr) {
+                                                             float bz1, unsigned tx0, unsigned ty0, unsigned tz0, unsigned ntx,
+                                                             unsigned nty, unsigned ntz, DCCounters* __restrict__ ctr) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
   unsigned* s_w = (unsigned*)(g_smem + (size_t)(nslots > 0 ? nslots : 1) * K * BLOCK);  // 4 wave totals
@@ -558,14 +559,15 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_origin_kernel(const uint32_t* __r
   // multi-GPU: this rank evaluates the z-slab [zlo, zhi) of the lattice (its own slab plus a one-cube halo).
   // Work tile = a compact 8 x 8 x 4K brick of cells (a wave = one 8x8 patch at K z-levels), not a K*256-long row:
   // spatially coherent waves are what lets D_SKIPFAR* drop the far children of a wide union for the whole wave.
+  // The host hands over the range of tiles to sweep: all of the slab, or -- for trees with an exact box -- the tiles
+  // that can hold a kept cube or a neighbour of one (box grown by the keep radius and two cells); cells outside that
+  // range are neither written here nor read by the later stages.
   const unsigned n = 1u << nshift;
-  const unsigned bxn = (n + 7u) >> 3;
-  const unsigned bzn = (zhi - zlo + 4u * K - 1u) / (4u * K);
-  const uint64_t ntiles = (uint64_t)bxn * bxn * bzn;
+  const uint64_t ntiles = (uint64_t)ntx * nty * ntz;
   const float maxDist = res * 2;
   unsigned long long my_evals = 0;
   for (uint64_t T = blockIdx.x; T < ntiles; T += gridDim.x) {  // block-uniform trip count
-    const unsigned tx = (unsigned)(T % bxn), ty = (unsigned)((T / bxn) % bxn), tz = (unsigned)(T / ((uint64_t)bxn * bxn));
+    const unsigned tx = tx0 + (unsigned)(T % ntx), ty = ty0 + (unsigned)((T / ntx) % nty), tz = tz0 + (unsigned)(T / ((uint64_t)ntx * nty));
     P3 p[K];
     float d[K];
     unsigned cx[K], cy[K], cz[K];
