@@ -288,6 +288,10 @@ static void spec_aux(gsdf_program* p) {
 extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
   if (!p) return fail(GSDF_ERR_BAD_ARGUMENT, "null program");
   if (p->spec_mod) return GSDF_OK;
+  // straight-line code grows with the program (multi-evaluation nodes are unrolled at lowering time): beyond a few
+  // thousand instructions the build takes minutes and the code no longer fits the instruction cache
+  if (gsdf_dev::spec_instruction_count(p->prog) > 4000)
+    return fail(GSDF_ERR_BAD_TREE, "program too large to specialise (more than 4000 instructions): the interpreter kernels stay in use");
   HIP_TRY(hipSetDevice(p->device));
   int lk, lw;
   size_t lds_m;
