@@ -43,6 +43,8 @@ struct Ctx {
   int max_slots = 0;
   size_t max_code;
   std::vector<int8_t> clob;  // memo: -1 unknown, 0/1
+  struct Table { size_t patch; float angle; int n; };
+  std::vector<Table> tables;  // D_CIRC_PRE sin/cos tables, emitted after D_END
   // Static tracking of "which P.xy value is live" so that hypot(P.x,P.y) can be shared by sibling
   // primitives (three cylinders and the screw of npt-flange all see the same x,y): every instruction
   // that rewrites x or y starts a new version; saved positions remember theirs.
@@ -384,6 +386,10 @@ void gen(Ctx& c, uint32_t i, int depth) {
       c.live.push_back({slotP, is2d});       // frames of the second pass find p0 here
       c.bump();                              // P = p1
       c.f((float)(2 * gsdf::kPi) / P[1]); c.f(P[1]); c.f((float)((int)P[0] - 1));
+      // the two rotations use sincos(angle * i) for an integer i < circleDiv: a table instead of two polynomial
+      // evaluations per point (same float32 routine and the same float32 product, computed here)
+      c.tables.push_back({c.code.size(), (float)(2 * gsdf::kPi) / P[1], (int)P[1]});
+      c.u(0);
       gen(c, c.child(n, 0), depth + 1);  // pos1 first
       c.op(D_SAVER, slotD);
       c.load_saved(slotP, is2d);
@@ -574,6 +580,15 @@ Program compile(const gsdf_tree& t, size_t max_code_words) {
   c.clob.assign(t.n_nodes, -1);
   gen(c, t.root, 0);
   c.op(D_END);
+  for (const Ctx::Table& tb : c.tables) {
+    if (tb.n < 1 || tb.n > 4096) continue;  // offset stays 0: the device computes
+    c.code[tb.patch] = (uint32_t)c.code.size();
+    for (int i = 0; i < tb.n; i++) {
+      float sn, cs;
+      gsdf::sincosf32(tb.angle * (float)i, sn, cs);
+      c.f(sn); c.f(cs);
+    }
+  }
   Program p;
   p.code = std::move(c.code);
   p.nslots = c.max_slots;

@@ -8,7 +8,8 @@
 // Slots are allocated statically by the host compiler, so there is no stack pointer at run time.
 //
 // Encoding: word0 = opcode (bits 0-11) | flags (bits 12-15) | slot<<16 ; then `nparam` 32-bit words.
-// The stream is straight-line except for D_SKIPFAR*, a forward wave-uniform skip.
+// The stream is straight-line except for D_SKIPFAR*, a forward wave-uniform skip. Read-only tables referenced by
+// instructions (D_CIRC_PRE) follow D_END.
 //   D_FLAG_HXY  (bit 14): hypot(P.x,P.y) of every point is already in the per-point `hxy` register (the host
 //                compiler proved P.xy unchanged since it was last computed): reuse instead of recomputing.
 //   D_FLAG_SHXY (bit 13): P.x and P.y are functions of the ENTRY x,y only (no z has been mixed in), and
@@ -68,7 +69,8 @@ enum DevOp : uint32_t {
   D_ELONGATE2D_PRE,// hx hy          slot <- min(max2(q),0)
   D_ARRAY_PRE,     // i j k sx sy sz nx ny nz   P = f(saved P at slot..slot+2)
   D_ARRAY2D_PRE,   // i j sx sy nx ny           P = f(saved P at slot..slot+1)
-  D_CIRC_PRE,      // angle ncirc ninsm1 : P = p1 ; slot..slot+1 <- p0.xy (3D keeps z in place)
+  D_CIRC_PRE,      // angle ncirc ninsm1 tab : P = p1 ; slot..slot+1 <- p0.xy (3D keeps z in place). tab: word offset of
+                   // the host-computed {sin, cos}(angle * i), i < ncirc, stored after D_END (0: compute on device)
   D_LOADP2_SUB,    // dx dy          P.xy = saved(slot..slot+1) - d
   // ---- distance post-ops: R = g(R)
   D_MULR,          // f
@@ -109,7 +111,7 @@ static const uint8_t kDevOpParams[D_OP_COUNT] = {
     /*HEX2D*/ 2, /*OCT2D*/ 2, /*ELLIPSE*/ 2, /*POLY*/ 3, /*LINES*/ 2,
     /*TRANSLATE*/ 3, /*SCALE_PRE*/ 1, /*SYMMETRY*/ 1, /*TRANSFORM*/ 12, /*TWIST*/ 1, /*ROT2D*/ 4,
     /*EXTRUDE_PRE*/ 1, /*REVOLVE_PRE*/ 1, /*SCREW_PRE*/ 6, /*ELONGATE_PRE*/ 3, /*ELONGATE2D_PRE*/ 2,
-    /*ARRAY_PRE*/ 9, /*ARRAY2D_PRE*/ 6, /*CIRC_PRE*/ 3, /*LOADP2_SUB*/ 2,
+    /*ARRAY_PRE*/ 9, /*ARRAY2D_PRE*/ 6, /*CIRC_PRE*/ 4, /*LOADP2_SUB*/ 2,
     /*MULR*/ 1, /*SHELL_POST*/ 1, /*ADDR*/ 1, /*ANNULUS*/ 1, /*EXTRUDE_POST*/ 0, /*MAXR_SLOT*/ 0, /*ADDR_SLOT*/ 0,
     /*SAVEP3*/ 0, /*LOADP3*/ 0, /*SAVEP2*/ 0, /*LOADP2*/ 0, /*SAVER*/ 0, /*SETSLOT*/ 1, /*SETR*/ 1,
     /*MIN*/ 0, /*MAX*/ 0, /*DIFF*/ 0, /*XOR*/ 0, /*SUNION*/ 2, /*SDIFF*/ 2, /*SINTER*/ 2,

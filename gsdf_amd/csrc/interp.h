@@ -687,14 +687,21 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
           float i0, i1;
           if (id >= ninsm1) { i0 = ninsm1; i1 = 0.f; } else { i0 = id; i1 = id + 1.f; }
           float s0, c0, s1, c1;
-          sincosf_(angle * i0, s0, c0);
-          sincosf_(angle * i1, s1, c1);
+          const uint32_t tab = PU(3);
+          if (tab) {  // i0, i1 are integers in [0, ncirc): {sin, cos}(angle * i) from the host's table (per-lane loads)
+            const uint32_t a0 = tab + 2u * (uint32_t)(int)i0, a1 = tab + 2u * (uint32_t)(int)i1;
+            s0 = __uint_as_float(code[a0]); c0 = __uint_as_float(code[a0 + 1]);
+            s1 = __uint_as_float(code[a1]); c1 = __uint_as_float(code[a1 + 1]);
+          } else {
+            sincosf_(angle * i0, s0, c0);
+            sincosf_(angle * i1, s1, c1);
+          }
           LDSF(slot) = c0 * p.x + s0 * p.y;
           LDSF(slot + 1) = (-s0) * p.x + c0 * p.y;
           float x1 = c1 * p.x + s1 * p.y, y1 = (-s1) * p.x + c1 * p.y;
           p.x = x1; p.y = y1;
         }
-        pc += 4;
+        pc += 5;
         break;
       }
       case D_LOADP2_SUB: {

@@ -35,7 +35,7 @@ def decode(code):
         pc += 1 + n
         if name == "D_END":
             break
-    assert pc == len(code)
+    assert pc <= len(code)   # read-only tables (D_CIRC_PRE sin/cos) may follow D_END
     return out
 
 
