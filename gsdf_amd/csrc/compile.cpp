@@ -188,6 +188,45 @@ bool exact_box(Ctx& c, uint32_t i, float bb[6], int depth = 0, bool* solid = nul
       bb[0] += P[0]; bb[3] += P[0]; bb[1] += P[1]; bb[4] += P[1]; bb[2] += tz; bb[5] += tz;
       return true;
     }
+    case GSDF_SCALE: case GSDF_SCALE2D: {  // f(p) = s * g(p / s): exact for exact g; the box scales with it
+      if (n.nchild != 1 || !(P[0] > 0) || !exact_box(c, c.child(n, 0), bb, depth + 1, solid)) return false;
+      for (int j = 0; j < 6; j++) bb[j] *= P[0];
+      return true;
+    }
+    case GSDF_TRANSFORM: case GSDF_ROTATION2D: {  // rigid motions only: p_local = A p + b with A orthonormal
+      if (n.nchild != 1) return false;
+      float A[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, b[3] = {0, 0, 0};
+      if (n.op == GSDF_TRANSFORM) {
+        if (n.aux_len < 16) return false;
+        const float* m = &c.t->aux[n.aux_off];
+        for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) A[r][q] = m[4 * r + q]; b[r] = m[4 * r + 3]; }
+      } else {
+        A[0][0] = P[0]; A[0][1] = P[1]; A[1][0] = P[2]; A[1][1] = P[3];
+      }
+      for (int r = 0; r < 3; r++)
+        for (int q = r; q < 3; q++) {
+          const double dot = (double)A[r][0] * A[q][0] + (double)A[r][1] * A[q][1] + (double)A[r][2] * A[q][2];
+          if (std::fabs(dot - (r == q ? 1.0 : 0.0)) > 1e-5) return false;  // scaling / shearing matrix: no claim
+        }
+      float lb[6];
+      if (!exact_box(c, c.child(n, 0), lb, depth + 1, solid)) return false;
+      for (int j = 0; j < 3; j++) { bb[j] = 3.0e38f; bb[j + 3] = -3.0e38f; }
+      for (int k = 0; k < 8; k++) {  // world corner = A^T (corner_local - b); pad by the matrix' deviation from orthonormal
+        const double cl[3] = {(double)lb[(k & 1) ? 3 : 0] - b[0], (double)lb[(k & 2) ? 4 : 1] - b[1], (double)lb[(k & 4) ? 5 : 2] - b[2]};
+        for (int j = 0; j < 3; j++) {
+          const double w = A[0][j] * cl[0] + A[1][j] * cl[1] + A[2][j] * cl[2];
+          bb[j] = std::fmin(bb[j], (float)w);
+          bb[j + 3] = std::fmax(bb[j + 3], (float)w);
+        }
+      }
+      // an almost-orthonormal matrix (1e-5) moves points by a relative 1e-5 at most: grow the box accordingly
+      double ext = 0;
+      for (int j = 0; j < 6; j++) ext = std::fmax(ext, std::fabs((double)bb[j]));
+      const float pad = (float)(ext * 4e-5 + 1e-30);
+      for (int j = 0; j < 3; j++) { bb[j] -= pad; bb[j + 3] += pad; }
+      if (n.op == GSDF_ROTATION2D) { bb[2] = 0; bb[5] = 0; }
+      return true;
+    }
     case GSDF_UNION: case GSDF_UNION2D: {
       float a[6];
       for (uint32_t k = 0; k < n.nchild; k++) {

@@ -144,7 +144,17 @@ def test_far_child_skip_in_wide_unions():
     names = lambda sh: [i[0] for i in decode(hip.lower(sh)[0])]
     assert names(mk(b.Translate2D(b.NewCircle(1), 9, 0))).count("D_SKIPFAR2D") == 4
     assert names(mk(b.Translate2D(b.NewEllipse(1, 0.5), 9, 0))).count("D_SKIPFAR2D") == 3
-    assert names(mk(b.Scale2D(b.NewCircle(1), 2.0))).count("D_SKIPFAR2D") == 3
+    assert names(mk(b.Offset2D(b.NewCircle(1), 0.1))).count("D_SKIPFAR2D") == 3
+    # uniform scaling and rigid motions keep the field exact: their (scaled / rotated, conservatively boxed) children qualify
+    assert names(mk(b.Scale2D(b.NewCircle(1), 2.0))).count("D_SKIPFAR2D") == 4
+    rot = hip.lower(mk(b.Translate2D(b.Rotate2D(b.NewRectangle(2, 1), 0.5), 9, 0)))[0]
+    ir = decode(rot)
+    assert [i[0] for i in ir].count("D_SKIPFAR2D") == 4
+    fr = rot.view(np.float32)
+    boxes = [tuple(fr[i[4] + 1:i[4] + 5]) for i in ir if i[0] == "D_SKIPFAR2D"]
+    rb = max(boxes, key=lambda q: q[0])                      # the rotated rectangle, translated to x = 9
+    half_w = 0.5 * (2 * abs(np.cos(0.5)) + 1 * abs(np.sin(0.5)))
+    assert abs((rb[2] - rb[0]) / 2 - half_w) < 1e-3 and abs((rb[0] + rb[2]) / 2 - 9) < 1e-3
     three = names(b.Union2D(b.NewCircle(1), b.Translate2D(b.NewCircle(1), 3, 0), b.Translate2D(b.NewCircle(1), 6, 0)))
     assert three.count("D_SKIPFAR2D") == 0 and three.count("D_UBOUND2D") == 0
     # fewer than three boxed children: no upper bound, the first child is always evaluated
