@@ -400,7 +400,8 @@ extern "C" uint64_t gsdf_hip_evaluations(const gsdf_program* p) { return p ? p->
 static int eval_dev(gsdf_program* p, int dim, const void* d_pos, size_t stride_bytes, float* d_dist, size_t n, hipStream_t s) {
   if (stride_bytes % 4 != 0 || stride_bytes < (size_t)dim * 4) return fail(GSDF_ERR_BAD_ARGUMENT, "bad position stride");
   const int k = p->batch_k();
-  const unsigned grid = grid_for((n + k - 1) / k, p->num_cu, 8);
+  static const int eval_bpc = [] { const char* e = getenv("GSDF_HIP_EVAL_BPC"); return e ? atoi(e) : 64; }();  // tuning knob: finer grids drain evenly (8 -> 64 per CU: +10 % on npt-flange)
+  const unsigned grid = grid_for((n + k - 1) / k, p->num_cu, eval_bpc);
   const uint32_t sf = (uint32_t)(stride_bytes / 4);
   const float* q = (const float*)d_pos;
   const uint64_t nn = (uint64_t)n;
@@ -620,8 +621,9 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
       const uint64_t full = (levels - lq) * 3 >= 40 ? UINT64_MAX : ((uint64_t)1 << (3 * (levels - 1)));
       if (bound > full) bound = full;
       const unsigned long long tcap = opts.max_tris ? opts.max_tris : m->cap;
+      static const int leaf_bpc = [] { const char* e = getenv("GSDF_HIP_LEAF_BPC"); return e ? atoi(e) : 64; }();  // grid = up to 64 workgroups per CU (4 resident): a few grid-stride iterations each, so the CUs drain evenly at the end (8 per CU: +8 % kernel time; one iteration per workgroup: +10 %)
 #define LAUNCH_LEAF(KK, WW)                                                                                           \
-  hipLaunchKernelGGL((leaf_kernel<KK, WW>), dim3(grid_for(bound, p->num_cu, 8)), dim3(BLOCK), lds_m, s, p->d_code,      \
+  hipLaunchKernelGGL((leaf_kernel<KK, WW>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), lds_m, s, p->d_code,      \
                      (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res,  \
                      m->d_tris, tcap, d_ctr)
       if (lq == 3 && lk == 4 && opts.share_corners) {
@@ -632,7 +634,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
                            p->prog.nslots, ox, oy, oz, res, m->d_tris, tcap, d_ctr);
         used_brick = true;
       } else if (p->f_leaf && p->spec_leaf_k == lk && p->spec_leaf_w == lw) {
-        HIP_TRYM(launch_fn(p->f_leaf, grid_for(bound, p->num_cu, 8), BLOCK, lds_m, s, (const uint32_t*)p->d_code, (const Cube*)q[lq & 1]->p,
+        HIP_TRYM(launch_fn(p->f_leaf, grid_for(bound, p->num_cu, leaf_bpc), BLOCK, lds_m, s, (const uint32_t*)p->d_code, (const Cube*)q[lq & 1]->p,
                            (unsigned long long)capq[lq & 1], (int)lq, (int)p->prog.nslots, ox, oy, oz, res, m->d_tris,
                            (unsigned long)tcap, d_ctr));
       } else {
@@ -792,7 +794,7 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(DCCounters), s));
     if (shard_count > 1) HIP_TRYM(hipMemsetAsync(grid.p, 0xff, ncell * sizeof(int), s));  // cells outside the slab read as empty
     HIP_TRYM(hipEventRecord(p->ev[0], s));
-    const unsigned g1 = grid_for((nslab + lk - 1) / lk, p->num_cu, 8);
+    const unsigned g1 = grid_for((nslab + lk - 1) / lk, p->num_cu, 32);
 #define LAUNCH_O(KK) hipLaunchKernelGGL((dc_origin_kernel<KK>), dim3(g1), dim3(BLOCK), p->lds_bytes(KK) + 32, s, p->d_code, p->prog.nslots, nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, zlo, zhi, ub, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], t0[0], t0[1], t0[2], tn[0], tn[1], tn[2], d_ctr)
     spec_aux(p);
     const int ub = p->prog.has_exact_bb ? 1 : 0;
