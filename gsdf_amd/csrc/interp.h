@@ -129,6 +129,31 @@ __device__ __forceinline__ bool all_far(const P3 (&pv)[K], const float (&a)[K], 
   return __all(far) != 0;
 }
 
+// hypot of the K points of a lane for the "outside distance" terms hypot(max(a,0), max(b,0)) of boxes, cylinders, prisms
+// and extrusions. Near a face of such a shape one argument is 0 for every point of a (spatially coherent) wave, and
+// math32.Hypot(p, 0) is p exactly (q/p = 0, sqrt(1 + 0) = 1, p * 1 = p): the wave then skips the division and the
+// square root. Same bits either way; the test is one compare per point and a wave vote.
+template <int K>
+__device__ __forceinline__ void hypot_k(const float (&a)[K], const float (&b)[K], float (&out)[K]) {
+  using namespace dm;
+  float hi[K], lo[K];
+  bool z = true;
+  KLOOP {
+    const float p = absf(a[kp]), q = absf(b[kp]);
+    hi[kp] = maxf(p, q);
+    lo[kp] = minf(p, q);
+    z = z && (lo[kp] == 0.0f);
+  }
+  if (__all(z)) {
+    KLOOP out[kp] = hi[kp];
+  } else {
+    KLOOP {
+      const float r = lo[kp] / maxf(hi[kp], 1.401298464324817e-45f);
+      out[kp] = hi[kp] * sqrt_1to2(1.0f + r * r);
+    }
+  }
+}
+
 // PAIRED (the mesher's leaf kernels only): the caller passes the corners of one leaf cube in the order
 // {0,4,1,5 | 3,7,2,6}, i.e. points 2j and 2j+1 enter with bitwise equal x,y and (K = 4) points j and j+2 with equal z.
 // Instructions the host compiler flagged D_FLAG_SHXY / D_FLAG_SHZ then compute their f(P.x,P.y) / g(P.z) once per
@@ -170,12 +195,18 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       case D_BOX: {
-        KLOOP {
-          [[maybe_unused]] P3& p = pv[kp];
-          [[maybe_unused]] float& R = Rv[kp];
+        {
           const float r = PF(3);
-          float qx = (absf(p.x) - PF(0)) + r, qy = (absf(p.y) - PF(1)) + r, qz = (absf(p.z) - PF(2)) + r;
-          R = norm3(maxf(qx, 0.f), maxf(qy, 0.f), maxf(qz, 0.f)) + minf(maxf(qx, maxf(qy, qz)), 0.0f) - r;
+          float mx[K], my[K], mz[K], in[K], hyz[K], n3[K];
+          KLOOP {
+            const P3& p = pv[kp];
+            const float qx = (absf(p.x) - PF(0)) + r, qy = (absf(p.y) - PF(1)) + r, qz = (absf(p.z) - PF(2)) + r;
+            mx[kp] = maxf(qx, 0.f); my[kp] = maxf(qy, 0.f); mz[kp] = maxf(qz, 0.f);
+            in[kp] = minf(maxf(qx, maxf(qy, qz)), 0.0f);
+          }
+          hypot_k<K>(my, mz, hyz);   // ms3.Norm = hypot(x, hypot(y, z))
+          hypot_k<K>(mx, hyz, n3);
+          KLOOP Rv[kp] = n3[kp] + in[kp] - r;
         }
         pc += 5;
         break;
@@ -211,25 +242,31 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_CYL0: {
         ENSURE_HXY();
-        KLOOP {
-          [[maybe_unused]] P3& p = pv[kp];
-          [[maybe_unused]] float& R = Rv[kp];
-          float dx = hxy[kp] - PF(0);
-          float dy = absf(p.z) - PF(1);
-          R = minf(0.f, maxf(dx, dy)) + hypotf_(maxf(0.f, dx), maxf(0.f, dy));
+        {
+          float ax[K], ay[K], in[K], h[K];
+          KLOOP {
+            const float dx = hxy[kp] - PF(0), dy = absf(pv[kp].z) - PF(1);
+            in[kp] = minf(0.f, maxf(dx, dy));
+            ax[kp] = maxf(0.f, dx); ay[kp] = maxf(0.f, dy);
+          }
+          hypot_k<K>(ax, ay, h);
+          KLOOP Rv[kp] = in[kp] + h[kp];
         }
         pc += 3;
         break;
       }
       case D_CYLR: {
         ENSURE_HXY();
-        KLOOP {
-          [[maybe_unused]] P3& p = pv[kp];
-          [[maybe_unused]] float& R = Rv[kp];
+        {
           const float round = PF(2);
-          float dx = hxy[kp] - PF(0) + round;
-          float dy = absf(p.z) - PF(1);
-          R = minf(maxf(dx, dy), 0.f) + hypotf_(maxf(dx, 0.f), maxf(dy, 0.f)) - round;
+          float ax[K], ay[K], in[K], h[K];
+          KLOOP {
+            const float dx = hxy[kp] - PF(0) + round, dy = absf(pv[kp].z) - PF(1);
+            in[kp] = minf(maxf(dx, dy), 0.f);
+            ax[kp] = maxf(dx, 0.f); ay[kp] = maxf(dy, 0.f);
+          }
+          hypot_k<K>(ax, ay, h);
+          KLOOP Rv[kp] = in[kp] + h[kp] - round;
         }
         pc += 4;
         break;
@@ -354,12 +391,16 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       case D_RECT2D: {
+        float rax[K], ray[K], rh[K];
         KLOOP {
           [[maybe_unused]] P3& p = pv[kp];
           [[maybe_unused]] float& R = Rv[kp];
           float dx = absf(p.x) - PF(0), dy = absf(p.y) - PF(1);
-          R = norm2(maxf(dx, 0.f), maxf(dy, 0.f)) + minf(0.f, maxf(dx, dy));
+          rax[kp] = maxf(dx, 0.f); ray[kp] = maxf(dy, 0.f);
+          R = minf(0.f, maxf(dx, dy));
         }
+        hypot_k<K>(rax, ray, rh);
+        KLOOP Rv[kp] = rh[kp] + Rv[kp];
         pc += 3;
         break;
       }
@@ -720,12 +761,16 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       case D_ADDR: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = R + PF(0); } pc += 2; break; }
       case D_ANNULUS: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = absf(R) - PF(0); } pc += 2; break; }
       case D_EXTRUDE_POST: {
+        float eax[K], eay[K], eh[K];
         KLOOP {
           [[maybe_unused]] P3& p = pv[kp];
           [[maybe_unused]] float& R = Rv[kp];
           float wy = LDSF(slot);
-          R = minf(0.f, maxf(R, wy)) + hypotf_(maxf(R, 0.f), maxf(wy, 0.f));
+          eax[kp] = maxf(R, 0.f); eay[kp] = maxf(wy, 0.f);
+          R = minf(0.f, maxf(R, wy));
         }
+        hypot_k<K>(eax, eay, eh);
+        KLOOP Rv[kp] = Rv[kp] + eh[kp];
         pc += 1;
         break;
       }

@@ -36,7 +36,7 @@ def test_generated_source_follows_the_program():
     assert [int(p) for p, _ in blocks] == sorted(int(p) for p, _ in blocks)
     assert "switch (op)" not in src and "readfirstlane" not in src
     # the statements are the interpreter's own: a characteristic line of the cylinder case appears verbatim
-    assert "R = minf(0.f, maxf(dx, dy)) + hypotf_(maxf(0.f, dx), maxf(0.f, dy));" in src
+    assert "hypot_k<K>(ax, ay, h);" in src and "in[kp] = minf(0.f, maxf(dx, dy));" in src
     # short buffer is reported, not overrun
     t = sh.tree()
     n = C.c_size_t()
