@@ -154,6 +154,24 @@ __device__ __forceinline__ void hypot_k(const float (&a)[K], const float (&b)[K]
   }
 }
 
+// Blend weight of the smooth combines, h = clamp(0.5 + sign * num / k, 0, 1) for the K points of a lane. Away from the
+// blend zone -- |num| >= 0.5005 k for every point of the wave -- the quotient is beyond +-0.5 whatever its rounding, so
+// the clamp yields exactly 0 or 1 and the division is skipped (wave vote); the callers' formulas run unchanged on h.
+template <int K, int SIGN>
+__device__ __forceinline__ void smooth_h(const float (&num)[K], float k, float rk, float (&h)[K]) {
+  using namespace dm;
+  const float thr = absf(0.5f * k) * 1.001f;
+  bool out = k != 0.0f;
+  KLOOP out = out && (absf(num[kp]) >= thr);
+  if (__all(out)) {
+    KLOOP h[kp] = (((num[kp] > 0.0f) == (k > 0.0f)) == (SIGN > 0)) ? 1.0f : 0.0f;
+  } else {
+    float q[K];
+    div_uniform_k<K>(num, k, rk, q);
+    KLOOP h[kp] = clampf(SIGN > 0 ? 0.5f + q[kp] : 0.5f - q[kp], 0.f, 1.f);
+  }
+}
+
 // PAIRED (the mesher's leaf kernels only): the caller passes the corners of one leaf cube in the order
 // {0,4,1,5 | 3,7,2,6}, i.e. points 2j and 2j+1 enter with bitwise equal x,y and (K = 4) points j and j+2 with equal z.
 // Instructions the host compiler flagged D_FLAG_SHXY / D_FLAG_SHZ then compute their f(P.x,P.y) / g(P.z) once per
@@ -792,18 +810,18 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       case D_COMBINE_SUNION: {
         {
           const float k = PF(0), rk = PF(1);  // (0.5*(b -+ a)) / k by a wave-uniform k: exact reciprocal form
-          float av[K], bv[K], num[K], q[K];
+          float av[K], bv[K], num[K], hv[K];
           KLOOP {
             float a = LDSF(slot), b = Rv[kp];
             if (swap_ab) { float t = a; a = b; b = t; }
             av[kp] = a; bv[kp] = b;
             num[kp] = 0.5f * (b - a);
           }
-          div_uniform_k<K>(num, k, rk, q);
+          smooth_h<K, 1>(num, k, rk, hv);
           KLOOP {
             float& R = Rv[kp];
             const float a = av[kp], b = bv[kp];
-            float h = clampf(0.5f + q[kp], 0.f, 1.f);
+            const float h = hv[kp];
             R = mixf(b, a, h) - k * h * (1.f - h);
           }
         }
@@ -813,18 +831,18 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       case D_COMBINE_SDIFF: {
         {
           const float k = PF(0), rk = PF(1);  // (0.5*(b -+ a)) / k by a wave-uniform k: exact reciprocal form
-          float av[K], bv[K], num[K], q[K];
+          float av[K], bv[K], num[K], hv[K];
           KLOOP {
             float a = LDSF(slot), b = Rv[kp];
             if (swap_ab) { float t = a; a = b; b = t; }
             av[kp] = a; bv[kp] = b;
             num[kp] = 0.5f * (b + a);
           }
-          div_uniform_k<K>(num, k, rk, q);
+          smooth_h<K, -1>(num, k, rk, hv);
           KLOOP {
             float& R = Rv[kp];
             const float a = av[kp], b = bv[kp];
-            float h = clampf(0.5f - q[kp], 0.f, 1.f);
+            const float h = hv[kp];
             R = mixf(a, -b, h) + k * h * (1.f - h);
           }
         }
@@ -834,18 +852,18 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       case D_COMBINE_SINTER: {
         {
           const float k = PF(0), rk = PF(1);  // (0.5*(b -+ a)) / k by a wave-uniform k: exact reciprocal form
-          float av[K], bv[K], num[K], q[K];
+          float av[K], bv[K], num[K], hv[K];
           KLOOP {
             float a = LDSF(slot), b = Rv[kp];
             if (swap_ab) { float t = a; a = b; b = t; }
             av[kp] = a; bv[kp] = b;
             num[kp] = 0.5f * (b - a);
           }
-          div_uniform_k<K>(num, k, rk, q);
+          smooth_h<K, -1>(num, k, rk, hv);
           KLOOP {
             float& R = Rv[kp];
             const float a = av[kp], b = bv[kp];
-            float h = clampf(0.5f - q[kp], 0.f, 1.f);
+            const float h = hv[kp];
             R = mixf(b, a, h) + k * h * (1.f - h);
           }
         }
