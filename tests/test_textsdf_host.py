@@ -96,6 +96,9 @@ def test_errors_like_reference():
         b.TextLine(TTF, "A", reltol=1.0)
     with pytest.raises(ShapeError, match="sfnt"):
         b.TextLine(b"\x00\x01\x00\x00garbage", "A")
+    assert b.TextLine(TTF, "Ø12 äöü").Bounds()[3] > 2.0       # multi-byte runes through the cmap
+    with pytest.raises(ShapeError, match="glyph has no contours"):
+        b.TextLine(TTF, "€")                                  # unmapped rune -> .notdef, which this font leaves empty (font.go:235)
     single = b.TextLine(TTF, "I")                            # one glyph: the translated glyph itself, no union
     assert b.op(single.id) == OP["TRANSLATE2D"]
 
