@@ -230,19 +230,24 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       case D_BOXFRAME: {
-        KLOOP {
-          [[maybe_unused]] P3& p = pv[kp];
-          [[maybe_unused]] float& R = Rv[kp];
+        {
+          // three "outside distance" norms of clamped components: ms3.Norm = hypot(x, hypot(y, z)) through hypot_k
           const float e = PF(0);
-          float px = absf(p.x) - PF(1), py = absf(p.y) - PF(2), pz = absf(p.z) - PF(3);
-          float qx = absf(px + e) + (-e), qy = absf(py + e) + (-e), qz = absf(pz + e) + (-e);
-          float s1 = minf(0.f, maxf(px, maxf(qy, qz)));
-          float n1 = norm3(maxf(px, 0.f), maxf(qy, 0.f), maxf(qz, 0.f)) + s1;
-          float s2 = minf(0.f, maxf(qx, maxf(py, qz)));
-          float n2 = norm3(maxf(qx, 0.f), maxf(py, 0.f), maxf(qz, 0.f)) + s2;
-          float s3 = minf(0.f, maxf(qx, maxf(qy, pz)));
-          float n3 = norm3(maxf(qx, 0.f), maxf(qy, 0.f), maxf(pz, 0.f)) + s3;
-          R = minf(n1, minf(n2, n3));
+          float ax[K], ay[K], az[K], bx[K], by[K], bz[K], s1[K], s2[K], s3[K], t[K], n1[K], n2[K], n3[K];
+          KLOOP {
+            const P3& p = pv[kp];
+            const float px = absf(p.x) - PF(1), py = absf(p.y) - PF(2), pz = absf(p.z) - PF(3);
+            const float qx = absf(px + e) + (-e), qy = absf(py + e) + (-e), qz = absf(pz + e) + (-e);
+            s1[kp] = minf(0.f, maxf(px, maxf(qy, qz)));
+            s2[kp] = minf(0.f, maxf(qx, maxf(py, qz)));
+            s3[kp] = minf(0.f, maxf(qx, maxf(qy, pz)));
+            ax[kp] = maxf(px, 0.f); ay[kp] = maxf(py, 0.f); az[kp] = maxf(pz, 0.f);
+            bx[kp] = maxf(qx, 0.f); by[kp] = maxf(qy, 0.f); bz[kp] = maxf(qz, 0.f);
+          }
+          hypot_k<K>(by, bz, t); hypot_k<K>(ax, t, n1);   // norm3(max(px,0), max(qy,0), max(qz,0))
+          hypot_k<K>(ay, bz, t); hypot_k<K>(bx, t, n2);   // norm3(max(qx,0), max(py,0), max(qz,0))
+          hypot_k<K>(by, az, t); hypot_k<K>(bx, t, n3);   // norm3(max(qx,0), max(qy,0), max(pz,0))
+          KLOOP Rv[kp] = minf(n1[kp] + s1[kp], minf(n2[kp] + s2[kp], n3[kp] + s3[kp]));
         }
         pc += 5;
         break;
@@ -290,6 +295,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       case D_HEX: {
+        float hax[K], hay[K], hh[K];
         KLOOP {
           [[maybe_unused]] P3& p = pv[kp];
           [[maybe_unused]] float& R = Rv[kp];
@@ -301,8 +307,11 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
           py -= 1.0f * pm;
           float d1 = hypotf_(px - clampf(px, -clm, clm), py - h1) * signf(py - h1);
           float d2 = pz - h2;
-          R = minf(maxf(d1, d2), 0.f) + hypotf_(maxf(d1, 0.f), maxf(d2, 0.f));
+          hax[kp] = maxf(d1, 0.f); hay[kp] = maxf(d2, 0.f);
+          R = minf(maxf(d1, d2), 0.f);
         }
+        hypot_k<K>(hax, hay, hh);
+        KLOOP Rv[kp] = Rv[kp] + hh[kp];
         pc += 4;
         break;
       }
