@@ -65,14 +65,14 @@ struct gsdf_program {
       return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-  } q0, q1, ctr, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge;  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell)
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  } q0, q1, ctr, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, flat_grid;  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   uint64_t last_tris = 0;  // triangle count of the previous mesh on this handle: sizes the next output buffer
   uint64_t last_dc_cubes = 0;  // kept cubes of the previous dual contouring pass: sizes the next queues
   // run-time specialised kernels for this program (gsdf_hip_program_specialize): hiprtc module, else interpreter
   hipModule_t spec_mod = nullptr, spec_mod2 = nullptr;  // spec_mod2: second group, built on first use (see spec_aux)
   hipFunction_t f_eval = nullptr, f_prune = nullptr, f_leaf = nullptr;
-  hipFunction_t f_dc_origin = nullptr, f_dc_edges = nullptr, f_dc_normals = nullptr, f_normals = nullptr, f_image = nullptr;
+  hipFunction_t f_dc_origin = nullptr, f_dc_edges = nullptr, f_dc_normals = nullptr, f_normals = nullptr, f_image = nullptr, f_flat_grid = nullptr;
   bool spec_aux_tried = false;
   int spec_eval_k = 0, spec_leaf_k = 0, spec_leaf_w = 0;
   double spec_compile_s = 0;
@@ -266,7 +266,7 @@ static int spec_build(gsdf_program* p, const std::vector<std::string>& names, hi
 }
 
 // Second group of a specialised handle, built the first time one of these entry points runs: the evaluating kernels of
-// dual contouring, central-difference normals and the 2-D image renderer. Failure leaves the interpreter kernels in use.
+// dual contouring, central-difference normals, the flat renderer's lattice pass and the 2-D image renderer. Failure leaves the interpreter kernels in use.
 static void spec_aux(gsdf_program* p) {
   if (!p->spec_mod || p->spec_aux_tried) return;
   p->spec_aux_tried = true;
@@ -275,9 +275,9 @@ static void spec_aux(gsdf_program* p) {
   if (p->prog.is2d) {
     if (spec_build(p, {"image2_kernel<" + k + ">"}, &p->spec_mod2, f, &p->spec_compile_s) == GSDF_OK) p->f_image = f[0];
   } else {
-    if (spec_build(p, {"dc_origin_kernel<" + k + ">", "dc_edges_kernel", "dc_normals_kernel", "normals_kernel"}, &p->spec_mod2, f,
-                   &p->spec_compile_s) == GSDF_OK) {
-      p->f_dc_origin = f[0]; p->f_dc_edges = f[1]; p->f_dc_normals = f[2]; p->f_normals = f[3];
+    if (spec_build(p, {"dc_origin_kernel<" + k + ">", "dc_edges_kernel", "dc_normals_kernel", "normals_kernel", "flat_grid_kernel<" + k + ">"},
+                   &p->spec_mod2, f, &p->spec_compile_s) == GSDF_OK) {
+      p->f_dc_origin = f[0]; p->f_dc_edges = f[1]; p->f_dc_normals = f[2]; p->f_normals = f[3]; p->f_flat_grid = f[4];
     }
   }
 }
@@ -343,7 +343,7 @@ extern "C" int gsdf_hip_specialize_check(const gsdf_tree* tree, size_t* code_obj
     std::vector<std::string> low;
     std::string log;
     const std::vector<std::string> names = pr.is2d ? std::vector<std::string>{"eval_kernel<2, 4>"}
-                                                   : std::vector<std::string>{"eval_kernel<3, 4>", "prune_kernel", "leaf_kernel<4, 4>"};
+                                                   : std::vector<std::string>{"eval_kernel<3, 4>", "prune_kernel", "leaf_kernel<4, 4>", "flat_grid_kernel<4>"};
     if (!gsdf_dev::spec_compile(pr, "gfx950", names, co, low, log)) return fail(GSDF_ERR_HIP, "specialised build failed:\n" + log);
     if (code_object_bytes) *code_object_bytes = co.size();
     return GSDF_OK;
@@ -377,7 +377,7 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (p->spec_mod) (void)hipModuleUnload(p->spec_mod);
   if (p->spec_mod2) (void)hipModuleUnload(p->spec_mod2);
   p->q0.release(); p->q1.release(); p->ctr.release();
-  p->dc_grid.release(); p->dc_dist.release(); p->dc_fv.release(); p->dc_nrm.release(); p->dc_edge.release();
+  p->flat_grid.release(); p->dc_grid.release(); p->dc_dist.release(); p->dc_fv.release(); p->dc_nrm.release(); p->dc_edge.release();
   for (auto e : p->ev) if (e) (void)hipEventDestroy(e);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
@@ -864,6 +864,124 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
   m->st.active_leaves = hc.n_edges;
   m->st.ms_total = ms;
   p->evals += m->st.evals;
+  *out = m;
+  return GSDF_OK;
+#undef HIP_TRYM
+}
+
+// glrender.FlatRenderer (flatrenderer.go:36-256) on device: Reset's lattice, evalGrid into a dense grid in HBM,
+// ReadTriangles as one marching-cubes pass over every cube. Multi-GPU: z-slabs of cubes like the reference's goroutines
+// (:120-122); a rank evaluates the planes its cubes touch (one shared plane per boundary is recomputed, nothing exchanged).
+extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, int shard_count, void* stream, gsdf_mesh** out) {
+  if (!p || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
+  if (!(res > 0) || std::isnan(res) || std::isinf(res)) return fail(GSDF_ERR_RESOLUTION, "invalid renderer cube resolution");
+  if (shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return fail(GSDF_ERR_BAD_ARGUMENT, "bad shard rank/count");
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  // Reset (:36-80)
+  float mn[3], mx[3];
+  scale_centered(p->prog.bb, 1.01f, mn, mx);
+  double nd[3];
+  for (int a = 0; a < 3; a++) nd[a] = (double)std::ceil((mx[a] - mn[a]) / res);
+  if (!(nd[0] > 0) || !(nd[1] > 0) || !(nd[2] > 0)) return fail(GSDF_ERR_RESOLUTION, "resolution not fine enough for marching cubes");
+  if (nd[0] > 65534 || nd[1] > 65534 || nd[2] > 1e9 || (nd[0] + 1) * (nd[1] + 1) >= 4294967296.0)
+    return fail(GSDF_ERR_RESOLUTION, "resolution too fine for the flat renderer's lattice");
+  const unsigned nx = (unsigned)nd[0], ny = (unsigned)nd[1], nz = (unsigned)nd[2];
+  const unsigned sx = nx + 1, sy = ny + 1;
+  const uint64_t sxy = (uint64_t)sx * sy;
+  const float ox = mn[0], oy = mn[1], oz = mn[2];
+  // this rank's cubes in z and the lattice planes they touch
+  const unsigned c0 = (unsigned)(((uint64_t)nz * (uint64_t)shard_rank) / (uint64_t)shard_count);
+  const unsigned c1 = (unsigned)(((uint64_t)nz * (uint64_t)(shard_rank + 1)) / (uint64_t)shard_count);
+  const unsigned ncz = c1 - c0, nk = ncz ? ncz + 1 : 0;
+
+  gsdf_mesh* m = new (std::nothrow) gsdf_mesh();
+  if (!m) return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory");
+  m->device = p->device; m->stream = s;
+  m->st.levels = 0; m->st.res = res;
+  m->st.origin[0] = ox; m->st.origin[1] = oy; m->st.origin[2] = oz;
+  auto bail = [&](int code) { gsdf_hip_mesh_destroy(m); return code; };
+#define HIP_TRYM(expr)                                                                                          \
+  do {                                                                                                          \
+    hipError_t _e = (expr);                                                                                     \
+    if (_e != hipSuccess) return bail(fail(GSDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
+  } while (0)
+  if (ncz == 0) { *out = m; return GSDF_OK; }  // more ranks than cube planes: nothing for this one
+  for (auto& e : p->ev)
+    if (!e) HIP_TRYM(hipEventCreate(&e));
+  HIP_TRYM(p->ctr.ensure(sizeof(MeshCounters)));
+  MeshCounters* d_ctr = (MeshCounters*)p->ctr.p;
+  if (p->flat_grid.ensure(sxy * nk * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();
+    return bail(fail(GSDF_ERR_CAPACITY, "flat renderer: no device memory for the distance grid (" + std::to_string(sxy * nk * 4) + " bytes)"));
+  }
+  float* grid = (float*)p->flat_grid.p;
+  const int ek = p->batch_k();
+  spec_aux(p);
+  HIP_TRYM(hipEventRecord(p->ev[0], s));
+  {
+    const int hcols = ek >= 2 ? ek / 2 : 1, zz = ek >= 2 ? 2 : 1;
+    const uint64_t npass = ((sxy + (uint64_t)BLOCK * hcols - 1) / ((uint64_t)BLOCK * hcols)) * ((nk + zz - 1) / zz);
+    static const int bpc = [] { const char* e = getenv("GSDF_HIP_EVAL_BPC"); return e ? atoi(e) : 64; }();
+    const uint64_t gmax = (uint64_t)p->num_cu * (uint64_t)(bpc > 0 ? bpc : 64);
+    const unsigned g = (unsigned)(npass < gmax ? npass : gmax);
+    if (p->f_flat_grid) HIP_TRYM(launch_fn(p->f_flat_grid, g, BLOCK, p->lds_bytes(ek), s, (const uint32_t*)p->d_code, ox, oy, oz, res, sx, sy, c0, nk, grid));
+    else if (ek == 4) hipLaunchKernelGGL((flat_grid_kernel<4>), dim3(g), dim3(BLOCK), p->lds_bytes(4), s, p->d_code, ox, oy, oz, res, sx, sy, c0, nk, grid);
+    else if (ek == 2) hipLaunchKernelGGL((flat_grid_kernel<2>), dim3(g), dim3(BLOCK), p->lds_bytes(2), s, p->d_code, ox, oy, oz, res, sx, sy, c0, nk, grid);
+    else hipLaunchKernelGGL((flat_grid_kernel<1>), dim3(g), dim3(BLOCK), p->lds_bytes(1), s, p->d_code, ox, oy, oz, res, sx, sy, c0, nk, grid);
+    HIP_TRYM(hipGetLastError());
+  }
+  HIP_TRYM(hipEventRecord(p->ev[1], s));
+  // ReadTriangles: the triangle count is not known in advance; the pass is cheap (HBM-bound over the grid), so a
+  // buffer that turns out too small is replaced by one of the exact size and only this pass is repeated.
+  MeshCounters hc{};
+  uint64_t want = p->last_tris ? p->last_tris + p->last_tris / 16 + 1024 : (uint64_t)1 << 20;
+  float ms_march = 0;
+  for (int attempt = 0;; attempt++) {
+    if (!m->d_tris) {
+      m->d_tris = pool_take(p->device, want, &m->cap);
+      if (!m->d_tris) { HIP_TRYM(hipMalloc((void**)&m->d_tris, want * 36)); m->cap = want; }
+    }
+    HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(MeshCounters), s));
+    HIP_TRYM(hipEventRecord(p->ev[2], s));
+    const uint64_t npass = (uint64_t)((nx + 63) / 64) * ((ny + 4 * FLAT_ROWS - 1) / (4 * FLAT_ROWS)) * ncz;
+    if ((double)npass + 1e6 >= 4294967296.0) return bail(fail(GSDF_ERR_RESOLUTION, "resolution too fine for the flat renderer's lattice"));
+    static const int mbpc = [] { const char* e = getenv("GSDF_HIP_FLAT_BPC"); return e ? atoi(e) : 32; }();  // tuning knob
+    const uint64_t gmax = (uint64_t)p->num_cu * (uint64_t)(mbpc > 0 ? mbpc : 32);
+    const size_t lds = (size_t)5 * BLOCK * FLAT_ROWS * 2 + (size_t)BLOCK * FLAT_ROWS + 4096 + FLAT_STAGE * 36 + 64;
+    hipLaunchKernelGGL(flat_march_kernel, dim3((unsigned)(npass < gmax ? npass : gmax)), dim3(BLOCK), lds, s, (const float*)grid, nx, ny, ncz, c0,
+                       ox, oy, oz, res, m->d_tris, (uint64_t)m->cap, d_ctr);
+    HIP_TRYM(hipGetLastError());
+    HIP_TRYM(hipEventRecord(p->ev[3], s));
+    HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));
+    HIP_TRYM(hipStreamSynchronize(s));
+    if (hc.overflow) {
+      if (attempt >= 4) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
+      pool_give(p->device, m->d_tris, m->cap);
+      m->d_tris = nullptr; m->cap = 0;
+      want = hc.n_tris + hc.n_tris / 16 + 1024;
+      continue;
+    }
+    break;
+  }
+  float ms_grid = 0;
+  HIP_TRYM(hipEventElapsedTime(&ms_march, p->ev[2], p->ev[3]));  // the last (successful) marching pass
+  HIP_TRYM(hipEventElapsedTime(&ms_grid, p->ev[0], p->ev[1]));
+  m->st.n_tris = hc.n_tris;
+  m->st.evals = sxy * nk;  // FlatRenderer.Evaluations(): every lattice corner once
+  m->st.evals_prune = 0;
+  m->st.evals_leaf = m->st.evals;
+  m->st.pruned_leaves = 0;
+  m->st.leaf_cubes = (uint64_t)nx * ny * ncz;
+  m->st.active_leaves = hc.n_active;
+  m->st.ms_prune = 0;
+  m->st.ms_leaf = ms_grid;
+  m->st.ms_march = ms_march;
+  m->st.ms_total = (double)ms_grid + (double)ms_march;
+  p->evals += m->st.evals;
+  p->last_tris = hc.n_tris;
   *out = m;
   return GSDF_OK;
 #undef HIP_TRYM

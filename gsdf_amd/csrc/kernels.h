@@ -222,7 +222,7 @@ __device__ __forceinline__ void mc_interp(float ax, float ay, float az, float bx
 // Marching cubes of one leaf per lane + block-wide triangle emission (shared by both leaf kernels).
 // vslot: the lane's 8 corner distances in its LDS column; index: the 8-bit inside mask (0 = no triangles).
 // Block-uniform control flow: every thread of the workgroup must call this the same number of times.
-template <typename CornerDist>
+template <int STAGE = TRI_STAGE, typename CornerDist>
 __device__ __forceinline__ void mc_emit_block(unsigned index, float x0, float y0, float z0, float x1, float y1, float z1,
                                               CornerDist vdist, const int8_t* s_tri, float* s_stage, unsigned* s_misc,
                                               unsigned long long* s_base, float* __restrict__ tris, uint64_t tri_cap,
@@ -246,9 +246,9 @@ __device__ __forceinline__ void mc_emit_block(unsigned index, float x0, float y0
   const unsigned total = w0 + w1 + w2 + w3;
   const unsigned wpre = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
   unsigned cur = s_misc[4];
-  const bool direct = total > TRI_STAGE;  // block-uniform
+  const bool direct = total > STAGE;  // block-uniform
   unsigned long long gbase = 0;
-  if (!direct && cur + total > TRI_STAGE) {  // flush the stage first (block-uniform)
+  if (!direct && cur + total > STAGE) {  // flush the stage first (block-uniform)
     if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)cur);
     __syncthreads();
     const unsigned long long fb = *s_base;
@@ -531,6 +531,230 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_brick_kernel(const uint32_t
     atomicAdd(&ctr->n_points, my_points);
   }
 }
+
+// =================================================================================================
+// FlatRenderer on device (glrender/flatrenderer.go): the SDF on every corner of the (nx+1)(ny+1)(nz+1) lattice into a
+// dense grid in HBM (1.7 GB at npt-flange resdiv 1600: with 288 GB the reference's layout is affordable as it is), then
+// marching cubes of every cube out of the grid.
+// =================================================================================================
+// evalKRange (:146-182): grid[i + sx*(j + sy*k)] = SDF(origin + (i,j,k)*res) for the planes [kfirst, kfirst+nk) of the
+// lattice, into a slab whose first plane is kfirst. A workgroup pass covers BLOCK*H lattice columns (i,j) of ONE group of
+// Z consecutive planes (K >= 2: H = K/2, Z = 2): the points 2h / 2h+1 of a lane are one column on two planes, so they
+// enter the evaluator with bitwise equal x,y (its PAIRED mode: hypot/atan2 of x,y once per pair), and for K = 4 points
+// h / h+2 have equal z. Passes never straddle plane groups; (i,j) comes from one division per lane and pass.
+template <int K>
+__global__ void __launch_bounds__(BLOCK, 3) flat_grid_kernel(const uint32_t* __restrict__ code_g, float ox, float oy, float oz, float res,
+                                                             unsigned sx, unsigned sy, unsigned kfirst, unsigned nk,
+                                                             float* __restrict__ grid) {
+  constexpr int H = K >= 2 ? K / 2 : 1;  // lattice columns per lane
+  constexpr int Z = K >= 2 ? 2 : 1;      // planes per pass
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  const unsigned sxy = sx * sy;  // < 2^32 (host checks)
+  const unsigned tpg = (sxy + BLOCK * H - 1) / (BLOCK * H);  // passes per plane group
+  const unsigned ngroups = (nk + Z - 1) / Z;
+  const uint64_t npass = (uint64_t)tpg * ngroups;
+  for (uint64_t w = blockIdx.x; w < npass; w += gridDim.x) {  // uniform trip count
+    const unsigned g = (unsigned)(w / tpg), t = (unsigned)(w - (uint64_t)g * tpg);
+    P3 p[K];
+    float d[K];
+    unsigned col[H];
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      unsigned c = t * (BLOCK * H) + (unsigned)h * BLOCK + threadIdx.x;
+      col[h] = c;
+      if (c >= sxy) c = sxy - 1;  // padding lanes evaluate a valid point, nothing is stored
+      const unsigned j = c / sx, i = c - j * sx;
+      const float x = ox + (float)i * res, y = oy + (float)j * res;
+#pragma unroll
+      for (int z = 0; z < Z; z++) p[h * Z + z] = P3{x, y, oz + (float)(kfirst + g * Z + (unsigned)z) * res};
+    }
+    gsdf_dev::sdf_eval<K, (K >= 2)>(code, p, d, lds, BLOCK);
+#pragma unroll
+    for (int h = 0; h < H; h++)
+#pragma unroll
+      for (int z = 0; z < Z; z++) {
+        const unsigned k = g * Z + (unsigned)z;
+        if (col[h] < sxy && k < nk) grid[(uint64_t)k * sxy + col[h]] = d[h * Z + z];
+      }
+  }
+}
+
+#ifndef GSDF_SPECIALIZED
+// ReadTriangles (:186-256): marching cubes of the cubes [0,nx) x [0,ny) x [0,ncz) of a grid slab (cube z = czfirst + cz
+// of the lattice). A workgroup pass covers 64 cubes in x (one wave = one row, so a cube's four row loads are coalesced)
+// by 4*FLAT_ROWS in y: corner 0 first (prefetched one pass ahead), the other seven only in waves where some lane passes
+// the reference's |d0| <= 2*sqrt3*res test (:207-209). Triangles are then emitted ONE PER LANE, not one cube per lane:
+// the block prefix sum of the per-cube triangle counts gives every triangle a slot and an owner list in LDS
+// (cube id, triangle number), lane t builds triangle t (corner distances re-read from the grid, L1/L2-hot) -- all 256
+// lanes busy instead of the few whose cube is cut, each for up to five rounds. Output staged in LDS, flushed
+// coalesced with one append on the global counter per FLAT_STAGE triangles.
+// HBM-bound by design: 4 B per lattice corner in, 36 B per triangle out.
+// LDS: [owner list 1280*FLAT_ROWS u16 | cube index 256*FLAT_ROWS u8 | tri table | triangle stage | misc].
+#define FLAT_ROWS 4
+#define FLAT_ID_BITS 10  // cube id within a pass: row (log2 FLAT_ROWS bits) | thread (8 bits)
+#define FLAT_STAGE 256
+__global__ void __launch_bounds__(BLOCK) flat_march_kernel(const float* __restrict__ grid, unsigned nx, unsigned ny, unsigned ncz,
+                                                           unsigned czfirst, float ox, float oy, float oz, float res,
+                                                           float* __restrict__ tris, uint64_t tri_cap, MeshCounters* __restrict__ ctr) {
+  uint16_t* s_owner = (uint16_t*)g_smem;                      // [5 * BLOCK * FLAT_ROWS]
+  uint8_t* s_index = (uint8_t*)(s_owner + 5 * BLOCK * FLAT_ROWS);  // [BLOCK * FLAT_ROWS]
+  int8_t* s_tri = (int8_t*)(s_index + BLOCK * FLAT_ROWS);
+  float* s_stage = (float*)(s_tri + 256 * 16);
+  unsigned* s_misc = (unsigned*)(s_stage + FLAT_STAGE * 9);  // [0..3] wave sums
+  unsigned long long* s_base = (unsigned long long*)(s_misc + 6);
+  for (int k = threadIdx.x; k < 256 * 16; k += BLOCK) s_tri[k] = GSDF_MC_TRI[k >> 4][k & 15];
+  __syncthreads();
+  const unsigned sx = nx + 1;
+  const uint64_t sxy = (uint64_t)sx * (ny + 1);
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned txn = (nx + 63) / 64, tyn = (ny + 4 * FLAT_ROWS - 1) / (4 * FLAT_ROWS);
+  const unsigned npass = txn * tyn * ncz;  // < 2^32 (host checks)
+  const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19 / flatrenderer.go:207
+  unsigned long long my_active = 0;
+  unsigned cur = 0;  // triangles in the stage (block-uniform, kept in a register by every thread)
+  auto flush = [&]() {  // all threads
+    if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)cur);
+    __syncthreads();
+    const unsigned long long fb = *s_base;
+    if (fb + cur <= tri_cap) {
+      float* dst = tris + fb * 9;
+      for (unsigned k = threadIdx.x; k < cur * 9; k += BLOCK) dst[k] = s_stage[k];
+    } else if (threadIdx.x == 0) {
+      ctr->overflow = 1ull;
+    }
+    __syncthreads();
+    cur = 0;
+  };
+  // Corner-0 distances of pass w; lanes outside the lattice get +inf (never active). The loads of the NEXT pass are
+  // issued before this pass is processed.
+  auto load_d0 = [&](unsigned tx, unsigned ty, unsigned cz, float (&d0)[FLAT_ROWS]) {
+    const unsigned cx = tx * 64 + lane, cy0 = (ty * 4 + wave) * FLAT_ROWS;
+    const float* g0 = grid + (uint64_t)cz * sxy + (uint64_t)cy0 * sx + cx;
+#pragma unroll
+    for (int r = 0; r < FLAT_ROWS; r++) d0[r] = (cx < nx && cy0 + (unsigned)r < ny) ? g0[(uint64_t)r * sx] : __builtin_inff();
+  };
+  auto pass_coords = [&](unsigned w, unsigned& tx, unsigned& ty, unsigned& cz) {  // npass < 2^32 (host checks)
+    const unsigned wr = w / txn;
+    tx = w - wr * txn;
+    cz = wr / tyn;
+    ty = wr - cz * tyn;
+  };
+  float dnext[FLAT_ROWS];
+  unsigned ntx = 0, nty = 0, ncz_ = 0;
+  if (blockIdx.x < npass) {
+    pass_coords(blockIdx.x, ntx, nty, ncz_);
+    load_d0(ntx, nty, ncz_, dnext);
+  }
+  for (unsigned w = blockIdx.x; w < npass; w += gridDim.x) {
+    const unsigned tx = ntx, ty = nty, cz = ncz_;
+    const unsigned cx = tx * 64 + lane, cy0 = (ty * 4 + wave) * FLAT_ROWS;
+    const float* g0 = grid + (uint64_t)cz * sxy + (uint64_t)cy0 * sx + cx;
+    float d0[FLAT_ROWS];
+    unsigned nt[FLAT_ROWS], index[FLAT_ROWS];
+    bool any_act = false;
+#pragma unroll
+    for (int r = 0; r < FLAT_ROWS; r++) {
+      d0[r] = dnext[r];
+      any_act = any_act || dm::absf(d0[r]) <= cubeDiag;
+      nt[r] = 0;
+      index[r] = 0;
+    }
+    if (w + gridDim.x < npass) {
+      pass_coords(w + gridDim.x, ntx, nty, ncz_);
+      load_d0(ntx, nty, ncz_, dnext);
+    }
+    unsigned ntl = 0;
+    if (__ballot(any_act) != 0ull) {  // wave-uniform
+#pragma unroll
+      for (int r = 0; r < FLAT_ROWS; r++) {
+        if (dm::absf(d0[r]) <= cubeDiag) {
+          const float* q = g0 + (uint64_t)r * sx;
+          const float v1 = q[1], v2 = q[1 + sx], v3 = q[sx], v4 = q[sxy], v5 = q[sxy + 1], v6 = q[sxy + 1 + sx], v7 = q[sxy + sx];
+          const unsigned ix = (d0[r] < 0.f ? 1u : 0u) | (v1 < 0.f ? 2u : 0u) | (v2 < 0.f ? 4u : 0u) | (v3 < 0.f ? 8u : 0u) |
+                              (v4 < 0.f ? 16u : 0u) | (v5 < 0.f ? 32u : 0u) | (v6 < 0.f ? 64u : 0u) | (v7 < 0.f ? 128u : 0u);
+          index[r] = ix;
+          const int8_t* row = s_tri + ix * 16;
+          unsigned n = 0;
+          while (n < 5 && row[3 * n] >= 0) n++;
+          nt[r] = n;
+          ntl += n;
+          my_active++;
+        }
+      }
+    }
+    if (!__syncthreads_or((int)ntl)) continue;  // block-uniform: no triangles anywhere in this pass
+    // block exclusive scan of the per-lane triangle counts
+    unsigned incl = ntl;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned u = __shfl_up(incl, off, 64);
+      if (lane >= (unsigned)off) incl += u;
+    }
+    if (lane == 63) s_misc[wave] = incl;
+    __syncthreads();
+    const unsigned w0 = s_misc[0], w1 = s_misc[1], w2 = s_misc[2], w3 = s_misc[3];
+    const unsigned total = w0 + w1 + w2 + w3;
+    unsigned first = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + (incl - ntl);
+#pragma unroll
+    for (int r = 0; r < FLAT_ROWS; r++) {
+      if (nt[r]) {
+        const unsigned id = (unsigned)r * BLOCK + threadIdx.x;
+        s_index[id] = (uint8_t)index[r];
+        for (unsigned k = 0; k < nt[r]; k++) s_owner[first + k] = (uint16_t)(id | (k << FLAT_ID_BITS));
+        first += nt[r];
+      }
+    }
+    __syncthreads();
+    const float z0 = oz + (float)(czfirst + cz) * res, z1 = z0 + res;
+    const float* gz = grid + (uint64_t)cz * sxy;
+    for (unsigned done = 0; done < total;) {  // block-uniform
+      const unsigned room = FLAT_STAGE - cur, left = total - done;
+      const unsigned n = left < room ? left : room;
+      for (unsigned t = threadIdx.x; t < n; t += BLOCK) {
+        const unsigned o = s_owner[done + t];
+        const unsigned k = o >> FLAT_ID_BITS, id = o & ((1u << FLAT_ID_BITS) - 1u), r = id >> 8, ot = id & 255u;
+        const unsigned ocx = tx * 64 + (ot & 63u), ocy = (ty * 4 + (ot >> 6)) * FLAT_ROWS + r;
+        const float* q = gz + (uint64_t)ocy * sx + ocx;
+        const float x0 = ox + (float)ocx * res, y0 = oy + (float)ocy * res;
+        const float x1 = x0 + res, y1 = y0 + res;
+        const int8_t* row = s_tri + (unsigned)s_index[id] * 16 + 3 * k;
+        float* dst = s_stage + (size_t)(cur + t) * 9;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const int e = row[2 - j];  // reversed winding (marchcubes.go:64-68)
+          const unsigned ca = GSDF_MC_PAIR_A(e), cb = GSDF_MC_PAIR_B(e);
+          const unsigned ax = (ca ^ (ca >> 1)) & 1u, ay = (ca >> 1) & 1u, az = (ca >> 2) & 1u;
+          const unsigned bx = (cb ^ (cb >> 1)) & 1u, by = (cb >> 1) & 1u, bz = (cb >> 2) & 1u;
+          const float va = q[ax + (ay ? sx : 0u) + (az ? sxy : 0ull)], vb = q[bx + (by ? sx : 0u) + (bz ? sxy : 0ull)];
+          float rx, ry, rz;
+          mc_interp(ax ? x1 : x0, ay ? y1 : y0, az ? z1 : z0, bx ? x1 : x0, by ? y1 : y0, bz ? z1 : z0, va, vb, rx, ry, rz);
+          dst[3 * j + 0] = rx;
+          dst[3 * j + 1] = ry;
+          dst[3 * j + 2] = rz;
+        }
+      }
+      cur += n;
+      done += n;
+      __syncthreads();
+      if (cur == FLAT_STAGE) flush();
+    }
+  }
+  __syncthreads();
+  if (cur) flush();
+  // statistics: one atomic per workgroup
+  unsigned na = (unsigned)my_active;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) na += __shfl_down(na, off, 64);
+  __syncthreads();
+  if (lane == 0) s_misc[wave] = na;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long a = (unsigned long long)s_misc[0] + s_misc[1] + s_misc[2] + s_misc[3];
+    if (a) atomicAdd(&ctr->n_active, a);
+  }
+}
+#endif  // GSDF_SPECIALIZED
 
 // =================================================================================================
 // Dual contouring on device (glrender/dual_contour.go, dual_contour_vertexplacement.go).

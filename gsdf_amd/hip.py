@@ -23,7 +23,7 @@ ErrMismatchBufferLength = "position and distance buffer length mismatch"
 SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "gsdf_hip_program_destroy",
            "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_blockcache_create", "gsdf_hip_blockcache_reset", "gsdf_hip_blockcache_eval3", "gsdf_hip_blockcache_hits", "gsdf_hip_blockcache_evaluations", "gsdf_hip_blockcache_destroy", "gsdf_hip_program_specialize", "gsdf_hip_program_is_specialized", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
            "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3", "gsdf_hip_image2",
-           "gsdf_hip_mesh_octree", "gsdf_hip_mesh_dualcontour", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
+           "gsdf_hip_mesh_octree", "gsdf_hip_mesh_dualcontour", "gsdf_hip_mesh_flat", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
            "gsdf_hip_mesh_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner"]
 
 
@@ -88,6 +88,7 @@ def lib():
         L.gsdf_hip_image2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.gsdf_hip_mesh_octree.argtypes = [C.c_void_p, C.c_float, C.POINTER(MeshOpts), C.POINTER(C.c_void_p)]
         L.gsdf_hip_mesh_dualcontour.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.gsdf_hip_mesh_flat.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.gsdf_hip_mesh_stats_get.argtypes = [C.c_void_p, C.POINTER(MeshStats)]
         L.gsdf_hip_mesh_read.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         L.gsdf_hip_mesh_dev_tris.restype = C.c_void_p
@@ -336,3 +337,35 @@ class DualContourHIP(OctreeHIP):
         st = MeshStats()
         _check(lib().gsdf_hip_mesh_stats_get(m, C.byref(st)))
         self.stats = st
+
+
+class FlatHIP(OctreeHIP):
+    """glrender.FlatRenderer drop-in (NewFlatRenderer(s, cubeResolution, evalBufferSize, numParallel)): the whole corner
+    lattice evaluated into a device-resident grid, then marching cubes of every cube. evalBufferSize / numParallel keep
+    the reference's argument checks (flatrenderer.go:37-45) and have no other meaning on the device."""
+
+    def __init__(self, sdf, res, evalBufferSize=4096, numParallel=1, stream=None, shard_rank=0, shard_count=1):
+        if evalBufferSize < 8:
+            raise ValueError("flat renderer eval buffer size must be at least 8")
+        if numParallel < 1:
+            raise ValueError("flat renderer numParallel must be at least 1")
+        self._shard = (shard_rank, shard_count)
+        self.sdf = sdf
+        self._mesh = None
+        self._cursor = 0
+        self._stream = stream
+        self.Reset(sdf, res)
+
+    def Reset(self, sdf, res):
+        self._free()
+        self.sdf = sdf
+        m = C.c_void_p()
+        _check(lib().gsdf_hip_mesh_flat(sdf._h, np.float32(res), self._shard[0], self._shard[1], self._stream, C.byref(m)))
+        self._mesh = m
+        self._cursor = 0
+        st = MeshStats()
+        _check(lib().gsdf_hip_mesh_stats_get(m, C.byref(st)))
+        self.stats = st
+
+    def Evaluations(self):
+        return int(self.stats.evals)

@@ -148,6 +148,14 @@ int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_opts* opts,
  * shard_rank of shard_count emits the quads of its z-slab of the lattice (one-cube halo recomputed, nothing exchanged). */
 int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chiseled, int shard_rank, int shard_count, void* stream,
                               gsdf_mesh** out);
+/* glrender.FlatRenderer (glrender/flatrenderer.go:36-256; the renderer gsdfaux.RenderShader3D picks for CPU runs,
+ * gsdfaux/gsdfaux.go:160-168): the SDF on every corner of the ceil(size/res)+1 lattice of the 1.01-scaled bounds into a
+ * device-resident grid, then marching cubes of every cube whose first corner passes |d| <= 2*sqrt3*res. Same triangle
+ * set as the reference's ReadTriangles loop (order differs). Stats: evals = lattice corners (FlatRenderer.Evaluations),
+ * leaf_cubes = cubes, active_leaves = cubes passing the first-corner test, ms_leaf = lattice pass, ms_march = marching
+ * pass, levels = 0. Multi-GPU: rank shard_rank of shard_count takes a z-slab of cubes (the reference's goroutine split,
+ * :120-122), nothing exchanged. */
+int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, int shard_count, void* stream, gsdf_mesh** out);
 int gsdf_hip_mesh_stats_get(const gsdf_mesh* m, gsdf_mesh_stats* st);
 /* Copy triangles [first, first+count) to host memory: 9 floats (36 B) each = ms3.Triangle. */
 int gsdf_hip_mesh_read(const gsdf_mesh* m, uint64_t first, uint64_t count, float* dst);

@@ -50,6 +50,13 @@ def test_random_trees_distances_and_meshes(gpu, seed):
         if m.n_tris:
             assert (_sorted(oc.RenderAll()).view(np.uint32) == _sorted(m.tris).view(np.uint32)).all(), (seed, k)
             meshed += 1
+        # flat renderer: the PAIRED lattice pass (two planes per lane) against the oracle's FlatRenderer
+        if k % 2 == 0:
+            fl = gpu.FlatHIP(sdf, res)
+            mf = ref.render_flat(res, 4096, 2)
+            assert fl.Evaluations() == mf.evals and fl.n_tris() == mf.n_tris, (seed, k, "flat")
+            if mf.n_tris:
+                assert (_sorted(fl.RenderAll()).view(np.uint32) == _sorted(mf.tris).view(np.uint32)).all(), (seed, k, "flat")
     assert meshed >= 8
 
 
