@@ -217,6 +217,7 @@ __device__ __forceinline__ void mc_interp(float ax, float ay, float az, float bx
   rx = x; ry = y; rz = z;
 }
 
+#define LEAF_MIN_COLS 14  // leaf_kernel's LDS columns per lane: 8 corner distances + 3 origin + 3 for the owner list / cube indices
 #define TRI_STAGE 128  // triangles staged in LDS per workgroup before one coalesced flush (4.5 KB: lets 4 workgroups of a 7-slot program share a CU)
 
 // Marching cubes of one leaf per lane + block-wide triangle emission (shared by both leaf kernels).
@@ -313,12 +314,112 @@ __device__ __forceinline__ void mc_final_flush(float* s_stage, unsigned* s_misc,
 }
 
 
+// Balanced marching-cubes emission of one workgroup pass: ONE TRIANGLE PER LANE instead of one cube per lane.
+// Every lane brings NC cubes (index[c] = 8-bit inside mask; 0 and 255 give no triangles). The block prefix sum of the
+// per-cube triangle counts gives every triangle a slot; the cubes write an owner list (cube id = c*BLOCK + thread,
+// triangle number) into LDS, and lane t builds triangle t from its owner's data: corner(id, 0..7) = corner distances,
+// origin(id, x0, y0, z0) = min corner (max corner = min + res, as Box{origin, origin+size}). With ~1 cube in 5 cut by
+// the surface and up to five triangles per cube, the cube-per-lane loop of mc_emit_block keeps a wave busy for five
+// rounds on behalf of a few lanes; here all lanes work for ceil(total/BLOCK) rounds.
+// Triangles are staged in LDS (`cur` = staged count: block-uniform, held in a register by every thread) and flushed
+// coalesced with ONE append on the global counter per STAGE triangles.
+// Block-uniform control flow: every thread of the workgroup calls this together. Ends with a barrier, so the caller
+// may overwrite whatever corner()/origin() read. LDS: s_owner[5*BLOCK*NC] u16, s_index[BLOCK*NC] u8.
+template <int STAGE>
+__device__ __forceinline__ void mc_stage_flush(float* s_stage, unsigned long long* s_base, unsigned& cur, float* __restrict__ tris,
+                                               uint64_t tri_cap, MeshCounters* __restrict__ ctr) {
+  if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)cur);
+  __syncthreads();
+  const unsigned long long fb = *s_base;
+  if (fb + cur <= tri_cap) {
+    float* dst = tris + fb * 9;
+    for (unsigned k = threadIdx.x; k < cur * 9; k += BLOCK) dst[k] = s_stage[k];
+  } else if (threadIdx.x == 0) {
+    ctr->overflow = 1ull;  // the counter keeps counting: the host learns the exact size and reruns
+  }
+  __syncthreads();
+  cur = 0;
+}
+
+template <int NC, int STAGE, typename Corner, typename Origin>
+__device__ __forceinline__ void mc_emit_balanced(const unsigned (&index)[NC], uint16_t* s_owner, uint8_t* s_index, const int8_t* s_tri,
+                                                 float* s_stage, unsigned* s_misc, unsigned long long* s_base, unsigned& cur,
+                                                 float res, Corner corner, Origin origin, float* __restrict__ tris, uint64_t tri_cap,
+                                                 MeshCounters* __restrict__ ctr) {
+  constexpr unsigned ID_BITS = NC == 1 ? 8 : (NC == 2 ? 9 : (NC <= 4 ? 10 : 11));
+  static_assert(NC <= 8, "owner entries are 16 bits: 3 bits of triangle number + 11 bits of cube id");
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned nt[NC], ntl = 0;
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    unsigned n = 0;
+    if (index[c]) {  // row 0 is empty anyway; saves the LDS walk for the common case
+      const int8_t* row = s_tri + index[c] * 16;
+      while (n < 5 && row[3 * n] >= 0) n++;
+    }
+    nt[c] = n;
+    ntl += n;
+  }
+  if (!__syncthreads_or((int)ntl)) return;  // no triangles anywhere in this pass (block-uniform)
+  unsigned incl = ntl;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned u = __shfl_up(incl, off, 64);
+    if (lane >= (unsigned)off) incl += u;
+  }
+  if (lane == 63) s_misc[wave] = incl;
+  __syncthreads();
+  const unsigned w0 = s_misc[0], w1 = s_misc[1], w2 = s_misc[2], w3 = s_misc[3];
+  const unsigned total = w0 + w1 + w2 + w3;
+  unsigned first = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + (incl - ntl);
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    if (nt[c]) {
+      const unsigned id = (unsigned)c * BLOCK + threadIdx.x;
+      s_index[id] = (uint8_t)index[c];
+      for (unsigned k = 0; k < nt[c]; k++) s_owner[first + k] = (uint16_t)(id | (k << ID_BITS));
+      first += nt[c];
+    }
+  }
+  __syncthreads();
+  for (unsigned done = 0; done < total;) {  // block-uniform
+    const unsigned room = STAGE - cur, left = total - done;
+    const unsigned n = left < room ? left : room;
+    for (unsigned t = threadIdx.x; t < n; t += BLOCK) {
+      const unsigned o = s_owner[done + t];
+      const unsigned k = o >> ID_BITS, id = o & ((1u << ID_BITS) - 1u);
+      float x0, y0, z0;
+      origin(id, x0, y0, z0);
+      const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;
+      const int8_t* row = s_tri + (unsigned)s_index[id] * 16 + 3 * k;
+      float* dst = s_stage + (size_t)(cur + t) * 9;
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int e = row[2 - j];  // reversed winding (marchcubes.go:64-68)
+        const unsigned ca = GSDF_MC_PAIR_A(e), cb = GSDF_MC_PAIR_B(e);
+        const bool ax = ((ca ^ (ca >> 1)) & 1u) != 0u, ay = ((ca >> 1) & 1u) != 0u, az = ((ca >> 2) & 1u) != 0u;
+        const bool bx = ((cb ^ (cb >> 1)) & 1u) != 0u, by = ((cb >> 1) & 1u) != 0u, bz = ((cb >> 2) & 1u) != 0u;
+        float rx, ry, rz;
+        mc_interp(ax ? x1 : x0, ay ? y1 : y0, az ? z1 : z0, bx ? x1 : x0, by ? y1 : y0, bz ? z1 : z0, corner(id, ca), corner(id, cb),
+                  rx, ry, rz);
+        dst[3 * j + 0] = rx;
+        dst[3 * j + 1] = ry;
+        dst[3 * j + 2] = rz;
+      }
+    }
+    cur += n;
+    done += n;
+    __syncthreads();
+    if (cur == STAGE) mc_stage_flush<STAGE>(s_stage, s_base, cur, tris, tri_cap, ctr);
+  }
+}
+
 // Leaf kernel: one lane per leaf cube of every surviving level-lq cube (64 leaves of a level-3 cube
 // = one wave). Corner 0 first; the wave runs the other 7 corners only if some lane passes the
 // reference's |d0| <= 2*sqrt3*res test (marchcubes.go:20-23). Marching cubes reads the triangle
 // table from LDS; triangles are staged in LDS and flushed with ONE global atomic per flush
 // (a single counter word saturates at ~88 atomics/us on MI355X, so per-wave appends do not scale).
-// LDS: [max(nslots*K, 8) floats per lane | tri table 256x16 i8 | TRI_STAGE*9 floats | 8 words]. The lane's 8 corner
+// LDS: [max(nslots*K, LEAF_MIN_COLS) floats per lane | tri table 256x16 i8 | TRI_STAGE*9 floats | 8 words]. The lane's 8 corner
 // distances reuse the interpreter's slot columns: the distances of the earlier passes ride in registers until the
 // last pass has finished with the slots, then all 8 are stored for marching cubes' dynamically indexed reads.
 template <int K, int WAVES>
@@ -329,13 +430,18 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
   float* vslot = lds;  // 8 per-lane corner distances, written after the last interpreter pass (aliases the slots)
-  int8_t* s_tri = (int8_t*)(g_smem + (size_t)(nslots * K > 8 ? nslots * K : 8) * BLOCK);
+  // columns 8..10: the lane's cube origin; columns 11..13 (3 KB, block-shared): owner list + cube indices of the
+  // balanced emission -- all of it aliases slot columns, which are idle between the last evaluation and the barrier
+  // that ends the emission
+  uint16_t* s_owner = (uint16_t*)(g_smem + 11 * BLOCK);  // [5 * BLOCK]
+  uint8_t* s_index = (uint8_t*)(s_owner + 5 * BLOCK);    // [BLOCK]
+  int8_t* s_tri = (int8_t*)(g_smem + (size_t)(nslots * K > LEAF_MIN_COLS ? nslots * K : LEAF_MIN_COLS) * BLOCK);
   float* s_stage = (float*)(s_tri + 256 * 16);
-  unsigned* s_misc = (unsigned*)(s_stage + TRI_STAGE * 9);  // [0..3] wave sums, [4] staged count
+  unsigned* s_misc = (unsigned*)(s_stage + TRI_STAGE * 9);  // [0..3] wave sums
   unsigned long long* s_base = (unsigned long long*)(s_misc + 6);
   for (int k = threadIdx.x; k < 256 * 16; k += BLOCK) s_tri[k] = GSDF_MC_TRI[k >> 4][k & 15];
-  if (threadIdx.x == 0) s_misc[4] = 0;
   __syncthreads();
+  unsigned cur = 0;  // triangles in the LDS stage (block-uniform)
 
   const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
   const int sh = lq - 1;
@@ -399,14 +505,28 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
         }
       }
     }
-    if (!pass) index = 0;
+    if (!pass || index == 255u) index = 0;
     // after the last pass dall[j] is the distance of corner order[j] (an early exit leaves index == 0: nothing is read)
+    if (index) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) vslot[((0x62735140u >> (4u * j)) & 7u) * BLOCK] = dall[j];
-    mc_emit_block(index, x0, y0, z0, x1, y1, z1, [&](unsigned cc) { return vslot[cc * BLOCK]; }, s_tri, s_stage, s_misc, s_base, tris,
-                  tri_cap, ctr);
+      for (int j = 0; j < 8; j++) vslot[((0x62735140u >> (4u * j)) & 7u) * BLOCK] = dall[j];
+      lds[8 * BLOCK] = x0;
+      lds[9 * BLOCK] = y0;
+      lds[10 * BLOCK] = z0;
+    }
+    const unsigned index1[1] = {index};
+    mc_emit_balanced<1, TRI_STAGE>(
+        index1, s_owner, s_index, s_tri, s_stage, s_misc, s_base, cur, res,
+        [&](unsigned id, unsigned cc) { return g_smem[cc * BLOCK + id]; },
+        [&](unsigned id, float& ax, float& ay, float& az) {
+          ax = g_smem[8 * BLOCK + id];
+          ay = g_smem[9 * BLOCK + id];
+          az = g_smem[10 * BLOCK + id];
+        },
+        tris, tri_cap, ctr);
   }
-  mc_final_flush(s_stage, s_misc, s_base, tris, tri_cap, ctr);
+  __syncthreads();
+  if (cur) mc_stage_flush<TRI_STAGE>(s_stage, s_base, cur, tris, tri_cap, ctr);
   // statistics: two atomics per workgroup, not per wave (they share the L2 atomic unit with the triangle appends)
   __syncthreads();
   unsigned* s_stat = (unsigned*)s_stage;
@@ -592,7 +712,6 @@ __global__ void __launch_bounds__(BLOCK, 3) flat_grid_kernel(const uint32_t* __r
 // HBM-bound by design: 4 B per lattice corner in, 36 B per triangle out.
 // LDS: [owner list 1280*FLAT_ROWS u16 | cube index 256*FLAT_ROWS u8 | tri table | triangle stage | misc].
 #define FLAT_ROWS 4
-#define FLAT_ID_BITS 10  // cube id within a pass: row (log2 FLAT_ROWS bits) | thread (8 bits)
 #define FLAT_STAGE 256
 __global__ void __launch_bounds__(BLOCK) flat_march_kernel(const float* __restrict__ grid, unsigned nx, unsigned ny, unsigned ncz,
                                                            unsigned czfirst, float ox, float oy, float oz, float res,
@@ -612,20 +731,7 @@ __global__ void __launch_bounds__(BLOCK) flat_march_kernel(const float* __restri
   const unsigned npass = txn * tyn * ncz;  // < 2^32 (host checks)
   const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19 / flatrenderer.go:207
   unsigned long long my_active = 0;
-  unsigned cur = 0;  // triangles in the stage (block-uniform, kept in a register by every thread)
-  auto flush = [&]() {  // all threads
-    if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)cur);
-    __syncthreads();
-    const unsigned long long fb = *s_base;
-    if (fb + cur <= tri_cap) {
-      float* dst = tris + fb * 9;
-      for (unsigned k = threadIdx.x; k < cur * 9; k += BLOCK) dst[k] = s_stage[k];
-    } else if (threadIdx.x == 0) {
-      ctr->overflow = 1ull;
-    }
-    __syncthreads();
-    cur = 0;
-  };
+  unsigned cur = 0;  // triangles in the stage (block-uniform)
   // Corner-0 distances of pass w; lanes outside the lattice get +inf (never active). The loads of the NEXT pass are
   // issued before this pass is processed.
   auto load_d0 = [&](unsigned tx, unsigned ty, unsigned cz, float (&d0)[FLAT_ROWS]) {
@@ -651,20 +757,18 @@ __global__ void __launch_bounds__(BLOCK) flat_march_kernel(const float* __restri
     const unsigned cx = tx * 64 + lane, cy0 = (ty * 4 + wave) * FLAT_ROWS;
     const float* g0 = grid + (uint64_t)cz * sxy + (uint64_t)cy0 * sx + cx;
     float d0[FLAT_ROWS];
-    unsigned nt[FLAT_ROWS], index[FLAT_ROWS];
+    unsigned index[FLAT_ROWS];
     bool any_act = false;
 #pragma unroll
     for (int r = 0; r < FLAT_ROWS; r++) {
       d0[r] = dnext[r];
       any_act = any_act || dm::absf(d0[r]) <= cubeDiag;
-      nt[r] = 0;
       index[r] = 0;
     }
     if (w + gridDim.x < npass) {
       pass_coords(w + gridDim.x, ntx, nty, ncz_);
       load_d0(ntx, nty, ncz_, dnext);
     }
-    unsigned ntl = 0;
     if (__ballot(any_act) != 0ull) {  // wave-uniform
 #pragma unroll
       for (int r = 0; r < FLAT_ROWS; r++) {
@@ -673,75 +777,30 @@ __global__ void __launch_bounds__(BLOCK) flat_march_kernel(const float* __restri
           const float v1 = q[1], v2 = q[1 + sx], v3 = q[sx], v4 = q[sxy], v5 = q[sxy + 1], v6 = q[sxy + 1 + sx], v7 = q[sxy + sx];
           const unsigned ix = (d0[r] < 0.f ? 1u : 0u) | (v1 < 0.f ? 2u : 0u) | (v2 < 0.f ? 4u : 0u) | (v3 < 0.f ? 8u : 0u) |
                               (v4 < 0.f ? 16u : 0u) | (v5 < 0.f ? 32u : 0u) | (v6 < 0.f ? 64u : 0u) | (v7 < 0.f ? 128u : 0u);
-          index[r] = ix;
-          const int8_t* row = s_tri + ix * 16;
-          unsigned n = 0;
-          while (n < 5 && row[3 * n] >= 0) n++;
-          nt[r] = n;
-          ntl += n;
+          index[r] = ix == 255u ? 0u : ix;
           my_active++;
         }
       }
     }
-    if (!__syncthreads_or((int)ntl)) continue;  // block-uniform: no triangles anywhere in this pass
-    // block exclusive scan of the per-lane triangle counts
-    unsigned incl = ntl;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned u = __shfl_up(incl, off, 64);
-      if (lane >= (unsigned)off) incl += u;
-    }
-    if (lane == 63) s_misc[wave] = incl;
-    __syncthreads();
-    const unsigned w0 = s_misc[0], w1 = s_misc[1], w2 = s_misc[2], w3 = s_misc[3];
-    const unsigned total = w0 + w1 + w2 + w3;
-    unsigned first = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + (incl - ntl);
-#pragma unroll
-    for (int r = 0; r < FLAT_ROWS; r++) {
-      if (nt[r]) {
-        const unsigned id = (unsigned)r * BLOCK + threadIdx.x;
-        s_index[id] = (uint8_t)index[r];
-        for (unsigned k = 0; k < nt[r]; k++) s_owner[first + k] = (uint16_t)(id | (k << FLAT_ID_BITS));
-        first += nt[r];
-      }
-    }
-    __syncthreads();
-    const float z0 = oz + (float)(czfirst + cz) * res, z1 = z0 + res;
+    // owner id = row*BLOCK + thread -> cube (ocx, ocy) of this pass; distances are re-read from the grid (L1/L2-hot)
     const float* gz = grid + (uint64_t)cz * sxy;
-    for (unsigned done = 0; done < total;) {  // block-uniform
-      const unsigned room = FLAT_STAGE - cur, left = total - done;
-      const unsigned n = left < room ? left : room;
-      for (unsigned t = threadIdx.x; t < n; t += BLOCK) {
-        const unsigned o = s_owner[done + t];
-        const unsigned k = o >> FLAT_ID_BITS, id = o & ((1u << FLAT_ID_BITS) - 1u), r = id >> 8, ot = id & 255u;
-        const unsigned ocx = tx * 64 + (ot & 63u), ocy = (ty * 4 + (ot >> 6)) * FLAT_ROWS + r;
-        const float* q = gz + (uint64_t)ocy * sx + ocx;
-        const float x0 = ox + (float)ocx * res, y0 = oy + (float)ocy * res;
-        const float x1 = x0 + res, y1 = y0 + res;
-        const int8_t* row = s_tri + (unsigned)s_index[id] * 16 + 3 * k;
-        float* dst = s_stage + (size_t)(cur + t) * 9;
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-          const int e = row[2 - j];  // reversed winding (marchcubes.go:64-68)
-          const unsigned ca = GSDF_MC_PAIR_A(e), cb = GSDF_MC_PAIR_B(e);
-          const unsigned ax = (ca ^ (ca >> 1)) & 1u, ay = (ca >> 1) & 1u, az = (ca >> 2) & 1u;
-          const unsigned bx = (cb ^ (cb >> 1)) & 1u, by = (cb >> 1) & 1u, bz = (cb >> 2) & 1u;
-          const float va = q[ax + (ay ? sx : 0u) + (az ? sxy : 0ull)], vb = q[bx + (by ? sx : 0u) + (bz ? sxy : 0ull)];
-          float rx, ry, rz;
-          mc_interp(ax ? x1 : x0, ay ? y1 : y0, az ? z1 : z0, bx ? x1 : x0, by ? y1 : y0, bz ? z1 : z0, va, vb, rx, ry, rz);
-          dst[3 * j + 0] = rx;
-          dst[3 * j + 1] = ry;
-          dst[3 * j + 2] = rz;
-        }
-      }
-      cur += n;
-      done += n;
-      __syncthreads();
-      if (cur == FLAT_STAGE) flush();
-    }
+    const float z0 = oz + (float)(czfirst + cz) * res;
+    mc_emit_balanced<FLAT_ROWS, FLAT_STAGE>(
+        index, s_owner, s_index, s_tri, s_stage, s_misc, s_base, cur, res,
+        [&](unsigned id, unsigned c) {
+          const unsigned ot = id & 255u, ocx = tx * 64 + (ot & 63u), ocy = (ty * 4 + (ot >> 6)) * FLAT_ROWS + (id >> 8);
+          return gz[(uint64_t)(ocy + ((c >> 1) & 1u)) * sx + ocx + ((c ^ (c >> 1)) & 1u) + ((c >> 2) ? sxy : 0ull)];
+        },
+        [&](unsigned id, float& x0, float& y0, float& zz) {
+          const unsigned ot = id & 255u, ocx = tx * 64 + (ot & 63u), ocy = (ty * 4 + (ot >> 6)) * FLAT_ROWS + (id >> 8);
+          x0 = ox + (float)ocx * res;
+          y0 = oy + (float)ocy * res;
+          zz = z0;
+        },
+        tris, tri_cap, ctr);
   }
   __syncthreads();
-  if (cur) flush();
+  if (cur) mc_stage_flush<FLAT_STAGE>(s_stage, s_base, cur, tris, tri_cap, ctr);
   // statistics: one atomic per workgroup
   unsigned na = (unsigned)my_active;
 #pragma unroll

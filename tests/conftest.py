@@ -25,6 +25,15 @@ def _native_libs():
 
 @pytest.fixture(scope="session")
 def gpu():
+    # Tests that hand device buffers to torch (the RCCL gather) need torch's bundled HIP runtime initialised BEFORE the
+    # system one that libgsdfhip.so links: in the other order torch reports "No HIP GPUs are available". Test order must
+    # not matter, so do it here.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     from gsdf_amd import hip
     hip.init(0)  # raises loudly when no device / no library: GPU tests must never fall back
     return hip
