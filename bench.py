@@ -45,13 +45,14 @@ VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SI
 def pmc_summary():
     """Latest committed rocprofv3 PMC summary of this same command (profiles/*_pmc_summary.json)."""
     import glob
-    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-    if not fs:
-        return {}
-    try:
-        return json.load(open(fs[-1])).get("leaf_kernel", {})
-    except Exception:
-        return {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(f)).get("leaf_kernel")
+        except Exception:
+            continue
+        if d:  # summaries of other commands (eval mode, flat renderer) carry no leaf_kernel entry
+            return d
+    return {}
 
 
 def pmc_traffic_gb():
@@ -114,6 +115,37 @@ def eval_mode(args, torch, np, hip, shader, sdf, res, dev):
                      "traffic": None, "kernel": "eval_kernel<3,K>", "kernel_ms": k_ms}}), flush=True)
 
 
+def flat_mode(args, torch, np, hip, shader, sdf, res, spec_note):
+    """glrender.FlatRenderer on device (gsdf_hip_mesh_flat): every corner of the lattice, then marching cubes of every
+    cube. Two kernels with different roofs: the lattice pass is VALU-bound like the octree's leaf kernel, the marching
+    pass streams the grid (4 B per corner) and the triangles (36 B each): HBM."""
+    for _ in range(args.warmup):
+        hip.FlatHIP(sdf, res)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g_ms = m_ms = 0.0
+    for _ in range(args.steps):
+        f = hip.FlatHIP(sdf, res)
+        g_ms += f.stats.ms_leaf
+        m_ms += f.stats.ms_march
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ev, nt = int(f.stats.evals), int(f.stats.n_tris)
+    g_ms /= args.steps
+    m_ms /= args.steps
+    alg_gb = (4.0 * ev + 36.0 * nt) / 1e9
+    achieved = alg_gb / (m_ms * 1e-3)
+    print(json.dumps({
+        "metric": "sdf_evals_per_s", "value": ev * args.steps / dt, "unit": "evals/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"FlatRenderer on device: {args.scene} resdiv {args.resdiv}, {ev} lattice corners, {nt} triangles; {spec_note}"},
+        "triangles": nt, "triangles_per_s": nt * args.steps / dt,
+        "lattice_pass": {"kernel": "flat_grid_kernel<K>", "kernel_ms": g_ms, "evals_per_s": ev / (g_ms * 1e-3)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "flat_march_kernel", "kernel_ms": m_ms, "algorithmic_gb_per_launch": alg_gb}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,9 +155,10 @@ def main():
     ap.add_argument("--scene", default="npt-flange")
     ap.add_argument("--cpu-resdiv", type=int, default=0, help="resdiv of the bounded CPU sample (0 = pick ~10-30 s of CPU work from the core count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["mesh", "eval"], default="mesh",
+    ap.add_argument("--mode", choices=["mesh", "eval", "flat"], default="mesh",
                     help="mesh (default, BASELINE configs[1]) or eval: the gleval.SDF3.Evaluate micro-benchmark (SURVEY 8(d) M1) on "
-                         "HBM-resident positions: 2^24-point chunks of the flat lattice of the scene at --resdiv")
+                         "HBM-resident positions: 2^24-point chunks of the flat lattice of the scene at --resdiv; flat: the reference's other "
+                         "renderer (FlatRenderer) on device, one GPU")
     ap.add_argument("--interpreter", action="store_true", help="run the generic interpreter kernels instead of kernels specialised for the tree")
     ap.add_argument("--share-corners", action="store_true", help="evaluate each bitwise-distinct lattice corner of a brick once (same triangles, fewer evals)")
     args = ap.parse_args()
@@ -170,6 +203,8 @@ def main():
 
     if args.mode == "eval":
         return eval_mode(args, torch, np, hip, shader, sdf, res, dev)
+    if args.mode == "flat":
+        return flat_mode(args, torch, np, hip, shader, sdf, res, spec_note)
 
     def barrier():
         torch.cuda.synchronize()

@@ -15,9 +15,10 @@ ap.add_argument("dir")
 ap.add_argument("--evals-per-launch", type=float, default=0)
 ap.add_argument("--kernel-ms", type=float, default=0)
 ap.add_argument("--workload", default="")
+ap.add_argument("--command", default="python bench.py --steps 5 --warmup 1 --no-cpu-baseline")
 a = ap.parse_args()
 
-KERNELS = ("leaf_kernel", "prune_kernel", "leaf_brick_kernel", "eval_kernel")
+KERNELS = ("leaf_kernel", "prune_kernel", "leaf_brick_kernel", "eval_kernel", "flat_grid_kernel", "flat_march_kernel")
 acc = {k: defaultdict(lambda: [0.0, 0]) for k in KERNELS}
 for f in glob.glob(os.path.join(a.dir, "**", "*counter_collection.csv"), recursive=True):
     per = defaultdict(float)
@@ -29,7 +30,7 @@ for f in glob.glob(os.path.join(a.dir, "**", "*counter_collection.csv"), recursi
     for (k, _, name), v in per.items():
         acc[k][name][0] += v
         acc[k][name][1] += 1
-out = {"command": "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline",
+out = {"command": "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- " + a.command,
        "note": "separate --pmc passes; values are averages per dispatch", "workload": a.workload}
 for k in KERNELS:
     if not acc[k]:
