@@ -922,8 +922,7 @@ extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, in
   spec_aux(p);
   HIP_TRYM(hipEventRecord(p->ev[0], s));
   {
-    const int hcols = ek >= 2 ? ek / 2 : 1, zz = ek >= 2 ? 2 : 1;
-    const uint64_t npass = ((sxy + (uint64_t)BLOCK * hcols - 1) / ((uint64_t)BLOCK * hcols)) * ((nk + zz - 1) / zz);
+    const uint64_t npass = ((sxy + (uint64_t)BLOCK - 1) / (uint64_t)BLOCK) * ((nk + ek - 1) / ek);
     static const int bpc = [] { const char* e = getenv("GSDF_HIP_EVAL_BPC"); return e ? atoi(e) : 64; }();
     const uint64_t gmax = (uint64_t)p->num_cu * (uint64_t)(bpc > 0 ? bpc : 64);
     const unsigned g = (unsigned)(npass < gmax ? npass : gmax);

@@ -91,8 +91,15 @@ __device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t n
 //                x,y column hold the same two x,y pairs, so lanes with even z evaluate pair 0, lanes with odd z pair 1
 //                -- ONE evaluation per lane instead of two -- and every lane fetches both results from the z = 0 / z = 1
 //                lanes of its column (ds_bpermute). Same inputs, same operations, same bits.
+//   column     : all K points of the lane entered with equal x,y (lattice sweeps: one lattice column on K planes)
+//                -> point 0 computes, the others copy.
 template <int K, typename F>
-__device__ __forceinline__ void xy_shared(const P3 (&pv)[K], float (&out)[K], bool shared, bool brick, F f) {
+__device__ __forceinline__ void xy_shared(const P3 (&pv)[K], float (&out)[K], bool shared, bool brick, F f, bool column = false) {
+  if (shared && column) {
+    const float v = f(pv[0].x, pv[0].y);
+    KLOOP out[kp] = v;
+    return;
+  }
   if (K == 4 && shared && brick) {
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const bool odd = ((lane >> 4) & 1u) != 0u;
@@ -110,7 +117,7 @@ __device__ __forceinline__ void xy_shared(const P3 (&pv)[K], float (&out)[K], bo
 
 // hypot(P.x,P.y) of every point into hxy[] unless the cache is valid
 #define ENSURE_HXY() \
-  if (!use_hxy) xy_shared<K>(pv, hxy, sh_xy, brick, [](float x, float y) { return dm::hypotf_(x, y); })
+  if (!use_hxy) xy_shared<K>(pv, hxy, sh_xy, brick, [](float x, float y) { return dm::hypotf_(x, y); }, sh_col)
 
 // D_SKIPFAR*: true (wave-uniform) if every point of the wave is outside the box [mn, mx] by more than the running
 // minimum `a` of the union, with margin: then no point's min(a, child) can differ from a (the child's field is at least
@@ -172,12 +179,14 @@ __device__ __forceinline__ void smooth_h(const float (&num)[K], float k, float r
   }
 }
 
-// PAIRED (the mesher's leaf kernels only): the caller passes the corners of one leaf cube in the order
+// SHARE = 0: K unrelated points. SHARE = 2 (COLUMN; lattice sweeps): the K points of a lane enter with bitwise equal
+// x,y (one lattice column on K planes): instructions flagged D_FLAG_SHXY compute their f(P.x,P.y) once per lane.
+// SHARE = 1 (PAIRED; the mesher's leaf kernels): the caller passes the corners of one leaf cube in the order
 // {0,4,1,5 | 3,7,2,6}, i.e. points 2j and 2j+1 enter with bitwise equal x,y and (K = 4) points j and j+2 with equal z.
 // Instructions the host compiler flagged D_FLAG_SHXY / D_FLAG_SHZ then compute their f(P.x,P.y) / g(P.z) once per
 // pair and copy it: same inputs, same operation sequence, same bits as evaluating every corner separately.
 #ifndef GSDF_SPECIALIZED
-template <int K, bool PAIRED = false>
+template <int K, int SHARE = 0>
 __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)[K],
                                          float* __restrict__ lds /* already offset by tid */, const uint32_t nthreads,
                                          const bool brick = false /* wave-uniform; see xy_shared */) {
@@ -197,8 +206,9 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
     const uint32_t slot = w >> 16;
     const bool use_hxy = (w & D_FLAG_HXY) != 0u;   // wave-uniform
     const bool swap_ab = (w & D_FLAG_SWAP) != 0u;  // wave-uniform
-    const bool sh_xy = PAIRED && K >= 2 && (w & D_FLAG_SHXY) != 0u;
-    const bool sh_z = PAIRED && K >= 4 && (w & D_FLAG_SHZ) != 0u;
+    const bool sh_xy = SHARE != 0 && K >= 2 && (w & D_FLAG_SHXY) != 0u;
+    const bool sh_z = SHARE == 1 && K >= 4 && (w & D_FLAG_SHZ) != 0u;
+    const bool sh_col = SHARE == 2;  // only read together with sh_xy
     switch (op) {
       case D_END:
         return;
@@ -666,7 +676,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_SCREW_PRE: {
         float th[K];  // atan2(P.y, P.x): a function of x,y only
-        xy_shared<K>(pv, th, sh_xy, brick, [](float x, float y) { return dm::atan2f_(y, x); });
+        xy_shared<K>(pv, th, sh_xy, brick, [](float x, float y) { return dm::atan2f_(y, x); }, sh_col);
         ENSURE_HXY();
         {
           // z' = z + lead*theta/2pi ; sawTooth(z', pitch): both divisors are wave-uniform -> exact reciprocal form
@@ -744,7 +754,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_CIRC_PRE: {
         float th[K];  // atan2(P.y, P.x): a function of x,y only
-        xy_shared<K>(pv, th, sh_xy, brick, [](float x, float y) { return dm::atan2f_(y, x); });
+        xy_shared<K>(pv, th, sh_xy, brick, [](float x, float y) { return dm::atan2f_(y, x); }, sh_col);
         KLOOP {
           [[maybe_unused]] P3& p = pv[kp];
           [[maybe_unused]] float& R = Rv[kp];
@@ -946,7 +956,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
 #undef PU
 }
 #else
-// Run-time specialisation (hiprtc): sdf_eval<K, PAIRED> for ONE lowered program, generated by specialize.cpp from the
+// Run-time specialisation (hiprtc): sdf_eval<K, SHARE> for ONE lowered program, generated by specialize.cpp from the
 // case bodies above -- the same statements in program order, with the instruction word, its flags, the slot number and
 // every parameter as literals, so there is no fetch/decode, no dispatch branch and no dead flag test left.
 }  // namespace gsdf_dev

@@ -658,45 +658,36 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_brick_kernel(const uint32_t
 // marching cubes of every cube out of the grid.
 // =================================================================================================
 // evalKRange (:146-182): grid[i + sx*(j + sy*k)] = SDF(origin + (i,j,k)*res) for the planes [kfirst, kfirst+nk) of the
-// lattice, into a slab whose first plane is kfirst. A workgroup pass covers BLOCK*H lattice columns (i,j) of ONE group of
-// Z consecutive planes (K >= 2: H = K/2, Z = 2): the points 2h / 2h+1 of a lane are one column on two planes, so they
-// enter the evaluator with bitwise equal x,y (its PAIRED mode: hypot/atan2 of x,y once per pair), and for K = 4 points
-// h / h+2 have equal z. Passes never straddle plane groups; (i,j) comes from one division per lane and pass.
+// lattice, into a slab whose first plane is kfirst. A lane carries ONE lattice column (i,j) on K consecutive planes, so
+// its K points enter the evaluator with bitwise equal x,y (COLUMN mode: every hypot/atan2 of x,y is computed once per
+// lane, not once per point); a workgroup pass covers BLOCK columns of one group of K planes, and stores stay coalesced
+// (consecutive lanes = consecutive columns of a plane). (i,j) comes from one division per lane and pass.
 template <int K>
 __global__ void __launch_bounds__(BLOCK, 3) flat_grid_kernel(const uint32_t* __restrict__ code_g, float ox, float oy, float oz, float res,
                                                              unsigned sx, unsigned sy, unsigned kfirst, unsigned nk,
                                                              float* __restrict__ grid) {
-  constexpr int H = K >= 2 ? K / 2 : 1;  // lattice columns per lane
-  constexpr int Z = K >= 2 ? 2 : 1;      // planes per pass
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
-  const unsigned sxy = sx * sy;  // < 2^32 (host checks)
-  const unsigned tpg = (sxy + BLOCK * H - 1) / (BLOCK * H);  // passes per plane group
-  const unsigned ngroups = (nk + Z - 1) / Z;
+  const unsigned sxy = sx * sy;                      // < 2^32 (host checks)
+  const unsigned tpg = (sxy + BLOCK - 1) / BLOCK;  // passes per plane group
+  const unsigned ngroups = (nk + K - 1) / K;
   const uint64_t npass = (uint64_t)tpg * ngroups;
   for (uint64_t w = blockIdx.x; w < npass; w += gridDim.x) {  // uniform trip count
     const unsigned g = (unsigned)(w / tpg), t = (unsigned)(w - (uint64_t)g * tpg);
+    const unsigned col = t * BLOCK + threadIdx.x;
+    const unsigned c = col < sxy ? col : sxy - 1;  // padding lanes evaluate a valid point, nothing is stored
+    const unsigned j = c / sx, i = c - j * sx;
+    const float x = ox + (float)i * res, y = oy + (float)j * res;
     P3 p[K];
     float d[K];
-    unsigned col[H];
 #pragma unroll
-    for (int h = 0; h < H; h++) {
-      unsigned c = t * (BLOCK * H) + (unsigned)h * BLOCK + threadIdx.x;
-      col[h] = c;
-      if (c >= sxy) c = sxy - 1;  // padding lanes evaluate a valid point, nothing is stored
-      const unsigned j = c / sx, i = c - j * sx;
-      const float x = ox + (float)i * res, y = oy + (float)j * res;
+    for (int z = 0; z < K; z++) p[z] = P3{x, y, oz + (float)(kfirst + g * K + (unsigned)z) * res};
+    gsdf_dev::sdf_eval<K, 2>(code, p, d, lds, BLOCK);
 #pragma unroll
-      for (int z = 0; z < Z; z++) p[h * Z + z] = P3{x, y, oz + (float)(kfirst + g * Z + (unsigned)z) * res};
+    for (int z = 0; z < K; z++) {
+      const unsigned k = g * K + (unsigned)z;
+      if (col < sxy && k < nk) grid[(uint64_t)k * sxy + col] = d[z];
     }
-    gsdf_dev::sdf_eval<K, (K >= 2)>(code, p, d, lds, BLOCK);
-#pragma unroll
-    for (int h = 0; h < H; h++)
-#pragma unroll
-      for (int z = 0; z < Z; z++) {
-        const unsigned k = g * Z + (unsigned)z;
-        if (col[h] < sxy && k < nk) grid[(uint64_t)k * sxy + col[h]] = d[h * Z + z];
-      }
   }
 }
 
@@ -878,7 +869,7 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_origin_kernel(const uint32_t* __r
 #pragma unroll
       for (int kp = 0; kp < K; kp++) d[kp] = 3.0e38f;
     } else {
-      gsdf_dev::sdf_eval<K>(code, p, d, lds, BLOCK);
+      gsdf_dev::sdf_eval<K, 2>(code, p, d, lds, BLOCK);  // COLUMN mode: the lane's K cells are one x,y column (z = wave + 4 kp)
 #pragma unroll
       for (int kp = 0; kp < K; kp++) {  // count the lattice cells (tiles overhang the lattice edge)
         const unsigned long long vm = __ballot(valid[kp]);
