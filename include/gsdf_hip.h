@@ -76,7 +76,9 @@ int gsdf_hip_selftest_sqrt(uint64_t* mismatches);
  * gleval/gpu.go:35-54, this is the same step for the HIP backend): builds, with hiprtc, eval / prune / leaf kernels in
  * which this program's instructions are laid out straight-line with literal parameters, and makes the handle launch
  * them. Same statements and compiler flags as the interpreter, so results stay bit-identical; costs a few seconds
- * once per handle. Without it (or if hiprtc is unavailable: GSDF_ERR_HIP) the handle runs the interpreter kernels. */
+ * once per handle. Without it (or if hiprtc is unavailable: GSDF_ERR_HIP) the handle runs the interpreter kernels.
+ * Environment: GSDF_HIP_CACHE_DIR=<dir> keeps the built code objects on disk (key: generated source, device headers,
+ * architecture, options, hiprtc version), so the next process that specialises the same tree reads a file instead. */
 int gsdf_hip_program_specialize(gsdf_program* p);
 int gsdf_hip_program_is_specialized(const gsdf_program* p, double* compile_seconds);
 /* Host-only (run without a GPU): text of the generated evaluator, and a gfx950 hiprtc build of the specialised kernels

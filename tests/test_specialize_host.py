@@ -59,3 +59,34 @@ def test_specialised_2d_program_builds():
     t = b.Union2D(b.NewCircle(1.0), b.Translate2D(b.NewRectangle(1.0, 2.0), 0.5, 0.25)).tree()
     n = C.c_size_t()
     assert hip.lib().gsdf_hip_specialize_check(C.byref(t), C.byref(n)) == 0, hip.lib().gsdf_hip_last_error().decode()[:2000]
+
+
+def test_code_object_cache_on_disk(tmp_path, monkeypatch):
+    """GSDF_HIP_CACHE_DIR: the second build of the same tree is a file read; a damaged file is ignored and rebuilt."""
+    import time
+    monkeypatch.setenv("GSDF_HIP_CACHE_DIR", str(tmp_path))
+    t = Builder().Scene("bolt").tree()
+    n1, n2, n3 = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    t0 = time.perf_counter()
+    assert hip.lib().gsdf_hip_specialize_check(C.byref(t), C.byref(n1)) == 0, hip.lib().gsdf_hip_last_error().decode()[:2000]
+    t_build = time.perf_counter() - t0
+    files = list(tmp_path.glob("gsdf_*.co"))
+    assert len(files) == 1 and not list(tmp_path.glob("*.tmp.*"))
+    assert files[0].stat().st_size > n1.value
+    t0 = time.perf_counter()
+    assert hip.lib().gsdf_hip_specialize_check(C.byref(t), C.byref(n2)) == 0
+    t_hit = time.perf_counter() - t0
+    assert n2.value == n1.value and t_hit < t_build / 4, (t_build, t_hit)
+    # another tree gets another key
+    t2 = Builder().Scene("npt-flange").tree()
+    assert hip.lib().gsdf_hip_specialize_check(C.byref(t2), C.byref(n3)) == 0
+    assert len(list(tmp_path.glob("gsdf_*.co"))) == 2
+    # flip a byte in the middle of the first file: checksum mismatch -> rebuilt and rewritten
+    raw = bytearray(files[0].read_bytes())
+    raw[len(raw) // 2] ^= 0x40
+    files[0].write_bytes(bytes(raw))
+    assert hip.lib().gsdf_hip_specialize_check(C.byref(t), C.byref(n2)) == 0
+    assert n2.value == n1.value and files[0].read_bytes() != bytes(raw)
+    # truncated file: ignored as well
+    files[0].write_bytes(files[0].read_bytes()[:100])
+    assert hip.lib().gsdf_hip_specialize_check(C.byref(t), C.byref(n2)) == 0 and n2.value == n1.value
