@@ -74,13 +74,15 @@ struct gsdf_program {
   hipFunction_t f_eval = nullptr, f_prune = nullptr, f_leaf = nullptr;
   hipFunction_t f_dc_origin = nullptr, f_dc_edges = nullptr, f_dc_normals = nullptr, f_normals = nullptr, f_image = nullptr, f_flat_grid = nullptr;
   bool spec_aux_tried = false;
-  int spec_eval_k = 0, spec_leaf_k = 0, spec_leaf_w = 0;
+  int spec_eval_k = 0, spec_eval_w = 0, spec_leaf_k = 0, spec_leaf_w = 0;
   double spec_compile_s = 0;
   // leaf kernel batching: K = 4 while 3 workgroups still fit the CU's LDS (<= 11 slots); 12..15 slots run K = 2 at 4
   // waves/SIMD instead of K = 4 at 2 (knurled-cylinder: 23.3 vs 23.8 ms). A 4th wave per SIMD is worth more than the
   // ~30 VGPRs it costs (flange 3.28 -> 2.95 ms), but only if 4 workgroups fit the CU's 160 KB of LDS.
   void leaf_config(int* k, int* w, size_t* lds) const;
   size_t lds_bytes(int k = 1) const { return (size_t)(prog.nslots > 0 ? prog.nslots : 1) * k * BLOCK * sizeof(float); }
+  // Workgroups per CU the lattice/eval sweeps are compiled for (their W template argument): 4 when the LDS allows it.
+  int sweep_waves(int k) const { return (k == 1 || 4 * (lds_bytes(k) + 64) <= (size_t)160 * 1024) ? 4 : 3; }
   // Points carried per lane: as many as keep >= 2 workgroups per CU resident (160 KB LDS per CU).
   int batch_k() const {
     static const int forced = [] { const char* e = getenv("GSDF_HIP_BATCH_K"); return e ? atoi(e) : 0; }();  // tuning knob
@@ -271,11 +273,12 @@ static void spec_aux(gsdf_program* p) {
   if (!p->spec_mod || p->spec_aux_tried) return;
   p->spec_aux_tried = true;
   const std::string k = std::to_string(p->batch_k());
+  const std::string kw = k + ", " + std::to_string(p->sweep_waves(p->batch_k()));
   std::vector<hipFunction_t> f;
   if (p->prog.is2d) {
     if (spec_build(p, {"image2_kernel<" + k + ">"}, &p->spec_mod2, f, &p->spec_compile_s) == GSDF_OK) p->f_image = f[0];
   } else {
-    if (spec_build(p, {"dc_origin_kernel<" + k + ">", "dc_edges_kernel", "dc_normals_kernel", "normals_kernel", "flat_grid_kernel<" + k + ">"},
+    if (spec_build(p, {"dc_origin_kernel<" + kw + ">", "dc_edges_kernel", "dc_normals_kernel", "normals_kernel", "flat_grid_kernel<" + kw + ">"},
                    &p->spec_mod2, f, &p->spec_compile_s) == GSDF_OK) {
       p->f_dc_origin = f[0]; p->f_dc_edges = f[1]; p->f_dc_normals = f[2]; p->f_normals = f[3]; p->f_flat_grid = f[4];
     }
@@ -298,7 +301,8 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
   p->leaf_config(&lk, &lw, &lds_m);
   const int ek = p->batch_k();
   std::vector<std::string> names;
-  names.push_back(std::string("eval_kernel<") + (p->prog.is2d ? "2" : "3") + ", " + std::to_string(ek) + ">");
+  const int ew = p->sweep_waves(ek);
+  names.push_back(std::string("eval_kernel<") + (p->prog.is2d ? "2" : "3") + ", " + std::to_string(ek) + ", " + std::to_string(ew) + ">");
   if (!p->prog.is2d) {
     names.push_back("prune_kernel");
     names.push_back("leaf_kernel<" + std::to_string(lk) + ", " + std::to_string(lw) + ">");
@@ -310,7 +314,7 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
   p->spec_mod = mod;
   p->f_eval = f[0];
   if (!p->prog.is2d) { p->f_prune = f[1]; p->f_leaf = f[2]; }
-  p->spec_eval_k = ek; p->spec_leaf_k = lk; p->spec_leaf_w = lw;
+  p->spec_eval_k = ek; p->spec_eval_w = ew; p->spec_leaf_k = lk; p->spec_leaf_w = lw;
   return GSDF_OK;
 }
 /* 1 if the handle runs specialised kernels; compile_seconds (optional) = what the build took */
@@ -342,8 +346,8 @@ extern "C" int gsdf_hip_specialize_check(const gsdf_tree* tree, size_t* code_obj
     std::vector<char> co;
     std::vector<std::string> low;
     std::string log;
-    const std::vector<std::string> names = pr.is2d ? std::vector<std::string>{"eval_kernel<2, 4>"}
-                                                   : std::vector<std::string>{"eval_kernel<3, 4>", "prune_kernel", "leaf_kernel<4, 4>", "flat_grid_kernel<4>"};
+    const std::vector<std::string> names = pr.is2d ? std::vector<std::string>{"eval_kernel<2, 4, 4>"}
+                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
     if (!gsdf_dev::spec_compile(pr, "gfx950", names, co, low, log)) return fail(GSDF_ERR_HIP, "specialised build failed:\n" + log);
     if (code_object_bytes) *code_object_bytes = co.size();
     return GSDF_OK;
@@ -405,12 +409,20 @@ static int eval_dev(gsdf_program* p, int dim, const void* d_pos, size_t stride_b
   const uint32_t sf = (uint32_t)(stride_bytes / 4);
   const float* q = (const float*)d_pos;
   const uint64_t nn = (uint64_t)n;
-#define LAUNCH_EVAL(D, KK) hipLaunchKernelGGL((eval_kernel<D, KK>), dim3(grid), dim3(BLOCK), p->lds_bytes(KK), s, p->d_code, q, sf, d_dist, nn)
-  if (p->f_eval && p->spec_eval_k == k) {
+  const int w = p->sweep_waves(k);
+#define LAUNCH_EVAL(D, KK, WW) hipLaunchKernelGGL((eval_kernel<D, KK, WW>), dim3(grid), dim3(BLOCK), p->lds_bytes(KK), s, p->d_code, q, sf, d_dist, nn)
+  if (p->f_eval && p->spec_eval_k == k && p->spec_eval_w == w) {
     HIP_TRY(launch_fn(p->f_eval, grid, BLOCK, p->lds_bytes(k), s, (const uint32_t*)p->d_code, q, sf, d_dist, nn));
   } else
-  if (dim == 3) { if (k == 4) LAUNCH_EVAL(3, 4); else if (k == 2) LAUNCH_EVAL(3, 2); else LAUNCH_EVAL(3, 1); }
-  else { if (k == 4) LAUNCH_EVAL(2, 4); else if (k == 2) LAUNCH_EVAL(2, 2); else LAUNCH_EVAL(2, 1); }
+  if (dim == 3) {
+    if (k == 4) { if (w == 4) LAUNCH_EVAL(3, 4, 4); else LAUNCH_EVAL(3, 4, 3); }
+    else if (k == 2) { if (w == 4) LAUNCH_EVAL(3, 2, 4); else LAUNCH_EVAL(3, 2, 3); }
+    else LAUNCH_EVAL(3, 1, 4);
+  } else {
+    if (k == 4) { if (w == 4) LAUNCH_EVAL(2, 4, 4); else LAUNCH_EVAL(2, 4, 3); }
+    else if (k == 2) { if (w == 4) LAUNCH_EVAL(2, 2, 4); else LAUNCH_EVAL(2, 2, 3); }
+    else LAUNCH_EVAL(2, 1, 4);
+  }
 #undef LAUNCH_EVAL
   HIP_TRY(hipGetLastError());
   p->evals += n;
@@ -795,7 +807,7 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     if (shard_count > 1) HIP_TRYM(hipMemsetAsync(grid.p, 0xff, ncell * sizeof(int), s));  // cells outside the slab read as empty
     HIP_TRYM(hipEventRecord(p->ev[0], s));
     const unsigned g1 = grid_for((nslab + lk - 1) / lk, p->num_cu, 32);
-#define LAUNCH_O(KK) hipLaunchKernelGGL((dc_origin_kernel<KK>), dim3(g1), dim3(BLOCK), p->lds_bytes(KK) + 32, s, p->d_code, p->prog.nslots, nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, zlo, zhi, ub, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], t0[0], t0[1], t0[2], tn[0], tn[1], tn[2], d_ctr)
+#define LAUNCH_O(KK, WW) hipLaunchKernelGGL((dc_origin_kernel<KK, WW>), dim3(g1), dim3(BLOCK), p->lds_bytes(KK) + 32, s, p->d_code, p->prog.nslots, nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, zlo, zhi, ub, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], t0[0], t0[1], t0[2], tn[0], tn[1], tn[2], d_ctr)
     spec_aux(p);
     const int ub = p->prog.has_exact_bb ? 1 : 0;
     const float* eb = p->prog.exact_bb;
@@ -817,7 +829,9 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     }
     if (p->f_dc_origin) HIP_TRYM(launch_fn(p->f_dc_origin, g1, BLOCK, p->lds_bytes(lk) + 32, s, (const uint32_t*)p->d_code, (int)p->prog.nslots, (int)nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, (unsigned)zlo, (unsigned)zhi, ub, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], t0[0], t0[1], t0[2], tn[0], tn[1], tn[2], d_ctr));
     else
-    if (lk == 4) LAUNCH_O(4); else if (lk == 2) LAUNCH_O(2); else LAUNCH_O(1);
+    if (lk == 4) { if (p->sweep_waves(4) == 4) LAUNCH_O(4, 4); else LAUNCH_O(4, 3); }
+    else if (lk == 2) { if (p->sweep_waves(2) == 4) LAUNCH_O(2, 4); else LAUNCH_O(2, 3); }
+    else LAUNCH_O(1, 4);
 #undef LAUNCH_O
     HIP_TRYM(hipGetLastError());
     if (p->lds_bytes(4) > 150 * 1024) return bail(fail(GSDF_ERR_BAD_TREE, "tree needs too much LDS scratch for the dual contouring edge pass"));
@@ -927,9 +941,11 @@ extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, in
     const uint64_t gmax = (uint64_t)p->num_cu * (uint64_t)(bpc > 0 ? bpc : 64);
     const unsigned g = (unsigned)(npass < gmax ? npass : gmax);
     if (p->f_flat_grid) HIP_TRYM(launch_fn(p->f_flat_grid, g, BLOCK, p->lds_bytes(ek), s, (const uint32_t*)p->d_code, ox, oy, oz, res, sx, sy, c0, nk, grid));
-    else if (ek == 4) hipLaunchKernelGGL((flat_grid_kernel<4>), dim3(g), dim3(BLOCK), p->lds_bytes(4), s, p->d_code, ox, oy, oz, res, sx, sy, c0, nk, grid);
-    else if (ek == 2) hipLaunchKernelGGL((flat_grid_kernel<2>), dim3(g), dim3(BLOCK), p->lds_bytes(2), s, p->d_code, ox, oy, oz, res, sx, sy, c0, nk, grid);
-    else hipLaunchKernelGGL((flat_grid_kernel<1>), dim3(g), dim3(BLOCK), p->lds_bytes(1), s, p->d_code, ox, oy, oz, res, sx, sy, c0, nk, grid);
+#define LAUNCH_FG(KK, WW) hipLaunchKernelGGL((flat_grid_kernel<KK, WW>), dim3(g), dim3(BLOCK), p->lds_bytes(KK), s, p->d_code, ox, oy, oz, res, sx, sy, c0, nk, grid)
+    else if (ek == 4) { if (p->sweep_waves(4) == 4) LAUNCH_FG(4, 4); else LAUNCH_FG(4, 3); }
+    else if (ek == 2) { if (p->sweep_waves(2) == 4) LAUNCH_FG(2, 4); else LAUNCH_FG(2, 3); }
+    else LAUNCH_FG(1, 4);
+#undef LAUNCH_FG
     HIP_TRYM(hipGetLastError());
   }
   HIP_TRYM(hipEventRecord(p->ev[1], s));

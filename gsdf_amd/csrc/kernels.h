@@ -34,8 +34,11 @@ extern __shared__ __attribute__((aligned(16))) float g_smem[];
 
 // dist[i] = SDF(pos[i]). Each lane carries K points per interpreter pass (tile = K*BLOCK points,
 // point kp of lane t = tile + kp*BLOCK + t, so every load/store stays coalesced).
-template <int DIM, int K>
-__global__ void __launch_bounds__(BLOCK, (K == 1 ? 4 : 3)) eval_kernel(const uint32_t* __restrict__ code_g, const float* __restrict__ pos,
+// W = workgroups per CU the register budget is sized for: the host asks for 4 (<= 128 VGPRs) whenever 4 workgroups'
+// slot columns fit the 160 KB of LDS -- the 4th wave per SIMD is worth more than the spills (interpreter build of
+// npt-flange: flat lattice 63 -> 73 G evals/s).
+template <int DIM, int K, int W = (K == 1 ? 4 : 3)>
+__global__ void __launch_bounds__(BLOCK, W) eval_kernel(const uint32_t* __restrict__ code_g, const float* __restrict__ pos,
                                                      uint32_t stride_f, float* __restrict__ dist, uint64_t n) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
@@ -662,8 +665,8 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_brick_kernel(const uint32_t
 // its K points enter the evaluator with bitwise equal x,y (COLUMN mode: every hypot/atan2 of x,y is computed once per
 // lane, not once per point); a workgroup pass covers BLOCK columns of one group of K planes, and stores stay coalesced
 // (consecutive lanes = consecutive columns of a plane). (i,j) comes from one division per lane and pass.
-template <int K>
-__global__ void __launch_bounds__(BLOCK, 3) flat_grid_kernel(const uint32_t* __restrict__ code_g, float ox, float oy, float oz, float res,
+template <int K, int W = 3>
+__global__ void __launch_bounds__(BLOCK, W) flat_grid_kernel(const uint32_t* __restrict__ code_g, float ox, float oy, float oz, float res,
                                                              unsigned sx, unsigned sy, unsigned kfirst, unsigned nk,
                                                              float* __restrict__ grid) {
   code_ptr code = as_code(code_g);
@@ -818,8 +821,8 @@ struct DCCounters {
 };
 
 // Stage 1 (Reset :26-83): evaluate every cube origin; keep iff |d| < 2*size (octreePrunea szMult=2, origin).
-template <int K>
-__global__ void __launch_bounds__(BLOCK, 3) dc_origin_kernel(const uint32_t* __restrict__ code_g, int nslots, int nshift, float ox, float oy,
+template <int K, int W = 3>
+__global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __restrict__ code_g, int nslots, int nshift, float ox, float oy,
                                                              float oz, float res, int* __restrict__ grid, Cube* __restrict__ cubes,
                                                              unsigned long long cube_cap, unsigned zlo, unsigned zhi,
                                                              int use_box, float bx0, float by0, float bz0, float bx1, float by1,
