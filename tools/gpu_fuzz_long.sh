@@ -29,9 +29,12 @@ for seed in range(lo, hi):
             oc = hip.OctreeHIP(sdf, res)
             e2 = (oc.n_tris() != m.n_tris) or (m.n_tris and not (srt(oc.RenderAll()).view(np.uint32) == srt(m.tris).view(np.uint32)).all())
             e3 = mism(sdf.Evaluate(pos), d)
+            fl = hip.FlatHIP(sdf, res)   # flat renderer: COLUMN-mode lattice pass + balanced marching pass
+            mf = ref.render_flat(res, 4096, 2)
+            e4 = (fl.n_tris() != mf.n_tris) or (fl.Evaluations() != mf.evals) or (mf.n_tris and not (srt(fl.RenderAll()).view(np.uint32) == srt(mf.tris).view(np.uint32)).all())
             n += 1
-            if e1 or e2 or e3:
-                bad += 1; print("FAIL seed", seed, "k", k, e1, bool(e2), e3)
+            if e1 or e2 or e3 or e4:
+                bad += 1; print("FAIL seed", seed, "k", k, e1, bool(e2), e3, bool(e4))
         except Exception as ex:
             bad += 1; print("EXC seed", seed, "k", k, repr(ex)[:200])
 print("trees", n, "failures", bad)
