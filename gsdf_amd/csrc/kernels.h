@@ -11,8 +11,12 @@
 //   prune_kernel         octree level: centre sample, keep iff |d| < size*sqrt3/2, block-wide
 //                        compaction of survivors                    glrender/octreerenderer.go:240-284
 //   leaf_kernel          8 leaf corners (corner 0 first, reject |d0| > 2*sqrt3*res) + marching cubes
-//                        with the LDS triangle table, block prefix-sum slot allocation, triangles
-//                        staged in LDS and flushed coalesced          glrender/marchcubes.go:14-98
+//                        with the LDS triangle table; triangles are built one per lane from an LDS
+//                        owner list (mc_emit_balanced), staged in LDS and flushed coalesced
+//                                                                   glrender/marchcubes.go:14-98
+//   flat_grid_kernel     SDF on every corner of the flat lattice    glrender/flatrenderer.go:103-182
+//   flat_march_kernel    marching cubes of every lattice cube from the distance grid (HBM-bound)
+//                                                                   glrender/flatrenderer.go:186-256
 //   dc_*_kernel          dual contouring stages                     glrender/dual_contour*.go
 //   stl_kernel           50-byte STL records staged through LDS     glrender/stl.go:15-62
 //   normals_kernel       central differences                        gleval/gleval.go:53-108
