@@ -927,6 +927,14 @@ extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, in
     if (!e) HIP_TRYM(hipEventCreate(&e));
   HIP_TRYM(p->ctr.ensure(sizeof(MeshCounters)));
   MeshCounters* d_ctr = (MeshCounters*)p->ctr.p;
+  {
+    // refuse up front what cannot fit (a failed multi-hundred-GB hipMalloc is slow and leaves the allocator fragmented)
+    size_t mfree = 0, mtotal = 0;
+    const double need = (double)sxy * (double)nk * sizeof(float);
+    if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && need > (double)mfree + (double)p->flat_grid.cap)
+      return bail(fail(GSDF_ERR_CAPACITY, "flat renderer: the distance grid (" + std::to_string((unsigned long long)(need / 1e9)) +
+                                              " GB) does not fit the device memory; use the octree renderer at this resolution"));
+  }
   if (p->flat_grid.ensure(sxy * nk * sizeof(float)) != hipSuccess) {
     (void)hipGetLastError();
     return bail(fail(GSDF_ERR_CAPACITY, "flat renderer: no device memory for the distance grid (" + std::to_string(sxy * nk * 4) + " bytes)"));

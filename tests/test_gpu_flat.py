@@ -85,6 +85,10 @@ def test_flat_argument_errors(gpu):
         gpu.FlatHIP(sdf, np.float32(0.1), numParallel=0)
     with pytest.raises(gpu.HipError, match="too fine"):
         gpu.FlatHIP(sdf, np.float32(1e-5))
+    # a lattice whose grid cannot fit the device (npt-flange at resdiv 12000: ~700 GB) is refused, not attempted
+    fl = b.Scene("npt-flange")
+    with pytest.raises(gpu.HipError, match="does not fit the device memory"):
+        gpu.FlatHIP(gpu.SDF3HIP(fl), np.float32(float(fl.Diagonal()) / 12000))
     # one cube per axis is a legal lattice
     one = gpu.FlatHIP(sdf, np.float32(3.0))
     assert one.stats.leaf_cubes == 1 and one.Evaluations() == 8
