@@ -246,3 +246,25 @@ def test_block_cached_sdf3_like_reference(gpu):
     with pytest.raises(gpu.HipError) as e:
         cg.Evaluate(np.zeros((0, 3), np.float32))
     assert e.value.msg == "empty buffers"
+
+
+def test_host_buffer_paths_agree_across_the_small_call_threshold(gpu):
+    """gsdf_hip_eval3 serves calls of up to 1 MiB of positions / 2^18 points from pinned, device-mapped host memory (the
+    kernel reads across PCIe) and larger ones through DMA staging: both sides of each limit, both strides, interleaved
+    on one handle, must give the oracle's bits."""
+    b = Builder()
+    s = b.Scene("bolt")
+    sdf = gpu.SDF3HIP(s)
+    ref = OracleSDF(s.tree())
+    rng = np.random.default_rng(5)
+    bb = s.Bounds()
+    for n, width in ((87381, 3), (87382, 3), (65536, 4), (65537, 4), (1, 3), (262144, 3), (40000, 4), (262145, 3), (5, 4)):
+        pos = np.zeros((n, width), np.float32)
+        pos[:, :3] = bb[:3] + rng.random((n, 3), np.float32) * (bb[3:] - bb[:3])
+        keep = pos.copy()
+        d = sdf.Evaluate(pos)
+        assert d.shape == (n,) and (pos == keep).all()
+        step = max(1, n // 3000)   # the oracle on a sample, plus the first and last points
+        idx = np.unique(np.concatenate([np.arange(0, n, step), [0, n - 1]]))
+        dr = ref.Evaluate(np.ascontiguousarray(pos[idx, :3]))
+        assert (d[idx].view(np.uint32) == dr.view(np.uint32)).all(), (n, width)
