@@ -24,7 +24,7 @@ SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "g
            "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_blockcache_create", "gsdf_hip_blockcache_reset", "gsdf_hip_blockcache_eval3", "gsdf_hip_blockcache_hits", "gsdf_hip_blockcache_evaluations", "gsdf_hip_blockcache_destroy", "gsdf_hip_program_specialize", "gsdf_hip_program_is_specialized", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
            "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3", "gsdf_hip_image2",
            "gsdf_hip_mesh_octree", "gsdf_hip_mesh_dualcontour", "gsdf_hip_mesh_flat", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
-           "gsdf_hip_mesh_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner"]
+           "gsdf_hip_mesh_stl", "gsdf_hip_mesh_host_tris", "gsdf_hip_mesh_host_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner"]
 
 
 class MeshOpts(C.Structure):
@@ -94,6 +94,8 @@ def lib():
         L.gsdf_hip_mesh_dev_tris.restype = C.c_void_p
         L.gsdf_hip_mesh_dev_tris.argtypes = [C.c_void_p]
         L.gsdf_hip_mesh_stl.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.gsdf_hip_mesh_host_tris.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.gsdf_hip_mesh_host_stl.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.gsdf_hip_mesh_destroy.argtypes = [C.c_void_p]
         L.gsdf_hip_mesh_destroy.restype = None
         L.gsdf_hip_brick_owner.restype = C.c_uint32
@@ -308,10 +310,32 @@ class OctreeHIP:
 
     def WriteBinarySTL(self):
         """glrender.WriteBinarySTL of the device-resident triangles, records built on device."""
+        return self.stl_view().tobytes()
+
+    def _view(self, ptr, nbytes, dtype):
+        # numpy array over memory the mesh owns; the ctypes object in its base chain keeps this renderer alive
+        raw = (C.c_ubyte * nbytes).from_address(ptr)
+        raw._owner = self
+        a = np.frombuffer(raw, dtype=dtype)
+        a.flags.writeable = False
+        return a
+
+    def triangles_view(self):
+        """All triangles as a read-only (n,3,3) float32 array over pinned host memory owned by the mesh (one DMA, no
+        copy). Valid until this renderer is Reset or freed."""
         n = self.n_tris()
-        buf = np.empty(84 + 50 * n, np.uint8)
-        _check(lib().gsdf_hip_mesh_stl(self._mesh, buf.ctypes.data, buf.size))
-        return buf.tobytes()
+        if n == 0:
+            return np.empty((0, 3, 3), np.float32)
+        p = C.c_void_p()
+        _check(lib().gsdf_hip_mesh_host_tris(self._mesh, C.byref(p)))
+        return self._view(p.value, n * 36, np.float32).reshape(n, 3, 3)
+
+    def stl_view(self):
+        """The complete binary STL file as a read-only uint8 array over pinned host memory owned by the mesh
+        (f.write(view) writes it without another copy). Valid until this renderer is Reset or freed."""
+        p, ln = C.c_void_p(), C.c_size_t()
+        _check(lib().gsdf_hip_mesh_host_stl(self._mesh, C.byref(p), C.byref(ln)))
+        return self._view(p.value, ln.value, np.uint8)
 
 
 class DualContourHIP(OctreeHIP):

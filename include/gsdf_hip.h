@@ -165,6 +165,13 @@ int gsdf_hip_mesh_read(const gsdf_mesh* m, uint64_t first, uint64_t count, float
 const float* gsdf_hip_mesh_dev_tris(const gsdf_mesh* m);
 /* Binary STL (84 + 50*n bytes) built on device into dst (host). dst_cap must be >= that size. */
 int gsdf_hip_mesh_stl(const gsdf_mesh* m, uint8_t* dst, size_t dst_cap);
+/* Zero-copy result views (no reference counterpart: the reference drains a renderer through ReadTriangles into a
+ * 4096-triangle buffer and appends, glrender/glrender.go:20-36, and WriteBinarySTL issues one Write per triangle,
+ * glrender/stl.go:40-58). The whole result is moved once, by DMA, into pinned host memory owned by the mesh: *tris is
+ * n_tris x 9 floats = []ms3.Triangle, *stl the complete binary STL file (84 + 50 n bytes, records built on device).
+ * Valid until gsdf_hip_mesh_destroy; repeated calls return the same memory. */
+int gsdf_hip_mesh_host_tris(gsdf_mesh* m, const float** tris);
+int gsdf_hip_mesh_host_stl(gsdf_mesh* m, const uint8_t** stl, size_t* len);
 void gsdf_hip_mesh_destroy(gsdf_mesh* m);
 
 /* Host-only helper (runs without a GPU): owner rank of octree brick (x,y,z) under the multi-GPU partition

@@ -335,3 +335,34 @@ def test_text_plate_from_reference_font(gpu):
         assert dc.n_tris() == md.n_tris
         assert (_sorted(dc.RenderAll()).view(np.uint32) == _sorted(md.tris).view(np.uint32)).all()
         assert dc.stats.evals < md.evals // 4                # the exact-box early-out applies: text + box are exact fields
+
+
+def test_zero_copy_host_views(gpu):
+    """gsdf_hip_mesh_host_tris / gsdf_hip_mesh_host_stl: pinned host memory owned by the mesh, same bytes as the copying
+    calls, for all three meshers; stable across repeated calls; kept alive by the arrays that look at it."""
+    import ctypes as C
+    import gc
+    b = Builder()
+    s = b.Scene("npt-flange")
+    sdf = gpu.SDF3HIP(s)
+    res = np.float32(float(s.Diagonal()) / 120)
+    for mk in (lambda: gpu.OctreeHIP(sdf, res), lambda: gpu.FlatHIP(sdf, res), lambda: gpu.DualContourHIP(sdf, np.float32(res * 2))):
+        m = mk()
+        tv = m.triangles_view()
+        assert tv.shape == (m.n_tris(), 3, 3) and not tv.flags.writeable
+        assert (tv.view(np.uint32) == m.RenderAll().view(np.uint32)).all()
+        assert m.triangles_view().ctypes.data == tv.ctypes.data           # same memory on the second call
+        sv = m.stl_view()
+        copy = np.empty(84 + 50 * m.n_tris(), np.uint8)                   # the copying entry point
+        assert gpu.lib().gsdf_hip_mesh_stl(m._mesh, copy.ctypes.data, copy.size) == 0
+        assert sv.size == copy.size and (sv == copy).all()
+        assert sv.tobytes() == oracle.write_stl(np.array(tv))
+        # the views keep the renderer (and with it the mesh's host memory) alive
+        del m
+        gc.collect()
+        assert int(tv.view(np.uint32).sum(dtype=np.uint64)) >= 0 and sv[80:84].view(np.uint32)[0] == tv.shape[0]
+    # empty mesh: no triangles to look at, and the reference refuses to write an empty STL (stl.go:19-21)
+    empty = gpu.OctreeHIP(gpu.SDF3HIP(b.Offset(b.NewSphere(1.0), 10.0)), np.float32(0.5))   # d > 0 everywhere
+    assert empty.n_tris() == 0 and empty.triangles_view().shape == (0, 3, 3)
+    with pytest.raises(gpu.HipError, match="empty triangle slice"):
+        empty.stl_view()

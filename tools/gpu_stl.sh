@@ -1,0 +1,27 @@
+#!/bin/bash
+# end-to-end cost of the STL path at resdiv 1600: device record build + transfer to the host
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+timeout 300 python - <<'PY'
+import time
+import numpy as np
+from gsdf_amd.builder import Builder
+from gsdf_amd import hip
+hip.init(0)
+b = Builder()
+s = b.Scene("npt-flange")
+sdf = hip.SDF3HIP(s)
+sdf.specialize()
+res = np.float32(float(s.Diagonal()) / 1600)
+oc = hip.OctreeHIP(sdf, res)
+n = oc.n_tris()
+for name, fn in (("WriteBinarySTL", oc.WriteBinarySTL), ("RenderAll", oc.RenderAll), ("stl_view (fresh mesh)", lambda: hip.OctreeHIP(sdf, res).stl_view()), ("triangles_view (fresh mesh)", lambda: hip.OctreeHIP(sdf, res).triangles_view())):
+    out = fn()
+    del out
+    t0 = time.perf_counter()
+    for _ in range(5):
+        out = fn()
+        nbytes = len(out) if isinstance(out, bytes) else out.nbytes
+        del out  # one mesh alive at a time: its pinned host memory goes back to the pool for the next one
+    dt = (time.perf_counter() - t0) / 5
+    print(f"{name}: {dt * 1e3:.2f} ms for {n} triangles, {nbytes / dt / 1e9:.1f} GB/s")
+PY
