@@ -1122,7 +1122,7 @@ static int host_buf(void** buf, size_t* cap, size_t need) {
   if (*buf) return GSDF_OK;
   *cap = 0;
   const size_t want = need + need / 16 + 4096;
-  hipError_t e = hipHostMalloc(buf, want, hipHostMallocDefault);
+  hipError_t e = hipHostMalloc(buf, want, hipHostMallocPortable);  // the pool is shared by all devices of the process
   if (e != hipSuccess) { *buf = nullptr; (void)hipGetLastError(); return fail(GSDF_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
   *cap = want;
   return GSDF_OK;
