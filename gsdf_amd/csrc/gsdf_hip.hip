@@ -119,6 +119,7 @@ struct gsdf_mesh {
   uint64_t cap = 0;
   gsdf_mesh_stats st{};
   hipStream_t stream = nullptr;
+  bool host_out = false;  // d_tris is pinned, device-mapped HOST memory (gsdf_mesh_opts.host_output): the kernels write across PCIe
   // pinned host copies handed out by gsdf_hip_mesh_host_tris / gsdf_hip_mesh_host_stl (owned by the mesh)
   void* h_tris = nullptr;
   size_t h_tris_cap = 0;
@@ -182,6 +183,13 @@ void pool_give(int device, float* p, uint64_t cap) {
   g_pool.push_back(TriBuf{device, p, cap});
 }
 }  // namespace
+
+static int host_buf(void** buf, size_t* cap, size_t need);
+static void release_tris(gsdf_mesh* m) {
+  if (m->host_out) hpool_give(m->d_tris, (size_t)m->cap * 36);
+  else pool_give(m->device, m->d_tris, m->cap);
+  m->d_tris = nullptr; m->cap = 0; m->host_out = false;
+}
 
 static unsigned grid_for(uint64_t n, int num_cu, int blocks_per_cu) {
   uint64_t b = (n + BLOCK - 1) / BLOCK;
@@ -654,10 +662,21 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     // triangle buffer: caller's size, else a pooled buffer, else a guess that is corrected by one exact rerun
     if (!m->d_tris) {
       uint64_t need = want ? want : (p->last_tris ? p->last_tris + p->last_tris / 16 + 1024 : (uint64_t)1 << 20);
-      m->d_tris = pool_take(p->device, need, &m->cap);
-      if (!m->d_tris) {
-        HIP_TRYM(hipMalloc((void**)&m->d_tris, need * 36));
-        m->cap = need;
+      if (opts.host_output) {
+        // triangles straight into pinned host memory: the stage flushes of leaf_kernel are 4.6 KB coalesced bursts,
+        // which PCIe takes well; the transfer then overlaps the kernel instead of following it
+        void* hb = nullptr;
+        size_t hcap = 0;
+        if (int rc = host_buf(&hb, &hcap, (size_t)need * 36)) return bail(rc);
+        m->d_tris = (float*)hb;
+        m->cap = hcap / 36;
+        m->host_out = true;
+      } else {
+        m->d_tris = pool_take(p->device, need, &m->cap);
+        if (!m->d_tris) {
+          HIP_TRYM(hipMalloc((void**)&m->d_tris, need * 36));
+          m->cap = need;
+        }
       }
     }
     HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(MeshCounters), s));
@@ -723,8 +742,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     if (hc.overflow) {  // triangle buffer too small: the kernel kept counting, so the exact size is known
       if (opts.max_tris) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
       if (attempt >= 8) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
-      pool_give(p->device, m->d_tris, m->cap);
-      m->d_tris = nullptr; m->cap = 0;
+      release_tris(m);
       want = hc.n_tris + hc.n_tris / 16 + 1024;
       continue;
     }
@@ -1122,7 +1140,7 @@ static int host_buf(void** buf, size_t* cap, size_t need) {
   if (*buf) return GSDF_OK;
   *cap = 0;
   const size_t want = need + need / 16 + 4096;
-  hipError_t e = hipHostMalloc(buf, want, hipHostMallocPortable);  // the pool is shared by all devices of the process
+  hipError_t e = hipHostMalloc(buf, want, hipHostMallocPortable | hipHostMallocMapped);  // the pool is shared by all devices of the process; mapped: may serve as a kernel's output buffer
   if (e != hipSuccess) { *buf = nullptr; (void)hipGetLastError(); return fail(GSDF_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
   *cap = want;
   return GSDF_OK;
@@ -1133,6 +1151,10 @@ extern "C" int gsdf_hip_mesh_host_tris(gsdf_mesh* m, const float** tris) {
   *tris = nullptr;
   const uint64_t n = m->st.n_tris;
   if (n == 0) return GSDF_OK;
+  if (m->host_out) {  // the mesher wrote them there
+    *tris = m->d_tris;
+    return GSDF_OK;
+  }
   HIP_TRY(hipSetDevice(m->device));
   if (!m->h_tris) {
     const int rc = host_buf(&m->h_tris, &m->h_tris_cap, (size_t)n * 36);
@@ -1185,7 +1207,7 @@ extern "C" int gsdf_hip_mesh_host_stl(gsdf_mesh* m, const uint8_t** stl, size_t*
 
 extern "C" void gsdf_hip_mesh_destroy(gsdf_mesh* m) {
   if (!m) return;
-  pool_give(m->device, m->d_tris, m->cap);
+  release_tris(m);
   hpool_give(m->h_tris, m->h_tris_cap);
   hpool_give(m->h_stl, m->h_stl_cap);
   delete m;

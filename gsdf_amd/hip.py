@@ -29,7 +29,7 @@ SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "g
 
 class MeshOpts(C.Structure):
     _fields_ = [("prune", C.c_int), ("shard_rank", C.c_int), ("shard_count", C.c_int), ("max_tris", C.c_uint64),
-                ("stream", C.c_void_p), ("share_corners", C.c_int)]
+                ("stream", C.c_void_p), ("share_corners", C.c_int), ("host_output", C.c_int)]
 
 
 class MeshStats(C.Structure):
@@ -249,13 +249,13 @@ class OctreeHIP:
     argument has no meaning here (positions are generated on device)."""
 
     def __init__(self, sdf, res, evalBufferSize=64, prune=True, shard_rank=0, shard_count=1, max_tris=0, stream=None,
-                 share_corners=False):
+                 share_corners=False, host_output=False):
         if evalBufferSize < 64:
             raise ValueError("bad octree eval buffer size")
         self.sdf = sdf
         self._mesh = None
         self._cursor = 0
-        self._opts = MeshOpts(int(prune), shard_rank, shard_count, max_tris, stream, int(share_corners))
+        self._opts = MeshOpts(int(prune), shard_rank, shard_count, max_tris, stream, int(share_corners), int(host_output))
         self.Reset(sdf, res)
 
     def Reset(self, sdf, res):

@@ -125,6 +125,10 @@ typedef struct gsdf_mesh_opts {
   int share_corners;  /* 0 (default): every leaf evaluates its own 8 corners like the reference (8 evals/leaf);
                          1: each bitwise-distinct lattice point of a 4x4x4-leaf brick is evaluated once (identical
                          triangles, ~1.5x fewer evaluations, ~9% less time at npt-flange resdiv 1600) */
+  int host_output;    /* 1: the triangle buffer is pinned, device-mapped HOST memory and the mesher writes it across PCIe
+                         while it runs (gsdf_hip_mesh_host_tris then returns that buffer: mesh + transfer 4.x ms instead
+                         of 1.7 + 4.4 ms at npt-flange resdiv 1600). For results that are consumed on the host only:
+                         device-side consumers (gsdf_hip_mesh_stl, RCCL gathers) would read back over PCIe. */
 } gsdf_mesh_opts;
 
 typedef struct gsdf_mesh_stats {

@@ -361,6 +361,16 @@ def test_zero_copy_host_views(gpu):
         del m
         gc.collect()
         assert int(tv.view(np.uint32).sum(dtype=np.uint64)) >= 0 and sv[80:84].view(np.uint32)[0] == tv.shape[0]
+    # host_output: the mesher writes into pinned host memory itself; same triangles, the view IS the output buffer.
+    # A fresh handle at 1.7 M triangles starts from the default 1 M-triangle buffer: overflow -> exact rerun included.
+    fresh = gpu.SDF3HIP(s)
+    res8 = np.float32(float(s.Diagonal()) / 800)
+    ho = gpu.OctreeHIP(fresh, res8, host_output=True)
+    dv = gpu.OctreeHIP(fresh, res8)
+    assert ho.n_tris() == dv.n_tris() > 1 << 20
+    assert (_sorted(ho.triangles_view()).view(np.uint32) == _sorted(dv.RenderAll()).view(np.uint32)).all()
+    assert (_sorted(ho.RenderAll()).view(np.uint32) == _sorted(dv.RenderAll()).view(np.uint32)).all()   # copying read of host memory
+    assert ho.stl_view().tobytes() == oracle.write_stl(np.array(ho.triangles_view()))               # device STL build reads it back
     # empty mesh: no triangles to look at, and the reference refuses to write an empty STL (stl.go:19-21)
     empty = gpu.OctreeHIP(gpu.SDF3HIP(b.Offset(b.NewSphere(1.0), 10.0)), np.float32(0.5))   # d > 0 everywhere
     assert empty.n_tris() == 0 and empty.triangles_view().shape == (0, 3, 3)
