@@ -1098,6 +1098,16 @@ extern "C" int gsdf_hip_mesh_read(const gsdf_mesh* m, uint64_t first, uint64_t c
   if (!m || (!dst && count)) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
   if (first + count > m->st.n_tris) return fail(GSDF_ERR_BAD_ARGUMENT, "triangle range out of bounds");
   if (count == 0) return GSDF_OK;
+  // The reference's pull loop (glrender.RenderAll: 4096 triangles per ReadTriangles call) would issue ~1700 small
+  // device-to-host copies at resdiv 1600. Partial reads are served from the mesh's pinned host copy instead: one DMA
+  // on the first call, plain memcpy afterwards. A read of everything goes straight to the caller's buffer.
+  if (m->host_out || (count < m->st.n_tris && count * 36 <= ((uint64_t)8 << 20))) {
+    const float* h = nullptr;
+    const int rc = gsdf_hip_mesh_host_tris(const_cast<gsdf_mesh*>(m), &h);
+    if (rc) return rc;
+    std::memcpy(dst, h + first * 9, count * 36);
+    return GSDF_OK;
+  }
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipMemcpy(dst, m->d_tris + first * 9, count * 36, hipMemcpyDeviceToHost));
   return GSDF_OK;

@@ -31,3 +31,28 @@ def srt(t):
 print("host_output mesh identical:", bool((srt(a.triangles_view()).view(np.uint32) == srt(h.triangles_view()).view(np.uint32)).all()),
       "device ms", a.stats.ms_total, "host_output ms", h.stats.ms_total)
 PY
+timeout 300 python - <<'PY'
+import time
+import numpy as np
+from gsdf_amd.builder import Builder
+from gsdf_amd import hip
+hip.init(0)
+b = Builder()
+s = b.Scene("npt-flange")
+sdf = hip.SDF3HIP(s)
+sdf.specialize()
+res = np.float32(float(s.Diagonal()) / 1600)
+buf = np.empty((4096, 3, 3), np.float32)
+for rep in range(3):
+    t0 = time.perf_counter()
+    oc = hip.OctreeHIP(sdf, res)
+    total = 0
+    while True:
+        n, eof = oc.ReadTriangles(buf)
+        total += n
+        if eof:
+            break
+    dt = time.perf_counter() - t0
+    print(f"mesh + ReadTriangles loop (4096 per call): {dt * 1e3:.2f} ms, {total} triangles")
+    del oc
+PY
