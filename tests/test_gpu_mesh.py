@@ -376,3 +376,44 @@ def test_zero_copy_host_views(gpu):
     assert empty.n_tris() == 0 and empty.triangles_view().shape == (0, 3, 3)
     with pytest.raises(gpu.HipError, match="empty triangle slice"):
         empty.stl_view()
+
+
+def test_concurrent_meshing_from_host_threads(gpu):
+    """Handles are independent (own stream, own workspace; buffer pools are locked): four host threads meshing four
+    different scenes at once get the results of the sequential runs."""
+    import threading
+    b = Builder()
+    jobs = [("npt-flange", 300), ("bolt", 260), ("knurled-cylinder", 220), ("npt-flange", 411)]
+    want = []
+    for name, rd in jobs:
+        s = b.Scene(name)
+        oc = gpu.OctreeHIP(gpu.SDF3HIP(s), np.float32(float(s.Diagonal()) / rd))
+        want.append(_digest(oc.RenderAll()))
+    got = [None] * len(jobs)
+    errs = []
+
+    def work(i):
+        try:
+            name, rd = jobs[i]
+            s = Builder().Scene(name)
+            sdf = gpu.SDF3HIP(s)
+            if i % 2 == 0:
+                sdf.specialize()            # hiprtc builds in parallel too
+            res = np.float32(float(s.Diagonal()) / rd)
+            for _ in range(3):
+                oc = gpu.OctreeHIP(sdf, res)
+                d = _digest(oc.triangles_view())
+                assert got[i] in (None, d)
+                got[i] = d
+            fl = gpu.FlatHIP(sdf, np.float32(res * 2))
+            assert fl.n_tris() > 0 and len(fl.stl_view()) == 84 + 50 * fl.n_tris()
+        except Exception as e:  # noqa: BLE001 - reported below, in the main thread
+            errs.append((i, repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert got == want
