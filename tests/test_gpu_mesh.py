@@ -417,3 +417,34 @@ def test_concurrent_meshing_from_host_threads(gpu):
         t.join()
     assert not errs, errs
     assert got == want
+
+
+@pytest.mark.parametrize("nv,inner,offset", [(40, 0.55, 0.0), (64, 0.8, 0.0), (24, 0.3, 75.0), (12, 0.97, -3.0)])
+def test_polygon_edge_culling_is_exact(gpu, nv, inner, offset):
+    """poly_cull (interp.h): the leaf kernel skips polygon edges that cannot hold the minimum / cannot be crossed for any
+    point of a brick. Stars and gears with fine teeth, meshed finely enough for the culling to bite, also far from the
+    origin (large coordinates, same absolute feature size: the margin scales with the magnitudes involved)."""
+    import math
+    b = Builder()
+    verts = []
+    for i in range(nv):
+        a = 2 * math.pi * i / nv
+        r = 1.0 if i % 2 == 0 else inner
+        verts.append((offset + r * math.cos(a), offset * 0.5 + r * math.sin(a)))
+    part = b.Extrude(b.NewPolygon(verts), 0.6)
+    if nv == 64:
+        part = b.Difference(part, b.Translate(b.NewCylinder(0.3, 2.0, 0.0), offset, offset * 0.5, 0.0))
+    res = np.float32(float(part.Diagonal()) / 260)
+    ref = OracleSDF(part.tree())
+    want = _sorted(ref.render_octree(res, 4096, True).tris)
+    sdf = gpu.SDF3HIP(part)
+    for spec in (False, True):
+        if spec:
+            sdf.specialize()
+        oc = gpu.OctreeHIP(sdf, res)
+        got = _sorted(oc.RenderAll())
+        assert got.shape == want.shape and (got.view(np.uint32) == want.view(np.uint32)).all(), (nv, spec)
+    rng = np.random.default_rng(nv)
+    bb = part.Bounds()
+    pos = (bb[:3] + rng.random((30000, 3), np.float32) * (bb[3:] - bb[:3])).astype(np.float32)
+    assert (sdf.Evaluate(pos).view(np.uint32) == ref.Evaluate(pos).view(np.uint32)).all()
