@@ -107,6 +107,29 @@ __device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t n
 // both endpoints the first two are (true, false), if it lies below both (false, true), for every point -- no flip,
 // decided with exact comparisons. Lane e works out edge e (nv <= 64); NaN/Inf anywhere makes every test fail towards
 // "evaluate". For the npt-flange thread profile (12 edges) a brick's wave keeps 2-4 edges.
+// Wave64 min / max with DPP row shifts and row broadcasts (v_min/max_f32 with a DPP operand: no LDS crossbar, no address
+// registers, no lgkmcnt wait -- a ds_bpermute butterfly costs about three times as much). Inclusive scan within each row of
+// 16 lanes (row_shr 1, 2, 4, 8; lanes without a source keep their own value), then lane 15 of rows 0 and 2 into rows 1
+// and 3 (row_bcast:15), then lane 31 into rows 2 and 3 (row_bcast:31): lane 63 holds the result, read back as a scalar.
+// All 64 lanes must be active.
+template <bool MAX>
+__device__ __forceinline__ float wave_minmax(float v) {
+#define GSDF_DPP_STEP(ctrl, rmask)                                                                                          \
+  {                                                                                                                         \
+    const float o = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), \
+                                                                          (ctrl), (rmask), 0xf, false));                     \
+    v = MAX ? dm::maxf(v, o) : dm::minf(v, o);                                                                              \
+  }
+  GSDF_DPP_STEP(0x111, 0xf)  // row_shr:1
+  GSDF_DPP_STEP(0x112, 0xf)  // row_shr:2
+  GSDF_DPP_STEP(0x114, 0xf)  // row_shr:4
+  GSDF_DPP_STEP(0x118, 0xf)  // row_shr:8
+  GSDF_DPP_STEP(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+  GSDF_DPP_STEP(0x143, 0xc)  // row_bcast:31 into rows 2 and 3
+#undef GSDF_DPP_STEP
+  return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+
 template <int K>
 __device__ __forceinline__ void poly_cull(code_ptr code, uint32_t q0, uint32_t nv, const P3 (&pv)[K], uint64_t& keepd,
                                           uint64_t& keeps) {
@@ -116,11 +139,8 @@ __device__ __forceinline__ void poly_cull(code_ptr code, uint32_t q0, uint32_t n
     x0 = minf(x0, pv[kp].x); x1 = maxf(x1, pv[kp].x);
     y0 = minf(y0, pv[kp].y); y1 = maxf(y1, pv[kp].y);
   }
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) {
-    x0 = minf(x0, __shfl_xor(x0, m, 64)); x1 = maxf(x1, __shfl_xor(x1, m, 64));
-    y0 = minf(y0, __shfl_xor(y0, m, 64)); y1 = maxf(y1, __shfl_xor(y1, m, 64));
-  }
+  x0 = wave_minmax<false>(x0); x1 = wave_minmax<true>(x1);
+  y0 = wave_minmax<false>(y0); y1 = wave_minmax<true>(y1);
   const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const bool valid = lane < nv;
   const float* rec = (const float*)(uintptr_t)code + q0 + 8u * (valid ? lane : 0u);  // this lane's edge record
@@ -133,11 +153,8 @@ __device__ __forceinline__ void poly_cull(code_ptr code, uint32_t q0, uint32_t n
   const float dc = sqrtf_(bx * bx + by * by);
   float U = valid ? dc + rb : __builtin_inff();
   float S = valid ? sqrtf_(wx * wx + wy * wy) + sqrtf_(n2e) + rb : 0.0f;
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) {
-    U = minf(U, __shfl_xor(U, m, 64));
-    S = maxf(S, __shfl_xor(S, m, 64));
-  }
+  U = wave_minmax<false>(U);
+  S = wave_minmax<true>(S);
   const float margin = 1.0e-5f * S;
   keepd = __builtin_amdgcn_ballot_w64(valid && !(dc - rb > U + margin));
   keeps = __builtin_amdgcn_ballot_w64(valid && !((y0 >= v1y && y0 >= v2y) || (y1 < v1y && y1 < v2y)));
