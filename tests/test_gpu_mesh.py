@@ -448,3 +448,22 @@ def test_polygon_edge_culling_is_exact(gpu, nv, inner, offset):
     bb = part.Bounds()
     pos = (bb[:3] + rng.random((30000, 3), np.float32) * (bb[3:] - bb[:3])).astype(np.float32)
     assert (sdf.Evaluate(pos).view(np.uint32) == ref.Evaluate(pos).view(np.uint32)).all()
+
+
+def test_example_render_stl(gpu, tmp_path):
+    """examples/render_stl.py: the reference's example flow (part -> mesh -> binary STL file) end to end."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("render_stl", os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "render_stl.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = tmp_path / "flange.stl"
+    assert mod.main(["npt-flange", "--resdiv", "400", "-o", str(out)]) == 0
+    blob = out.read_bytes()
+    assert struct.unpack_from("<I", blob, 80)[0] == 423852 and len(blob) == 84 + 50 * 423852   # README.md:116
+    b = Builder()
+    s = b.Scene("npt-flange")
+    ref = OracleSDF(s.tree()).render_octree(np.float32(float(s.Diagonal()) / 400), 4096, True)
+    # same triangles as the oracle's octree renderer, records in device emission order
+    rec = np.frombuffer(blob, np.uint8, offset=84).reshape(-1, 50)
+    tris = np.ascontiguousarray(rec[:, 12:48]).view(np.float32).reshape(-1, 9)
+    assert (_sorted(tris).view(np.uint32) == _sorted(ref.tris).view(np.uint32)).all()
