@@ -72,3 +72,42 @@ def test_brick_owner_partition_is_balanced_and_total():
         again = np.array([L.gsdf_hip_brick_owner(x, y, z, world) for x, y, z in coords])
         assert (owners == again).all()
     assert L.gsdf_hip_brick_owner(1, 2, 3, 0) == 0
+
+
+def test_headers_are_plain_c_and_the_library_links_from_c(tmp_path):
+    """cgo sees include/*.h as C: they must compile as C11, and a C program must be able to link the library and drive a
+    host-only entry point (a one-node tree through gsdf_hip_lower) -- no C++ types, no name mangling at the boundary."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "gsdf_hip.h"
+int main(void) {
+  gsdf_node n;
+  memset(&n, 0, sizeof n);
+  n.op = GSDF_SPHERE;
+  n.p[0] = 1.5f;
+  gsdf_tree t;
+  memset(&t, 0, sizeof t);
+  t.nodes = &n; t.n_nodes = 1; t.root = 0;
+  t.bb[0] = t.bb[1] = t.bb[2] = -1.5f; t.bb[3] = t.bb[4] = t.bb[5] = 1.5f;
+  uint32_t code[64], words = 0, slots = 0;
+  int rc = gsdf_hip_lower(&t, code, 64, &words, &slots);
+  if (rc != GSDF_OK) { printf("error %d: %s\n", rc, gsdf_hip_last_error()); return 1; }
+  printf("words %u slots %u owner %u\n", words, slots, gsdf_hip_brick_owner(1, 2, 3, 8));
+  return 0;
+}
+''')
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.join(ROOT, "gsdf_amd", "csrc")
+    for h in ("gsdf_hip.h", "gsdf_program.h"):
+        subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, h)])
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-I", inc, str(src), "-L", libdir, "-lgsdfhip", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True)
+    m = re.match(r"words (\d+) slots (\d+) owner (\d+)", out)
+    assert m and int(m.group(1)) >= 2 and int(m.group(3)) == hip.lib().gsdf_hip_brick_owner(1, 2, 3, 8)
