@@ -143,8 +143,9 @@ __device__ __forceinline__ void poly_cull(code_ptr code, uint32_t q0, uint32_t n
   y0 = wave_minmax<false>(y0); y1 = wave_minmax<true>(y1);
   const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const bool valid = lane < nv;
-  const float* rec = (const float*)(uintptr_t)code + q0 + 8u * (valid ? lane : 0u);  // this lane's edge record
-  const float v1x = rec[0], v1y = rec[1], ex = rec[2], ey = rec[3], n2e = rec[4], v2y = rec[5];
+  const v4f* rec = (const v4f*)((const float*)(uintptr_t)code + q0 + 8u * (valid ? lane : 0u));  // this lane's edge record (32-byte aligned)
+  const v4f r0 = rec[0], r1 = rec[1];
+  const float v1x = r0.x, v1y = r0.y, ex = r0.z, ey = r0.w, n2e = r1.x, v2y = r1.y;
   const float cx = 0.5f * (x0 + x1), cy = 0.5f * (y0 + y1), hx = 0.5f * (x1 - x0), hy = 0.5f * (y1 - y0);
   const float rb = sqrtf_(hx * hx + hy * hy);
   const float wx = cx - v1x, wy = cy - v1y;
