@@ -159,6 +159,9 @@ def main():
                     help="mesh (default, BASELINE configs[1]) or eval: the gleval.SDF3.Evaluate micro-benchmark (SURVEY 8(d) M1) on "
                          "HBM-resident positions: 2^24-point chunks of the flat lattice of the scene at --resdiv; flat: the reference's other "
                          "renderer (FlatRenderer) on device, one GPU")
+    ap.add_argument("--renderer", choices=["octree", "dualcontour"], default="octree",
+                    help="mesh mode: octree + marching cubes (default, the headline) or dual contouring (BASELINE configs[4]; "
+                         "e.g. --scene glyph-plate --resdiv 800 --renderer dualcontour)")
     ap.add_argument("--preheat", type=int, default=50, help="untimed meshes run during setup, before the W warmup steps, so that the GPU clocks are up")
     ap.add_argument("--interpreter", action="store_true", help="run the generic interpreter kernels instead of kernels specialised for the tree")
     ap.add_argument("--share-corners", action="store_true", help="evaluate each bitwise-distinct lattice corner of a brick once (same triangles, fewer evals)")
@@ -214,7 +217,10 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        oc = hip.OctreeHIP(sdf, res, shard_rank=rank, shard_count=world, share_corners=args.share_corners)
+        if args.renderer == "dualcontour":  # BASELINE configs[4]: dual contouring, z-slabs of the lattice per rank
+            oc = hip.DualContourHIP(sdf, res, shard_rank=rank, shard_count=world)
+        else:
+            oc = hip.OctreeHIP(sdf, res, shard_rank=rank, shard_count=world, share_corners=args.share_corners)
         gathered = None
         if dist is not None:
             from gsdf_amd.gather import all_gatherv_triangles
@@ -257,6 +263,9 @@ def main():
         st = oc.stats
         # dominant kernel: leaf_kernel. ALGORITHMIC bytes per launch = 16 B per evaluation it performs
         # (12 B position + 4 B distance; positions are generated on device but counted) + 36 B per triangle.
+        dc = args.renderer == "dualcontour"
+        if dc:  # no single dominant kernel is timed apart: price the whole device pass (origin sweep + 4 follow-up kernels)
+            march_ms, march_evals, march_tris = st.ms_total * args.steps, float(st.evals) * args.steps, float(st.n_tris) * args.steps
         k_ms = march_ms / max(1, args.steps)
         k_bytes = (march_evals * 16.0 + march_tris * 36.0) / max(1, args.steps)
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
@@ -266,24 +275,26 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"examples/{args.scene} resdiv {args.resdiv}: octree prune + marching cubes on device "
-                                   f"(res {float(res):.7f}, {st.levels} levels)",
-                       "sharding": "octree bricks by coordinate hash, RCCL all-gatherv of triangles" if world > 1 else "single GPU",
+            "config": {"workload": f"examples/{args.scene} resdiv {args.resdiv}: "
+                                   + ("dual contouring (least-squares vertex placement) on device " if dc else "octree prune + marching cubes on device ")
+                                   + f"(res {float(res):.7f}, {st.levels} levels)",
+                       "sharding": (("z-slabs of the lattice, halo recomputed" if dc else "octree bricks by coordinate hash")
+                                    + ", RCCL all-gatherv of triangles") if world > 1 else "single GPU",
                        "leaf_corners": "shared (distinct lattice points once)" if args.share_corners else "8 per leaf (as the reference)",
                        "evaluator": spec_note,
                        "setup": f"{args.preheat} untimed meshes before the warmup steps (clock ramp)"},
             "triangles_per_s": tris_all / dt,
             "triangles_per_step": tris_all / args.steps, "evals_per_step": evals_all / args.steps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_gb(), "traffic_unit": "GB per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if dc else pmc_traffic_gb(), "traffic_unit": "GB per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
                          "algorithmic_gb_per_launch": k_bytes / 1e9,
-                         "kernel": "leaf_kernel<4>", "kernel_ms": k_ms,
-                         "kernel_evals_per_s": kernel_rate, "valu": valu_roofline(kernel_rate),
+                         "kernel": "dc_origin/edges/normals/place/quads (whole device pass)" if dc else "leaf_kernel<4>", "kernel_ms": k_ms,
+                         "kernel_evals_per_s": kernel_rate, "valu": None if dc else valu_roofline(kernel_rate),
                          "note": "path is fp32-VALU bound (SURVEY 8(d)): algorithmic HBM bytes are tiny by construction; "
                                  "'valu' prices the same kernel against the VALU issue peak"},
             "phase_ms_rank0": {"prune": st.ms_prune, "leaf": st.ms_leaf, "march_kernel": st.ms_march, "total_device": st.ms_total},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not dc:
             threads = max(1, (os.cpu_count() or 2) - 1)  # GOMAXPROCS-1 (gsdfaux/gsdfaux.go:162-164)
             # bounded sample of the SAME workload: full resdiv 1600 lattice (420 M evals) on big hosts, coarser on small ones
             cpu_rd = args.cpu_resdiv or (args.resdiv if threads >= 64 else (1000 if threads >= 16 else 600))
