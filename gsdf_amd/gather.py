@@ -35,11 +35,11 @@ def all_gatherv(local, group=None):
     mx = max(counts_l)
     if mx == 0:
         return torch.empty((0, 9), dtype=torch.float32, device=dev), counts_l
-    if local.shape[0] == mx and local.is_contiguous():
-        send = local                                   # no padding needed: gather straight out of the mesher's buffer
-    else:
-        send = torch.empty((mx, 9), dtype=torch.float32, device=dev)   # the padding rows are never read back
-        send[: local.shape[0]] = local
+    # The collective always works on torch-owned memory: `local` may be a view of a buffer that another HIP runtime
+    # instance allocated (libgsdfhip.so links the system runtime, PyTorch bundles its own), and one device copy of a
+    # rank's share (30 MB at 8 ranks) is cheap insurance against RCCL's pointer bookkeeping.
+    send = torch.empty((mx, 9), dtype=torch.float32, device=dev)   # the padding rows are never read back
+    send[: local.shape[0]] = local
     recv = torch.empty((world, mx, 9), dtype=torch.float32, device=dev)
     dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
     out = torch.cat([recv[r, : counts_l[r]] for r in range(world)], dim=0)
