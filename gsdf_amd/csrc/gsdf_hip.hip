@@ -701,6 +701,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     }
     HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(MeshCounters), s));
     HIP_TRYM(hipEventRecord(ev0, s));
+    static const int prune_bpc = [] { const char* e = getenv("GSDF_HIP_PRUNE_BPC"); return e ? atoi(e) : 4; }();  // tuning knob
     for (int level = levels; level >= lq; level--) {
       const int expand = level != levels;
       const int do_test = (level >= 3 && opts.prune) ? 1 : 0;
@@ -708,13 +709,13 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
       uint64_t bound = (levels - level) * 3 >= 40 ? UINT64_MAX : ((uint64_t)1 << (3 * (levels - level)));
       if (bound > capq[(level + 1) & 1] * 8) bound = capq[(level + 1) & 1] * 8;
       if (p->f_prune) {
-        HIP_TRYM(launch_fn(p->f_prune, grid_for(bound, p->num_cu, 4), BLOCK, lds_prune, s, (const uint32_t*)p->d_code,
+        HIP_TRYM(launch_fn(p->f_prune, grid_for(bound, p->num_cu, prune_bpc), BLOCK, lds_prune, s, (const uint32_t*)p->d_code,
                            (const Cube*)q[(level + 1) & 1]->p, (unsigned long long)capq[(level + 1) & 1], (int)expand, (int)level,
                            (int)p->prog.nslots, ox, oy, oz, res, (int)do_test,
                            (Cube*)q[level & 1]->p, (unsigned long long)capq[level & 1], (int)((opts.shard_count > 1 && level == ls) ? 1 : 0),
                            (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr));
       } else
-      hipLaunchKernelGGL(prune_kernel, dim3(grid_for(bound, p->num_cu, 4)), dim3(BLOCK), lds_prune, s, p->d_code,
+      hipLaunchKernelGGL(prune_kernel, dim3(grid_for(bound, p->num_cu, prune_bpc)), dim3(BLOCK), lds_prune, s, p->d_code,
                          (const Cube*)q[(level + 1) & 1]->p, (unsigned long long)capq[(level + 1) & 1], expand, level, p->prog.nslots, ox, oy,
                          oz, res, do_test, (Cube*)q[level & 1]->p,
                          (unsigned long long)capq[level & 1], (opts.shard_count > 1 && level == ls) ? 1 : 0,
