@@ -1121,24 +1121,17 @@ extern "C" int gsdf_hip_mesh_read(const gsdf_mesh* m, uint64_t first, uint64_t c
   if (count == 0) return GSDF_OK;
   // The reference's pull loop (glrender.RenderAll: 4096 triangles per ReadTriangles call) would issue ~1700 small
   // device-to-host copies at resdiv 1600. Partial reads are served from the mesh's pinned host copy instead: one DMA
-  // on the first call, plain memcpy afterwards. A read of everything goes straight to the caller's buffer.
-  if (m->host_out || (count < m->st.n_tris && count * 36 <= ((uint64_t)8 << 20))) {
-    const float* h = nullptr;
-    const int rc = gsdf_hip_mesh_host_tris(const_cast<gsdf_mesh*>(m), &h);
-    if (rc) return rc;
-    std::memcpy(dst, h + first * 9, count * 36);
-    return GSDF_OK;
-  }
-  // bulk read: DMA into pinned memory at PCIe speed, then a multi-threaded copy (a pageable hipMemcpy is staged by the
-  // runtime at ~12 GB/s)
+  // on the first call, plain memcpy afterwards.
+  // A read of (nearly) everything takes the same route, with a multi-threaded copy out of the pinned buffer (a pageable
+  // hipMemcpy is staged by the runtime at ~12 GB/s).
   {
     const float* h = nullptr;
     if (gsdf_hip_mesh_host_tris(const_cast<gsdf_mesh*>(m), &h) == GSDF_OK) {
-      big_memcpy(dst, h + first * 9, count * 36);
+      big_memcpy(dst, h + first * 9, count * 36);  // single memcpy below 32 MB
       return GSDF_OK;
     }
   }
-  HIP_TRY(hipSetDevice(m->device));  // no pinned memory to be had: plain copy
+  HIP_TRY(hipSetDevice(m->device));  // no pinned memory to be had: plain copy from the device
   HIP_TRY(hipMemcpy(dst, m->d_tris + first * 9, count * 36, hipMemcpyDeviceToHost));
   return GSDF_OK;
 }
