@@ -852,8 +852,8 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
   // [zown_lo-1, zown_hi) placed, which in turn need the distances and normals of [zown_lo-1, zown_hi+1). Every stage is
   // a pure function of the lattice cell, so the halo is recomputed instead of exchanged (no data-path collective).
   const unsigned nz = 1u << nshift;
-  const unsigned zown_lo = (unsigned)(((uint64_t)nz * (uint64_t)shard_rank) / (uint64_t)shard_count);
-  const unsigned zown_hi = (unsigned)(((uint64_t)nz * (uint64_t)(shard_rank + 1)) / (uint64_t)shard_count);
+  uint32_t zown_lo = 0, zown_hi = 0;
+  gsdf_hip_slab_range(nz, (uint32_t)shard_rank, (uint32_t)shard_count, &zown_lo, &zown_hi);
   const unsigned zlo = zown_lo > 0 ? zown_lo - 1 : 0, zhi = zown_hi < nz ? zown_hi + 1 : nz;
   const uint64_t nslab = (uint64_t)(zhi - zlo) << (2 * nshift);
 
@@ -1001,8 +1001,8 @@ extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, in
   const uint64_t sxy = (uint64_t)sx * sy;
   const float ox = mn[0], oy = mn[1], oz = mn[2];
   // this rank's cubes in z and the lattice planes they touch
-  const unsigned c0 = (unsigned)(((uint64_t)nz * (uint64_t)shard_rank) / (uint64_t)shard_count);
-  const unsigned c1 = (unsigned)(((uint64_t)nz * (uint64_t)(shard_rank + 1)) / (uint64_t)shard_count);
+  uint32_t c0 = 0, c1 = 0;
+  gsdf_hip_slab_range(nz, (uint32_t)shard_rank, (uint32_t)shard_count, &c0, &c1);
   const unsigned ncz = c1 - c0, nk = ncz ? ncz + 1 : 0;
 
   gsdf_mesh* m = new (std::nothrow) gsdf_mesh();
@@ -1106,6 +1106,14 @@ extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, in
 
 // Pure host helper (no GPU): owner rank of the brick (x,y,z) under the multi-GPU partition that
 // gsdf_hip_mesh_octree applies on device (same function, SURVEY 8(e): no data-path collective).
+// Pure host helper (no GPU): the z-slab [lo, hi) of n lattice planes that rank `rank` of `count` owns in the flat
+// renderer and in dual contouring -- contiguous, disjoint, covering [0, n); ranks beyond n get empty slabs.
+extern "C" void gsdf_hip_slab_range(uint32_t n, uint32_t rank, uint32_t count, uint32_t* lo, uint32_t* hi) {
+  if (!count || rank >= count) { if (lo) *lo = 0; if (hi) *hi = 0; return; }
+  if (lo) *lo = (uint32_t)(((uint64_t)n * (uint64_t)rank) / (uint64_t)count);
+  if (hi) *hi = (uint32_t)(((uint64_t)n * (uint64_t)(rank + 1)) / (uint64_t)count);
+}
+
 extern "C" uint32_t gsdf_hip_brick_owner(uint32_t x, uint32_t y, uint32_t z, uint32_t count) {
   return count ? brick_owner(x, y, z, count) : 0;
 }

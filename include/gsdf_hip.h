@@ -181,6 +181,10 @@ void gsdf_hip_mesh_destroy(gsdf_mesh* m);
 /* Host-only helper (runs without a GPU): owner rank of octree brick (x,y,z) under the multi-GPU partition
  * gsdf_hip_mesh_octree applies on device -- a pure function of the coordinates, so ranks never communicate. */
 uint32_t gsdf_hip_brick_owner(uint32_t x, uint32_t y, uint32_t z, uint32_t count);
+/* Host-only helper: the z-slab [*lo, *hi) of n lattice planes owned by rank `rank` of `count` in gsdf_hip_mesh_flat (cube
+ * planes) and gsdf_hip_mesh_dualcontour (cell planes): contiguous, disjoint, covering [0, n) -- the reference's goroutine
+ * split of the flat lattice (flatrenderer.go:120-122). */
+void gsdf_hip_slab_range(uint32_t n, uint32_t rank, uint32_t count, uint32_t* lo, uint32_t* hi);
 
 #ifdef __cplusplus
 }

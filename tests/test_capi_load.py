@@ -111,3 +111,25 @@ int main(void) {
     out = subprocess.check_output([str(exe)], text=True)
     m = re.match(r"words (\d+) slots (\d+) owner (\d+)", out)
     assert m and int(m.group(1)) >= 2 and int(m.group(3)) == hip.lib().gsdf_hip_brick_owner(1, 2, 3, 8)
+
+
+def test_slab_partition_tiles_the_lattice():
+    """The z-slab split of the flat renderer and of dual contouring (multi-GPU, no data-path collective): for any plane
+    count and world size the ranks' slabs are contiguous, disjoint, in order, cover [0, n) and differ by at most one."""
+    L = hip.lib()
+    lo, hi = C.c_uint32(), C.c_uint32()
+    for n in (0, 1, 2, 7, 8, 335, 1024, 2048, 4095, 2**31 + 5):
+        for world in (1, 2, 3, 4, 8, 16, 64):
+            edges, sizes = [], []
+            for r in range(world):
+                L.gsdf_hip_slab_range(n, r, world, C.byref(lo), C.byref(hi))
+                assert lo.value <= hi.value <= n
+                edges.append((lo.value, hi.value))
+                sizes.append(hi.value - lo.value)
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            assert max(sizes) - min(sizes) <= 1
+    L.gsdf_hip_slab_range(10, 5, 4, C.byref(lo), C.byref(hi))     # rank out of range: empty
+    assert (lo.value, hi.value) == (0, 0)
+    L.gsdf_hip_slab_range(10, 0, 0, C.byref(lo), C.byref(hi))     # no ranks: empty
+    assert (lo.value, hi.value) == (0, 0)
