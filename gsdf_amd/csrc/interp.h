@@ -101,7 +101,7 @@ __device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t n
 // change a single bit of the result. With B = the bounding box of the wave's K*64 points (centre c, half diagonal rb)
 // and dc(e) = distance from c to edge e, every point p of the wave has dist(p, e) in [dc(e) - rb, dc(e) + rb]; so with
 // U = min over e of dc(e) + rb, an edge with dc(e) - rb > U + margin is never the nearest one. The margin (1e-5 of the
-// largest |p - v|, |e| magnitude entering any of these sums -- the float error of the compared quantities is < 1e-6
+// largest |p - v|, |e|, |c| magnitude entering any of these sums -- the float error of the compared quantities is < 1e-6
 // of that) keeps the decision on the safe side: a doubtful edge is evaluated. The winding predicates of an edge are
 // (p.y >= v1.y, p.y < v2.y, cross > 0) and flip the sign only when all three agree: if the whole box lies at or above
 // both endpoints the first two are (true, false), if it lies below both (false, true), for every point -- no flip,
@@ -153,7 +153,8 @@ __device__ __forceinline__ void poly_cull(code_ptr code, uint32_t q0, uint32_t n
   const float bx = wx - t * ex, by = wy - t * ey;
   const float dc = sqrtf_(bx * bx + by * by);
   float U = valid ? dc + rb : __builtin_inff();
-  float S = valid ? sqrtf_(wx * wx + wy * wy) + sqrtf_(n2e) + rb : 0.0f;
+  // (|c| too: the rounded centre may sit half an ulp of its own magnitude off the box's true centre)
+  float S = valid ? sqrtf_(wx * wx + wy * wy) + sqrtf_(n2e) + rb + absf(cx) + absf(cy) : 0.0f;
   U = wave_minmax<false>(U);
   S = wave_minmax<true>(S);
   const float margin = 1.0e-5f * S;

@@ -419,7 +419,7 @@ def test_concurrent_meshing_from_host_threads(gpu):
     assert got == want
 
 
-@pytest.mark.parametrize("nv,inner,offset", [(40, 0.55, 0.0), (64, 0.8, 0.0), (24, 0.3, 75.0), (12, 0.97, -3.0)])
+@pytest.mark.parametrize("nv,inner,offset", [(40, 0.55, 0.0), (64, 0.8, 0.0), (24, 0.3, 75.0), (12, 0.97, -3.0), (30, 0.6, 3000.0)])
 def test_polygon_edge_culling_is_exact(gpu, nv, inner, offset):
     """poly_cull (interp.h): the leaf kernel skips polygon edges that cannot hold the minimum / cannot be crossed for any
     point of a brick. Stars and gears with fine teeth, meshed finely enough for the culling to bite, also far from the
