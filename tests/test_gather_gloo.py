@@ -1,5 +1,6 @@
 """N>1 path on CPU: world_size-2 gloo run of the variable-length triangle gather (gsdf_amd/gather.py)
-over the partition the mesher uses (gsdf_hip_shard_bricks), with oracle-free synthetic triangles."""
+with oracle-free synthetic triangles of ragged per-rank counts (the partition itself -- gsdf_hip_brick_owner,
+gsdf_hip_slab_range -- is tested in tests/test_capi_load.py)."""
 import os
 import socket
 import sys
