@@ -3,7 +3,7 @@
 The mesher shards octree bricks across ranks with no data-path communication; the only exchange is
 this final gather. RCCL has no all-gatherv: exchange the counts (one all_gather of
 world int64), pad every rank's payload to the maximum count and run ONE all_gather_into_tensor (one
-large collective; bricks are dealt round-robin so counts are balanced and padding is small), then
+large collective; bricks are dealt by a coordinate hash so counts are balanced and padding is small), then
 compact on device.
 """
 import torch

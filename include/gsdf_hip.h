@@ -119,7 +119,7 @@ int gsdf_hip_image2(gsdf_program* p, int w, int h, float* dist_out, uint8_t* rgb
 typedef struct gsdf_mesh_opts {
   int prune;          /* 1: octree centre-test pruning of every Level>=3 cube (default); 0: visit all leaves */
   int shard_rank;     /* multi-GPU: this rank ... */
-  int shard_count;    /* ... of this many (1 = whole model). Bricks are dealt round-robin. */
+  int shard_count;    /* ... of this many (1 = whole model). Bricks of 16^3 leaves go to rank gsdf_hip_brick_owner(x, y, z, count). */
   uint64_t max_tris;  /* device triangle buffer capacity; 0 = size automatically */
   void* stream;       /* hipStream_t to run on; NULL = the program's stream */
   int share_corners;  /* 0 (default): every leaf evaluates its own 8 corners like the reference (8 evals/leaf);
