@@ -74,7 +74,7 @@ struct gsdf_program {
   uint64_t last_tris = 0;  // triangle count of the previous mesh on this handle: sizes the next output buffer
   uint64_t last_dc_cubes = 0;  // kept cubes of the previous dual contouring pass: sizes the next queues
   // run-time specialised kernels for this program (gsdf_hip_program_specialize): hiprtc module, else interpreter
-  hipModule_t spec_mod = nullptr, spec_mod2 = nullptr;  // spec_mod2: second group, built on first use (see spec_aux)
+  hipModule_t spec_mod = nullptr, spec_mod2 = nullptr, spec_mod3 = nullptr, spec_mod4 = nullptr;  // spec_mod4: leaf kernel rebuilt with a larger register budget; spec_mod2: second group, built on first use (see spec_aux); spec_mod3: eval kernel rebuilt for 3 workgroups per CU
   hipFunction_t f_eval = nullptr, f_prune = nullptr, f_leaf = nullptr;
   hipFunction_t f_dc_origin = nullptr, f_dc_edges = nullptr, f_dc_normals = nullptr, f_normals = nullptr, f_image = nullptr, f_flat_grid = nullptr;
   bool spec_aux_tried = false;
@@ -86,7 +86,11 @@ struct gsdf_program {
   void leaf_config(int* k, int* w, size_t* lds) const;
   size_t lds_bytes(int k = 1) const { return (size_t)(prog.nslots > 0 ? prog.nslots : 1) * k * BLOCK * sizeof(float); }
   // Workgroups per CU the lattice/eval sweeps are compiled for (their W template argument): 4 when the LDS allows it.
-  int sweep_waves(int k) const { return (k == 1 || 4 * (lds_bytes(k) + 64) <= (size_t)160 * 1024) ? 4 : 3; }
+  int sweep_waves(int k) const {
+    static const int forced = [] { const char* e = getenv("GSDF_HIP_SWEEP_WAVES"); return e ? atoi(e) : 0; }();  // tuning / debugging knob
+    if (k != 1 && (forced == 3 || forced == 4)) return forced;
+    return (k == 1 || 4 * (lds_bytes(k) + 64) <= (size_t)160 * 1024) ? 4 : 3;
+  }
   // Points carried per lane: as many as keep >= 2 workgroups per CU resident (160 KB LDS per CU).
   int batch_k() const {
     static const int forced = [] { const char* e = getenv("GSDF_HIP_BATCH_K"); return e ? atoi(e) : 0; }();  // tuning knob
@@ -329,6 +333,24 @@ static int spec_build(gsdf_program* p, const std::vector<std::string>& names, hi
   return GSDF_OK;
 }
 
+// Scratch (private segment) bytes per lane of a built kernel. A specialised kernel is used only if this is 0: its code
+// shape is new for every tree, and a build that spills registers inside divergent regions has been seen to lose the
+// spilled values of the lanes that were inactive at the spill (2-D fuzz tree 708: eval_kernel<2,4,4>, 128 VGPRs + 132 B
+// of scratch, wrote the results of 216 points of a ragged last tile to the wrong addresses). The ahead-of-time
+// interpreter kernels have ONE code shape each, and that shape is what the whole test suite runs.
+static int fn_scratch_bytes(hipFunction_t f) {
+  int v = 0;
+  if (hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f) != hipSuccess) { (void)hipGetLastError(); return 1 << 30; }
+  return v;
+}
+static void spec_report(const char* what, const std::string& name, hipFunction_t f, bool used) {
+  if (!getenv("GSDF_HIP_DEBUG")) return;
+  int regs = -1;
+  (void)hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, f);
+  fprintf(stderr, "gsdf_hip: %s %s: %d registers, %d B scratch per lane -> %s\n", what, name.c_str(), regs, fn_scratch_bytes(f),
+          used ? "used" : "not used (interpreter kernel instead)");
+}
+
 // Second group of a specialised handle, built the first time one of these entry points runs: the evaluating kernels of
 // dual contouring, central-difference normals, the flat renderer's lattice pass and the 2-D image renderer. Failure leaves the interpreter kernels in use.
 static void spec_aux(gsdf_program* p) {
@@ -338,11 +360,21 @@ static void spec_aux(gsdf_program* p) {
   const std::string kw = k + ", " + std::to_string(p->sweep_waves(p->batch_k()));
   std::vector<hipFunction_t> f;
   if (p->prog.is2d) {
-    if (spec_build(p, {"image2_kernel<" + k + ">"}, &p->spec_mod2, f, &p->spec_compile_s) == GSDF_OK) p->f_image = f[0];
+    if (spec_build(p, {"image2_kernel<" + k + ">"}, &p->spec_mod2, f, &p->spec_compile_s) == GSDF_OK) {
+      const bool ok = fn_scratch_bytes(f[0]) == 0;
+      spec_report("specialised", "image2_kernel", f[0], ok);
+      p->f_image = ok ? f[0] : nullptr;
+    }
   } else {
     if (spec_build(p, {"dc_origin_kernel<" + kw + ">", "dc_edges_kernel", "dc_normals_kernel", "normals_kernel", "flat_grid_kernel<" + kw + ">"},
                    &p->spec_mod2, f, &p->spec_compile_s) == GSDF_OK) {
-      p->f_dc_origin = f[0]; p->f_dc_edges = f[1]; p->f_dc_normals = f[2]; p->f_normals = f[3]; p->f_flat_grid = f[4];
+      const char* nm[5] = {"dc_origin_kernel", "dc_edges_kernel", "dc_normals_kernel", "normals_kernel", "flat_grid_kernel"};
+      hipFunction_t* dst[5] = {&p->f_dc_origin, &p->f_dc_edges, &p->f_dc_normals, &p->f_normals, &p->f_flat_grid};
+      for (int i = 0; i < 5; i++) {
+        const bool ok = fn_scratch_bytes(f[(size_t)i]) == 0;
+        spec_report("specialised", nm[i], f[(size_t)i], ok);
+        *dst[i] = ok ? f[(size_t)i] : nullptr;
+      }
     }
   }
 }
@@ -374,9 +406,43 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
   const int rc = spec_build(p, names, &mod, f, &p->spec_compile_s);
   if (rc != GSDF_OK) return rc;
   p->spec_mod = mod;
-  p->f_eval = f[0];
-  if (!p->prog.is2d) { p->f_prune = f[1]; p->f_leaf = f[2]; }
   p->spec_eval_k = ek; p->spec_eval_w = ew; p->spec_leaf_k = lk; p->spec_leaf_w = lw;
+  // No scratch, or not used (see fn_scratch_bytes). The eval kernel gets a second chance with the larger register
+  // budget of 3 workgroups per CU before the handle falls back to the interpreter kernel for that entry point.
+  {
+    bool ok = fn_scratch_bytes(f[0]) == 0;
+    spec_report("specialised", names[0], f[0], ok);
+    p->f_eval = ok ? f[0] : nullptr;
+    if (!ok && ew == 4) {
+      std::vector<hipFunction_t> f3;
+      const std::string n3 = std::string("eval_kernel<") + (p->prog.is2d ? "2" : "3") + ", " + std::to_string(ek) + ", 3>";
+      if (spec_build(p, {n3}, &p->spec_mod3, f3, &p->spec_compile_s) == GSDF_OK) {
+        ok = fn_scratch_bytes(f3[0]) == 0;
+        spec_report("specialised", n3, f3[0], ok);
+        if (ok) { p->f_eval = f3[0]; p->spec_eval_w = 3; }
+      }
+    }
+  }
+  if (!p->prog.is2d) {
+    const bool okp = fn_scratch_bytes(f[1]) == 0;
+    bool okl = fn_scratch_bytes(f[2]) == 0;
+    spec_report("specialised", names[1], f[1], okp);
+    spec_report("specialised", names[2], f[2], okl);
+    p->f_prune = okp ? f[1] : nullptr;
+    p->f_leaf = okl ? f[2] : nullptr;
+    // the leaf kernel is where the time goes: before giving it up, trade occupancy for registers (W = workgroups per CU
+    // the register budget is sized for; the launch is the same)
+    for (int w2 = lw - 1; !okl && w2 >= 2; w2--) {
+      std::vector<hipFunction_t> fl;
+      hipModule_t m2 = nullptr;
+      const std::string nl = "leaf_kernel<" + std::to_string(lk) + ", " + std::to_string(w2) + ">";
+      if (spec_build(p, {nl}, &m2, fl, &p->spec_compile_s) != GSDF_OK) break;
+      okl = fn_scratch_bytes(fl[0]) == 0;
+      spec_report("specialised", nl, fl[0], okl);
+      if (okl) { p->f_leaf = fl[0]; p->spec_leaf_w = w2; p->spec_mod4 = m2; }
+      else (void)hipModuleUnload(m2);
+    }
+  }
   return GSDF_OK;
 }
 /* 1 if the handle runs specialised kernels; compile_seconds (optional) = what the build took */
@@ -444,6 +510,8 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (p->h_dist) (void)hipHostFree(p->h_dist);
   if (p->spec_mod) (void)hipModuleUnload(p->spec_mod);
   if (p->spec_mod2) (void)hipModuleUnload(p->spec_mod2);
+  if (p->spec_mod3) (void)hipModuleUnload(p->spec_mod3);
+  if (p->spec_mod4) (void)hipModuleUnload(p->spec_mod4);
   p->q0.release(); p->q1.release(); p->ctr.release();
   p->flat_grid.release(); p->dc_grid.release(); p->dc_dist.release(); p->dc_fv.release(); p->dc_nrm.release(); p->dc_edge.release();
   for (auto e : p->ev) if (e) (void)hipEventDestroy(e);
@@ -475,7 +543,7 @@ static int eval_dev(gsdf_program* p, int dim, const void* d_pos, size_t stride_b
   const uint64_t nn = (uint64_t)n;
   const int w = p->sweep_waves(k);
 #define LAUNCH_EVAL(D, KK, WW) hipLaunchKernelGGL((eval_kernel<D, KK, WW>), dim3(grid), dim3(BLOCK), p->lds_bytes(KK), s, p->d_code, q, sf, d_dist, nn)
-  if (p->f_eval && p->spec_eval_k == k && p->spec_eval_w == w) {
+  if (p->f_eval && p->spec_eval_k == k) {  // whichever W the specialised kernel was built for: same launch
     HIP_TRY(launch_fn(p->f_eval, grid, BLOCK, p->lds_bytes(k), s, (const uint32_t*)p->d_code, q, sf, d_dist, nn));
   } else
   if (dim == 3) {
@@ -740,7 +808,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
                            dim3(BLOCK), lds_b, s, p->d_code, (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1],
                            p->prog.nslots, ox, oy, oz, res, m->d_tris, tcap, d_ctr);
         used_brick = true;
-      } else if (p->f_leaf && p->spec_leaf_k == lk && p->spec_leaf_w == lw) {
+      } else if (p->f_leaf && p->spec_leaf_k == lk) {  // whichever W it was built for: same launch
         HIP_TRYM(launch_fn(p->f_leaf, grid_for(bound, p->num_cu, leaf_bpc), BLOCK, lds_m, s, (const uint32_t*)p->d_code, (const Cube*)q[lq & 1]->p,
                            (unsigned long long)capq[lq & 1], (int)lq, (int)p->prog.nslots, ox, oy, oz, res, m->d_tris,
                            (unsigned long)tcap, d_ctr));
