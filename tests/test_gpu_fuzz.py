@@ -100,3 +100,25 @@ def test_random_trees_dual_contouring_and_normals(gpu):
         pos = _points(sh, rng, 2000)
         assert _mismatch(sdf.normals(pos, 1e-3), ref.normals_central_diff(pos, 1e-3)) == 0, k
     assert done >= 4
+
+
+def test_ragged_last_tile_of_a_large_specialised_2d_program(gpu):
+    """Regression (2-D fuzz tree 708/1): under the 4-workgroup register budget its specialised eval kernel needs scratch, and
+    that build wrote the results of the points sharing a lane with the padding of a ragged last tile to wrong addresses.
+    Kernels that need scratch are no longer used; whatever kernel the handle ends up with must give the oracle's bits
+    for ragged and full batch sizes alike."""
+    _, shapes = fuzz_trees.random_shapes2d(708, 6, depth=3)
+    sh = shapes[1]
+    ref = OracleSDF(sh.tree())
+    rng = np.random.default_rng(1)
+    bb = np.asarray(sh.Bounds(), np.float32)
+    lo, hi = bb[[0, 1]], bb[[3, 4]]
+    allpos = ((lo + hi) / 2 + (rng.random((5000, 2), np.float32) * 2 - 1) * (hi - lo) * np.float32(0.6)).astype(np.float32)
+    want = ref.Evaluate(allpos)
+    for spec in (False, True):
+        sdf = gpu.SDF2HIP(sh)
+        if spec:
+            sdf.specialize()
+        for n in (3000, 4097, 1024, 216, 257, 1, 5000):
+            got = sdf.Evaluate(allpos[:n].copy())
+            assert _mismatch(got, want[:n]) == 0, (spec, n)
