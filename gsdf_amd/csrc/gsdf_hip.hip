@@ -804,7 +804,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
       if (lq == 3 && lk == 4 && opts.share_corners) {
         // exact corner sharing: one wave per level-3 brick
         const size_t lds_b = (size_t)(p->prog.nslots * 4) * BLOCK * sizeof(float) + 4096 + TRI_STAGE * 36 + 32 + 4 * 512 * 4 + 4 * 24 * 4;
-        hipLaunchKernelGGL((leaf_brick_kernel<4, 3>), dim3(grid_for(capq[lq & 1] * 64 < bound ? capq[lq & 1] * 64 : bound, p->num_cu, 8)),
+        hipLaunchKernelGGL((leaf_brick_kernel<4, 2>), dim3(grid_for(capq[lq & 1] * 64 < bound ? capq[lq & 1] * 64 : bound, p->num_cu, 8)),
                            dim3(BLOCK), lds_b, s, p->d_code, (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1],
                            p->prog.nslots, ox, oy, oz, res, m->d_tris, tcap, d_ctr);
         used_brick = true;
@@ -813,8 +813,11 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
                            (unsigned long long)capq[lq & 1], (int)lq, (int)p->prog.nslots, ox, oy, oz, res, m->d_tris,
                            (unsigned long)tcap, d_ctr));
       } else {
-        if (lk == 4) { if (lw == 2) LAUNCH_LEAF(4, 2); else if (lw == 4) LAUNCH_LEAF(4, 4); else LAUNCH_LEAF(4, 3); }
-        else if (lk == 2) { if (lw == 4) LAUNCH_LEAF(2, 4); else LAUNCH_LEAF(2, 3); }
+        // Ahead-of-time (interpreter) leaf kernels exist only at occupancies the compiler reaches WITHOUT scratch
+        // (tests/test_kernel_resources.py reads the shipped code object): at 4 workgroups per CU (128 VGPRs) the K = 4 and
+        // K = 2 interpreter builds spill, and a spilling build is not trusted (see fn_scratch_bytes).
+        if (lk == 4) { if (lw == 2) LAUNCH_LEAF(4, 2); else LAUNCH_LEAF(4, 3); }
+        else if (lk == 2) LAUNCH_LEAF(2, 3);
         else LAUNCH_LEAF(1, 4);
       }
 #undef LAUNCH_LEAF
@@ -991,7 +994,7 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     }
     if (p->f_dc_origin) HIP_TRYM(launch_fn(p->f_dc_origin, g1, BLOCK, p->lds_bytes(lk) + 32, s, (const uint32_t*)p->d_code, (int)p->prog.nslots, (int)nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, (unsigned)zlo, (unsigned)zhi, ub, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], t0[0], t0[1], t0[2], tn[0], tn[1], tn[2], d_ctr));
     else
-    if (lk == 4) { if (p->sweep_waves(4) == 4) LAUNCH_O(4, 4); else LAUNCH_O(4, 3); }
+    if (lk == 4) LAUNCH_O(4, 3);  // <4, 4> needs scratch: not built (see fn_scratch_bytes)
     else if (lk == 2) { if (p->sweep_waves(2) == 4) LAUNCH_O(2, 4); else LAUNCH_O(2, 3); }
     else LAUNCH_O(1, 4);
 #undef LAUNCH_O
