@@ -5,10 +5,12 @@
 // device sees bit-identical parameters. MUST be compiled with -ffp-contract=off.
 #include "compile.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 
 #include "../host/ms.hpp"
 #include "dev_ops.h"
@@ -148,29 +150,96 @@ bool clobbers(Ctx& c, uint32_t i) {
 
 void gen(Ctx& c, uint32_t i, int depth);
 
-// Bounding box (min xyz, max xyz; z ignored for 2-D nodes) of a subtree whose field is at least the Euclidean distance
-// to that box: exact-distance primitives under translation, union, and as the first operand of a difference or an
-// intersection (max(a, .) >= a). Everything else -- smoothing, scaling, domain repetition, approximate primitives --
-// answers false: no claim, the child is always evaluated.
-// *solid (optional): additionally the shape is known to be non-empty inside the box, so the field is also <= the
-// distance to the box's farthest corner (the upper bound D_UBOUND* uses). A difference or intersection may be empty.
-bool exact_box(Ctx& c, uint32_t i, float bb[6], int depth = 0, bool* solid = nullptr) {
+// ---------------------------------------------------------------------------------------------------------------------
+// Lower-bound regions. For a subtree S, lower_region() answers with a region G such that, for every point p OUTSIDE G,
+//   S(p) >= LB_G(p) > 0,        LB_BOX(p)  = max over axes of (mn - p, p - mx)              (Chebyshev distance)
+//                               LB_ZCYL(p) = max(z0 - z, z - z1, rs * (hypot(x - cx, y - cy) - r))
+// (the device uses a cheaper lower estimate of the hypot, see region_lb in interp.h). Both are lower bounds of the
+// Euclidean distance to G, which in turn bounds exact-distance fields from below; the screw and the smooth combines
+// are not exact, their rules are derived one by one below. The claim is about values > 0 only: inside G nothing is said.
+// Users: the gates of gen_combine (a child whose lower bound proves it cannot influence its parent's combine for any
+// point of a wave is skipped, D_GATE*), and Program::exact_bb (dual contouring's origin pass).
+//   *solid (optional): additionally the shape is non-empty inside the box, so the field is also <= the distance to the
+//   box's farthest corner (the upper bound D_UBOUND* uses); only claimed for exact primitives under rigid motions,
+//   uniform scaling and plain unions.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Region {
+  enum Kind { NONE = 0, BOX = 1, ZCYL = 2 } kind = NONE;
+  float b[6] = {0, 0, 0, 0, 0, 0};  // BOX: min xyz, max xyz (2-D: z = 0) | ZCYL: cx cy r z0 z1 rs
+};
+
+// The z-axis cylinder (about the axis through (cx, cy)) that encloses a region: what survives a rotation about z.
+Region enclose_zcyl(const Region& g, float cx, float cy, bool is2d) {
+  Region o;
+  o.kind = Region::ZCYL;
+  o.b[0] = cx; o.b[1] = cy;
+  if (g.kind == Region::BOX) {
+    double r = 0;
+    for (int k = 0; k < 4; k++) {
+      const double dx = (double)g.b[(k & 1) ? 3 : 0] - cx, dy = (double)g.b[(k & 2) ? 4 : 1] - cy;
+      r = std::fmax(r, std::sqrt(dx * dx + dy * dy));
+    }
+    o.b[2] = (float)(r * (1 + 1e-6) + 1e-30);
+    o.b[3] = is2d ? -3.0e38f : g.b[2]; o.b[4] = is2d ? 3.0e38f : g.b[5]; o.b[5] = 1.0f;
+  } else {
+    const double dx = (double)g.b[0] - cx, dy = (double)g.b[1] - cy;
+    o.b[2] = (float)((std::sqrt(dx * dx + dy * dy) + (double)g.b[2]) * (1 + 1e-6) + 1e-30);
+    o.b[3] = g.b[3]; o.b[4] = g.b[4]; o.b[5] = g.b[5];
+  }
+  return o;
+}
+
+// Smallest region of a common kind holding both (what a minimum of the two fields is bounded by).
+bool hull(const Region& a, const Region& b, bool is2d, Region& o) {
+  if (a.kind == Region::NONE || b.kind == Region::NONE) return false;
+  if (a.kind == Region::BOX && b.kind == Region::BOX) {
+    o.kind = Region::BOX;
+    for (int j = 0; j < 3; j++) { o.b[j] = std::fmin(a.b[j], b.b[j]); o.b[j + 3] = std::fmax(a.b[j + 3], b.b[j + 3]); }
+    return true;
+  }
+  // at least one cylinder: both about the axis of the (first) cylinder
+  const Region& zc = a.kind == Region::ZCYL ? a : b;
+  const Region ea = enclose_zcyl(a, zc.b[0], zc.b[1], is2d), eb = enclose_zcyl(b, zc.b[0], zc.b[1], is2d);
+  o.kind = Region::ZCYL;
+  o.b[0] = zc.b[0]; o.b[1] = zc.b[1];
+  o.b[2] = std::fmax(ea.b[2], eb.b[2]);
+  o.b[3] = std::fmin(ea.b[3], eb.b[3]); o.b[4] = std::fmax(ea.b[4], eb.b[4]);
+  o.b[5] = std::fmin(ea.b[5], eb.b[5]);
+  return true;
+}
+
+// field - d (d >= 0): the region grows by d (ZCYL: radially by d / rs, since the radial term carries the factor rs)
+void inflate(Region& g, float d, bool is2d) {
+  if (g.kind == Region::BOX) {
+    for (int j = 0; j < (is2d ? 2 : 3); j++) { g.b[j] -= d; g.b[j + 3] += d; }
+  } else if (g.kind == Region::ZCYL) {
+    g.b[2] += d / g.b[5];
+    g.b[3] -= d; g.b[4] += d;
+  }
+}
+
+bool lower_region(Ctx& c, uint32_t i, Region& out, int depth = 0, bool* solid = nullptr) {
   bool dummy = true;
   if (!solid) solid = &dummy;
   if (depth == 0) *solid = true;
+  out.kind = Region::NONE;
   if (depth > 64) return false;
   const gsdf_node& n = c.node(i);
   const float* P = n.p;
-  auto set = [&](float x0, float y0, float z0, float x1, float y1, float z1) {
-    bb[0] = x0; bb[1] = y0; bb[2] = z0; bb[3] = x1; bb[4] = y1; bb[5] = z1;
+  const bool is2d = gsdf_op_is2d(n.op);
+  auto box = [&](float x0, float y0, float z0, float x1, float y1, float z1) {
+    out.kind = Region::BOX;
+    out.b[0] = x0; out.b[1] = y0; out.b[2] = z0; out.b[3] = x1; out.b[4] = y1; out.b[5] = z1;
     return true;
   };
+  auto child_region = [&](uint32_t k, Region& g) { return n.nchild > k && lower_region(c, c.child(n, k), g, depth + 1, solid); };
   switch (n.op) {
-    case GSDF_SPHERE: return set(-P[0], -P[0], -P[0], P[0], P[0], P[0]);
-    case GSDF_BOX: return set(-0.5f * P[0], -0.5f * P[1], -0.5f * P[2], 0.5f * P[0], 0.5f * P[1], 0.5f * P[2]);
-    case GSDF_CYLINDER: return set(-P[0], -P[0], -0.5f * P[1], P[0], P[0], 0.5f * P[1]);
-    case GSDF_CIRCLE2D: return set(-P[0], -P[0], 0, P[0], P[0], 0);
-    case GSDF_RECT2D: return set(-0.5f * P[0], -0.5f * P[1], 0, 0.5f * P[0], 0.5f * P[1], 0);
+    // ---- exact-distance primitives: the field is the Euclidean distance to the shape, which lies inside its box
+    case GSDF_SPHERE: return box(-P[0], -P[0], -P[0], P[0], P[0], P[0]);
+    case GSDF_BOX: return box(-0.5f * P[0], -0.5f * P[1], -0.5f * P[2], 0.5f * P[0], 0.5f * P[1], 0.5f * P[2]);
+    case GSDF_CYLINDER: return box(-P[0], -P[0], -0.5f * P[1], P[0], P[0], 0.5f * P[1]);
+    case GSDF_CIRCLE2D: return box(-P[0], -P[0], 0, P[0], P[0], 0);
+    case GSDF_RECT2D: return box(-0.5f * P[0], -0.5f * P[1], 0, 0.5f * P[0], 0.5f * P[1], 0);
     case GSDF_POLY2D: {
       const uint32_t nv = n.aux_len / 2;
       if (nv < 3) return false;
@@ -180,17 +249,19 @@ bool exact_box(Ctx& c, uint32_t i, float bb[6], int depth = 0, bool* solid = nul
         x0 = std::fmin(x0, v[2 * k]); x1 = std::fmax(x1, v[2 * k]);
         y0 = std::fmin(y0, v[2 * k + 1]); y1 = std::fmax(y1, v[2 * k + 1]);
       }
-      return set(x0, y0, 0, x1, y1, 0);
+      return box(x0, y0, 0, x1, y1, 0);
     }
+    // ---- rigid motions and uniform scaling carry the claim along
     case GSDF_TRANSLATE: case GSDF_TRANSLATE2D: {
-      if (n.nchild != 1 || !exact_box(c, c.child(n, 0), bb, depth + 1, solid)) return false;
+      if (n.nchild != 1 || !child_region(0, out)) return false;
       const float tz = n.op == GSDF_TRANSLATE ? P[2] : 0.f;
-      bb[0] += P[0]; bb[3] += P[0]; bb[1] += P[1]; bb[4] += P[1]; bb[2] += tz; bb[5] += tz;
+      if (out.kind == Region::BOX) { out.b[0] += P[0]; out.b[3] += P[0]; out.b[1] += P[1]; out.b[4] += P[1]; out.b[2] += tz; out.b[5] += tz; }
+      else { out.b[0] += P[0]; out.b[1] += P[1]; out.b[3] += tz; out.b[4] += tz; }
       return true;
     }
-    case GSDF_SCALE: case GSDF_SCALE2D: {  // f(p) = s * g(p / s): exact for exact g; the box scales with it
-      if (n.nchild != 1 || !(P[0] > 0) || !exact_box(c, c.child(n, 0), bb, depth + 1, solid)) return false;
-      for (int j = 0; j < 6; j++) bb[j] *= P[0];
+    case GSDF_SCALE: case GSDF_SCALE2D: {  // f(p) = s * g(p / s): LB_f(p) = s * LB_g(p / s) = LB of the scaled region
+      if (n.nchild != 1 || !(P[0] > 0) || !child_region(0, out)) return false;
+      for (int j = 0; j < (out.kind == Region::BOX ? 6 : 5); j++) out.b[j] *= P[0];
       return true;
     }
     case GSDF_TRANSFORM: case GSDF_ROTATION2D: {  // rigid motions only: p_local = A p + b with A orthonormal
@@ -208,8 +279,23 @@ bool exact_box(Ctx& c, uint32_t i, float bb[6], int depth = 0, bool* solid = nul
           const double dot = (double)A[r][0] * A[q][0] + (double)A[r][1] * A[q][1] + (double)A[r][2] * A[q][2];
           if (std::fabs(dot - (r == q ? 1.0 : 0.0)) > 1e-5) return false;  // scaling / shearing matrix: no claim
         }
-      float lb[6];
-      if (!exact_box(c, c.child(n, 0), lb, depth + 1, solid)) return false;
+      Region lr;
+      if (!child_region(0, lr)) return false;
+      if (lr.kind == Region::ZCYL) {
+        // a cylinder about z stays one only under a rotation about z (and any translation)
+        if (std::fabs((double)A[2][2] - 1.0) > 1e-6 || std::fabs(A[0][2]) > 1e-6 || std::fabs(A[1][2]) > 1e-6 || std::fabs(A[2][0]) > 1e-6 ||
+            std::fabs(A[2][1]) > 1e-6)
+          return false;
+        const double lx = (double)lr.b[0] - b[0], ly = (double)lr.b[1] - b[1];
+        out = lr;
+        out.b[0] = (float)(A[0][0] * lx + A[1][0] * ly); out.b[1] = (float)(A[0][1] * lx + A[1][1] * ly);
+        double ext = std::fabs((double)out.b[0]) + std::fabs((double)out.b[1]) + std::fabs((double)lr.b[2]) + std::fabs((double)lr.b[3]) + std::fabs((double)lr.b[4]) + std::fabs((double)b[2]);
+        const float pad = (float)(ext * 4e-5 + 1e-30);
+        out.b[2] += pad; out.b[3] = lr.b[3] - b[2] - pad; out.b[4] = lr.b[4] - b[2] + pad;
+        return true;
+      }
+      const float* lb = lr.b;
+      float bb[6];
       for (int j = 0; j < 3; j++) { bb[j] = 3.0e38f; bb[j + 3] = -3.0e38f; }
       for (int k = 0; k < 8; k++) {  // world corner = A^T (corner_local - b); pad by the matrix' deviation from orthonormal
         const double cl[3] = {(double)lb[(k & 1) ? 3 : 0] - b[0], (double)lb[(k & 2) ? 4 : 1] - b[1], (double)lb[(k & 4) ? 5 : 2] - b[2]};
@@ -225,40 +311,180 @@ bool exact_box(Ctx& c, uint32_t i, float bb[6], int depth = 0, bool* solid = nul
       const float pad = (float)(ext * 4e-5 + 1e-30);
       for (int j = 0; j < 3; j++) { bb[j] -= pad; bb[j + 3] += pad; }
       if (n.op == GSDF_ROTATION2D) { bb[2] = 0; bb[5] = 0; }
+      return box(bb[0], bb[1], bb[2], bb[3], bb[4], bb[5]);
+    }
+    case GSDF_SYMMETRY: case GSDF_SYMMETRY2D: {  // child(|p|) on the masked axes: the region and its mirror images
+      if (n.nchild != 1 || !child_region(0, out)) return false;
+      *solid = false;
+      const int bits = (int)P[0];
+      if (out.kind == Region::ZCYL) {
+        if ((bits & 3) && (out.b[0] != 0.f || out.b[1] != 0.f)) out = enclose_zcyl(out, 0.f, 0.f, is2d);
+        if (bits & 4) { const float m = std::fmax(std::fabs(out.b[3]), std::fabs(out.b[4])); out.b[3] = -m; out.b[4] = m; }
+        return true;
+      }
+      for (int j = 0; j < 3; j++)
+        if (bits & (1 << j)) { const float lo = std::fmin(out.b[j], -out.b[j + 3]), hi = std::fmax(out.b[j + 3], -out.b[j]); out.b[j] = lo; out.b[j + 3] = hi; }
       return true;
     }
+    // ---- minimum of fields: every child's bound holds outside the hull
     case GSDF_UNION: case GSDF_UNION2D: {
-      float a[6];
+      Region a;
       for (uint32_t k = 0; k < n.nchild; k++) {
-        if (!exact_box(c, c.child(n, k), a, depth + 1, solid)) return false;
-        if (k == 0) std::memcpy(bb, a, sizeof a);
-        else for (int j = 0; j < 3; j++) { bb[j] = std::fmin(bb[j], a[j]); bb[j + 3] = std::fmax(bb[j + 3], a[j + 3]); }
+        if (!child_region(k, a)) return false;
+        if (k == 0) out = a;
+        else { Region h; if (!hull(out, a, is2d, h)) return false; out = h; }
       }
       return n.nchild > 0;
     }
-    case GSDF_DIFF: case GSDF_DIFF2D: case GSDF_INTERSECT: case GSDF_INTERSECT2D:
-      *solid = false;  // what is left after the cut may be anywhere in the box, or nothing
-      return n.nchild == 2 && exact_box(c, c.child(n, 0), bb, depth + 1, solid);
-    case GSDF_EXTRUSION: {  // exact for an exact 2-D child: min(0,max(d,|z|-h/2)) + |max((d,|z|-h/2),0)|
-      if (n.nchild != 1 || !exact_box(c, c.child(n, 0), bb, depth + 1, solid)) return false;
-      bb[2] = -0.5f * P[0]; bb[5] = 0.5f * P[0];
+    // smooth union = mix(b, a, h) - k h (1 - h) >= min(a, b) - k / 4 (cpu_evaluators.go:213-236): the hull, grown by k / 4
+    case GSDF_SMOOTH_UNION: {
+      Region a, b2;
+      *solid = false;
+      if (n.nchild != 2 || !(P[0] > 0) || !child_region(0, a) || !child_region(1, b2) || !hull(a, b2, is2d, out)) return false;
+      inflate(out, 0.25f * P[0] * 1.0001f, is2d);
+      return true;
+    }
+    // max(a, .) >= a, and the smooth maxima are >= max: the first operand's bound holds (for an intersection either one's)
+    case GSDF_DIFF: case GSDF_DIFF2D: case GSDF_SMOOTH_DIFF:
+      *solid = false;  // what is left after the cut may be anywhere in the region, or nothing
+      return n.nchild == 2 && child_region(0, out);
+    case GSDF_INTERSECT: case GSDF_INTERSECT2D: case GSDF_SMOOTH_INTERSECT:
+      *solid = false;
+      return n.nchild == 2 && (child_region(0, out) || child_region(1, out));
+    case GSDF_EXTRUSION: {  // outside: hypot(max(d,0), max(w,0)) >= max(d, w), w = |z| - h/2, d >= the 2-D child's bound
+      Region g;
+      if (n.nchild != 1 || !child_region(0, g)) return false;
+      out = g;
+      if (g.kind == Region::BOX) { out.b[2] = -0.5f * P[0]; out.b[5] = 0.5f * P[0]; }
+      else { out.b[3] = -0.5f * P[0]; out.b[4] = 0.5f * P[0]; }
+      return true;
+    }
+    // screw = max(child(p0), |z| - L), p0 = (sawtooth, hypot(x,y) + z tanT) (threads.go:141-181). With [.., y1] the top of
+    // the 2-D child's box: child(p0) >= p0.y - y1 >= rho - y1 - |z| t (t = |tanT|). For |z| <= L that is >= rho - r with
+    // r = y1 + L t; for |z| > L, max(rho - y1 - |z| t, |z| - L) >= (rho - r) / (1 + t) (the two terms cross there). So
+    // screw(p) >= max(|z| - L, (rho - r) / (1 + t)) everywhere outside the cylinder: a ZCYL with rs = 1 / (1 + t).
+    case GSDF_SCREW: {
+      Region g;
+      *solid = false;
+      if (n.nchild != 1 || !child_region(0, g) || g.kind != Region::BOX) return false;
+      const double t = std::fabs((double)gsdf::tanf32(P[3]));
+      if (!(t < 0.5) || !(P[2] > 0)) return false;
+      out.kind = Region::ZCYL;
+      out.b[0] = 0; out.b[1] = 0;
+      out.b[2] = (float)(((double)g.b[4] + (double)P[2] * t) * (1 + 1e-6) + 1e-30);
+      out.b[3] = -P[2]; out.b[4] = P[2];
+      out.b[5] = (float)((1.0 - 1e-6) / (1.0 + t));
+      return out.b[2] > 0;
+    }
+    // rotations about z that depend on the point (twist: by k z; circular array: by a multiple of the sector angle, two
+    // candidates, minimum): rho and z of the evaluated position equal those of p, so a cylinder about the z axis holds
+    case GSDF_TWIST: case GSDF_CIRCARRAY: case GSDF_CIRCARRAY2D: {
+      Region g;
+      *solid = false;
+      if (n.nchild != 1 || !child_region(0, g)) return false;
+      out = enclose_zcyl(g, 0.f, 0.f, is2d);
+      return true;
+    }
+    case GSDF_OFFSET: case GSDF_OFFSET2D: {  // child + off: a negative offset grows the shape by |off|; a positive one only raises the field
+      if (n.nchild != 1 || !child_region(0, out)) return false;
+      *solid = false;
+      if (P[0] < 0) inflate(out, -P[0] * 1.0001f, is2d);
+      return true;
+    }
+    case GSDF_TRANSLATEMULTI2D: {  // min over displacements of child(p - d)
+      Region g;
+      const uint32_t nd = n.aux_len / 2;
+      if (n.nchild != 1 || nd == 0 || !child_region(0, g)) return false;
+      const float* d = &c.t->aux[n.aux_off];
+      for (uint32_t k = 0; k < nd; k++) {
+        Region s = g;
+        if (s.kind == Region::BOX) { s.b[0] += d[2 * k]; s.b[3] += d[2 * k]; s.b[1] += d[2 * k + 1]; s.b[4] += d[2 * k + 1]; }
+        else { s.b[0] += d[2 * k]; s.b[1] += d[2 * k + 1]; }
+        if (k == 0) out = s;
+        else { Region h; if (!hull(out, s, true, h)) return false; out = h; }
+      }
       return true;
     }
     default: return false;
   }
 }
 
+// The box form only (Program::exact_bb, D_UBOUND*).
+bool exact_box(Ctx& c, uint32_t i, float bb[6], bool* solid = nullptr) {
+  Region g;
+  if (!lower_region(c, i, g, 0, solid) || g.kind != Region::BOX) return false;
+  std::memcpy(bb, g.b, sizeof g.b);
+  return true;
+}
+
+// Rough VALU instructions per point of a subtree: decides which children are worth a gate and which is evaluated last.
+double subtree_cost(Ctx& c, uint32_t i, int depth = 0) {
+  if (depth > 64) return 1e9;
+  const gsdf_node& n = c.node(i);
+  double kids = 0;
+  for (uint32_t k = 0; k < n.nchild; k++) kids += subtree_cost(c, c.child(n, k), depth + 1);
+  switch (n.op) {
+    case GSDF_POLY2D: return 20.0 + 24.0 * (n.aux_len / 2);
+    case GSDF_LINES2D: return 20.0 + 20.0 * (n.aux_len / 4);
+    case GSDF_SCREW: return 150.0 + kids;
+    case GSDF_TWIST: return 130.0 + kids;
+    case GSDF_CIRCARRAY: case GSDF_CIRCARRAY2D: return 140.0 + 2 * kids;
+    case GSDF_ARRAY: return 8 * (40.0 + kids);
+    case GSDF_ARRAY2D: return 4 * (30.0 + kids);
+    case GSDF_TRANSLATEMULTI2D: return (n.aux_len / 2) * (4.0 + kids);
+    case GSDF_ELLIPSE2D: case GSDF_QUADBEZIER2D: return 250.0;
+    case GSDF_BOX: case GSDF_BOXFRAME: case GSDF_HEX: return 45.0;
+    default: return 25.0 + kids;
+  }
+}
+constexpr double kGateMinCost = 80.0;  // cheaper children are evaluated rather than tested (a gate costs ~12 per point)
+
 // n-ary / binary combine frame (cpu_evaluators.go:124-286, 821-912). Children that do not rewrite the
 // position are evaluated first (min/max are order-independent; for the asymmetric binary ops the
 // combine gets D_FLAG_SWAP), so the position only has to be saved when two or more children rewrite it.
+//
+// Gates (D_GATE*). With `a` the value of the children evaluated so far (LDS slot) and B the next child, bounded from below
+// outside its region by L(p) (lower_region): if for EVERY point of the wave
+//     union         min(a, b)            : L > a           -> b >= L > a: the result is a
+//     difference    max(a, -b)           : L > -a          -> -b <= -L < a: the result is a
+//     smooth union  (either operand order): L - a > 1.002 k -> |b - a| / 2 >= 0.501 k: the blend weight clamps to exactly 0
+//                                                           or 1 whatever b is, and b only enters multiplied by 0
+//     smooth diff.  (b the subtrahend)   : L + a > 1.002 k -> likewise
+// (each with a safety margin, see region_lb / gate_far in interp.h), then B is not evaluated: R <- L (positive, finite,
+// on the same side of every comparison as the true b) and the combine instruction runs unchanged on it -- the same
+// float operations on operands that yield the same bits. Intersections, xor and the minuend of a difference need b's
+// value itself: no gate. Children worth a gate (cost >= kGateMinCost, region known) are evaluated last, cheapest first.
 void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int depth) {
   bool is2d = gsdf_op_is2d(n.op);
-  std::vector<uint32_t> order;
-  for (uint32_t k = 0; k < n.nchild; k++) if (!clobbers(c, c.child(n, k))) order.push_back(k);
-  for (uint32_t k = 0; k < n.nchild; k++) if (clobbers(c, c.child(n, k))) order.push_back(k);
   const bool asym = comb == D_COMBINE_DIFF || comb == D_COMBINE_SUNION || comb == D_COMBINE_SDIFF || comb == D_COMBINE_SINTER;
-  const bool swapped = n.nchild == 2 && order[0] != 0;
   if (n.nchild != 2 && asym) throw std::runtime_error("asymmetric combine needs exactly 2 children");
+  // which children could be gated if evaluated after another one
+  const bool wide = comb == D_COMBINE_MIN && n.nchild >= 4;  // wide unions gate every child with a region, cheap or not
+  std::vector<Region> reg(n.nchild);
+  std::vector<double> cost(n.nchild, 0.0);
+  std::vector<char> worth(n.nchild, 0);
+  const bool gate_kind = comb == D_COMBINE_MIN || comb == D_COMBINE_DIFF || (comb == D_COMBINE_SUNION && n.p[0] > 0) ||
+                         (comb == D_COMBINE_SDIFF && n.p[0] > 0);
+  for (uint32_t k = 0; k < n.nchild; k++) {
+    cost[k] = subtree_cost(c, c.child(n, k));
+    if (!gate_kind) continue;
+    if ((comb == D_COMBINE_DIFF || comb == D_COMBINE_SDIFF) && k == 0) continue;  // the minuend's value is the result
+    if (lower_region(c, c.child(n, k), reg[k]) && (wide || cost[k] >= kGateMinCost)) worth[k] = 1;
+  }
+  std::vector<uint32_t> order;
+  for (uint32_t k = 0; k < n.nchild; k++) if (!worth[k] && !clobbers(c, c.child(n, k))) order.push_back(k);
+  for (uint32_t k = 0; k < n.nchild; k++) if (!worth[k] && clobbers(c, c.child(n, k))) order.push_back(k);
+  if (wide) {
+    for (uint32_t k = 0; k < n.nchild; k++) if (worth[k] && !clobbers(c, c.child(n, k))) order.push_back(k);
+    for (uint32_t k = 0; k < n.nchild; k++) if (worth[k] && clobbers(c, c.child(n, k))) order.push_back(k);
+  } else {
+    std::vector<uint32_t> w;
+    for (uint32_t k = 0; k < n.nchild; k++) if (worth[k]) w.push_back(k);
+    std::stable_sort(w.begin(), w.end(), [&](uint32_t x, uint32_t y) { return cost[x] < cost[y]; });
+    for (uint32_t k : w) order.push_back(k);
+  }
+  // a frame whose every child is worth a gate still evaluates the first one unconditionally: prefer one that leaves the position alone
+  const bool swapped = n.nchild == 2 && order[0] != 0;
   bool need_save = false;
   for (uint32_t k = 0; k + 1 < n.nchild; k++) need_save = need_save || clobbers(c, c.child(n, order[k]));
   int slotP = -1;
@@ -275,11 +501,11 @@ void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int dept
   // Wide union with >= 3 exact-boxed children: start the running minimum at an upper bound of the union (D_UBOUND*),
   // so that far children are skipped from the first one on, wherever the point is.
   std::vector<float> ub;
-  if (comb == D_COMBINE_MIN && n.nchild >= 4) {
+  if (wide) {
     float cb[6];
     for (uint32_t k = 0; k < n.nchild; k++) {
       bool solid = true;
-      if (exact_box(c, c.child(n, k), cb, 0, &solid) && solid) {
+      if (exact_box(c, c.child(n, k), cb, &solid) && solid) {
         if (is2d) { ub.push_back(cb[0]); ub.push_back(cb[1]); ub.push_back(cb[3]); ub.push_back(cb[4]); }
         else for (int j = 0; j < 6; j++) ub.push_back(cb[j]);
       }
@@ -299,24 +525,36 @@ void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int dept
   bool dirty = false;
   for (uint32_t k = 0; k < n.nchild; k++) {
     if (k > 0 && dirty) { c.load_saved(slotP, is2d); dirty = false; }
-    uint32_t ch = c.child(n, order[k]);
-    // wide union: a child that provably cannot lower the running minimum for any point of the wave is skipped
-    long skip_at = -1;
-    float cb[6];
-    if (comb == D_COMBINE_MIN && n.nchild >= 4 && (k > 0 || bounded) && exact_box(c, ch, cb)) {
-      c.op(is2d ? D_SKIPFAR2D : D_SKIPFAR3D, slotD);
-      if (is2d) { c.f(cb[0]); c.f(cb[1]); c.f(cb[3]); c.f(cb[4]); }
-      else { for (int j = 0; j < 6; j++) c.f(cb[j]); }
+    const uint32_t ck = order[k];
+    uint32_t ch = c.child(n, ck);
+    long skip_at = -1, gate_pc = -1;
+    if (worth[ck] && (k > 0 || bounded)) {
+      const Region& g = reg[ck];
+      const bool minus = comb == D_COMBINE_DIFF || comb == D_COMBINE_SDIFF;  // compare with -a
+      const float kk = (comb == D_COMBINE_SUNION || comb == D_COMBINE_SDIFF) ? 1.002f * n.p[0] : 0.0f;
+      gate_pc = (long)c.code.size();
+      if (g.kind == Region::BOX) {
+        c.op(is2d ? D_GATE2D : D_GATE3D, slotD);
+        if (is2d) { c.f(g.b[0]); c.f(g.b[1]); c.f(g.b[3]); c.f(g.b[4]); }
+        else { for (int j = 0; j < 6; j++) c.f(g.b[j]); }
+      } else {
+        // hypot(P.x, P.y) already in the register (and the cylinder about the origin): the exact radius instead of the estimate
+        const bool centred = g.b[0] == 0.f && g.b[1] == 0.f;
+        c.op(D_GATEZC | ((centred && c.hxyver == c.xyver) ? D_FLAG_HXY : 0u), slotD);
+        for (int j = 0; j < 6; j++) c.f(g.b[j]);
+      }
+      c.f(minus ? -1.0f : 1.0f);
+      c.f(kk);
       skip_at = (long)c.code.size();
-      c.u(0);  // patched below: words from this instruction to the one after the child's D_COMBINE_MIN
+      c.u(0);  // patched below: words from this instruction to the child's combine instruction
     }
     const uint32_t hxy_before = c.hxyver;
     gen(c, ch, depth + 1);
     // a child that may be skipped at run time may not have refreshed the hypot(x,y) register: forget what it cached
     if (skip_at >= 0 && c.hxyver != hxy_before) c.hxyver = 0;
     dirty = dirty || clobbers(c, ch);
+    if (skip_at >= 0) c.code[(size_t)skip_at] = (uint32_t)((long)c.code.size() - gate_pc);
     if (k > 0 || bounded) { c.op(comb | ((asym && swapped) ? D_FLAG_SWAP : 0u), slotD); if (has_k) { c.f(n.p[0]); c.f(recip_for(n.p[0])); } }
-    if (skip_at >= 0) c.code[(size_t)skip_at] = (uint32_t)(c.code.size() - ((size_t)skip_at - (is2d ? 5 : 7)));
     if (k + 1 < n.nchild) {
       if (slotD < 0) slotD = c.alloc(1);
       c.op(D_SAVER, slotD);
@@ -603,7 +841,7 @@ void gen(Ctx& c, uint32_t i, int depth) {
 
 }  // namespace
 
-Program compile(const gsdf_tree& t, size_t max_code_words) {
+static void validate(const gsdf_tree& t) {
   if (!t.nodes || t.n_nodes == 0 || t.root >= t.n_nodes) throw std::runtime_error("malformed tree: bad root");
   for (uint32_t i = 0; i < t.n_nodes; i++) {
     const gsdf_node& nd = t.nodes[i];
@@ -613,6 +851,45 @@ Program compile(const gsdf_tree& t, size_t max_code_words) {
     for (uint32_t k = 0; k < nd.nchild; k++)
       if (t.links[nd.link_off + k] >= t.n_nodes) throw std::runtime_error("malformed tree: child out of range");
   }
+  // The node graph must be acyclic (shared subtrees are fine): iterative DFS with in-progress marks, so that a blob like
+  // node 0 = UNION{0, 0} is refused here instead of recursing without bound in clobbers() / lower_region().
+  std::vector<uint8_t> state(t.n_nodes, 0);  // 0 new, 1 on the stack, 2 done
+  std::vector<std::pair<uint32_t, uint32_t>> stack;
+  stack.push_back({t.root, 0});
+  state[t.root] = 1;
+  while (!stack.empty()) {
+    auto& top = stack.back();
+    const gsdf_node& nd = t.nodes[top.first];
+    if (top.second < nd.nchild) {
+      const uint32_t ch = t.links[nd.link_off + top.second++];
+      if (state[ch] == 1) throw std::runtime_error("malformed tree: cycle through node " + std::to_string(ch));
+      if (state[ch] == 0) {
+        if (stack.size() > 4096) throw std::runtime_error("tree too deep");
+        state[ch] = 1;
+        stack.push_back({ch, 0});
+      }
+    } else {
+      state[top.first] = 2;
+      stack.pop_back();
+    }
+  }
+}
+
+int region_of(const gsdf_tree& t, uint32_t node, float params[6]) {
+  validate(t);
+  if (node >= t.n_nodes) throw std::runtime_error("node out of range");
+  Ctx c;
+  c.t = &t;
+  c.max_code = 0;
+  c.clob.assign(t.n_nodes, -1);
+  Region g;
+  if (!lower_region(c, node, g)) return 0;
+  std::memcpy(params, g.b, sizeof g.b);
+  return (int)g.kind;
+}
+
+Program compile(const gsdf_tree& t, size_t max_code_words) {
+  validate(t);
   Ctx c;
   c.t = &t;
   c.max_code = max_code_words;

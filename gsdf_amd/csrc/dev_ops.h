@@ -8,7 +8,7 @@
 // Slots are allocated statically by the host compiler, so there is no stack pointer at run time.
 //
 // Encoding: word0 = opcode (bits 0-11) | flags (bits 12-15) | slot<<16 ; then `nparam` 32-bit words.
-// The stream is straight-line except for D_SKIPFAR*, a forward wave-uniform skip. Read-only tables referenced by
+// The stream is straight-line except for D_GATE*, a forward wave-uniform skip. Read-only tables referenced by
 // instructions (D_CIRC_PRE) follow D_END.
 //   D_FLAG_HXY  (bit 14): hypot(P.x,P.y) of every point is already in the per-point `hxy` register (the host
 //                compiler proved P.xy unchanged since it was last computed): reuse instead of recomputing.
@@ -87,16 +87,21 @@ enum DevOp : uint32_t {
   // ---- combine: a = lds[slot] (first operand), b = R  ->  R
   D_COMBINE_MIN, D_COMBINE_MAX, D_COMBINE_DIFF, D_COMBINE_XOR,
   D_COMBINE_SUNION, D_COMBINE_SDIFF, D_COMBINE_SINTER,  // k RN(1/k)|0
-  // ---- wide unions: skip a child that cannot lower the running minimum. a = lds[slot] is the minimum so far, the
-  //      child's field is >= its Euclidean distance to the child's bounding box (exact-distance subtrees only, see
-  //      compile.cpp: exact_box). If EVERY point of the wave lies outside the box by more than a (plus a 1e-3 relative
-  //      margin, a thousand times the rounding of either side), min(a, child) == a for all of them: R = a and the
-  //      program counter advances by `skip` words past the child and its D_COMBINE_MIN. Wave-uniform branch.
-  D_SKIPFAR2D,  // minx miny maxx maxy skip
-  D_SKIPFAR3D,  // minx miny minz maxx maxy maxz skip
-  //      D_UBOUND* opens such a union: lds[slot] <- (1 + 1e-3) * min over the listed boxes of the distance to the box's
+  // ---- gates: skip a child that provably cannot influence its parent's combine for ANY point of the wave.
+  //      a = lds[slot] is the value of the children evaluated so far; the child's field is bounded from below, outside
+  //      the child's region, by L(p) (compile.cpp: lower_region; box: Chebyshev distance, z-cylinder: max(z excess,
+  //      rs * radial excess)). If for every point of the wave L > 0 and L > sg * a + kk + margin (sg = +1: union and
+  //      smooth union, -1: difference and smooth difference; kk = 1.002 k for the smooth combines, else 0; margin =
+  //      1e-3 (L + |a|) + 2e-6 (|x| + |y| + |z|), a thousand times the rounding of either side), the child's value b >= L
+  //      leaves the combine's result unchanged bit for bit (see gen_combine): R = L and the program counter advances
+  //      by `skip` words to the child's combine instruction, which runs on (a, L). Wave-uniform forward branch -- the one
+  //      non-straight-line instruction of the stream.
+  D_GATE2D,  // minx miny maxx maxy sg kk skip
+  D_GATE3D,  // minx miny minz maxx maxy maxz sg kk skip
+  D_GATEZC,  // cx cy r z0 z1 rs sg kk skip     (D_FLAG_HXY: cx = cy = 0 and hypot(P.x,P.y) is in the register)
+  //      D_UBOUND* opens a wide union: lds[slot] <- (1 + 1e-3) * min over the listed boxes of the distance to the box's
   //      FARTHEST corner -- an upper bound of that child's field (the shape lies inside its box), hence of the union.
-  //      Starting the running minimum there lets D_SKIPFAR* drop far children from the first one on; the bound never
+  //      Starting the running minimum there lets the gates drop far children from the first one on; the bound never
   //      reaches the result (it is >= the nearest child's value, which is always evaluated: its L <= bound).
   D_UBOUND2D,   // nb then nb x {minx miny maxx maxy}
   D_UBOUND3D,   // nb then nb x {minx miny minz maxx maxy maxz}
@@ -115,5 +120,5 @@ static const uint8_t kDevOpParams[D_OP_COUNT] = {
     /*MULR*/ 1, /*SHELL_POST*/ 1, /*ADDR*/ 1, /*ANNULUS*/ 1, /*EXTRUDE_POST*/ 0, /*MAXR_SLOT*/ 0, /*ADDR_SLOT*/ 0,
     /*SAVEP3*/ 0, /*LOADP3*/ 0, /*SAVEP2*/ 0, /*LOADP2*/ 0, /*SAVER*/ 0, /*SETSLOT*/ 1, /*SETR*/ 1,
     /*MIN*/ 0, /*MAX*/ 0, /*DIFF*/ 0, /*XOR*/ 0, /*SUNION*/ 2, /*SDIFF*/ 2, /*SINTER*/ 2,
-    /*SKIPFAR2D*/ 5, /*SKIPFAR3D*/ 7, /*UBOUND2D*/ 1, /*UBOUND3D*/ 1,
+    /*GATE2D*/ 7, /*GATE3D*/ 9, /*GATEZC*/ 9, /*UBOUND2D*/ 1, /*UBOUND3D*/ 1,
 };

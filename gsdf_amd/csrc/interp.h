@@ -197,19 +197,46 @@ __device__ __forceinline__ void xy_shared(const P3 (&pv)[K], float (&out)[K], bo
 #define ENSURE_HXY() \
   if (!use_hxy) xy_shared<K>(pv, hxy, sh_xy, brick, [](float x, float y) { return dm::hypotf_(x, y); }, sh_col)
 
-// D_SKIPFAR*: true (wave-uniform) if every point of the wave is outside the box [mn, mx] by more than the running
-// minimum `a` of the union, with margin: then no point's min(a, child) can differ from a (the child's field is at least
-// the distance to its box; the Chebyshev distance used here is a lower bound of the Euclidean one). Inside the box
-// (L <= 0) there is no bound: never skip.
+// D_GATE*: lower bound L of a child's field outside its region (compile.cpp: lower_region), per point.
+//   box        : Chebyshev distance max over axes of (mn - p, p - mx) -- a lower bound of the Euclidean one.
+//   z-cylinder : max(z0 - z, z - z1, rs * (rad - r)), rad <= hypot(x - cx, y - cy): the cached hypot when the host says it
+//                is valid, else the octagon estimate max(|x|, |y|, (|x| + |y|) / sqrt 2) >= 0.92 hypot, with the constant
+//                rounded down so that float rounding cannot lift it above the true radius.
+// Inside the region L <= 0: no claim, the gate stays shut.
 template <int K, int DIM>
-__device__ __forceinline__ bool all_far(const P3 (&pv)[K], const float (&a)[K], float mnx, float mny, float mnz, float mxx, float mxy,
-                                        float mxz) {
+__device__ __forceinline__ void region_lb_box(const P3 (&pv)[K], float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                                              float (&L)[K]) {
+  using namespace dm;
+  KLOOP {
+    float l = maxf(maxf(mnx - pv[kp].x, pv[kp].x - mxx), maxf(mny - pv[kp].y, pv[kp].y - mxy));
+    if (DIM == 3) l = maxf(l, maxf(mnz - pv[kp].z, pv[kp].z - mxz));
+    L[kp] = l;
+  }
+}
+template <int K>
+__device__ __forceinline__ void region_lb_zcyl(const P3 (&pv)[K], const float (&hxy)[K], bool use_hxy, float cx, float cy, float r,
+                                               float z0, float z1, float rs, float (&L)[K]) {
+  using namespace dm;
+  KLOOP {
+    float rad;
+    if (use_hxy) {
+      rad = hxy[kp];
+    } else {
+      const float ax = absf(pv[kp].x - cx), ay = absf(pv[kp].y - cy);
+      rad = maxf(maxf(ax, ay), 0.70710605f * (ax + ay));
+    }
+    L[kp] = maxf(maxf(z0 - pv[kp].z, pv[kp].z - z1), rs * (rad - r));
+  }
+}
+// The gate's verdict: true (wave-uniform) if EVERY point of the wave has L > 0 and L > sg * a + kk by the margin.
+template <int K, int DIM>
+__device__ __forceinline__ bool gate_far(const P3 (&pv)[K], const float (&a)[K], const float (&L)[K], float sg, float kk) {
   using namespace dm;
   bool far = true;
   KLOOP {
-    float L = maxf(maxf(mnx - pv[kp].x, pv[kp].x - mxx), maxf(mny - pv[kp].y, pv[kp].y - mxy));
-    if (DIM == 3) L = maxf(L, maxf(mnz - pv[kp].z, pv[kp].z - mxz));
-    far = far && (L > 0.0f) && (L > a[kp] + 1e-3f * (L + absf(a[kp])));
+    float S = absf(pv[kp].x) + absf(pv[kp].y);
+    if (DIM == 3) S += absf(pv[kp].z);
+    far = far && (L[kp] > 0.0f) && (L[kp] > sg * a[kp] + kk + (1e-3f * (L[kp] + absf(a[kp])) + 2e-6f * S));
   }
   return __all(far) != 0;
 }
@@ -1005,25 +1032,39 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         pc = q;
         break;
       }
-      case D_SKIPFAR2D: {
-        float a[K];
+      case D_GATE2D: {
+        float a[K], L[K];
         KLOOP a[kp] = LDSF(slot);
-        if (all_far<K, 2>(pv, a, PF(0), PF(1), 0.f, PF(2), PF(3), 0.f)) {
-          KLOOP Rv[kp] = a[kp];
-          pc += PU(4);
-        } else {
-          pc += 6;
-        }
-        break;
-      }
-      case D_SKIPFAR3D: {
-        float a[K];
-        KLOOP a[kp] = LDSF(slot);
-        if (all_far<K, 3>(pv, a, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5))) {
-          KLOOP Rv[kp] = a[kp];
+        region_lb_box<K, 2>(pv, PF(0), PF(1), 0.f, PF(2), PF(3), 0.f, L);
+        if (gate_far<K, 2>(pv, a, L, PF(4), PF(5))) {
+          KLOOP Rv[kp] = L[kp];
           pc += PU(6);
         } else {
           pc += 8;
+        }
+        break;
+      }
+      case D_GATE3D: {
+        float a[K], L[K];
+        KLOOP a[kp] = LDSF(slot);
+        region_lb_box<K, 3>(pv, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5), L);
+        if (gate_far<K, 3>(pv, a, L, PF(6), PF(7))) {
+          KLOOP Rv[kp] = L[kp];
+          pc += PU(8);
+        } else {
+          pc += 10;
+        }
+        break;
+      }
+      case D_GATEZC: {
+        float a[K], L[K];
+        KLOOP a[kp] = LDSF(slot);
+        region_lb_zcyl<K>(pv, hxy, use_hxy, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5), L);
+        if (gate_far<K, 3>(pv, a, L, PF(6), PF(7))) {
+          KLOOP Rv[kp] = L[kp];
+          pc += PU(8);
+        } else {
+          pc += 10;
         }
         break;
       }

@@ -58,7 +58,18 @@ def test_npt_flange_program():
     # hypot(x,y) is computed once and reused by the other two cylinders and the screw (z-only translate keeps it)
     users = [i for i in ins if i[0] in ("D_CYL0", "D_CYLR", "D_SCREW_PRE")]
     assert [u[1] for u in users].count(False) == 1 and [u[1] for u in users].count(True) == 3
-    assert slots == 6   # 1 root distance + 3 saved position + 2 nested partial results
+    assert slots == 7   # 1 root distance + 3 saved position + 2 nested partial results + the screw's |z| - L
+    # gates: the cheap plate is evaluated before the threaded pipe, which is skipped where the plate's value proves the smooth
+    # union's blend weight clamps (box of the nut cylinder); inside it the screw + thread polygon is skipped where the nut
+    # cylinder's value proves max(nut, -screw) = nut (z-cylinder of the screw, exact radius from the cached hypot)
+    gates = [i for i in ins if i[0].startswith("D_GATE")]
+    assert [g[0] for g in gates] == ["D_GATE3D", "D_GATEZC"] and gates[1][1] is True
+    f = code.view(np.float32)
+    g0, g1 = gates[0][4], gates[1][4]
+    assert f[g0 + 7] == 1.0 and abs(f[g0 + 8] - 1.002 * 0.2) < 1e-6 and f[g1 + 7] == -1.0 and f[g1 + 8] == 0.0
+    t0, t1 = g0 + int(code[g0 + 9]), g1 + int(code[g1 + 9])
+    assert [i[0] for i in ins if i[4] == t0] == ["D_COMBINE_SUNION"] and [i[0] for i in ins if i[4] == t1] == ["D_COMBINE_DIFF"]
+    assert [i[3] for i in ins if i[4] == t0] == [gates[0][3]] and [i[3] for i in ins if i[4] == t1] == [gates[1][3]]
     # polygon edge records start on a 32-byte boundary
     poly = [i for i in ins if i[0] == "D_POLY2D"][0]
     assert ((poly[4] + 4 + 7) & ~7) % 8 == 0
@@ -114,62 +125,151 @@ def test_corner_pair_sharing_flags():
 
 
 def test_far_child_skip_in_wide_unions():
-    """Wide unions (>= 4 children) of exact-boxed children: D_UBOUND* starts the running minimum at an upper bound of the
-    union, every boxed child is preceded by D_SKIPFAR* whose skip lands on the instruction after the child's
-    D_COMBINE_MIN; the boxes are the children's (translated polygon bounds)."""
+    """Wide unions (>= 4 children) of children with a lower-bound region: D_UBOUND* starts the running minimum at an upper
+    bound of the union, every such child is preceded by a D_GATE* whose skip lands on the child's D_COMBINE_MIN (which then
+    runs on (a, L)); the boxes are the children's (translated polygon bounds)."""
     b = Builder()
     code, _ = hip.lower(b.Scene("glyph-plate"))
     ins = decode(code)
-    starts = {i[4] for i in ins}
     f = code.view(np.float32)
     ub = [i for i in ins if i[0] == "D_UBOUND2D"]
     nb = int(code[ub[0][4] + 1])
     assert len(ub) == 1 and nb == 18                         # the 6 "D" glyphs are differences: lower bound only, no upper bound
     ub_boxes = {tuple(f[ub[0][4] + 2 + 4 * k: ub[0][4] + 6 + 4 * k]) for k in range(nb)}
-    skips = [i for i in ins if i[0] == "D_SKIPFAR2D"]
+    gates = [i for i in ins if i[0] == "D_GATE2D"]
+    skips = [i for i in gates if i[3] == ub[0][3]]           # those testing against the slot the bound was stored in
     assert len(skips) == 24                                  # every glyph, the first one included
     for k, (name, _, _, slot, pc) in enumerate(skips):
-        assert slot == ub[0][3]                              # all test against the slot the bound was stored in
-        target = pc + int(code[pc + 5])
-        assert target in starts                              # lands on an instruction boundary ...
-        prev = max(p for p in starts if p < target)
-        assert [i[0] for i in ins if i[4] == prev] == ["D_COMBINE_MIN"]   # ... right after the child's combine
-        assert [i[3] for i in ins if i[4] == prev] == [slot]              # same running-minimum slot
+        target = pc + int(code[pc + 7])
+        assert [i[0] for i in ins if i[4] == target] == ["D_COMBINE_MIN"]   # lands on the child's combine ...
+        assert [i[3] for i in ins if i[4] == target] == [slot]              # ... of the same running-minimum slot
         x0, y0, x1, y1 = f[pc + 1:pc + 5]
         assert x1 - x0 == 6.0 and y1 - y0 == 10.0            # glyph cell of the scene (threads.hpp: 6 x 10)
+        assert f[pc + 5] == 1.0 and f[pc + 6] == 0.0         # union: compare with +a, no blend width
         assert ((x0, y0, x1, y1) in ub_boxes) == (k % 4 != 2)  # the bound lists the boxes of the solid glyphs (G, S, F)
-    # children without an exact-distance guarantee are never skipped: smoothing, scaling, approximate primitives
+    # the "D" glyphs are differences of two polygons: the inner one (the subtrahend) is gated by the outer one's value
+    inner = [i for i in gates if i[3] != ub[0][3]]
+    assert len(inner) == 6
+    for (name, _, _, slot, pc) in inner:
+        target = pc + int(code[pc + 7])
+        assert [i[0] for i in ins if i[4] == target] == ["D_COMBINE_DIFF"] and f[pc + 5] == -1.0 and f[pc + 6] == 0.0
+        assert [i[2] for i in ins if i[4] == target] == [False]   # never with swapped operands: only a subtrahend can be skipped
+    # children without a lower-bound claim are never skipped: approximate primitives
     def mk(child):
         return b.Union2D(b.NewCircle(1), b.Translate2D(b.NewCircle(1), 3, 0), b.Translate2D(b.NewCircle(1), 6, 0), child)
     names = lambda sh: [i[0] for i in decode(hip.lower(sh)[0])]
-    assert names(mk(b.Translate2D(b.NewCircle(1), 9, 0))).count("D_SKIPFAR2D") == 4
-    assert names(mk(b.Translate2D(b.NewEllipse(1, 0.5), 9, 0))).count("D_SKIPFAR2D") == 3
-    assert names(mk(b.Offset2D(b.NewCircle(1), 0.1))).count("D_SKIPFAR2D") == 3
+    assert names(mk(b.Translate2D(b.NewCircle(1), 9, 0))).count("D_GATE2D") == 4
+    assert names(mk(b.Translate2D(b.NewEllipse(1, 0.5), 9, 0))).count("D_GATE2D") == 3
+    # an offset shifts the field: a negative one grows the region by |off|, a positive one keeps the child's region
+    off = hip.lower(mk(b.Translate2D(b.Offset2D(b.NewCircle(1), -0.25), 9, 0)))[0]
+    io = decode(off)
+    assert [i[0] for i in io].count("D_GATE2D") == 4
+    fo = off.view(np.float32)
+    ob = max((tuple(fo[i[4] + 1:i[4] + 5]) for i in io if i[0] == "D_GATE2D"), key=lambda q: q[0])
+    assert abs(ob[0] - (9 - 1.25)) < 1e-3 and abs(ob[2] - (9 + 1.25)) < 1e-3
     # uniform scaling and rigid motions keep the field exact: their (scaled / rotated, conservatively boxed) children qualify
-    assert names(mk(b.Scale2D(b.NewCircle(1), 2.0))).count("D_SKIPFAR2D") == 4
+    assert names(mk(b.Scale2D(b.NewCircle(1), 2.0))).count("D_GATE2D") == 4
     rot = hip.lower(mk(b.Translate2D(b.Rotate2D(b.NewRectangle(2, 1), 0.5), 9, 0)))[0]
     ir = decode(rot)
-    assert [i[0] for i in ir].count("D_SKIPFAR2D") == 4
+    assert [i[0] for i in ir].count("D_GATE2D") == 4
     fr = rot.view(np.float32)
-    boxes = [tuple(fr[i[4] + 1:i[4] + 5]) for i in ir if i[0] == "D_SKIPFAR2D"]
+    boxes = [tuple(fr[i[4] + 1:i[4] + 5]) for i in ir if i[0] == "D_GATE2D"]
     rb = max(boxes, key=lambda q: q[0])                      # the rotated rectangle, translated to x = 9
     half_w = 0.5 * (2 * abs(np.cos(0.5)) + 1 * abs(np.sin(0.5)))
     assert abs((rb[2] - rb[0]) / 2 - half_w) < 1e-3 and abs((rb[0] + rb[2]) / 2 - 9) < 1e-3
+    # narrow unions of cheap children: evaluating a circle costs less than testing whether it matters
     three = names(b.Union2D(b.NewCircle(1), b.Translate2D(b.NewCircle(1), 3, 0), b.Translate2D(b.NewCircle(1), 6, 0)))
-    assert three.count("D_SKIPFAR2D") == 0 and three.count("D_UBOUND2D") == 0
-    # fewer than three boxed children: no upper bound, the first child is always evaluated
+    assert three.count("D_GATE2D") == 0 and three.count("D_UBOUND2D") == 0
+    # fewer than three solid boxed children: no upper bound; the children without a claim go first, the others are gated
     two = names(b.Union2D(b.NewCircle(1), b.Translate2D(b.NewCircle(1), 3, 0), b.NewEllipse(1, 0.5), b.NewEllipse(2, 0.5)))
-    assert two.count("D_UBOUND2D") == 0 and two.count("D_SKIPFAR2D") == 1
+    assert two.count("D_UBOUND2D") == 0 and two.count("D_GATE2D") == 2
+    assert [n for n in two if n in ("D_ELLIPSE2D", "D_CIRCLE2D")] == ["D_ELLIPSE2D", "D_ELLIPSE2D", "D_CIRCLE2D", "D_CIRCLE2D"]
     # a difference may be empty: it can be skipped (lower bound) but contributes no upper bound
     dd = b.Union2D(b.NewCircle(1), b.Translate2D(b.NewCircle(1), 3, 0), b.Translate2D(b.NewCircle(1), 6, 0),
                    b.Translate2D(b.Difference2D(b.NewCircle(1), b.NewCircle(2)), 9, 0))
     cdd = hip.lower(dd)[0]
     idd = decode(cdd)
-    assert [i[0] for i in idd].count("D_SKIPFAR2D") == 4 and int(cdd[[i[4] for i in idd if i[0] == "D_UBOUND2D"][0] + 1]) == 3
+    assert [i[0] for i in idd].count("D_GATE2D") == 4 and int(cdd[[i[4] for i in idd if i[0] == "D_UBOUND2D"][0] + 1]) == 3
     # 3-D: extruded exact shapes and boxes qualify
     sh3 = b.Union(b.NewSphere(1), b.Translate(b.NewBox(1, 1, 1, 0), 3, 0, 0), b.Translate(b.Extrude(b.NewRectangle(1, 1), 1), 6, 0, 0),
                   b.Translate(b.NewTorus(1, 0.2), 9, 0, 0))
-    assert names(sh3).count("D_SKIPFAR3D") == 3 and names(sh3).count("D_UBOUND3D") == 1   # the torus makes no claim
+    assert names(sh3).count("D_GATE3D") == 3 and names(sh3).count("D_UBOUND3D") == 1   # the torus makes no claim
+
+
+def test_gates_of_binary_combines():
+    """A child that is expensive and has a lower-bound region is evaluated last and preceded by a gate: unions, the
+    subtrahend of a (smooth) difference, either operand of a smooth union. Minuends, intersections and xor never."""
+    b = Builder()
+    poly = lambda: b.NewPolygon([(0, 0), (2, 0), (2.5, 1), (2, 2), (1, 2.5), (0, 2), (-0.5, 1)])   # 7 edges: worth a gate
+    ext = lambda: b.Extrude(poly(), 1.0)
+    sph = lambda: b.Translate(b.NewSphere(1), 4, 0, 0)
+
+    def gate(sh):
+        code = hip.lower(sh)[0]
+        ins = decode(code)
+        g = [i for i in ins if i[0].startswith("D_GATE")]
+        f = code.view(np.float32)
+        return ins, g, f, code
+
+    # union: the cheap sphere first, the extrusion gated (sg = +1)
+    ins, g, f, code = gate(b.Union(ext(), sph()))
+    assert len(g) == 1 and g[0][0] == "D_GATE3D" and f[g[0][4] + 7] == 1.0 and f[g[0][4] + 8] == 0.0
+    names = [i[0] for i in ins]
+    assert names.index("D_SPHERE") < names.index("D_POLY2D")
+    tgt = g[0][4] + int(code[g[0][4] + 9])
+    assert [i[0] for i in ins if i[4] == tgt] == ["D_COMBINE_MIN"]
+    # difference sphere - extrusion: the subtrahend is gated with sg = -1; extrusion - sphere: nothing (the minuend is the
+    # result, and the sphere is not worth a test)
+    ins, g, f, code = gate(b.Difference(sph(), ext()))
+    assert len(g) == 1 and f[g[0][4] + 7] == -1.0
+    assert [i[2] for i in ins if i[0] == "D_COMBINE_DIFF"] == [False]
+    assert gate(b.Difference(ext(), sph()))[1] == []
+    # smooth union: either order, gate carries 1.002 k; smooth difference: subtrahend only
+    for sh in (b.SmoothUnion(0.3, ext(), sph()), b.SmoothUnion(0.3, sph(), ext())):
+        ins, g, f, code = gate(sh)
+        assert len(g) == 1 and f[g[0][4] + 7] == 1.0 and abs(f[g[0][4] + 8] - 1.002 * 0.3) < 1e-6
+        assert [i[0] for i in ins if i[4] == g[0][4] + int(code[g[0][4] + 9])] == ["D_COMBINE_SUNION"]
+    ins, g, f, code = gate(b.SmoothDifference(0.3, sph(), ext()))
+    assert len(g) == 1 and f[g[0][4] + 7] == -1.0 and abs(f[g[0][4] + 8] - 1.002 * 0.3) < 1e-6
+    assert gate(b.SmoothDifference(0.3, ext(), sph()))[1] == []
+    # a smooth union's own region is the hull of its operands grown by k / 4
+    ins, g, f, code = gate(b.Union(b.Translate(b.SmoothUnion(0.4, ext(), b.NewSphere(1)), 10, 0, 0), sph()))
+    outer = [q for q in g if [i[0] for i in ins if i[4] == q[4] + int(code[q[4] + 9])] == ["D_COMBINE_MIN"]]
+    assert len(outer) == 1
+    x0, y0, z0, x1, y1, z1 = f[outer[0][4] + 1:outer[0][4] + 7]
+    assert abs(x0 - (10 - 1 - 0.1)) < 1e-3 and abs(x1 - (10 + 2.5 + 0.1)) < 1e-3 and abs(z0 - (-1 - 0.1)) < 1e-3 and abs(y1 - (2.5 + 0.1)) < 1e-3
+    # no gate where the child's value itself is needed
+    for sh in (b.Intersection(sph(), ext()), b.Xor(sph(), ext()), b.SmoothIntersect(0.3, sph(), ext())):
+        assert gate(sh)[1] == []
+
+
+def test_gate_regions_of_screws_and_rotational_ops():
+    """A screw is bounded from below outside its bounding cylinder (z-cylinder region, radial slope 1 / (1 + |tan taper|));
+    twist and circular arrays rotate about z, so what they wrap is bounded outside the enclosing cylinder about the z axis."""
+    b = Builder()
+    code, _ = hip.lower(b.Scene("bolt"))
+    ins = decode(code)
+    f = code.view(np.float32)
+    zc = [i for i in ins if i[0] == "D_GATEZC"]
+    assert len(zc) == 1
+    pc = zc[0][4]
+    cx, cy, r, z0, z1, rs, sg, kk = f[pc + 1:pc + 9]
+    assert cx == 0 and cy == 0 and 1.5 < r < 1.56 and abs((z1 - z0) - 8.0) < 1e-3 and 0.99999 < rs < 1.0 and sg == 1.0 and kk == 0.0
+    assert [i[0] for i in ins if i[4] == pc + int(code[pc + 9])] == ["D_COMBINE_MIN"]
+    # npt-flange: tapered thread -> rs = 1 / (1 + 1/32)
+    code, _ = hip.lower(b.Scene("npt-flange"))
+    f = code.view(np.float32)
+    pc = [i for i in decode(code) if i[0] == "D_GATEZC"][0][4]
+    assert abs(f[pc + 6] - 32.0 / 33.0) < 1e-5
+    # a twisted, circularly repeated box: bounded outside the cylinder through the box's farthest corner
+    box = b.Translate(b.NewBox(1, 1, 4, 0), 3, 0, 0)
+    knurl = b.Twist(b.CircularArray(box, 12, 12), 0.2)
+    code, _ = hip.lower(b.Union(b.NewSphere(1), knurl))
+    f = code.view(np.float32)
+    g = [i for i in decode(code) if i[0] == "D_GATEZC"]
+    assert len(g) == 1
+    cx, cy, r, z0, z1, rs = f[g[0][4] + 1:g[0][4] + 7]
+    assert cx == 0 and cy == 0 and abs(r - np.hypot(3.5, 0.5)) < 1e-3 and abs(z0 + 2) < 1e-6 and abs(z1 - 2) < 1e-6 and rs == 1.0
 
 
 def test_hxy_not_reused_across_xy_changes():
