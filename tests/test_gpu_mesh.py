@@ -156,7 +156,7 @@ def test_full_size_npt_flange_resdiv1600(gpu):
 def test_dualcontour_identical_to_oracle(gpu, chiseled):
     b = Builder()
     cases = [(b.NewSphere(1.0), 1.0 / 8), (b.NewBox(2, 2, 2, 0), 2.0 / 8), (b.Scene("bolt"), 0.5), (b.Scene("npt-flange"), 0.9),
-             (b.Scene("knurled-cylinder"), 0.8)]
+             (b.Scene("knurled-cylinder"), 0.8), (b.Union(b.NewTorus(1.0, 0.3), b.NewHexagonalPrism(0.4, 0.6)), 1.0 / 6)]
     for k, (sh, res) in enumerate(cases):
         res = np.float32(res)
         dc = gpu.DualContourHIP(gpu.SDF3HIP(sh), res, chiseled=chiseled)
@@ -165,10 +165,10 @@ def test_dualcontour_identical_to_oracle(gpu, chiseled):
         assert dc.n_tris() == ref.n_tris, (sh, dc.n_tris(), ref.n_tris)
         tg, tc = _sorted(dc.RenderAll()), _sorted(ref.tris)
         assert (tg.view(np.uint32) == tc.view(np.uint32)).all(), sh   # float64 QR reproduced bit for bit
-        # the reference sweeps the whole cubic lattice; for trees with an exact bounding box (sphere, box) the device
-        # skips lattice cells farther than 2*res outside that box -- same kept cubes, fewer evaluations
-        exact = sh.Bounds() is not None and k < 2
-        assert (dc.stats.evals <= ref.evals) if exact else (dc.stats.evals == ref.evals), (k, dc.stats.evals, ref.evals)
+        # the reference sweeps the whole cubic lattice; for trees whose field is bounded from below outside a box (all of
+        # these but the torus / hexagonal prism union, which makes no such claim) the device skips lattice cells farther
+        # than 2*res outside that box -- same kept cubes, fewer evaluations
+        assert (dc.stats.evals <= ref.evals) if k < 5 else (dc.stats.evals == ref.evals), (k, dc.stats.evals, ref.evals)
 
 
 def test_dualcontour_reference_tolerances(gpu):
