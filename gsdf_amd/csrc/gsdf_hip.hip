@@ -451,6 +451,29 @@ extern "C" int gsdf_hip_program_is_specialized(const gsdf_program* p, double* co
   return p && p->spec_mod ? 1 : 0;
 }
 
+/* The kernels this handle launches, e.g. "eval=eval_kernel<3,4,4>:specialised leaf=leaf_kernel<4,3>:specialised
+ * prune=prune_kernel:specialised" (":interpreter" for the ahead-of-time kernels): what a profile of the handle shows. */
+extern "C" int gsdf_hip_program_kernels(const gsdf_program* p, char* dst, size_t dst_cap) {
+  if (!p || !dst || dst_cap == 0) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  int lk, lw;
+  size_t lds_m;
+  p->leaf_config(&lk, &lw, &lds_m);
+  const int ek = p->batch_k();
+  const bool se = p->f_eval && p->spec_eval_k == ek, sl = p->f_leaf && p->spec_leaf_k == lk;
+  const int ew = se ? p->spec_eval_w : p->sweep_waves(ek);
+  // ahead-of-time leaf kernels exist at the scratch-free occupancies only (see gsdf_hip_mesh_octree)
+  const int aw = lk == 4 ? (lw == 2 ? 2 : 3) : (lk == 2 ? 3 : 4);
+  char buf[256];
+  if (p->prog.is2d)
+    snprintf(buf, sizeof buf, "eval=eval_kernel<2,%d,%d>:%s", ek, ew, se ? "specialised" : "interpreter");
+  else
+    snprintf(buf, sizeof buf, "eval=eval_kernel<3,%d,%d>:%s leaf=leaf_kernel<%d,%d>:%s prune=prune_kernel:%s", ek, ew, se ? "specialised" : "interpreter",
+             lk, sl ? p->spec_leaf_w : aw, sl ? "specialised" : "interpreter", p->f_prune ? "specialised" : "interpreter");
+  if (strlen(buf) + 1 > dst_cap) return fail(GSDF_ERR_SHORT_BUFFER, "short buffer");
+  std::memcpy(dst, buf, strlen(buf) + 1);
+  return GSDF_OK;
+}
+
 // Host-only (no GPU): the generated evaluator source of a tree's specialised build, and a hiprtc compile of the
 // specialised kernels for gfx950 that stops before loading them (proves the generated code builds).
 extern "C" int gsdf_hip_specialize_source(const gsdf_tree* tree, char* dst, size_t dst_cap, size_t* len) {
@@ -783,7 +806,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     static const int prune_bpc = [] { const char* e = getenv("GSDF_HIP_PRUNE_BPC"); return e ? atoi(e) : 4; }();  // tuning knob
     for (int level = levels; level >= lq; level--) {
       const int expand = level != levels;
-      const int do_test = (level >= 3 && opts.prune) ? 1 : 0;
+      const int do_test = (level >= 3 && (opts.prune == 1 || (opts.prune > 1 && ((opts.prune >> level) & 1)))) ? 1 : 0;
       // upper bound of candidates at this level (for the grid only): 8^(levels-level), capped by the queue
       uint64_t bound = (levels - level) * 3 >= 40 ? UINT64_MAX : ((uint64_t)1 << (3 * (levels - level)));
       if (bound > capq[(level + 1) & 1] * 8) bound = capq[(level + 1) & 1] * 8;

@@ -21,7 +21,7 @@ ErrMismatchBufferLength = "position and distance buffer length mismatch"
 
 # every symbol include/gsdf_hip.h declares
 SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "gsdf_hip_program_destroy",
-           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_lower_region", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_blockcache_create", "gsdf_hip_blockcache_reset", "gsdf_hip_blockcache_eval3", "gsdf_hip_blockcache_hits", "gsdf_hip_blockcache_evaluations", "gsdf_hip_blockcache_destroy", "gsdf_hip_program_specialize", "gsdf_hip_program_is_specialized", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
+           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_lower_region", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_blockcache_create", "gsdf_hip_blockcache_reset", "gsdf_hip_blockcache_eval3", "gsdf_hip_blockcache_hits", "gsdf_hip_blockcache_evaluations", "gsdf_hip_blockcache_destroy", "gsdf_hip_program_specialize", "gsdf_hip_program_is_specialized", "gsdf_hip_program_kernels", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
            "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3", "gsdf_hip_image2",
            "gsdf_hip_mesh_octree", "gsdf_hip_mesh_dualcontour", "gsdf_hip_mesh_flat", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
            "gsdf_hip_mesh_stl", "gsdf_hip_mesh_host_tris", "gsdf_hip_mesh_host_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner", "gsdf_hip_slab_range"]
@@ -77,6 +77,7 @@ def lib():
         L.gsdf_hip_blockcache_destroy.argtypes = [C.c_void_p]
         L.gsdf_hip_program_specialize.argtypes = [C.c_void_p]
         L.gsdf_hip_program_is_specialized.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.gsdf_hip_program_kernels.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         L.gsdf_hip_specialize_source.argtypes = [C.POINTER(GsdfTree), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.gsdf_hip_specialize_check.argtypes = [C.POINTER(GsdfTree), C.POINTER(C.c_size_t)]
         L.gsdf_hip_evaluations.restype = C.c_uint64
@@ -165,7 +166,10 @@ class SDFHIP:
         _check(lib().gsdf_hip_program_info(self._h, C.byref(a), C.byref(b)))
         t = C.c_double()
         sp = lib().gsdf_hip_program_is_specialized(self._h, C.byref(t))
-        return {"code_words": a.value, "lds_slots": b.value, "specialized": bool(sp), "specialize_s": t.value}
+        buf = C.create_string_buffer(256)
+        _check(lib().gsdf_hip_program_kernels(self._h, buf, 256))
+        kern = dict(kv.split("=") for kv in buf.value.decode().split())
+        return {"code_words": a.value, "lds_slots": b.value, "specialized": bool(sp), "specialize_s": t.value, "kernels": kern}
 
     def specialize(self):
         """Build (hiprtc) and switch to kernels specialised for this tree: same bits, no fetch/decode. Returns self."""
@@ -258,6 +262,7 @@ class OctreeHIP:
         self.sdf = sdf
         self._mesh = None
         self._cursor = 0
+        # prune: True / False, or an int bit mask of the octree levels to centre-test (bit L = Level L >= 3)
         self._opts = MeshOpts(int(prune), shard_rank, shard_count, max_tris, stream, int(share_corners), int(host_output))
         self.Reset(sdf, res)
 

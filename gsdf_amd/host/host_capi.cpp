@@ -130,6 +130,8 @@ int gsdfb_op(void* hv, const char* name, const float* f, int nf, const int* i, i
     // ---- scenes (benchmark configs)
     if (n == "scene.npt-flange") return scenes::NptFlange(b).id;
     if (n == "scene.bolt") return scenes::Bolt(b).id;
+    if (n == "scene.fibonacci-showerhead") return scenes::Showerhead(b).id;
+    if (n == "threads.PlasticButtress.Thread") { need(2, 0); return threads::PlasticButtress(f[0], f[1]).Thread(b).id; }
     if (n == "scene.glyph-plate") return scenes::GlyphPlate(b, ni > 0 ? i[0] : 24).id;
     if (n == "scene.knurled-cylinder") return scenes::KnurledCylinder(b, nf > 0 ? f[0] : 20.f).id;
     g_err = "unknown builder method: " + n;

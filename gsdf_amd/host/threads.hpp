@@ -140,6 +140,41 @@ inline Shader3D HexHead(Builder& bld, float radius, float height, bool roundNeg,
   return hex3d;
 }
 
+// PlasticButtress (plasticbuttress.go:9-53): screw-top style buttress thread, similar to ANSI 45/7 with more rounding.
+// Go evaluates the untyped constant expressions exactly and rounds them once to float32 where they meet a float32
+// operand: t0 + t1, threadEngage / 2.0, 0.05, 0.15 are single literals here for that reason.
+struct PlasticButtress : Threader {
+  float D = 0, P = 0;
+  PlasticButtress() = default;
+  PlasticButtress(float d, float p) : D(d), P(p) {}
+  Parameters ThreadParams() const override {  // basic(butt).ThreadParams() threads.go:212-222
+    float radius = D / 2;
+    return Parameters{"basic", radius, P, 1, 0, metricf2f(radius)};
+  }
+  Shader2D Thread(Builder& bld) const override {
+    const float radius = D / 2;
+    const float t0 = 1.0f;
+    const float t1 = (float)0.1227845609029046L;          // math.Tan(7 deg)
+    const float t0t1 = (float)(1.0L + 0.1227845609029046L);
+    const float p = P;
+    const float h0 = p / t0t1;
+    const float h1 = ((float)(0.6L / 2.0L) * p) + (0.5f * h0);
+    const float hp = p / 2.0f;
+    PolygonBuilder tp;
+    tp.AddXY(p, 0);
+    tp.AddXY(p, radius);
+    const float p2 = hp - ((h0 - h1) * t1);
+    tp.AddXY(p2, radius).Smooth((float)0.05L * p, 5);
+    const float p3 = t0 * h0 - hp;
+    tp.AddXY(p3, radius - h1).Smooth((float)0.15L * p, 5);
+    const float p4 = (h0 - h1) * t0 - hp;
+    tp.AddXY(p4, radius).Smooth((float)0.15L * p, 5);
+    tp.AddXY(-p, radius);
+    tp.AddXY(-p, 0);
+    return bld.NewPolygon(tp.AppendVecs());
+  }
+};
+
 // Knurl (knurl.go:18-101)
 struct KnurlParams : Threader {
   float Length = 0, Radius = 0, Pitch = 0, Height = 0, Theta = 0;
@@ -289,6 +324,38 @@ inline Shader3D KnurledCylinder(Builder& bld, float diameter = 20) {
   obj = bld.SmoothDifference(sk, obj, bld.Translate(ventCyl, 0, 0, -length / 2));
   obj = bld.SmoothDifference(sk, obj, bld.Translate(ventCyl, 0, 0, length / 2));
   return obj;
+}
+
+// examples/fibonacci-showerhead/main.go:30-88,138-148: knurled cap with an internal plastic-buttress thread on a base plate
+// drilled with 131 holes on a Fibonacci spiral. The reference's README holds its triangle count at resdiv 350 (309,872).
+inline Vec2 fibonacci(int n) {
+  const float angleOfDivergence = 137.3f, spacing = 2.6f;
+  const float nf = (float)n;
+  const float a = nf * angleOfDivergence / 360 * kPiF;
+  const float r = spacing * std::sqrt(nf);
+  float sa, ca;
+  sincosf32(a, sa, ca);
+  return Vec2{r * ca, r * sa};
+}
+inline Shader3D Showerhead(Builder& bld) {
+  const float threadExtDiameter = 65.f, threadedLength = 5.f;
+  const float threadPitch = (float)(5.0L / 3.0L);  // threadedLength / threadTurns, an exact constant expression in Go
+  const float showerheadBaseThick = 2.5f, showerheadWall = 4.f, threadheight = 5.f;
+  threads::PlasticButtress showerThread(threadExtDiameter, threadPitch);
+  Shader3D knurled = threads::KnurledHead(bld, threadExtDiameter / 2 + showerheadWall, threadheight, 1);
+  Shader3D thr = threads::Screw(bld, threadheight + .5f, showerThread);
+  Shader3D object = bld.Difference(knurled, thr);
+  Shader3D base = bld.NewCylinder(threadExtDiameter / 2 + showerheadWall, showerheadBaseThick, 0);
+  base = bld.Translate(base, 0, 0, -(threadedLength / 2 + showerheadBaseThick / 2 - 1));
+  Shader3D hole = bld.NewCylinder(0.8f, showerheadBaseThick * 10, 0);
+  Shader3D holes = hole;
+  for (int i = 0; i < 130; i++) {
+    const Vec2 v = fibonacci(i);
+    holes = bld.Union(holes, bld.Translate(hole, v.X, v.Y, 0));
+  }
+  base = bld.Difference(base, holes);
+  object = bld.Union(object, base);
+  return object;
 }
 
 // Synthetic stand-in for BASELINE.json configs[4] (forge/textsdf multi-glyph plate): forge/textsdf needs

@@ -81,6 +81,9 @@ int gsdf_hip_selftest_sqrt(uint64_t* mismatches);
  * architecture, options, hiprtc version), so the next process that specialises the same tree reads a file instead. */
 int gsdf_hip_program_specialize(gsdf_program* p);
 int gsdf_hip_program_is_specialized(const gsdf_program* p, double* compile_seconds);
+/* Names of the kernels this handle launches, as a profiler shows them: "eval=eval_kernel<3,4,4>:specialised
+ * leaf=leaf_kernel<4,3>:specialised prune=prune_kernel:specialised" (":interpreter" = the ahead-of-time kernels). */
+int gsdf_hip_program_kernels(const gsdf_program* p, char* dst, size_t dst_cap);
 /* Host-only (run without a GPU): text of the generated evaluator, and a gfx950 hiprtc build of the specialised kernels
  * that stops before loading them. dst may be NULL to query the length. */
 int gsdf_hip_specialize_source(const gsdf_tree* tree, char* dst, size_t dst_cap, size_t* len);
@@ -121,7 +124,13 @@ int gsdf_hip_normals3(gsdf_program* p, const float* pos, float* normals, size_t 
 int gsdf_hip_image2(gsdf_program* p, int w, int h, float* dist_out, uint8_t* rgba_out);
 
 typedef struct gsdf_mesh_opts {
-  int prune;          /* 1: octree centre-test pruning of every Level>=3 cube (default); 0: visit all leaves */
+  int prune;          /* 1: octree centre-test pruning of every Level>=3 cube (default); 0: visit all leaves; any other value:
+                         bit mask of the levels to test (bit L = cubes of Level L, L >= 3). The reference tests the
+                         capacity-limited frontier of its DecomposeBFS buffer only (octreerenderer.go:94-105,140): a handful
+                         of upper levels. Testing more levels changes nothing for fields that never grow faster than the
+                         distance; for the others (e.g. a 45-degree knurl screw, |grad| up to sqrt 2) a small cube can be
+                         dropped that holds surface -- examples/fibonacci-showerhead at resdiv 350 loses 23 of its 309,872
+                         triangles to the Level-3 tests and none to Levels >= 4 (tests/test_gpu_mesh.py) */
   int shard_rank;     /* multi-GPU: this rank ... */
   int shard_count;    /* ... of this many (1 = whole model). Bricks of 16^3 leaves go to rank gsdf_hip_brick_owner(x, y, z, count). */
   uint64_t max_tris;  /* device triangle buffer capacity; 0 = size automatically */

@@ -285,7 +285,7 @@ int orc_render_octree(const orc_sdf* s, float res, int batch, int prune, orc_mes
   double t0 = now_s();
   for (int level = levels; level >= 2; level--) {
     nxt.n = 0;
-    if (level >= 3 && prune) {
+    if (level >= 3 && (prune == 1 || (prune > 1 && ((prune >> level) & 1)))) { /* prune: 0 none, 1 every level >= 3, else a bit mask of the levels to test */
       float size = cube_size(level, res);
       float maxDist = size * szMult;
       for (size_t b0 = 0; b0 < cur.n; b0 += (size_t)batch) {

@@ -9,8 +9,11 @@ from gsdf_amd.builder import Builder, ShapeError
 
 
 def _prim3(b, r):
-    k = r.integers(0, 7)
+    k = r.integers(0, 9)
     u = lambda lo, hi: float(r.uniform(lo, hi))
+    # threaded parts (forge/threads): expensive children with a z-cylinder lower bound -- what the skip gates are for
+    if k == 7: return b.ScrewISO(u(0.6, 1.4), u(0.15, 0.4), bool(r.integers(0, 2)), u(0.5, 2.0))
+    if k == 8: return b.ScrewNPT(float(r.choice([0.125, 0.25, 0.5])), u(0.3, 0.8))
     if k == 0: return b.NewSphere(u(0.3, 1.2))
     if k == 1: return b.NewBox(u(0.4, 1.5), u(0.4, 1.5), u(0.4, 1.5), u(0.0, 0.1))
     if k == 2: return b.NewCylinder(u(0.3, 1.0), u(0.5, 2.0), float(r.choice([0.0, 0.05])))

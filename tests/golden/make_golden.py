@@ -48,13 +48,24 @@ def main():
              ("npt_flange_resdiv100", b.Scene("npt-flange"), None), ("npt_flange_resdiv400", b.Scene("npt-flange"), None),
              ("bolt_resdiv150", b.Scene("bolt"), None), ("knurled_cylinder_resdiv120", b.Scene("knurled-cylinder"), None)]
     if "--full" in sys.argv:
+        # the single-GPU BASELINE.json configs at full size (configs[1], [2], [3]): minutes of CPU each
         cases.append(("npt_flange_resdiv1600", b.Scene("npt-flange"), None))
+        cases.append(("bolt_resdiv2000", b.Scene("bolt"), None))
+        cases.append(("knurled_cylinder_resdiv2000", b.Scene("knurled-cylinder"), None))
+    if "--full" in sys.argv or "--showerhead" in sys.argv:
+        # the reference's second held answer (README.md:152,166): 309,872 with centre tests at Levels >= 4 (and from the flat
+        # renderer); every Level >= 3 tested: 309,849 (non-Lipschitz knurl field)
+        sh = b.Scene("fibonacci-showerhead")
+        r350 = np.float32(float(sh.Diagonal()) / 350)
+        cases.append(("showerhead_resdiv350_prune_ge4", sh, r350))
+        cases.append(("showerhead_resdiv350_prune_all", sh, r350))
     for name, sh, res in cases:
         if res is None:
             res = np.float32(float(sh.Diagonal()) / int(name.rsplit("resdiv", 1)[1]))
-        m = OracleSDF(sh.tree()).render_octree(res, 4096, True)
+        mask = sum(1 << l for l in range(4, 22)) if name.endswith("prune_ge4") else True
+        m = OracleSDF(sh.tree()).render_octree(res, 4096, mask)
         meshes[name] = {"res_bits": int(np.float32(res).view(np.uint32)), "res": float(res), "n_tris": m.n_tris,
-                        "levels": m.levels, "sha256_sorted": tri_digest(m.tris)}
+                        "levels": m.levels, "sha256_sorted": tri_digest(m.tris), "oracle_evals": m.evals}
         print(name, meshes[name])
     path = os.path.join(HERE, "mesh_digests.json")
     old = {}

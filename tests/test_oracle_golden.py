@@ -48,6 +48,29 @@ def test_npt_flange_readme_known_answers():
     assert octree.levels == 10
 
 
+def test_fibonacci_showerhead_readme_known_answers():
+    """The reference's other held answer (README.md:152,166): examples/fibonacci-showerhead at resdiv 350 -> resolution
+    0.2979682, 1,512,025 CPU evaluations (lattice + 1 probe), 309,872 triangles from the flat renderer (CPU run) and from the
+    octree renderer (GPU run). It exercises what the npt-flange pin does not: the plastic-buttress thread polygon (three
+    Smooth corners of different radii), KnurledHead (intersection of a left- and a right-hand 229-start screw), a 131-way
+    union of translated cylinders, fibonacci() in float32."""
+    b = Builder()
+    s = b.Scene("fibonacci-showerhead")
+    res = np.float32(float(s.Diagonal()) / 350)
+    assert f"{float(res):.7f}" == "0.2979682"            # README.md:152,166
+    sdf = OracleSDF(s.tree())
+    flat = sdf.render_flat(res, 4096, 4)
+    assert flat.evals == 1512024                          # README.md:166 prints 1,512,025 = lattice + 1 constructor probe
+    assert flat.n_tris == 309872                          # README.md:166
+    # Octree renderer (README.md:152: 309,872 as well). The reference centre-tests only the frontier its DecomposeBFS buffer
+    # holds -- for this 9-level tree cubes of Level 5 and some of Level 4 -- and with tests at Levels >= 4 the count is the
+    # flat renderer's. This field is NOT 1-Lipschitz (the knurl's 45-degree helix: |grad| up to sqrt 2), and testing every
+    # Level >= 3 cube, as the device does by default, drops 23 triangles at Level 3: the one tree found where the superset
+    # schedule is not result-preserving (DESIGN.md section 6). prune = bit mask of the levels to test.
+    octree = sdf.render_octree(res, 4096, sum(1 << l for l in range(4, 10)))
+    assert octree.levels == 9 and octree.n_tris == 309872
+
+
 def test_octree_resolutions_like_reference_TestOctree():
     # glrender_test.go:104-124: a range of awkward resolutions must render without error; octree == flat count
     b = Builder()
