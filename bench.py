@@ -211,15 +211,20 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
+    comm = None
+    torch.cuda.set_device(local_rank if world > 1 else 0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     hip.init(dev.index)
+    if world > 1:
+        # Data plane: the library's own RCCL communicator (gsdf_hip_comm_*, one rank per GPU over xGMI) -- the triangle
+        # all-gatherv runs inside libgsdfhip.so, exactly what a Go caller of the C ABI would use. Control plane
+        # (rendezvous of the 128-byte RCCL id, barriers, three scalars at the end): torch.distributed over gloo.
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        ids = [hip.CommHIP.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = hip.CommHIP(ids[0], rank, world)
 
     bld = Builder()
     shader = bld.NewSphere(1.0) if args.scene == "sphere" else bld.Scene(args.scene)
@@ -253,10 +258,7 @@ def main():
             oc = hip.DualContourHIP(sdf, res, shard_rank=rank, shard_count=world)
         else:
             oc = hip.OctreeHIP(sdf, res, shard_rank=rank, shard_count=world, share_corners=args.share_corners)
-        gathered = None
-        if dist is not None:
-            from gsdf_amd.gather import all_gatherv_triangles
-            gathered = all_gatherv_triangles(oc.dev_ptr(), oc.n_tris(), dev)
+        gathered = oc.gatherv(comm) if comm is not None else None   # every rank ends up with all triangles, device resident
         return oc, gathered
 
     # Setup, untimed: bring the GPU out of its idle clock state before the W warmup steps. The first ~20 meshes after
@@ -282,7 +284,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    tot = torch.tensor([float(evals), float(tris), dt], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(evals), float(tris), dt], dtype=torch.float64)
     if dist is not None:
         tmax = tot.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -313,7 +315,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "sharding": (("z-slabs of the lattice, halo recomputed" if dc else "octree bricks by coordinate hash")
-                                    + ", RCCL all-gatherv of triangles") if world > 1 else "single GPU",
+                                    + ", RCCL all-gatherv of triangles inside the library (gsdf_hip_mesh_gatherv)") if world > 1 else "single GPU",
                        "leaf_corners": "shared (distinct lattice points once)" if args.share_corners else "8 per leaf (as the reference)",
                        "evaluator": spec_note,
                        "setup": f"{args.preheat} untimed meshes before the warmup steps (clock ramp)"},
@@ -335,7 +337,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(shader, args.scene, cpu_rd, threads)
         print(json.dumps(out), flush=True)
     if dist is not None:
+        if rank == 0 and last[1] is not None:
+            assert last[1].n_tris() == int(tris_all / args.steps), "gathered triangle count differs from the sum of the ranks'"
         dist.barrier()
+        comm.close()
         dist.destroy_process_group()
 
 

@@ -123,7 +123,8 @@ struct gsdf_mesh {
   float* d_tris = nullptr;
   uint64_t cap = 0;
   gsdf_mesh_stats st{};
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // the stream the mesher ran on (the program's or the caller's); the mesher has synchronised it
+  hipStream_t rstream = nullptr;  // the mesh's OWN stream for later reads / STL builds: a mesh may outlive its program handle
   bool host_out = false;  // d_tris is pinned, device-mapped HOST memory (gsdf_mesh_opts.host_output): the kernels write across PCIe
   // pinned host copies handed out by gsdf_hip_mesh_host_tris / gsdf_hip_mesh_host_stl (owned by the mesh)
   void* h_tris = nullptr;
@@ -209,6 +210,13 @@ static void big_memcpy(void* dst, const void* src, size_t n) {
 }
 
 static int host_buf(void** buf, size_t* cap, size_t need);
+// Stream for work issued on a finished mesh (result copies, stl_kernel): created on first use and destroyed with the mesh,
+// so that reading a mesh after gsdf_hip_program_destroy (finalisers / garbage collectors run in any order) never touches
+// the program's destroyed stream. nullptr (the null stream) if a stream cannot be had.
+static hipStream_t mesh_stream(gsdf_mesh* m) {
+  if (!m->rstream && hipStreamCreateWithFlags(&m->rstream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); m->rstream = nullptr; }
+  return m->rstream;
+}
 static void release_tris(gsdf_mesh* m) {
   if (m->host_out) hpool_give(m->d_tris, (size_t)m->cap * 36);
   else pool_give(m->device, m->d_tris, m->cap);
@@ -339,6 +347,8 @@ static int spec_build(gsdf_program* p, const std::vector<std::string>& names, hi
 // of scratch, wrote the results of 216 points of a ragged last tile to the wrong addresses). The ahead-of-time
 // interpreter kernels have ONE code shape each, and that shape is what the whole test suite runs.
 static int fn_scratch_bytes(hipFunction_t f) {
+  static const bool allow = getenv("GSDF_HIP_EXP_ALLOW_SCRATCH") != nullptr;  // developer experiments only: timing of a spilling build
+  if (allow) return 0;
   int v = 0;
   if (hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f) != hipSuccess) { (void)hipGetLastError(); return 1 << 30; }
   return v;
@@ -1223,6 +1233,180 @@ extern "C" uint32_t gsdf_hip_brick_owner(uint32_t x, uint32_t y, uint32_t z, uin
   return count ? brick_owner(x, y, z, count) : 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// multi-GPU: RCCL all-gatherv of the ranks' triangle buffers
+// ---------------------------------------------------------------------------------------------
+// One process per GPU. The mesher shards with no data-path collective (brick_owner / z-slabs); the one exchange is the
+// final variable-length gather, done here on RCCL directly so that a Go (or C) caller of this ABI has the multi-GPU path
+// without any Python: ncclAllGather of the counts, then ONE ncclGroup of ncclBroadcast's, root r sending exactly
+// count_r * 36 bytes straight from its mesh's triangle buffer into every rank's output at offset sum(count_<r) -- no
+// padding, no staging copies. librccl is loaded at first use (dlopen by soname: the process-wide copy), so the library
+// itself has no link-time dependency on it and single-GPU users never load it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+struct RcclApi {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+};
+RcclApi* rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) { api.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (api.h) break; }
+    if (!api.h) { api.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return; }
+#define GSDF_RCCL_SYM(field, sym)                                                          \
+  api.field = (decltype(api.field))dlsym(api.h, sym);                                      \
+  if (!api.field && api.err.empty()) api.err = std::string("librccl lacks ") + sym;
+    GSDF_RCCL_SYM(GetUniqueId, "ncclGetUniqueId") GSDF_RCCL_SYM(CommInitRank, "ncclCommInitRank") GSDF_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    GSDF_RCCL_SYM(AllGather, "ncclAllGather") GSDF_RCCL_SYM(AllReduce, "ncclAllReduce") GSDF_RCCL_SYM(Broadcast, "ncclBroadcast")
+    GSDF_RCCL_SYM(GroupStart, "ncclGroupStart") GSDF_RCCL_SYM(GroupEnd, "ncclGroupEnd") GSDF_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef GSDF_RCCL_SYM
+  });
+  return &api;
+}
+}  // namespace
+
+struct gsdf_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  hipStream_t stream = nullptr;
+  unsigned long long* d_counts = nullptr;  // [world + 1]: the gathered counts, then this rank's own
+  unsigned long long* h_counts = nullptr;  // pinned mirror
+};
+
+#define RCCL_TRY(expr)                                                                                                   \
+  do {                                                                                                                   \
+    ncclResult_t _r = (expr);                                                                                            \
+    if (_r != ncclSuccess) return fail(GSDF_ERR_HIP, std::string(#expr) + ": " + (R->GetErrorString ? R->GetErrorString(_r) : "rccl error")); \
+  } while (0)
+
+extern "C" int gsdf_hip_comm_unique_id(uint8_t id[GSDF_COMM_ID_BYTES]) {
+  if (!id) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  RcclApi* R = rccl();
+  if (!R->err.empty()) return fail(GSDF_ERR_HIP, R->err);
+  static_assert(sizeof(ncclUniqueId) <= GSDF_COMM_ID_BYTES, "ncclUniqueId larger than GSDF_COMM_ID_BYTES");
+  ncclUniqueId u;
+  RCCL_TRY(R->GetUniqueId(&u));
+  std::memset(id, 0, GSDF_COMM_ID_BYTES);
+  std::memcpy(id, &u, sizeof u);
+  return GSDF_OK;
+}
+
+extern "C" void gsdf_hip_comm_destroy(gsdf_comm* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(c->comm);
+  if (c->d_counts) (void)hipFree(c->d_counts);
+  if (c->h_counts) (void)hipHostFree(c->h_counts);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int gsdf_hip_comm_create(const uint8_t id[GSDF_COMM_ID_BYTES], int rank, int world, gsdf_comm** out) {
+  if (!id || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (world < 1 || rank < 0 || rank >= world) return fail(GSDF_ERR_BAD_ARGUMENT, "bad rank / world size");
+  RcclApi* R = rccl();
+  if (!R->err.empty()) return fail(GSDF_ERR_HIP, R->err);
+  gsdf_comm* c = new (std::nothrow) gsdf_comm();
+  if (!c) return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory");
+  c->rank = rank; c->world = world;
+  auto bail = [&](int code) { gsdf_hip_comm_destroy(c); return code; };
+  if (hipGetDevice(&c->device) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipGetDevice failed"));
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipStreamCreate failed"));
+  if (hipMalloc((void**)&c->d_counts, sizeof(unsigned long long) * (size_t)(world + 1)) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipMalloc(counts) failed"));
+  if (hipHostMalloc((void**)&c->h_counts, sizeof(unsigned long long) * (size_t)(world + 1), hipHostMallocDefault) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipHostMalloc(counts) failed"));
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof u);
+  ncclResult_t r = R->CommInitRank(&c->comm, world, u, rank);
+  if (r != ncclSuccess) { c->comm = nullptr; return bail(fail(GSDF_ERR_HIP, std::string("ncclCommInitRank: ") + R->GetErrorString(r))); }
+  *out = c;
+  return GSDF_OK;
+}
+extern "C" int gsdf_hip_comm_rank(const gsdf_comm* c) { return c ? c->rank : -1; }
+extern "C" int gsdf_hip_comm_world(const gsdf_comm* c) { return c ? c->world : 0; }
+
+// Sum of `n` host uint64 values over all ranks, in place (Evaluations(), TotalPruned(), triangle totals).
+extern "C" int gsdf_hip_comm_allreduce_sum_u64(gsdf_comm* c, uint64_t* vals, size_t n) {
+  if (!c || !vals) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  if (n == 0) return GSDF_OK;
+  RcclApi* R = rccl();
+  HIP_TRY(hipSetDevice(c->device));
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, n * 8));
+  int rc = GSDF_OK;
+  do {
+    if (hipMemcpyAsync(d, vals, n * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "H2D copy failed"); break; }
+    ncclResult_t r = R->AllReduce(d, d, n, ncclUint64, ncclSum, c->comm, c->stream);
+    if (r != ncclSuccess) { rc = fail(GSDF_ERR_HIP, std::string("ncclAllReduce: ") + R->GetErrorString(r)); break; }
+    if (hipMemcpyAsync(vals, d, n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "D2H copy failed"); break; }
+  } while (0);
+  (void)hipFree(d);
+  return rc;
+}
+
+// All-gatherv of triangle buffers: the result is a mesh like any other (device-resident triangles of ALL ranks in rank
+// order: read / host views / STL / destroy as usual); counts (optional) receives the per-rank triangle counts.
+extern "C" int gsdf_hip_mesh_gatherv(const gsdf_mesh* m, gsdf_comm* c, gsdf_mesh** out, uint64_t* counts) {
+  if (!m || !c || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (m->host_out) return fail(GSDF_ERR_BAD_ARGUMENT, "gatherv needs device-resident triangles (host_output meshes live in host memory)");
+  if (m->device != c->device) return fail(GSDF_ERR_BAD_ARGUMENT, "mesh and communicator are on different devices");
+  RcclApi* R = rccl();
+  HIP_TRY(hipSetDevice(c->device));
+  const int W = c->world;
+  // 1. counts
+  c->h_counts[W] = m->st.n_tris;
+  HIP_TRY(hipMemcpyAsync(c->d_counts + W, c->h_counts + W, 8, hipMemcpyHostToDevice, c->stream));
+  RCCL_TRY(R->AllGather(c->d_counts + W, c->d_counts, 1, ncclUint64, c->comm, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, 8 * (size_t)W, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  uint64_t total = 0;
+  for (int r = 0; r < W; r++) { if (counts) counts[r] = c->h_counts[r]; total += c->h_counts[r]; }
+  gsdf_mesh* g = new (std::nothrow) gsdf_mesh();
+  if (!g) return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory");
+  g->device = c->device;
+  g->st = m->st;  // resolution, origin, levels; per-rank counters stay per-rank (sum them with gsdf_hip_comm_allreduce_sum_u64)
+  g->st.n_tris = total;
+  auto bail = [&](int code) { gsdf_hip_mesh_destroy(g); return code; };
+  if (total) {
+    g->d_tris = pool_take(c->device, total, &g->cap);
+    if (!g->d_tris) {
+      if (hipMalloc((void**)&g->d_tris, total * 36) != hipSuccess) { (void)hipGetLastError(); return bail(fail(GSDF_ERR_HIP, "hipMalloc of the gathered triangle buffer failed")); }
+      g->cap = total;
+    }
+    // 2. payload: one grouped launch of world broadcasts, root r -> everyone's [offset_r, offset_r + count_r)
+    ncclResult_t r0 = R->GroupStart();
+    if (r0 != ncclSuccess) return bail(fail(GSDF_ERR_HIP, std::string("ncclGroupStart: ") + R->GetErrorString(r0)));
+    uint64_t off = 0;
+    ncclResult_t rb = ncclSuccess;
+    for (int r = 0; r < W && rb == ncclSuccess; r++) {
+      const uint64_t n = c->h_counts[r];
+      if (n) rb = R->Broadcast(r == c->rank ? (const void*)m->d_tris : (const void*)(g->d_tris + off * 9), g->d_tris + off * 9, (size_t)n * 9, ncclFloat32, r, c->comm, c->stream);
+      off += n;
+    }
+    ncclResult_t r1 = R->GroupEnd();
+    if (rb != ncclSuccess) return bail(fail(GSDF_ERR_HIP, std::string("ncclBroadcast: ") + R->GetErrorString(rb)));
+    if (r1 != ncclSuccess) return bail(fail(GSDF_ERR_HIP, std::string("ncclGroupEnd: ") + R->GetErrorString(r1)));
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return bail(fail(GSDF_ERR_HIP, std::string("gatherv: ") + hipGetErrorString(e)));
+  }
+  *out = g;
+  return GSDF_OK;
+}
+
 extern "C" int gsdf_hip_mesh_stats_get(const gsdf_mesh* m, gsdf_mesh_stats* st) {
   if (!m || !st) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
   *st = m->st;
@@ -1296,8 +1480,9 @@ extern "C" int gsdf_hip_mesh_host_tris(gsdf_mesh* m, const float** tris) {
   if (!m->h_tris) {
     const int rc = host_buf(&m->h_tris, &m->h_tris_cap, (size_t)n * 36);
     if (rc) return rc;
-    hipError_t e = hipMemcpyAsync(m->h_tris, m->d_tris, (size_t)n * 36, hipMemcpyDeviceToHost, m->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    hipStream_t rs = mesh_stream(m);
+    hipError_t e = hipMemcpyAsync(m->h_tris, m->d_tris, (size_t)n * 36, hipMemcpyDeviceToHost, rs);
+    if (e == hipSuccess) e = hipStreamSynchronize(rs);
     if (e != hipSuccess) { hpool_give(m->h_tris, m->h_tris_cap); m->h_tris = nullptr; m->h_tris_cap = 0; return fail(GSDF_ERR_HIP, std::string("D2H triangles: ") + hipGetErrorString(e)); }
   }
   *tris = (const float*)m->h_tris;
@@ -1327,13 +1512,14 @@ extern "C" int gsdf_hip_mesh_host_stl(gsdf_mesh* m, const uint8_t** stl, size_t*
     std::memset(hdr, 0, 84);
     const uint32_t cnt = (uint32_t)n;
     std::memcpy(hdr + 80, &cnt, 4);
-    hipError_t e = hipMemcpyAsync(d_out, hdr, 84, hipMemcpyHostToDevice, m->stream);
+    hipStream_t rs = mesh_stream(m);
+    hipError_t e = hipMemcpyAsync(d_out, hdr, 84, hipMemcpyHostToDevice, rs);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(stl_kernel, dim3(grid_for(n, 256, 8)), dim3(BLOCK), 0, m->stream, m->d_tris, n, (uint8_t*)d_out);
+      hipLaunchKernelGGL(stl_kernel, dim3(grid_for(n, 256, 8)), dim3(BLOCK), 0, rs, m->d_tris, n, (uint8_t*)d_out);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(m->h_stl, d_out, bytes, hipMemcpyDeviceToHost, m->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(m->h_stl, d_out, bytes, hipMemcpyDeviceToHost, rs);
+    if (e == hipSuccess) e = hipStreamSynchronize(rs);
     pool_give(m->device, d_out, dcap);
     if (e != hipSuccess) { hpool_give(m->h_stl, m->h_stl_cap); m->h_stl = nullptr; m->h_stl_cap = 0; return fail(GSDF_ERR_HIP, std::string("STL build/transfer: ") + hipGetErrorString(e)); }
   }
@@ -1347,6 +1533,7 @@ extern "C" void gsdf_hip_mesh_destroy(gsdf_mesh* m) {
   release_tris(m);
   hpool_give(m->h_tris, m->h_tris_cap);
   hpool_give(m->h_stl, m->h_stl_cap);
+  if (m->rstream) (void)hipStreamDestroy(m->rstream);
   delete m;
 }
 

@@ -513,6 +513,9 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
       }
     }
     if (!pass || index == 255u) index = 0;
+#ifdef GSDF_EXP_NO_EMIT  // developer experiment (GSDF_HIP_SPEC_FLAGS=-DGSDF_EXP_NO_EMIT): evaluation cost alone
+    index = 0;
+#endif
     // after the last pass dall[j] is the distance of corner order[j] (an early exit leaves index == 0: nothing is read)
     if (index) {
 #pragma unroll

@@ -1,4 +1,7 @@
-"""Variable-length gather of per-rank triangle buffers (RCCL over xGMI on GPUs, gloo on CPU in tests).
+"""Variable-length gather of per-rank triangle buffers over torch.distributed -- the gloo-testable REFERENCE of the
+rank-major layout. The product's multi-GPU exchange is gsdf_hip_mesh_gatherv (include/gsdf_hip.h): RCCL called directly
+inside libgsdfhip.so, no padding and no staging copies; bench.py --gpus N uses that. This module remains for CPU tests
+of the ordering (tests/test_gather_gloo.py) and for callers that already hold torch tensors.
 
 The mesher shards octree bricks across ranks with no data-path communication; the only exchange is
 this final gather. RCCL has no all-gatherv: exchange the counts (one all_gather of

@@ -21,7 +21,7 @@ ErrMismatchBufferLength = "position and distance buffer length mismatch"
 
 # every symbol include/gsdf_hip.h declares
 SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "gsdf_hip_program_destroy",
-           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_lower_region", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_blockcache_create", "gsdf_hip_blockcache_reset", "gsdf_hip_blockcache_eval3", "gsdf_hip_blockcache_hits", "gsdf_hip_blockcache_evaluations", "gsdf_hip_blockcache_destroy", "gsdf_hip_program_specialize", "gsdf_hip_program_is_specialized", "gsdf_hip_program_kernels", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
+           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_lower_region", "gsdf_hip_comm_unique_id", "gsdf_hip_comm_create", "gsdf_hip_comm_rank", "gsdf_hip_comm_world", "gsdf_hip_comm_allreduce_sum_u64", "gsdf_hip_mesh_gatherv", "gsdf_hip_comm_destroy", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_blockcache_create", "gsdf_hip_blockcache_reset", "gsdf_hip_blockcache_eval3", "gsdf_hip_blockcache_hits", "gsdf_hip_blockcache_evaluations", "gsdf_hip_blockcache_destroy", "gsdf_hip_program_specialize", "gsdf_hip_program_is_specialized", "gsdf_hip_program_kernels", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
            "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3", "gsdf_hip_image2",
            "gsdf_hip_mesh_octree", "gsdf_hip_mesh_dualcontour", "gsdf_hip_mesh_flat", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
            "gsdf_hip_mesh_stl", "gsdf_hip_mesh_host_tris", "gsdf_hip_mesh_host_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner", "gsdf_hip_slab_range"]
@@ -64,6 +64,13 @@ def lib():
         L.gsdf_hip_program_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.gsdf_hip_lower.argtypes = [C.POINTER(GsdfTree), C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.gsdf_hip_lower_region.argtypes = [C.POINTER(GsdfTree), C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_float)]
+        L.gsdf_hip_comm_unique_id.argtypes = [C.c_void_p]
+        L.gsdf_hip_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.gsdf_hip_comm_rank.argtypes = [C.c_void_p]
+        L.gsdf_hip_comm_world.argtypes = [C.c_void_p]
+        L.gsdf_hip_comm_allreduce_sum_u64.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]
+        L.gsdf_hip_mesh_gatherv.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.gsdf_hip_comm_destroy.argtypes = [C.c_void_p]
         L.gsdf_hip_selftest_div.argtypes = [C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
         L.gsdf_hip_selftest_sqrt.argtypes = [C.POINTER(C.c_uint64)]
         L.gsdf_hip_blockcache_create.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_void_p)]
@@ -344,6 +351,73 @@ class OctreeHIP:
         p, ln = C.c_void_p(), C.c_size_t()
         _check(lib().gsdf_hip_mesh_host_stl(self._mesh, C.byref(p), C.byref(ln)))
         return self._view(p.value, ln.value, np.uint8)
+
+
+class CommHIP:
+    """RCCL communicator of the multi-GPU mesher (one process per GPU; gsdf_hip_comm_* in include/gsdf_hip.h).
+    Rank 0 draws CommHIP.unique_id() and ships the 128 bytes to the other ranks by any means; every rank then builds
+    CommHIP(id, rank, world) after hip.init(device) -- a collective call."""
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * CommHIP.ID_BYTES)()
+        _check(lib().gsdf_hip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, unique_id, rank, world):
+        if len(unique_id) != CommHIP.ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % CommHIP.ID_BYTES)
+        buf = (C.c_ubyte * CommHIP.ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        _check(lib().gsdf_hip_comm_create(buf, rank, world, C.byref(h)))
+        self._h, self.rank, self.world = h, rank, world
+
+    def allreduce_sum(self, values):
+        """Sum of each of `values` (ints) over all ranks. Collective."""
+        arr = (C.c_uint64 * len(values))(*[int(v) for v in values])
+        _check(lib().gsdf_hip_comm_allreduce_sum_u64(self._h, arr, len(values)))
+        return [int(v) for v in arr]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gsdf_hip_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GatheredMeshHIP(OctreeHIP):
+    """All ranks' triangles, rank-major, device resident on every rank: the result of <renderer>.gatherv(comm)
+    (gsdf_hip_mesh_gatherv: RCCL all-gather of the counts + one group of broadcasts, no padding, no staging copies).
+    Reads like any renderer: n_tris / RenderAll / ReadTriangles / triangles_view / WriteBinarySTL / dev_ptr."""
+
+    def __init__(self, mesh, counts, stats):
+        self.sdf = None
+        self._mesh = mesh
+        self._cursor = 0
+        self.counts = counts
+        self.stats = stats
+
+    def Reset(self, sdf, res):
+        raise TypeError("a gathered mesh is a result, not a renderer")
+
+
+def _gatherv(self, comm):
+    """RCCL all-gatherv of this rank's triangles with those of the other ranks of `comm`. Collective."""
+    out = C.c_void_p()
+    counts = (C.c_uint64 * comm.world)()
+    _check(lib().gsdf_hip_mesh_gatherv(self._mesh, comm._h, C.byref(out), counts))
+    st = MeshStats()
+    _check(lib().gsdf_hip_mesh_stats_get(out, C.byref(st)))
+    return GatheredMeshHIP(out, [int(c) for c in counts], st)
+
+
+OctreeHIP.gatherv = _gatherv
 
 
 class DualContourHIP(OctreeHIP):

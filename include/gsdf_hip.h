@@ -191,6 +191,28 @@ int gsdf_hip_mesh_host_tris(gsdf_mesh* m, const float** tris);
 int gsdf_hip_mesh_host_stl(gsdf_mesh* m, const uint8_t** stl, size_t* len);
 void gsdf_hip_mesh_destroy(gsdf_mesh* m);
 
+/* ---- multi-GPU (one process per GPU). The meshers shard with NO data-path collective (shard_rank / shard_count above); the
+ * one exchange is the final variable-length gather of the ranks' triangle buffers, on RCCL over xGMI, inside this library:
+ * a Go caller needs no Python for it. Replaces nothing in the reference (single device); SURVEY.md section 8(e).
+ *   rank 0: gsdf_hip_comm_unique_id(id) -> ship the 128 bytes to the other ranks by any means (file, socket, MPI, env)
+ *   every rank (after gsdf_hip_init(device)): gsdf_hip_comm_create(id, rank, world, &comm)            [collective]
+ *   per mesh: gsdf_hip_mesh_gatherv(local_mesh, comm, &all, counts)                                   [collective]
+ * gatherv = ncclAllGather of the counts + one ncclGroup of ncclBroadcast's, root r sending exactly count_r x 36 bytes from
+ * its mesh into every rank's result at offset sum(count_<r): no padding, no staging copies. The result is a gsdf_mesh
+ * holding the triangles of ALL ranks in rank order (device resident; every mesh accessor works on it). librccl is loaded
+ * at first use; without it these calls fail with GSDF_ERR_HIP and everything else works. */
+typedef struct gsdf_comm gsdf_comm;
+#define GSDF_COMM_ID_BYTES 128
+int gsdf_hip_comm_unique_id(uint8_t id[GSDF_COMM_ID_BYTES]);
+int gsdf_hip_comm_create(const uint8_t id[GSDF_COMM_ID_BYTES], int rank, int world, gsdf_comm** out);
+int gsdf_hip_comm_rank(const gsdf_comm* c);
+int gsdf_hip_comm_world(const gsdf_comm* c);
+/* Sum over all ranks, in place, of n host values (Evaluations(), TotalPruned(), triangle totals). Collective. */
+int gsdf_hip_comm_allreduce_sum_u64(gsdf_comm* c, uint64_t* vals, size_t n);
+/* counts (optional): world entries, triangles contributed by each rank. */
+int gsdf_hip_mesh_gatherv(const gsdf_mesh* m, gsdf_comm* c, gsdf_mesh** out, uint64_t* counts);
+void gsdf_hip_comm_destroy(gsdf_comm* c);
+
 /* Host-only helper (runs without a GPU): owner rank of octree brick (x,y,z) under the multi-GPU partition
  * gsdf_hip_mesh_octree applies on device -- a pure function of the coordinates, so ranks never communicate. */
 uint32_t gsdf_hip_brick_owner(uint32_t x, uint32_t y, uint32_t z, uint32_t count);

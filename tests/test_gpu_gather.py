@@ -1,0 +1,56 @@
+"""Multi-GPU exchange through the C ABI on RCCL (gsdf_hip_comm_* / gsdf_hip_mesh_gatherv, include/gsdf_hip.h), exercised
+at world size 1 -- what one GPU allows: the communicator, the count all-gather, the grouped broadcast of the payload and
+the reduction all run through librccl, so the `nccl` path executes at least once per round. The rank-major ordering of a
+real multi-rank gather is covered on CPU by tests/test_gather_gloo.py (same layout, gloo)."""
+import numpy as np
+import pytest
+
+from gsdf_amd.builder import Builder
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_gatherv_world_size_one(gpu):
+    b = Builder()
+    comm = gpu.CommHIP(gpu.CommHIP.unique_id(), 0, 1)
+    assert comm.allreduce_sum([5, 7, 2**40 + 3]) == [5, 7, 2**40 + 3]
+    for sh, res in ((b.NewSphere(1.0), 1.0 / 16), (b.Scene("npt-flange"), None)):
+        res = np.float32(res if res else float(sh.Diagonal()) / 200)
+        sdf = gpu.SDF3HIP(sh)
+        for mesh in (gpu.OctreeHIP(sdf, res), gpu.FlatHIP(sdf, res), gpu.DualContourHIP(sdf, np.float32(4 * res))):
+            g = mesh.gatherv(comm)
+            assert g.counts == [mesh.n_tris()] and g.n_tris() == mesh.n_tris() > 0
+            assert g.dev_ptr() != mesh.dev_ptr()                       # its own device buffer
+            assert (g.RenderAll().view(np.uint32) == mesh.RenderAll().view(np.uint32)).all()   # same triangles, same order
+            assert g.WriteBinarySTL() == mesh.WriteBinarySTL()
+    # shard union through the gather: with one rank per shard the gathered mesh is the concatenation; here the two
+    # shards of a 2-way split are gathered one after the other on the same communicator
+    sdf = gpu.SDF3HIP(b.Scene("bolt"))
+    res = np.float32(float(b.Scene("bolt").Diagonal()) / 150)
+    whole = gpu.OctreeHIP(sdf, res)
+    parts = [gpu.OctreeHIP(sdf, res, shard_rank=r, shard_count=2).gatherv(comm) for r in range(2)]
+    assert sum(p.n_tris() for p in parts) == whole.n_tris()
+    # an empty contribution is legal (a rank may own no surface bricks)
+    empty = gpu.OctreeHIP(gpu.SDF3HIP(b.Translate(b.NewSphere(0.01), 100, 100, 100)), np.float32(0.5), prune=True)
+    if empty.n_tris() == 0:
+        g = empty.gatherv(comm)
+        assert g.n_tris() == 0 and g.counts == [0] and g.RenderAll().shape == (0, 3, 3)
+    comm.close()
+    with pytest.raises(ValueError):
+        gpu.CommHIP(b"short", 0, 1)
+    with pytest.raises(gpu.HipError):
+        gpu.CommHIP(gpu.CommHIP.unique_id(), 3, 2)                     # rank out of range
+
+
+def test_mesh_outlives_its_program(gpu):
+    """A mesh owns what it needs to be read: destroying the program handle first (Go finalisers / Python GC run in any
+    order) must not break later reads or the on-device STL build."""
+    b = Builder()
+    sh = b.NewSphere(1.0)
+    sdf = gpu.SDF3HIP(sh)
+    oc = gpu.OctreeHIP(sdf, np.float32(1.0 / 20))
+    want = gpu.OctreeHIP(sdf, np.float32(1.0 / 20)).RenderAll()
+    sdf.close()                                                        # gsdf_hip_program_destroy: its stream is gone
+    assert (oc.RenderAll() == want).all()
+    assert len(oc.WriteBinarySTL()) == 84 + 50 * oc.n_tris()
+    assert oc.triangles_view().shape == want.shape
