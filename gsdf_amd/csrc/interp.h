@@ -23,6 +23,10 @@ typedef const v4f __attribute__((address_space(4))) * f4ptr;
 
 struct P3 { float x, y, z; };
 
+// Lane number within the wave (mbcnt pair; `threadIdx.x & 63` is equivalent here but, measured, costs the leaf kernels
+// registers: knurled-cylinder's leaf_kernel<4,3> 168 VGPRs + 1 spill instead of 168 + 0).
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
 // Slot s of point k of this lane: one float per lane per (slot, k) -> conflict-free columns.
 #define LDSF(slot) lds[((slot) * K + kp) * nthreads]
 // Each instruction is applied to the K points this lane carries before the next dispatch: the decode,
@@ -86,7 +90,7 @@ __device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t n
   }
   {  // the mask is the per-lane predicate (shift/and rather than the inverse-ballot builtin: the run-time compiler
      // of a process that loaded an older ROCm first, e.g. PyTorch's bundled one, does not have it)
-    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t lane = lane_id();
     KLOOP neg[kp] = ((negm[kp] >> lane) & 1ull) != 0ull;
   }
   if (!FAST) return true;
@@ -141,7 +145,7 @@ __device__ __forceinline__ void poly_cull(code_ptr code, uint32_t q0, uint32_t n
   }
   x0 = wave_minmax<false>(x0); x1 = wave_minmax<true>(x1);
   y0 = wave_minmax<false>(y0); y1 = wave_minmax<true>(y1);
-  const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const uint32_t lane = lane_id();
   const bool valid = lane < nv;
   const v4f* rec = (const v4f*)((const float*)(uintptr_t)code + q0 + 8u * (valid ? lane : 0u));  // this lane's edge record (32-byte aligned)
   const v4f r0 = rec[0], r1 = rec[1];
@@ -179,7 +183,7 @@ __device__ __forceinline__ void xy_shared(const P3 (&pv)[K], float (&out)[K], bo
     return;
   }
   if (K == 4 && shared && brick) {
-    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t lane = lane_id();
     const bool odd = ((lane >> 4) & 1u) != 0u;
     const float sx = odd ? pv[K > 2 ? 2 : 0].x : pv[0].x, sy = odd ? pv[K > 2 ? 2 : 0].y : pv[0].y;
     const float v = f(sx, sy);

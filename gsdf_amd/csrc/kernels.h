@@ -335,6 +335,11 @@ __device__ __forceinline__ void mc_final_flush(float* s_stage, unsigned* s_misc,
 template <int STAGE>
 __device__ __forceinline__ void mc_stage_flush(float* s_stage, unsigned long long* s_base, unsigned& cur, float* __restrict__ tris,
                                                uint64_t tri_cap, MeshCounters* __restrict__ ctr) {
+#ifdef GSDF_EXP_NO_FLUSH  // developer experiment: emission without the global append (timing only)
+  __syncthreads();
+  cur = 0;
+  return;
+#endif
   if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)cur);
   __syncthreads();
   const unsigned long long fb = *s_base;
@@ -376,9 +381,12 @@ __device__ __forceinline__ void mc_emit_balanced(const unsigned (&index)[NC], ui
   }
   if (lane == 63) s_misc[wave] = incl;
   __syncthreads();
-  const unsigned w0 = s_misc[0], w1 = s_misc[1], w2 = s_misc[2], w3 = s_misc[3];
+  // block-uniform values read back from LDS: pin them to SGPRs (the compiler cannot know they are uniform)
+  const unsigned w0 = __builtin_amdgcn_readfirstlane(s_misc[0]), w1 = __builtin_amdgcn_readfirstlane(s_misc[1]),
+                 w2 = __builtin_amdgcn_readfirstlane(s_misc[2]), w3 = __builtin_amdgcn_readfirstlane(s_misc[3]);
   const unsigned total = w0 + w1 + w2 + w3;
-  unsigned first = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + (incl - ntl);
+  const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+  unsigned first = (wave_u > 0 ? w0 : 0u) + (wave_u > 1 ? w1 : 0u) + (wave_u > 2 ? w2 : 0u) + (incl - ntl);
 #pragma unroll
   for (int c = 0; c < NC; c++) {
     if (nt[c]) {
@@ -392,6 +400,7 @@ __device__ __forceinline__ void mc_emit_balanced(const unsigned (&index)[NC], ui
   for (unsigned done = 0; done < total;) {  // block-uniform
     const unsigned room = STAGE - cur, left = total - done;
     const unsigned n = left < room ? left : room;
+#ifndef GSDF_EXP_NO_BUILD  // developer experiment: emission without building the triangles (timing only)
     for (unsigned t = threadIdx.x; t < n; t += BLOCK) {
       const unsigned o = s_owner[done + t];
       const unsigned k = o >> ID_BITS, id = o & ((1u << ID_BITS) - 1u);
@@ -414,6 +423,7 @@ __device__ __forceinline__ void mc_emit_balanced(const unsigned (&index)[NC], ui
         dst[3 * j + 2] = rz;
       }
     }
+#endif
     cur += n;
     done += n;
     __syncthreads();
@@ -454,9 +464,8 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
   const int sh = lq - 1;
   unsigned long long n_cubes = uniform_u64(ctr->n_level[lq]);  // survivors of the last prune level (device-side count)
   if (n_cubes > cube_cap) n_cubes = cube_cap;                  // queue overflowed: host reruns with larger queues
-  const uint64_t n_leaves = n_cubes << (3 * sh);
-  const unsigned lane = threadIdx.x & 63;
-  unsigned long long my_active = 0, my_cont = 0;
+  const uint64_t n_leaves = uniform_u64(n_cubes << (3 * sh));  // wave-uniform: keep it in SGPRs (the clamp above is a per-lane select otherwise)
+  unsigned my_active = 0, my_cont = 0;  // per wave, < 2^32: a workgroup visits at most 2^32 / BLOCK iterations
   const uint64_t step = (uint64_t)gridDim.x * BLOCK;
   for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_leaves; base += step) {
     const uint64_t i = base + threadIdx.x;
@@ -506,10 +515,9 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
         const unsigned long long pmask = __ballot(pass);
         if (pmask == 0ull) break;  // wave-uniform
         const unsigned long long vmask = __ballot(valid);
-        if (lane == 0) {
-          my_active += (unsigned long long)__builtin_popcountll(pmask);
-          my_cont += (unsigned long long)__builtin_popcountll(vmask);
-        }
+        // wave-uniform counters (every lane adds the same scalar): they live in SGPRs, not in four VGPRs
+        my_active += (unsigned)__builtin_popcountll(pmask);
+        my_cont += (unsigned)__builtin_popcountll(vmask);
       }
     }
     if (!pass || index == 255u) index = 0;
@@ -540,7 +548,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
   // statistics: two atomics per workgroup, not per wave (they share the L2 atomic unit with the triangle appends)
   __syncthreads();
   unsigned* s_stat = (unsigned*)s_stage;
-  if (lane == 0) { s_stat[2 * (threadIdx.x >> 6)] = (unsigned)my_active; s_stat[2 * (threadIdx.x >> 6) + 1] = (unsigned)my_cont; }
+  if ((threadIdx.x & 63u) == 0u) { s_stat[2 * (threadIdx.x >> 6)] = my_active; s_stat[2 * (threadIdx.x >> 6) + 1] = my_cont; }
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned long long a = (unsigned long long)s_stat[0] + s_stat[2] + s_stat[4] + s_stat[6];

@@ -31,10 +31,12 @@ def test_rccl_gatherv_world_size_one(gpu):
     parts = [gpu.OctreeHIP(sdf, res, shard_rank=r, shard_count=2).gatherv(comm) for r in range(2)]
     assert sum(p.n_tris() for p in parts) == whole.n_tris()
     # an empty contribution is legal (a rank may own no surface bricks)
-    empty = gpu.OctreeHIP(gpu.SDF3HIP(b.Translate(b.NewSphere(0.01), 100, 100, 100)), np.float32(0.5), prune=True)
-    if empty.n_tris() == 0:
-        g = empty.gatherv(comm)
-        assert g.n_tris() == 0 and g.counts == [0] and g.RenderAll().shape == (0, 3, 3)
+    small = gpu.SDF3HIP(b.NewSphere(1.0))
+    shards = [gpu.OctreeHIP(small, np.float32(0.25), shard_rank=r, shard_count=64) for r in range(64)]
+    empties = [m for m in shards if m.n_tris() == 0]
+    assert empties and sum(m.n_tris() for m in shards) == gpu.OctreeHIP(small, np.float32(0.25)).n_tris()
+    g = empties[0].gatherv(comm)
+    assert g.n_tris() == 0 and g.counts == [0] and g.RenderAll().shape == (0, 3, 3)
     comm.close()
     with pytest.raises(ValueError):
         gpu.CommHIP(b"short", 0, 1)
@@ -49,8 +51,10 @@ def test_mesh_outlives_its_program(gpu):
     sh = b.NewSphere(1.0)
     sdf = gpu.SDF3HIP(sh)
     oc = gpu.OctreeHIP(sdf, np.float32(1.0 / 20))
-    want = gpu.OctreeHIP(sdf, np.float32(1.0 / 20)).RenderAll()
+    want = oc.RenderAll().copy()
+    oc2 = gpu.OctreeHIP(sdf, np.float32(1.0 / 20))                     # a second mesh, read only after the program is gone
     sdf.close()                                                        # gsdf_hip_program_destroy: its stream is gone
-    assert (oc.RenderAll() == want).all()
-    assert len(oc.WriteBinarySTL()) == 84 + 50 * oc.n_tris()
-    assert oc.triangles_view().shape == want.shape
+    srt = lambda t: t.reshape(-1, 9)[np.lexsort(t.reshape(-1, 9).view(np.uint32).T[::-1])]
+    assert (srt(oc2.RenderAll()) == srt(want)).all()                   # first read of oc2: DMA on the mesh's own stream
+    assert len(oc2.WriteBinarySTL()) == 84 + 50 * oc2.n_tris()      # stl_kernel on the mesh's own stream
+    assert oc2.triangles_view().shape == want.shape

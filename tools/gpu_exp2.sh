@@ -11,9 +11,10 @@ print('$label', 'ms/step %.3f' % d['ms_per_step'], 'kernel %.3f ms' % r['kernel_
 }
 run base A=1
 run no_emit GSDF_HIP_SPEC_FLAGS=-DGSDF_EXP_NO_EMIT
-run w4_scratch GSDF_HIP_EXP_ALLOW_SCRATCH=1
-run w2 GSDF_HIP_LEAF_WAVES=2
-run bpc8 GSDF_HIP_LEAF_BPC=8
-run bpc16 GSDF_HIP_LEAF_BPC=16
-run bpc128 GSDF_HIP_LEAF_BPC=128
-
+run no_flush GSDF_HIP_SPEC_FLAGS=-DGSDF_EXP_NO_FLUSH
+run no_build GSDF_HIP_SPEC_FLAGS=-DGSDF_EXP_NO_BUILD
+run w3 GSDF_HIP_LEAF_WAVES=3
+SCENE_ARGS="--scene bolt --resdiv 2000"
+run bolt A=1
+SCENE_ARGS="--scene knurled-cylinder --resdiv 2000"
+run knurled A=1

@@ -14,6 +14,17 @@ DEV = os.path.join(ROOT, "tools", "specdev")
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
+def preload_torch_rocm():
+    """Bind the shim to PyTorch's bundled ROCm (hiprtc / comgr 7.0.x) instead of /opt/rocm's: bench.py and the GPU tests
+    import torch before libgsdfhip.so, so THAT compiler builds the specialised kernels on the GPU box -- and its register
+    allocation differs from the system compiler's."""
+    import glob
+    import importlib.util
+    lib = os.path.join(os.path.dirname(importlib.util.find_spec("torch").origin), "lib")
+    for n in ("libamd_comgr.so", "libamdhip64.so", "libhiprtc.so"):
+        C.CDLL(os.path.join(lib, n), mode=C.RTLD_GLOBAL)
+
+
 def build_shim():
     subprocess.check_call([sys.executable, "gen_embedded.py", "embedded_src.inc"], cwd=CSRC)
     so = os.path.join(DEV, "libspecdev.so")
@@ -50,7 +61,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("scene"); ap.add_argument("names")
     ap.add_argument("--isa"); ap.add_argument("--src")
+    ap.add_argument("--system-rocm", action="store_true", help="compile with /opt/rocm's hiprtc instead of PyTorch's bundled one (default: PyTorch's, like the GPU box)")
     a = ap.parse_args()
+    if not a.system_rocm:
+        preload_torch_rocm()
     lib = build_shim()
     sh = scene(a.scene)
     t = sh.tree()
