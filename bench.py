@@ -80,7 +80,7 @@ def pmc_summary(workload):
         except Exception:
             continue
         k2 = re.match(r"examples/(\S+) resdiv (\d+)", j.get("workload", ""))
-        d = j.get("leaf_kernel")
+        d = j.get("leaf_eval_kernel") or j.get("leaf_kernel")
         if d and k2 and k2.groups() == key.groups():  # summaries of other commands (eval mode, flat renderer) carry no leaf_kernel entry
             return dict(d, source=os.path.basename(f))
     return {}
@@ -270,7 +270,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     evals = tris = 0
-    march_ms = march_evals = march_tris = 0.0
+    march_ms = march_evals = march_tris = emit_ms = cut = 0.0
     last = None
     for _ in range(args.steps):
         oc, g = step()
@@ -280,6 +280,8 @@ def main():
         march_ms += st.ms_march
         march_evals += st.evals_leaf
         march_tris += st.n_tris
+        emit_ms += st.ms_emit
+        cut += st.cut_leaves
         last = (oc, g)
     barrier()
     dt = time.perf_counter() - t0
@@ -295,13 +297,18 @@ def main():
     if rank == 0:
         oc, g = last
         st = oc.stats
-        # dominant kernel: leaf_kernel. ALGORITHMIC bytes per launch = 16 B per evaluation it performs
+        # dominant kernel: leaf_eval_kernel (fused mode: leaf_kernel). ALGORITHMIC bytes per launch = 16 B per evaluation it performs
         # (12 B position + 4 B distance; positions are generated on device but counted) + 36 B per triangle.
         dc = args.renderer == "dualcontour"
         if dc:  # no single dominant kernel is timed apart: price the whole device pass (origin sweep + 4 follow-up kernels)
             march_ms, march_evals, march_tris = st.ms_total * args.steps, float(st.evals) * args.steps, float(st.n_tris) * args.steps
         k_ms = march_ms / max(1, args.steps)
-        k_bytes = (march_evals * 16.0 + march_tris * 36.0) / max(1, args.steps)
+        two_kernel = emit_ms > 0  # leaf phase = leaf_eval_kernel (dominant) + march_records_kernel
+        # ALGORITHMIC bytes of the dominant kernel: 16 B per evaluation; the fused kernel also emits the
+        # triangles (36 B each), the evaluating kernel of the two-kernel phase hands 40-byte cut-leaf records on instead
+        k_bytes = (march_evals * 16.0 + (cut * 40.0 if two_kernel else march_tris * 36.0)) / max(1, args.steps)
+        e_ms = emit_ms / max(1, args.steps)
+        e_bytes = (cut * 40.0 + march_tris * 36.0) / max(1, args.steps)
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         kernel_rate = (march_evals / max(1, args.steps)) / (k_ms * 1e-3) if k_ms > 0 else 0.0
         workload = (f"examples/{args.scene} resdiv {args.resdiv}: "
@@ -328,7 +335,11 @@ def main():
                          "kernel_evals_per_s": kernel_rate, "valu": None if dc else valu_roofline(kernel_rate, workload),
                          "note": "path is fp32-VALU bound (SURVEY 8(d)): algorithmic HBM bytes are tiny by construction; "
                                  "'valu' prices the same kernel against the VALU issue peak"},
-            "phase_ms_rank0": {"prune": st.ms_prune, "leaf": st.ms_leaf, "march_kernel": st.ms_march, "total_device": st.ms_total},
+            "roofline_march": None if (dc or not two_kernel) else {
+                "bound": "hbm", "kernel": "march_records_kernel", "kernel_ms": e_ms, "algorithmic_gb_per_launch": e_bytes / 1e9,
+                "achieved": e_bytes / (e_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": e_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "marching cubes over the cut-leaf records: 40 B read per record + 36 B written per triangle"},
+            "phase_ms_rank0": {"prune": st.ms_prune, "leaf": st.ms_leaf, "eval_kernel": st.ms_march, "march_kernel": st.ms_emit, "total_device": st.ms_total},
         }
         if world == 1 and not args.no_cpu_baseline and not dc:
             threads = max(1, (os.cpu_count() or 2) - 1)  # GOMAXPROCS-1 (gsdfaux/gsdfaux.go:162-164)

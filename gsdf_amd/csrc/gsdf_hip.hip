@@ -69,7 +69,7 @@ struct gsdf_program {
       return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-  } q0, q1, ctr, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, flat_grid;  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
+  } q0, q1, ctr, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, flat_grid, rec, hdr;  // rec / hdr: cut-leaf records of the two-kernel leaf phase  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   uint64_t last_tris = 0;  // triangle count of the previous mesh on this handle: sizes the next output buffer
   uint64_t last_dc_cubes = 0;  // kept cubes of the previous dual contouring pass: sizes the next queues
@@ -99,7 +99,26 @@ struct gsdf_program {
   }
 };
 
+// Leaf phase: two kernels by default (leaf_eval_kernel: evaluation + cut-leaf records, no barrier and no atomic in its
+// loop; march_records_kernel: marching cubes over the records); GSDF_HIP_FUSED_LEAF=1 keeps the fused leaf_kernel.
+static bool fused_leaf() {
+  static const bool f = [] { const char* e = getenv("GSDF_HIP_FUSED_LEAF"); return e && atoi(e) != 0; }();
+  return f;
+}
+
 void gsdf_program::leaf_config(int* k, int* w, size_t* lds) const {
+  if (!fused_leaf()) {  // the evaluating kernel needs the interpreter's columns only
+    static const int forced_w = [] { const char* e = getenv("GSDF_HIP_LEAF_WAVES"); return e ? atoi(e) : 0; }();  // tuning knob
+    const int ns = prog.nslots > 0 ? prog.nslots : 1;
+    const int lk = (batch_k() == 4 && ns > 11) ? 2 : batch_k();
+    const size_t lds_e = (size_t)ns * lk * BLOCK * sizeof(float);
+    int ww = forced_w ? forced_w : (4 * lds_e <= 160 * 1024 ? 4 : 3);
+    if (lk == 4) { if (ww != 2 && ww != 4) ww = 3; }
+    else if (lk == 2) { if (ww != 4) ww = 3; }
+    else ww = 4;
+    *k = lk; *w = ww; *lds = lds_e;
+    return;
+  }
   static const int forced_w = [] { const char* e = getenv("GSDF_HIP_LEAF_WAVES"); return e ? atoi(e) : 0; }();  // tuning knob
   const int ns = prog.nslots;
   const int lk = (batch_k() == 4 && ns > 11) ? 2 : batch_k();
@@ -409,7 +428,7 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
   names.push_back(std::string("eval_kernel<") + (p->prog.is2d ? "2" : "3") + ", " + std::to_string(ek) + ", " + std::to_string(ew) + ">");
   if (!p->prog.is2d) {
     names.push_back("prune_kernel");
-    names.push_back("leaf_kernel<" + std::to_string(lk) + ", " + std::to_string(lw) + ">");
+    names.push_back(std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(lw) + ">");
   }
   std::vector<hipFunction_t> f;
   hipModule_t mod = nullptr;
@@ -445,7 +464,7 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
     for (int w2 = lw - 1; !okl && w2 >= 2; w2--) {
       std::vector<hipFunction_t> fl;
       hipModule_t m2 = nullptr;
-      const std::string nl = "leaf_kernel<" + std::to_string(lk) + ", " + std::to_string(w2) + ">";
+      const std::string nl = std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(w2) + ">";
       if (spec_build(p, {nl}, &m2, fl, &p->spec_compile_s) != GSDF_OK) break;
       okl = fn_scratch_bytes(fl[0]) == 0;
       spec_report("specialised", nl, fl[0], okl);
@@ -477,8 +496,9 @@ extern "C" int gsdf_hip_program_kernels(const gsdf_program* p, char* dst, size_t
   if (p->prog.is2d)
     snprintf(buf, sizeof buf, "eval=eval_kernel<2,%d,%d>:%s", ek, ew, se ? "specialised" : "interpreter");
   else
-    snprintf(buf, sizeof buf, "eval=eval_kernel<3,%d,%d>:%s leaf=leaf_kernel<%d,%d>:%s prune=prune_kernel:%s", ek, ew, se ? "specialised" : "interpreter",
-             lk, sl ? p->spec_leaf_w : aw, sl ? "specialised" : "interpreter", p->f_prune ? "specialised" : "interpreter");
+    snprintf(buf, sizeof buf, "eval=eval_kernel<3,%d,%d>:%s leaf=%s<%d,%d>:%s prune=prune_kernel:%s", ek, ew, se ? "specialised" : "interpreter",
+             fused_leaf() ? "leaf_kernel" : "leaf_eval_kernel", lk, sl ? p->spec_leaf_w : aw, sl ? "specialised" : "interpreter",
+             p->f_prune ? "specialised" : "interpreter");
   if (strlen(buf) + 1 > dst_cap) return fail(GSDF_ERR_SHORT_BUFFER, "short buffer");
   std::memcpy(dst, buf, strlen(buf) + 1);
   return GSDF_OK;
@@ -508,7 +528,7 @@ extern "C" int gsdf_hip_specialize_check(const gsdf_tree* tree, size_t* code_obj
     std::vector<std::string> low;
     std::string log;
     const std::vector<std::string> names = pr.is2d ? std::vector<std::string>{"eval_kernel<2, 4, 4>"}
-                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
+                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "leaf_eval_kernel<4, 4>", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
     if (!gsdf_dev::spec_compile(pr, "gfx950", names, co, low, log)) return fail(GSDF_ERR_HIP, "specialised build failed:\n" + log);
     if (code_object_bytes) *code_object_bytes = co.size();
     return GSDF_OK;
@@ -557,6 +577,7 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (p->spec_mod3) (void)hipModuleUnload(p->spec_mod3);
   if (p->spec_mod4) (void)hipModuleUnload(p->spec_mod4);
   p->q0.release(); p->q1.release(); p->ctr.release();
+  p->rec.release(); p->hdr.release();
   p->flat_grid.release(); p->dc_grid.release(); p->dc_dist.release(); p->dc_fv.release(); p->dc_nrm.release(); p->dc_edge.release();
   for (auto e : p->ev) if (e) (void)hipEventDestroy(e);
   if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -783,8 +804,8 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   }
   uint64_t want = opts.max_tris;
   MeshCounters hc{};
-  bool used_brick = false;
-  float ms01 = 0, ms12 = 0;
+  bool used_brick = false, two_kernel = false;
+  float ms01 = 0, ms12 = 0, ms13 = 0;
   for (int attempt = 0;; attempt++) {
     HIP_TRYM(p->q0.ensure(qcap * sizeof(Cube)));
     HIP_TRYM(p->q1.ensure(qcap * sizeof(Cube)));
@@ -845,7 +866,36 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   hipLaunchKernelGGL((leaf_kernel<KK, WW>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), lds_m, s, p->d_code,      \
                      (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res,  \
                      m->d_tris, tcap, d_ctr)
-      if (lq == 3 && lk == 4 && opts.share_corners) {
+      if (!fused_leaf() && !(lq == 3 && lk == 4 && opts.share_corners)) {
+        // two kernels: evaluation + cut-leaf records, then marching cubes over the records
+        const uint64_t nblk = (bound + 63) / 64;  // 64-leaf blocks the queue capacity allows for
+        HIP_TRYM(p->hdr.ensure(nblk * sizeof(uint32_t)));
+        HIP_TRYM(p->rec.ensure(nblk * (size_t)REC_BLOCK * sizeof(uint32_t)));
+        uint32_t* d_hdr = (uint32_t*)p->hdr.p;
+        uint32_t* d_rec = (uint32_t*)p->rec.p;
+#define LAUNCH_LEAF_EVAL(KK, WW)                                                                                               \
+  hipLaunchKernelGGL((leaf_eval_kernel<KK, WW>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), lds_m, s, p->d_code,  \
+                     (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res, d_hdr,   \
+                     d_rec, (unsigned long long)nblk, d_ctr)
+        if (p->f_leaf && p->spec_leaf_k == lk) {
+          HIP_TRYM(launch_fn(p->f_leaf, grid_for(bound, p->num_cu, leaf_bpc), BLOCK, lds_m, s, (const uint32_t*)p->d_code, (const Cube*)q[lq & 1]->p,
+                             (unsigned long long)capq[lq & 1], (int)lq, (int)p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec,
+                             (unsigned long long)nblk, d_ctr));
+        } else {
+          // ahead-of-time kernels exist at the scratch-free occupancies only (tests/test_kernel_resources.py)
+          if (lk == 4) { if (lw == 2) LAUNCH_LEAF_EVAL(4, 2); else LAUNCH_LEAF_EVAL(4, 3); }
+          else if (lk == 2) LAUNCH_LEAF_EVAL(2, 3);
+          else LAUNCH_LEAF_EVAL(1, 4);
+        }
+#undef LAUNCH_LEAF_EVAL
+        HIP_TRYM(hipGetLastError());
+        HIP_TRYM(hipEventRecord(p->ev[3], s));
+        two_kernel = true;
+        static const int march_bpc = [] { const char* e = getenv("GSDF_HIP_MARCH_BPC"); return e ? atoi(e) : 4; }();  // tuning knob
+        const size_t lds_march = (size_t)11 * BLOCK * 4 + 5 * BLOCK * 2 + BLOCK + 256 * 16 + (size_t)MARCH_STAGE * 36 + (BLOCK + 1) * 4 + 8 * 4 + 16;
+        hipLaunchKernelGGL(march_records_kernel, dim3(grid_for(nblk, p->num_cu, march_bpc)), dim3(BLOCK), lds_march, s, d_hdr, d_rec,
+                           (unsigned long long)nblk, lq, ox, oy, oz, res, m->d_tris, (uint64_t)tcap, d_ctr);
+      } else if (lq == 3 && lk == 4 && opts.share_corners) {
         // exact corner sharing: one wave per level-3 brick
         const size_t lds_b = (size_t)(p->prog.nslots * 4) * BLOCK * sizeof(float) + 4096 + TRI_STAGE * 36 + 32 + 4 * 512 * 4 + 4 * 24 * 4;
         hipLaunchKernelGGL((leaf_brick_kernel<4, 2>), dim3(grid_for(capq[lq & 1] * 64 < bound ? capq[lq & 1] * 64 : bound, p->num_cu, 8)),
@@ -886,6 +936,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   }
   HIP_TRYM(hipEventElapsedTime(&ms01, ev0, ev1));
   HIP_TRYM(hipEventElapsedTime(&ms12, ev1, ev2));
+  if (two_kernel) HIP_TRYM(hipEventElapsedTime(&ms13, ev1, p->ev[3]));  // the evaluating kernel alone
   uint64_t evals_prune = 0, pruned = 0;
   for (int level = levels; level >= lq; level--) {
     evals_prune += hc.n_items[level];
@@ -903,7 +954,9 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   m->st.active_leaves = hc.n_active;
   m->st.ms_prune = ms01;
   m->st.ms_leaf = ms12;
-  m->st.ms_march = ms12;
+  m->st.ms_march = two_kernel ? ms13 : ms12;
+  m->st.ms_emit = two_kernel ? ms12 - ms13 : 0.0;
+  m->st.cut_leaves = hc.n_cut;
   m->st.ms_total = (double)ms01 + (double)ms12;
   p->evals += m->st.evals;
   p->last_tris = hc.n_tris;

@@ -88,6 +88,7 @@ struct MeshCounters {
   unsigned long long n_cont;               // leaves whose wave went on to the remaining corners
   unsigned long long q_overflow;           // cube queue capacity exceeded
   unsigned long long n_points;             // lattice points evaluated by leaf_brick_kernel
+  unsigned long long n_cut;                // leaves the surface cuts (records written by leaf_eval_kernel)
 };
 
 // wave64 compaction: returns the global slot for lanes with keep=true (others undefined).
@@ -555,6 +556,214 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
     const unsigned long long c = (unsigned long long)s_stat[1] + s_stat[3] + s_stat[5] + s_stat[7];
     if (c) { atomicAdd(&ctr->n_active, a); atomicAdd(&ctr->n_cont, c); }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Two-kernel leaf phase (default): leaf_eval_kernel evaluates, march_records_kernel builds the triangles.
+//
+// The fused leaf_kernel above spends 45 % of its time in the emission (block scan, owner list, LDS stage, four workgroup
+// barriers per pass and a global append every ~1.4 passes): the four waves of a workgroup stall together at every barrier
+// and at the atomic's round trip, with only 3-4 waves per SIMD to cover for them. Here the evaluating kernel has NO
+// barrier and NO atomic in its loop -- its waves are independent -- and leaves, per 64-leaf block (one wave pass), the leaves
+// the surface cuts as compact records in HBM:
+//     hdr[block]                    = number of records (0..64)
+//     rec[block][c][r], c < 10      = SoA inside the block (coalesced both ways): 8 corner distances (corner order 0..7),
+//                                     leaf x | y << 16, leaf z | index << 16       (40 B per cut leaf, ~16 % of the leaves)
+// Sized for the worst case (64 records per block: no overflow path); only the cut leaves' lines are ever touched.
+// march_records_kernel then runs marching cubes over the records alone: 256 blocks per workgroup pass (prefix of their
+// record counts in LDS), one record per lane in chunks of 256, triangles one per lane (mc_emit_balanced) into a large LDS
+// stage (this kernel has no interpreter columns to make room for), one global append per MARCH_STAGE triangles.
+// Same float operations on the same values as the fused kernel: the leaf origin is recomputed from the stored leaf
+// coordinates by the expression the evaluation used.
+// ---------------------------------------------------------------------------------------------------------------------
+#define REC_WORDS 10            // dwords per record
+#define REC_BLOCK (64 * REC_WORDS)  // dwords per 64-leaf block
+
+template <int K, int WAVES>
+__global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
+                                                          unsigned long long cube_cap, int lq, int nslots, float ox, float oy, float oz,
+                                                          float res, uint32_t* __restrict__ hdr, uint32_t* __restrict__ rec,
+                                                          unsigned long long n_blocks_cap, MeshCounters* __restrict__ ctr) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
+  const int sh = lq - 1;
+  unsigned long long n_cubes = uniform_u64(ctr->n_level[lq]);  // survivors of the last prune level (device-side count)
+  if (n_cubes > cube_cap) n_cubes = cube_cap;                  // queue overflowed: host reruns with larger queues
+  const uint64_t n_leaves = uniform_u64(n_cubes << (3 * sh));
+  unsigned my_active = 0, my_cont = 0, my_cut = 0;  // wave-uniform (SGPRs)
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_leaves; base += step) {
+    const uint64_t i = base + threadIdx.x;
+    const bool valid = i < n_leaves;
+    Cube lf = {0, 0, 0, 0};
+    if (valid) {
+      const Cube pc = cubes[i >> (3 * sh)];
+      const unsigned l = (unsigned)(i & ((1u << (3 * sh)) - 1u));
+      const unsigned m = (1u << sh) - 1u;
+      lf.x = (uint16_t)((pc.x << sh) + (l & m));
+      lf.y = (uint16_t)((pc.y << sh) + ((l >> sh) & m));
+      lf.z = (uint16_t)((pc.z << sh) + ((l >> (2 * sh)) & m));
+    }
+    const float x0 = ox + res * (float)lf.x, y0 = oy + res * (float)lf.y, z0 = oz + res * (float)lf.z;
+    const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;  // Box max = origin + size
+    unsigned index = 0;
+    bool pass = false;
+    float dall[8];  // distances in evaluation order {0,4,1,5,3,7,2,6}; static shift register
+#pragma unroll
+    for (int j = 0; j < 8; j++) dall[j] = 0.f;
+#pragma unroll 1
+    for (unsigned c0 = 0; c0 < 8; c0 += K) {
+      P3 pk[K];
+      float dk[K];
+#pragma unroll
+      for (int kp = 0; kp < K; kp++) {
+        const unsigned c = (0x62735140u >> (4u * (c0 + kp))) & 7u;
+        pk[kp].x = ((c ^ (c >> 1)) & 1u) ? x1 : x0;
+        pk[kp].y = ((c >> 1) & 1u) ? y1 : y0;
+        pk[kp].z = ((c >> 2) & 1u) ? z1 : z0;
+      }
+      gsdf_dev::sdf_eval<K, true>(code, pk, dk, lds, BLOCK, /*brick=*/sh == 2);  // lq == 3: one wave = one 4x4x4 brick
+#pragma unroll
+      for (int j = 0; j < 8 - K; j++) dall[j] = dall[j + K];
+#pragma unroll
+      for (int kp = 0; kp < K; kp++) {
+        const unsigned c = (0x62735140u >> (4u * (c0 + kp))) & 7u;
+        dall[8 - K + kp] = dk[kp];
+        index |= (dk[kp] < 0.f ? 1u : 0u) << c;
+      }
+      if (c0 == 0) {
+        pass = valid && (dm::absf(dk[0]) <= cubeDiag);
+        const unsigned long long pmask = __ballot(pass);
+        if (pmask == 0ull) break;  // wave-uniform
+        const unsigned long long vmask = __ballot(valid);
+        my_active += (unsigned)__builtin_popcountll(pmask);
+        my_cont += (unsigned)__builtin_popcountll(vmask);
+      }
+    }
+    const bool cut = pass && index != 0u && index != 255u;
+    // compact the cut leaves of this wave's block: rank among the cut lanes, one header word per block
+    const unsigned long long cm = __ballot(cut);
+    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+    const uint64_t blk = uniform_u64((base + (uint64_t)(threadIdx.x & ~63u)) >> 6);  // block = wave pass = 64 consecutive leaves
+    my_cut += (unsigned)__builtin_popcountll(cm);
+    if (blk < n_blocks_cap) {
+      if ((threadIdx.x & 63u) == 0u) hdr[blk] = (uint32_t)__builtin_popcountll(cm);
+      if (cut) {
+        uint32_t* w = rec + blk * REC_BLOCK + rank;
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[((0x62735140u >> (4u * j)) & 7u) * 64] = __float_as_uint(dall[j]);  // dall[j] = corner order[j]
+        w[8 * 64] = (uint32_t)lf.x | ((uint32_t)lf.y << 16);
+        w[9 * 64] = (uint32_t)lf.z | (index << 16);
+      }
+    }
+  }
+  // statistics: three atomics per workgroup
+  unsigned* s_stat = (unsigned*)g_smem;
+  __syncthreads();  // everyone is done with the interpreter columns
+  if ((threadIdx.x & 63u) == 0u) {
+    s_stat[3 * (threadIdx.x >> 6)] = my_active; s_stat[3 * (threadIdx.x >> 6) + 1] = my_cont; s_stat[3 * (threadIdx.x >> 6) + 2] = my_cut;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long a = (unsigned long long)s_stat[0] + s_stat[3] + s_stat[6] + s_stat[9];
+    const unsigned long long c = (unsigned long long)s_stat[1] + s_stat[4] + s_stat[7] + s_stat[10];
+    const unsigned long long u = (unsigned long long)s_stat[2] + s_stat[5] + s_stat[8] + s_stat[11];
+    if (c) { atomicAdd(&ctr->n_active, a); atomicAdd(&ctr->n_cont, c); }
+    if (u) atomicAdd(&ctr->n_cut, u);
+  }
+}
+
+#define MARCH_STAGE 896  // triangles staged per workgroup (31.5 KB: three workgroups per CU): one global append per 896 -- a single
+                         // counter word takes ~88 atomics/us and this kernel lasts ~0.1 ms, so appends must be rare
+// LDS: [11 record columns of BLOCK floats | owner list 5*BLOCK u16 | index BLOCK u8 | tri table | stage | prefix BLOCK+1 | misc]
+__global__ void __launch_bounds__(BLOCK) march_records_kernel(const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ rec,
+                                                              unsigned long long n_blocks_cap, int lq, float ox, float oy, float oz,
+                                                              float res, float* __restrict__ tris, uint64_t tri_cap,
+                                                              MeshCounters* __restrict__ ctr) {
+  float* s_col = g_smem;                                       // [11][BLOCK]: 8 distances + origin of the chunk's records
+  uint16_t* s_owner = (uint16_t*)(s_col + 11 * BLOCK);         // [5 * BLOCK]
+  uint8_t* s_index = (uint8_t*)(s_owner + 5 * BLOCK);          // [BLOCK]
+  int8_t* s_tri = (int8_t*)(s_index + BLOCK);
+  float* s_stage = (float*)(s_tri + 256 * 16);
+  unsigned* s_pre = (unsigned*)(s_stage + MARCH_STAGE * 9);    // [BLOCK + 1] exclusive prefix of the pass's record counts
+  unsigned* s_misc = s_pre + BLOCK + 1;                        // [0..3] wave sums (mc_emit_balanced), [4..7] wave sums of the prefix
+  unsigned long long* s_base = (unsigned long long*)(((uintptr_t)(s_misc + 8) + 7) & ~(uintptr_t)7);
+  for (int k = threadIdx.x; k < 256 * 16; k += BLOCK) s_tri[k] = GSDF_MC_TRI[k >> 4][k & 15];
+  __syncthreads();
+  unsigned cur = 0;
+  unsigned long long n_cubes = uniform_u64(ctr->n_level[lq]);
+  const uint64_t n_leaves = n_cubes << (3 * (lq - 1));
+  uint64_t n_blocks = (n_leaves + 63) >> 6;
+  if (n_blocks > n_blocks_cap) n_blocks = n_blocks_cap;  // (the cube queue overflowed: the host reruns)
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (uint64_t b0 = (uint64_t)blockIdx.x * BLOCK; b0 < n_blocks; b0 += (uint64_t)gridDim.x * BLOCK) {  // block-uniform
+    // exclusive prefix of the record counts of blocks b0 .. b0+255
+    const uint64_t b = b0 + threadIdx.x;
+    const unsigned nr = b < n_blocks ? hdr[b] : 0u;
+    unsigned incl = nr;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned u = __shfl_up(incl, off, 64);
+      if (lane >= (unsigned)off) incl += u;
+    }
+    if (lane == 63) s_misc[4 + wave] = incl;
+    __syncthreads();
+    const unsigned p0 = s_misc[4], p1 = s_misc[5], p2 = s_misc[6], p3 = s_misc[7];
+    const unsigned wpre = (wave > 0 ? p0 : 0u) + (wave > 1 ? p1 : 0u) + (wave > 2 ? p2 : 0u);
+    s_pre[threadIdx.x] = wpre + incl - nr;
+    const unsigned R = p0 + p1 + p2 + p3;  // records of this pass (block-uniform)
+    if (threadIdx.x == 0) s_pre[BLOCK] = R;
+    __syncthreads();
+    // One record per lane in chunks of 256. The next chunk's record is fetched into registers BEFORE the current chunk is
+    // marched: with three workgroups per CU there is little else to cover the ~2 us of a dependent global load.
+    uint32_t rw[REC_WORDS];
+    auto fetch = [&](unsigned q) {
+#pragma unroll
+      for (int c = 0; c < REC_WORDS; c++) rw[c] = 0u;
+      if (q < R) {
+        // the block holding record q: largest j with s_pre[j] <= q (blocks without records share their successor's prefix)
+        unsigned lo = 0, hi = BLOCK;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+          const unsigned mid = (lo + hi) >> 1;
+          if (s_pre[mid] <= q) lo = mid; else hi = mid;
+        }
+        const uint32_t* w = rec + (b0 + lo) * REC_BLOCK + (q - s_pre[lo]);
+#pragma unroll
+        for (int c = 0; c < REC_WORDS; c++) rw[c] = w[c * 64];
+      }
+    };
+    fetch(threadIdx.x);
+    for (unsigned q0 = 0; q0 < R; q0 += BLOCK) {  // block-uniform
+      const unsigned q = q0 + threadIdx.x;
+      unsigned index = 0;
+      if (q < R) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) s_col[c * BLOCK + threadIdx.x] = __uint_as_float(rw[c]);
+        const uint32_t xy = rw[8], zi = rw[9];
+        index = zi >> 16;
+        // the leaf origin exactly as the evaluating kernel formed it
+        s_col[8 * BLOCK + threadIdx.x] = ox + res * (float)(xy & 0xffffu);
+        s_col[9 * BLOCK + threadIdx.x] = oy + res * (float)(xy >> 16);
+        s_col[10 * BLOCK + threadIdx.x] = oz + res * (float)(zi & 0xffffu);
+      }
+      fetch(q + BLOCK);  // in flight while this chunk is marched
+      const unsigned index1[1] = {index};
+      mc_emit_balanced<1, MARCH_STAGE>(
+          index1, s_owner, s_index, s_tri, s_stage, s_misc, s_base, cur, res,
+          [&](unsigned id, unsigned cc) { return s_col[cc * BLOCK + id]; },
+          [&](unsigned id, float& ax, float& ay, float& az) {
+            ax = s_col[8 * BLOCK + id];
+            ay = s_col[9 * BLOCK + id];
+            az = s_col[10 * BLOCK + id];
+          },
+          tris, tri_cap, ctr);
+    }
+    __syncthreads();  // s_pre / s_misc[4..7] are rewritten by the next pass
+  }
+  __syncthreads();
+  if (cur) mc_stage_flush<MARCH_STAGE>(s_stage, s_base, cur, tris, tri_cap, ctr);
 }
 
 // Leaf kernel with exact corner sharing (level-3 bricks: one wave = one brick of 4x4x4 leaves).

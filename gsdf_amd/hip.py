@@ -36,7 +36,7 @@ class MeshStats(C.Structure):
     _fields_ = [("n_tris", C.c_uint64), ("evals", C.c_uint64), ("pruned_leaves", C.c_uint64), ("leaf_cubes", C.c_uint64),
                 ("active_leaves", C.c_uint64), ("levels", C.c_int), ("origin", C.c_float * 3), ("res", C.c_float),
                 ("ms_total", C.c_double), ("ms_prune", C.c_double), ("ms_leaf", C.c_double), ("ms_march", C.c_double),
-                ("evals_prune", C.c_uint64), ("evals_leaf", C.c_uint64)]
+                ("evals_prune", C.c_uint64), ("evals_leaf", C.c_uint64), ("ms_emit", C.c_double), ("cut_leaves", C.c_uint64)]
 
 
 class HipError(RuntimeError):

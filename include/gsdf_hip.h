@@ -156,9 +156,12 @@ typedef struct gsdf_mesh_stats {
   double ms_total;         /* device time for the whole mesh, HIP events */
   double ms_prune;         /* pruning levels */
   double ms_leaf;          /* leaf phase */
-  double ms_march;         /* dominant kernel alone: leaf_kernel (8 corners + marching cubes), HIP events */
+  double ms_march;         /* dominant kernel alone, HIP events: leaf_eval_kernel (the 8 corner evaluations of every leaf);
+                              with GSDF_HIP_FUSED_LEAF=1 the fused leaf_kernel (evaluations + marching cubes) */
   uint64_t evals_prune;    /* evaluations done by the pruning levels (cube centres) */
-  uint64_t evals_leaf;     /* evaluations done by leaf_kernel (leaf corners) */
+  uint64_t evals_leaf;     /* evaluations done by the leaf phase (leaf corners) */
+  double ms_emit;          /* march_records_kernel: marching cubes over the cut-leaf records (0 for the fused kernel) */
+  uint64_t cut_leaves;     /* leaves the surface cuts = 40-byte records handed from leaf_eval_kernel to march_records_kernel */
 } gsdf_mesh_stats;
 
 int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_opts* opts, gsdf_mesh** out);

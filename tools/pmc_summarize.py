@@ -18,7 +18,7 @@ ap.add_argument("--workload", default="")
 ap.add_argument("--command", default="python bench.py --steps 5 --warmup 1 --no-cpu-baseline")
 a = ap.parse_args()
 
-KERNELS = ("leaf_kernel", "prune_kernel", "leaf_brick_kernel", "eval_kernel", "flat_grid_kernel", "flat_march_kernel")
+KERNELS = ("leaf_eval_kernel", "march_records_kernel", "leaf_kernel", "prune_kernel", "leaf_brick_kernel", "eval_kernel", "flat_grid_kernel", "flat_march_kernel")
 acc = {k: defaultdict(lambda: [0.0, 0]) for k in KERNELS}
 for f in glob.glob(os.path.join(a.dir, "**", "*counter_collection.csv"), recursive=True):
     per = defaultdict(float)
@@ -41,7 +41,7 @@ for k in KERNELS:
     if "SQ_INSTS_VALU" in d:
         if "SQ_INSTS_SALU" in d:
             d["salu_per_valu"] = d["SQ_INSTS_SALU"] / d["SQ_INSTS_VALU"]
-        if k == "leaf_kernel" and a.evals_per_launch:
+        if k in ("leaf_kernel", "leaf_eval_kernel") and a.evals_per_launch:
             d["valu_lane_instr_per_eval"] = d["SQ_INSTS_VALU"] * 64 / a.evals_per_launch
             if a.kernel_ms:
                 rate = d["SQ_INSTS_VALU"] * 64 / (a.kernel_ms * 1e-3)
