@@ -7,12 +7,10 @@ run() {  # label, env...
   env "$@" timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline ${SCENE_ARGS} 2>&1 | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']; ph=d['phase_ms_rank0']
-print('$label', 'ms/step %.3f' % d['ms_per_step'], 'kernel %.3f ms' % r['kernel_ms'], r['kernel'], 'phases', {k: round(v,3) for k,v in ph.items()}, 'tris', int(d['triangles_per_step']))"
+print('$label', 'ms/step %.3f' % d['ms_per_step'], 'kernel %.3f ms' % r['kernel_ms'], r['kernel'], 'phases', {k: round(v,3) for k,v in ph.items()}, 'tris', int(d['triangles_per_step']), d['config']['evaluator'][:60])"
 }
-run two_kernel A=1
-run march_bpc3 GSDF_HIP_MARCH_BPC=3
-run march_bpc6 GSDF_HIP_MARCH_BPC=6
-run march_bpc12 GSDF_HIP_MARCH_BPC=12
+run hipcc A=1
+run hiprtc GSDF_HIP_SPEC_COMPILER=hiprtc
 SCENE_ARGS="--scene bolt --resdiv 2000"
 run bolt A=1
 SCENE_ARGS="--scene knurled-cylinder --resdiv 2000"
