@@ -237,7 +237,8 @@ def main():
         # also remain in use if the run-time build is not possible on this box (still the HIP path, same bits).
         try:
             sdf.specialize()
-            spec_note = "kernels specialised for the tree at setup (hiprtc, %.1f s, untimed)" % sdf.info()["specialize_s"]
+            inf = sdf.info()
+            spec_note = "kernels specialised for the tree at setup (%s, %.1f s, untimed)" % (inf["kernels"].get("compiler", "hiprtc"), inf["specialize_s"])
         except hip.HipError as e:
             print("bench: specialised build unavailable, using the interpreter kernels: %s" % str(e)[:300], file=sys.stderr)
             spec_note = "interpreter kernels (specialised build failed)"

@@ -80,6 +80,7 @@ struct gsdf_program {
   bool spec_aux_tried = false;
   int spec_eval_k = 0, spec_eval_w = 0, spec_leaf_k = 0, spec_leaf_w = 0;
   double spec_compile_s = 0;
+  std::string spec_compiler;  // hipcc | hiprtc | cache: what built the specialised kernels
   // leaf kernel batching: K = 4 while 3 workgroups still fit the CU's LDS (<= 11 slots); 12..15 slots run K = 2 at 4
   // waves/SIMD instead of K = 4 at 2 (knurled-cylinder: 23.3 vs 23.8 ms). A 4th wave per SIMD is worth more than the
   // ~30 VGPRs it costs (flange 3.28 -> 2.95 ms), but only if 4 workgroups fit the CU's 160 KB of LDS.
@@ -435,6 +436,7 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
   const int rc = spec_build(p, names, &mod, f, &p->spec_compile_s);
   if (rc != GSDF_OK) return rc;
   p->spec_mod = mod;
+  p->spec_compiler = gsdf_dev::spec_last_compiler();
   p->spec_eval_k = ek; p->spec_eval_w = ew; p->spec_leaf_k = lk; p->spec_leaf_w = lw;
   // No scratch, or not used (see fn_scratch_bytes). The eval kernel gets a second chance with the larger register
   // budget of 3 workgroups per CU before the handle falls back to the interpreter kernel for that entry point.
@@ -499,6 +501,7 @@ extern "C" int gsdf_hip_program_kernels(const gsdf_program* p, char* dst, size_t
     snprintf(buf, sizeof buf, "eval=eval_kernel<3,%d,%d>:%s leaf=%s<%d,%d>:%s prune=prune_kernel:%s", ek, ew, se ? "specialised" : "interpreter",
              fused_leaf() ? "leaf_kernel" : "leaf_eval_kernel", lk, sl ? p->spec_leaf_w : aw, sl ? "specialised" : "interpreter",
              p->f_prune ? "specialised" : "interpreter");
+  if (p->spec_mod && strlen(buf) + 32 < sizeof buf) { strcat(buf, " compiler="); strcat(buf, p->spec_compiler.c_str()); }
   if (strlen(buf) + 1 > dst_cap) return fail(GSDF_ERR_SHORT_BUFFER, "short buffer");
   std::memcpy(dst, buf, strlen(buf) + 1);
   return GSDF_OK;

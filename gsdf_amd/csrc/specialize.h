@@ -20,4 +20,8 @@ int spec_instruction_count(const Program& p);
 bool spec_compile(const Program& p, const std::string& arch, const std::vector<std::string>& name_exprs,
                   std::vector<char>& code_object, std::vector<std::string>& lowered, std::string& log);
 
+// "hipcc" (out-of-process build with the installed compiler), "hiprtc" (the process's run-time compiler) or "cache": how
+// the calling thread's last successful spec_compile got its code object.
+const char* spec_last_compiler();
+
 }  // namespace gsdf_dev

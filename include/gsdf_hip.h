@@ -82,7 +82,8 @@ int gsdf_hip_selftest_sqrt(uint64_t* mismatches);
 int gsdf_hip_program_specialize(gsdf_program* p);
 int gsdf_hip_program_is_specialized(const gsdf_program* p, double* compile_seconds);
 /* Names of the kernels this handle launches, as a profiler shows them: "eval=eval_kernel<3,4,4>:specialised
- * leaf=leaf_kernel<4,3>:specialised prune=prune_kernel:specialised" (":interpreter" = the ahead-of-time kernels). */
+ * leaf=leaf_eval_kernel<4,4>:specialised prune=prune_kernel:specialised compiler=hipcc" (":interpreter" = the ahead-of-time
+ * kernels; compiler = what built the specialised ones: the installed hipcc out of process, or the process's hiprtc). */
 int gsdf_hip_program_kernels(const gsdf_program* p, char* dst, size_t dst_cap);
 /* Host-only (run without a GPU): text of the generated evaluator, and a gfx950 hiprtc build of the specialised kernels
  * that stops before loading them. dst may be NULL to query the length. */
