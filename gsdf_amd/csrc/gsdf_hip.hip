@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -52,8 +54,17 @@ struct gsdf_program {
   float* d_dist = nullptr;
   size_t cap_pos_bytes = 0, cap_dist = 0;
   // pinned, device-mapped host staging for small host-buffer calls (the reference's callers hand over <= 32768 points)
-  void* h_pos = nullptr;
+  void* h_pos = nullptr;   // (slot 0 of the staging slots below; kept for the struct's older users)
   float* h_dist = nullptr;
+  // Staging slots of the host-buffer API: pinned, device-mapped position / distance buffers with a stream each, so that
+  // several host threads (glrender.FlatRenderer evaluates from numParallel goroutines, flatrenderer.go:120-129) -- or one
+  // caller pipelining gsdf_hip_eval3_submit / gsdf_hip_eval_wait -- have calls in flight at the same time.
+  struct Slot { void* h_pos = nullptr; float* h_dist = nullptr; hipStream_t s = nullptr; bool busy = false; float* user_dist = nullptr; size_t n = 0; bool zero_copy = false; };
+  static constexpr int kSlots = 4;
+  Slot slot[kSlots];
+  std::mutex slot_mu;
+  std::condition_variable slot_cv;
+  std::atomic<uint64_t> evals_host{0};
   int num_cu = 256;
   // mesher workspace, grow-only, reused by every gsdf_hip_mesh_octree call on this handle
   struct Arena {
@@ -575,6 +586,11 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (p->d_dist) (void)hipFree(p->d_dist);
   if (p->h_pos) (void)hipHostFree(p->h_pos);
   if (p->h_dist) (void)hipHostFree(p->h_dist);
+  for (auto& sl : p->slot) {
+    if (sl.h_pos) (void)hipHostFree(sl.h_pos);
+    if (sl.h_dist) (void)hipHostFree(sl.h_dist);
+    if (sl.s) (void)hipStreamDestroy(sl.s);
+  }
   if (p->spec_mod) (void)hipModuleUnload(p->spec_mod);
   if (p->spec_mod2) (void)hipModuleUnload(p->spec_mod2);
   if (p->spec_mod3) (void)hipModuleUnload(p->spec_mod3);
@@ -599,9 +615,9 @@ extern "C" int gsdf_hip_program_info(const gsdf_program* p, uint32_t* code_words
   if (lds_slots) *lds_slots = (uint32_t)p->prog.nslots;
   return GSDF_OK;
 }
-extern "C" uint64_t gsdf_hip_evaluations(const gsdf_program* p) { return p ? p->evals : 0; }
+extern "C" uint64_t gsdf_hip_evaluations(const gsdf_program* p) { return p ? p->evals + p->evals_host.load() : 0; }
 
-static int eval_dev(gsdf_program* p, int dim, const void* d_pos, size_t stride_bytes, float* d_dist, size_t n, hipStream_t s) {
+static int eval_dev(gsdf_program* p, int dim, const void* d_pos, size_t stride_bytes, float* d_dist, size_t n, hipStream_t s, bool count = true) {
   if (stride_bytes % 4 != 0 || stride_bytes < (size_t)dim * 4) return fail(GSDF_ERR_BAD_ARGUMENT, "bad position stride");
   const int k = p->batch_k();
   static const int eval_bpc = [] { const char* e = getenv("GSDF_HIP_EVAL_BPC"); return e ? atoi(e) : 64; }();  // tuning knob: finer grids drain evenly (8 -> 64 per CU: +10 % on npt-flange)
@@ -625,11 +641,76 @@ static int eval_dev(gsdf_program* p, int dim, const void* d_pos, size_t stride_b
   }
 #undef LAUNCH_EVAL
   HIP_TRY(hipGetLastError());
-  p->evals += n;
+  if (count) p->evals += n;  // (concurrent host-buffer callers count through evals_host instead)
   return GSDF_OK;
 }
 
-static int eval_host(gsdf_program* p, int dim, const void* pos, size_t stride, size_t n_pos, float* dist, size_t n_dist) {
+// ---- caller buffers the GPU can reach directly (pinned + device-mapped): no staging copy at all ----------------------
+// Process-wide table of host ranges registered through gsdf_hip_host_alloc / gsdf_hip_host_register. A call whose
+// positions AND distances lie inside such ranges runs the kernel straight on the caller's memory across PCIe.
+namespace {
+struct HostRange { char* p; size_t n; bool owned; };
+std::mutex g_reg_mu;
+std::vector<HostRange> g_reg;
+void* reg_device_ptr(const void* h, size_t n) {
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  for (const HostRange& r : g_reg)
+    if ((const char*)h >= r.p && (const char*)h + n <= r.p + r.n) {
+      void* d = nullptr;
+      if (hipHostGetDevicePointer(&d, r.p, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+      return (char*)d + ((const char*)h - r.p);
+    }
+  return nullptr;
+}
+}  // namespace
+extern "C" void* gsdf_hip_host_alloc(size_t bytes) {
+  void* h = nullptr;
+  if (bytes == 0 || hipHostMalloc(&h, bytes, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  g_reg.push_back(HostRange{(char*)h, bytes, true});
+  return h;
+}
+extern "C" int gsdf_hip_host_register(void* ptr, size_t bytes) {
+  if (!ptr || bytes == 0) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  g_reg.push_back(HostRange{(char*)ptr, bytes, false});
+  return GSDF_OK;
+}
+extern "C" int gsdf_hip_host_release(void* ptr) {  // gsdf_hip_host_alloc'ed: freed; gsdf_hip_host_register'ed: unregistered
+  if (!ptr) return GSDF_OK;
+  HostRange r{nullptr, 0, false};
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    for (size_t i = 0; i < g_reg.size(); i++)
+      if (g_reg[i].p == (char*)ptr) { r = g_reg[i]; g_reg.erase(g_reg.begin() + (long)i); break; }
+  }
+  if (!r.p) return fail(GSDF_ERR_BAD_ARGUMENT, "not a registered host buffer");
+  if (r.owned) HIP_TRY(hipHostFree(r.p));
+  else HIP_TRY(hipHostUnregister(r.p));
+  return GSDF_OK;
+}
+
+static constexpr size_t kSmallPos = (size_t)1 << 20, kSmallDist = (size_t)1 << 18;
+
+static int slot_acquire(gsdf_program* p, int* idx) {
+  std::unique_lock<std::mutex> lk(p->slot_mu);
+  for (;;) {
+    for (int i = 0; i < gsdf_program::kSlots; i++)
+      if (!p->slot[i].busy) { p->slot[i].busy = true; *idx = i; return GSDF_OK; }
+    p->slot_cv.wait(lk);
+  }
+}
+static void slot_release(gsdf_program* p, int idx) {
+  { std::lock_guard<std::mutex> lk(p->slot_mu); p->slot[idx].busy = false; }
+  p->slot_cv.notify_one();
+}
+
+// Enqueue one host-buffer evaluation on a staging slot (no wait). Small calls (what the reference's renderers issue:
+// <= 32768 points, gsdfaux.go:89,113) make no DMA round trips: the kernel reads the positions from -- and writes the
+// distances to -- pinned, device-mapped host memory across PCIe itself: the caller's own buffers when they are registered
+// (zero copy), else the slot's staging buffers (one memcpy in, one out).
+static int eval_submit(gsdf_program* p, int dim, const void* pos, size_t stride, size_t n_pos, float* dist, size_t n_dist, int* ticket) {
   if (!p) return fail(GSDF_ERR_BAD_ARGUMENT, "null program");
   if (n_pos != n_dist) return fail(GSDF_ERR_LENGTH_MISMATCH, "position and distance buffer length mismatch");
   if (n_pos == 0) return fail(GSDF_ERR_EMPTY_BUFFERS, "empty buffers");
@@ -637,25 +718,57 @@ static int eval_host(gsdf_program* p, int dim, const void* pos, size_t stride, s
   if (p->prog.is2d != (dim == 2)) return fail(GSDF_ERR_DIMENSION, dim == 2 ? "program is 3D, eval2 called" : "program is 2D, eval3 called");
   HIP_TRY(hipSetDevice(p->device));
   const size_t pbytes = n_pos * stride;
-  // Small calls (what the reference's renderers issue: <= 32768 points, gsdfaux.go:89,113): no DMA round trips. The
-  // positions are copied into pinned, device-mapped host memory and the kernel reads them -- and writes the distances --
-  // across PCIe itself: 61 -> 40-47 us per 32768-point call, 49 -> 28 us per 4096-point call (staging through pinned
-  // memory with DMA copies: 61 / 34 us; spinning on hipStreamQuery instead of hipStreamSynchronize: no better).
-  constexpr size_t kSmallPos = (size_t)1 << 20, kSmallDist = (size_t)1 << 18;
-  if (pbytes <= kSmallPos && n_pos <= kSmallDist) {
-    if (!p->h_pos) HIP_TRY(hipHostMalloc(&p->h_pos, kSmallPos, hipHostMallocMapped | hipHostMallocPortable));
-    if (!p->h_dist) HIP_TRY(hipHostMalloc((void**)&p->h_dist, kSmallDist * sizeof(float), hipHostMallocMapped | hipHostMallocPortable));
-    std::memcpy(p->h_pos, pos, pbytes);
-    void* dp = nullptr;
-    void* dd = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(&dp, p->h_pos, 0));
-    HIP_TRY(hipHostGetDevicePointer(&dd, p->h_dist, 0));
-    const int rc = eval_dev(p, dim, dp, stride, (float*)dd, n_pos, p->stream);
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    std::memcpy(dist, p->h_dist, n_pos * sizeof(float));
-    return GSDF_OK;
+  int si = -1;
+  int rc = slot_acquire(p, &si);
+  if (rc) return rc;
+  gsdf_program::Slot& sl = p->slot[si];
+  auto bail = [&](int code) { slot_release(p, si); return code; };
+  if (!sl.s && hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipStreamCreate failed"));
+  void* dp = reg_device_ptr(pos, pbytes);
+  void* dd = dp ? reg_device_ptr(dist, n_pos * sizeof(float)) : nullptr;
+  sl.zero_copy = dp && dd;
+  sl.user_dist = dist;
+  sl.n = n_pos;
+  if (!sl.zero_copy) {
+    if (pbytes > kSmallPos || n_pos > kSmallDist) return bail(fail(GSDF_ERR_BAD_ARGUMENT, "internal: large call on the small path"));
+    if (!sl.h_pos && hipHostMalloc(&sl.h_pos, kSmallPos, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipHostMalloc failed"));
+    if (!sl.h_dist && hipHostMalloc((void**)&sl.h_dist, kSmallDist * sizeof(float), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipHostMalloc failed"));
+    std::memcpy(sl.h_pos, pos, pbytes);
+    if (hipHostGetDevicePointer(&dp, sl.h_pos, 0) != hipSuccess || hipHostGetDevicePointer(&dd, sl.h_dist, 0) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipHostGetDevicePointer failed"));
   }
+  rc = eval_dev(p, dim, dp, stride, (float*)dd, n_pos, sl.s, /*count=*/false);
+  if (rc) return bail(rc);
+  p->evals_host.fetch_add(n_pos);
+  *ticket = si;
+  return GSDF_OK;
+}
+static int eval_wait(gsdf_program* p, int ticket) {
+  if (!p || ticket < 0 || ticket >= gsdf_program::kSlots || !p->slot[ticket].busy) return fail(GSDF_ERR_BAD_ARGUMENT, "bad evaluation ticket");
+  gsdf_program::Slot& sl = p->slot[ticket];
+  hipError_t e = hipStreamSynchronize(sl.s);
+  if (e == hipSuccess && !sl.zero_copy) std::memcpy(sl.user_dist, sl.h_dist, sl.n * sizeof(float));
+  slot_release(p, ticket);
+  if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+  return GSDF_OK;
+}
+
+static int eval_host(gsdf_program* p, int dim, const void* pos, size_t stride, size_t n_pos, float* dist, size_t n_dist) {
+  if (!p) return fail(GSDF_ERR_BAD_ARGUMENT, "null program");
+  const size_t pbytes = n_pos * stride;
+  const bool small = pbytes <= kSmallPos && n_pos <= kSmallDist;
+  if (small || (pos && dist && n_pos == n_dist && n_pos && reg_device_ptr(pos, pbytes) && reg_device_ptr(dist, n_pos * sizeof(float)))) {
+    int t = -1;
+    const int rc = eval_submit(p, dim, pos, stride, n_pos, dist, n_dist, &t);
+    return rc ? rc : eval_wait(p, t);
+  }
+  if (n_pos != n_dist) return fail(GSDF_ERR_LENGTH_MISMATCH, "position and distance buffer length mismatch");
+  if (n_pos == 0) return fail(GSDF_ERR_EMPTY_BUFFERS, "empty buffers");
+  if (!pos || !dist) return fail(GSDF_ERR_BAD_ARGUMENT, "null buffer");
+  if (p->prog.is2d != (dim == 2)) return fail(GSDF_ERR_DIMENSION, dim == 2 ? "program is 3D, eval2 called" : "program is 2D, eval3 called");
+  HIP_TRY(hipSetDevice(p->device));
+  // large calls: DMA in, kernel, DMA out on the program's stream (one caller at a time, as before)
+  static std::mutex big_mu;
+  std::lock_guard<std::mutex> lk(big_mu);
   if (pbytes > p->cap_pos_bytes) {
     if (p->d_pos) (void)hipFree(p->d_pos);
     p->d_pos = nullptr; p->cap_pos_bytes = 0;
@@ -675,6 +788,20 @@ static int eval_host(gsdf_program* p, int dim, const void* pos, size_t stride, s
   HIP_TRY(hipStreamSynchronize(p->stream));
   return GSDF_OK;
 }
+
+// Pipelined form of the host-buffer API: submit returns at once with a ticket (at most 4 in flight per program: a fifth
+// submit waits for a free slot), wait blocks until that call's distances are in `dist`. For callers that can prepare the
+// next batch while the previous one is on the GPU. Batches of up to 2^18 points (2^20 position bytes), or any size in
+// registered memory.
+extern "C" int gsdf_hip_eval3_submit(gsdf_program* p, const void* pos, size_t stride, size_t n_pos, float* dist, size_t n_dist, int* ticket) {
+  if (!ticket) return fail(GSDF_ERR_BAD_ARGUMENT, "null ticket");
+  if (n_pos * stride > kSmallPos || n_pos > kSmallDist) {
+    if (!(pos && dist && reg_device_ptr(pos, n_pos * stride) && reg_device_ptr(dist, n_pos * sizeof(float))))
+      return fail(GSDF_ERR_BAD_ARGUMENT, "submit takes at most 262144 points per call unless both buffers are registered host memory");
+  }
+  return eval_submit(p, 3, pos, stride, n_pos, dist, n_dist, ticket);
+}
+extern "C" int gsdf_hip_eval_wait(gsdf_program* p, int ticket) { return eval_wait(p, ticket); }
 
 extern "C" int gsdf_hip_eval3(gsdf_program* p, const void* pos, size_t stride, size_t n_pos, float* dist, size_t n_dist) {
   return eval_host(p, 3, pos, stride, n_pos, dist, n_dist);

@@ -21,7 +21,7 @@ ErrMismatchBufferLength = "position and distance buffer length mismatch"
 
 # every symbol include/gsdf_hip.h declares
 SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "gsdf_hip_program_destroy",
-           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_lower_region", "gsdf_hip_comm_unique_id", "gsdf_hip_comm_create", "gsdf_hip_comm_rank", "gsdf_hip_comm_world", "gsdf_hip_comm_allreduce_sum_u64", "gsdf_hip_mesh_gatherv", "gsdf_hip_comm_destroy", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_blockcache_create", "gsdf_hip_blockcache_reset", "gsdf_hip_blockcache_eval3", "gsdf_hip_blockcache_hits", "gsdf_hip_blockcache_evaluations", "gsdf_hip_blockcache_destroy", "gsdf_hip_program_specialize", "gsdf_hip_program_is_specialized", "gsdf_hip_program_kernels", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
+           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_lower_region", "gsdf_hip_eval3_submit", "gsdf_hip_eval_wait", "gsdf_hip_host_alloc", "gsdf_hip_host_register", "gsdf_hip_host_release", "gsdf_hip_comm_unique_id", "gsdf_hip_comm_create", "gsdf_hip_comm_rank", "gsdf_hip_comm_world", "gsdf_hip_comm_allreduce_sum_u64", "gsdf_hip_mesh_gatherv", "gsdf_hip_comm_destroy", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_blockcache_create", "gsdf_hip_blockcache_reset", "gsdf_hip_blockcache_eval3", "gsdf_hip_blockcache_hits", "gsdf_hip_blockcache_evaluations", "gsdf_hip_blockcache_destroy", "gsdf_hip_program_specialize", "gsdf_hip_program_is_specialized", "gsdf_hip_program_kernels", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
            "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3", "gsdf_hip_image2",
            "gsdf_hip_mesh_octree", "gsdf_hip_mesh_dualcontour", "gsdf_hip_mesh_flat", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
            "gsdf_hip_mesh_stl", "gsdf_hip_mesh_host_tris", "gsdf_hip_mesh_host_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner", "gsdf_hip_slab_range"]
@@ -71,6 +71,12 @@ def lib():
         L.gsdf_hip_comm_allreduce_sum_u64.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]
         L.gsdf_hip_mesh_gatherv.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.gsdf_hip_comm_destroy.argtypes = [C.c_void_p]
+        L.gsdf_hip_eval3_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
+        L.gsdf_hip_eval_wait.argtypes = [C.c_void_p, C.c_int]
+        L.gsdf_hip_host_alloc.restype = C.c_void_p
+        L.gsdf_hip_host_alloc.argtypes = [C.c_size_t]
+        L.gsdf_hip_host_register.argtypes = [C.c_void_p, C.c_size_t]
+        L.gsdf_hip_host_release.argtypes = [C.c_void_p]
         L.gsdf_hip_selftest_div.argtypes = [C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
         L.gsdf_hip_selftest_sqrt.argtypes = [C.POINTER(C.c_uint64)]
         L.gsdf_hip_blockcache_create.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_void_p)]
@@ -191,9 +197,24 @@ class SDFHIP:
         n = pos.shape[0]
         if dist is None:
             dist = np.empty(n, np.float32)
+        elif not (isinstance(dist, np.ndarray) and dist.dtype == np.float32 and dist.ndim == 1 and dist.flags.c_contiguous and dist.flags.writeable):
+            # the C side writes n float32 values at dist's address: anything else would be silently corrupted
+            raise ValueError("dist must be a writeable, C-contiguous, 1-D float32 array")
         f = lib().gsdf_hip_eval2 if self.is2d else lib().gsdf_hip_eval3
         _check(f(self._h, pos.ctypes.data, pos.strides[0], n, dist.ctypes.data, dist.shape[0]))
         return dist
+
+    def submit(self, pos, dist):
+        """Pipelined Evaluate: returns a ticket at once; wait(ticket) blocks until `dist` holds the distances. pos / dist
+        must stay alive and untouched until then (C-contiguous float32 arrays)."""
+        if pos.dtype != np.float32 or dist.dtype != np.float32 or not pos.flags.c_contiguous or not dist.flags.c_contiguous or dist.ndim != 1:
+            raise ValueError("submit needs C-contiguous float32 arrays (pos (n,3|4), dist (n,))")
+        t = C.c_int(-1)
+        _check(lib().gsdf_hip_eval3_submit(self._h, pos.ctypes.data, pos.strides[0], pos.shape[0], dist.ctypes.data, dist.shape[0], C.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        _check(lib().gsdf_hip_eval_wait(self._h, ticket))
 
     def evaluate_dev(self, d_pos_ptr, stride_bytes, d_dist_ptr, n, stream=None):
         """Device-resident evaluation on raw device pointers (e.g. torch tensors' data_ptr())."""
@@ -212,6 +233,24 @@ class SDFHIP:
         out = np.empty_like(pos)
         _check(lib().gsdf_hip_normals3(self._h, pos.ctypes.data, out.ctypes.data, pos.shape[0], step))
         return out
+
+
+def host_array(shape, dtype=np.float32):
+    """numpy array over pinned, device-mapped host memory (gsdf_hip_host_alloc): Evaluate calls on such arrays make no
+    staging copy -- the kernel reads / writes them across PCIe. Freed when the array (and its views) are collected."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = lib().gsdf_hip_host_alloc(max(n, 1))
+    if not ptr:
+        raise MemoryError("gsdf_hip_host_alloc failed")
+
+    class _Owner:
+        def __init__(self, p): self.p = p
+        def __del__(self):
+            try: lib().gsdf_hip_host_release(self.p)
+            except Exception: pass
+    raw = (C.c_ubyte * max(n, 1)).from_address(ptr)
+    raw._owner = _Owner(ptr)
+    return np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
 SDF3HIP = SDFHIP

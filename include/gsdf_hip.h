@@ -113,6 +113,22 @@ void gsdf_hip_blockcache_destroy(gsdf_blockcache* c);
  * n_pos/n_dist are the two slice lengths (mismatch and zero are reported like the reference does). */
 int gsdf_hip_eval3(gsdf_program* p, const void* pos, size_t pos_stride_bytes, size_t n_pos, float* dist, size_t n_dist);
 int gsdf_hip_eval2(gsdf_program* p, const void* pos, size_t pos_stride_bytes, size_t n_pos, float* dist, size_t n_dist);
+/* Thread safety of the host-buffer calls: gsdf_hip_eval3 / _eval2 may be called from several host threads on one program at
+ * the same time (glrender.FlatRenderer evaluates from numParallel goroutines, flatrenderer.go:120-129): up to 4 calls are
+ * in flight on their own streams and staging buffers, further callers wait for a slot. Everything else on a handle is one
+ * caller at a time.
+ * Pipelined form: submit returns at once with a ticket, wait blocks until that call's distances are in `dist` (batches of
+ * up to 262144 points, any size in registered memory; at most 4 tickets outstanding per program). */
+int gsdf_hip_eval3_submit(gsdf_program* p, const void* pos, size_t pos_stride_bytes, size_t n_pos, float* dist, size_t n_dist, int* ticket);
+int gsdf_hip_eval_wait(gsdf_program* p, int ticket);
+/* Caller buffers the GPU reaches directly. A host-buffer call whose positions AND distances lie inside memory from
+ * gsdf_hip_host_alloc (pinned, device-mapped; C memory, so a Go caller may wrap it in a slice and keep it) or registered
+ * with gsdf_hip_host_register (pins and maps memory the caller allocated and keeps alive, e.g. the renderer's long-lived
+ * posbuf/distbuf) makes no staging copy: the kernel reads and writes the caller's memory across PCIe.
+ * gsdf_hip_host_release frees / unregisters. */
+void* gsdf_hip_host_alloc(size_t bytes);
+int gsdf_hip_host_register(void* ptr, size_t bytes);
+int gsdf_hip_host_release(void* ptr);
 /* Device-resident evaluation: d_pos/d_dist are device pointers on the program's GPU; stream is a
  * hipStream_t (NULL = the program's own stream). Asynchronous when stream != NULL. */
 int gsdf_hip_eval3_dev(gsdf_program* p, const void* d_pos, size_t pos_stride_bytes, float* d_dist, size_t n, void* stream);

@@ -268,3 +268,77 @@ def test_host_buffer_paths_agree_across_the_small_call_threshold(gpu):
         idx = np.unique(np.concatenate([np.arange(0, n, step), [0, n - 1]]))
         dr = ref.Evaluate(np.ascontiguousarray(pos[idx, :3]))
         assert (d[idx].view(np.uint32) == dr.view(np.uint32)).all(), (n, width)
+
+
+def test_registered_buffers_pipelined_and_concurrent_host_calls(gpu):
+    """The host-buffer drop-in beyond one blocking call: caller buffers the GPU reaches directly (gsdf_hip_host_alloc: no
+    staging copy), the submit / wait pair with several batches in flight, and concurrent callers on one program -- what
+    glrender.FlatRenderer's goroutines do to an evaluator (flatrenderer.go:120-129). Same bits on every path; the
+    evaluation counter adds up."""
+    import threading
+    b = Builder()
+    s = b.Scene("npt-flange")
+    ref = OracleSDF(s.tree())
+    bb = s.Bounds()
+    rng = np.random.default_rng(9)
+    for spec in (False, True):
+        sdf = gpu.SDF3HIP(s)
+        if spec:
+            sdf.specialize()
+        total = 0
+        for n in (1, 257, 4096, 32768, 300001):                        # the last one is beyond the staging slots' size
+            src = (bb[:3] + rng.random((n, 3), np.float32) * (bb[3:] - bb[:3])).astype(np.float32)
+            want = ref.Evaluate(src)
+            ppos, pdist = gpu.host_array((n, 3)), gpu.host_array((n,))
+            ppos[:] = src
+            pdist[:] = np.nan
+            sdf.Evaluate(ppos, pdist)                                  # zero copy: the kernel reads / writes these arrays
+            assert _mismatch(np.asarray(pdist), want) == 0 and (np.asarray(ppos) == src).all(), n
+            total += n
+            mixed = np.full(n, np.nan, np.float32)                     # registered positions, pageable distances: staged
+            sdf.Evaluate(ppos, mixed)
+            assert _mismatch(mixed, want) == 0
+            total += n
+        # pipelined: four batches in flight, waited in another order than submitted
+        n = 20000
+        batches = []
+        for k in range(4):
+            src = (bb[:3] + rng.random((n, 3), np.float32) * (bb[3:] - bb[:3])).astype(np.float32)
+            batches.append((src, np.full(n, np.nan, np.float32), ref.Evaluate(src)))
+        tickets = [sdf.submit(p_, d_) for p_, d_, _ in batches]
+        assert sorted(tickets) == [0, 1, 2, 3]
+        for k in (2, 0, 3, 1):
+            sdf.wait(tickets[k])
+            assert _mismatch(batches[k][1], batches[k][2]) == 0
+        total += 4 * n
+        with pytest.raises(gpu.HipError):
+            sdf.wait(tickets[0])                                       # already waited for
+        with pytest.raises(gpu.HipError):
+            sdf.submit(np.zeros((1 << 19, 3), np.float32), np.zeros(1 << 19, np.float32))   # too large for a staging slot
+        # concurrent callers
+        errs = []
+
+        done = []
+
+        def worker2(seed):
+            r = np.random.default_rng(seed)
+            tot = 0
+            myref = OracleSDF(s.tree())                                # the oracle's evaluator is not shared between threads
+            for _ in range(25):
+                m = int(r.integers(1, 40000))
+                p_ = (bb[:3] + r.random((m, 3), np.float32) * (bb[3:] - bb[:3])).astype(np.float32)
+                if _mismatch(sdf.Evaluate(p_), myref.Evaluate(p_)):
+                    errs.append(seed)
+                tot += m
+            done.append(tot)
+
+        th = [threading.Thread(target=worker2, args=(100 + k,)) for k in range(6)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs and len(done) == 6
+        total += sum(done)
+        assert sdf.Evaluations() == total
+    with pytest.raises(ValueError):
+        gpu.SDF3HIP(b.NewSphere(1)).Evaluate(np.zeros((4, 3), np.float32), np.zeros(4, np.float64))   # wrong dist dtype: refused

@@ -1,10 +1,11 @@
 #!/bin/bash
-# latency of the host-buffer Evaluate drop-in for reference-sized batches
+# The host-buffer Evaluate drop-in (gsdf_hip_eval3) at the reference's batch sizes: latency of one blocking call, the
+# same in registered (pinned, device-mapped) caller buffers, pipelined submit/wait, and concurrent callers.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-for mode in default; do
-GSDF_HIP_SMALL_MODE=$mode timeout 300 python - <<'PY'
-import os, time
+timeout 600 python - <<'PY'
+import threading, time
 import numpy as np
+import torch  # noqa: F401  (load order of the GPU box's processes)
 from gsdf_amd.builder import Builder
 from gsdf_amd import hip
 from oracle.oracle import OracleSDF
@@ -13,18 +14,52 @@ b = Builder()
 s = b.Scene("npt-flange")
 sdf = hip.SDF3HIP(s)
 sdf.specialize()
+ref = OracleSDF(s.tree())
 rng = np.random.default_rng(0)
 bb = s.Bounds()
+REPS = 400
 for n in (4096, 32768, 65536):
-    pos = (bb[:3] + rng.random((n, 3), np.float32) * (bb[3:] - bb[:3])).astype(np.float32)
-    dist = np.empty(n, np.float32)
-    for _ in range(50):
-        sdf.Evaluate(pos, dist)
+    src = (bb[:3] + rng.random((n, 3), np.float32) * (bb[3:] - bb[:3])).astype(np.float32)
+    want = ref.Evaluate(src)
+    def bench(label, fn, calls=REPS, pts=n):
+        for _ in range(30): fn()
+        t0 = time.perf_counter()
+        for _ in range(calls): fn()
+        dt = (time.perf_counter() - t0) / calls
+        print(f"n {n:6d} {label:34s} {dt * 1e6:7.1f} us per call  {pts / dt / 1e9:6.3f} G evals/s", flush=True)
+    # 1. one blocking call, pageable caller buffers (staging copy in and out)
+    pos, dist = src.copy(), np.empty(n, np.float32)
+    bench("blocking, pageable buffers", lambda: sdf.Evaluate(pos, dist))
+    assert (dist.view(np.uint32) == want.view(np.uint32)).all()
+    # 2. the same in registered caller buffers (zero copy)
+    ppos, pdist = hip.host_array((n, 3)), hip.host_array((n,))
+    ppos[:] = src
+    bench("blocking, registered buffers", lambda: sdf.Evaluate(ppos, pdist))
+    assert (pdist.view(np.uint32) == want.view(np.uint32)).all()
+    # 3. pipelined: two batches in flight (submit next, then wait previous), pageable and registered
+    for label, mk in (("pipelined x2, pageable", lambda: (src.copy(), np.empty(n, np.float32))), ("pipelined x2, registered", lambda: (hip.host_array((n, 3)), hip.host_array((n,))))):
+        bufs = [mk() for _ in range(2)]
+        for p_, _ in bufs: p_[:] = src
+        state = {"t": [None, None], "k": 0}
+        def step():
+            k = state["k"]; state["k"] ^= 1
+            if state["t"][k] is not None: sdf.wait(state["t"][k])
+            state["t"][k] = sdf.submit(bufs[k][0], bufs[k][1])
+        bench(label, step)
+        for k in range(2):
+            if state["t"][k] is not None: sdf.wait(state["t"][k]); state["t"][k] = None
+        assert all((d.view(np.uint32) == want.view(np.uint32)).all() for _, d in bufs)
+    # 4. concurrent callers (FlatRenderer's goroutines): 4 threads, each blocking calls on its own buffers
+    def worker(res, k):
+        p_, d_ = src.copy(), np.empty(n, np.float32)
+        for _ in range(REPS): sdf.Evaluate(p_, d_)
+        res[k] = bool((d_.view(np.uint32) == want.view(np.uint32)).all())
+    res = [None] * 4
+    th = [threading.Thread(target=worker, args=(res, k)) for k in range(4)]
     t0 = time.perf_counter()
-    for _ in range(400):
-        sdf.Evaluate(pos, dist)
-    dt = (time.perf_counter() - t0) / 400
-    ok = (dist.view(np.uint32) == OracleSDF(s.tree()).Evaluate(pos).view(np.uint32)).all() if n == 4096 else True
-    print(f"mode {os.environ['GSDF_HIP_SMALL_MODE']} n {n}: {dt * 1e6:.1f} us per call, {n / dt / 1e9:.3f} G evals/s, exact {bool(ok)}")
+    for t in th: t.start()
+    for t in th: t.join()
+    dt = time.perf_counter() - t0
+    print(f"n {n:6d} {'4 threads, blocking, pageable':34s} {dt / (4 * REPS) * 1e6:7.1f} us per call  {4 * REPS * n / dt / 1e9:6.3f} G evals/s  exact {all(res)}", flush=True)
+print("Evaluations()", sdf.Evaluations())
 PY
-done
