@@ -76,6 +76,9 @@ struct Ctx {
       default: dep[0] = dep[1] = dep[2] = 7; break;
     }
   }
+  // Context handed from a (smooth) difference to its MINUEND when the subtrahend c was evaluated first: values of the
+  // minuend that are <= -c - ok (and negative) are discarded by that difference, see D_GATE* in dev_ops.h.
+  struct Outer { bool valid = false; int slot = 0; float ok = 0.f; } outer;
   struct Saved { int slot; bool is2d; };
   std::vector<Saved> live;
   int find_saved(bool is2d) const {
@@ -153,7 +156,7 @@ void gen(Ctx& c, uint32_t i, int depth);
 // ---------------------------------------------------------------------------------------------------------------------
 // Lower-bound regions. For a subtree S, lower_region() answers with a region G such that, for every point p OUTSIDE G,
 //   S(p) >= LB_G(p) > 0,        LB_BOX(p)  = max over axes of (mn - p, p - mx)              (Chebyshev distance)
-//                               LB_ZCYL(p) = max(z0 - z, z - z1, rs * (hypot(x - cx, y - cy) - r))
+//                               LB_ZCYL(p) = max(z0 - z, z - z1, rs * (rho - r), rs * (rin - rho)), rho = hypot(x - cx, y - cy)
 // (the device uses a cheaper lower estimate of the hypot, see region_lb in interp.h). Both are lower bounds of the
 // Euclidean distance to G, which in turn bounds exact-distance fields from below; the screw and the smooth combines
 // are not exact, their rules are derived one by one below. The claim is about values > 0 only: inside G nothing is said.
@@ -165,7 +168,9 @@ void gen(Ctx& c, uint32_t i, int depth);
 // ---------------------------------------------------------------------------------------------------------------------
 struct Region {
   enum Kind { NONE = 0, BOX = 1, ZCYL = 2 } kind = NONE;
-  float b[6] = {0, 0, 0, 0, 0, 0};  // BOX: min xyz, max xyz (2-D: z = 0) | ZCYL: cx cy r z0 z1 rs
+  float b[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // BOX: min xyz, max xyz (2-D: z = 0) | ZCYL: cx cy r z0 z1 rs rin
+  // ZCYL's rin (0: solid): additionally S(p) >= rs * (rin - rho) for rho < rin at ANY z -- the shape keeps at least rin away
+  // from the axis (an annulus: boxes on a circle around the axis; lets a gate fire for points near the axis)
 };
 
 // The z-axis cylinder (about the axis through (cx, cy)) that encloses a region: what survives a rotation about z.
@@ -181,10 +186,16 @@ Region enclose_zcyl(const Region& g, float cx, float cy, bool is2d) {
     }
     o.b[2] = (float)(r * (1 + 1e-6) + 1e-30);
     o.b[3] = is2d ? -3.0e38f : g.b[2]; o.b[4] = is2d ? 3.0e38f : g.b[5]; o.b[5] = 1.0f;
+    // nearest point of the box's xy rectangle to the axis (0 if the axis passes through it)
+    const double nx = std::fmax(std::fmax((double)g.b[0] - cx, (double)cx - g.b[3]), 0.0), ny = std::fmax(std::fmax((double)g.b[1] - cy, (double)cy - g.b[4]), 0.0);
+    o.b[6] = (float)std::fmax(0.0, std::sqrt(nx * nx + ny * ny) * (1 - 1e-6) - 1e-30);
   } else {
-    const double dx = (double)g.b[0] - cx, dy = (double)g.b[1] - cy;
-    o.b[2] = (float)((std::sqrt(dx * dx + dy * dy) + (double)g.b[2]) * (1 + 1e-6) + 1e-30);
+    const double dx = (double)g.b[0] - cx, dy = (double)g.b[1] - cy, dc = std::sqrt(dx * dx + dy * dy);
+    o.b[2] = (float)((dc + (double)g.b[2]) * (1 + 1e-6) + 1e-30);
     o.b[3] = g.b[3]; o.b[4] = g.b[4]; o.b[5] = g.b[5];
+    // the other axis lies outside that cylinder by dc - r, or inside its hole by rin - dc; the inner claim carries rs
+    o.b[6] = (float)std::fmax(0.0, std::fmax(dc - (double)g.b[2], (double)g.b[6] - dc) * (1 - 1e-6) - 1e-30);
+    if (dc == 0.0) o.b[6] = g.b[6];
   }
   return o;
 }
@@ -205,6 +216,7 @@ bool hull(const Region& a, const Region& b, bool is2d, Region& o) {
   o.b[2] = std::fmax(ea.b[2], eb.b[2]);
   o.b[3] = std::fmin(ea.b[3], eb.b[3]); o.b[4] = std::fmax(ea.b[4], eb.b[4]);
   o.b[5] = std::fmin(ea.b[5], eb.b[5]);
+  o.b[6] = std::fmin(ea.b[6], eb.b[6]);
   return true;
 }
 
@@ -215,6 +227,7 @@ void inflate(Region& g, float d, bool is2d) {
   } else if (g.kind == Region::ZCYL) {
     g.b[2] += d / g.b[5];
     g.b[3] -= d; g.b[4] += d;
+    g.b[6] = std::fmax(0.f, g.b[6] - d / g.b[5]);
   }
 }
 
@@ -262,6 +275,7 @@ bool lower_region(Ctx& c, uint32_t i, Region& out, int depth = 0, bool* solid = 
     case GSDF_SCALE: case GSDF_SCALE2D: {  // f(p) = s * g(p / s): LB_f(p) = s * LB_g(p / s) = LB of the scaled region
       if (n.nchild != 1 || !(P[0] > 0) || !child_region(0, out)) return false;
       for (int j = 0; j < (out.kind == Region::BOX ? 6 : 5); j++) out.b[j] *= P[0];
+      if (out.kind == Region::ZCYL) out.b[6] *= P[0];
       return true;
     }
     case GSDF_TRANSFORM: case GSDF_ROTATION2D: {  // rigid motions only: p_local = A p + b with A orthonormal
@@ -292,6 +306,7 @@ bool lower_region(Ctx& c, uint32_t i, Region& out, int depth = 0, bool* solid = 
         double ext = std::fabs((double)out.b[0]) + std::fabs((double)out.b[1]) + std::fabs((double)lr.b[2]) + std::fabs((double)lr.b[3]) + std::fabs((double)lr.b[4]) + std::fabs((double)b[2]);
         const float pad = (float)(ext * 4e-5 + 1e-30);
         out.b[2] += pad; out.b[3] = lr.b[3] - b[2] - pad; out.b[4] = lr.b[4] - b[2] + pad;
+        out.b[6] = std::fmax(0.f, lr.b[6] - pad);
         return true;
       }
       const float* lb = lr.b;
@@ -374,6 +389,7 @@ bool lower_region(Ctx& c, uint32_t i, Region& out, int depth = 0, bool* solid = 
       out.b[2] = (float)(((double)g.b[4] + (double)P[2] * t) * (1 + 1e-6) + 1e-30);
       out.b[3] = -P[2]; out.b[4] = P[2];
       out.b[5] = (float)((1.0 - 1e-6) / (1.0 + t));
+      out.b[6] = 0.f;
       return out.b[2] > 0;
     }
     // rotations about z that depend on the point (twist: by k z; circular array: by a multiple of the sector angle, two
@@ -413,7 +429,7 @@ bool lower_region(Ctx& c, uint32_t i, Region& out, int depth = 0, bool* solid = 
 bool exact_box(Ctx& c, uint32_t i, float bb[6], bool* solid = nullptr) {
   Region g;
   if (!lower_region(c, i, g, 0, solid) || g.kind != Region::BOX) return false;
-  std::memcpy(bb, g.b, sizeof g.b);
+  std::memcpy(bb, g.b, 6 * sizeof(float));
   return true;
 }
 
@@ -456,6 +472,8 @@ constexpr double kGateMinCost = 80.0;  // cheaper children are evaluated rather 
 // value itself: no gate. Children worth a gate (cost >= kGateMinCost, region known) are evaluated last, cheapest first.
 void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int depth) {
   bool is2d = gsdf_op_is2d(n.op);
+  const Ctx::Outer outer = c.outer;  // meant for this frame only (set by the enclosing difference right before gen())
+  c.outer.valid = false;
   const bool asym = comb == D_COMBINE_DIFF || comb == D_COMBINE_SUNION || comb == D_COMBINE_SDIFF || comb == D_COMBINE_SINTER;
   if (n.nchild != 2 && asym) throw std::runtime_error("asymmetric combine needs exactly 2 children");
   // which children could be gated if evaluated after another one
@@ -541,15 +559,27 @@ void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int dept
         // hypot(P.x, P.y) already in the register (and the cylinder about the origin): the exact radius instead of the estimate
         const bool centred = g.b[0] == 0.f && g.b[1] == 0.f;
         c.op(D_GATEZC | ((centred && c.hxyver == c.xyver) ? D_FLAG_HXY : 0u), slotD);
-        for (int j = 0; j < 6; j++) c.f(g.b[j]);
+        for (int j = 0; j < 7; j++) c.f(g.b[j]);
       }
       c.f(minus ? -1.0f : 1.0f);
       c.f(kk);
+      // context of the enclosing difference: this frame is its minuend and B its own subtrahend (unswapped)
+      const bool ctx = outer.valid && minus && !swapped && ck == 1;
+      c.u(ctx ? (uint32_t)outer.slot : 0xffffu);
+      c.f(ctx ? outer.ok : 0.0f);
+      c.f(ctx && comb == D_COMBINE_SDIFF ? 0.25f * n.p[0] * 1.0001f : 0.0f);
       skip_at = (long)c.code.size();
       c.u(0);  // patched below: words from this instruction to the child's combine instruction
     }
     const uint32_t hxy_before = c.hxyver;
+    // a (smooth) difference whose subtrahend is already in slotD hands its minuend the context (k == 1: evaluated second)
+    if ((comb == D_COMBINE_DIFF || (comb == D_COMBINE_SDIFF && n.p[0] > 0)) && swapped && k == 1 && slotD >= 0) {
+      c.outer.valid = true;
+      c.outer.slot = slotD;
+      c.outer.ok = comb == D_COMBINE_SDIFF ? 1.002f * n.p[0] : 0.0f;
+    }
     gen(c, ch, depth + 1);
+    c.outer.valid = false;
     // a child that may be skipped at run time may not have refreshed the hypot(x,y) register: forget what it cached
     if (skip_at >= 0 && c.hxyver != hxy_before) c.hxyver = 0;
     dirty = dirty || clobbers(c, ch);
@@ -567,6 +597,9 @@ void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int dept
 void gen(Ctx& c, uint32_t i, int depth) {
   if (depth > 256) throw std::runtime_error("tree too deep (cycle?)");
   const gsdf_node& n = c.node(i);
+  // the enclosing difference's context is about THIS node's value: only a difference consumes it (gen_combine); any
+  // other node between the two (a scale multiplies the value, an offset shifts it ...) ends it
+  if (n.op != GSDF_DIFF && n.op != GSDF_SMOOTH_DIFF && n.op != GSDF_DIFF2D) c.outer.valid = false;
   const float* P = n.p;
   auto need_children = [&](uint32_t k) { if (n.nchild != k) throw std::runtime_error("bad child count for op " + std::to_string(n.op)); };
   auto child_dim = [&](bool want2d) {
@@ -875,7 +908,7 @@ static void validate(const gsdf_tree& t) {
   }
 }
 
-int region_of(const gsdf_tree& t, uint32_t node, float params[6]) {
+int region_of(const gsdf_tree& t, uint32_t node, float params[8]) {
   validate(t);
   if (node >= t.n_nodes) throw std::runtime_error("node out of range");
   Ctx c;
@@ -884,7 +917,7 @@ int region_of(const gsdf_tree& t, uint32_t node, float params[6]) {
   c.clob.assign(t.n_nodes, -1);
   Region g;
   if (!lower_region(c, node, g)) return 0;
-  std::memcpy(params, g.b, sizeof g.b);
+  std::memcpy(params, g.b, sizeof g.b);  // 8 floats
   return (int)g.kind;
 }
 

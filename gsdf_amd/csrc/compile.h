@@ -24,8 +24,8 @@ struct Program {
 float recip_for(float d);
 
 // Lower-bound region of node `node`'s subtree (compile.cpp: lower_region), for tests: kind 0 = no claim, 1 = box
-// {min xyz, max xyz}, 2 = z-cylinder {cx cy r z0 z1 rs}. Throws on malformed trees.
-int region_of(const gsdf_tree& t, uint32_t node, float params[6]);
+// {min xyz, max xyz}, 2 = z-cylinder {cx cy r z0 z1 rs rin}. Throws on malformed trees.
+int region_of(const gsdf_tree& t, uint32_t node, float params[8]);
 
 // Throws std::runtime_error on malformed trees. max_code_words bounds unrolling blow-up.
 Program compile(const gsdf_tree& t, size_t max_code_words = (1u << 22));

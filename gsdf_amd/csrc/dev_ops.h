@@ -90,15 +90,23 @@ enum DevOp : uint32_t {
   // ---- gates: skip a child that provably cannot influence its parent's combine for ANY point of the wave.
   //      a = lds[slot] is the value of the children evaluated so far; the child's field is bounded from below, outside
   //      the child's region, by L(p) (compile.cpp: lower_region; box: Chebyshev distance, z-cylinder: max(z excess,
-  //      rs * radial excess)). If for every point of the wave L > 0 and L > sg * a + kk + margin (sg = +1: union and
+  //      rs * radial excess, rs * (rin - rho))). If for every point of the wave L > 0 and L > sg * a + kk + margin (sg = +1: union and
   //      smooth union, -1: difference and smooth difference; kk = 1.002 k for the smooth combines, else 0; margin =
   //      1e-3 (L + |a|) + 2e-6 (|x| + |y| + |z|), a thousand times the rounding of either side), the child's value b >= L
   //      leaves the combine's result unchanged bit for bit (see gen_combine): R = L and the program counter advances
   //      by `skip` words to the child's combine instruction, which runs on (a, L). Wave-uniform forward branch -- the one
   //      non-straight-line instruction of the stream.
-  D_GATE2D,  // minx miny maxx maxy sg kk skip
-  D_GATE3D,  // minx miny minz maxx maxy maxz sg kk skip
-  D_GATEZC,  // cx cy r z0 z1 rs sg kk skip     (D_FLAG_HXY: cx = cy = 0 and hypot(P.x,P.y) is in the register)
+  //      Context of ONE enclosing combine (oslot != 0xffff; differences only): the gated child b is the subtrahend of
+  //      X = (smooth) max(a, -b), and X is itself the minuend of an enclosing (smooth) difference max(X, -c) whose other
+  //      operand c was evaluated first and sits in lds[oslot]. With U = max(a, -L) + k4 >= X (k4 = a quarter of the inner
+  //      blend width, 0 for a plain difference): if U < 0 and c + U <= -ok - margin (ok = 1.002 x the outer blend width, 0
+  //      for a plain difference), the enclosing combine yields -c whatever X is (its weight clamps; X only enters times 0,
+  //      and substitute and true value are both negative) -- b is skipped although it does change X. A lane passes if
+  //      either test holds. Example: a body with cutters, then a through hole (knurled-cylinder): at the hole's wall the
+  //      cutters change the body's field but the hole discards it.
+  D_GATE2D,  // minx miny maxx maxy sg kk oslot ok k4 skip
+  D_GATE3D,  // minx miny minz maxx maxy maxz sg kk oslot ok k4 skip
+  D_GATEZC,  // cx cy r z0 z1 rs rin sg kk oslot ok k4 skip (D_FLAG_HXY: cx = cy = 0 and hypot(P.x,P.y) is in the register)
   //      D_UBOUND* opens a wide union: lds[slot] <- (1 + 1e-3) * min over the listed boxes of the distance to the box's
   //      FARTHEST corner -- an upper bound of that child's field (the shape lies inside its box), hence of the union.
   //      Starting the running minimum there lets the gates drop far children from the first one on; the bound never
@@ -120,5 +128,5 @@ static const uint8_t kDevOpParams[D_OP_COUNT] = {
     /*MULR*/ 1, /*SHELL_POST*/ 1, /*ADDR*/ 1, /*ANNULUS*/ 1, /*EXTRUDE_POST*/ 0, /*MAXR_SLOT*/ 0, /*ADDR_SLOT*/ 0,
     /*SAVEP3*/ 0, /*LOADP3*/ 0, /*SAVEP2*/ 0, /*LOADP2*/ 0, /*SAVER*/ 0, /*SETSLOT*/ 1, /*SETR*/ 1,
     /*MIN*/ 0, /*MAX*/ 0, /*DIFF*/ 0, /*XOR*/ 0, /*SUNION*/ 2, /*SDIFF*/ 2, /*SINTER*/ 2,
-    /*GATE2D*/ 7, /*GATE3D*/ 9, /*GATEZC*/ 9, /*UBOUND2D*/ 1, /*UBOUND3D*/ 1,
+    /*GATE2D*/ 10, /*GATE3D*/ 12, /*GATEZC*/ 13, /*UBOUND2D*/ 1, /*UBOUND3D*/ 1,
 };

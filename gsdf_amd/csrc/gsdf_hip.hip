@@ -569,7 +569,7 @@ extern "C" int gsdf_hip_lower(const gsdf_tree* tree, uint32_t* code_out, uint32_
 }
 
 // Host-only test hook: the lower-bound region the compiler claims for the subtree of `node` (0 none, 1 box, 2 z-cylinder).
-extern "C" int gsdf_hip_lower_region(const gsdf_tree* tree, uint32_t node, int* kind, float params[6]) {
+extern "C" int gsdf_hip_lower_region(const gsdf_tree* tree, uint32_t node, int* kind, float params[8]) {
   if (!tree || !kind || !params) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
   try {
     *kind = gsdf_dev::region_of(*tree, node, params);

@@ -206,6 +206,7 @@ __device__ __forceinline__ void xy_shared(const P3 (&pv)[K], float (&out)[K], bo
 //   z-cylinder : max(z0 - z, z - z1, rs * (rad - r)), rad <= hypot(x - cx, y - cy): the cached hypot when the host says it
 //                is valid, else the octagon estimate max(|x|, |y|, (|x| + |y|) / sqrt 2) >= 0.92 hypot, with the constant
 //                rounded down so that float rounding cannot lift it above the true radius.
+//                an annulus (rin > 0) also bounds points near the axis: rs * (rin - rad'), rad' >= hypot (max + 0.4142 min).
 // Inside the region L <= 0: no claim, the gate stays shut.
 template <int K, int DIM>
 __device__ __forceinline__ void region_lb_box(const P3 (&pv)[K], float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
@@ -219,28 +220,42 @@ __device__ __forceinline__ void region_lb_box(const P3 (&pv)[K], float mnx, floa
 }
 template <int K>
 __device__ __forceinline__ void region_lb_zcyl(const P3 (&pv)[K], const float (&hxy)[K], bool use_hxy, float cx, float cy, float r,
-                                               float z0, float z1, float rs, float (&L)[K]) {
+                                               float z0, float z1, float rs, float rin, float (&L)[K]) {
   using namespace dm;
   KLOOP {
-    float rad;
+    float rlo, rhi;  // rlo <= rho <= rhi
     if (use_hxy) {
-      rad = hxy[kp];
+      rlo = hxy[kp] * 0.999999f; rhi = hxy[kp] * 1.000001f;
     } else {
       const float ax = absf(pv[kp].x - cx), ay = absf(pv[kp].y - cy);
-      rad = maxf(maxf(ax, ay), 0.70710605f * (ax + ay));
+      const float mx = maxf(ax, ay), mn = minf(ax, ay);
+      rlo = maxf(mx, 0.70710605f * (ax + ay));  // octagon inside the circle
+      rhi = (mx + 0.41421402f * mn) * 1.000001f;  // max + (sqrt2 - 1) min >= hypot (octagon around it), constants rounded up
     }
-    L[kp] = maxf(maxf(z0 - pv[kp].z, pv[kp].z - z1), rs * (rad - r));
+    float l = maxf(maxf(z0 - pv[kp].z, pv[kp].z - z1), rs * (rlo - r));
+    if (rin > 0.0f) l = maxf(l, rs * (rin - rhi));  // wave-uniform test
+    L[kp] = l;
   }
 }
-// The gate's verdict: true (wave-uniform) if EVERY point of the wave has L > 0 and L > sg * a + kk by the margin.
+// The gate's verdict: true (wave-uniform) if EVERY point of the wave passes: L > 0 and L > sg * a + kk by the margin (the
+// child cannot change its own combine), or -- with the context of the enclosing difference, c = its other operand -- the
+// upper bound U = max(a, -L) + k4 of the inner result is negative and c + U <= -ok by the margin (the enclosing combine
+// discards the inner result).
 template <int K, int DIM>
-__device__ __forceinline__ bool gate_far(const P3 (&pv)[K], const float (&a)[K], const float (&L)[K], float sg, float kk) {
+__device__ __forceinline__ bool gate_far(const P3 (&pv)[K], const float (&a)[K], const float (&L)[K], float sg, float kk,
+                                         const float (&c)[K], bool has_outer, float ok, float k4) {
   using namespace dm;
   bool far = true;
   KLOOP {
     float S = absf(pv[kp].x) + absf(pv[kp].y);
     if (DIM == 3) S += absf(pv[kp].z);
-    far = far && (L[kp] > 0.0f) && (L[kp] > sg * a[kp] + kk + (1e-3f * (L[kp] + absf(a[kp])) + 2e-6f * S));
+    const float pad = 2e-6f * S;
+    bool good = (L[kp] > 0.0f) && (L[kp] > sg * a[kp] + kk + (1e-3f * (L[kp] + absf(a[kp])) + pad));
+    if (has_outer) {
+      const float U = maxf(a[kp], -L[kp]) + k4;
+      good = good || ((U < 0.0f) && (c[kp] + U <= -ok - (1e-3f * (absf(c[kp]) + absf(U)) + pad)));
+    }
+    far = far && good;
   }
   return __all(far) != 0;
 }
@@ -1037,38 +1052,44 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       case D_GATE2D: {
-        float a[K], L[K];
-        KLOOP a[kp] = LDSF(slot);
+        float a[K], L[K], cc[K];
+        const uint32_t oslot = PU(6);
+        const bool has_outer = oslot != 0xffffu;  // wave-uniform
+        KLOOP { a[kp] = LDSF(slot); cc[kp] = has_outer ? LDSF(oslot) : 0.0f; }
         region_lb_box<K, 2>(pv, PF(0), PF(1), 0.f, PF(2), PF(3), 0.f, L);
-        if (gate_far<K, 2>(pv, a, L, PF(4), PF(5))) {
+        if (gate_far<K, 2>(pv, a, L, PF(4), PF(5), cc, has_outer, PF(7), PF(8))) {
           KLOOP Rv[kp] = L[kp];
-          pc += PU(6);
+          pc += PU(9);
         } else {
-          pc += 8;
+          pc += 11;
         }
         break;
       }
       case D_GATE3D: {
-        float a[K], L[K];
-        KLOOP a[kp] = LDSF(slot);
+        float a[K], L[K], cc[K];
+        const uint32_t oslot = PU(8);
+        const bool has_outer = oslot != 0xffffu;
+        KLOOP { a[kp] = LDSF(slot); cc[kp] = has_outer ? LDSF(oslot) : 0.0f; }
         region_lb_box<K, 3>(pv, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5), L);
-        if (gate_far<K, 3>(pv, a, L, PF(6), PF(7))) {
+        if (gate_far<K, 3>(pv, a, L, PF(6), PF(7), cc, has_outer, PF(9), PF(10))) {
           KLOOP Rv[kp] = L[kp];
-          pc += PU(8);
+          pc += PU(11);
         } else {
-          pc += 10;
+          pc += 13;
         }
         break;
       }
       case D_GATEZC: {
-        float a[K], L[K];
-        KLOOP a[kp] = LDSF(slot);
-        region_lb_zcyl<K>(pv, hxy, use_hxy, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5), L);
-        if (gate_far<K, 3>(pv, a, L, PF(6), PF(7))) {
+        float a[K], L[K], cc[K];
+        const uint32_t oslot = PU(9);
+        const bool has_outer = oslot != 0xffffu;
+        KLOOP { a[kp] = LDSF(slot); cc[kp] = has_outer ? LDSF(oslot) : 0.0f; }
+        region_lb_zcyl<K>(pv, hxy, use_hxy, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5), PF(6), L);
+        if (gate_far<K, 3>(pv, a, L, PF(7), PF(8), cc, has_outer, PF(10), PF(11))) {
           KLOOP Rv[kp] = L[kp];
-          pc += PU(8);
+          pc += PU(12);
         } else {
-          pc += 10;
+          pc += 14;
         }
         break;
       }

@@ -94,8 +94,9 @@ int gsdf_hip_specialize_check(const gsdf_tree* tree, size_t* code_object_bytes);
 int gsdf_hip_lower(const gsdf_tree* tree, uint32_t* code_out, uint32_t code_cap, uint32_t* code_words, uint32_t* lds_slots);
 /* Host-only test hook: the region outside which the lowering claims a positive lower bound of the subtree rooted at
  * `node` (what its skip gates test): *kind 0 = no claim, 1 = box {min xyz, max xyz}, 2 = z-axis cylinder {cx cy r z0 z1
- * rs}; tests check the claim against the CPU oracle (tests/test_gate_regions.py). */
-int gsdf_hip_lower_region(const gsdf_tree* tree, uint32_t node, int* kind, float params[6]);
+ * rs rin} (rin > 0: an annulus -- the shape also keeps rin away from the axis); tests check the claim against the CPU
+ * oracle (tests/test_gate_regions.py). */
+int gsdf_hip_lower_region(const gsdf_tree* tree, uint32_t node, int* kind, float params[8]);
 
 /* gleval.BlockCachedSDF3 (gleval/gleval.go:110-218): host-side lossy cache in front of a 3-D program, keyed by the
  * lattice cell int(mul*(p - bb.Min)), mul = 1/res per axis; misses go to the program in one batch. reset = Reset

@@ -63,8 +63,15 @@ def _shape3(b, r, depth):
     if depth <= 0 or r.random() < 0.1:
         return _prim3(b, r)
     u = lambda lo, hi: float(r.uniform(lo, hi))
-    k = r.integers(0, 18)
+    k = r.integers(0, 20)
     a = _shape3(b, r, depth - 1)
+    if k >= 18:   # a body with a cutter, then a cheap through hole: the cutter's gate gets the enclosing difference's context
+        cut = b.Translate(_shape3(b, r, depth - 1), u(0.3, 0.9), u(-0.3, 0.3), u(-0.3, 0.3))
+        hole = b.NewCylinder(u(0.1, 0.4), 6.0, 0.0) if r.random() < 0.6 else b.NewSphere(u(0.2, 0.5))
+        if k == 18:
+            kk = u(0.05, 0.3)
+            return b.SmoothDifference(kk, b.SmoothDifference(u(0.05, 0.3), a, cut), hole)
+        return b.Difference(b.Difference(a, cut), hole)
     if k >= 16:                                                                  # wide union: exercises the far-child skip
         parts = [a] + [b.Translate(_shape3(b, r, max(0, depth - 2)), u(-4, 4), u(-4, 4), u(-2, 2)) for _ in range(int(r.integers(3, 6)))]
         return b.Union(*parts)

@@ -41,7 +41,7 @@ def _subtree(t, node):
 
 
 def _region(t, node):
-    kind, par = C.c_int(), (C.c_float * 6)()
+    kind, par = C.c_int(), (C.c_float * 8)()
     assert hip.lib().gsdf_hip_lower_region(C.byref(t), node, C.byref(kind), par) == 0, hip.lib().gsdf_hip_last_error()
     return kind.value, np.array(par[:], np.float64)
 
@@ -58,6 +58,8 @@ def _lower_bound(kind, g, pos, is2d):
     L = g[5] * (rad - g[2])
     if not is2d:
         L = np.maximum(L, np.maximum(g[3] - z, z - g[4]))
+    if g[6] > 0:                       # annulus: the shape also keeps rin away from the axis, at any z
+        L = np.maximum(L, g[5] * (g[6] - rad))
     return L
 
 
@@ -70,7 +72,7 @@ def check_tree(t, rng, npts=3000):
             continue
         is2d = t.nodes[node].op >= FIRST_2D
         if kind == 1:
-            lo, hi = g[:3].copy(), g[3:].copy()
+            lo, hi = g[:3].copy(), g[3:6].copy()
         else:
             lo = np.array([g[0] - g[2], g[1] - g[2], max(g[3], -1e3)])
             hi = np.array([g[0] + g[2], g[1] + g[2], min(g[4], 1e3)])
@@ -139,6 +141,14 @@ def test_screw_and_rotational_regions():
         t = sh.tree()
         assert _region(t, int(t.root))[0] != 0, sh
         assert check_tree(t, rng, 4000) > 2000, sh
+    # boxes on a circle around the axis: an annulus -- also bounded from below near the axis (what lets knurled-cylinder's
+    # through hole skip the knurl cutters)
+    t = b.CircularArray(box, 12, 12).tree()
+    k, g = _region(t, int(t.root))
+    assert k == 2 and abs(g[6] - 2.5) < 1e-3 and abs(g[2] - np.hypot(3.5, 0.5)) < 1e-3
+    t = b.Scene("knurled-cylinder").tree()
+    rins = [_region(t, i)[1][6] for i in _reachable(t) if OPS[t.nodes[i].op] in ("TWIST", "CIRCARRAY")]
+    assert rins and all(8.9 < r < 8.94 for r in rins)
     # a z-cylinder does not survive a rotation about another axis: no claim
     t = b.Rotate(b.Twist(box, 0.3), 0.7, (1, 0, 0)).tree()
     assert _region(t, int(t.root))[0] == 0

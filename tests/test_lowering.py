@@ -66,8 +66,9 @@ def test_npt_flange_program():
     assert [g[0] for g in gates] == ["D_GATE3D", "D_GATEZC"] and gates[1][1] is True
     f = code.view(np.float32)
     g0, g1 = gates[0][4], gates[1][4]
-    assert f[g0 + 7] == 1.0 and abs(f[g0 + 8] - 1.002 * 0.2) < 1e-6 and f[g1 + 7] == -1.0 and f[g1 + 8] == 0.0
-    t0, t1 = g0 + int(code[g0 + 9]), g1 + int(code[g1 + 9])
+    assert f[g0 + 7] == 1.0 and abs(f[g0 + 8] - 1.002 * 0.2) < 1e-6 and f[g1 + 8] == -1.0 and f[g1 + 9] == 0.0
+    assert int(code[g0 + 9]) == 0xffff and int(code[g1 + 10]) == 0xffff            # no enclosing-difference context here
+    t0, t1 = g0 + int(code[g0 + 12]), g1 + int(code[g1 + 13])
     assert [i[0] for i in ins if i[4] == t0] == ["D_COMBINE_SUNION"] and [i[0] for i in ins if i[4] == t1] == ["D_COMBINE_DIFF"]
     assert [i[3] for i in ins if i[4] == t0] == [gates[0][3]] and [i[3] for i in ins if i[4] == t1] == [gates[1][3]]
     # polygon edge records start on a 32-byte boundary
@@ -140,7 +141,7 @@ def test_far_child_skip_in_wide_unions():
     skips = [i for i in gates if i[3] == ub[0][3]]           # those testing against the slot the bound was stored in
     assert len(skips) == 24                                  # every glyph, the first one included
     for k, (name, _, _, slot, pc) in enumerate(skips):
-        target = pc + int(code[pc + 7])
+        target = pc + int(code[pc + 10])
         assert [i[0] for i in ins if i[4] == target] == ["D_COMBINE_MIN"]   # lands on the child's combine ...
         assert [i[3] for i in ins if i[4] == target] == [slot]              # ... of the same running-minimum slot
         x0, y0, x1, y1 = f[pc + 1:pc + 5]
@@ -151,7 +152,7 @@ def test_far_child_skip_in_wide_unions():
     inner = [i for i in gates if i[3] != ub[0][3]]
     assert len(inner) == 6
     for (name, _, _, slot, pc) in inner:
-        target = pc + int(code[pc + 7])
+        target = pc + int(code[pc + 10])
         assert [i[0] for i in ins if i[4] == target] == ["D_COMBINE_DIFF"] and f[pc + 5] == -1.0 and f[pc + 6] == 0.0
         assert [i[2] for i in ins if i[4] == target] == [False]   # never with swapped operands: only a subtrahend can be skipped
     # children without a lower-bound claim are never skipped: approximate primitives
@@ -216,7 +217,7 @@ def test_gates_of_binary_combines():
     assert len(g) == 1 and g[0][0] == "D_GATE3D" and f[g[0][4] + 7] == 1.0 and f[g[0][4] + 8] == 0.0
     names = [i[0] for i in ins]
     assert names.index("D_SPHERE") < names.index("D_POLY2D")
-    tgt = g[0][4] + int(code[g[0][4] + 9])
+    tgt = g[0][4] + int(code[g[0][4] + 12])
     assert [i[0] for i in ins if i[4] == tgt] == ["D_COMBINE_MIN"]
     # difference sphere - extrusion: the subtrahend is gated with sg = -1; extrusion - sphere: nothing (the minuend is the
     # result, and the sphere is not worth a test)
@@ -228,13 +229,13 @@ def test_gates_of_binary_combines():
     for sh in (b.SmoothUnion(0.3, ext(), sph()), b.SmoothUnion(0.3, sph(), ext())):
         ins, g, f, code = gate(sh)
         assert len(g) == 1 and f[g[0][4] + 7] == 1.0 and abs(f[g[0][4] + 8] - 1.002 * 0.3) < 1e-6
-        assert [i[0] for i in ins if i[4] == g[0][4] + int(code[g[0][4] + 9])] == ["D_COMBINE_SUNION"]
+        assert [i[0] for i in ins if i[4] == g[0][4] + int(code[g[0][4] + 12])] == ["D_COMBINE_SUNION"]
     ins, g, f, code = gate(b.SmoothDifference(0.3, sph(), ext()))
     assert len(g) == 1 and f[g[0][4] + 7] == -1.0 and abs(f[g[0][4] + 8] - 1.002 * 0.3) < 1e-6
     assert gate(b.SmoothDifference(0.3, ext(), sph()))[1] == []
     # a smooth union's own region is the hull of its operands grown by k / 4
     ins, g, f, code = gate(b.Union(b.Translate(b.SmoothUnion(0.4, ext(), b.NewSphere(1)), 10, 0, 0), sph()))
-    outer = [q for q in g if [i[0] for i in ins if i[4] == q[4] + int(code[q[4] + 9])] == ["D_COMBINE_MIN"]]
+    outer = [q for q in g if [i[0] for i in ins if i[4] == q[4] + int(code[q[4] + 12])] == ["D_COMBINE_MIN"]]
     assert len(outer) == 1
     x0, y0, z0, x1, y1, z1 = f[outer[0][4] + 1:outer[0][4] + 7]
     assert abs(x0 - (10 - 1 - 0.1)) < 1e-3 and abs(x1 - (10 + 2.5 + 0.1)) < 1e-3 and abs(z0 - (-1 - 0.1)) < 1e-3 and abs(y1 - (2.5 + 0.1)) < 1e-3
@@ -253,9 +254,9 @@ def test_gate_regions_of_screws_and_rotational_ops():
     zc = [i for i in ins if i[0] == "D_GATEZC"]
     assert len(zc) == 1
     pc = zc[0][4]
-    cx, cy, r, z0, z1, rs, sg, kk = f[pc + 1:pc + 9]
-    assert cx == 0 and cy == 0 and 1.5 < r < 1.56 and abs((z1 - z0) - 8.0) < 1e-3 and 0.99999 < rs < 1.0 and sg == 1.0 and kk == 0.0
-    assert [i[0] for i in ins if i[4] == pc + int(code[pc + 9])] == ["D_COMBINE_MIN"]
+    cx, cy, r, z0, z1, rs, rin, sg, kk = f[pc + 1:pc + 10]
+    assert cx == 0 and cy == 0 and 1.5 < r < 1.56 and abs((z1 - z0) - 8.0) < 1e-3 and 0.99999 < rs < 1.0 and rin == 0 and sg == 1.0 and kk == 0.0
+    assert [i[0] for i in ins if i[4] == pc + int(code[pc + 13])] == ["D_COMBINE_MIN"]
     # npt-flange: tapered thread -> rs = 1 / (1 + 1/32)
     code, _ = hip.lower(b.Scene("npt-flange"))
     f = code.view(np.float32)
@@ -268,8 +269,22 @@ def test_gate_regions_of_screws_and_rotational_ops():
     f = code.view(np.float32)
     g = [i for i in decode(code) if i[0] == "D_GATEZC"]
     assert len(g) == 1
-    cx, cy, r, z0, z1, rs = f[g[0][4] + 1:g[0][4] + 7]
+    cx, cy, r, z0, z1, rs, rin = f[g[0][4] + 1:g[0][4] + 8]
     assert cx == 0 and cy == 0 and abs(r - np.hypot(3.5, 0.5)) < 1e-3 and abs(z0 + 2) < 1e-6 and abs(z1 - 2) < 1e-6 and rs == 1.0
+    assert abs(rin - 2.5) < 1e-3                                                   # the boxes keep 2.5 away from the axis
+    # knurled-cylinder: the knurl cutters are the subtrahend of a smooth difference that is itself the minuend of the next
+    # one (the through hole, evaluated first): their gate carries that context (slot of the hole's value, 1.002 k, k / 4)
+    code, _ = hip.lower(b.Scene("knurled-cylinder"))
+    f = code.view(np.float32)
+    ins = decode(code)
+    gz = [i for i in ins if i[0] == "D_GATEZC"]
+    ctx = [i for i in gz if int(code[i[4] + 10]) != 0xffff]
+    assert len(ctx) == 1
+    pc = ctx[0][4]
+    hole = [i for i in ins if i[0] == "D_SAVER"][0]                                 # the hole cylinder's value is saved first
+    assert int(code[pc + 10]) == hole[3] and f[pc + 8] == -1.0 and abs(f[pc + 9] - 1.002) < 1e-6
+    assert abs(f[pc + 11] - 1.002) < 1e-6 and abs(f[pc + 12] - 0.25) < 1e-4 and 8.9 < f[pc + 7] < 8.94
+    assert [i[0] for i in ins if i[4] == pc + int(code[pc + 13])] == ["D_COMBINE_SDIFF"]
 
 
 def test_hxy_not_reused_across_xy_changes():
