@@ -567,8 +567,11 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
 // barrier and NO atomic in its loop -- its waves are independent -- and leaves, per 64-leaf block (one wave pass), the leaves
 // the surface cuts as compact records in HBM:
 //     hdr[block]                    = number of records (0..64)
-//     rec[block][c][r], c < 10      = SoA inside the block (coalesced both ways): 8 corner distances (corner order 0..7),
-//                                     leaf x | y << 16, leaf z | index << 16       (40 B per cut leaf, ~16 % of the leaves)
+//     rec[block][r][c], c < 10      = the block's records side by side (r = rank among the wave's cut lanes): 8 corner distances
+//                                     (corner order 0..7), leaf x | y << 16, leaf z | index << 16 (40 B per cut leaf, ~16 % of
+//                                     the leaves). A block holds ~10 records: 420 contiguous bytes -- four cache lines; a
+//                                     column-major block (tried first) spread them over ten lines and made the marching
+//                                     kernel fetch 2.2x the bytes it used.
 // Sized for the worst case (64 records per block: no overflow path); only the cut leaves' lines are ever touched.
 // march_records_kernel then runs marching cubes over the records alone: 256 blocks per workgroup pass (prefix of their
 // record counts in LDS), one record per lane in chunks of 256, triangles one per lane (mc_emit_balanced) into a large LDS
@@ -650,11 +653,13 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
     if (blk < n_blocks_cap) {
       if ((threadIdx.x & 63u) == 0u) hdr[blk] = (uint32_t)__builtin_popcountll(cm);
       if (cut) {
-        uint32_t* w = rec + blk * REC_BLOCK + rank;
-#pragma unroll
-        for (int j = 0; j < 8; j++) w[((0x62735140u >> (4u * j)) & 7u) * 64] = __float_as_uint(dall[j]);  // dall[j] = corner order[j]
-        w[8 * 64] = (uint32_t)lf.x | ((uint32_t)lf.y << 16);
-        w[9 * 64] = (uint32_t)lf.z | (index << 16);
+        uint2* w = (uint2*)(rec + blk * REC_BLOCK + rank * REC_WORDS);  // 40-byte records: 8-byte aligned, five 8-byte stores
+        // dall[j] is the distance of corner order[j], order = {0,4,1,5,3,7,2,6}: corners (0,1) = dall[0], dall[2] ...
+        w[0] = make_uint2(__float_as_uint(dall[0]), __float_as_uint(dall[2]));  // corners 0, 1
+        w[1] = make_uint2(__float_as_uint(dall[6]), __float_as_uint(dall[4]));  // corners 2, 3
+        w[2] = make_uint2(__float_as_uint(dall[1]), __float_as_uint(dall[3]));  // corners 4, 5
+        w[3] = make_uint2(__float_as_uint(dall[7]), __float_as_uint(dall[5]));  // corners 6, 7
+        w[4] = make_uint2((uint32_t)lf.x | ((uint32_t)lf.y << 16), (uint32_t)lf.z | (index << 16));
       }
     }
   }
@@ -729,9 +734,9 @@ __global__ void __launch_bounds__(BLOCK) march_records_kernel(const uint32_t* __
           const unsigned mid = (lo + hi) >> 1;
           if (s_pre[mid] <= q) lo = mid; else hi = mid;
         }
-        const uint32_t* w = rec + (b0 + lo) * REC_BLOCK + (q - s_pre[lo]);
+        const uint2* w = (const uint2*)(rec + (b0 + lo) * REC_BLOCK + (q - s_pre[lo]) * REC_WORDS);
 #pragma unroll
-        for (int c = 0; c < REC_WORDS; c++) rw[c] = w[c * 64];
+        for (int c = 0; c < REC_WORDS / 2; c++) { const uint2 v = w[c]; rw[2 * c] = v.x; rw[2 * c + 1] = v.y; }
       }
     };
     fetch(threadIdx.x);

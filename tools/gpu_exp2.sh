@@ -9,8 +9,8 @@ import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']; ph=d['phase_ms_rank0']
 print('$label', 'ms/step %.3f' % d['ms_per_step'], 'kernel %.3f ms' % r['kernel_ms'], r['kernel'], 'phases', {k: round(v,3) for k,v in ph.items()}, 'tris', int(d['triangles_per_step']), d['config']['evaluator'][:60])"
 }
-run hipcc A=1
-run hiprtc GSDF_HIP_SPEC_COMPILER=hiprtc
+run base A=1
+run base2 A=1
 SCENE_ARGS="--scene bolt --resdiv 2000"
 run bolt A=1
 SCENE_ARGS="--scene knurled-cylinder --resdiv 2000"
