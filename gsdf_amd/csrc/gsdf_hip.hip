@@ -1361,12 +1361,14 @@ extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, in
     }
     HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(MeshCounters), s));
     HIP_TRYM(hipEventRecord(p->ev[2], s));
-    const uint64_t npass = (uint64_t)((nx + 63) / 64) * ((ny + 4 * FLAT_ROWS - 1) / (4 * FLAT_ROWS)) * ncz;
-    if ((double)npass + 1e6 >= 4294967296.0) return bail(fail(GSDF_ERR_RESOLUTION, "resolution too fine for the flat renderer's lattice"));
+    const uint64_t npass = (uint64_t)((nx + 63) / 64) * ((ny + FLAT_ROWS - 1) / FLAT_ROWS) * ncz;  // wave passes: 64 x FLAT_ROWS cubes each
+    if ((double)npass + 1e6 >= 4294967296.0 || nx >= 65536u || ny >= 65536u || (uint64_t)c0 + ncz >= 65536u)
+      return bail(fail(GSDF_ERR_RESOLUTION, "resolution too fine for the flat renderer's lattice"));
     static const int mbpc = [] { const char* e = getenv("GSDF_HIP_FLAT_BPC"); return e ? atoi(e) : 32; }();  // tuning knob
     const uint64_t gmax = (uint64_t)p->num_cu * (uint64_t)(mbpc > 0 ? mbpc : 32);
-    const size_t lds = (size_t)5 * BLOCK * FLAT_ROWS * 2 + (size_t)BLOCK * FLAT_ROWS + 4096 + FLAT_STAGE * 36 + 64;
-    hipLaunchKernelGGL(flat_march_kernel, dim3((unsigned)(npass < gmax ? npass : gmax)), dim3(BLOCK), lds, s, (const float*)grid, nx, ny, ncz, c0,
+    const uint64_t nwg = (npass + 3) / 4;
+    const size_t lds = (size_t)256 * 16 + (size_t)4 * FLAT_WAVE_RECS * REC_WORDS * 4;
+    hipLaunchKernelGGL(flat_march_kernel, dim3((unsigned)(nwg < gmax ? (nwg ? nwg : 1) : gmax)), dim3(BLOCK), lds, s, (const float*)grid, nx, ny, ncz, c0,
                        ox, oy, oz, res, m->d_tris, (uint64_t)m->cap, d_ctr);
     HIP_TRYM(hipGetLastError());
     HIP_TRYM(hipEventRecord(p->ev[3], s));

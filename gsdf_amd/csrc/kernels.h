@@ -924,115 +924,178 @@ __global__ void __launch_bounds__(BLOCK, W) flat_grid_kernel(const uint32_t* __r
 }
 
 #ifndef GSDF_SPECIALIZED
-// ReadTriangles (:186-256): marching cubes of the cubes [0,nx) x [0,ny) x [0,ncz) of a grid slab (cube z = czfirst + cz
-// of the lattice). A workgroup pass covers 64 cubes in x (one wave = one row, so a cube's four row loads are coalesced)
-// by 4*FLAT_ROWS in y: corner 0 first (prefetched one pass ahead), the other seven only in waves where some lane passes
-// the reference's |d0| <= 2*sqrt3*res test (:207-209). Triangles are then emitted ONE PER LANE, not one cube per lane:
-// the block prefix sum of the per-cube triangle counts gives every triangle a slot and an owner list in LDS
-// (cube id, triangle number), lane t builds triangle t (corner distances re-read from the grid, L1/L2-hot) -- all 256
-// lanes busy instead of the few whose cube is cut, each for up to five rounds. Output staged in LDS, flushed
-// coalesced with one append on the global counter per FLAT_STAGE triangles.
-// HBM-bound by design: 4 B per lattice corner in, 36 B per triangle out.
-// LDS: [owner list 1280*FLAT_ROWS u16 | cube index 256*FLAT_ROWS u8 | tri table | triangle stage | misc].
-#define FLAT_ROWS 4
-#define FLAT_STAGE 256  // triangles staged per workgroup: 128 costs more flushes (0.93 ms), 512 a workgroup per CU less (0.90 ms); 256: 0.74 ms
+// flat_march_kernel: marching cubes of every cube of the lattice from the distance grid (FlatRenderer.ReadTriangles,
+// glrender/flatrenderer.go:186-256). HBM-bound by design: 4 B per lattice corner in, 36 B per triangle out. Round 2:
+// every WAVE on its own -- no workgroup barrier and no shared stage in the loop (round 1's kernel had one barrier per
+// pass and its waves waited 68 % of their cycles at 32 % of the HBM peak).
+//   * a wave pass = 64 consecutive x cubes x FLAT_ROWS rows at one z: corner 0 of the four rows per lane, prefetched one
+//     pass ahead; the other seven corners only in waves where some lane passes the reference's |d0| <= 2*sqrt3*res test
+//     (:207-209); ~95 % of the passes end there;
+//   * cubes the surface cuts are appended (ballot rank) as records -- 8 distances, cube coordinates, case index -- to a
+//     buffer of FLAT_WAVE_RECS records in LDS that only this wave touches;
+//   * when the buffer cannot take another row (> FLAT_WAVE_RECS - 64 records) the wave marches it: triangle counts per
+//     record from the LDS table, exclusive prefix from three ballots, ONE global atomic for the whole flush (~350
+//     triangles: ~20 K atomics per mesh, well under the ~88 per microsecond a counter word takes), then every lane builds
+//     its record's triangles and stores them at their final address.
+// LDS: [tri table 4 KB (row byte 15 = triangle count) | 4 x FLAT_WAVE_RECS x 10 words].
+#define FLAT_ROWS 8
+#define FLAT_WAVE_RECS 192
 __global__ void __launch_bounds__(BLOCK) flat_march_kernel(const float* __restrict__ grid, unsigned nx, unsigned ny, unsigned ncz,
                                                            unsigned czfirst, float ox, float oy, float oz, float res,
                                                            float* __restrict__ tris, uint64_t tri_cap, MeshCounters* __restrict__ ctr) {
-  uint16_t* s_owner = (uint16_t*)g_smem;                      // [5 * BLOCK * FLAT_ROWS]
-  uint8_t* s_index = (uint8_t*)(s_owner + 5 * BLOCK * FLAT_ROWS);  // [BLOCK * FLAT_ROWS]
-  int8_t* s_tri = (int8_t*)(s_index + BLOCK * FLAT_ROWS);
-  float* s_stage = (float*)(s_tri + 256 * 16);
-  unsigned* s_misc = (unsigned*)(s_stage + FLAT_STAGE * 9);  // [0..3] wave sums
-  unsigned long long* s_base = (unsigned long long*)(s_misc + 6);
-  for (int k = threadIdx.x; k < 256 * 16; k += BLOCK) s_tri[k] = GSDF_MC_TRI[k >> 4][k & 15];
+  int8_t* s_tri = (int8_t*)g_smem;
+  uint32_t* buf = (uint32_t*)(s_tri + 256 * 16) + (threadIdx.x >> 6) * (FLAT_WAVE_RECS * REC_WORDS);  // [REC_WORDS][FLAT_WAVE_RECS], this wave's
+  for (int k = threadIdx.x; k < 256 * 16; k += BLOCK) s_tri[k] = (k & 15) == 15 ? (int8_t)GSDF_MC_NTRI[k >> 4] : GSDF_MC_TRI[k >> 4][k & 15];
   __syncthreads();
   const unsigned sx = nx + 1;
   const uint64_t sxy = (uint64_t)sx * (ny + 1);
-  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned txn = (nx + 63) / 64, tyn = (ny + 4 * FLAT_ROWS - 1) / (4 * FLAT_ROWS);
-  const unsigned npass = txn * tyn * ncz;  // < 2^32 (host checks)
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned txn = (nx + 63) / 64, tyn = (ny + FLAT_ROWS - 1) / FLAT_ROWS;
+  const unsigned npass = txn * tyn * ncz;  // wave passes, < 2^32 (host checks)
   const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19 / flatrenderer.go:207
-  unsigned long long my_active = 0;
-  unsigned cur = 0;  // triangles in the stage (block-uniform)
-  // Corner-0 distances of pass w; lanes outside the lattice get +inf (never active). The loads of the NEXT pass are
-  // issued before this pass is processed.
-  auto load_d0 = [&](unsigned tx, unsigned ty, unsigned cz, float (&d0)[FLAT_ROWS]) {
-    const unsigned cx = tx * 64 + lane, cy0 = (ty * 4 + wave) * FLAT_ROWS;
-    const float* g0 = grid + (uint64_t)cz * sxy + (uint64_t)cy0 * sx + cx;
+  unsigned my_active = 0;  // wave-uniform
+  unsigned cnt = 0;        // records in this wave's buffer (wave-uniform)
+  auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
+
+  // marching cubes of the buffered records, wave-local
+  auto flush = [&]() {
+    if (cnt == 0) return;
+    // pass 1: triangles of the whole flush
+    unsigned total = 0;
+    for (unsigned i0 = 0; i0 < cnt; i0 += 64u) {
+      const unsigned i = i0 + lane;
+      const unsigned nt = i < cnt ? (unsigned)(uint8_t)s_tri[(buf[9 * FLAT_WAVE_RECS + i] >> 16) * 16 + 15] : 0u;
+      total += (unsigned)__builtin_popcountll(__ballot((nt & 1u) != 0u)) + 2u * (unsigned)__builtin_popcountll(__ballot((nt & 2u) != 0u)) +
+               4u * (unsigned)__builtin_popcountll(__ballot((nt & 4u) != 0u));
+    }
+    unsigned long long gbase = 0;
+    if (lane == 0) gbase = atomicAdd(&ctr->n_tris, (unsigned long long)total);
+    gbase = uniform_u64(gbase);
+    if (gbase + total > tri_cap) {  // wave-uniform: the counter keeps counting, the host learns the exact size and reruns
+      if (lane == 0) ctr->overflow = 1ull;
+      cnt = 0;
+      return;
+    }
+    // pass 2: build and store
+    unsigned done = 0;
+    for (unsigned i0 = 0; i0 < cnt; i0 += 64u) {
+      const unsigned i = i0 + lane;
+      unsigned nt = 0, idx = 0;
+      if (i < cnt) { idx = buf[9 * FLAT_WAVE_RECS + i] >> 16; nt = (unsigned)(uint8_t)s_tri[idx * 16 + 15]; }
+      const unsigned long long q0 = __ballot((nt & 1u) != 0u), q1 = __ballot((nt & 2u) != 0u), q2 = __ballot((nt & 4u) != 0u);
+      const unsigned pre = below(q0) + 2u * below(q1) + 4u * below(q2);
+      const unsigned ctot = (unsigned)__builtin_popcountll(q0) + 2u * (unsigned)__builtin_popcountll(q1) + 4u * (unsigned)__builtin_popcountll(q2);
+      if (nt) {
+        const uint32_t xy = buf[8 * FLAT_WAVE_RECS + i], zi = buf[9 * FLAT_WAVE_RECS + i];
+        // cube origin exactly as the fused round-1 kernel formed it: o + (float)index * res
+        const float x0 = ox + (float)(xy & 0xffffu) * res, y0 = oy + (float)(xy >> 16) * res, z0 = oz + (float)(zi & 0xffffu) * res;
+        const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;
+        float* dst = tris + (gbase + done + pre) * 9;
+        for (unsigned k = 0; k < nt; k++) {
+          const int8_t* row = s_tri + idx * 16 + 3 * k;
 #pragma unroll
-    for (int r = 0; r < FLAT_ROWS; r++) d0[r] = (cx < nx && cy0 + (unsigned)r < ny) ? g0[(uint64_t)r * sx] : __builtin_inff();
+          for (int j = 0; j < 3; j++) {
+            const int e = row[2 - j];  // reversed winding (marchcubes.go:64-68)
+            const unsigned ca = GSDF_MC_PAIR_A(e), cb = GSDF_MC_PAIR_B(e);
+            const bool ax = ((ca ^ (ca >> 1)) & 1u) != 0u, ay = ((ca >> 1) & 1u) != 0u, az = ((ca >> 2) & 1u) != 0u;
+            const bool bx = ((cb ^ (cb >> 1)) & 1u) != 0u, by = ((cb >> 1) & 1u) != 0u, bz = ((cb >> 2) & 1u) != 0u;
+            float rx, ry, rz;
+            mc_interp(ax ? x1 : x0, ay ? y1 : y0, az ? z1 : z0, bx ? x1 : x0, by ? y1 : y0, bz ? z1 : z0,
+                      __uint_as_float(buf[ca * FLAT_WAVE_RECS + i]), __uint_as_float(buf[cb * FLAT_WAVE_RECS + i]), rx, ry, rz);
+            dst[9 * k + 3 * j + 0] = rx;
+            dst[9 * k + 3 * j + 1] = ry;
+            dst[9 * k + 3 * j + 2] = rz;
+          }
+        }
+      }
+      done += ctot;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // the buffer is read out before new records overwrite it
+    __builtin_amdgcn_wave_barrier();
+    cnt = 0;
   };
-  auto pass_coords = [&](unsigned w, unsigned& tx, unsigned& ty, unsigned& cz) {  // npass < 2^32 (host checks)
+
+  auto pass_coords = [&](unsigned w, unsigned& tx, unsigned& ty, unsigned& cz) {
     const unsigned wr = w / txn;
     tx = w - wr * txn;
     cz = wr / tyn;
     ty = wr - cz * tyn;
   };
+  auto load_d0 = [&](unsigned tx, unsigned ty, unsigned cz, float (&d0)[FLAT_ROWS]) {
+    const unsigned cx = tx * 64 + lane, cy0 = ty * FLAT_ROWS;
+    const float* g0 = grid + (uint64_t)cz * sxy + (uint64_t)cy0 * sx + cx;
+#pragma unroll
+    for (int r = 0; r < FLAT_ROWS; r++) d0[r] = (cx < nx && cy0 + (unsigned)r < ny) ? g0[(uint64_t)r * sx] : __builtin_inff();
+  };
+  const unsigned wid = blockIdx.x * 4u + (threadIdx.x >> 6), wstride = gridDim.x * 4u;
   float dnext[FLAT_ROWS];
   unsigned ntx = 0, nty = 0, ncz_ = 0;
-  if (blockIdx.x < npass) {
-    pass_coords(blockIdx.x, ntx, nty, ncz_);
+  if (wid < npass) {
+    pass_coords(wid, ntx, nty, ncz_);
     load_d0(ntx, nty, ncz_, dnext);
   }
-  for (unsigned w = blockIdx.x; w < npass; w += gridDim.x) {
+  for (unsigned w = wid; w < npass; w += wstride) {  // wave-uniform
     const unsigned tx = ntx, ty = nty, cz = ncz_;
-    const unsigned cx = tx * 64 + lane, cy0 = (ty * 4 + wave) * FLAT_ROWS;
+    const unsigned cx = tx * 64 + lane, cy0 = ty * FLAT_ROWS;
     const float* g0 = grid + (uint64_t)cz * sxy + (uint64_t)cy0 * sx + cx;
     float d0[FLAT_ROWS];
-    unsigned index[FLAT_ROWS];
     bool any_act = false;
 #pragma unroll
     for (int r = 0; r < FLAT_ROWS; r++) {
       d0[r] = dnext[r];
       any_act = any_act || dm::absf(d0[r]) <= cubeDiag;
-      index[r] = 0;
     }
-    if (w + gridDim.x < npass) {
-      pass_coords(w + gridDim.x, ntx, nty, ncz_);
+    if (w + wstride < npass) {
+      pass_coords(w + wstride, ntx, nty, ncz_);
       load_d0(ntx, nty, ncz_, dnext);
     }
-    if (__ballot(any_act) != 0ull) {  // wave-uniform
+    if (__ballot(any_act) == 0ull) continue;  // wave-uniform
+    // the other seven corners of every active cube of the pass, ALL rows' loads issued before the first is used: a load
+    // takes ~2 us under load, and paying that once per active row (tried first) is what bounded this kernel, not bandwidth
+    float v[FLAT_ROWS][7];
 #pragma unroll
-      for (int r = 0; r < FLAT_ROWS; r++) {
-        if (dm::absf(d0[r]) <= cubeDiag) {
-          const float* q = g0 + (uint64_t)r * sx;
-          const float v1 = q[1], v2 = q[1 + sx], v3 = q[sx], v4 = q[sxy], v5 = q[sxy + 1], v6 = q[sxy + 1 + sx], v7 = q[sxy + sx];
-          const unsigned ix = (d0[r] < 0.f ? 1u : 0u) | (v1 < 0.f ? 2u : 0u) | (v2 < 0.f ? 4u : 0u) | (v3 < 0.f ? 8u : 0u) |
-                              (v4 < 0.f ? 16u : 0u) | (v5 < 0.f ? 32u : 0u) | (v6 < 0.f ? 64u : 0u) | (v7 < 0.f ? 128u : 0u);
-          index[r] = ix == 255u ? 0u : ix;
-          my_active++;
-        }
-      }
+    for (int r = 0; r < FLAT_ROWS; r++) {
+      const float* q = g0 + (uint64_t)r * sx;
+      const bool act = dm::absf(d0[r]) <= cubeDiag;
+      v[r][0] = act ? q[1] : 0.f; v[r][1] = act ? q[1 + sx] : 0.f; v[r][2] = act ? q[sx] : 0.f; v[r][3] = act ? q[sxy] : 0.f;
+      v[r][4] = act ? q[sxy + 1] : 0.f; v[r][5] = act ? q[sxy + 1 + sx] : 0.f; v[r][6] = act ? q[sxy + sx] : 0.f;
     }
-    // owner id = row*BLOCK + thread -> cube (ocx, ocy) of this pass; distances are re-read from the grid (L1/L2-hot)
-    const float* gz = grid + (uint64_t)cz * sxy;
-    const float z0 = oz + (float)(czfirst + cz) * res;
-    mc_emit_balanced<FLAT_ROWS, FLAT_STAGE>(
-        index, s_owner, s_index, s_tri, s_stage, s_misc, s_base, cur, res,
-        [&](unsigned id, unsigned c) {
-          const unsigned ot = id & 255u, ocx = tx * 64 + (ot & 63u), ocy = (ty * 4 + (ot >> 6)) * FLAT_ROWS + (id >> 8);
-          return gz[(uint64_t)(ocy + ((c >> 1) & 1u)) * sx + ocx + ((c ^ (c >> 1)) & 1u) + ((c >> 2) ? sxy : 0ull)];
-        },
-        [&](unsigned id, float& x0, float& y0, float& zz) {
-          const unsigned ot = id & 255u, ocx = tx * 64 + (ot & 63u), ocy = (ty * 4 + (ot >> 6)) * FLAT_ROWS + (id >> 8);
-          x0 = ox + (float)ocx * res;
-          y0 = oy + (float)ocy * res;
-          zz = z0;
-        },
-        tris, tri_cap, ctr);
-  }
-  __syncthreads();
-  if (cur) mc_stage_flush<FLAT_STAGE>(s_stage, s_base, cur, tris, tri_cap, ctr);
-  // statistics: one atomic per workgroup
-  unsigned na = (unsigned)my_active;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) na += __shfl_down(na, off, 64);
+    for (int r = 0; r < FLAT_ROWS; r++) {
+      const bool act = dm::absf(d0[r]) <= cubeDiag;
+      const unsigned long long am = __ballot(act);
+      if (am == 0ull) continue;  // wave-uniform
+      my_active += (unsigned)__builtin_popcountll(am);
+      unsigned ix = 0;
+      if (act) {
+        ix = (d0[r] < 0.f ? 1u : 0u);
+#pragma unroll
+        for (int c = 0; c < 7; c++) ix |= (v[r][c] < 0.f ? 1u : 0u) << (c + 1);
+        if (ix == 255u) ix = 0u;
+      }
+      const unsigned long long cm = __ballot(ix != 0u);
+      if (cm == 0ull) continue;  // wave-uniform
+      if (cnt + 64u > FLAT_WAVE_RECS) flush();  // room for a whole row
+      if (ix) {
+        const unsigned pos = cnt + below(cm);
+        buf[0 * FLAT_WAVE_RECS + pos] = __float_as_uint(d0[r]);
+#pragma unroll
+        for (int c = 0; c < 7; c++) buf[(c + 1) * FLAT_WAVE_RECS + pos] = __float_as_uint(v[r][c]);
+        buf[8 * FLAT_WAVE_RECS + pos] = cx | ((cy0 + (unsigned)r) << 16);
+        buf[9 * FLAT_WAVE_RECS + pos] = (czfirst + cz) | (ix << 16);
+      }
+      cnt += (unsigned)__builtin_popcountll(cm);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+  }
+  flush();
+  // statistics: one atomic per workgroup
   __syncthreads();
-  if (lane == 0) s_misc[wave] = na;
+  unsigned* s_stat = (unsigned*)(s_tri + 256 * 16);
+  if (lane == 0) s_stat[threadIdx.x >> 6] = my_active;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned long long a = (unsigned long long)s_misc[0] + s_misc[1] + s_misc[2] + s_misc[3];
+    const unsigned long long a = (unsigned long long)s_stat[0] + s_stat[1] + s_stat[2] + s_stat[3];
     if (a) atomicAdd(&ctr->n_active, a);
   }
 }
