@@ -212,6 +212,7 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     dist = None
     comm = None
+    torch_gather = False
     torch.cuda.set_device(local_rank if world > 1 else 0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     hip.init(dev.index)
@@ -222,9 +223,24 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
-        ids = [hip.CommHIP.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        comm = hip.CommHIP(ids[0], rank, world)
+        try:
+            ids = [hip.CommHIP.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = hip.CommHIP(ids[0], rank, world)
+            ok = 1
+        except Exception as e:  # librccl missing / refused: every rank must take the same path
+            print("bench: library RCCL communicator unavailable on rank %d: %s" % (rank, str(e)[:300]), file=sys.stderr)
+            comm, ok = None, 0
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            # fallback: the torch.distributed gather of gsdf_amd/gather.py on torch's own RCCL process group
+            if comm is not None:
+                comm.close()
+                comm = None
+            dist.destroy_process_group()
+            dist.init_process_group("nccl", device_id=dev)
+            torch_gather = True
 
     bld = Builder()
     shader = bld.NewSphere(1.0) if args.scene == "sphere" else bld.Scene(args.scene)
@@ -259,7 +275,12 @@ def main():
             oc = hip.DualContourHIP(sdf, res, shard_rank=rank, shard_count=world)
         else:
             oc = hip.OctreeHIP(sdf, res, shard_rank=rank, shard_count=world, share_corners=args.share_corners)
-        gathered = oc.gatherv(comm) if comm is not None else None   # every rank ends up with all triangles, device resident
+        gathered = None
+        if comm is not None:
+            gathered = oc.gatherv(comm)   # every rank ends up with all triangles, device resident
+        elif torch_gather:
+            from gsdf_amd.gather import all_gatherv_triangles
+            gathered = all_gatherv_triangles(oc.dev_ptr(), oc.n_tris(), dev)[0]
         return oc, gathered
 
     # Setup, untimed: bring the GPU out of its idle clock state before the W warmup steps. The first ~20 meshes after
@@ -287,7 +308,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    tot = torch.tensor([float(evals), float(tris), dt], dtype=torch.float64)
+    tot = torch.tensor([float(evals), float(tris), dt], dtype=torch.float64, device=dev if torch_gather else "cpu")
     if dist is not None:
         tmax = tot.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -323,7 +344,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "sharding": (("z-slabs of the lattice, halo recomputed" if dc else "octree bricks by coordinate hash")
-                                    + ", RCCL all-gatherv of triangles inside the library (gsdf_hip_mesh_gatherv)") if world > 1 else "single GPU",
+                                    + (", RCCL all-gatherv of triangles inside the library (gsdf_hip_mesh_gatherv)" if comm is not None else ", RCCL all-gatherv of triangles through torch.distributed (fallback)")) if world > 1 else "single GPU",
                        "leaf_corners": "shared (distinct lattice points once)" if args.share_corners else "8 per leaf (as the reference)",
                        "evaluator": spec_note,
                        "setup": f"{args.preheat} untimed meshes before the warmup steps (clock ramp)"},
@@ -350,9 +371,11 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         if rank == 0 and last[1] is not None:
-            assert last[1].n_tris() == int(tris_all / args.steps), "gathered triangle count differs from the sum of the ranks'"
+            ng = last[1].n_tris() if hasattr(last[1], "n_tris") else int(last[1].shape[0])
+            assert ng == int(tris_all / args.steps), "gathered triangle count differs from the sum of the ranks'"
         dist.barrier()
-        comm.close()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 
