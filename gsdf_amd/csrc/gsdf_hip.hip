@@ -80,7 +80,7 @@ struct gsdf_program {
       return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-  } q0, q1, ctr, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, flat_grid, rec, hdr;  // rec / hdr: cut-leaf records of the two-kernel leaf phase  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
+  } q0, q1, ctr, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, flat_grid, rec, hdr, psum;  // rec / hdr / psum: cut-leaf records, block headers and group sums of the two-kernel leaf phase  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   uint64_t last_tris = 0;  // triangle count of the previous mesh on this handle: sizes the next output buffer
   uint64_t last_dc_cubes = 0;  // kept cubes of the previous dual contouring pass: sizes the next queues
@@ -123,7 +123,7 @@ void gsdf_program::leaf_config(int* k, int* w, size_t* lds) const {
     static const int forced_w = [] { const char* e = getenv("GSDF_HIP_LEAF_WAVES"); return e ? atoi(e) : 0; }();  // tuning knob
     const int ns = prog.nslots > 0 ? prog.nslots : 1;
     const int lk = (batch_k() == 4 && ns > 11) ? 2 : batch_k();
-    const size_t lds_e = (size_t)ns * lk * BLOCK * sizeof(float);
+    const size_t lds_e = (size_t)ns * lk * BLOCK * sizeof(float) + 256;  // + the triangles-per-case table
     int ww = forced_w ? forced_w : (4 * lds_e <= 160 * 1024 ? 4 : 3);
     if (lk == 4) { if (ww != 2 && ww != 4) ww = 3; }
     else if (lk == 2) { if (ww != 4) ww = 3; }
@@ -440,7 +440,7 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
   names.push_back(std::string("eval_kernel<") + (p->prog.is2d ? "2" : "3") + ", " + std::to_string(ek) + ", " + std::to_string(ew) + ">");
   if (!p->prog.is2d) {
     names.push_back("prune_kernel");
-    names.push_back(std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(lw) + ">");
+    names.push_back(std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(lw) + (fused_leaf() ? ">" : ", true>"));
   }
   std::vector<hipFunction_t> f;
   hipModule_t mod = nullptr;
@@ -477,7 +477,7 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
     for (int w2 = lw - 1; !okl && w2 >= 2; w2--) {
       std::vector<hipFunction_t> fl;
       hipModule_t m2 = nullptr;
-      const std::string nl = std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(w2) + ">";
+      const std::string nl = std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(w2) + (fused_leaf() ? ">" : ", true>");
       if (spec_build(p, {nl}, &m2, fl, &p->spec_compile_s) != GSDF_OK) break;
       okl = fn_scratch_bytes(fl[0]) == 0;
       spec_report("specialised", nl, fl[0], okl);
@@ -542,7 +542,7 @@ extern "C" int gsdf_hip_specialize_check(const gsdf_tree* tree, size_t* code_obj
     std::vector<std::string> low;
     std::string log;
     const std::vector<std::string> names = pr.is2d ? std::vector<std::string>{"eval_kernel<2, 4, 4>"}
-                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "leaf_eval_kernel<4, 4>", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
+                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "leaf_eval_kernel<4, 4, true>", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
     if (!gsdf_dev::spec_compile(pr, "gfx950", names, co, low, log)) return fail(GSDF_ERR_HIP, "specialised build failed:\n" + log);
     if (code_object_bytes) *code_object_bytes = co.size();
     return GSDF_OK;
@@ -596,7 +596,7 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (p->spec_mod3) (void)hipModuleUnload(p->spec_mod3);
   if (p->spec_mod4) (void)hipModuleUnload(p->spec_mod4);
   p->q0.release(); p->q1.release(); p->ctr.release();
-  p->rec.release(); p->hdr.release();
+  p->rec.release(); p->hdr.release(); p->psum.release();
   p->flat_grid.release(); p->dc_grid.release(); p->dc_dist.release(); p->dc_fv.release(); p->dc_nrm.release(); p->dc_edge.release();
   for (auto e : p->ev) if (e) (void)hipEventDestroy(e);
   if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -1001,15 +1001,21 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
         const uint64_t nblk = (bound + 63) / 64;  // 64-leaf blocks the queue capacity allows for
         HIP_TRYM(p->hdr.ensure(nblk * sizeof(uint32_t)));
         HIP_TRYM(p->rec.ensure(nblk * (size_t)REC_BLOCK * sizeof(uint32_t)));
+        const uint64_t ngrp = (nblk + MARCH_GROUP - 1) / MARCH_GROUP;
+        HIP_TRYM(p->psum.ensure(ngrp * sizeof(unsigned long long)));
         uint32_t* d_hdr = (uint32_t*)p->hdr.p;
         uint32_t* d_rec = (uint32_t*)p->rec.p;
-#define LAUNCH_LEAF_EVAL(KK, WW)                                                                                               \
-  hipLaunchKernelGGL((leaf_eval_kernel<KK, WW>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), lds_m, s, p->d_code,  \
+        unsigned long long* d_psum = (unsigned long long*)p->psum.p;
+        HIP_TRYM(hipMemsetAsync(d_psum, 0, ngrp * sizeof(unsigned long long), s));  // (the prune chain is already queued: this is behind it)
+#define LAUNCH_LEAF_EVAL_U(KK, WW, UU)                                                                                             \
+  hipLaunchKernelGGL((leaf_eval_kernel<KK, WW, UU>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), lds_m, s, p->d_code,  \
                      (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res, d_hdr,   \
-                     d_rec, (unsigned long long)nblk, d_ctr)
-        if (p->f_leaf && p->spec_leaf_k == lk) {
+                     d_rec, d_psum, (unsigned long long)nblk, d_ctr)
+        // lq == 3 (three levels or more): a wave pass is one level-3 cube (scalar, prefetched cube load); else a few leaves
+#define LAUNCH_LEAF_EVAL(KK, WW) do { if (lq == 3) LAUNCH_LEAF_EVAL_U(KK, WW, true); else LAUNCH_LEAF_EVAL_U(KK, WW, false); } while (0)
+        if (p->f_leaf && p->spec_leaf_k == lk && lq == 3) {
           HIP_TRYM(launch_fn(p->f_leaf, grid_for(bound, p->num_cu, leaf_bpc), BLOCK, lds_m, s, (const uint32_t*)p->d_code, (const Cube*)q[lq & 1]->p,
-                             (unsigned long long)capq[lq & 1], (int)lq, (int)p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec,
+                             (unsigned long long)capq[lq & 1], (int)lq, (int)p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec, d_psum,
                              (unsigned long long)nblk, d_ctr));
         } else {
           // ahead-of-time kernels exist at the scratch-free occupancies only (tests/test_kernel_resources.py)
@@ -1018,13 +1024,15 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
           else LAUNCH_LEAF_EVAL(1, 4);
         }
 #undef LAUNCH_LEAF_EVAL
+#undef LAUNCH_LEAF_EVAL_U
         HIP_TRYM(hipGetLastError());
         HIP_TRYM(hipEventRecord(p->ev[3], s));
         two_kernel = true;
-        static const int march_bpc = [] { const char* e = getenv("GSDF_HIP_MARCH_BPC"); return e ? atoi(e) : 4; }();  // tuning knob
-        const size_t lds_march = (size_t)11 * BLOCK * 4 + 5 * BLOCK * 2 + BLOCK + 256 * 16 + (size_t)MARCH_STAGE * 36 + (BLOCK + 1) * 4 + 8 * 4 + 16;
+        // one wave of workgroups: each takes an equal share of the records (computed on device from the group sums)
+        static const int march_bpc = [] { const char* e = getenv("GSDF_HIP_MARCH_BPC"); return e ? atoi(e) : 7; }();  // tuning knob (7 fit a CU)
+        const size_t lds_march = (size_t)11 * BLOCK * 4 + 5 * BLOCK * 4 + 256 * 16 + (BLOCK + 1) * 4 + 8 * 4 + 8 + 14 * 8;
         hipLaunchKernelGGL(march_records_kernel, dim3(grid_for(nblk, p->num_cu, march_bpc)), dim3(BLOCK), lds_march, s, d_hdr, d_rec,
-                           (unsigned long long)nblk, lq, ox, oy, oz, res, m->d_tris, (uint64_t)tcap, d_ctr);
+                           d_psum, (unsigned long long)nblk, lq, ox, oy, oz, res, m->d_tris, (uint64_t)tcap, d_ctr);
       } else if (lq == 3 && lk == 4 && opts.share_corners) {
         // exact corner sharing: one wave per level-3 brick
         const size_t lds_b = (size_t)(p->prog.nslots * 4) * BLOCK * sizeof(float) + 4096 + TRI_STAGE * 36 + 32 + 4 * 512 * 4 + 4 * 24 * 4;

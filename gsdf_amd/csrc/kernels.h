@@ -566,29 +566,36 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
 // and at the atomic's round trip, with only 3-4 waves per SIMD to cover for them. Here the evaluating kernel has NO
 // barrier and NO atomic in its loop -- its waves are independent -- and leaves, per 64-leaf block (one wave pass), the leaves
 // the surface cuts as compact records in HBM:
-//     hdr[block]                    = number of records (0..64)
+//     hdr[block]                    = number of records (0..64) | number of triangles << 8
 //     rec[block][r][c], c < 10      = the block's records side by side (r = rank among the wave's cut lanes): 8 corner distances
 //                                     (corner order 0..7), leaf x | y << 16, leaf z | index << 16 (40 B per cut leaf, ~16 % of
 //                                     the leaves). A block holds ~10 records: 420 contiguous bytes -- four cache lines; a
 //                                     column-major block (tried first) spread them over ten lines and made the marching
 //                                     kernel fetch 2.2x the bytes it used.
 // Sized for the worst case (64 records per block: no overflow path); only the cut leaves' lines are ever touched.
-// march_records_kernel then runs marching cubes over the records alone: 256 blocks per workgroup pass (prefix of their
-// record counts in LDS), one record per lane in chunks of 256, triangles one per lane (mc_emit_balanced) into a large LDS
-// stage (this kernel has no interpreter columns to make room for), one global append per MARCH_STAGE triangles.
+// march_records_kernel then runs marching cubes over the records alone (see there): it needs no append counter, because the
+// evaluating kernel also leaves the triangle count of every block (hdr, bits 8..) and the sums of both counts per group of
+// MARCH_GROUP blocks (psum).
 // Same float operations on the same values as the fused kernel: the leaf origin is recomputed from the stored leaf
 // coordinates by the expression the evaluation used.
 // ---------------------------------------------------------------------------------------------------------------------
 #define REC_WORDS 10            // dwords per record
 #define REC_BLOCK (64 * REC_WORDS)  // dwords per 64-leaf block
+#define MARCH_GROUP 64              // blocks per entry of the group sums (records, triangles) the evaluating kernel accumulates
 
-template <int K, int WAVES>
+// UCUBE: lq == 3 (every mesh of three levels or more): the 64 leaves of a wave pass are one level-3 cube.
+template <int K, int WAVES, bool UCUBE = true>
 __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
                                                           unsigned long long cube_cap, int lq, int nslots, float ox, float oy, float oz,
                                                           float res, uint32_t* __restrict__ hdr, uint32_t* __restrict__ rec,
-                                                          unsigned long long n_blocks_cap, MeshCounters* __restrict__ ctr) {
+                                                          unsigned long long* __restrict__ psum, unsigned long long n_blocks_cap,
+                                                          MeshCounters* __restrict__ ctr) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
+  // triangles per marching-cubes case, behind the interpreter's columns (256 B)
+  uint8_t* s_nt = (uint8_t*)(g_smem + (size_t)(nslots > 0 ? nslots : 1) * K * BLOCK);
+  s_nt[threadIdx.x] = GSDF_MC_NTRI[threadIdx.x];
+  __syncthreads();
   const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
   const int sh = lq - 1;
   unsigned long long n_cubes = uniform_u64(ctr->n_level[lq]);  // survivors of the last prune level (device-side count)
@@ -596,12 +603,27 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
   const uint64_t n_leaves = uniform_u64(n_cubes << (3 * sh));
   unsigned my_active = 0, my_cont = 0, my_cut = 0;  // wave-uniform (SGPRs)
   const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  // UCUBE: the 64 leaves of a wave pass belong to ONE cube (and n_leaves is a multiple of 64), so the cube is a scalar load --
+  // issued one pass ahead: a wave has ~5 passes and the load is a trip to L2/HBM it would otherwise sit out at every start
+  auto cube_word = [&](uint64_t b) -> unsigned long long {
+    const uint64_t li = uniform_u64(b + (threadIdx.x & ~63u));
+    if (li >= n_leaves) return 0ull;
+    return *(const unsigned long long*)(cubes + (li >> (3 * sh)));
+  };
+  unsigned long long cw_next = UCUBE ? cube_word((uint64_t)blockIdx.x * BLOCK) : 0ull;
   for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_leaves; base += step) {
     const uint64_t i = base + threadIdx.x;
-    const bool valid = i < n_leaves;
+    const bool valid = UCUBE ? uniform_u64(base + (threadIdx.x & ~63u)) < n_leaves : i < n_leaves;
     Cube lf = {0, 0, 0, 0};
+    const unsigned long long cw = cw_next;
+    if (UCUBE) {
+      cw_next = cube_word(base + step);
+      if (!valid) continue;  // wave-uniform: nothing of this pass is read by anyone
+    }
     if (valid) {
-      const Cube pc = cubes[i >> (3 * sh)];
+      Cube pc;
+      if (UCUBE) { pc.x = (uint16_t)cw; pc.y = (uint16_t)(cw >> 16); pc.z = (uint16_t)(cw >> 32); pc.w = 0; }
+      else pc = cubes[i >> (3 * sh)];
       const unsigned l = (unsigned)(i & ((1u << (3 * sh)) - 1u));
       const unsigned m = (1u << sh) - 1u;
       lf.x = (uint16_t)((pc.x << sh) + (l & m));
@@ -651,7 +673,24 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
     const uint64_t blk = uniform_u64((base + (uint64_t)(threadIdx.x & ~63u)) >> 6);  // block = wave pass = 64 consecutive leaves
     my_cut += (unsigned)__builtin_popcountll(cm);
     if (blk < n_blocks_cap) {
-      if ((threadIdx.x & 63u) == 0u) hdr[blk] = (uint32_t)__builtin_popcountll(cm);
+      // header word: records | triangles << 8; the same pair is added to the sum of the block's group of MARCH_GROUP
+      // blocks (low / high half of one 64-bit word: a fire-and-forget atomic, one per wave pass the surface cuts), from which
+      // march_records_kernel derives every workgroup's share of the records and its triangles' place in the output
+      unsigned ntri = 0;
+#ifndef GSDF_EXP_NO_NTRI  // developer experiments (GSDF_HIP_SPEC_FLAGS=-DGSDF_EXP_NO_NTRI / _NO_PSUM): what the counts cost (timing only)
+      if (cm != 0ull) {  // wave-uniform
+        const unsigned nt = cut ? (unsigned)s_nt[index] : 0u;  // 0..5
+        ntri = (unsigned)__builtin_popcountll(__ballot((nt & 1u) != 0u)) + 2u * (unsigned)__builtin_popcountll(__ballot((nt & 2u) != 0u)) +
+               4u * (unsigned)__builtin_popcountll(__ballot((nt & 4u) != 0u));
+      }
+#endif
+      if ((threadIdx.x & 63u) == 0u) {
+        const uint32_t nrec = (uint32_t)__builtin_popcountll(cm);
+        hdr[blk] = nrec | (ntri << 8);
+#ifndef GSDF_EXP_NO_PSUM
+        if (nrec) atomicAdd(&psum[blk / MARCH_GROUP], (unsigned long long)nrec | ((unsigned long long)ntri << 32));
+#endif
+      }
       if (cut) {
         uint2* w = (uint2*)(rec + blk * REC_BLOCK + rank * REC_WORDS);  // 40-byte records: 8-byte aligned, five 8-byte stores
         // dall[j] is the distance of corner order[j], order = {0,4,1,5,3,7,2,6}: corners (0,1) = dall[0], dall[2] ...
@@ -679,33 +718,138 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
   }
 }
 
-#define MARCH_STAGE 896  // triangles staged per workgroup (31.5 KB: three workgroups per CU): one global append per 896 -- a single
-                         // counter word takes ~88 atomics/us and this kernel lasts ~0.1 ms, so appends must be rare
-// LDS: [11 record columns of BLOCK floats | owner list 5*BLOCK u16 | index BLOCK u8 | tri table | stage | prefix BLOCK+1 | misc]
-__global__ void __launch_bounds__(BLOCK) march_records_kernel(const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ rec,
+// Inclusive prefix sum over the workgroup (thread order) of a 64-bit value; *total = the workgroup's sum. s_w: 4 words of LDS.
+__device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long v, unsigned long long* s_w, unsigned long long* total) {
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned lo = __shfl_up((unsigned)incl, off, 64), hi = __shfl_up((unsigned)(incl >> 32), off, 64);
+    if (lane >= (unsigned)off) incl += ((unsigned long long)hi << 32) | lo;
+  }
+  __syncthreads();  // s_w may still be read from an earlier call
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  const unsigned long long a = s_w[0], b = s_w[1], c = s_w[2], d = s_w[3];
+  *total = uniform_u64(a + b + c + d);
+  return incl + (wave > 0 ? a : 0ull) + (wave > 1 ? b : 0ull) + (wave > 2 ? c : 0ull);
+}
+
+// Marching cubes over the cut-leaf records. NO atomic, NO staging, a deterministic output.
+//  * Where things go: the evaluating kernel left, per group of MARCH_GROUP blocks, the number of records and of triangles
+//    (psum); every workgroup sums those (a few KB from L2), takes an equal share of the RECORDS -- a contiguous range of
+//    blocks, cut at block granularity -- and knows from the same sums where its first triangle goes. Triangles appear in
+//    block order, record order, table order: the same mesh in the same order on every run.
+//  * Who computes what: records are taken 256 at a time (one per lane, 8 distances + origin into LDS columns); a prefix sum of
+//    their triangle counts gives an owner list (triangle -> record, table row); then ONE OUTPUT VERTEX PER LANE: lane k of a
+//    round computes vertex k % 3 of triangle k / 3 and stores its 12 bytes at out*36 + 12 k -- one store instruction of a wave
+//    is 768 contiguous bytes, nothing is staged, and the rounds of a chunk are independent of each other (no barrier between
+//    them). (One output FLOAT per lane -- 256-byte stores, the edge parameter computed three times -- was slower: 0.127 ms.)
+//  (History: the first version appended LDS stages of 896 triangles through the one counter word, ~88 appends/us: three
+//  workgroups per CU, and a static deal of 256-block passes of which a workgroup got one or two -- it ran for two pass times
+//  with half its slots idle in the second: 0.158 ms. Known offsets + equal shares + a 512-triangle stage: 0.115 ms.)
+// LDS: [11 record columns of BLOCK floats | owner list 5*BLOCK u32 | tri table | prefix BLOCK+1 | misc] = 21.7 KB: 7 workgroups per CU
+__global__ void __launch_bounds__(BLOCK, 7) march_records_kernel(const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ rec,
+                                                              const unsigned long long* __restrict__ psum,
                                                               unsigned long long n_blocks_cap, int lq, float ox, float oy, float oz,
                                                               float res, float* __restrict__ tris, uint64_t tri_cap,
                                                               MeshCounters* __restrict__ ctr) {
-  float* s_col = g_smem;                                       // [11][BLOCK]: 8 distances + origin of the chunk's records
-  uint16_t* s_owner = (uint16_t*)(s_col + 11 * BLOCK);         // [5 * BLOCK]
-  uint8_t* s_index = (uint8_t*)(s_owner + 5 * BLOCK);          // [BLOCK]
-  int8_t* s_tri = (int8_t*)(s_index + BLOCK);
-  float* s_stage = (float*)(s_tri + 256 * 16);
-  unsigned* s_pre = (unsigned*)(s_stage + MARCH_STAGE * 9);    // [BLOCK + 1] exclusive prefix of the pass's record counts
-  unsigned* s_misc = s_pre + BLOCK + 1;                        // [0..3] wave sums (mc_emit_balanced), [4..7] wave sums of the prefix
-  unsigned long long* s_base = (unsigned long long*)(((uintptr_t)(s_misc + 8) + 7) & ~(uintptr_t)7);
-  for (int k = threadIdx.x; k < 256 * 16; k += BLOCK) s_tri[k] = GSDF_MC_TRI[k >> 4][k & 15];
-  __syncthreads();
-  unsigned cur = 0;
+  float* s_col = g_smem;                                       // [BLOCK][11]: 8 distances + origin of the chunk's records (odd stride:
+                                                               // the values of one record, read together by neighbouring lanes, sit in 11 banks)
+  uint32_t* s_own = (uint32_t*)(s_col + 11 * BLOCK);           // [5 * BLOCK] triangle -> table offset (index*16 + 3*number) | record << 12
+  int8_t* s_tri = (int8_t*)(s_own + 5 * BLOCK);
+  unsigned* s_pre = (unsigned*)(s_tri + 256 * 16);             // [BLOCK + 1] exclusive prefix of the pass's record counts
+  unsigned* s_misc = s_pre + BLOCK + 1;                        // [0..3] wave sums of the triangle counts, [4..7] of the record counts
+  unsigned long long* s_u64 = (unsigned long long*)(((uintptr_t)(s_misc + 8) + 7) & ~(uintptr_t)7);  // [0..3] scan, [4..9] found, [10..13] result
+  for (int k = threadIdx.x; k < 256 * 4; k += BLOCK) {  // the table by dwords; a row's spare byte 15 takes its triangle count
+    uint32_t w = ((const uint32_t*)&GSDF_MC_TRI[0][0])[k];
+    if ((k & 3) == 3) w = (w & 0x00ffffffu) | ((uint32_t)GSDF_MC_NTRI[k >> 2] << 24);
+    ((uint32_t*)s_tri)[k] = w;
+  }
   unsigned long long n_cubes = uniform_u64(ctr->n_level[lq]);
   const uint64_t n_leaves = n_cubes << (3 * (lq - 1));
   uint64_t n_blocks = (n_leaves + 63) >> 6;
   if (n_blocks > n_blocks_cap) n_blocks = n_blocks_cap;  // (the cube queue overflowed: the host reruns)
   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  for (uint64_t b0 = (uint64_t)blockIdx.x * BLOCK; b0 < n_blocks; b0 += (uint64_t)gridDim.x * BLOCK) {  // block-uniform
+
+  // ---- this workgroup's share of the records, and where its triangles go
+  const uint64_t n_grp = (n_blocks + MARCH_GROUP - 1) / MARCH_GROUP;
+  const uint64_t per = (n_grp + BLOCK - 1) / BLOCK;  // groups per thread (contiguous)
+  uint64_t e0 = (uint64_t)threadIdx.x * per, e1 = e0 + per;
+  if (e0 > n_grp) e0 = n_grp;
+  if (e1 > n_grp) e1 = n_grp;
+  unsigned long long lr = 0, lt = 0;
+#pragma unroll 4
+  for (uint64_t e = e0; e < e1; e++) {
+    const unsigned long long v = psum[e];
+    lr += (unsigned)v;
+    lt += v >> 32;
+  }
+  unsigned long long R, T;
+  const unsigned long long br = block_scan_u64(lr, s_u64, &R) - lr, bt = block_scan_u64(lt, s_u64, &T) - lt;
+  if (R == 0ull) return;  // no surface here (n_tris stays 0)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ctr->n_tris = T;
+    if (T > tri_cap) ctr->overflow = 1ull;  // the host learns the exact size and reruns
+  }
+  if (T > tri_cap) return;
+  const unsigned long long X0 = R * blockIdx.x / gridDim.x, X1 = R * (blockIdx.x + 1ull) / gridDim.x;  // records [X0, X1)
+  if (X0 == X1) return;
+  // the group in which the running record count reaches X (X > 0): found by the one thread whose groups straddle it
+#pragma unroll
+  for (int w = 0; w < 2; w++) {
+    const unsigned long long X = w ? X1 : X0;
+    if (br < X && X <= br + lr) {
+      unsigned long long acc = br, tacc = bt;
+      for (uint64_t e = e0; e < e1; e++) {
+        const unsigned long long v = psum[e];
+        if (acc + (unsigned)v >= X) {
+          s_u64[4 + 3 * w] = e; s_u64[5 + 3 * w] = acc; s_u64[6 + 3 * w] = tacc;
+          break;
+        }
+        acc += (unsigned)v;
+        tacc += v >> 32;
+      }
+    }
+  }
+  __syncthreads();
+  // first block whose exclusive record prefix is >= X, and the triangles before it (waves 0 and 1: X0 and X1)
+  if (wave < 2) {
+    const unsigned long long X = wave ? X1 : X0;
+    unsigned long long B = 0, tb = 0;
+    if (X != 0ull) {
+      const unsigned long long e = s_u64[4 + 3 * wave], acc = s_u64[5 + 3 * wave], tacc = s_u64[6 + 3 * wave];
+      const uint64_t b = e * MARCH_GROUP + lane;
+      const uint32_t h = b < n_blocks ? hdr[b] : 0u;
+      const unsigned nr = h & 255u, ntr = h >> 8;
+      unsigned ir = nr, it = ntr;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned ur = __shfl_up(ir, off, 64), ut = __shfl_up(it, off, 64);
+        if (lane >= (unsigned)off) { ir += ur; it += ut; }
+      }
+      const unsigned long long m = __ballot(acc + (ir - nr) >= X);
+      if (m != 0ull) {
+        const int j = __builtin_ctzll(m);
+        B = e * MARCH_GROUP + (unsigned)j;
+        tb = tacc + (unsigned)__shfl(it - ntr, j, 64);
+      } else {
+        B = (e + 1) * MARCH_GROUP;
+        tb = tacc + (unsigned)__shfl(it, 63, 64);
+      }
+    }
+    if (lane == 0) { s_u64[10 + 2 * wave] = B; s_u64[11 + 2 * wave] = tb; }
+  }
+  __syncthreads();
+  const uint64_t b_begin = uniform_u64(s_u64[10]);
+  uint64_t b_end = uniform_u64(s_u64[12]);
+  if (b_end > n_blocks) b_end = n_blocks;
+  unsigned long long out = uniform_u64(s_u64[11]);
+
+  for (uint64_t b0 = b_begin; b0 < b_end; b0 += BLOCK) {  // block-uniform
     // exclusive prefix of the record counts of blocks b0 .. b0+255
     const uint64_t b = b0 + threadIdx.x;
-    const unsigned nr = b < n_blocks ? hdr[b] : 0u;
+    const unsigned nr = b < b_end ? (hdr[b] & 255u) : 0u;
     unsigned incl = nr;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -717,16 +861,16 @@ __global__ void __launch_bounds__(BLOCK) march_records_kernel(const uint32_t* __
     const unsigned p0 = s_misc[4], p1 = s_misc[5], p2 = s_misc[6], p3 = s_misc[7];
     const unsigned wpre = (wave > 0 ? p0 : 0u) + (wave > 1 ? p1 : 0u) + (wave > 2 ? p2 : 0u);
     s_pre[threadIdx.x] = wpre + incl - nr;
-    const unsigned R = p0 + p1 + p2 + p3;  // records of this pass (block-uniform)
-    if (threadIdx.x == 0) s_pre[BLOCK] = R;
+    const unsigned Rp = __builtin_amdgcn_readfirstlane(p0 + p1 + p2 + p3);  // records of this pass (block-uniform)
+    if (threadIdx.x == 0) s_pre[BLOCK] = Rp;
     __syncthreads();
     // One record per lane in chunks of 256. The next chunk's record is fetched into registers BEFORE the current chunk is
-    // marched: with three workgroups per CU there is little else to cover the ~2 us of a dependent global load.
+    // marched: a dependent global load is ~2 us.
     uint32_t rw[REC_WORDS];
     auto fetch = [&](unsigned q) {
 #pragma unroll
       for (int c = 0; c < REC_WORDS; c++) rw[c] = 0u;
-      if (q < R) {
+      if (q < Rp) {
         // the block holding record q: largest j with s_pre[j] <= q (blocks without records share their successor's prefix)
         unsigned lo = 0, hi = BLOCK;
 #pragma unroll
@@ -734,41 +878,75 @@ __global__ void __launch_bounds__(BLOCK) march_records_kernel(const uint32_t* __
           const unsigned mid = (lo + hi) >> 1;
           if (s_pre[mid] <= q) lo = mid; else hi = mid;
         }
-        const uint2* w = (const uint2*)(rec + (b0 + lo) * REC_BLOCK + (q - s_pre[lo]) * REC_WORDS);
+        struct __attribute__((packed, aligned(8))) Rec { uint32_t w[REC_WORDS]; };  // 40 bytes, 8-byte aligned: wide loads
+#ifdef GSDF_EXP_MARCH_ONE_LINE  // developer experiment: every lane reads the FIRST record of its block (a third of the record traffic)
+        const Rec v = *(const Rec*)(rec + (b0 + lo) * REC_BLOCK);
+#else
+        const Rec v = *(const Rec*)(rec + (b0 + lo) * REC_BLOCK + (q - s_pre[lo]) * REC_WORDS);
+#endif
 #pragma unroll
-        for (int c = 0; c < REC_WORDS / 2; c++) { const uint2 v = w[c]; rw[2 * c] = v.x; rw[2 * c + 1] = v.y; }
+        for (int c = 0; c < REC_WORDS; c++) rw[c] = v.w[c];
       }
     };
     fetch(threadIdx.x);
-    for (unsigned q0 = 0; q0 < R; q0 += BLOCK) {  // block-uniform
+    for (unsigned q0 = 0; q0 < Rp; q0 += BLOCK) {  // block-uniform
       const unsigned q = q0 + threadIdx.x;
       unsigned index = 0;
-      if (q < R) {
+      if (q < Rp) {
 #pragma unroll
-        for (int c = 0; c < 8; c++) s_col[c * BLOCK + threadIdx.x] = __uint_as_float(rw[c]);
+        for (int c = 0; c < 8; c++) s_col[threadIdx.x * 11u + c] = __uint_as_float(rw[c]);
         const uint32_t xy = rw[8], zi = rw[9];
         index = zi >> 16;
         // the leaf origin exactly as the evaluating kernel formed it
-        s_col[8 * BLOCK + threadIdx.x] = ox + res * (float)(xy & 0xffffu);
-        s_col[9 * BLOCK + threadIdx.x] = oy + res * (float)(xy >> 16);
-        s_col[10 * BLOCK + threadIdx.x] = oz + res * (float)(zi & 0xffffu);
+        s_col[threadIdx.x * 11u + 8u] = ox + res * (float)(xy & 0xffffu);
+        s_col[threadIdx.x * 11u + 9u] = oy + res * (float)(xy >> 16);
+        s_col[threadIdx.x * 11u + 10u] = oz + res * (float)(zi & 0xffffu);
       }
       fetch(q + BLOCK);  // in flight while this chunk is marched
-      const unsigned index1[1] = {index};
-      mc_emit_balanced<1, MARCH_STAGE>(
-          index1, s_owner, s_index, s_tri, s_stage, s_misc, s_base, cur, res,
-          [&](unsigned id, unsigned cc) { return s_col[cc * BLOCK + id]; },
-          [&](unsigned id, float& ax, float& ay, float& az) {
-            ax = s_col[8 * BLOCK + id];
-            ay = s_col[9 * BLOCK + id];
-            az = s_col[10 * BLOCK + id];
-          },
-          tris, tri_cap, ctr);
+      // owner list: prefix sum of the records' triangle counts (the table's spare byte holds the row's count)
+      const unsigned nt = index ? (unsigned)s_tri[index * 16 + 15] : 0u;
+      unsigned ti = nt;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned u = __shfl_up(ti, off, 64);
+        if (lane >= (unsigned)off) ti += u;
+      }
+      if (lane == 63) s_misc[wave] = ti;
+      __syncthreads();
+      const unsigned w0 = __builtin_amdgcn_readfirstlane(s_misc[0]), w1 = __builtin_amdgcn_readfirstlane(s_misc[1]),
+                     w2 = __builtin_amdgcn_readfirstlane(s_misc[2]), w3 = __builtin_amdgcn_readfirstlane(s_misc[3]);
+      const unsigned total = w0 + w1 + w2 + w3;
+      const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+      const unsigned first = (wave_u > 0 ? w0 : 0u) + (wave_u > 1 ? w1 : 0u) + (wave_u > 2 ? w2 : 0u) + (ti - nt);
+      for (unsigned k = 0; k < nt; k++) s_own[first + k] = (index * 16u + 3u * k) | (threadIdx.x << 12);
+      __syncthreads();
+      // one output VERTEX per lane: a wave's store is 768 contiguous bytes
+      struct __attribute__((packed, aligned(4))) V3 { float x, y, z; };
+      V3* dst = (V3*)(tris + out * 9);
+      const unsigned n3 = total * 3u;
+#pragma unroll 2
+      for (unsigned k = threadIdx.x; k < n3; k += BLOCK) {
+        const unsigned t = k / 3u, j = k - 3u * t;
+        const uint32_t o = s_own[t];
+        const float* col = s_col + (o >> 12) * 11u;
+        const int e = s_tri[(o & 4095u) + (2u - j)];  // reversed winding (marchcubes.go:64-68)
+        const unsigned ca = GSDF_MC_PAIR_A(e), cb = GSDF_MC_PAIR_B(e);
+        const float x0 = col[8], y0 = col[9], z0 = col[10];
+        const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;  // Box max = origin + size
+        const bool ax = ((ca ^ (ca >> 1)) & 1u) != 0u, ay = ((ca >> 1) & 1u) != 0u, az = ((ca >> 2) & 1u) != 0u;
+        const bool bx = ((cb ^ (cb >> 1)) & 1u) != 0u, by = ((cb >> 1) & 1u) != 0u, bz = ((cb >> 2) & 1u) != 0u;
+        V3 r;
+        mc_interp(ax ? x1 : x0, ay ? y1 : y0, az ? z1 : z0, bx ? x1 : x0, by ? y1 : y0, bz ? z1 : z0, col[ca], col[cb], r.x, r.y, r.z);
+#ifdef GSDF_EXP_MARCH_NO_STORE  // developer experiment (library built with -D...): the kernel without its output stream (timing only)
+        if (r.x == 1.2345678e-30f) dst[k] = r;
+#else
+        dst[k] = r;
+#endif
+      }
+      out += total;
+      __syncthreads();  // the next chunk rewrites the columns, the owner list and s_misc
     }
-    __syncthreads();  // s_pre / s_misc[4..7] are rewritten by the next pass
   }
-  __syncthreads();
-  if (cur) mc_stage_flush<MARCH_STAGE>(s_stage, s_base, cur, tris, tri_cap, ctr);
 }
 
 // Leaf kernel with exact corner sharing (level-3 bricks: one wave = one brick of 4x4x4 leaves).
