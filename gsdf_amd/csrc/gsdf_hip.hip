@@ -123,7 +123,7 @@ void gsdf_program::leaf_config(int* k, int* w, size_t* lds) const {
     static const int forced_w = [] { const char* e = getenv("GSDF_HIP_LEAF_WAVES"); return e ? atoi(e) : 0; }();  // tuning knob
     const int ns = prog.nslots > 0 ? prog.nslots : 1;
     const int lk = (batch_k() == 4 && ns > 11) ? 2 : batch_k();
-    const size_t lds_e = (size_t)ns * lk * BLOCK * sizeof(float) + 256;  // + the triangles-per-case table
+    const size_t lds_e = (size_t)(ns * lk > 8 ? ns * lk : 8) * BLOCK * sizeof(float) + 256;  // (8 rows at least: a brick's distances) + the triangles-per-case table
     int ww = forced_w ? forced_w : (4 * lds_e <= 160 * 1024 ? 4 : 3);
     if (lk == 4) { if (ww != 2 && ww != 4) ww = 3; }
     else if (lk == 2) { if (ww != 4) ww = 3; }

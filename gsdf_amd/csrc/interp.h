@@ -303,8 +303,10 @@ __device__ __forceinline__ void smooth_h(const float (&num)[K], float k, float r
   }
 }
 
-// SHARE = 0: K unrelated points. SHARE = 2 (COLUMN; lattice sweeps): the K points of a lane enter with bitwise equal
-// x,y (one lattice column on K planes): instructions flagged D_FLAG_SHXY compute their f(P.x,P.y) once per lane.
+// SHARE = 0: K unrelated points. SHARE = 2 (COLUMN; lattice sweeps, the mesher's column bricks): the K points of a lane enter
+// with bitwise equal x,y (one lattice column on K planes): instructions flagged D_FLAG_SHXY compute their f(P.x,P.y) once per
+// lane. With `brick` (leaf_eval_kernel's column bricks) the caller also guarantees that point kp has the SAME z in every lane
+// of the wave: instructions flagged D_FLAG_SHZ compute their g(P.z) once per wave and point (one lane each).
 // SHARE = 1 (PAIRED; the mesher's leaf kernels): the caller passes the corners of one leaf cube in the order
 // {0,4,1,5 | 3,7,2,6}, i.e. points 2j and 2j+1 enter with bitwise equal x,y and (K = 4) points j and j+2 with equal z.
 // Instructions the host compiler flagged D_FLAG_SHXY / D_FLAG_SHZ then compute their f(P.x,P.y) / g(P.z) once per
@@ -333,6 +335,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
     const bool sh_xy = SHARE != 0 && K >= 2 && (w & D_FLAG_SHXY) != 0u;
     const bool sh_z = SHARE == 1 && K >= 4 && (w & D_FLAG_SHZ) != 0u;
     const bool sh_col = SHARE == 2;  // only read together with sh_xy
+    const bool sh_zu = SHARE == 2 && brick && (w & D_FLAG_SHZ) != 0u;  // column brick (leaf_eval_kernel): P.z of point kp is wave-uniform
     switch (op) {
       case D_END:
         return;
@@ -757,9 +760,23 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         float tc[K], ts[K];  // cos/sin(k * P.z): a function of z only
         {
           const float k = PF(0);
-          KLOOP if (kp < (K + 1) / 2) cossinf_(k * pv[kp].z, tc[kp], ts[kp]);
-          if (sh_z) { KLOOP if (kp >= (K + 1) / 2) { tc[kp] = tc[kp - K / 2]; ts[kp] = ts[kp - K / 2]; } }
-          else { KLOOP if (kp >= (K + 1) / 2) cossinf_(k * pv[kp].z, tc[kp], ts[kp]); }
+          if (sh_zu) {
+            // column brick: P.z of point kp is the same in every lane, so lane l evaluates point l % K and everyone reads
+            // lanes 0..K-1 -- one evaluation per lane instead of K (same function of the same input: same bits)
+            const uint32_t sel = lane_id() & (uint32_t)(K - 1);
+            float zs = pv[0].z;
+            KLOOP if (sel == (uint32_t)kp) zs = pv[kp].z;
+            float c1, s1;
+            cossinf_(k * zs, c1, s1);
+            KLOOP {
+              tc[kp] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c1), kp));
+              ts[kp] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s1), kp));
+            }
+          } else {
+            KLOOP if (kp < (K + 1) / 2) cossinf_(k * pv[kp].z, tc[kp], ts[kp]);
+            if (sh_z) { KLOOP if (kp >= (K + 1) / 2) { tc[kp] = tc[kp - K / 2]; ts[kp] = ts[kp - K / 2]; } }
+            else { KLOOP if (kp >= (K + 1) / 2) cossinf_(k * pv[kp].z, tc[kp], ts[kp]); }
+          }
         }
         KLOOP {
           [[maybe_unused]] P3& p = pv[kp];

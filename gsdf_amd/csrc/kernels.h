@@ -593,12 +593,24 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
   // triangles per marching-cubes case, behind the interpreter's columns (256 B)
-  uint8_t* s_nt = (uint8_t*)(g_smem + (size_t)(nslots > 0 ? nslots : 1) * K * BLOCK);
-  s_nt[threadIdx.x] = GSDF_MC_NTRI[threadIdx.x];
+  uint8_t* s_nt = (uint8_t*)(g_smem + (size_t)(nslots * K > 8 ? nslots * K : 8) * BLOCK);  // (8 rows at least: the brick's distances)
+  const int sh = lq - 1;
+  // The three loads a wave starts with -- table byte, cube count, first cube -- are issued together (one trip to memory, not
+  // three in a row: a workgroup lives for ~5 passes only). The first cube is read before the count is known: its index is
+  // clamped into the queue, and the pass is skipped below if the count says so.
+  const uint8_t nt0 = GSDF_MC_NTRI[threadIdx.x];
+  unsigned long long cw_first = 0ull;
+  if (UCUBE) {
+    uint64_t ci = uniform_u64(((uint64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63u)) >> (3 * sh));
+    if (ci >= cube_cap) ci = cube_cap - 1;
+    cw_first = *(const unsigned long long*)(cubes + ci);
+  }
+  unsigned long long n_cubes = ctr->n_level[lq];  // survivors of the last prune level (device-side count)
+  cw_first = uniform_u64(cw_first);
+  n_cubes = uniform_u64(n_cubes);
+  s_nt[threadIdx.x] = nt0;
   __syncthreads();
   const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
-  const int sh = lq - 1;
-  unsigned long long n_cubes = uniform_u64(ctr->n_level[lq]);  // survivors of the last prune level (device-side count)
   if (n_cubes > cube_cap) n_cubes = cube_cap;                  // queue overflowed: host reruns with larger queues
   const uint64_t n_leaves = uniform_u64(n_cubes << (3 * sh));
   unsigned my_active = 0, my_cont = 0, my_cut = 0;  // wave-uniform (SGPRs)
@@ -610,7 +622,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
     if (li >= n_leaves) return 0ull;
     return *(const unsigned long long*)(cubes + (li >> (3 * sh)));
   };
-  unsigned long long cw_next = UCUBE ? cube_word((uint64_t)blockIdx.x * BLOCK) : 0ull;
+  unsigned long long cw_next = cw_first;
   for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_leaves; base += step) {
     const uint64_t i = base + threadIdx.x;
     const bool valid = UCUBE ? uniform_u64(base + (threadIdx.x & ~63u)) < n_leaves : i < n_leaves;
@@ -630,41 +642,95 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
       lf.y = (uint16_t)((pc.y << sh) + ((l >> sh) & m));
       lf.z = (uint16_t)((pc.z << sh) + ((l >> (2 * sh)) & m));
     }
-    const float x0 = ox + res * (float)lf.x, y0 = oy + res * (float)lf.y, z0 = oz + res * (float)lf.z;
-    const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;  // Box max = origin + size
     unsigned index = 0;
     bool pass = false;
-    float dall[8];  // distances in evaluation order {0,4,1,5,3,7,2,6}; static shift register
+    float dc[8];  // the leaf's corner distances, by corner number
+    if (UCUBE) {
+      // COLUMN BRICK. The 512 evaluations of a brick -- 64 leaves x 8 corners -- are the product of eight x, eight y and eight z
+      // coordinates (leaf i of an axis contributes min_i = origin + res*i and max_i = min_i + res, Box{origin, origin+size}):
+      // the lane is the (x, y) COLUMN (lane & 7, lane >> 3), its points the eight z. All points of a lane enter the evaluator
+      // with the same x, y registers (SHARE = 2), so every subexpression of x and y alone is computed once per lane instead of
+      // once per point -- flagged hypot / atan2 in the interpreter, and in the specialised build whatever the compiler's value
+      // numbering finds (2-D profiles under an extrusion, sector folds of circular arrays, ...). Same points, same operations on
+      // the same values, same bits as one leaf per lane; only the assignment of points to lanes differs. The distances then
+      // change hands through the wave's own (now idle) interpreter columns: leaf (i, j, k) = lane i + 4j + 16k reads corner
+      // (cx, cy, cz) from column (2i + cx, 2j + cy), row 2k + cz.
+      const unsigned lane = threadIdx.x & 63u;
+      const unsigned bx = ((unsigned)(cw & 0xffffu)) << 2, by = ((unsigned)((cw >> 16) & 0xffffu)) << 2, bz = ((unsigned)((cw >> 32) & 0xffffu)) << 2;
+      const float xa = ox + res * (float)(uint16_t)(bx + ((lane & 7u) >> 1)), ya = oy + res * (float)(uint16_t)(by + (lane >> 4));
+      const float px = (lane & 1u) ? xa + res : xa, py = (lane & 8u) ? ya + res : ya;
+      float dall[8];  // distances of rows 0..7; static shift register
 #pragma unroll
-    for (int j = 0; j < 8; j++) dall[j] = 0.f;
+      for (int j = 0; j < 8; j++) dall[j] = 0.f;
 #pragma unroll 1
-    for (unsigned c0 = 0; c0 < 8; c0 += K) {
-      P3 pk[K];
-      float dk[K];
+      for (unsigned c0 = 0; c0 < 8; c0 += K) {
+        P3 pk[K];
+        float dk[K];
 #pragma unroll
-      for (int kp = 0; kp < K; kp++) {
-        const unsigned c = (0x62735140u >> (4u * (c0 + kp))) & 7u;
-        pk[kp].x = ((c ^ (c >> 1)) & 1u) ? x1 : x0;
-        pk[kp].y = ((c >> 1) & 1u) ? y1 : y0;
-        pk[kp].z = ((c >> 2) & 1u) ? z1 : z0;
-      }
-      gsdf_dev::sdf_eval<K, true>(code, pk, dk, lds, BLOCK, /*brick=*/sh == 2);  // lq == 3: one wave = one 4x4x4 brick
+        for (int kp = 0; kp < K; kp++) {
+          const unsigned r = c0 + kp;  // wave-uniform
+          const float za = oz + res * (float)(uint16_t)(bz + (r >> 1));
+          pk[kp].x = px;
+          pk[kp].y = py;
+          pk[kp].z = (r & 1u) ? za + res : za;
+        }
+        gsdf_dev::sdf_eval<K, 2>(code, pk, dk, lds, BLOCK, /*brick=*/true);
 #pragma unroll
-      for (int j = 0; j < 8 - K; j++) dall[j] = dall[j + K];
+        for (int j = 0; j < 8 - K; j++) dall[j] = dall[j + K];
 #pragma unroll
-      for (int kp = 0; kp < K; kp++) {
-        const unsigned c = (0x62735140u >> (4u * (c0 + kp))) & 7u;
-        dall[8 - K + kp] = dk[kp];
-        index |= (dk[kp] < 0.f ? 1u : 0u) << c;
+        for (int kp = 0; kp < K; kp++) dall[8 - K + kp] = dk[kp];
       }
-      if (c0 == 0) {
-        pass = valid && (dm::absf(dk[0]) <= cubeDiag);
-        const unsigned long long pmask = __ballot(pass);
-        if (pmask == 0ull) break;  // wave-uniform
-        const unsigned long long vmask = __ballot(valid);
-        my_active += (unsigned)__builtin_popcountll(pmask);
-        my_cont += (unsigned)__builtin_popcountll(vmask);
+      float* D = g_smem + (threadIdx.x & ~63u);  // rows of BLOCK floats; this wave's 64 columns of each
+#pragma unroll
+      for (int r = 0; r < 8; r++) D[r * BLOCK + lane] = dall[r];
+      __builtin_amdgcn_wave_barrier();  // (the wave's LDS operations execute in order; this only pins the compiler's schedule)
+      const unsigned li = lane & 3u, lj = (lane >> 2) & 3u, lk = lane >> 4;
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const unsigned cx = (c ^ (c >> 1)) & 1u, cy = (c >> 1) & 1u, cz = (c >> 2) & 1u;
+        dc[c] = D[(2u * lk + cz) * BLOCK + (2u * lj + cy) * 8u + 2u * li + cx];
+        index |= (dc[c] < 0.f ? 1u : 0u) << c;
       }
+      pass = dm::absf(dc[0]) <= cubeDiag;
+      my_active += (unsigned)__builtin_popcountll(__ballot(pass));
+      my_cont += 64u;
+    } else {
+      const float x0 = ox + res * (float)lf.x, y0 = oy + res * (float)lf.y, z0 = oz + res * (float)lf.z;
+      const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;  // Box max = origin + size
+      float dall[8];  // distances in evaluation order {0,4,1,5,3,7,2,6}; static shift register
+#pragma unroll
+      for (int j = 0; j < 8; j++) dall[j] = 0.f;
+#pragma unroll 1
+      for (unsigned c0 = 0; c0 < 8; c0 += K) {
+        P3 pk[K];
+        float dk[K];
+#pragma unroll
+        for (int kp = 0; kp < K; kp++) {
+          const unsigned c = (0x62735140u >> (4u * (c0 + kp))) & 7u;
+          pk[kp].x = ((c ^ (c >> 1)) & 1u) ? x1 : x0;
+          pk[kp].y = ((c >> 1) & 1u) ? y1 : y0;
+          pk[kp].z = ((c >> 2) & 1u) ? z1 : z0;
+        }
+        gsdf_dev::sdf_eval<K, true>(code, pk, dk, lds, BLOCK, /*brick=*/false);
+#pragma unroll
+        for (int j = 0; j < 8 - K; j++) dall[j] = dall[j + K];
+#pragma unroll
+        for (int kp = 0; kp < K; kp++) {
+          const unsigned c = (0x62735140u >> (4u * (c0 + kp))) & 7u;
+          dall[8 - K + kp] = dk[kp];
+          index |= (dk[kp] < 0.f ? 1u : 0u) << c;
+        }
+        if (c0 == 0) {
+          pass = valid && (dm::absf(dk[0]) <= cubeDiag);
+          const unsigned long long pmask = __ballot(pass);
+          if (pmask == 0ull) break;  // wave-uniform
+          const unsigned long long vmask = __ballot(valid);
+          my_active += (unsigned)__builtin_popcountll(pmask);
+          my_cont += (unsigned)__builtin_popcountll(vmask);
+        }
+      }
+      // dall[j] is the distance of corner order[j], order = {0,4,1,5,3,7,2,6}
+      dc[0] = dall[0]; dc[1] = dall[2]; dc[2] = dall[6]; dc[3] = dall[4]; dc[4] = dall[1]; dc[5] = dall[3]; dc[6] = dall[7]; dc[7] = dall[5];
     }
     const bool cut = pass && index != 0u && index != 255u;
     // compact the cut leaves of this wave's block: rank among the cut lanes, one header word per block
@@ -693,11 +759,10 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
       }
       if (cut) {
         uint2* w = (uint2*)(rec + blk * REC_BLOCK + rank * REC_WORDS);  // 40-byte records: 8-byte aligned, five 8-byte stores
-        // dall[j] is the distance of corner order[j], order = {0,4,1,5,3,7,2,6}: corners (0,1) = dall[0], dall[2] ...
-        w[0] = make_uint2(__float_as_uint(dall[0]), __float_as_uint(dall[2]));  // corners 0, 1
-        w[1] = make_uint2(__float_as_uint(dall[6]), __float_as_uint(dall[4]));  // corners 2, 3
-        w[2] = make_uint2(__float_as_uint(dall[1]), __float_as_uint(dall[3]));  // corners 4, 5
-        w[3] = make_uint2(__float_as_uint(dall[7]), __float_as_uint(dall[5]));  // corners 6, 7
+        w[0] = make_uint2(__float_as_uint(dc[0]), __float_as_uint(dc[1]));
+        w[1] = make_uint2(__float_as_uint(dc[2]), __float_as_uint(dc[3]));
+        w[2] = make_uint2(__float_as_uint(dc[4]), __float_as_uint(dc[5]));
+        w[3] = make_uint2(__float_as_uint(dc[6]), __float_as_uint(dc[7]));
         w[4] = make_uint2((uint32_t)lf.x | ((uint32_t)lf.y << 16), (uint32_t)lf.z | (index << 16));
       }
     }
