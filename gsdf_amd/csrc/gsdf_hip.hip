@@ -80,8 +80,9 @@ struct gsdf_program {
       return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-  } q0, q1, ctr, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, flat_grid, rec, hdr, psum;  // rec / hdr / psum: cut-leaf records, block headers and group sums of the two-kernel leaf phase  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
+  } q0, q1, ctr, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, flat_grid, rec, hdr;  // rec / hdr: cut-leaf records and block headers of the two-kernel leaf phase (the group sums follow the counters in ctr)  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  void* h_ctr = nullptr;  // pinned host copy of the device counters (a pageable destination makes the D2H copy a staged, blocking one)
   uint64_t last_tris = 0;  // triangle count of the previous mesh on this handle: sizes the next output buffer
   uint64_t last_dc_cubes = 0;  // kept cubes of the previous dual contouring pass: sizes the next queues
   // run-time specialised kernels for this program (gsdf_hip_program_specialize): hiprtc module, else interpreter
@@ -596,9 +597,10 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (p->spec_mod3) (void)hipModuleUnload(p->spec_mod3);
   if (p->spec_mod4) (void)hipModuleUnload(p->spec_mod4);
   p->q0.release(); p->q1.release(); p->ctr.release();
-  p->rec.release(); p->hdr.release(); p->psum.release();
+  p->rec.release(); p->hdr.release();
   p->flat_grid.release(); p->dc_grid.release(); p->dc_dist.release(); p->dc_fv.release(); p->dc_nrm.release(); p->dc_edge.release();
   for (auto e : p->ev) if (e) (void)hipEventDestroy(e);
+  if (p->h_ctr) (void)hipHostFree(p->h_ctr);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
 }
@@ -907,8 +909,8 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     if (_e != hipSuccess) return bail(fail(GSDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
   } while (0)
 
-  HIP_TRYM(p->ctr.ensure(sizeof(MeshCounters)));
-  MeshCounters* d_ctr = (MeshCounters*)p->ctr.p;
+  if (!p->h_ctr) HIP_TRYM(hipHostMalloc(&p->h_ctr, 4096, hipHostMallocDefault));
+  static_assert(sizeof(MeshCounters) <= 2048, "counters: first half of the pinned block (second half: DCCounters)");
   for (auto& e : p->ev)
     if (!e) HIP_TRYM(hipEventCreate(&e));
   hipEvent_t ev0 = p->ev[0], ev1 = p->ev[1], ev2 = p->ev[2];
@@ -933,7 +935,10 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     if (qcap < 64) qcap = 64;
   }
   uint64_t want = opts.max_tris;
-  MeshCounters hc{};
+  MeshCounters& hc = *(MeshCounters*)p->h_ctr;
+  hc = MeshCounters{};
+  MeshCounters* d_ctr = nullptr;
+  constexpr size_t kCtrBytes = (sizeof(MeshCounters) + 255) & ~(size_t)255;  // the group sums follow the counters: one memset clears both
   bool used_brick = false, two_kernel = false;
   float ms01 = 0, ms12 = 0, ms13 = 0;
   for (int attempt = 0;; attempt++) {
@@ -962,7 +967,18 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
         }
       }
     }
-    HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(MeshCounters), s));
+    // 64-leaf blocks the queue capacity allows for, and their groups (two-kernel leaf phase)
+    uint64_t lbound = capq[lq & 1] << (3 * (lq - 1));
+    {
+      const uint64_t full = (levels - lq) * 3 >= 40 ? UINT64_MAX : ((uint64_t)1 << (3 * (levels - 1)));
+      if (lbound > full) lbound = full;
+    }
+    const uint64_t nblk = (lbound + 63) / 64, ngrp = (nblk + MARCH_GROUP - 1) / MARCH_GROUP;
+    const bool want_two = !fused_leaf() && !(lq == 3 && lk == 4 && opts.share_corners);
+    const size_t clear_bytes = kCtrBytes + (want_two ? ngrp * sizeof(unsigned long long) : 0);
+    HIP_TRYM(p->ctr.ensure(clear_bytes));
+    d_ctr = (MeshCounters*)p->ctr.p;
+    HIP_TRYM(hipMemsetAsync(d_ctr, 0, clear_bytes, s));
     HIP_TRYM(hipEventRecord(ev0, s));
     static const int prune_bpc = [] { const char* e = getenv("GSDF_HIP_PRUNE_BPC"); return e ? atoi(e) : 4; }();  // tuning knob
     for (int level = levels; level >= lq; level--) {
@@ -987,26 +1003,20 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     }
     HIP_TRYM(hipEventRecord(ev1, s));
     {
-      uint64_t bound = capq[lq & 1] << (3 * (lq - 1));
-      const uint64_t full = (levels - lq) * 3 >= 40 ? UINT64_MAX : ((uint64_t)1 << (3 * (levels - 1)));
-      if (bound > full) bound = full;
+      const uint64_t bound = lbound;
       const unsigned long long tcap = opts.max_tris ? opts.max_tris : m->cap;
       static const int leaf_bpc = [] { const char* e = getenv("GSDF_HIP_LEAF_BPC"); return e ? atoi(e) : 64; }();  // grid = up to 64 workgroups per CU (4 resident): a few grid-stride iterations each, so the CUs drain evenly at the end (8 per CU: +8 % kernel time; one iteration per workgroup: +10 %)
 #define LAUNCH_LEAF(KK, WW)                                                                                           \
   hipLaunchKernelGGL((leaf_kernel<KK, WW>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), lds_m, s, p->d_code,      \
                      (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res,  \
                      m->d_tris, tcap, d_ctr)
-      if (!fused_leaf() && !(lq == 3 && lk == 4 && opts.share_corners)) {
+      if (want_two) {
         // two kernels: evaluation + cut-leaf records, then marching cubes over the records
-        const uint64_t nblk = (bound + 63) / 64;  // 64-leaf blocks the queue capacity allows for
         HIP_TRYM(p->hdr.ensure(nblk * sizeof(uint32_t)));
         HIP_TRYM(p->rec.ensure(nblk * (size_t)REC_BLOCK * sizeof(uint32_t)));
-        const uint64_t ngrp = (nblk + MARCH_GROUP - 1) / MARCH_GROUP;
-        HIP_TRYM(p->psum.ensure(ngrp * sizeof(unsigned long long)));
         uint32_t* d_hdr = (uint32_t*)p->hdr.p;
         uint32_t* d_rec = (uint32_t*)p->rec.p;
-        unsigned long long* d_psum = (unsigned long long*)p->psum.p;
-        HIP_TRYM(hipMemsetAsync(d_psum, 0, ngrp * sizeof(unsigned long long), s));  // (the prune chain is already queued: this is behind it)
+        unsigned long long* d_psum = (unsigned long long*)((char*)p->ctr.p + kCtrBytes);  // cleared with the counters
 #define LAUNCH_LEAF_EVAL_U(KK, WW, UU)                                                                                             \
   hipLaunchKernelGGL((leaf_eval_kernel<KK, WW, UU>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), lds_m, s, p->d_code,  \
                      (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res, d_hdr,   \
