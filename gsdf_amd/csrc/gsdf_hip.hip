@@ -1315,6 +1315,7 @@ extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, in
   const unsigned nx = (unsigned)nd[0], ny = (unsigned)nd[1], nz = (unsigned)nd[2];
   const unsigned sx = nx + 1, sy = ny + 1;
   const uint64_t sxy = (uint64_t)sx * sy;
+  const uint64_t pxy = (uint64_t)FLAT_PITCH(sx) * sy;  // the grid's rows are padded to 256 bytes
   const float ox = mn[0], oy = mn[1], oz = mn[2];
   // this rank's cubes in z and the lattice planes they touch
   uint32_t c0 = 0, c1 = 0;
@@ -1340,14 +1341,14 @@ extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, in
   {
     // refuse up front what cannot fit (a failed multi-hundred-GB hipMalloc is slow and leaves the allocator fragmented)
     size_t mfree = 0, mtotal = 0;
-    const double need = (double)sxy * (double)nk * sizeof(float);
+    const double need = (double)pxy * (double)nk * sizeof(float);
     if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && need > (double)mfree + (double)p->flat_grid.cap)
       return bail(fail(GSDF_ERR_CAPACITY, "flat renderer: the distance grid (" + std::to_string((unsigned long long)(need / 1e9)) +
                                               " GB) does not fit the device memory; use the octree renderer at this resolution"));
   }
-  if (p->flat_grid.ensure(sxy * nk * sizeof(float)) != hipSuccess) {
+  if (p->flat_grid.ensure(pxy * nk * sizeof(float)) != hipSuccess) {
     (void)hipGetLastError();
-    return bail(fail(GSDF_ERR_CAPACITY, "flat renderer: no device memory for the distance grid (" + std::to_string(sxy * nk * 4) + " bytes)"));
+    return bail(fail(GSDF_ERR_CAPACITY, "flat renderer: no device memory for the distance grid (" + std::to_string(pxy * nk * 4) + " bytes)"));
   }
   float* grid = (float*)p->flat_grid.p;
   const int ek = p->batch_k();

@@ -1137,6 +1137,9 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_brick_kernel(const uint32_t
 // its K points enter the evaluator with bitwise equal x,y (COLUMN mode: every hypot/atan2 of x,y is computed once per
 // lane, not once per point); a workgroup pass covers BLOCK columns of one group of K planes, and stores stay coalesced
 // (consecutive lanes = consecutive columns of a plane). (i,j) comes from one division per lane and pass.
+// Rows of the distance grid start on a 256-byte boundary (pitch = sx rounded up to 64 floats): flat_march_kernel's row loads
+// (64 lanes x 4 B) then cover two 128-byte lines instead of straddling three.
+#define FLAT_PITCH(sx) (((sx) + 63u) & ~63u)
 template <int K, int W = 3>
 __global__ void __launch_bounds__(BLOCK, W) flat_grid_kernel(const uint32_t* __restrict__ code_g, float ox, float oy, float oz, float res,
                                                              unsigned sx, unsigned sy, unsigned kfirst, unsigned nk,
@@ -1161,7 +1164,7 @@ __global__ void __launch_bounds__(BLOCK, W) flat_grid_kernel(const uint32_t* __r
 #pragma unroll
     for (int z = 0; z < K; z++) {
       const unsigned k = g * K + (unsigned)z;
-      if (col < sxy && k < nk) grid[(uint64_t)k * sxy + col] = d[z];
+      if (col < sxy && k < nk) grid[(uint64_t)k * FLAT_PITCH(sx) * sy + (uint64_t)j * FLAT_PITCH(sx) + i] = d[z];
     }
   }
 }
@@ -1171,8 +1174,8 @@ __global__ void __launch_bounds__(BLOCK, W) flat_grid_kernel(const uint32_t* __r
 // glrender/flatrenderer.go:186-256). HBM-bound by design: 4 B per lattice corner in, 36 B per triangle out. Round 2:
 // every WAVE on its own -- no workgroup barrier and no shared stage in the loop (round 1's kernel had one barrier per
 // pass and its waves waited 68 % of their cycles at 32 % of the HBM peak).
-//   * a wave pass = 64 consecutive x cubes x FLAT_ROWS rows at one z: corner 0 of the four rows per lane, prefetched one
-//     pass ahead; the other seven corners only in waves where some lane passes the reference's |d0| <= 2*sqrt3*res test
+//   * a wave pass = 64 consecutive x cubes x FLAT_ROWS rows at one z: corner 0 of the rows per lane, prefetched two
+//     passes ahead; the other seven corners only in waves where some lane passes the reference's |d0| <= 2*sqrt3*res test
 //     (:207-209); ~95 % of the passes end there;
 //   * cubes the surface cuts are appended (ballot rank) as records -- 8 distances, cube coordinates, case index -- to a
 //     buffer of FLAT_WAVE_RECS records in LDS that only this wave touches;
@@ -1183,14 +1186,14 @@ __global__ void __launch_bounds__(BLOCK, W) flat_grid_kernel(const uint32_t* __r
 // LDS: [tri table 4 KB (row byte 15 = triangle count) | 4 x FLAT_WAVE_RECS x 10 words].
 #define FLAT_ROWS 8
 #define FLAT_WAVE_RECS 192
-__global__ void __launch_bounds__(BLOCK) flat_march_kernel(const float* __restrict__ grid, unsigned nx, unsigned ny, unsigned ncz,
+__global__ void __launch_bounds__(BLOCK, 4) flat_march_kernel(const float* __restrict__ grid, unsigned nx, unsigned ny, unsigned ncz,
                                                            unsigned czfirst, float ox, float oy, float oz, float res,
                                                            float* __restrict__ tris, uint64_t tri_cap, MeshCounters* __restrict__ ctr) {
   int8_t* s_tri = (int8_t*)g_smem;
   uint32_t* buf = (uint32_t*)(s_tri + 256 * 16) + (threadIdx.x >> 6) * (FLAT_WAVE_RECS * REC_WORDS);  // [REC_WORDS][FLAT_WAVE_RECS], this wave's
   for (int k = threadIdx.x; k < 256 * 16; k += BLOCK) s_tri[k] = (k & 15) == 15 ? (int8_t)GSDF_MC_NTRI[k >> 4] : GSDF_MC_TRI[k >> 4][k & 15];
   __syncthreads();
-  const unsigned sx = nx + 1;
+  const unsigned sx = FLAT_PITCH(nx + 1);  // row pitch
   const uint64_t sxy = (uint64_t)sx * (ny + 1);
   const unsigned lane = threadIdx.x & 63u;
   const unsigned txn = (nx + 63) / 64, tyn = (ny + FLAT_ROWS - 1) / FLAT_ROWS;
@@ -1245,9 +1248,14 @@ __global__ void __launch_bounds__(BLOCK) flat_march_kernel(const float* __restri
             float rx, ry, rz;
             mc_interp(ax ? x1 : x0, ay ? y1 : y0, az ? z1 : z0, bx ? x1 : x0, by ? y1 : y0, bz ? z1 : z0,
                       __uint_as_float(buf[ca * FLAT_WAVE_RECS + i]), __uint_as_float(buf[cb * FLAT_WAVE_RECS + i]), rx, ry, rz);
+#ifdef GSDF_EXP_FLAT_NO_STORE  // developer experiment: no output stream (timing only)
+            if (rx == 1.2345678e-30f) dst[9 * k + 3 * j] = rx;
+            (void)ry; (void)rz;
+#else
             dst[9 * k + 3 * j + 0] = rx;
             dst[9 * k + 3 * j + 1] = ry;
             dst[9 * k + 3 * j + 2] = rz;
+#endif
           }
         }
       }
@@ -1271,64 +1279,84 @@ __global__ void __launch_bounds__(BLOCK) flat_march_kernel(const float* __restri
     for (int r = 0; r < FLAT_ROWS; r++) d0[r] = (cx < nx && cy0 + (unsigned)r < ny) ? g0[(uint64_t)r * sx] : __builtin_inff();
   };
   const unsigned wid = blockIdx.x * 4u + (threadIdx.x >> 6), wstride = gridDim.x * 4u;
-  float dnext[FLAT_ROWS];
-  unsigned ntx = 0, nty = 0, ncz_ = 0;
+  // corner 0 of the next TWO passes is in flight while a pass is examined: with one (round 2's first version) a wave had
+  // 2 KB outstanding, 12 waves per CU (166 registers: the seven other corners of all eight rows were loaded together) --
+  // a quarter of what 8 TB/s needs at ~2 us per trip. Now 4 KB per wave at 16 waves per CU.
+  float dn1[FLAT_ROWS], dn2[FLAT_ROWS];
+  unsigned t1x = 0, t1y = 0, t1z = 0, t2x = 0, t2y = 0, t2z = 0;
+#pragma unroll
+  for (int r = 0; r < FLAT_ROWS; r++) dn1[r] = dn2[r] = __builtin_inff();
   if (wid < npass) {
-    pass_coords(wid, ntx, nty, ncz_);
-    load_d0(ntx, nty, ncz_, dnext);
+    pass_coords(wid, t1x, t1y, t1z);
+    load_d0(t1x, t1y, t1z, dn1);
+  }
+  if ((uint64_t)wid + wstride < npass) {
+    pass_coords(wid + wstride, t2x, t2y, t2z);
+    load_d0(t2x, t2y, t2z, dn2);
   }
   for (unsigned w = wid; w < npass; w += wstride) {  // wave-uniform
-    const unsigned tx = ntx, ty = nty, cz = ncz_;
+    const unsigned tx = t1x, ty = t1y, cz = t1z;
     const unsigned cx = tx * 64 + lane, cy0 = ty * FLAT_ROWS;
     const float* g0 = grid + (uint64_t)cz * sxy + (uint64_t)cy0 * sx + cx;
     float d0[FLAT_ROWS];
     bool any_act = false;
 #pragma unroll
     for (int r = 0; r < FLAT_ROWS; r++) {
-      d0[r] = dnext[r];
+      d0[r] = dn1[r];
+      dn1[r] = dn2[r];
       any_act = any_act || dm::absf(d0[r]) <= cubeDiag;
     }
-    if (w + wstride < npass) {
-      pass_coords(w + wstride, ntx, nty, ncz_);
-      load_d0(ntx, nty, ncz_, dnext);
+    t1x = t2x; t1y = t2y; t1z = t2z;
+    if ((uint64_t)w + 2ull * wstride < npass) {
+      pass_coords(w + 2u * wstride, t2x, t2y, t2z);
+      load_d0(t2x, t2y, t2z, dn2);
     }
     if (__ballot(any_act) == 0ull) continue;  // wave-uniform
-    // the other seven corners of every active cube of the pass, ALL rows' loads issued before the first is used: a load
-    // takes ~2 us under load, and paying that once per active row (tried first) is what bounded this kernel, not bandwidth
-    float v[FLAT_ROWS][7];
+#ifdef GSDF_EXP_FLAT_STREAM_ONLY  // developer experiment: the streaming read of corner 0 alone (timing only)
+    my_active += 1u;
+    continue;
+#endif
+    // the other seven corners of the active cubes, two rows at a time (all 14 loads issued before the first is used)
 #pragma unroll
-    for (int r = 0; r < FLAT_ROWS; r++) {
-      const float* q = g0 + (uint64_t)r * sx;
-      const bool act = dm::absf(d0[r]) <= cubeDiag;
-      v[r][0] = act ? q[1] : 0.f; v[r][1] = act ? q[1 + sx] : 0.f; v[r][2] = act ? q[sx] : 0.f; v[r][3] = act ? q[sxy] : 0.f;
-      v[r][4] = act ? q[sxy + 1] : 0.f; v[r][5] = act ? q[sxy + 1 + sx] : 0.f; v[r][6] = act ? q[sxy + sx] : 0.f;
-    }
+    for (int r0 = 0; r0 < FLAT_ROWS; r0 += 2) {
+      const bool act0 = dm::absf(d0[r0]) <= cubeDiag, act1 = dm::absf(d0[r0 + 1]) <= cubeDiag;
+      if (__ballot(act0 || act1) == 0ull) continue;  // wave-uniform
+      float v[2][7];
 #pragma unroll
-    for (int r = 0; r < FLAT_ROWS; r++) {
-      const bool act = dm::absf(d0[r]) <= cubeDiag;
-      const unsigned long long am = __ballot(act);
-      if (am == 0ull) continue;  // wave-uniform
-      my_active += (unsigned)__builtin_popcountll(am);
-      unsigned ix = 0;
-      if (act) {
-        ix = (d0[r] < 0.f ? 1u : 0u);
-#pragma unroll
-        for (int c = 0; c < 7; c++) ix |= (v[r][c] < 0.f ? 1u : 0u) << (c + 1);
-        if (ix == 255u) ix = 0u;
+      for (int h = 0; h < 2; h++) {
+        const float* q = g0 + (uint64_t)(r0 + h) * sx;
+        const bool act = h ? act1 : act0;
+        v[h][0] = act ? q[1] : 0.f; v[h][1] = act ? q[1 + sx] : 0.f; v[h][2] = act ? q[sx] : 0.f; v[h][3] = act ? q[sxy] : 0.f;
+        v[h][4] = act ? q[sxy + 1] : 0.f; v[h][5] = act ? q[sxy + 1 + sx] : 0.f; v[h][6] = act ? q[sxy + sx] : 0.f;
       }
-      const unsigned long long cm = __ballot(ix != 0u);
-      if (cm == 0ull) continue;  // wave-uniform
-      if (cnt + 64u > FLAT_WAVE_RECS) flush();  // room for a whole row
-      if (ix) {
-        const unsigned pos = cnt + below(cm);
-        buf[0 * FLAT_WAVE_RECS + pos] = __float_as_uint(d0[r]);
 #pragma unroll
-        for (int c = 0; c < 7; c++) buf[(c + 1) * FLAT_WAVE_RECS + pos] = __float_as_uint(v[r][c]);
-        buf[8 * FLAT_WAVE_RECS + pos] = cx | ((cy0 + (unsigned)r) << 16);
-        buf[9 * FLAT_WAVE_RECS + pos] = (czfirst + cz) | (ix << 16);
+      for (int h = 0; h < 2; h++) {
+        const int r = r0 + h;
+        const bool act = h ? act1 : act0;
+        const unsigned long long am = __ballot(act);
+        if (am == 0ull) continue;  // wave-uniform
+        my_active += (unsigned)__builtin_popcountll(am);
+        unsigned ix = 0;
+        if (act) {
+          ix = (d0[r] < 0.f ? 1u : 0u);
+#pragma unroll
+          for (int c = 0; c < 7; c++) ix |= (v[h][c] < 0.f ? 1u : 0u) << (c + 1);
+          if (ix == 255u) ix = 0u;
+        }
+        const unsigned long long cm = __ballot(ix != 0u);
+        if (cm == 0ull) continue;  // wave-uniform
+        if (cnt + 64u > FLAT_WAVE_RECS) flush();  // room for a whole row
+        if (ix) {
+          const unsigned pos = cnt + below(cm);
+          buf[0 * FLAT_WAVE_RECS + pos] = __float_as_uint(d0[r]);
+#pragma unroll
+          for (int c = 0; c < 7; c++) buf[(c + 1) * FLAT_WAVE_RECS + pos] = __float_as_uint(v[h][c]);
+          buf[8 * FLAT_WAVE_RECS + pos] = cx | ((cy0 + (unsigned)r) << 16);
+          buf[9 * FLAT_WAVE_RECS + pos] = (czfirst + cz) | (ix << 16);
+        }
+        cnt += (unsigned)__builtin_popcountll(cm);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       }
-      cnt += (unsigned)__builtin_popcountll(cm);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
   }
   flush();
