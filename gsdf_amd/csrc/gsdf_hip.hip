@@ -97,6 +97,12 @@ struct gsdf_program {
   // waves/SIMD instead of K = 4 at 2 (knurled-cylinder: 23.3 vs 23.8 ms). A 4th wave per SIMD is worth more than the
   // ~30 VGPRs it costs (flange 3.28 -> 2.95 ms), but only if 4 workgroups fit the CU's 160 KB of LDS.
   void leaf_config(int* k, int* w, size_t* lds) const;
+  bool leaf_nt_in_lds() const {  // see leaf_config
+    const int ns = prog.nslots > 0 ? prog.nslots : 1;
+    const int lk = (batch_k() == 4 && ns > 11) ? 2 : batch_k();
+    const size_t rows_e = (size_t)(ns * lk > 8 ? ns * lk : 8) * BLOCK * sizeof(float);
+    return !(4 * rows_e <= 160 * 1024 && 4 * (rows_e + 256) > 160 * 1024);
+  }
   size_t lds_bytes(int k = 1) const { return (size_t)(prog.nslots > 0 ? prog.nslots : 1) * k * BLOCK * sizeof(float); }
   // Workgroups per CU the lattice/eval sweeps are compiled for (their W template argument): 4 when the LDS allows it.
   int sweep_waves(int k) const {
@@ -124,7 +130,10 @@ void gsdf_program::leaf_config(int* k, int* w, size_t* lds) const {
     static const int forced_w = [] { const char* e = getenv("GSDF_HIP_LEAF_WAVES"); return e ? atoi(e) : 0; }();  // tuning knob
     const int ns = prog.nslots > 0 ? prog.nslots : 1;
     const int lk = (batch_k() == 4 && ns > 11) ? 2 : batch_k();
-    const size_t lds_e = (size_t)(ns * lk > 8 ? ns * lk : 8) * BLOCK * sizeof(float) + 256;  // (8 rows at least: a brick's distances) + the triangles-per-case table
+    // (8 rows at least: a brick's distances) + the 256-byte triangles-per-case table, unless it is exactly that table which
+    // would cost the fourth workgroup per CU (40 rows = 40 KB): the kernel then reads the counts from the table in global memory
+    const size_t rows_e = (size_t)(ns * lk > 8 ? ns * lk : 8) * BLOCK * sizeof(float);
+    const size_t lds_e = rows_e + (leaf_nt_in_lds() ? 256 : 0);
     int ww = forced_w ? forced_w : (4 * lds_e <= 160 * 1024 ? 4 : 3);
     if (lk == 4) { if (ww != 2 && ww != 4) ww = 3; }
     else if (lk == 2) { if (ww != 4) ww = 3; }
@@ -1020,13 +1029,13 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
 #define LAUNCH_LEAF_EVAL_U(KK, WW, UU)                                                                                             \
   hipLaunchKernelGGL((leaf_eval_kernel<KK, WW, UU>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), lds_m, s, p->d_code,  \
                      (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res, d_hdr,   \
-                     d_rec, d_psum, (unsigned long long)nblk, d_ctr)
+                     d_rec, d_psum, (unsigned long long)nblk, (int)(p->leaf_nt_in_lds() ? 1 : 0), d_ctr)
         // lq == 3 (three levels or more): a wave pass is one level-3 cube (scalar, prefetched cube load); else a few leaves
 #define LAUNCH_LEAF_EVAL(KK, WW) do { if (lq == 3) LAUNCH_LEAF_EVAL_U(KK, WW, true); else LAUNCH_LEAF_EVAL_U(KK, WW, false); } while (0)
         if (p->f_leaf && p->spec_leaf_k == lk && lq == 3) {
           HIP_TRYM(launch_fn(p->f_leaf, grid_for(bound, p->num_cu, leaf_bpc), BLOCK, lds_m, s, (const uint32_t*)p->d_code, (const Cube*)q[lq & 1]->p,
                              (unsigned long long)capq[lq & 1], (int)lq, (int)p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec, d_psum,
-                             (unsigned long long)nblk, d_ctr));
+                             (unsigned long long)nblk, (int)(p->leaf_nt_in_lds() ? 1 : 0), d_ctr));
         } else {
           // ahead-of-time kernels exist at the scratch-free occupancies only (tests/test_kernel_resources.py)
           if (lk == 4) { if (lw == 2) LAUNCH_LEAF_EVAL(4, 2); else LAUNCH_LEAF_EVAL(4, 3); }

@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
                                                           unsigned long long cube_cap, int lq, int nslots, float ox, float oy, float oz,
                                                           float res, uint32_t* __restrict__ hdr, uint32_t* __restrict__ rec,
                                                           unsigned long long* __restrict__ psum, unsigned long long n_blocks_cap,
-                                                          MeshCounters* __restrict__ ctr) {
+                                                          int nt_lds, MeshCounters* __restrict__ ctr) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
   // triangles per marching-cubes case, behind the interpreter's columns (256 B)
@@ -598,7 +598,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
   // The three loads a wave starts with -- table byte, cube count, first cube -- are issued together (one trip to memory, not
   // three in a row: a workgroup lives for ~5 passes only). The first cube is read before the count is known: its index is
   // clamped into the queue, and the pass is skipped below if the count says so.
-  const uint8_t nt0 = GSDF_MC_NTRI[threadIdx.x];
+  const uint8_t nt0 = nt_lds ? GSDF_MC_NTRI[threadIdx.x] : (uint8_t)0;  // (nt_lds = 0: no room for the table, the host says)
   unsigned long long cw_first = 0ull;
   if (UCUBE) {
     uint64_t ci = uniform_u64(((uint64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63u)) >> (3 * sh));
@@ -608,8 +608,10 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
   unsigned long long n_cubes = ctr->n_level[lq];  // survivors of the last prune level (device-side count)
   cw_first = uniform_u64(cw_first);
   n_cubes = uniform_u64(n_cubes);
-  s_nt[threadIdx.x] = nt0;
-  __syncthreads();
+  if (nt_lds) {  // block-uniform
+    s_nt[threadIdx.x] = nt0;
+    __syncthreads();
+  }
   const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
   if (n_cubes > cube_cap) n_cubes = cube_cap;                  // queue overflowed: host reruns with larger queues
   const uint64_t n_leaves = uniform_u64(n_cubes << (3 * sh));
@@ -745,7 +747,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
       unsigned ntri = 0;
 #ifndef GSDF_EXP_NO_NTRI  // developer experiments (GSDF_HIP_SPEC_FLAGS=-DGSDF_EXP_NO_NTRI / _NO_PSUM): what the counts cost (timing only)
       if (cm != 0ull) {  // wave-uniform
-        const unsigned nt = cut ? (unsigned)s_nt[index] : 0u;  // 0..5
+        const unsigned nt = cut ? (unsigned)(nt_lds ? s_nt[index] : GSDF_MC_NTRI[index]) : 0u;  // 0..5
         ntri = (unsigned)__builtin_popcountll(__ballot((nt & 1u) != 0u)) + 2u * (unsigned)__builtin_popcountll(__ballot((nt & 2u) != 0u)) +
                4u * (unsigned)__builtin_popcountll(__ballot((nt & 4u) != 0u));
       }
