@@ -135,7 +135,7 @@ void gsdf_program::leaf_config(int* k, int* w, size_t* lds) const {
     const size_t rows_e = (size_t)(ns * lk > 8 ? ns * lk : 8) * BLOCK * sizeof(float);
     const size_t lds_e = rows_e + (leaf_nt_in_lds() ? 256 : 0);
     int ww = forced_w ? forced_w : (4 * lds_e <= 160 * 1024 ? 4 : 3);
-    if (lk == 4) { if (ww != 2 && ww != 4) ww = 3; }
+    if (lk == 4) { if (ww != 2 && ww != 4 && !(ww == 5 && 5 * lds_e <= 160 * 1024)) ww = 3; }
     else if (lk == 2) { if (ww != 4) ww = 3; }
     else ww = 4;
     *k = lk; *w = ww; *lds = lds_e;
@@ -451,6 +451,9 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
   if (!p->prog.is2d) {
     names.push_back("prune_kernel");
     names.push_back(std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(lw) + (fused_leaf() ? ">" : ", true>"));
+    // a fifth workgroup per CU where the LDS has room for it (npt-flange's 7 slots): the 96-register build is taken if the
+    // compiler reaches it without scratch (-3 % on the evaluating kernel); built beside the 128-register one, same process
+    if (!fused_leaf() && lk == 4 && lw == 4 && 5 * lds_m <= (size_t)160 * 1024) names.push_back("leaf_eval_kernel<4, 5, true>");
   }
   std::vector<hipFunction_t> f;
   hipModule_t mod = nullptr;
@@ -482,6 +485,11 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
     spec_report("specialised", names[2], f[2], okl);
     p->f_prune = okp ? f[1] : nullptr;
     p->f_leaf = okl ? f[2] : nullptr;
+    if (f.size() > 3) {
+      const bool ok5 = fn_scratch_bytes(f[3]) == 0;
+      spec_report("specialised", names[3], f[3], ok5);
+      if (ok5) { p->f_leaf = f[3]; p->spec_leaf_w = 5; okl = true; }
+    }
     // the leaf kernel is where the time goes: before giving it up, trade occupancy for registers (W = workgroups per CU
     // the register budget is sized for; the launch is the same)
     for (int w2 = lw - 1; !okl && w2 >= 2; w2--) {
