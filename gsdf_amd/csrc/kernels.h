@@ -802,11 +802,11 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
   return incl + (wave > 0 ? a : 0ull) + (wave > 1 ? b : 0ull) + (wave > 2 ? c : 0ull);
 }
 
-// Marching cubes over the cut-leaf records. NO atomic, NO staging, a deterministic output.
+// Marching cubes over the cut-leaf records. NO atomic, NO staging.
 //  * Where things go: the evaluating kernel left, per group of MARCH_GROUP blocks, the number of records and of triangles
 //    (psum); every workgroup sums those (a few KB from L2), takes an equal share of the RECORDS -- a contiguous range of
 //    blocks, cut at block granularity -- and knows from the same sums where its first triangle goes. Triangles appear in
-//    block order, record order, table order: the same mesh in the same order on every run.
+//    block order, record order, table order (a pure function of the survivor queue's order).
 //  * Who computes what: records are taken 256 at a time (one per lane, 8 distances + origin into LDS columns); a prefix sum of
 //    their triangle counts gives an owner list (triangle -> record, table row); then ONE OUTPUT VERTEX PER LANE: lane k of a
 //    round computes vertex k % 3 of triangle k / 3 and stores its 12 bytes at out*36 + 12 k -- one store instruction of a wave
