@@ -216,7 +216,10 @@ def main():
     torch.cuda.set_device(local_rank if world > 1 else 0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     hip.init(dev.index)
-    if world > 1:
+    # (developer knobs, used by tools/gpu_dist1.sh to run the N > 1 code path on the one GPU a gpurun box has:
+    # GSDF_BENCH_FORCE_DIST=1 takes it at world size 1, GSDF_BENCH_FORCE_TORCH_GATHER=1 also forces its fallback)
+    force_dist = bool(os.environ.get("GSDF_BENCH_FORCE_DIST"))
+    if world > 1 or force_dist:
         # Data plane: the library's own RCCL communicator (gsdf_hip_comm_*, one rank per GPU over xGMI) -- the triangle
         # all-gatherv runs inside libgsdfhip.so, exactly what a Go caller of the C ABI would use. Control plane
         # (rendezvous of the 128-byte RCCL id, barriers, three scalars at the end): torch.distributed over gloo.
@@ -227,7 +230,7 @@ def main():
             ids = [hip.CommHIP.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
             comm = hip.CommHIP(ids[0], rank, world)
-            ok = 1
+            ok = 0 if os.environ.get("GSDF_BENCH_FORCE_TORCH_GATHER") else 1
         except Exception as e:  # librccl missing / refused: every rank must take the same path
             print("bench: library RCCL communicator unavailable on rank %d: %s" % (rank, str(e)[:300]), file=sys.stderr)
             comm, ok = None, 0

@@ -450,10 +450,10 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
   names.push_back(std::string("eval_kernel<") + (p->prog.is2d ? "2" : "3") + ", " + std::to_string(ek) + ", " + std::to_string(ew) + ">");
   if (!p->prog.is2d) {
     names.push_back("prune_kernel");
-    names.push_back(std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(lw) + (fused_leaf() ? ">" : ", true>"));
+    names.push_back(std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(lw) + (fused_leaf() ? ">" : (p->leaf_nt_in_lds() ? ", true, true>" : ", true, false>")));
     // a fifth workgroup per CU where the LDS has room for it (npt-flange's 7 slots): the 96-register build is taken if the
     // compiler reaches it without scratch (-3 % on the evaluating kernel); built beside the 128-register one, same process
-    if (!fused_leaf() && lk == 4 && lw == 4 && 5 * lds_m <= (size_t)160 * 1024) names.push_back("leaf_eval_kernel<4, 5, true>");
+    if (!fused_leaf() && lk == 4 && lw == 4 && 5 * lds_m <= (size_t)160 * 1024) names.push_back("leaf_eval_kernel<4, 5, true, true>");
   }
   std::vector<hipFunction_t> f;
   hipModule_t mod = nullptr;
@@ -495,7 +495,7 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
     for (int w2 = lw - 1; !okl && w2 >= 2; w2--) {
       std::vector<hipFunction_t> fl;
       hipModule_t m2 = nullptr;
-      const std::string nl = std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(w2) + (fused_leaf() ? ">" : ", true>");
+      const std::string nl = std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(w2) + (fused_leaf() ? ">" : (p->leaf_nt_in_lds() ? ", true, true>" : ", true, false>"));
       if (spec_build(p, {nl}, &m2, fl, &p->spec_compile_s) != GSDF_OK) break;
       okl = fn_scratch_bytes(fl[0]) == 0;
       spec_report("specialised", nl, fl[0], okl);
@@ -560,7 +560,7 @@ extern "C" int gsdf_hip_specialize_check(const gsdf_tree* tree, size_t* code_obj
     std::vector<std::string> low;
     std::string log;
     const std::vector<std::string> names = pr.is2d ? std::vector<std::string>{"eval_kernel<2, 4, 4>"}
-                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "leaf_eval_kernel<4, 4, true>", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
+                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "leaf_eval_kernel<4, 4, true, true>", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
     if (!gsdf_dev::spec_compile(pr, "gfx950", names, co, low, log)) return fail(GSDF_ERR_HIP, "specialised build failed:\n" + log);
     if (code_object_bytes) *code_object_bytes = co.size();
     return GSDF_OK;
@@ -1034,16 +1034,22 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
         uint32_t* d_hdr = (uint32_t*)p->hdr.p;
         uint32_t* d_rec = (uint32_t*)p->rec.p;
         unsigned long long* d_psum = (unsigned long long*)((char*)p->ctr.p + kCtrBytes);  // cleared with the counters
-#define LAUNCH_LEAF_EVAL_U(KK, WW, UU)                                                                                             \
-  hipLaunchKernelGGL((leaf_eval_kernel<KK, WW, UU>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), lds_m, s, p->d_code,  \
+#define LAUNCH_LEAF_EVAL_U(KK, WW, UU, NN, LDS)                                                                                    \
+  hipLaunchKernelGGL((leaf_eval_kernel<KK, WW, UU, NN>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), LDS, s, p->d_code, \
                      (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res, d_hdr,   \
-                     d_rec, d_psum, (unsigned long long)nblk, (int)(p->leaf_nt_in_lds() ? 1 : 0), d_ctr)
-        // lq == 3 (three levels or more): a wave pass is one level-3 cube (scalar, prefetched cube load); else a few leaves
-#define LAUNCH_LEAF_EVAL(KK, WW) do { if (lq == 3) LAUNCH_LEAF_EVAL_U(KK, WW, true); else LAUNCH_LEAF_EVAL_U(KK, WW, false); } while (0)
+                     d_rec, d_psum, (unsigned long long)nblk, d_ctr)
+        // lq == 3 (three levels or more): a wave pass is one level-3 cube (column bricks, scalar prefetched cube load), its
+        // case-count table in LDS unless that costs a workgroup per CU; else a few leaves (occupancy is no concern: table in LDS)
+#define LAUNCH_LEAF_EVAL(KK, WW)                                                             \
+  do {                                                                                       \
+    if (lq != 3) LAUNCH_LEAF_EVAL_U(KK, WW, false, true, lds_m + 256);                       \
+    else if (p->leaf_nt_in_lds()) LAUNCH_LEAF_EVAL_U(KK, WW, true, true, lds_m);             \
+    else LAUNCH_LEAF_EVAL_U(KK, WW, true, false, lds_m);                                     \
+  } while (0)
         if (p->f_leaf && p->spec_leaf_k == lk && lq == 3) {
           HIP_TRYM(launch_fn(p->f_leaf, grid_for(bound, p->num_cu, leaf_bpc), BLOCK, lds_m, s, (const uint32_t*)p->d_code, (const Cube*)q[lq & 1]->p,
                              (unsigned long long)capq[lq & 1], (int)lq, (int)p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec, d_psum,
-                             (unsigned long long)nblk, (int)(p->leaf_nt_in_lds() ? 1 : 0), d_ctr));
+                             (unsigned long long)nblk, d_ctr));
         } else {
           // ahead-of-time kernels exist at the scratch-free occupancies only (tests/test_kernel_resources.py)
           if (lk == 4) { if (lw == 2) LAUNCH_LEAF_EVAL(4, 2); else LAUNCH_LEAF_EVAL(4, 3); }

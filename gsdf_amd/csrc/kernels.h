@@ -584,12 +584,16 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
 #define MARCH_GROUP 64              // blocks per entry of the group sums (records, triangles) the evaluating kernel accumulates
 
 // UCUBE: lq == 3 (every mesh of three levels or more): the 64 leaves of a wave pass are one level-3 cube.
-template <int K, int WAVES, bool UCUBE = true>
+// NTLDS: the triangles-per-case table sits in LDS behind the interpreter's columns; false when exactly those 256 bytes would
+// cost a workgroup per CU (the host decides): the counts are then read from the table in global memory. A template argument
+// and not a run-time flag: a select between an LDS and a global load makes the compiler form a flat pointer, and ROCm
+// 7.0-7.2's backend then dies on some trees ("Illegal instruction detected ... V_CMP_NE_U32_e32 0, $src_shared_base").
+template <int K, int WAVES, bool UCUBE = true, bool NTLDS = true>
 __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
                                                           unsigned long long cube_cap, int lq, int nslots, float ox, float oy, float oz,
                                                           float res, uint32_t* __restrict__ hdr, uint32_t* __restrict__ rec,
                                                           unsigned long long* __restrict__ psum, unsigned long long n_blocks_cap,
-                                                          int nt_lds, MeshCounters* __restrict__ ctr) {
+                                                          MeshCounters* __restrict__ ctr) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
   // triangles per marching-cubes case, behind the interpreter's columns (256 B)
@@ -598,7 +602,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
   // The three loads a wave starts with -- table byte, cube count, first cube -- are issued together (one trip to memory, not
   // three in a row: a workgroup lives for ~5 passes only). The first cube is read before the count is known: its index is
   // clamped into the queue, and the pass is skipped below if the count says so.
-  const uint8_t nt0 = nt_lds ? GSDF_MC_NTRI[threadIdx.x] : (uint8_t)0;  // (nt_lds = 0: no room for the table, the host says)
+  const uint8_t nt0 = NTLDS ? GSDF_MC_NTRI[threadIdx.x] : (uint8_t)0;
   unsigned long long cw_first = 0ull;
   if (UCUBE) {
     uint64_t ci = uniform_u64(((uint64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63u)) >> (3 * sh));
@@ -608,7 +612,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
   unsigned long long n_cubes = ctr->n_level[lq];  // survivors of the last prune level (device-side count)
   cw_first = uniform_u64(cw_first);
   n_cubes = uniform_u64(n_cubes);
-  if (nt_lds) {  // block-uniform
+  if (NTLDS) {
     s_nt[threadIdx.x] = nt0;
     __syncthreads();
   }
@@ -747,7 +751,9 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
       unsigned ntri = 0;
 #ifndef GSDF_EXP_NO_NTRI  // developer experiments (GSDF_HIP_SPEC_FLAGS=-DGSDF_EXP_NO_NTRI / _NO_PSUM): what the counts cost (timing only)
       if (cm != 0ull) {  // wave-uniform
-        const unsigned nt = cut ? (unsigned)(nt_lds ? s_nt[index] : GSDF_MC_NTRI[index]) : 0u;  // 0..5
+        unsigned nt = 0u;  // 0..5
+        if (NTLDS) { if (cut) nt = (unsigned)s_nt[index]; }
+        else { if (cut) nt = (unsigned)GSDF_MC_NTRI[index]; }
         ntri = (unsigned)__builtin_popcountll(__ballot((nt & 1u) != 0u)) + 2u * (unsigned)__builtin_popcountll(__ballot((nt & 2u) != 0u)) +
                4u * (unsigned)__builtin_popcountll(__ballot((nt & 4u) != 0u));
       }

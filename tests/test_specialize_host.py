@@ -57,6 +57,20 @@ def test_specialised_kernels_build_for_gfx950(scene):
     assert n.value > 10000
 
 
+def test_tree_that_broke_the_backend_builds():
+    """tools/gpu_fuzz_long.sh seed 5009, tree 7 (round 2): with the triangle-count table of leaf_eval_kernel chosen between LDS
+    and global memory by a RUN-TIME flag, the compiler merged the two loads into one through a flat pointer and ROCm's backend
+    stopped with "Illegal instruction detected ... V_CMP_NE_U32_e32 0, $src_shared_base" -- for 4 of 146 random trees. The
+    choice is a template argument now; this tree must build."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fuzz_trees
+    _, shapes = fuzz_trees.random_shapes(5009, 10, depth=4)
+    t = shapes[7].tree()
+    n = C.c_size_t()
+    assert hip.lib().gsdf_hip_specialize_check(C.byref(t), C.byref(n)) == 0, hip.lib().gsdf_hip_last_error().decode()[:2000]
+
+
 def test_specialised_2d_program_builds():
     b = Builder()
     t = b.Union2D(b.NewCircle(1.0), b.Translate2D(b.NewRectangle(1.0, 2.0), 0.5, 0.25)).tree()

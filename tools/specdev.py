@@ -36,6 +36,10 @@ def build_shim():
 
 def scene(name):
     from gsdf_amd.builder import Builder
+    if name.startswith("fuzzlong:"):  # the trees of tools/gpu_fuzz_long.sh: fuzzlong:<seed>:<k>
+        import fuzz_trees
+        _, seed, idx = name.split(":")
+        return fuzz_trees.random_shapes(int(seed), 10, depth=4)[1][int(idx)]
     if name.startswith("fuzz2d:") or name.startswith("fuzz3d:"):
         import fuzz_trees
         _, seed, idx = name.split(":")
