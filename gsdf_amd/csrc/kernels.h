@@ -1182,45 +1182,52 @@ __global__ void __launch_bounds__(BLOCK, W) flat_grid_kernel(const uint32_t* __r
 // glrender/flatrenderer.go:186-256). HBM-bound by design: 4 B per lattice corner in, 36 B per triangle out. Round 2:
 // every WAVE on its own -- no workgroup barrier and no shared stage in the loop (round 1's kernel had one barrier per
 // pass and its waves waited 68 % of their cycles at 32 % of the HBM peak).
-//   * a wave pass = 64 consecutive x cubes x FLAT_ROWS rows at one z: corner 0 of the rows per lane, prefetched two
-//     passes ahead; the other seven corners only in waves where some lane passes the reference's |d0| <= 2*sqrt3*res test
-//     (:207-209); ~95 % of the passes end there;
+//   * a wave pass = FLAT_TX consecutive x cubes x FLAT_ROWS rows at one z: corner 0 of the rows per lane, prefetched two
+//     passes ahead; the other corners only in waves where some lane passes the reference's |d0| <= 2*sqrt3*res test
+//     (:207-209) -- ~85 % of the passes end there -- and then from the neighbouring lanes / rows and one batch of ten loads;
 //   * cubes the surface cuts are appended (ballot rank) as records -- 8 distances, cube coordinates, case index -- to a
 //     buffer of FLAT_WAVE_RECS records in LDS that only this wave touches;
 //   * when the buffer cannot take another row (> FLAT_WAVE_RECS - 64 records) the wave marches it: triangle counts per
 //     record from the LDS table, exclusive prefix from three ballots, ONE global atomic for the whole flush (~350
 //     triangles: ~20 K atomics per mesh, well under the ~88 per microsecond a counter word takes), then every lane builds
 //     its record's triangles and stores them at their final address.
-// LDS: [tri table 4 KB (row byte 15 = triangle count) | 4 x FLAT_WAVE_RECS x 10 words].
-#define FLAT_ROWS 8
-#define FLAT_WAVE_RECS 192
+// LDS: [tri table 4 KB (row byte 15 = triangle count) | 4 x FLAT_WAVE_RECS x 10 words | 4 x 5 FLAT_WAVE_RECS u16 owner lists].
+#define FLAT_ROWS 8        // cube rows of a pass
+#define FLAT_TX 63         // cube columns of a pass (lane 63 supplies the last x + 1 neighbour)
+#define FLAT_WAVE_RECS 160  // records per wave buffer (8 KB per wave with the owner list: four workgroups per CU)
 __global__ void __launch_bounds__(BLOCK, 4) flat_march_kernel(const float* __restrict__ grid, unsigned nx, unsigned ny, unsigned ncz,
                                                            unsigned czfirst, float ox, float oy, float oz, float res,
                                                            float* __restrict__ tris, uint64_t tri_cap, MeshCounters* __restrict__ ctr) {
   int8_t* s_tri = (int8_t*)g_smem;
   uint32_t* buf = (uint32_t*)(s_tri + 256 * 16) + (threadIdx.x >> 6) * (FLAT_WAVE_RECS * REC_WORDS);  // [REC_WORDS][FLAT_WAVE_RECS], this wave's
+  uint16_t* own = (uint16_t*)((uint32_t*)(s_tri + 256 * 16) + 4 * FLAT_WAVE_RECS * REC_WORDS) + (threadIdx.x >> 6) * (5 * FLAT_WAVE_RECS);  // this wave's owner list
   for (int k = threadIdx.x; k < 256 * 16; k += BLOCK) s_tri[k] = (k & 15) == 15 ? (int8_t)GSDF_MC_NTRI[k >> 4] : GSDF_MC_TRI[k >> 4][k & 15];
   __syncthreads();
   const unsigned sx = FLAT_PITCH(nx + 1);  // row pitch
   const uint64_t sxy = (uint64_t)sx * (ny + 1);
   const unsigned lane = threadIdx.x & 63u;
-  const unsigned txn = (nx + 63) / 64, tyn = (ny + FLAT_ROWS - 1) / FLAT_ROWS;
+  const unsigned txn = (nx + FLAT_TX - 1) / FLAT_TX, tyn = (ny + FLAT_ROWS - 1) / FLAT_ROWS;
   const unsigned npass = txn * tyn * ncz;  // wave passes, < 2^32 (host checks)
   const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19 / flatrenderer.go:207
   unsigned my_active = 0;  // wave-uniform
   unsigned cnt = 0;        // records in this wave's buffer (wave-uniform)
   auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
 
-  // marching cubes of the buffered records, wave-local
+  // marching cubes of the buffered records, wave-local and balanced: an owner list (triangle -> record, number) from the
+  // ballot prefix sums, then ONE OUTPUT VERTEX PER LANE -- every lane busy, a wave store = 768 contiguous bytes (the first
+  // version built each record's triangles in its own lane: 2.2 triangles on average, 5 at most, three divisions each, and
+  // 36-byte pieces scattered per lane: that, not memory, was most of the 0.39 ms the active passes cost)
   auto flush = [&]() {
     if (cnt == 0) return;
-    // pass 1: triangles of the whole flush
     unsigned total = 0;
     for (unsigned i0 = 0; i0 < cnt; i0 += 64u) {
       const unsigned i = i0 + lane;
-      const unsigned nt = i < cnt ? (unsigned)(uint8_t)s_tri[(buf[9 * FLAT_WAVE_RECS + i] >> 16) * 16 + 15] : 0u;
-      total += (unsigned)__builtin_popcountll(__ballot((nt & 1u) != 0u)) + 2u * (unsigned)__builtin_popcountll(__ballot((nt & 2u) != 0u)) +
-               4u * (unsigned)__builtin_popcountll(__ballot((nt & 4u) != 0u));
+      unsigned nt = 0, idx = 0;
+      if (i < cnt) { idx = buf[9 * FLAT_WAVE_RECS + i] >> 16; nt = (unsigned)(uint8_t)s_tri[idx * 16 + 15]; }
+      const unsigned long long q0 = __ballot((nt & 1u) != 0u), q1 = __ballot((nt & 2u) != 0u), q2 = __ballot((nt & 4u) != 0u);
+      const unsigned first = total + below(q0) + 2u * below(q1) + 4u * below(q2);
+      for (unsigned k = 0; k < nt; k++) own[first + k] = (uint16_t)(i | (k << 8));
+      total += (unsigned)__builtin_popcountll(q0) + 2u * (unsigned)__builtin_popcountll(q1) + 4u * (unsigned)__builtin_popcountll(q2);
     }
     unsigned long long gbase = 0;
     if (lane == 0) gbase = atomicAdd(&ctr->n_tris, (unsigned long long)total);
@@ -1230,44 +1237,30 @@ __global__ void __launch_bounds__(BLOCK, 4) flat_march_kernel(const float* __res
       cnt = 0;
       return;
     }
-    // pass 2: build and store
-    unsigned done = 0;
-    for (unsigned i0 = 0; i0 < cnt; i0 += 64u) {
-      const unsigned i = i0 + lane;
-      unsigned nt = 0, idx = 0;
-      if (i < cnt) { idx = buf[9 * FLAT_WAVE_RECS + i] >> 16; nt = (unsigned)(uint8_t)s_tri[idx * 16 + 15]; }
-      const unsigned long long q0 = __ballot((nt & 1u) != 0u), q1 = __ballot((nt & 2u) != 0u), q2 = __ballot((nt & 4u) != 0u);
-      const unsigned pre = below(q0) + 2u * below(q1) + 4u * below(q2);
-      const unsigned ctot = (unsigned)__builtin_popcountll(q0) + 2u * (unsigned)__builtin_popcountll(q1) + 4u * (unsigned)__builtin_popcountll(q2);
-      if (nt) {
-        const uint32_t xy = buf[8 * FLAT_WAVE_RECS + i], zi = buf[9 * FLAT_WAVE_RECS + i];
-        // cube origin exactly as the fused round-1 kernel formed it: o + (float)index * res
-        const float x0 = ox + (float)(xy & 0xffffu) * res, y0 = oy + (float)(xy >> 16) * res, z0 = oz + (float)(zi & 0xffffu) * res;
-        const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;
-        float* dst = tris + (gbase + done + pre) * 9;
-        for (unsigned k = 0; k < nt; k++) {
-          const int8_t* row = s_tri + idx * 16 + 3 * k;
-#pragma unroll
-          for (int j = 0; j < 3; j++) {
-            const int e = row[2 - j];  // reversed winding (marchcubes.go:64-68)
-            const unsigned ca = GSDF_MC_PAIR_A(e), cb = GSDF_MC_PAIR_B(e);
-            const bool ax = ((ca ^ (ca >> 1)) & 1u) != 0u, ay = ((ca >> 1) & 1u) != 0u, az = ((ca >> 2) & 1u) != 0u;
-            const bool bx = ((cb ^ (cb >> 1)) & 1u) != 0u, by = ((cb >> 1) & 1u) != 0u, bz = ((cb >> 2) & 1u) != 0u;
-            float rx, ry, rz;
-            mc_interp(ax ? x1 : x0, ay ? y1 : y0, az ? z1 : z0, bx ? x1 : x0, by ? y1 : y0, bz ? z1 : z0,
-                      __uint_as_float(buf[ca * FLAT_WAVE_RECS + i]), __uint_as_float(buf[cb * FLAT_WAVE_RECS + i]), rx, ry, rz);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the owner list is read by other lanes of this wave)
+    __builtin_amdgcn_wave_barrier();
+    struct __attribute__((packed, aligned(4))) V3 { float x, y, z; };
+    V3* dst = (V3*)(tris + gbase * 9);
+    const unsigned n3 = total * 3u;
+    for (unsigned v = lane; v < n3; v += 64u) {
+      const unsigned t = v / 3u, j = v - 3u * t;
+      const unsigned o = own[t], i = o & 255u, k = o >> 8;
+      const uint32_t xy = buf[8 * FLAT_WAVE_RECS + i], zi = buf[9 * FLAT_WAVE_RECS + i];
+      const int e = s_tri[(zi >> 16) * 16 + 3u * k + (2u - j)];  // reversed winding (marchcubes.go:64-68)
+      const unsigned ca = GSDF_MC_PAIR_A(e), cb = GSDF_MC_PAIR_B(e);
+      // cube origin exactly as the fused round-1 kernel formed it: o + (float)index * res
+      const float x0 = ox + (float)(xy & 0xffffu) * res, y0 = oy + (float)(xy >> 16) * res, z0 = oz + (float)(zi & 0xffffu) * res;
+      const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;
+      const bool ax = ((ca ^ (ca >> 1)) & 1u) != 0u, ay = ((ca >> 1) & 1u) != 0u, az = ((ca >> 2) & 1u) != 0u;
+      const bool bx = ((cb ^ (cb >> 1)) & 1u) != 0u, by = ((cb >> 1) & 1u) != 0u, bz = ((cb >> 2) & 1u) != 0u;
+      V3 r;
+      mc_interp(ax ? x1 : x0, ay ? y1 : y0, az ? z1 : z0, bx ? x1 : x0, by ? y1 : y0, bz ? z1 : z0,
+                __uint_as_float(buf[ca * FLAT_WAVE_RECS + i]), __uint_as_float(buf[cb * FLAT_WAVE_RECS + i]), r.x, r.y, r.z);
 #ifdef GSDF_EXP_FLAT_NO_STORE  // developer experiment: no output stream (timing only)
-            if (rx == 1.2345678e-30f) dst[9 * k + 3 * j] = rx;
-            (void)ry; (void)rz;
+      if (r.x == 1.2345678e-30f) dst[v] = r;
 #else
-            dst[9 * k + 3 * j + 0] = rx;
-            dst[9 * k + 3 * j + 1] = ry;
-            dst[9 * k + 3 * j + 2] = rz;
+      dst[v] = r;
 #endif
-          }
-        }
-      }
-      done += ctot;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // the buffer is read out before new records overwrite it
     __builtin_amdgcn_wave_barrier();
@@ -1280,11 +1273,12 @@ __global__ void __launch_bounds__(BLOCK, 4) flat_march_kernel(const float* __res
     cz = wr / tyn;
     ty = wr - cz * tyn;
   };
+  // (lane 63 of a tile holds the x + 1 neighbours of lane 62's cubes and owns none itself: tiles are FLAT_TX = 63 cubes wide)
   auto load_d0 = [&](unsigned tx, unsigned ty, unsigned cz, float (&d0)[FLAT_ROWS]) {
-    const unsigned cx = tx * 64 + lane, cy0 = ty * FLAT_ROWS;
+    const unsigned cx = tx * FLAT_TX + lane, cy0 = ty * FLAT_ROWS;
     const float* g0 = grid + (uint64_t)cz * sxy + (uint64_t)cy0 * sx + cx;
 #pragma unroll
-    for (int r = 0; r < FLAT_ROWS; r++) d0[r] = (cx < nx && cy0 + (unsigned)r < ny) ? g0[(uint64_t)r * sx] : __builtin_inff();
+    for (int r = 0; r < FLAT_ROWS; r++) d0[r] = (cx <= nx && cy0 + (unsigned)r <= ny) ? g0[(uint64_t)r * sx] : __builtin_inff();
   };
   const unsigned wid = blockIdx.x * 4u + (threadIdx.x >> 6), wstride = gridDim.x * 4u;
   // corner 0 of the next TWO passes is in flight while a pass is examined: with one (round 2's first version) a wave had
@@ -1304,7 +1298,8 @@ __global__ void __launch_bounds__(BLOCK, 4) flat_march_kernel(const float* __res
   }
   for (unsigned w = wid; w < npass; w += wstride) {  // wave-uniform
     const unsigned tx = t1x, ty = t1y, cz = t1z;
-    const unsigned cx = tx * 64 + lane, cy0 = ty * FLAT_ROWS;
+    const unsigned cx = tx * FLAT_TX + lane, cy0 = ty * FLAT_ROWS;
+    const bool cube_x = lane < FLAT_TX && cx < nx;  // this lane owns a cube column
     const float* g0 = grid + (uint64_t)cz * sxy + (uint64_t)cy0 * sx + cx;
     float d0[FLAT_ROWS];
     bool any_act = false;
@@ -1312,7 +1307,7 @@ __global__ void __launch_bounds__(BLOCK, 4) flat_march_kernel(const float* __res
     for (int r = 0; r < FLAT_ROWS; r++) {
       d0[r] = dn1[r];
       dn1[r] = dn2[r];
-      any_act = any_act || dm::absf(d0[r]) <= cubeDiag;
+      any_act = any_act || (cube_x && cy0 + (unsigned)r < ny && dm::absf(d0[r]) <= cubeDiag);
     }
     t1x = t2x; t1y = t2y; t1z = t2z;
     if ((uint64_t)w + 2ull * wstride < npass) {
@@ -1324,47 +1319,48 @@ __global__ void __launch_bounds__(BLOCK, 4) flat_march_kernel(const float* __res
     my_active += 1u;
     continue;
 #endif
-    // the other seven corners of the active cubes, two rows at a time (all 14 loads issued before the first is used)
+    // The other seven corners of the active cubes. Three of them are in registers already -- x + 1 is the next lane, y + 1
+    // the lane's next row -- and the plane above is fetched as nine rows at once: ONE trip to memory per active pass (the
+    // first version fetched seven corners per active row, two rows at a time: four trips in a row, 0.27 ms of the
+    // kernel's 0.74).
+    const bool corner_x = cx <= nx;
+    float up[FLAT_ROWS + 1];  // plane z + 1, rows 0..8
 #pragma unroll
-    for (int r0 = 0; r0 < FLAT_ROWS; r0 += 2) {
-      const bool act0 = dm::absf(d0[r0]) <= cubeDiag, act1 = dm::absf(d0[r0 + 1]) <= cubeDiag;
-      if (__ballot(act0 || act1) == 0ull) continue;  // wave-uniform
-      float v[2][7];
+    for (int r = 0; r <= FLAT_ROWS; r++) up[r] = (corner_x && cy0 + (unsigned)r <= ny) ? g0[sxy + (uint64_t)r * sx] : __builtin_inff();
+    const float d8 = (corner_x && cy0 + FLAT_ROWS <= ny) ? g0[(uint64_t)FLAT_ROWS * sx] : __builtin_inff();  // plane z, row 8
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const float* q = g0 + (uint64_t)(r0 + h) * sx;
-        const bool act = h ? act1 : act0;
-        v[h][0] = act ? q[1] : 0.f; v[h][1] = act ? q[1 + sx] : 0.f; v[h][2] = act ? q[sx] : 0.f; v[h][3] = act ? q[sxy] : 0.f;
-        v[h][4] = act ? q[sxy + 1] : 0.f; v[h][5] = act ? q[sxy + 1 + sx] : 0.f; v[h][6] = act ? q[sxy + sx] : 0.f;
+    for (int r = 0; r < FLAT_ROWS; r++) {
+      const bool act = cube_x && cy0 + (unsigned)r < ny && dm::absf(d0[r]) <= cubeDiag;  // the reference's |d0| <= 2*sqrt3*res test (:207-209)
+      const unsigned long long am = __ballot(act);
+      if (am == 0ull) continue;  // wave-uniform
+      my_active += (unsigned)__builtin_popcountll(am);
+      const float c3 = r + 1 < FLAT_ROWS ? d0[r + 1 < FLAT_ROWS ? r + 1 : 0] : d8;
+      const float c1 = __shfl_down(d0[r], 1, 64), c2 = __shfl_down(c3, 1, 64);
+      const float c4 = up[r], c7 = up[r + 1], c5 = __shfl_down(c4, 1, 64), c6 = __shfl_down(c7, 1, 64);
+      unsigned ix = 0;
+      if (act) {
+        ix = (d0[r] < 0.f ? 1u : 0u) | (c1 < 0.f ? 2u : 0u) | (c2 < 0.f ? 4u : 0u) | (c3 < 0.f ? 8u : 0u) | (c4 < 0.f ? 16u : 0u) |
+             (c5 < 0.f ? 32u : 0u) | (c6 < 0.f ? 64u : 0u) | (c7 < 0.f ? 128u : 0u);
+        if (ix == 255u) ix = 0u;
       }
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int r = r0 + h;
-        const bool act = h ? act1 : act0;
-        const unsigned long long am = __ballot(act);
-        if (am == 0ull) continue;  // wave-uniform
-        my_active += (unsigned)__builtin_popcountll(am);
-        unsigned ix = 0;
-        if (act) {
-          ix = (d0[r] < 0.f ? 1u : 0u);
-#pragma unroll
-          for (int c = 0; c < 7; c++) ix |= (v[h][c] < 0.f ? 1u : 0u) << (c + 1);
-          if (ix == 255u) ix = 0u;
-        }
-        const unsigned long long cm = __ballot(ix != 0u);
-        if (cm == 0ull) continue;  // wave-uniform
-        if (cnt + 64u > FLAT_WAVE_RECS) flush();  // room for a whole row
-        if (ix) {
-          const unsigned pos = cnt + below(cm);
-          buf[0 * FLAT_WAVE_RECS + pos] = __float_as_uint(d0[r]);
-#pragma unroll
-          for (int c = 0; c < 7; c++) buf[(c + 1) * FLAT_WAVE_RECS + pos] = __float_as_uint(v[h][c]);
-          buf[8 * FLAT_WAVE_RECS + pos] = cx | ((cy0 + (unsigned)r) << 16);
-          buf[9 * FLAT_WAVE_RECS + pos] = (czfirst + cz) | (ix << 16);
-        }
-        cnt += (unsigned)__builtin_popcountll(cm);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      const unsigned long long cm = __ballot(ix != 0u);
+      if (cm == 0ull) continue;  // wave-uniform
+      if (cnt + 64u > FLAT_WAVE_RECS) flush();  // room for a whole row
+      if (ix) {
+        const unsigned pos = cnt + below(cm);
+        buf[0 * FLAT_WAVE_RECS + pos] = __float_as_uint(d0[r]);
+        buf[1 * FLAT_WAVE_RECS + pos] = __float_as_uint(c1);
+        buf[2 * FLAT_WAVE_RECS + pos] = __float_as_uint(c2);
+        buf[3 * FLAT_WAVE_RECS + pos] = __float_as_uint(c3);
+        buf[4 * FLAT_WAVE_RECS + pos] = __float_as_uint(c4);
+        buf[5 * FLAT_WAVE_RECS + pos] = __float_as_uint(c5);
+        buf[6 * FLAT_WAVE_RECS + pos] = __float_as_uint(c6);
+        buf[7 * FLAT_WAVE_RECS + pos] = __float_as_uint(c7);
+        buf[8 * FLAT_WAVE_RECS + pos] = cx | ((cy0 + (unsigned)r) << 16);
+        buf[9 * FLAT_WAVE_RECS + pos] = (czfirst + cz) | (ix << 16);
       }
+      cnt += (unsigned)__builtin_popcountll(cm);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
   }
   flush();
