@@ -80,7 +80,7 @@ struct gsdf_program {
       return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-  } q0, q1, ctr, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, flat_grid, rec, hdr;  // rec / hdr: cut-leaf records and block headers of the two-kernel leaf phase (the group sums follow the counters in ctr)  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
+  } q0, q1, ctr, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, flat_grid, flat_bits, flat_list, rec, hdr;  // flat_bits: sign and near-surface bit planes of the flat renderer's lattice (flat_grid_kernel -> flat_cut_scan_kernel), flat_list: the cut cubes (-> flat_march_list_kernel)  // rec / hdr: cut-leaf records and block headers of the two-kernel leaf phase (the group sums follow the counters in ctr)  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   void* h_ctr = nullptr;  // pinned host copy of the device counters (a pageable destination makes the D2H copy a staged, blocking one)
   uint64_t last_tris = 0;  // triangle count of the previous mesh on this handle: sizes the next output buffer
@@ -615,7 +615,7 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (p->spec_mod4) (void)hipModuleUnload(p->spec_mod4);
   p->q0.release(); p->q1.release(); p->ctr.release();
   p->rec.release(); p->hdr.release();
-  p->flat_grid.release(); p->dc_grid.release(); p->dc_dist.release(); p->dc_fv.release(); p->dc_nrm.release(); p->dc_edge.release();
+  p->flat_grid.release(); p->flat_bits.release(); p->flat_list.release(); p->dc_grid.release(); p->dc_dist.release(); p->dc_fv.release(); p->dc_nrm.release(); p->dc_edge.release();
   for (auto e : p->ev) if (e) (void)hipEventDestroy(e);
   if (p->h_ctr) (void)hipHostFree(p->h_ctr);
   if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -1374,6 +1374,15 @@ extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, in
     return bail(fail(GSDF_ERR_CAPACITY, "flat renderer: no device memory for the distance grid (" + std::to_string(pxy * nk * 4) + " bytes)"));
   }
   float* grid = (float*)p->flat_grid.p;
+  // two bit planes per lattice plane beside it (1/32 + 1/32 of the grid's size): "d < 0" and "|d| <= 2 sqrt3 res" per corner,
+  // in whole words per flat_grid_kernel pass (BLOCK corners = BLOCK / 64 words)
+  const unsigned wpp = (unsigned)((sxy + (uint64_t)BLOCK - 1) / (uint64_t)BLOCK) * (BLOCK / 64);
+  if (p->flat_bits.ensure((size_t)2 * wpp * nk * sizeof(unsigned long long)) != hipSuccess) {
+    (void)hipGetLastError();
+    return bail(fail(GSDF_ERR_CAPACITY, "flat renderer: no device memory for the lattice's bit planes"));
+  }
+  unsigned long long* negbits = (unsigned long long*)p->flat_bits.p;
+  unsigned long long* nearbits = negbits + (size_t)wpp * nk;
   const int ek = p->batch_k();
   spec_aux(p);
   HIP_TRYM(hipEventRecord(p->ev[0], s));
@@ -1382,8 +1391,8 @@ extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, in
     static const int bpc = [] { const char* e = getenv("GSDF_HIP_EVAL_BPC"); return e ? atoi(e) : 64; }();
     const uint64_t gmax = (uint64_t)p->num_cu * (uint64_t)(bpc > 0 ? bpc : 64);
     const unsigned g = (unsigned)(npass < gmax ? npass : gmax);
-    if (p->f_flat_grid) HIP_TRYM(launch_fn(p->f_flat_grid, g, BLOCK, p->lds_bytes(ek), s, (const uint32_t*)p->d_code, ox, oy, oz, res, sx, sy, c0, nk, grid));
-#define LAUNCH_FG(KK, WW) hipLaunchKernelGGL((flat_grid_kernel<KK, WW>), dim3(g), dim3(BLOCK), p->lds_bytes(KK), s, p->d_code, ox, oy, oz, res, sx, sy, c0, nk, grid)
+    if (p->f_flat_grid) HIP_TRYM(launch_fn(p->f_flat_grid, g, BLOCK, p->lds_bytes(ek), s, (const uint32_t*)p->d_code, ox, oy, oz, res, sx, sy, c0, nk, grid, negbits, nearbits));
+#define LAUNCH_FG(KK, WW) hipLaunchKernelGGL((flat_grid_kernel<KK, WW>), dim3(g), dim3(BLOCK), p->lds_bytes(KK), s, p->d_code, ox, oy, oz, res, sx, sy, c0, nk, grid, negbits, nearbits)
     else if (ek == 4) { if (p->sweep_waves(4) == 4) LAUNCH_FG(4, 4); else LAUNCH_FG(4, 3); }
     else if (ek == 2) { if (p->sweep_waves(2) == 4) LAUNCH_FG(2, 4); else LAUNCH_FG(2, 3); }
     else LAUNCH_FG(1, 4);
@@ -1403,23 +1412,44 @@ extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, in
     }
     HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(MeshCounters), s));
     HIP_TRYM(hipEventRecord(p->ev[2], s));
-    const uint64_t npass = (uint64_t)((nx + FLAT_TX - 1) / FLAT_TX) * ((ny + FLAT_ROWS - 1) / FLAT_ROWS) * ncz;  // wave passes: FLAT_TX x FLAT_ROWS cubes each
-    if ((double)npass + 1e6 >= 4294967296.0 || nx >= 65536u || ny >= 65536u || (uint64_t)c0 + ncz >= 65536u)
+    // default: the marching pass over the bit planes (flat_cut_scan_kernel + flat_march_list_kernel); GSDF_HIP_FLAT_STREAM=1:
+    // the pass that streams the float grid (flat_march_kernel, the kernel of rounds 1-2), kept for comparison -- same triangles
+    static const bool stream_march = [] { const char* e = getenv("GSDF_HIP_FLAT_STREAM"); return e && atoi(e) != 0; }();
+    if (nx >= 65536u || ny >= 65536u || (uint64_t)c0 + ncz >= 65536u)  // record coordinates are 16-bit
       return bail(fail(GSDF_ERR_RESOLUTION, "resolution too fine for the flat renderer's lattice"));
-    // four workgroups per CU are resident (36 KB of LDS each): a grid of exactly those, ~200 passes per wave, measured best
-    // (0.63 ms; 8 per CU 0.66, 32 per CU 0.74, 6 per CU 0.82 -- the stride between a wave's passes matters)
-    static const int mbpc = [] { const char* e = getenv("GSDF_HIP_FLAT_BPC"); return e ? atoi(e) : 4; }();  // tuning knob
-    const uint64_t gmax = (uint64_t)p->num_cu * (uint64_t)(mbpc > 0 ? mbpc : 4);
-    const uint64_t nwg = (npass + 3) / 4;
-    const size_t lds = (size_t)256 * 16 + (size_t)4 * FLAT_WAVE_RECS * REC_WORDS * 4 + (size_t)4 * 5 * FLAT_WAVE_RECS * 2;
-    hipLaunchKernelGGL(flat_march_kernel, dim3((unsigned)(nwg < gmax ? (nwg ? nwg : 1) : gmax)), dim3(BLOCK), lds, s, (const float*)grid, nx, ny, ncz, c0,
-                       ox, oy, oz, res, m->d_tris, (uint64_t)m->cap, d_ctr);
+    if (stream_march) {
+      const uint64_t npass = (uint64_t)((nx + FLAT_TX - 1) / FLAT_TX) * ((ny + FLAT_ROWS - 1) / FLAT_ROWS) * ncz;  // wave passes: FLAT_TX x FLAT_ROWS cubes each
+      if ((double)npass + 1e6 >= 4294967296.0) return bail(fail(GSDF_ERR_RESOLUTION, "resolution too fine for the flat renderer's lattice"));
+      // four workgroups per CU are resident (36 KB of LDS each): a grid of exactly those, ~200 passes per wave, measured best
+      // (0.63 ms; 8 per CU 0.66, 32 per CU 0.74, 6 per CU 0.82 -- the stride between a wave's passes matters)
+      static const int mbpc = [] { const char* e = getenv("GSDF_HIP_FLAT_BPC"); return e ? atoi(e) : 4; }();  // tuning knob
+      const uint64_t gmax = (uint64_t)p->num_cu * (uint64_t)(mbpc > 0 ? mbpc : 4);
+      const uint64_t nwg = (npass + 3) / 4;
+      const size_t lds = (size_t)256 * 16 + (size_t)4 * FLAT_WAVE_RECS * REC_WORDS * 4 + (size_t)4 * 5 * FLAT_WAVE_RECS * 2;
+      hipLaunchKernelGGL(flat_march_kernel, dim3((unsigned)(nwg < gmax ? (nwg ? nwg : 1) : gmax)), dim3(BLOCK), lds, s, (const float*)grid, nx, ny, ncz, c0,
+                         ox, oy, oz, res, m->d_tris, (uint64_t)m->cap, d_ctr);
+    } else {
+      // a cut cube has at least one triangle: a list of the triangle buffer's capacity overflows only if that does
+      if (p->flat_list.ensure((size_t)m->cap * sizeof(FlatCut)) != hipSuccess) {
+        (void)hipGetLastError();
+        return bail(fail(GSDF_ERR_CAPACITY, "flat renderer: no device memory for the list of cut cubes"));
+      }
+      FlatCut* list = (FlatCut*)p->flat_list.p;
+      const uint64_t npass = (((uint64_t)sx * ny + 4095u) >> 12) * ncz;  // wave passes of the scan: 4096 cubes each
+      static const int sbpc = [] { const char* e = getenv("GSDF_HIP_FLAT_SCAN_BPC"); return e ? atoi(e) : 16; }();   // tuning knobs
+      static const int lbpc = [] { const char* e = getenv("GSDF_HIP_FLAT_LIST_BPC"); return e ? atoi(e) : 8; }();
+      const uint64_t gmax = (uint64_t)p->num_cu * (uint64_t)(sbpc > 0 ? sbpc : 16), nwg = (npass + 3) / 4;
+      hipLaunchKernelGGL(flat_cut_scan_kernel, dim3((unsigned)(nwg < gmax ? (nwg ? nwg : 1) : gmax)), dim3(BLOCK), 0, s, (const unsigned long long*)negbits,
+                         (const unsigned long long*)nearbits, wpp, nx, ny, ncz, list, (uint64_t)m->cap, (uint64_t)m->cap, d_ctr);
+      hipLaunchKernelGGL(flat_march_list_kernel, dim3((unsigned)p->num_cu * (unsigned)(lbpc > 0 ? lbpc : 8)), dim3(BLOCK), FLATB_LDS_BYTES, s, (const float*)grid,
+                         (const FlatCut*)list, (uint64_t)m->cap, nx, ny, c0, ox, oy, oz, res, m->d_tris, (uint64_t)m->cap, d_ctr);
+    }
     HIP_TRYM(hipGetLastError());
     HIP_TRYM(hipEventRecord(p->ev[3], s));
     HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));
     HIP_TRYM(hipStreamSynchronize(s));
-    if (hc.overflow) {
-      if (attempt >= 4) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
+    if (hc.overflow) {  // (either pass keeps counting: n_tris is exact)
+      if (attempt >= 5) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
       pool_give(p->device, m->d_tris, m->cap);
       m->d_tris = nullptr; m->cap = 0;
       want = hc.n_tris + hc.n_tris / 16 + 1024;

@@ -55,6 +55,45 @@ def test_flat_sphere_41072(gpu):
     assert fl.n_tris() == ref.n_tris and _same(fl.RenderAll(), ref.tris)
 
 
+@pytest.mark.parametrize("nx", [3, 4, 31, 62, 63, 64, 65, 127, 128, 191])
+def test_flat_row_lengths_around_the_bit_words(gpu, nx):
+    """The marching pass reads the lattice as bit planes in words of 64 corners, rows running on (flat_cut_scan_kernel): row
+    lengths of nx + 1 corners below, at and around multiples of 64 (a row further on = a whole number of words, or 63 bits
+    more), and rows shorter than a word."""
+    b = Builder()
+    sdf = gpu.SDF3HIP(b.NewSphere(1.0))
+    res = np.float32(2.02 / (nx - 0.5))
+    fl = gpu.FlatHIP(sdf, res)
+    ref = OracleSDF(b.NewSphere(1.0).tree()).render_flat(res, 4096, 1)
+    assert ref.grid[0] == nx and fl.stats.leaf_cubes == ref.grid[0] * ref.grid[1] * ref.grid[2]
+    assert fl.n_tris() == ref.n_tris and _same(fl.RenderAll(), ref.tris)
+    for count in (2, 5):
+        parts = [gpu.FlatHIP(sdf, res, shard_rank=r, shard_count=count).RenderAll().reshape(-1, 9) for r in range(count)]
+        assert _same(np.concatenate(parts), ref.tris)
+
+
+def test_flat_float_stream_pass_gives_the_same_triangles(gpu):
+    """GSDF_HIP_FLAT_STREAM=1 selects the marching pass of rounds 1-2 (flat_march_kernel, which streams the float grid) in
+    place of the bit-plane pass; read once per process, hence the subprocess."""
+    import hashlib, os, subprocess, sys
+    code = ("import hashlib, numpy as np\n"
+            "from gsdf_amd.builder import Builder\n"
+            "from gsdf_amd import hip\n"
+            "hip.init(0)\n"
+            "s = Builder().Scene('npt-flange')\n"
+            "t = hip.FlatHIP(hip.SDF3HIP(s), np.float32(float(s.Diagonal()) / 233)).RenderAll().reshape(-1, 9)\n"
+            "t = t[np.lexsort(t.view(np.uint32).T[::-1])]\n"
+            "print(len(t), hashlib.sha256(t.tobytes()).hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSDF_HIP_FLAT_STREAM="1", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    n, digest = out.stdout.split()[-2:]
+    s = Builder().Scene("npt-flange")
+    t = _sorted(gpu.FlatHIP(gpu.SDF3HIP(s), np.float32(float(s.Diagonal()) / 233)).RenderAll())
+    assert int(n) == len(t) and digest == hashlib.sha256(t.tobytes()).hexdigest()
+
+
 def test_flat_sharded_union_equals_whole(gpu):
     b = Builder()
     s = b.Scene("npt-flange")
