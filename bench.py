@@ -149,8 +149,12 @@ def eval_mode(args, torch, np, hip, shader, sdf, res, dev):
 
 def flat_mode(args, torch, np, hip, shader, sdf, res, spec_note):
     """glrender.FlatRenderer on device (gsdf_hip_mesh_flat): every corner of the lattice, then marching cubes of every
-    cube. Two kernels with different roofs: the lattice pass is VALU-bound like the octree's leaf kernel, the marching
-    pass streams the grid (4 B per corner) and the triangles (36 B each): HBM."""
+    cube. Two phases with different roofs: the lattice pass is VALU-bound like the octree's leaf kernel; the marching
+    pass is priced, as SURVEY 8(d) counts it, at 4 B per corner + 36 B per triangle. Since round 2 it no longer streams the
+    float grid: the lattice pass leaves two bits per corner, flat_cut_scan_kernel reads those (1/16 of the bytes) and
+    flat_march_list_kernel fetches the eight distances of the cut cubes only -- the figure is notional like the octree's
+    (GSDF_HIP_FLAT_STREAM=1 brings back flat_march_kernel, which streams)."""
+    streaming = os.environ.get("GSDF_HIP_FLAT_STREAM", "0") not in ("", "0")
     for _ in range(args.warmup):
         hip.FlatHIP(sdf, res)
     torch.cuda.synchronize()
@@ -175,7 +179,9 @@ def flat_mode(args, torch, np, hip, shader, sdf, res, spec_note):
         "triangles": nt, "triangles_per_s": nt * args.steps / dt,
         "lattice_pass": {"kernel": "flat_grid_kernel<K>", "kernel_ms": g_ms, "evals_per_s": ev / (g_ms * 1e-3)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "flat_march_kernel", "kernel_ms": m_ms, "algorithmic_gb_per_launch": alg_gb}}), flush=True)
+                     "traffic": None, "kernel": "flat_march_kernel" if streaming else "flat_cut_scan_kernel + flat_march_list_kernel",
+                     "kernel_ms": m_ms, "algorithmic_gb_per_launch": alg_gb,
+                     "note": "marching phase (both kernels); notional for the bit-plane pass, whose measured HBM traffic is in profiles/*_flat_pmc_summary.json"}}), flush=True)
 
 
 def main():

@@ -18,7 +18,7 @@ ap.add_argument("--workload", default="")
 ap.add_argument("--command", default="python bench.py --steps 5 --warmup 1 --no-cpu-baseline")
 a = ap.parse_args()
 
-KERNELS = ("leaf_eval_kernel", "march_records_kernel", "leaf_kernel", "prune_kernel", "leaf_brick_kernel", "eval_kernel", "flat_grid_kernel", "flat_march_kernel")
+KERNELS = ("leaf_eval_kernel", "march_records_kernel", "leaf_kernel", "prune_kernel", "leaf_brick_kernel", "eval_kernel", "flat_grid_kernel", "flat_march_kernel", "flat_cut_scan_kernel", "flat_march_list_kernel")
 acc = {k: defaultdict(lambda: [0.0, 0]) for k in KERNELS}
 for f in glob.glob(os.path.join(a.dir, "**", "*counter_collection.csv"), recursive=True):
     per = defaultdict(float)
