@@ -1430,19 +1430,19 @@ extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, in
                          ox, oy, oz, res, m->d_tris, (uint64_t)m->cap, d_ctr);
     } else {
       // a cut cube has at least one triangle: a list of the triangle buffer's capacity overflows only if that does
-      if (p->flat_list.ensure((size_t)m->cap * sizeof(FlatCut)) != hipSuccess) {
+      if (p->flat_list.ensure((size_t)m->cap * sizeof(unsigned long long)) != hipSuccess) {
         (void)hipGetLastError();
         return bail(fail(GSDF_ERR_CAPACITY, "flat renderer: no device memory for the list of cut cubes"));
       }
-      FlatCut* list = (FlatCut*)p->flat_list.p;
+      unsigned long long* list = (unsigned long long*)p->flat_list.p;
       const uint64_t npass = (((uint64_t)sx * ny + 4095u) >> 12) * ncz;  // wave passes of the scan: 4096 cubes each
       static const int sbpc = [] { const char* e = getenv("GSDF_HIP_FLAT_SCAN_BPC"); return e ? atoi(e) : 16; }();   // tuning knobs
-      static const int lbpc = [] { const char* e = getenv("GSDF_HIP_FLAT_LIST_BPC"); return e ? atoi(e) : 8; }();
+      static const int lbpc = [] { const char* e = getenv("GSDF_HIP_FLAT_LIST_BPC"); return e ? atoi(e) : 6; }();
       const uint64_t gmax = (uint64_t)p->num_cu * (uint64_t)(sbpc > 0 ? sbpc : 16), nwg = (npass + 3) / 4;
       hipLaunchKernelGGL(flat_cut_scan_kernel, dim3((unsigned)(nwg < gmax ? (nwg ? nwg : 1) : gmax)), dim3(BLOCK), 0, s, (const unsigned long long*)negbits,
-                         (const unsigned long long*)nearbits, wpp, nx, ny, ncz, list, (uint64_t)m->cap, (uint64_t)m->cap, d_ctr);
-      hipLaunchKernelGGL(flat_march_list_kernel, dim3((unsigned)p->num_cu * (unsigned)(lbpc > 0 ? lbpc : 8)), dim3(BLOCK), FLATB_LDS_BYTES, s, (const float*)grid,
-                         (const FlatCut*)list, (uint64_t)m->cap, nx, ny, c0, ox, oy, oz, res, m->d_tris, (uint64_t)m->cap, d_ctr);
+                         (const unsigned long long*)nearbits, wpp, nx, ny, ncz, list, (uint64_t)m->cap, d_ctr);
+      hipLaunchKernelGGL(flat_march_list_kernel, dim3((unsigned)p->num_cu * (unsigned)(lbpc > 0 ? lbpc : 6)), dim3(BLOCK), FLATB_LDS_BYTES, s, (const float*)grid,
+                         (const unsigned long long*)list, (uint64_t)m->cap, nx, ny, c0, ox, oy, oz, res, m->d_tris, (uint64_t)m->cap, d_ctr);
     }
     HIP_TRYM(hipGetLastError());
     HIP_TRYM(hipEventRecord(p->ev[3], s));

@@ -1210,11 +1210,14 @@ __global__ void __launch_bounds__(BLOCK, W) flat_grid_kernel(const uint32_t* __r
 // ballot prefix sums, then ONE OUTPUT VERTEX PER LANE -- every lane busy, a wave store = 768 contiguous bytes (the first
 // version built each record's triangles in its own lane: 2.2 triangles on average, 5 at most, three divisions each, and
 // 36-byte pieces scattered per lane: that, not memory, was most of the 0.39 ms the active passes cost)
-template <int RECS>
-__device__ __forceinline__ void flat_flush_wave(uint32_t* buf, uint16_t* own, const int8_t* s_tri, unsigned& cnt, unsigned lane, float ox, float oy,
-                                                float oz, float res, float* __restrict__ tris, uint64_t tri_cap, MeshCounters* __restrict__ ctr) {
+// KNOWN: the first triangle's index is given (`known`, wave-uniform) instead of taken from the append counter.
+// Returns the number of triangles of the records.
+template <int RECS, bool KNOWN = false>
+__device__ __forceinline__ unsigned flat_flush_wave(uint32_t* buf, uint16_t* own, const int8_t* s_tri, unsigned& cnt, unsigned lane, float ox, float oy,
+                                                    float oz, float res, float* __restrict__ tris, uint64_t tri_cap, MeshCounters* __restrict__ ctr,
+                                                    unsigned long long known = 0ull) {
   auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
-  if (cnt == 0) return;
+  if (cnt == 0) return 0u;
   unsigned total = 0;
   for (unsigned i0 = 0; i0 < cnt; i0 += 64u) {
     const unsigned i = i0 + lane;
@@ -1225,13 +1228,15 @@ __device__ __forceinline__ void flat_flush_wave(uint32_t* buf, uint16_t* own, co
     for (unsigned k = 0; k < nt; k++) own[first + k] = (uint16_t)(i | (k << 8));
     total += (unsigned)__builtin_popcountll(q0) + 2u * (unsigned)__builtin_popcountll(q1) + 4u * (unsigned)__builtin_popcountll(q2);
   }
-  unsigned long long gbase = 0;
-  if (lane == 0) gbase = atomicAdd(&ctr->n_tris, (unsigned long long)total);
-  gbase = uniform_u64(gbase);
+  unsigned long long gbase = known;
+  if (!KNOWN) {
+    if (lane == 0) gbase = atomicAdd(&ctr->n_tris, (unsigned long long)total);
+    gbase = uniform_u64(gbase);
+  }
   if (gbase + total > tri_cap) {  // wave-uniform: the counter keeps counting, the host learns the exact size and reruns
     if (lane == 0) ctr->overflow = 1ull;
     cnt = 0;
-    return;
+    return total;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the owner list is read by other lanes of this wave)
   __builtin_amdgcn_wave_barrier();
@@ -1261,6 +1266,7 @@ __device__ __forceinline__ void flat_flush_wave(uint32_t* buf, uint16_t* own, co
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // the buffer is read out before new records overwrite it
   __builtin_amdgcn_wave_barrier();
   cnt = 0;
+  return total;
 }
 
 __global__ void __launch_bounds__(BLOCK, 4) flat_march_kernel(const float* __restrict__ grid, unsigned nx, unsigned ny, unsigned ncz,
@@ -1281,7 +1287,7 @@ __global__ void __launch_bounds__(BLOCK, 4) flat_march_kernel(const float* __res
   unsigned cnt = 0;        // records in this wave's buffer (wave-uniform)
   auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
 
-  auto flush = [&]() { flat_flush_wave<FLAT_WAVE_RECS>(buf, own, s_tri, cnt, lane, ox, oy, oz, res, tris, tri_cap, ctr); };
+  auto flush = [&]() { (void)flat_flush_wave<FLAT_WAVE_RECS>(buf, own, s_tri, cnt, lane, ox, oy, oz, res, tris, tri_cap, ctr); };
 
   auto pass_coords = [&](unsigned w, unsigned& tx, unsigned& ty, unsigned& cz) {
     const unsigned wr = w / txn;
@@ -1394,35 +1400,32 @@ __global__ void __launch_bounds__(BLOCK, 4) flat_march_kernel(const float* __res
 // The marching pass driven by the two bit planes flat_grid_kernel leaves beside the grid -- "distance < 0" and
 // "|distance| <= 2*sqrt3*res" per lattice corner, bit (i + sx*j) of plane k in words of 64. Which cubes the surface cuts (the
 // reference's corner-0 test, then a case index other than 0 and 255: flatrenderer.go:207-225, marchcubes.go:20-40), and with
-// how many triangles, is a matter of eight shifted copies of the sign words: one LANE decides 64 cubes with ~40 integer
+// which case index, is a matter of eight shifted copies of the sign words: one LANE decides 64 cubes with a few dozen integer
 // instructions and 72 bytes of loads, and only for the cubes that are cut (0.7 % at npt-flange resdiv 1600) are the eight
 // distances fetched from the grid -- 1/32 of the bytes flat_march_kernel streams for the same decisions on the same
 // comparisons. Two kernels, like the octree's leaf phase, because cut cubes come in slabs (a machined face parallel to a
 // lattice plane cuts every cube of it) and because a counter word takes only ~88 returning atomics per microsecond:
 //   flat_cut_scan_kernel   a wave pass = 64 words = 4096 consecutive cubes (corner order, rows run on) of one plane. A
-//                          workgroup walks its passes twice: once counting cut cubes and their triangles, then -- after ONE
-//                          pair of atomics for the whole workgroup (~2 000 per mesh) has reserved its stretch of the list and
-//                          of the triangle buffer -- again (the words are in L2), writing (plane, bit, first triangle) per
-//                          cut cube;
-//   flat_march_list_kernel the list in equal shares: 64 cut cubes per wave and trip to memory, one output vertex per lane,
-//                          every triangle written at the address its list entry names: no atomic, no barrier in the loop.
+//                          workgroup walks its passes twice: once counting cut cubes (a popcount), then -- after ONE atomic
+//                          for the whole workgroup has reserved its stretch of the list -- again (the words are in L2),
+//                          writing one 8-byte entry (case index, plane, bit) per cut cube;
+//   flat_march_list_kernel the list in equal shares. A wave first adds up the triangles of its entries (count table in LDS)
+//                          and reserves them with ONE atomic, then takes 64 cut cubes per trip to memory, one output vertex
+//                          per lane, its triangles back to back: no atomic, no barrier in the loop.
 // (Measured on the way, npt-flange resdiv 1600 / 400, where flat_march_kernel takes 0.63 / 0.08 ms: one kernel doing both,
 // one atomic per flush: 0.56 / 0.18 ms -- a wave that draws a pass inside a face has 4096 cubes to march, 64 dependent trips,
 // while its neighbours have none; scan + list kernels with one atomic per pass and per flush: 1.22 / 0.08 ms -- over 100 K atomics
-// on two words inside 0.1 ms of work.)
+// on two words inside 0.1 ms of work; triangle offsets fixed by the scan, three per-lane loops with a table lookup per cut
+// bit: 0.33 / 0.05 ms, the scan VALU-bound at 400 instructions per pass and walk.)
 #define FLATB_RECS 64    // records per wave buffer of flat_march_list_kernel: one per lane
 #define FLATB_FLAGS 2048  // passes of a wave whose "holds surface" bit flat_cut_scan_kernel keeps between its two walks
-#define FLATB_WORDS 12   // 8 distances, x | y << 16, z | case << 16, first triangle (64 bits)
-#define FLATB_LDS_BYTES ((size_t)256 * 16 + (size_t)4 * FLATB_RECS * FLATB_WORDS * 4 + (size_t)4 * 5 * FLATB_RECS * 2)
-struct FlatCut { unsigned long long where, tri; };  // plane << 32 | bit of corner 0 (unpadded corner order); index of the first triangle
+#define FLATB_LDS_BYTES ((size_t)256 * 16 + (size_t)4 * FLATB_RECS * REC_WORDS * 4 + (size_t)4 * 5 * FLATB_RECS * 2)
+// list entry: case index << 48 | plane (of the slab) << 32 | bit of corner 0 (unpadded corner order)
 __global__ void __launch_bounds__(BLOCK) flat_cut_scan_kernel(const unsigned long long* __restrict__ negbits, const unsigned long long* __restrict__ nearbits,
-                                                              unsigned wpp, unsigned nx, unsigned ny, unsigned ncz, FlatCut* __restrict__ list,
-                                                              uint64_t list_cap, uint64_t tri_cap, MeshCounters* __restrict__ ctr) {
-  __shared__ unsigned long long s_red[3][BLOCK / 64], s_base[2];
-  __shared__ uint8_t s_nt[256];
+                                                              unsigned wpp, unsigned nx, unsigned ny, unsigned ncz,
+                                                              unsigned long long* __restrict__ list, uint64_t list_cap, MeshCounters* __restrict__ ctr) {
+  __shared__ unsigned long long s_red[2][BLOCK / 64], s_base;
   __shared__ unsigned s_flag[BLOCK / 64][FLATB_FLAGS / 32];
-  s_nt[threadIdx.x] = GSDF_MC_NTRI[threadIdx.x];
-  __syncthreads();
   const unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
   const unsigned sx = nx + 1;                      // corners per row: the bit planes' row length
   const uint64_t ncube_bits = (uint64_t)sx * ny;  // corner 0 of every cube has j < ny; < 2^32 (host checks sx * sy)
@@ -1449,8 +1452,8 @@ __global__ void __launch_bounds__(BLOCK) flat_cut_scan_kernel(const unsigned lon
     r.b0 = word(n1, wi); r.b1 = word(n1, wi + 1u); r.b2 = word(n1, wi + wq); r.b3 = word(n1, wi + wq + 1u);
     r.nr = word(nearbits + (uint64_t)cz * wpp, wi);
   };
-  // ... and what they say: sg[c] = sign word of corner c of the lane's 64 cubes, near = cubes passing the
-  // corner-0 test, cut = cubes to march
+  // ... and what they say: near = cubes passing the corner-0 test, cut = cubes to march, sg[c] = sign word of corner c of
+  // the lane's 64 cubes (SIGNS: the second walk needs them for the case indices)
   auto decide = [&](unsigned c, const Raw& r, unsigned long long (&sg)[8], unsigned long long& near, unsigned long long& cut) {
     // the cubes of this word that exist: i < nx (a row's last corner starts no cube), j < ny
     const uint64_t bit0 = (uint64_t)(c * 64u + lane) << 6;
@@ -1469,28 +1472,14 @@ __global__ void __launch_bounds__(BLOCK) flat_cut_scan_kernel(const unsigned lon
     const unsigned long long all = sg[0] & sg[1] & sg[2] & sg[3] & sg[4] & sg[5] & sg[6] & sg[7];
     cut = near & any & ~all;
   };
-  // triangles of cube t of the lane's word: the case index is bit t of the eight sign words (32-bit selects and bit-field
-  // extracts: a 64-bit shift by a per-lane amount costs four times as much)
-  auto ntri_of = [&](const unsigned long long (&sg)[8], unsigned t) {
+  // case index of cube t of the lane's word: bit t of the eight sign words (32-bit selects and bit-field extracts: a 64-bit
+  // shift by a per-lane amount costs four times as much)
+  auto case_of = [&](const unsigned long long (&sg)[8], unsigned t) {
     const bool hi = t >= 32u;
     unsigned ix = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) ix |= (((hi ? (unsigned)(sg[k] >> 32) : (unsigned)sg[k]) >> (t & 31u)) & 1u) << k;
-    return (unsigned)s_nt[ix];
-  };
-  // triangles of all cut cubes of the lane's word, two cubes per iteration (their table lookups are independent: the
-  // loop's length is the lookup latency times the iterations of the wave's fullest lane)
-  auto ntri_sum = [&](const unsigned long long (&sg)[8], unsigned long long m) {
-    unsigned n = 0;
-    while (m != 0ull) {
-      const unsigned t1 = (unsigned)__builtin_ctzll(m);
-      m &= m - 1ull;
-      const unsigned t2 = m != 0ull ? (unsigned)__builtin_ctzll(m) : t1;
-      const unsigned n1 = ntri_of(sg, t1), n2 = ntri_of(sg, t2);
-      n += n1 + (m != 0ull ? n2 : 0u);
-      m &= m - 1ull;  // (0 & anything = 0)
-    }
-    return n;
+    return ix;
   };
   auto wave_sum = [](unsigned long long v) {
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
@@ -1505,7 +1494,7 @@ __global__ void __launch_bounds__(BLOCK) flat_cut_scan_kernel(const unsigned lon
   };
   // first walk: how many. The next pass's words are in flight while a pass is decided; passes that hold surface are
   // remembered (one bit each, FLATB_FLAGS per wave; later ones are simply looked at again) so that the second walk skips the rest.
-  unsigned long long my_active = 0, my_cut = 0, my_tri = 0;
+  unsigned long long my_active = 0, my_cut = 0;
   unsigned flagw = 0u, it = 0;  // wave-uniform
   if (z0 < ncz) {
     unsigned cz = (unsigned)z0, c = (unsigned)(w0 - z0 * nchunk);
@@ -1515,13 +1504,11 @@ __global__ void __launch_bounds__(BLOCK) flat_cut_scan_kernel(const unsigned lon
       unsigned cz2 = cz, c2 = c;
       advance(cz2, c2);
       if (cz2 < ncz) fetch(cz2, c2, nxt);
-      unsigned long long sg[8];
-      unsigned long long near, cut;
+      unsigned long long sg[8], near, cut;
       decide(c, cur, sg, near, cut);
       cur = nxt; cz = cz2; c = c2;
       my_active += (unsigned long long)__builtin_popcountll(near);
       my_cut += (unsigned long long)__builtin_popcountll(cut);
-      my_tri += ntri_sum(sg, cut);
       if (it < FLATB_FLAGS) {
         if (__ballot(cut != 0ull) != 0ull) flagw |= 1u << (it & 31u);
         if ((it & 31u) == 31u) { if (lane == 0) s_flag[wv][it >> 5] = flagw; flagw = 0u; }
@@ -1529,164 +1516,124 @@ __global__ void __launch_bounds__(BLOCK) flat_cut_scan_kernel(const unsigned lon
     }
     if (it < FLATB_FLAGS && (it & 31u) != 0u && lane == 0) s_flag[wv][it >> 5] = flagw;
   }
-  my_active = wave_sum(my_active); my_cut = wave_sum(my_cut); my_tri = wave_sum(my_tri);
-  if (lane == 0) { s_red[0][wv] = my_active; s_red[1][wv] = my_cut; s_red[2][wv] = my_tri; }
+  my_active = wave_sum(my_active); my_cut = wave_sum(my_cut);
+  if (lane == 0) { s_red[0][wv] = my_active; s_red[1][wv] = my_cut; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned long long a = 0, c = 0, t = 0;
-    for (int k = 0; k < BLOCK / 64; k++) { a += s_red[0][k]; c += s_red[1][k]; t += s_red[2][k]; }
+    unsigned long long a = 0, c = 0;
+    for (int k = 0; k < BLOCK / 64; k++) { a += s_red[0][k]; c += s_red[1][k]; }
     if (a) atomicAdd(&ctr->n_active, a);
-    s_base[0] = c ? atomicAdd(&ctr->n_cut, c) : 0ull;   // the workgroup's stretch of the list ...
-    s_base[1] = t ? atomicAdd(&ctr->n_tris, t) : 0ull;  // ... and of the triangle buffer (both counters keep counting on overflow)
-    if (c && (s_base[0] + c > list_cap || s_base[1] + t > tri_cap)) ctr->overflow = 1ull;
+    s_base = c ? atomicAdd(&ctr->n_cut, c) : 0ull;  // the workgroup's stretch of the list (the counter keeps counting on overflow)
+    if (c && s_base + c > list_cap) ctr->overflow = 1ull;
   }
   __syncthreads();
-  unsigned long long at_c = s_base[0], at_t = s_base[1];  // wave-uniform: where this wave's next pass goes
-  for (unsigned k = 0; k < wv; k++) { at_c += s_red[1][k]; at_t += s_red[2][k]; }
-  at_c = uniform_u64(at_c); at_t = uniform_u64(at_t);
+  unsigned long long at_c = s_base;  // wave-uniform: where this wave's next pass goes
+  for (unsigned k = 0; k < wv; k++) at_c += s_red[1][k];
+  at_c = uniform_u64(at_c);
   if (my_cut == 0ull) return;  // (wave-uniform; no barrier follows)
   // second walk: the list
   unsigned cz = (unsigned)z0, c = (unsigned)(w0 - z0 * nchunk);
   for (it = 0; cz < ncz; it++, advance(cz, c)) {  // wave-uniform
     if (it < FLATB_FLAGS && ((s_flag[wv][it >> 5] >> (it & 31u)) & 1u) == 0u) continue;  // (wave-uniform) known to hold no surface
     Raw cur;
-    unsigned long long sg[8];
-    unsigned long long near, cut;
+    unsigned long long sg[8], near, cut;
     fetch(cz, c, cur);
     decide(c, cur, sg, near, cut);
     if (__ballot(cut != 0ull) == 0ull) continue;  // wave-uniform: no surface in these 4096 cubes
     const unsigned pc = (unsigned)__builtin_popcountll(cut);
-    const unsigned pt = ntri_sum(sg, cut);
-    unsigned long long pre = (unsigned long long)pc | ((unsigned long long)pt << 32);  // both prefix sums in one scan (< 2^32 each)
+    unsigned pre = pc;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const unsigned long long o = __shfl_up(pre, d, 64);
+      const unsigned o = __shfl_up(pre, d, 64);
       if (lane >= (unsigned)d) pre += o;
     }
-    const unsigned long long tot = __shfl(pre, 63, 64);  // wave-uniform
-    pre -= (unsigned long long)pc | ((unsigned long long)pt << 32);
-    unsigned long long ec = at_c + (unsigned)pre, et = at_t + (pre >> 32);
+    const unsigned tot = __shfl(pre, 63, 64);  // wave-uniform
+    unsigned long long ec = at_c + (pre - pc);
     const unsigned long long where0 = ((unsigned long long)cz << 32) | ((uint64_t)(c * 64u + lane) << 6);
-    for (unsigned long long m = cut; m != 0ull;) {  // two cubes per iteration, as above
-      const unsigned t1 = (unsigned)__builtin_ctzll(m);
-      m &= m - 1ull;
-      const bool two = m != 0ull;
-      const unsigned t2 = two ? (unsigned)__builtin_ctzll(m) : t1;
-      m &= m - 1ull;
-      const unsigned n1 = ntri_of(sg, t1), n2 = ntri_of(sg, t2);
-      if (ec < list_cap) list[ec] = FlatCut{where0 + t1, et};
-      if (two && ec + 1u < list_cap) list[ec + 1u] = FlatCut{where0 + t2, et + n1};
-      et += n1 + (two ? n2 : 0u);
-      ec += two ? 2u : 1u;
+    for (unsigned long long m = cut; m != 0ull; m &= m - 1ull, ec++) {  // (as long as the wave's fullest lane)
+      const unsigned t = (unsigned)__builtin_ctzll(m);
+      if (ec < list_cap) list[ec] = ((unsigned long long)case_of(sg, t) << 48) | (where0 + t);
     }
-    at_c += (unsigned)tot;
-    at_t += tot >> 32;
+    at_c += tot;
   }
 }
 
-// LDS: [tri table 4 KB | 4 x FLATB_RECS x 12 words | 4 x 5 FLATB_RECS u16 owner lists] = 18.5 KB: eight workgroups per CU.
-__global__ void __launch_bounds__(BLOCK, 8) flat_march_list_kernel(const float* __restrict__ grid, const FlatCut* __restrict__ list, uint64_t list_cap,
-                                                                unsigned nx, unsigned ny, unsigned czfirst, float ox, float oy, float oz, float res,
-                                                                float* __restrict__ tris, uint64_t tri_cap, MeshCounters* __restrict__ ctr) {
+// LDS: [tri table 4 KB | 4 x FLATB_RECS x 10 words | 4 x 5 FLATB_RECS u16 owner lists] = 16.5 KB; 80 registers: six workgroups per CU (at eight the kernel spills).
+__global__ void __launch_bounds__(BLOCK, 6) flat_march_list_kernel(const float* __restrict__ grid, const unsigned long long* __restrict__ list,
+                                                                uint64_t list_cap, unsigned nx, unsigned ny, unsigned czfirst, float ox, float oy,
+                                                                float oz, float res, float* __restrict__ tris, uint64_t tri_cap,
+                                                                MeshCounters* __restrict__ ctr) {
   int8_t* s_tri = (int8_t*)g_smem;
   const unsigned wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  uint32_t* buf = (uint32_t*)(s_tri + 256 * 16) + wv * (FLATB_RECS * FLATB_WORDS);  // [FLATB_WORDS][FLATB_RECS], this wave's
-  uint16_t* own = (uint16_t*)((uint32_t*)(s_tri + 256 * 16) + 4 * FLATB_RECS * FLATB_WORDS) + wv * (5 * FLATB_RECS);
+  uint32_t* buf = (uint32_t*)(s_tri + 256 * 16) + wv * (FLATB_RECS * REC_WORDS);  // [REC_WORDS][FLATB_RECS], this wave's
+  uint16_t* own = (uint16_t*)((uint32_t*)(s_tri + 256 * 16) + 4 * FLATB_RECS * REC_WORDS) + wv * (5 * FLATB_RECS);
   unsigned long long n = uniform_u64(ctr->n_cut);  // written by flat_cut_scan_kernel, the launch before
   for (int k = threadIdx.x; k < 256 * 16; k += BLOCK) s_tri[k] = (k & 15) == 15 ? (int8_t)GSDF_MC_NTRI[k >> 4] : GSDF_MC_TRI[k >> 4][k & 15];
   __syncthreads();
-  if (n > list_cap) n = list_cap;  // (the host reruns both kernels with room; what is listed is still marched within tri_cap)
+  if (n > list_cap) n = list_cap;  // (the host reruns both kernels with room; the triangles are still counted)
   const unsigned sx = nx + 1;
   const unsigned pitch = FLAT_PITCH(sx);  // the grid's row pitch
   const uint64_t pxy = (uint64_t)pitch * (ny + 1);
-  auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
-  // marching cubes of the buffered records: owner list (triangle -> record, number) from ballot prefix sums, then one output
-  // vertex per lane, at the address the record's list entry fixed (consecutive records = consecutive triangles, except where
-  // two workgroups' stretches of the list meet)
-  unsigned cnt = 0;  // records in this wave's buffer (wave-uniform)
-  auto flush = [&]() {
-    if (cnt == 0) return;
-    unsigned total = 0;
-    for (unsigned i0 = 0; i0 < cnt; i0 += 64u) {
-      const unsigned i = i0 + lane;
-      unsigned nt = 0;
-      if (i < cnt) nt = (unsigned)(uint8_t)s_tri[(buf[9 * FLATB_RECS + i] >> 16) * 16 + 15];
-      const unsigned long long q0 = __ballot((nt & 1u) != 0u), q1 = __ballot((nt & 2u) != 0u), q2 = __ballot((nt & 4u) != 0u);
-      const unsigned first = total + below(q0) + 2u * below(q1) + 4u * below(q2);
-      for (unsigned k = 0; k < nt; k++) own[first + k] = (uint16_t)(i | (k << 8));
-      total += (unsigned)__builtin_popcountll(q0) + 2u * (unsigned)__builtin_popcountll(q1) + 4u * (unsigned)__builtin_popcountll(q2);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the owner list is read by other lanes of this wave)
-    __builtin_amdgcn_wave_barrier();
-    struct __attribute__((packed, aligned(4))) V3 { float x, y, z; };
-    const unsigned n3 = total * 3u;
-    for (unsigned v = lane; v < n3; v += 64u) {
-      const unsigned t = v / 3u, j = v - 3u * t;
-      const unsigned o = own[t], i = o & 255u, k = o >> 8;
-      const uint32_t xy = buf[8 * FLATB_RECS + i], zi = buf[9 * FLATB_RECS + i];
-      const unsigned long long tri = ((unsigned long long)buf[11 * FLATB_RECS + i] << 32 | buf[10 * FLATB_RECS + i]) + k;
-      const int e = s_tri[(zi >> 16) * 16 + 3u * k + (2u - j)];  // reversed winding (marchcubes.go:64-68)
-      const unsigned ca = GSDF_MC_PAIR_A(e), cb = GSDF_MC_PAIR_B(e);
-      // cube origin exactly as the fused round-1 kernel formed it: o + (float)index * res
-      const float x0 = ox + (float)(xy & 0xffffu) * res, y0 = oy + (float)(xy >> 16) * res, z0 = oz + (float)(zi & 0xffffu) * res;
-      const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;
-      const bool ax = ((ca ^ (ca >> 1)) & 1u) != 0u, ay = ((ca >> 1) & 1u) != 0u, az = ((ca >> 2) & 1u) != 0u;
-      const bool bx = ((cb ^ (cb >> 1)) & 1u) != 0u, by = ((cb >> 1) & 1u) != 0u, bz = ((cb >> 2) & 1u) != 0u;
-      V3 r;
-      mc_interp(ax ? x1 : x0, ay ? y1 : y0, az ? z1 : z0, bx ? x1 : x0, by ? y1 : y0, bz ? z1 : z0,
-                __uint_as_float(buf[ca * FLATB_RECS + i]), __uint_as_float(buf[cb * FLATB_RECS + i]), r.x, r.y, r.z);
-      if (tri < tri_cap) *(V3*)(tris + tri * 9u + 3u * j) = r;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // the buffer is read out before new records overwrite it
-    __builtin_amdgcn_wave_barrier();
-    cnt = 0;
-  };
   // equal shares of whole 64-entry chunks, contiguous per wave (neighbouring entries are neighbouring cubes: their corner
-  // lines are shared). A chunk = one record per lane = one flush; the next chunk's distances and the list entries of the one
-  // after are in flight meanwhile.
+  // lines are shared)
   const uint64_t nchunks = (n + 63u) >> 6, nwaves = (uint64_t)gridDim.x * 4u, me = (uint64_t)blockIdx.x * 4u + wv;
   const uint64_t c_lo = nchunks * me / nwaves, c_hi = nchunks * (me + 1u) / nwaves;
-  struct Got { float d[8]; unsigned ci, cj, cz; unsigned long long tri; };
-  auto entry = [&](uint64_t ch, FlatCut& e) {
+  auto entry = [&](uint64_t ch) {
     const uint64_t at = (ch << 6) + lane;
-    e = at < n ? list[at] : FlatCut{0ull, 0ull};  // (padding lanes read cube 0 of plane 0: valid memory, nothing is kept)
+    return list[at < n ? at : n - 1u];  // (padding lanes of the last chunk read a valid entry; nothing of it is kept)
   };
-  auto gather = [&](const FlatCut& e, Got& g) {
-    const unsigned bit = (unsigned)e.where;
-    g.tri = e.tri;
-    g.cz = (unsigned)(e.where >> 32);
+  // how many triangles this workgroup's entries make, and where they go: one atomic per workgroup (one per wave -- 8 000 of
+  // them on one word as the kernel starts -- cost 60 us)
+  __shared__ unsigned long long s_mine[4], s_base;
+  unsigned long long mine = 0;
+  for (uint64_t ch = c_lo; ch < c_hi; ch++) {
+    const unsigned long long e = entry(ch);
+    if ((ch << 6) + lane < n) mine += (unsigned long long)(uint8_t)s_tri[(unsigned)(e >> 48) * 16u + 15u];
+  }
+  for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+  if (lane == 0) s_mine[wv] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long all = s_mine[0] + s_mine[1] + s_mine[2] + s_mine[3];
+    s_base = all ? atomicAdd(&ctr->n_tris, all) : 0ull;
+    if (all && s_base + all > tri_cap) ctr->overflow = 1ull;  // the counter keeps counting: the host learns the exact size and reruns
+  }
+  __syncthreads();
+  if (c_lo >= c_hi) return;  // (wave-uniform; no barrier follows)
+  unsigned long long base = s_base;
+  for (unsigned k = 0; k < wv; k++) base += s_mine[k];
+  base = uniform_u64(base);
+  // 64 cut cubes per trip: a chunk = one record per lane = one flush; the next chunk's distances and the list entries of the
+  // one after are in flight meanwhile
+  struct Got { float d[8]; unsigned ci, cj, cz, ix; };
+  auto gather = [&](unsigned long long e, Got& g) {
+    const unsigned bit = (unsigned)e;
+    g.ix = (unsigned)(e >> 48);
+    g.cz = (unsigned)(e >> 32) & 0xffffu;
     g.cj = bit / sx;
     g.ci = bit - g.cj * sx;
     const float* g0 = grid + (uint64_t)g.cz * pxy + (uint64_t)g.cj * pitch + g.ci;
     g.d[0] = g0[0]; g.d[1] = g0[1]; g.d[3] = g0[pitch]; g.d[2] = g0[pitch + 1u];
     g.d[4] = g0[pxy]; g.d[5] = g0[pxy + 1u]; g.d[7] = g0[pxy + pitch]; g.d[6] = g0[pxy + pitch + 1u];
   };
-  FlatCut e_nxt{0ull, 0ull};
+  unsigned long long e_nxt = entry(c_lo);
   Got cur{}, nxt{};
-  if (c_lo < c_hi) {
-    entry(c_lo, e_nxt);
-    gather(e_nxt, cur);
-    if (c_lo + 1u < c_hi) entry(c_lo + 1u, e_nxt);
-  }
+  gather(e_nxt, cur);
+  if (c_lo + 1u < c_hi) e_nxt = entry(c_lo + 1u);
+  unsigned cnt = 0;
   for (uint64_t ch = c_lo; ch < c_hi; ch++) {  // wave-uniform
     if (ch + 1u < c_hi) gather(e_nxt, nxt);
-    if (ch + 2u < c_hi) entry(ch + 2u, e_nxt);
+    if (ch + 2u < c_hi) e_nxt = entry(ch + 2u);
     const unsigned here = n - (ch << 6) < 64u ? (unsigned)(n - (ch << 6)) : 64u;  // records of this chunk (wave-uniform)
     if (lane < here) {
-      unsigned ix = 0;
 #pragma unroll
-      for (int c = 0; c < 8; c++) {
-        ix |= (cur.d[c] < 0.f ? 1u : 0u) << c;  // the same comparisons the bits came from
-        buf[c * FLATB_RECS + lane] = __float_as_uint(cur.d[c]);
-      }
+      for (int k = 0; k < 8; k++) buf[k * FLATB_RECS + lane] = __float_as_uint(cur.d[k]);
       buf[8 * FLATB_RECS + lane] = cur.ci | (cur.cj << 16);
-      buf[9 * FLATB_RECS + lane] = (czfirst + cur.cz) | (ix << 16);
-      buf[10 * FLATB_RECS + lane] = (uint32_t)cur.tri;
-      buf[11 * FLATB_RECS + lane] = (uint32_t)(cur.tri >> 32);
+      buf[9 * FLATB_RECS + lane] = (czfirst + cur.cz) | (cur.ix << 16);  // (the case index the sign bits gave: the same comparisons on the same values)
     }
     cnt = here;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    flush();
+    base += flat_flush_wave<FLATB_RECS, true>(buf, own, s_tri, cnt, lane, ox, oy, oz, res, tris, tri_cap, ctr, base);
     cur = nxt;
   }
 }
