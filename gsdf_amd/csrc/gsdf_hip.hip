@@ -336,6 +336,29 @@ extern "C" int gsdf_hip_selftest_div(float d, uint64_t* mismatches, uint64_t* fa
   return rc;
 }
 
+// Test hook: dm::circ_sector_fast (the circular array's sector index without the angle) against the reference's
+// floor(float32(atan2(y, x)) / angle) over 2^32 points -- all magnitudes, signed zeros, and points hugging the sector
+// boundaries -- for angle = float32(2 pi) / ncirc as circarray forms it (cpu_evaluators.go:1047).
+extern "C" int gsdf_hip_selftest_circ(float ncirc, uint64_t* mismatches, uint64_t* fast_path_points) {
+  if (mismatches) *mismatches = 0;
+  if (fast_path_points) *fast_path_points = 0;
+  if (!(ncirc >= 1.f)) return fail(GSDF_ERR_BAD_ARGUMENT, "ncirc must be >= 1");
+  const float angle = 6.2831853071795862f / ncirc;
+  unsigned long long* d_c = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_c, 16));
+  int rc = GSDF_OK;
+  do {
+    if (hipMemset(d_c, 0, 16) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "memset failed"); break; }
+    hipLaunchKernelGGL(circ_selftest_kernel, dim3(4096), dim3(BLOCK), 0, nullptr, angle, d_c, d_c + 1);
+    unsigned long long h[2] = {0, 0};
+    if (hipMemcpy(h, d_c, 16, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "selftest kernel failed"); break; }
+    if (mismatches) *mismatches = h[0];
+    if (fast_path_points) *fast_path_points = h[1];
+  } while (0);
+  (void)hipFree(d_c);
+  return rc;
+}
+
 // Test hook: dm::sqrt_1to2 against sqrtf for all 8,388,609 floats in [1, 2].
 extern "C" int gsdf_hip_selftest_sqrt(uint64_t* mismatches) {
   unsigned long long* d_c = nullptr;

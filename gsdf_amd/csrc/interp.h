@@ -896,14 +896,26 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       case D_CIRC_PRE: {
-        float th[K];  // atan2(P.y, P.x): a function of x,y only
-        xy_shared<K>(pv, th, sh_xy, brick, [](float x, float y) { return dm::atan2f_(y, x); }, sh_col);
+        // the sector index floor(atan2(P.y, P.x) / angle): from a float32 estimate of the angle where that decides it for
+        // every point of the wave (dm::circ_sector_fast), else by the reference's expression (where the points share x,y
+        // that one is computed once per pair / column anyway)
+        float idv[K];
+        bool fast = !sh_xy;
+        if (fast) {
+          const float inv_angle = __builtin_amdgcn_rcpf(PF(0)), m = 6e-6f * inv_angle;
+          KLOOP fast = dm::circ_sector_fast(pv[kp].x, pv[kp].y, inv_angle, m, idv[kp]) && fast;
+          fast = __builtin_amdgcn_ballot_w64(!fast) == 0ull;  // wave-uniform
+        }
+        if (!fast) {
+          float th[K];  // atan2(P.y, P.x): a function of x,y only
+          xy_shared<K>(pv, th, sh_xy, brick, [](float x, float y) { return dm::atan2f_(y, x); }, sh_col);
+          KLOOP idv[kp] = floorf_(th[kp] / PF(0));
+        }
         KLOOP {
           [[maybe_unused]] P3& p = pv[kp];
           [[maybe_unused]] float& R = Rv[kp];
           const float angle = PF(0), ncirc = PF(1), ninsm1 = PF(2);
-          const float pangle = th[kp];
-          float id = floorf_(pangle / angle);
+          float id = idv[kp];
           if (id < 0.f) id += ncirc;
           float i0, i1;
           if (id >= ninsm1) { i0 = ninsm1; i1 = 0.f; } else { i0 = id; i1 = id + 1.f; }

@@ -2036,6 +2036,43 @@ __global__ void __launch_bounds__(BLOCK) sqrt_selftest_kernel(unsigned long long
   if (nb) atomicAdd(bad, nb);
 }
 
+// Self-test of dm::circ_sector_fast against the reference's expression floor(float32(atan2(y, x)) / angle): 2^32 points --
+// even indices: both coordinates from a hash, all magnitudes and signs (exponents 2^-40 .. 2^40, plus zeros); odd indices:
+// points within 1e-3 .. 1e-9 rad of a sector boundary at radii 1e-2 .. 1e2. bad counts the points where the fast path decides
+// and differs; fast_count the points where it decides.
+__global__ void __launch_bounds__(BLOCK) circ_selftest_kernel(float angle, unsigned long long* __restrict__ bad,
+                                                              unsigned long long* __restrict__ fast_count) {
+  unsigned long long nb = 0, nf = 0;
+  const float inv_angle = __builtin_amdgcn_rcpf(angle), m = 6e-6f * inv_angle;
+  auto hash = [](unsigned v) { v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16; return v; };
+  for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < (1ull << 32); i += (unsigned long long)gridDim.x * BLOCK) {
+    const unsigned h1 = hash((unsigned)i), h2 = hash((unsigned)i ^ 0x9e3779b9u);
+    float x, y;
+    if ((i & 1ull) == 0ull) {
+      // sign | exponent 87..167 | 23 mantissa bits; one in 64 is a zero
+      x = __uint_as_float((h1 & 0x80000000u) | ((87u + (h1 >> 8) % 81u) << 23) | (h2 & 0x7fffffu));
+      y = __uint_as_float((h2 & 0x80000000u) | ((87u + (h2 >> 8) % 81u) << 23) | (h1 & 0x7fffffu));
+      if ((h1 & 63u) == 0u) x = (h2 & 1u) ? 0.f : -0.f;
+      if ((h2 & 63u) == 1u) y = (h1 & 1u) ? 0.f : -0.f;
+    } else {
+      const int k = (int)(h1 % 2001u) - 1000;
+      const float eps = __builtin_exp2f(-10.f - 20.f * (float)(h2 & 0xffffu) * (1.f / 65536.f)) * ((h2 & 0x10000u) ? 1.f : -1.f);
+      const float th = (float)k * angle + eps, rad = __builtin_exp2f(-6.6f + 13.2f * (float)(h1 >> 16) * (1.f / 65536.f));
+      float sn, cs;
+      dm::sincosf_(th, sn, cs);
+      x = rad * cs; y = rad * sn;
+    }
+    float id;
+    if (dm::circ_sector_fast(x, y, inv_angle, m, id)) {
+      nf++;
+      const float ref = dm::floorf_(dm::atan2f_(y, x) / angle);
+      if (__float_as_uint(id) != __float_as_uint(ref) && !(id == 0.f && ref == 0.f)) nb++;
+    }
+  }
+  if (nb) atomicAdd(bad, nb);
+  if (nf) atomicAdd(fast_count, nf);
+}
+
 // Exhaustive self-test of dm::div_by_uniform: every float32 numerator against the IEEE division.
 __global__ void __launch_bounds__(BLOCK) div_selftest_kernel(float d, float r, unsigned long long* __restrict__ bad,
                                                              unsigned long long* __restrict__ fast_count) {

@@ -72,6 +72,9 @@ uint64_t gsdf_hip_evaluations(const gsdf_program* p);
 int gsdf_hip_selftest_div(float d, uint64_t* mismatches, uint64_t* fast_path_numerators, float* recip);
 /* Test hook (needs a GPU): the interpreter's sqrt for hypot's [1,2] argument range against sqrtf, all floats in range. */
 int gsdf_hip_selftest_sqrt(uint64_t* mismatches);
+/* Test hook (needs a GPU): the circular array's sector index from a float32 angle estimate (taken only where it provably
+ * decides floor(atan2(y, x) / angle), cpu_evaluators.go:1047-1056) against that expression, over 2^32 points. */
+int gsdf_hip_selftest_circ(float ncirc, uint64_t* mismatches, uint64_t* fast_path_points);
 /* Run-time specialisation (no reference counterpart; the reference's GPU path compiles GLSL per tree at
  * gleval/gpu.go:35-54, this is the same step for the HIP backend): builds, with hiprtc, eval / prune / leaf kernels in
  * which this program's instructions are laid out straight-line with literal parameters, and makes the handle launch

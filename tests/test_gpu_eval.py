@@ -206,6 +206,16 @@ def test_large_batch_and_special_values(gpu):
     assert np.isfinite(d).all()
 
 
+def test_circular_array_sector_index_without_the_angle(gpu):
+    """dm::circ_sector_fast decides floor(atan2(y, x) / angle) from a float32 estimate only where that is certain: 2^32 points
+    per sector count (all magnitudes, signed zeros, points within 1e-9 rad of the boundaries), no mismatch allowed."""
+    import ctypes as C
+    for ncirc in (24, 3, 7, 12, 100, 1000):
+        bad, nfast = C.c_uint64(1), C.c_uint64(0)
+        assert gpu.lib().gsdf_hip_selftest_circ(np.float32(ncirc), C.byref(bad), C.byref(nfast)) == 0
+        assert bad.value == 0 and nfast.value > 1_500_000_000, (ncirc, bad.value, nfast.value)
+
+
 def test_sqrt_unit_range_exhaustive(gpu):
     import ctypes as C
     bad = C.c_uint64(1)
