@@ -1471,11 +1471,17 @@ extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, in
     HIP_TRYM(hipEventRecord(p->ev[3], s));
     HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));
     HIP_TRYM(hipStreamSynchronize(s));
-    if (hc.overflow) {  // (either pass keeps counting: n_tris is exact)
+    if (hc.overflow) {
+      // The float-stream pass keeps counting: n_tris is exact. So does the bit-plane pass as long as its cut-cube list held
+      // every cut cube (n_cut <= capacity); if not, n_cut is still exact and n_tris covers the listed cubes only: a cut cube
+      // has 1 to 5 triangles (2.2 on the configs' surfaces), so room for 3 per cut cube holds the list for certain and
+      // the triangles nearly always -- one more exact rerun otherwise.
       if (attempt >= 5) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
+      const bool list_short = hc.n_cut > m->cap;
       pool_give(p->device, m->d_tris, m->cap);
       m->d_tris = nullptr; m->cap = 0;
       want = hc.n_tris + hc.n_tris / 16 + 1024;
+      if (list_short && want < 3 * hc.n_cut) want = 3 * hc.n_cut;
       continue;
     }
     break;
