@@ -15,8 +15,11 @@
 //                        owner list (mc_emit_balanced), staged in LDS and flushed coalesced
 //                                                                   glrender/marchcubes.go:14-98
 //   flat_grid_kernel     SDF on every corner of the flat lattice    glrender/flatrenderer.go:103-182
-//   flat_march_kernel    marching cubes of every lattice cube from the distance grid (HBM-bound)
+//                        (+ two bits per corner: d < 0, |d| <= 2 sqrt3 res)
+//   flat_cut_scan_kernel, flat_march_list_kernel
+//                        marching cubes of every lattice cube: cut cubes found from the bit planes, listed, marched
 //                                                                   glrender/flatrenderer.go:186-256
+//   flat_march_kernel    the same from the float grid alone (GSDF_HIP_FLAT_STREAM=1; rounds 1-2)
 //   dc_*_kernel          dual contouring stages                     glrender/dual_contour*.go
 //   stl_kernel           50-byte STL records staged through LDS     glrender/stl.go:15-62
 //   normals_kernel       central differences                        gleval/gleval.go:53-108
@@ -1176,7 +1179,7 @@ __global__ void __launch_bounds__(BLOCK, W) flat_grid_kernel(const uint32_t* __r
       const unsigned k = g * K + (unsigned)z;
       const bool ok = col < sxy && k < nk;
       if (ok) grid[(uint64_t)k * FLAT_PITCH(sx) * sy + (uint64_t)j * FLAT_PITCH(sx) + i] = d[z];
-      // the two things the marching pass wants to know about most corners, one bit each (see flat_march_bits_kernel):
+      // the two things the marching pass wants to know about most corners, one bit each (see flat_cut_scan_kernel):
       // word (t * 4 + wave) of plane k, bit = lane, i.e. bit (i + sx * j) of the plane in the UNPADDED corner order
       const unsigned long long ng = __ballot(ok && d[z] < 0.f), nr = __ballot(ok && dm::absf(d[z]) <= cubeDiag);
       if (k < nk && (threadIdx.x & 63u) == 0u) {
@@ -1189,7 +1192,8 @@ __global__ void __launch_bounds__(BLOCK, W) flat_grid_kernel(const uint32_t* __r
 }
 
 #ifndef GSDF_SPECIALIZED
-// flat_march_kernel: marching cubes of every cube of the lattice from the distance grid (FlatRenderer.ReadTriangles,
+// flat_march_kernel (GSDF_HIP_FLAT_STREAM=1; the default marching pass is flat_cut_scan_kernel + flat_march_list_kernel
+// below): marching cubes of every cube of the lattice from the distance grid (FlatRenderer.ReadTriangles,
 // glrender/flatrenderer.go:186-256). HBM-bound by design: 4 B per lattice corner in, 36 B per triangle out. Round 2:
 // every WAVE on its own -- no workgroup barrier and no shared stage in the loop (round 1's kernel had one barrier per
 // pass and its waves waited 68 % of their cycles at 32 % of the HBM peak).
