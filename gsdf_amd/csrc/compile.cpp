@@ -453,7 +453,7 @@ double subtree_cost(Ctx& c, uint32_t i, int depth = 0) {
     default: return 25.0 + kids;
   }
 }
-constexpr double kGateMinCost = 60.0;  // cheaper children are evaluated rather than tested (a gate costs ~12 per point); 80 until the end of round 2, which left the vents of knurled-cylinder (translate + rotation + cylinder = 75) ungated
+constexpr double kGateMinCost = 60.0;  // cheaper children are evaluated rather than tested (a gate costs ~12 per point); 80 until the end of round 2, which left the vents of knurled-cylinder (translate + rotation + cylinder = 75) ungated; 40 measured no better for knurled-cylinder and bolt and 6 % worse for npt-flange (gates on cheap primitives that rarely fire)
 
 // n-ary / binary combine frame (cpu_evaluators.go:124-286, 821-912). Children that do not rewrite the
 // position are evaluated first (min/max are order-independent; for the asymmetric binary ops the
