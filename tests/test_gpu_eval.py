@@ -216,6 +216,38 @@ def test_circular_array_sector_index_without_the_angle(gpu):
         assert bad.value == 0 and nfast.value > 1_500_000_000, (ncirc, bad.value, nfast.value)
 
 
+def test_circular_array_points_on_sector_boundaries(gpu):
+    """The sector index comes from a float32 angle estimate unless some point of the wave is too close to a sector boundary:
+    points ON the boundaries (angle k * 2 pi / n to the last bit, the axes, +-0, the origin) mixed with ordinary ones, so that
+    waves take both paths and the hand-over is exact; interpreter and specialised kernels, 3-D and 2-D arrays."""
+    b = Builder()
+    rng = np.random.default_rng(5)
+    for div in (3, 4, 7, 24, 45):
+        n = max(1, div - 1)
+        sh3 = b.CircularArray(b.Translate(b.NewBox(0.6, 0.4, 0.5, 0.05), 1.5, 0, 0), n, div)
+        sh2 = b.CircularArray2D(b.Translate2D(b.NewRectangle(0.6, 0.4), 1.5, 0), n, div)
+        k = rng.integers(-2 * div, 2 * div, 40000)
+        th = (k * (2 * np.pi / div)).astype(np.float64)
+        th[::3] += rng.standard_normal(len(th[::3])) * 10.0 ** rng.uniform(-9, -1, len(th[::3]))   # a third near, not on
+        rad = 10.0 ** rng.uniform(-1.5, 1.0, len(th))
+        xy = np.stack([rad * np.cos(th), rad * np.sin(th)], 1).astype(np.float32)
+        xy[:64] = 0.0
+        xy[64:128, 1] = 0.0
+        xy[128:192, 1] = -0.0
+        xy[192:256, 0] = 0.0
+        xy[256:320, 0] = -0.0
+        far = (rng.standard_normal((20000, 2)) * 3).astype(np.float32)                                 # waves that never leave the fast path
+        xy = np.concatenate([xy, far])
+        z = (rng.standard_normal(len(xy)) * 0.4).astype(np.float32)
+        for shape, pos in ((sh3, np.concatenate([xy, z[:, None]], 1)), (sh2, xy)):
+            pos = np.ascontiguousarray(pos, np.float32)
+            ref = OracleSDF(shape.tree()).Evaluate(pos)
+            sdf = gpu.SDFHIP(shape)
+            assert _mismatch(sdf.Evaluate(pos), ref) == 0, (div, pos.shape)
+            sdf.specialize()
+            assert _mismatch(sdf.Evaluate(pos), ref) == 0, (div, pos.shape, "specialised")
+
+
 def test_sqrt_unit_range_exhaustive(gpu):
     import ctypes as C
     bad = C.c_uint64(1)
