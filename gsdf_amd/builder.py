@@ -206,6 +206,8 @@ class Builder:
     def BoltISO(self, D, P, ext, style, total, shank): return self._call("threads.Bolt.ISO", [D, P, total, shank], [int(ext), style])
     def HexHead(self, r, h, round_neg, round_pos): return self._call("threads.HexHead", [r, h], [int(round_neg), int(round_pos)])
     def KnurledHead(self, r, h, pitch): return self._call("threads.KnurledHead", [r, h, pitch])
+    def ScrewPlasticButtress(self, D, P, length): return self._call("threads.Screw.PlasticButtress", [D, P, length])
+    def Knurl(self, length, radius, pitch, height, theta): return self._call("threads.Knurl", [length, radius, pitch, height, theta])
     # ---- forge/textsdf (font.go): one line of text set in a TrueType font, as a 2-D shape
     def TextLine(self, ttf_bytes, text, reltol=0.0):
         """textsdf.Font{}.LoadTTFBytes(ttf); Configure(FontConfig{RelativeGlyphTolerance: reltol}); TextLine(text)."""

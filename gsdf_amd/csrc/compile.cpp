@@ -43,6 +43,9 @@ struct Ctx {
   std::vector<uint32_t> code;
   int slots = 0;      // currently allocated
   int max_slots = 0;
+  int lip_depth = 0, max_lip_depth = 0;  // nesting of the position maps that stretch (interval stack of D_LIP_PUSH / _POP)
+  int lip_push() { const int d = lip_depth++; if (lip_depth > max_lip_depth) max_lip_depth = lip_depth; op(D_LIP_PUSH, d); return d; }
+  void lip_pop(int d) { op(D_LIP_POP, d); lip_depth--; }
   size_t max_code;
   std::vector<int8_t> clob;  // memo: -1 unknown, 0/1
   struct Table { size_t patch; float angle; int n; };
@@ -127,6 +130,66 @@ struct Ctx {
   const gsdf_node& node(uint32_t i) const { return t->nodes[i]; }
   uint32_t child(const gsdf_node& n, uint32_t k) const { return t->links[n.link_off + k]; }
 };
+
+// ---- interval mode of the octree's centre tests (dev_ops.h: D_LIP_*): constants of the stretch factors. The oracle
+// computes the same numbers with the same operation sequences (oracle/orc_eval.c: lip_norm3, lip_norm2, lip_screw_seam).
+// Largest singular value of the 3x3 linear part of a row-major 4x4 (cyclic Jacobi on A^T A, fixed sweeps, double).
+float lip_norm3(const float* m) {
+  double b[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double acc = 0;
+      for (int k = 0; k < 3; k++) acc += (double)m[4 * k + i] * (double)m[4 * k + j];
+      b[i][j] = acc;
+    }
+  for (int sweep = 0; sweep < 12; sweep++)
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        double apq = b[p][q];
+        if (apq == 0.0) continue;
+        double theta = (b[q][q] - b[p][p]) / (2.0 * apq);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < 3; k++) { double x = b[k][p], y = b[k][q]; b[k][p] = c * x - sn * y; b[k][q] = sn * x + c * y; }
+        for (int k = 0; k < 3; k++) { double x = b[p][k], y = b[q][k]; b[p][k] = c * x - sn * y; b[q][k] = sn * x + c * y; }
+      }
+  double e = b[0][0] > b[1][1] ? b[0][0] : b[1][1];
+  if (b[2][2] > e) e = b[2][2];
+  return (float)std::sqrt(e);
+}
+float lip_norm2(float a, float b, float c, float d) {  // 2x2 [[a b][c d]]
+  double S = (double)a * a + (double)b * b + (double)c * c + (double)d * d, D = (double)a * d - (double)b * c;
+  double disc = S * S - 4.0 * D * D;
+  if (disc < 0) disc = 0;
+  return (float)std::sqrt(0.5 * (S + std::sqrt(disc)));
+}
+constexpr float kLipRigidTol = 1.00001f;  // a linear map counts as rigid (factor 1) up to this;
+constexpr float kLipRoundUp = 1.000001f;  // beyond it the factor is rounded up
+// How much a screw's field may jump across a seam of its sawtooth: the profile is evaluated at ONE period of the axial
+// coordinate, so its field at (+pitch/2, y) meets its field at (-pitch/2, y) there. They differ by less than the distance
+// between the two points, the pitch; if the profile is a polygon that is its own mirror image in x up to d (vertex i of the
+// mirror image within d, per coordinate, of vertex k - i of the polygon for some k: the same boundary the other way round),
+// the boundaries lie within sqrt2 d of each other and so do their distance fields: 3 d. ISO / NPT forms come out of
+// PolygonBuilder.Smooth symmetric to a few 1e-7; buttress forms are not symmetric at all.
+float lip_screw_seam(const gsdf_tree& t, uint32_t child, float pitch) {
+  const gsdf_node& c = t.nodes[child];
+  const float ap = std::fabs(pitch);
+  if (c.op != GSDF_POLY2D) return ap;
+  const float* v = &t.aux[c.aux_off];
+  const uint32_t nv = c.aux_len / 2;
+  float best = ap;
+  for (uint32_t k = 0; k < nv; k++) {
+    float dk = 0.0f;
+    for (uint32_t i = 0; i < nv; i++) {
+      const uint32_t w = (k + nv - i) % nv;
+      const float dx = std::fabs(-v[2 * i] - v[2 * w]), dy = std::fabs(v[2 * i + 1] - v[2 * w + 1]);
+      if (dx > dk) dk = dx;
+      if (dy > dk) dk = dy;
+    }
+    if (dk < best) best = dk;
+  }
+  return best <= 1e-3f * ap ? 3.0f * best : ap;
+}
 
 // Does evaluating node i overwrite the position register?
 bool clobbers(Ctx& c, uint32_t i) {
@@ -676,10 +739,16 @@ void gen(Ctx& c, uint32_t i, int depth) {
     case GSDF_TRANSFORM: {                                                                         // :488-504
       need_children(1); child_dim(false);
       if (n.aux_len < 16) throw std::runtime_error("transform needs 16 aux floats");
+      int lipd = -1;
+      {  // a map that is not rigid stretches the cube's image: interval mode scales its radius (prune_kernel only)
+        float f = lip_norm3(&c.t->aux[n.aux_off]);
+        if (f > kLipRigidTol) { lipd = c.lip_push(); c.op(D_LIP_MUL); c.f(f * kLipRoundUp); }
+      }
       c.op(D_TRANSFORM);
       for (int k = 0; k < 12; k++) c.f(c.t->aux[n.aux_off + k]);
       c.bump();
       gen(c, c.child(n, 0), depth + 1);
+      if (lipd >= 0) c.lip_pop(lipd);
       break;
     }
     case GSDF_CIRCARRAY: case GSDF_CIRCARRAY2D: {                                                  // :1042-1143
@@ -710,8 +779,13 @@ void gen(Ctx& c, uint32_t i, int depth) {
       c.release(is2d ? 3 : 4);
       break;
     }
-    case GSDF_TWIST: need_children(1); child_dim(false);                                           // :1257-1274
-      c.op(D_TWIST | c.shz_flag()); c.f(P[0]); c.bump(); gen(c, c.child(n, 0), depth + 1); break;
+    case GSDF_TWIST: {                                                                             // :1257-1274
+      need_children(1); child_dim(false);
+      const int lipd = c.lip_push();  // D_TWIST stretches the interval radius by the twist's shear (interp.h, LIP)
+      c.op(D_TWIST | c.shz_flag()); c.f(P[0]); c.bump(); gen(c, c.child(n, 0), depth + 1);
+      c.lip_pop(lipd);
+      break;
+    }
     // ------------------------------- 2D -> 3D -------------------------------
     case GSDF_EXTRUSION: {                                                                         // :506-531
       need_children(1); child_dim(true);
@@ -727,10 +801,13 @@ void gen(Ctx& c, uint32_t i, int depth) {
     case GSDF_SCREW: {                                                                             // threads.go:141-181
       need_children(1); child_dim(true);
       int s = c.alloc(1);
+      const int lipd = c.lip_push();  // D_SCREW_PRE stretches the interval radius by the helix map (interp.h, LIP)
       c.op(D_SCREW_PRE | c.hxy_flag() | c.shxy_flag(), s);
       c.bump();
       c.f(P[0]); c.f(P[1]); c.f(P[2]); c.f(gsdf::tanf32(P[3])); c.f(P[0] / 2); c.f(recip_for(P[0]));
+      c.op(D_LIP_WRAP); c.f(P[0] / 2); c.f(lip_screw_seam(*c.t, c.child(n, 0), P[0]));
       gen(c, c.child(n, 0), depth + 1);
+      c.lip_pop(lipd);
       c.op(D_MAXR_SLOT, s);
       c.release(1);
       break;
@@ -853,8 +930,17 @@ void gen(Ctx& c, uint32_t i, int depth) {
       c.release(3);
       break;
     }
-    case GSDF_ROTATION2D: need_children(1); child_dim(true);                                       // :1186-1203
-      c.op(D_ROT2D); c.f(P[0]); c.f(P[1]); c.f(P[2]); c.f(P[3]); c.bump(); gen(c, c.child(n, 0), depth + 1); break;
+    case GSDF_ROTATION2D: {                                                                        // :1186-1203
+      need_children(1); child_dim(true);
+      int lipd = -1;
+      {
+        float f = lip_norm2(P[0], P[1], P[2], P[3]);
+        if (f > kLipRigidTol) { lipd = c.lip_push(); c.op(D_LIP_MUL); c.f(f * kLipRoundUp); }
+      }
+      c.op(D_ROT2D); c.f(P[0]); c.f(P[1]); c.f(P[2]); c.f(P[3]); c.bump(); gen(c, c.child(n, 0), depth + 1);
+      if (lipd >= 0) c.lip_pop(lipd);
+      break;
+    }
     case GSDF_SCALE2D: need_children(1); child_dim(true);                                          // :1205-1226
       c.op(D_SCALE_PRE); c.f(1.f / P[0]); c.bump(); gen(c, c.child(n, 0), depth + 1); c.op(D_MULR); c.f(P[0]); break;
     case GSDF_ELONGATE2D: {                                                                        // :1228-1255
@@ -941,6 +1027,7 @@ Program compile(const gsdf_tree& t, size_t max_code_words) {
   Program p;
   p.code = std::move(c.code);
   p.nslots = c.max_slots;
+  p.lip_depth = c.max_lip_depth;
   p.is2d = gsdf_op_is2d(t.nodes[t.root].op);
   p.has_exact_bb = exact_box(c, t.root, p.exact_bb);
   std::memcpy(p.bb, t.bb, sizeof(p.bb));

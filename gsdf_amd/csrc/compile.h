@@ -11,6 +11,7 @@ namespace gsdf_dev {
 struct Program {
   std::vector<uint32_t> code;  // dev_ops.h stream, terminated by D_END
   int nslots = 0;              // LDS scratch slots per lane
+  int lip_depth = 0;           // slots of the interval stack (dev_ops.h: D_LIP_PUSH / _POP); prune_kernel's columns = nslots + lip_depth
   bool is2d = false;           // root takes 2D positions
   float bb[6] = {0};
   // Set when the whole field is known to be >= the Euclidean distance to `exact_bb` (exact-distance primitives under

@@ -112,6 +112,34 @@ DM_INL float hypotf_(float p, float q) {
   const float r = lo / maxf(hi, 1.401298464324817e-45f);
   return hi * sqrt_1to2(1.0f + r * r);  // r in [0,1]
 }
+// ---- interval mode of the octree's centre tests (dev_ops.h: D_LIP_*). Stretch factors of the two position maps of the
+// reference that are not 1-Lipschitz; rho = distance of the cube centre from the node's z axis, rl = radius of the ball
+// that holds the cube's image there. The same float32 sequences as the oracle's (orc_eval.c: lip_twist / lip_screw).
+//   twist  (x,y) -> R(k z)(x,y) (cpu_evaluators.go:1257-1274): in the (radial, tangential, axial) frame the Jacobian is a
+//          shear by s = |k| rho in the (tangential, axial) plane, spectral norm (s + sqrt(s^2 + 4)) / 2, largest at the
+//          largest rho;
+//   screw  (threads.go:141-181) x' = saw(z + lead theta / 2pi), y' = rho + z tanT: rows (0, a, 1) and (1, 0, t) in that frame,
+//          a = |lead| / (2 pi rho); J J^T = [[1 + a^2, t], [t, 1 + t^2]], largest eigenvalue ((2 + a^2 + t^2) + sqrt((a^2 -
+//          t^2)^2 + 4 t^2)) / 2, largest at the smallest rho; no bound on the axis (LIP_BIG, finite so that nothing
+//          downstream sees Inf - Inf).
+#define GSDF_LIP_BIG 1e18f
+DM_INL float lip_twist(float rho, float rl, float ak) {
+  const float s = ak * (rho + rl);
+  return 0.5f * (s + sqrtf_(s * s + 4.0f));
+}
+DM_INL float lip_screw(float rho, float rl, float alead, float t) {
+  const float rmin = rho - rl;
+  if (!(rmin > 0.0f)) return GSDF_LIP_BIG;
+  const float a = alead / (6.2831855f * rmin);
+  const float a2 = a * a, t2 = t * t, dd = a2 - t2;
+  return sqrtf_(0.5f * ((2.0f + a2 + t2) + sqrtf_(dd * dd + 4.0f * t2)));
+}
+// |x| of the interval [lo, hi]
+DM_INL void lip_abs(float lo, float hi, float& alo, float& ahi) {
+  alo = maxf(maxf(lo, -hi), 0.0f);
+  ahi = maxf(-lo, hi);
+}
+
 DM_INL float norm3(float x, float y, float z) { return hypotf_(x, hypotf_(y, z)); }  // ms3.Norm
 DM_INL float norm2(float x, float y) { return hypotf_(x, y); }                       // ms2.Norm
 

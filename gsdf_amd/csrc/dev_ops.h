@@ -113,6 +113,22 @@ enum DevOp : uint32_t {
   //      reaches the result (it is >= the nearest child's value, which is always evaluated: its L <= bound).
   D_UBOUND2D,   // nb then nb x {minx miny maxx maxy}
   D_UBOUND3D,   // nb then nb x {minx miny minz maxx maxy maxz}
+  // ---- interval mode (sdf_eval<2, 0, LIP = true>; prune_kernel only -- every other kernel steps over these four).
+  //      The octree drops a cube when the field cannot vanish inside it. The reference decides that from the centre value
+  //      alone, |d| >= size * sqrt3/2 (octreerenderer.go:270-273): right for true distance fields, wrong for fields that grow
+  //      faster than distance (twist, screw, non-rigid transform) or jump (a screw with an asymmetric thread form, across
+  //      the seams of its sawtooth) -- examples/fibonacci-showerhead loses 23 triangles to it. In interval mode the lane's
+  //      two "points" are the SAME cube centre; point 0 carries a lower bound and point 1 an upper bound of the field over
+  //      the cube's bounding ball. lipR = radius of a ball holding that ball's image in the current frame (h at the root,
+  //      times the scale factors, times the stretch of the non-1-Lipschitz maps, plus the seam term): primitives, being exact
+  //      distances, yield value -+ lipR; monotone instructions act on the two points unchanged; the rest cross them
+  //      (difference, xor, |d|). For a tree of primitives under rigid motions and min / max the bounds are d -+ h exactly,
+  //      i.e. the reference's predicate. The oracle does the same with doubled batches (oracle/orc_eval.c: lipctx).
+  D_LIP_PUSH,   // (slot = nesting depth)  interval stack[depth] <- lipR           (before a map that stretches)
+  D_LIP_POP,    // (slot = nesting depth)  lipR <- interval stack[depth]           (after its subtree)
+  D_LIP_MUL,    // f : lipR *= f  (non-rigid D_TRANSFORM / D_ROT2D: largest singular value, rounded up)
+  D_LIP_WRAP,   // halfpitch seam : after D_SCREW_PRE; if |P.x| + lipR >= halfpitch (the image may reach a seam of the
+                // sawtooth) lipR += seam (what the profile's field can jump by there; compile.cpp: lip_screw_seam)
   D_OP_COUNT
 };
 
@@ -129,4 +145,5 @@ static const uint8_t kDevOpParams[D_OP_COUNT] = {
     /*SAVEP3*/ 0, /*LOADP3*/ 0, /*SAVEP2*/ 0, /*LOADP2*/ 0, /*SAVER*/ 0, /*SETSLOT*/ 1, /*SETR*/ 1,
     /*MIN*/ 0, /*MAX*/ 0, /*DIFF*/ 0, /*XOR*/ 0, /*SUNION*/ 2, /*SDIFF*/ 2, /*SINTER*/ 2,
     /*GATE2D*/ 10, /*GATE3D*/ 12, /*GATEZC*/ 13, /*UBOUND2D*/ 1, /*UBOUND3D*/ 1,
+    /*LIP_PUSH*/ 0, /*LIP_POP*/ 0, /*LIP_MUL*/ 1, /*LIP_WRAP*/ 2,
 };

@@ -961,7 +961,11 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   const int lq = levels < 3 ? levels : 3;
   // multi-GPU: bricks of level ls are dealt to ranks by a hash of their coordinates (brick_owner).
   const int ls = levels < lq + 2 ? levels : lq + 2;
-  const size_t lds_prune = p->lds_bytes(1) + PRUNE_STAGE * sizeof(Cube) + 64;
+  const int prune_cols = p->prog.nslots + p->prog.lip_depth;  // interval mode: two points per lane + the interval stack
+  const size_t lds_prune = (size_t)(prune_cols > 0 ? prune_cols : 1) * 2 * BLOCK * sizeof(float) + PRUNE_STAGE * sizeof(Cube) + 64;
+  int pmask = opts.prune & ~GSDF_PRUNE_ASSUME_SDF;  // levels to test: 0 none, 1 all, else bit L = Level L
+  if ((opts.prune & GSDF_PRUNE_ASSUME_SDF) && pmask == 0) pmask = 1;
+  const int ptest = (opts.prune & GSDF_PRUNE_ASSUME_SDF) ? 2 : 1;
   int lk, lw;
   size_t lds_m;
   p->leaf_config(&lk, &lw, &lds_m);
@@ -1023,20 +1027,20 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     static const int prune_bpc = [] { const char* e = getenv("GSDF_HIP_PRUNE_BPC"); return e ? atoi(e) : 4; }();  // tuning knob
     for (int level = levels; level >= lq; level--) {
       const int expand = level != levels;
-      const int do_test = (level >= 3 && (opts.prune == 1 || (opts.prune > 1 && ((opts.prune >> level) & 1)))) ? 1 : 0;
+      const int do_test = (level >= 3 && (pmask == 1 || (pmask > 1 && ((pmask >> level) & 1)))) ? ptest : 0;
       // upper bound of candidates at this level (for the grid only): 8^(levels-level), capped by the queue
       uint64_t bound = (levels - level) * 3 >= 40 ? UINT64_MAX : ((uint64_t)1 << (3 * (levels - level)));
       if (bound > capq[(level + 1) & 1] * 8) bound = capq[(level + 1) & 1] * 8;
       if (p->f_prune) {
         HIP_TRYM(launch_fn(p->f_prune, grid_for(bound, p->num_cu, prune_bpc), BLOCK, lds_prune, s, (const uint32_t*)p->d_code,
                            (const Cube*)q[(level + 1) & 1]->p, (unsigned long long)capq[(level + 1) & 1], (int)expand, (int)level,
-                           (int)p->prog.nslots, ox, oy, oz, res, (int)do_test,
+                           (int)prune_cols, (int)p->prog.nslots, ox, oy, oz, res, (int)do_test,
                            (Cube*)q[level & 1]->p, (unsigned long long)capq[level & 1], (int)((opts.shard_count > 1 && level == ls) ? 1 : 0),
                            (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr));
       } else
       hipLaunchKernelGGL(prune_kernel, dim3(grid_for(bound, p->num_cu, prune_bpc)), dim3(BLOCK), lds_prune, s, p->d_code,
-                         (const Cube*)q[(level + 1) & 1]->p, (unsigned long long)capq[(level + 1) & 1], expand, level, p->prog.nslots, ox, oy,
-                         oz, res, do_test, (Cube*)q[level & 1]->p,
+                         (const Cube*)q[(level + 1) & 1]->p, (unsigned long long)capq[(level + 1) & 1], expand, level, prune_cols,
+                         p->prog.nslots, ox, oy, oz, res, do_test, (Cube*)q[level & 1]->p,
                          (unsigned long long)capq[level & 1], (opts.shard_count > 1 && level == ls) ? 1 : 0,
                          (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr);
       HIP_TRYM(hipGetLastError());

@@ -311,12 +311,22 @@ __device__ __forceinline__ void smooth_h(const float (&num)[K], float k, float r
 // {0,4,1,5 | 3,7,2,6}, i.e. points 2j and 2j+1 enter with bitwise equal x,y and (K = 4) points j and j+2 with equal z.
 // Instructions the host compiler flagged D_FLAG_SHXY / D_FLAG_SHZ then compute their f(P.x,P.y) / g(P.z) once per
 // pair and copy it: same inputs, same operation sequence, same bits as evaluating every corner separately.
+// LIP (interval mode, dev_ops.h: D_LIP_*; prune_kernel only): K = 2, both points are the same cube centre, point 0 ends up
+// with a lower and point 1 with an upper bound of the field over the ball of radius lip_h around it. lip_base = first LDS
+// slot of the interval stack (the program's own slots come first).
+#define LIP_LO 0
+#define LIP_HI (K - 1)
+// value -+ radius: an exact distance (or any other 1-Lipschitz term of the current frame) over the ball
+#define LIP_WIDEN(lo, hi) { lo = lo - lipR; hi = hi + lipR; }
 #ifndef GSDF_SPECIALIZED
-template <int K, int SHARE = 0>
+template <int K, int SHARE = 0, bool LIP = false>
 __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)[K],
                                          float* __restrict__ lds /* already offset by tid */, const uint32_t nthreads,
-                                         const bool brick = false /* wave-uniform; see xy_shared */) {
+                                         const bool brick = false /* wave-uniform; see xy_shared */,
+                                         const float lip_h = 0.0f, const uint32_t lip_base = 0u) {
   using namespace dm;
+  static_assert(!LIP || (K == 2 && SHARE == 0), "interval mode: two points per lane, lower and upper bound");
+  [[maybe_unused]] float lipR = lip_h;
   KLOOP Rv[kp] = 0.0f;
   float hxy[K];  // hypot(P.x, P.y) cache shared by sibling primitives (validity is tracked by the host compiler)
   KLOOP hxy[kp] = 0.0f;
@@ -729,6 +739,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
           const float f = PF(0);
           p.x = f * p.x; p.y = f * p.y; p.z = f * p.z;
         }
+        if (LIP) lipR = lipR * PF(0);
         pc += 2;
         break;
       }
@@ -758,6 +769,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_TWIST: {
         float tc[K], ts[K];  // cos/sin(k * P.z): a function of z only
+        if (LIP) lipR = minf(lipR * lip_twist(hypotf_(pv[0].x, pv[0].y), lipR, absf(PF(0))), GSDF_LIP_BIG);
         {
           const float k = PF(0);
           if (sh_zu) {
@@ -804,6 +816,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
           [[maybe_unused]] float& R = Rv[kp];
           LDSF(slot) = absf(p.z) - PF(0);
         }
+        if (LIP) LIP_WIDEN(lds[((slot) * K + LIP_LO) * nthreads], lds[((slot) * K + LIP_HI) * nthreads]);  // |z| - h/2 over the ball
         pc += 2;
         break;
       }
@@ -838,6 +851,10 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
             LDSF(slot) = absf(p.z) - L;
             p.x = x0; p.y = y0;
           }
+          if (LIP) {
+            LIP_WIDEN(lds[((slot) * K + LIP_LO) * nthreads], lds[((slot) * K + LIP_HI) * nthreads]);  // |z| - L in the screw's own frame
+            lipR = minf(lipR * lip_screw(hxy[0], lipR, absf(lead), tanTaper), GSDF_LIP_BIG);
+          }
         }
         pc += 7;
         break;
@@ -850,6 +867,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
           LDSF(slot) = minf(maxf(qx, maxf(qy, qz)), 0.f);
           p.x = maxf(qx, 0.f); p.y = maxf(qy, 0.f); p.z = maxf(qz, 0.f);
         }
+        if (LIP) LIP_WIDEN(lds[((slot) * K + LIP_LO) * nthreads], lds[((slot) * K + LIP_HI) * nthreads]);  // min(max3(q), 0) is 1-Lipschitz here
         pc += 4;
         break;
       }
@@ -861,6 +879,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
           LDSF(slot) = minf(maxf(qx, qy), 0.f);
           p.x = maxf(qx, 0.f); p.y = maxf(qy, 0.f);
         }
+        if (LIP) LIP_WIDEN(lds[((slot) * K + LIP_LO) * nthreads], lds[((slot) * K + LIP_HI) * nthreads]);
         pc += 3;
         break;
       }
@@ -948,10 +967,43 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       // ------------------------------------------------ distance post-ops
-      case D_MULR: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = R * PF(0); } pc += 2; break; }
-      case D_SHELL_POST: { const float th = PF(0); KLOOP { float& R = Rv[kp]; R = th * (absf(R) - th); } pc += 2; break; }
+      case D_MULR: {
+        if (LIP) {  // the scale nodes' d * f on an interval (f of either sign); the ball's image is back in the outer frame
+          lipR = lipR * PF(0);
+          const float x0 = Rv[LIP_LO] * PF(0), x1 = Rv[LIP_HI] * PF(0);
+          Rv[LIP_LO] = minf(x0, x1); Rv[LIP_HI] = maxf(x0, x1);
+        } else {
+          KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = R * PF(0); }
+        }
+        pc += 2;
+        break;
+      }
+      case D_SHELL_POST: {
+        const float th = PF(0);
+        if (LIP) {
+          lipR = lipR * th;
+          float alo, ahi;
+          lip_abs(Rv[LIP_LO], Rv[LIP_HI], alo, ahi);
+          const float x0 = th * (alo - th), x1 = th * (ahi - th);
+          Rv[LIP_LO] = minf(x0, x1); Rv[LIP_HI] = maxf(x0, x1);
+        } else {
+          KLOOP { float& R = Rv[kp]; R = th * (absf(R) - th); }
+        }
+        pc += 2;
+        break;
+      }
       case D_ADDR: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = R + PF(0); } pc += 2; break; }
-      case D_ANNULUS: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = absf(R) - PF(0); } pc += 2; break; }
+      case D_ANNULUS: {
+        if (LIP) {
+          float alo, ahi;
+          lip_abs(Rv[LIP_LO], Rv[LIP_HI], alo, ahi);
+          Rv[LIP_LO] = alo - PF(0); Rv[LIP_HI] = ahi - PF(0);
+        } else {
+          KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = absf(R) - PF(0); }
+        }
+        pc += 2;
+        break;
+      }
       case D_EXTRUDE_POST: {
         float eax[K], eay[K], eh[K];
         KLOOP {
@@ -979,8 +1031,25 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       // ------------------------------------------------ combine (a = saved first operand, b = R)
       case D_COMBINE_MIN: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = minf(LDSF(slot), R); } pc += 1; break; }
       case D_COMBINE_MAX: { KLOOP { P3& p = pv[kp]; float& R = Rv[kp]; (void)p; (void)R; R = maxf(LDSF(slot), R); } pc += 1; break; }
-      case D_COMBINE_DIFF: { KLOOP { float& R = Rv[kp]; float a = LDSF(slot), b = R; if (swap_ab) { float t = a; a = b; b = t; } R = maxf(a, -b); } pc += 1; break; }
-      case D_COMBINE_XOR: { KLOOP { float& R = Rv[kp]; float a = LDSF(slot), b = R; R = maxf(minf(a, b), -maxf(a, b)); } pc += 1; break; }
+      case D_COMBINE_DIFF: {
+        float av[K], bv[K];
+        KLOOP { float a = LDSF(slot), b = Rv[kp]; if (swap_ab) { float t = a; a = b; b = t; } av[kp] = a; bv[kp] = b; }
+        if (LIP) { const float t = bv[LIP_LO]; bv[LIP_LO] = bv[LIP_HI]; bv[LIP_HI] = t; }  // decreasing in b: its bounds change places
+        KLOOP Rv[kp] = maxf(av[kp], -bv[kp]);
+        pc += 1;
+        break;
+      }
+      case D_COMBINE_XOR: {
+        if (LIP) {
+          const float alo = lds[((slot) * K + LIP_LO) * nthreads], ahi = lds[((slot) * K + LIP_HI) * nthreads], blo = Rv[LIP_LO], bhi = Rv[LIP_HI];
+          Rv[LIP_LO] = maxf(minf(alo, blo), -maxf(ahi, bhi));
+          Rv[LIP_HI] = maxf(minf(ahi, bhi), -maxf(alo, blo));
+        } else {
+          KLOOP { float& R = Rv[kp]; float a = LDSF(slot), b = R; R = maxf(minf(a, b), -maxf(a, b)); }
+        }
+        pc += 1;
+        break;
+      }
       case D_COMBINE_SUNION: {
         {
           const float k = PF(0), rk = PF(1);  // (0.5*(b -+ a)) / k by a wave-uniform k: exact reciprocal form
@@ -1010,8 +1079,9 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
             float a = LDSF(slot), b = Rv[kp];
             if (swap_ab) { float t = a; a = b; b = t; }
             av[kp] = a; bv[kp] = b;
-            num[kp] = 0.5f * (b + a);
           }
+          if (LIP) { const float t = bv[LIP_LO]; bv[LIP_LO] = bv[LIP_HI]; bv[LIP_HI] = t; }  // decreasing in b
+          KLOOP num[kp] = 0.5f * (bv[kp] + av[kp]);
           smooth_h<K, -1>(num, k, rk, hv);
           KLOOP {
             float& R = Rv[kp];
@@ -1058,7 +1128,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
             m2[kp] = minf(m2[kp], dx * dx + dy * dy);
           }
         }
-        KLOOP LDSF(slot) = 1.001f * sqrtf_(m2[kp]) + 1e-30f;
+        KLOOP LDSF(slot) = LIP ? 3.0e38f : 1.001f * sqrtf_(m2[kp]) + 1e-30f;  // (a bound at the centre says nothing about the cube)
         pc = q;
         break;
       }
@@ -1076,7 +1146,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
             m2[kp] = minf(m2[kp], dx * dx + dy * dy + dz * dz);
           }
         }
-        KLOOP LDSF(slot) = 1.001f * sqrtf_(m2[kp]) + 1e-30f;
+        KLOOP LDSF(slot) = LIP ? 3.0e38f : 1.001f * sqrtf_(m2[kp]) + 1e-30f;
         pc = q;
         break;
       }
@@ -1086,7 +1156,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         const bool has_outer = oslot != 0xffffu;  // wave-uniform
         KLOOP { a[kp] = LDSF(slot); cc[kp] = has_outer ? LDSF(oslot) : 0.0f; }
         region_lb_box<K, 2>(pv, PF(0), PF(1), 0.f, PF(2), PF(3), 0.f, L);
-        if (gate_far<K, 2>(pv, a, L, PF(4), PF(5), cc, has_outer, PF(7), PF(8))) {
+        if (!LIP && gate_far<K, 2>(pv, a, L, PF(4), PF(5), cc, has_outer, PF(7), PF(8))) {  // (a skip decided at the centre says nothing about the cube)
           KLOOP Rv[kp] = L[kp];
           pc += PU(9);
         } else {
@@ -1100,7 +1170,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         const bool has_outer = oslot != 0xffffu;
         KLOOP { a[kp] = LDSF(slot); cc[kp] = has_outer ? LDSF(oslot) : 0.0f; }
         region_lb_box<K, 3>(pv, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5), L);
-        if (gate_far<K, 3>(pv, a, L, PF(6), PF(7), cc, has_outer, PF(9), PF(10))) {
+        if (!LIP && gate_far<K, 3>(pv, a, L, PF(6), PF(7), cc, has_outer, PF(9), PF(10))) {
           KLOOP Rv[kp] = L[kp];
           pc += PU(11);
         } else {
@@ -1114,7 +1184,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         const bool has_outer = oslot != 0xffffu;
         KLOOP { a[kp] = LDSF(slot); cc[kp] = has_outer ? LDSF(oslot) : 0.0f; }
         region_lb_zcyl<K>(pv, hxy, use_hxy, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5), PF(6), L);
-        if (gate_far<K, 3>(pv, a, L, PF(7), PF(8), cc, has_outer, PF(10), PF(11))) {
+        if (!LIP && gate_far<K, 3>(pv, a, L, PF(7), PF(8), cc, has_outer, PF(10), PF(11))) {
           KLOOP Rv[kp] = L[kp];
           pc += PU(12);
         } else {
@@ -1122,10 +1192,16 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         }
         break;
       }
+      // ------------------------------------------------ interval mode bookkeeping (no-ops elsewhere)
+      case D_LIP_PUSH: { if (LIP) lds[((lip_base + slot) * K) * nthreads] = lipR; pc += 1; break; }
+      case D_LIP_POP: { if (LIP) lipR = lds[((lip_base + slot) * K) * nthreads]; pc += 1; break; }
+      case D_LIP_MUL: { if (LIP) lipR = minf(lipR * PF(0), GSDF_LIP_BIG); pc += 2; break; }
+      case D_LIP_WRAP: { if (LIP) { if (absf(pv[0].x) + lipR >= PF(0)) lipR = lipR + PF(1); } pc += 3; break; }
       default:
         KLOOP Rv[kp] = __builtin_nanf("");
         return;
     }
+    if (LIP && op >= D_SPHERE && op <= D_LINES2D) LIP_WIDEN(Rv[LIP_LO], Rv[LIP_HI]);  // a primitive: exact distance -+ radius
   }
 #undef PF
 #undef PU
@@ -1142,5 +1218,8 @@ namespace gsdf_dev {
 #undef ENSURE_HXY
 #undef LDSF
 #undef KLOOP
+#undef LIP_WIDEN
+#undef LIP_LO
+#undef LIP_HI
 
 }  // namespace gsdf_dev

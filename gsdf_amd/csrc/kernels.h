@@ -8,8 +8,9 @@
 // Kernels (all wave64, 256-thread workgroups, grid-stride with wave-uniform trip counts so that the
 // interpreter's program counter stays scalar):
 //   eval_kernel<DIM>     dist[i] = SDF(pos[i])                      gleval SDF3/SDF2.Evaluate
-//   prune_kernel         octree level: centre sample, keep iff |d| < size*sqrt3/2, block-wide
-//                        compaction of survivors                    glrender/octreerenderer.go:240-284
+//   prune_kernel         octree level: centre sample, keep unless the field's bounds over the cube exclude 0
+//                        (|d| >= size*sqrt3/2 for a distance field), block-wide compaction of survivors
+//                                                                   glrender/octreerenderer.go:240-284
 //   leaf_kernel          8 leaf corners (corner 0 first, reject |d0| > 2*sqrt3*res) + marching cubes
 //                        with the LDS triangle table; triangles are built one per lane from an LDS
 //                        owner list (mc_emit_balanced), staged in LDS and flushed coalesced
@@ -128,17 +129,21 @@ __host__ __device__ __forceinline__ unsigned brick_owner(unsigned x, unsigned y,
 // through LDS) into an LDS stage of PRUNE_STAGE cubes and appended to `out` with ONE global atomic per flush: a
 // single counter word takes ~88 atomics/us on MI355X, so the per-wave appends of the first version bounded the two
 // big levels (8940 waves at level 3 = 100 us of a 124 us kernel).
-// LDS: [nslots floats per lane | PRUNE_STAGE cubes | 4 wave totals | base].
+// The test (do_test = 1): the field's bounds over the cube's bounding ball, by interval evaluation at the centre (interp.h: LIP;
+// two "points" per lane), exclude 0 -- for a true distance field exactly the reference's |d| >= size * sqrt3/2, and still
+// surface-preserving for twists, screws and non-rigid transforms (dev_ops.h: D_LIP_*). do_test = 2: the reference's predicate
+// verbatim on the centre value, whatever the field (gsdf_mesh_opts.prune: GSDF_PRUNE_ASSUME_SDF).
+// LDS: [2 * ncols floats per lane (ncols = program slots + interval stack) | PRUNE_STAGE cubes | 4 wave totals | base].
 #define PRUNE_STAGE 1024
 __global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ in,
-                                                      unsigned long long in_cap, int expand, int level, int nslots, float ox,
+                                                      unsigned long long in_cap, int expand, int level, int ncols, int lip_base, float ox,
                                                       float oy, float oz, float res,
                                                       int do_test, Cube* __restrict__ out, unsigned long long out_cap,
                                                       int shard_here, unsigned shard_rank, unsigned shard_count,
                                                       MeshCounters* __restrict__ ctr) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
-  Cube* s_q = (Cube*)(g_smem + (size_t)(nslots > 0 ? nslots : 1) * BLOCK);
+  Cube* s_q = (Cube*)(g_smem + (size_t)(ncols > 0 ? ncols : 1) * 2 * BLOCK);
   unsigned* s_w = (unsigned*)(s_q + PRUNE_STAGE);  // [0..3] wave totals, [4..7] per-wave "passed the test" counts
   unsigned long long* s_base = (unsigned long long*)(s_w + 8);
   // the previous level counts every survivor, also those its queue had no room for (the host then grows the queues
@@ -184,10 +189,15 @@ __global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict
       p.x = 0.5f * (cx0 + (cx0 + size));
       p.y = 0.5f * (cy0 + (cy0 + size));
       p.z = 0.5f * (cz0 + (cz0 + size));
-      P3 pv[1] = {p};
-      float dv[1];
-      gsdf_dev::sdf_eval<1>(code, pv, dv, lds, BLOCK);
-      keep = valid && !(dm::absf(dv[0]) >= maxDist);
+      P3 pv[2] = {p, p};
+      float dv[2];
+      if (do_test == 2) {
+        gsdf_dev::sdf_eval<2>(code, pv, dv, lds, BLOCK);
+        keep = valid && !(dm::absf(dv[0]) >= maxDist);
+      } else {
+        gsdf_dev::sdf_eval<2, 0, true>(code, pv, dv, lds, BLOCK, false, maxDist, (uint32_t)lip_base);
+        keep = valid && !(dv[0] >= 0.0f || dv[1] <= 0.0f);
+      }
     }
     const unsigned long long pm = __ballot(keep);
     if (lane == 0) my_pass += (unsigned long long)__builtin_popcountll(pm);

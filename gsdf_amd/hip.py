@@ -27,6 +27,9 @@ SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "g
            "gsdf_hip_mesh_stl", "gsdf_hip_mesh_host_tris", "gsdf_hip_mesh_host_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner", "gsdf_hip_slab_range"]
 
 
+PRUNE_ASSUME_SDF = 1 << 30  # gsdf_hip.h: GSDF_PRUNE_ASSUME_SDF
+
+
 class MeshOpts(C.Structure):
     _fields_ = [("prune", C.c_int), ("shard_rank", C.c_int), ("shard_count", C.c_int), ("max_tris", C.c_uint64),
                 ("stream", C.c_void_p), ("share_corners", C.c_int), ("host_output", C.c_int)]
@@ -303,14 +306,15 @@ class OctreeHIP:
     argument has no meaning here (positions are generated on device)."""
 
     def __init__(self, sdf, res, evalBufferSize=64, prune=True, shard_rank=0, shard_count=1, max_tris=0, stream=None,
-                 share_corners=False, host_output=False):
+                 share_corners=False, host_output=False, assume_sdf=False):
         if evalBufferSize < 64:
             raise ValueError("bad octree eval buffer size")
         self.sdf = sdf
         self._mesh = None
         self._cursor = 0
-        # prune: True / False, or an int bit mask of the octree levels to centre-test (bit L = Level L >= 3)
-        self._opts = MeshOpts(int(prune), shard_rank, shard_count, max_tris, stream, int(share_corners), int(host_output))
+        # prune: True / False, or an int bit mask of the octree levels to centre-test (bit L = Level L >= 3);
+        # assume_sdf: the reference's predicate verbatim instead of the field's bounds over the cube (gsdf_hip.h)
+        self._opts = MeshOpts(int(prune) | (PRUNE_ASSUME_SDF if assume_sdf else 0), shard_rank, shard_count, max_tris, stream, int(share_corners), int(host_output))
         self.Reset(sdf, res)
 
     def Reset(self, sdf, res):

@@ -127,6 +127,13 @@ int gsdfb_op(void* hv, const char* name, const float* f, int nf, const int* i, i
     }
     if (n == "threads.HexHead") { need(2, 2); return threads::HexHead(b, f[0], f[1], i[0] != 0, i[1] != 0).id; }
     if (n == "threads.KnurledHead") { need(3, 0); return threads::KnurledHead(b, f[0], f[1], f[2]).id; }
+    if (n == "threads.Screw.PlasticButtress") { need(3, 0); return threads::Screw(b, f[2], threads::PlasticButtress(f[0], f[1])).id; }
+    if (n == "threads.Knurl") {
+      need(5, 0);
+      threads::KnurlParams k;
+      k.Length = f[0]; k.Radius = f[1]; k.Pitch = f[2]; k.Height = f[3]; k.Theta = f[4];
+      return threads::Knurl(b, k).id;
+    }
     // ---- scenes (benchmark configs)
     if (n == "scene.npt-flange") return scenes::NptFlange(b).id;
     if (n == "scene.bolt") return scenes::Bolt(b).id;

@@ -144,14 +144,23 @@ int gsdf_hip_normals3(gsdf_program* p, const float* pos, float* normals, size_t 
  * (w*h*4 bytes: black inside, white outside, red for NaN/Inf -- the renderer's default conversion). */
 int gsdf_hip_image2(gsdf_program* p, int w, int h, float* dist_out, uint8_t* rgba_out);
 
+/* gsdf_mesh_opts.prune flag: apply the reference's centre test verbatim, |d(centre)| >= size * sqrt3/2
+ * (octreerenderer.go:270-273), at the tested levels, as if the field were a true distance field. */
+#define GSDF_PRUNE_ASSUME_SDF (1 << 30)
 typedef struct gsdf_mesh_opts {
-  int prune;          /* 1: octree centre-test pruning of every Level>=3 cube (default); 0: visit all leaves; any other value:
-                         bit mask of the levels to test (bit L = cubes of Level L, L >= 3). The reference tests the
-                         capacity-limited frontier of its DecomposeBFS buffer only (octreerenderer.go:94-105,140): a handful
-                         of upper levels. Testing more levels changes nothing for fields that never grow faster than the
-                         distance; for the others (e.g. a 45-degree knurl screw, |grad| up to sqrt 2) a small cube can be
-                         dropped that holds surface -- examples/fibonacci-showerhead at resdiv 350 loses 23 of its 309,872
-                         triangles to the Level-3 tests and none to Levels >= 4 (tests/test_gpu_mesh.py) */
+  int prune;          /* which octree levels are centre-tested: 1 = every Level >= 3 (default), 0 = none (visit all leaves), any
+                         other value = bit mask (bit L = cubes of Level L, L >= 3). The reference tests the capacity-limited
+                         frontier of its DecomposeBFS buffer only (octreerenderer.go:94-105,140): a handful of upper levels.
+                         The test drops a cube when the field cannot vanish inside it: the bounds of the field over the cube's
+                         bounding ball, obtained by interval evaluation of the tree at the centre, exclude 0. For a true
+                         distance field those bounds are d -+ size * sqrt3/2, i.e. the reference's predicate
+                         |d| >= size * sqrt3/2 (:270-273); for fields that grow faster than distance (twist, screw, non-rigid
+                         transform) or jump (a screw with an asymmetric thread form, across the seams of its sawtooth) they
+                         are wider, so that no cube holding surface is dropped at any level: examples/fibonacci-showerhead
+                         at resdiv 350 gives the reference's 309,872 triangles (README.md:152,166), where the reference's
+                         predicate applied to every Level >= 3 cube gives 309,849. Or'ing GSDF_PRUNE_ASSUME_SDF in selects
+                         that predicate (a few percent fewer evaluations; exact only for 1-Lipschitz fields). Sector and cell
+                         seams of (circular) arrays are taken as continuous, as those nodes' own Bounds() assume. */
   int shard_rank;     /* multi-GPU: this rank ... */
   int shard_count;    /* ... of this many (1 = whole model). Bricks of 16^3 leaves go to rank gsdf_hip_brick_owner(x, y, z, count). */
   uint64_t max_tris;  /* device triangle buffer capacity; 0 = size automatically */

@@ -18,6 +18,9 @@ class _Mesh(C.Structure):
                 ("t_eval_s", C.c_double), ("t_march_s", C.c_double)]
 
 
+PRUNE_ASSUME_SDF = 1 << 30  # orc_eval.h: ORC_PRUNE_ASSUME_SDF
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
@@ -38,6 +41,8 @@ def lib():
         for f in (L.orc_eval3, L.orc_eval2):
             f.restype = C.c_int
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_eval3_bounds.restype = C.c_int
+        L.orc_eval3_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]
         L.orc_render_flat.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.POINTER(_Mesh)]
         L.orc_render_octree.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.POINTER(_Mesh)]
         L.orc_render_dualcontour.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(_Mesh)]
@@ -111,6 +116,16 @@ class OracleSDF:
         self.evals += n
         return dist
 
+    def EvaluateBounds(self, pos, h):
+        """(lo, hi): bounds of the field over the ball of radius h around each point (orc_eval3_bounds)."""
+        pos = np.ascontiguousarray(pos, np.float32)
+        n = pos.shape[0]
+        lo, hi = np.empty(n, np.float32), np.empty(n, np.float32)
+        err = self._L.orc_eval3_bounds(self._h, self._pool, pos.ctypes.data, lo.ctypes.data, hi.ctypes.data, n, np.float32(h))
+        if err:
+            raise RuntimeError(f"oracle eval error {err}")
+        return lo, hi
+
     def render_flat(self, res, batch=4096, nthreads=1):
         m = _Mesh()
         err = self._L.orc_render_flat(self._h, np.float32(res), batch, nthreads, C.byref(m))
@@ -120,7 +135,10 @@ class OracleSDF:
         self._L.orc_mesh_free(C.byref(m))
         return r
 
-    def render_octree(self, res, batch=4096, prune=True):
+    def render_octree(self, res, batch=4096, prune=True, assume_sdf=False):
+        """prune: True / False / bit mask of the levels to centre-test; assume_sdf: the reference's predicate verbatim
+        (|d| >= size*sqrt3/2) instead of the field's bounds over the cube."""
+        prune = int(prune) | (PRUNE_ASSUME_SDF if assume_sdf else 0)
         m = _Mesh()
         err = self._L.orc_render_octree(self._h, np.float32(res), batch, int(prune), C.byref(m))
         if err:

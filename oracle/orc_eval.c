@@ -30,9 +30,24 @@ typedef struct {
   size_t elem;
 } bufpool;
 
+/* Interval bookkeeping of the octree's centre tests (NOT part of the reference). With a context
+ * attached, a batch holds every point TWICE: entry 2j carries a lower bound and entry 2j+1 an upper bound of the field
+ * over the ball of radius h around point j (the cube whose centre it is). Primitives are exact distances (1-Lipschitz),
+ * so they yield value -+ e with e = the radius of the ball's image in their frame; the monotone nodes (min, max, smooth
+ * union / intersection, offset, scale ...) act on the two entries unchanged; the others (difference, xor, |d|) cross
+ * them, see binop_combine_lip / lip_abs. R[j] = radius of a ball that holds the image of ball j in the frame of the node
+ * being evaluated: h at the root, scaled by the scale nodes, stretched by the position maps that are not 1-Lipschitz
+ * (twist, screw, non-rigid transform), widened where the image may straddle a seam of a screw's sawtooth.
+ * The device evaluates the same thing with two "points" per lane (interp.h: LIP); same float32 operation sequences. */
+typedef struct {
+  float* R; /* per pair */
+} lipctx;
+#define LIP_BIG 1e18f /* cap of R: "no bound" (a ball that reaches a screw's axis) without Inf - Inf = NaN downstream */
+
 struct orc_pool {
   bufpool v3, v2, f;
   size_t min_alloc;
+  lipctx* lip;
 };
 
 orc_pool* orc_pool_create(size_t min_alloc) {
@@ -146,12 +161,136 @@ static inline float cross2(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
 static inline float ms1_clamp(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 static inline float ms1_sign(float a) { return a == 0 ? 0.0f : go_copysignf(1.0f, a); }
 
+/* ---- stretch factors: rho = distance of the centre from the node's z axis, rl = radius of the ball's image there.
+ *   twist  (x,y) -> R(k z)(x,y): in the (radial, tangential, axial) frame the Jacobian is a shear by s = |k| rho in the
+ *          (tangential, axial) plane; its spectral norm is (s + sqrt(s^2 + 4)) / 2, largest at the largest rho.
+ *   screw  (threads.go:141-181) x' = saw(z + lead theta / 2pi), y' = rho + z tanT: rows (0, a, 1) and (1, 0, t) in that
+ *          frame with a = |lead| / (2 pi rho); J J^T = [[1 + a^2, t], [t, 1 + t^2]], largest eigenvalue
+ *          ((2 + a^2 + t^2) + sqrt((a^2 - t^2)^2 + 4 t^2)) / 2, largest at the smallest rho; unbounded on the axis. */
+static inline float lip_twist(float rho, float rl, float ak) {
+  float s = ak * (rho + rl);
+  return 0.5f * (s + sqrtf(s * s + 4.0f));
+}
+static inline float lip_screw(float rho, float rl, float alead, float t) {
+  float rmin = rho - rl;
+  if (!(rmin > 0.0f)) return LIP_BIG;
+  float a = alead / (6.2831855f * rmin);
+  float a2 = a * a, t2 = t * t, dd = a2 - t2;
+  return sqrtf(0.5f * ((2.0f + a2 + t2) + sqrtf(dd * dd + 4.0f * t2)));
+}
+/* largest singular value of the 3x3 linear part of a row-major 4x4 (cyclic Jacobi on A^T A, fixed sweeps, double) */
+static float lip_norm3(const float* m) {
+  double b[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double acc = 0;
+      for (int k = 0; k < 3; k++) acc += (double)m[4 * k + i] * (double)m[4 * k + j];
+      b[i][j] = acc;
+    }
+  for (int sweep = 0; sweep < 12; sweep++)
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        double apq = b[p][q];
+        if (apq == 0.0) continue;
+        double theta = (b[q][q] - b[p][p]) / (2.0 * apq);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < 3; k++) { double x = b[k][p], y = b[k][q]; b[k][p] = c * x - sn * y; b[k][q] = sn * x + c * y; }
+        for (int k = 0; k < 3; k++) { double x = b[p][k], y = b[q][k]; b[p][k] = c * x - sn * y; b[q][k] = sn * x + c * y; }
+      }
+  double e = b[0][0] > b[1][1] ? b[0][0] : b[1][1];
+  if (b[2][2] > e) e = b[2][2];
+  return (float)sqrt(e);
+}
+static float lip_norm2(float a, float b, float c, float d) { /* 2x2 [[a b][c d]] */
+  double S = (double)a * a + (double)b * b + (double)c * c + (double)d * d, D = (double)a * d - (double)b * c;
+  double disc = S * S - 4.0 * D * D;
+  if (disc < 0) disc = 0;
+  return (float)sqrt(0.5 * (S + sqrt(disc)));
+}
+/* a linear map counts as rigid (factor 1) up to this; beyond it the factor is rounded up */
+#define LIP_RIGID_TOL 1.00001f
+#define LIP_ROUND_UP 1.000001f
+
+/* radius of the ball's image in the current frame, pair j */
+static inline float lip_radius(const lipctx* lc, size_t j) { return lc->R[j]; }
+static void lip_scale(lipctx* lc, size_t n, float f) { for (size_t j = 0; j < n / 2; j++) lc->R[j] = lc->R[j] * f; }
+/* value -+ radius: an exact distance (or any 1-Lipschitz term of the current frame) over the ball */
+static void lip_widen(const lipctx* lc, float* d, size_t n) {
+  for (size_t j = 0; j < n / 2; j++) {
+    float e = lip_radius(lc, j);
+    d[2 * j] = d[2 * j] - e;
+    d[2 * j + 1] = d[2 * j + 1] + e;
+  }
+}
+/* |x| of an interval */
+static inline void lip_abs(float lo, float hi, float* alo, float* ahi) {
+  *alo = go_maxf(go_maxf(lo, -hi), 0.0f);
+  *ahi = go_maxf(-lo, hi);
+}
+/* enter / leave a node whose position map stretches by f around pair j */
+static float* lip_enter(orc_pool* vp, size_t n) {
+  float* save = (float*)pool_acquire(vp, &vp->f, n / 2);
+  memcpy(save, vp->lip->R, (n / 2) * sizeof(float));
+  return save;
+}
+static inline void lip_stretch(lipctx* lc, size_t j, float f) { lc->R[j] = go_minf(lc->R[j] * f, LIP_BIG); }
+static void lip_leave(orc_pool* vp, float* save, size_t n) {
+  memcpy(vp->lip->R, save, (n / 2) * sizeof(float));
+  pool_release(&vp->f, save);
+}
+
+/* the scale nodes' d * f on an interval (f of either sign) */
+static void lip_mul(float* d, size_t n, float f) {
+  for (size_t j = 0; j < n / 2; j++) {
+    float x0 = d[2 * j] * f, x1 = d[2 * j + 1] * f;
+    d[2 * j] = go_minf(x0, x1);
+    d[2 * j + 1] = go_maxf(x0, x1);
+  }
+}
+
 static const float TRIBISECT = 0.8660254037844386467637231707529361834714026269051903140279034897f;
 static const float SQRT3 = 1.7320508075688772935274463415058723669428052538103806280558069794f;
 static const float LARGENUM = 1e20f;
 
-static int eval3(const orc_sdf* s, uint32_t ni, const V3* pos, float* dist, size_t n, orc_pool* vp);
-static int eval2(const orc_sdf* s, uint32_t ni, const V2* pos, float* dist, size_t n, orc_pool* vp);
+/* How much a screw's field may jump across a seam of its sawtooth. The profile's field at (+pitch/2, y) and at
+ * (-pitch/2, y) differ by less than the distance between the two points, the pitch. If the profile is a polygon that is
+ * its own mirror image in x up to d (vertex i of the mirror image within d, per coordinate, of vertex k - i of the
+ * polygon, for some k: the same boundary traversed the other way round), the two boundaries lie within sqrt2 d of each
+ * other and so do their distance fields: 3 d. The thread forms with rounded roots (ISO, NPT) come out of PolygonBuilder.Smooth
+ * symmetric to a few 1e-7; buttress forms are not symmetric at all. Same float32 sequence as compile.cpp: lip_screw_seam. */
+static float lip_screw_seam(const orc_sdf* s, uint32_t child, float pitch) {
+  const gsdf_node* c = &s->nodes[child];
+  const float ap = go_absf(pitch);
+  if (c->op != GSDF_POLY2D) return ap;
+  const float* v = &s->aux[c->aux_off];
+  const uint32_t nv = c->aux_len / 2;
+  float best = ap;
+  for (uint32_t k = 0; k < nv; k++) {
+    float dk = 0.0f;
+    for (uint32_t i = 0; i < nv; i++) {
+      const uint32_t w = (k + nv - i) % nv;
+      const float dx = go_absf(-v[2 * i] - v[2 * w]), dy = go_absf(v[2 * i + 1] - v[2 * w + 1]);
+      if (dx > dk) dk = dx;
+      if (dy > dk) dk = dy;
+    }
+    if (dk < best) best = dk;
+  }
+  return best <= 1e-3f * ap ? 3.0f * best : ap;
+}
+static int eval3_node(const orc_sdf* s, uint32_t ni, const V3* pos, float* dist, size_t n, orc_pool* vp);
+static int eval2_node(const orc_sdf* s, uint32_t ni, const V2* pos, float* dist, size_t n, orc_pool* vp);
+/* the reference's Evaluate of node ni; with an interval context attached, a primitive's distances become bounds */
+static int eval3(const orc_sdf* s, uint32_t ni, const V3* pos, float* dist, size_t n, orc_pool* vp) {
+  int err = eval3_node(s, ni, pos, dist, n, vp);
+  if (!err && vp->lip && s->nodes[ni].op >= GSDF_SPHERE && s->nodes[ni].op <= GSDF_HEX) lip_widen(vp->lip, dist, n);
+  return err;
+}
+static int eval2(const orc_sdf* s, uint32_t ni, const V2* pos, float* dist, size_t n, orc_pool* vp) {
+  int err = eval2_node(s, ni, pos, dist, n, vp);
+  if (!err && vp->lip && s->nodes[ni].op >= GSDF_LINE2D && s->nodes[ni].op <= GSDF_LINES2D) lip_widen(vp->lip, dist, n);
+  return err;
+}
 
 #define CHILD(nd, k) (s->links[(nd)->link_off + (k)])
 
@@ -161,6 +300,30 @@ static void min_reduce(float* d1_and_dst, const float* d2, size_t n) {
 }
 
 /* generic binary op frame: cpu_evaluators.go:146-286 (3D) and :847-912 (2D) */
+static inline float smooth_diff(float a, float b, float k) {
+  float h = orc_clampf(0.5f - 0.5f * (b + a) / k, 0, 1);
+  return orc_mixf(a, -b, h) + k * h * (1 - h);
+}
+/* interval forms of the combines that DEcrease in their second operand (entries 2j / 2j+1 = lower / upper bound) */
+static void binop_combine_lip(int op, float k, float* dist, const float* d2, size_t n) {
+  for (size_t j = 0; j < n / 2; j++) {
+    float alo = dist[2 * j], ahi = dist[2 * j + 1], blo = d2[2 * j], bhi = d2[2 * j + 1];
+    switch (op) {
+      case GSDF_DIFF: case GSDF_DIFF2D:
+        dist[2 * j] = go_maxf(alo, -bhi);
+        dist[2 * j + 1] = go_maxf(ahi, -blo);
+        break;
+      case GSDF_XOR: case GSDF_XOR2D:
+        dist[2 * j] = go_maxf(go_minf(alo, blo), -go_maxf(ahi, bhi));
+        dist[2 * j + 1] = go_maxf(go_minf(ahi, bhi), -go_maxf(alo, blo));
+        break;
+      default: /* GSDF_SMOOTH_DIFF */
+        dist[2 * j] = smooth_diff(alo, bhi, k);
+        dist[2 * j + 1] = smooth_diff(ahi, blo, k);
+        break;
+    }
+  }
+}
 static void binop_combine(int op, float k, float* dist, const float* d2, size_t n) {
   switch (op) {
     case GSDF_INTERSECT: case GSDF_INTERSECT2D:
@@ -199,7 +362,7 @@ static void binop_combine(int op, float k, float* dist, const float* d2, size_t 
   }
 }
 
-static int eval3(const orc_sdf* s, uint32_t ni, const V3* pos, float* dist, size_t n, orc_pool* vp) {
+static int eval3_node(const orc_sdf* s, uint32_t ni, const V3* pos, float* dist, size_t n, orc_pool* vp) {
   const gsdf_node* nd = &s->nodes[ni];
   const float* P = nd->p;
   int err = 0;
@@ -301,7 +464,10 @@ static int eval3(const orc_sdf* s, uint32_t ni, const V3* pos, float* dist, size
       float* d2 = ACQ_F(n);
       err = eval3(s, CHILD(nd, 0), pos, dist, n, vp);
       if (!err) err = eval3(s, CHILD(nd, 1), pos, d2, n, vp);
-      if (!err) binop_combine(nd->op, P[0], dist, d2, n);
+      if (!err) {
+        if (vp->lip && (nd->op == GSDF_DIFF || nd->op == GSDF_XOR || nd->op == GSDF_SMOOTH_DIFF)) binop_combine_lip(nd->op, P[0], dist, d2, n);
+        else binop_combine(nd->op, P[0], dist, d2, n);
+      }
       REL_F(d2);
       return err;
     }
@@ -310,7 +476,12 @@ static int eval3(const orc_sdf* s, uint32_t ni, const V3* pos, float* dist, size
       float factor = P[0];
       float inv = 1.f / P[0];
       for (size_t i = 0; i < n; i++) { sc[i].x = inv * pos[i].x; sc[i].y = inv * pos[i].y; sc[i].z = inv * pos[i].z; }
+      if (vp->lip) lip_scale(vp->lip, n, inv);
       err = eval3(s, CHILD(nd, 0), sc, dist, n, vp);
+      if (vp->lip) {
+        lip_scale(vp->lip, n, factor);
+        if (!err) lip_mul(dist, n, factor);
+      } else
       if (!err) for (size_t i = 0; i < n; i++) dist[i] *= factor;
       REL_V3(sc);
       return err;
@@ -362,6 +533,7 @@ static int eval3(const orc_sdf* s, uint32_t ni, const V3* pos, float* dist, size
         aux[i] = go_minf(go_maxf(q.x, go_maxf(q.y, q.z)), 0);
         t[i].x = go_maxf(q.x, 0); t[i].y = go_maxf(q.y, 0); t[i].z = go_maxf(q.z, 0);
       }
+      if (vp->lip) lip_widen(vp->lip, aux, n); /* min(max3(q), 0) is 1-Lipschitz in this frame */
       err = eval3(s, CHILD(nd, 0), t, dist, n, vp);
       if (!err) for (size_t i = 0; i < n; i++) dist[i] += aux[i];
       REL_F(aux);
@@ -372,7 +544,19 @@ static int eval3(const orc_sdf* s, uint32_t ni, const V3* pos, float* dist, size
       V3* t = ACQ_V3(n);
       float th = P[0];
       for (size_t i = 0; i < n; i++) { float f = 1 / th; t[i].x = f * pos[i].x; t[i].y = f * pos[i].y; t[i].z = f * pos[i].z; }
+      if (vp->lip) lip_scale(vp->lip, n, 1 / th);
       err = eval3(s, CHILD(nd, 0), t, dist, n, vp);
+      if (vp->lip) {
+        lip_scale(vp->lip, n, th);
+        if (!err)
+          for (size_t j = 0; j < n / 2; j++) {
+            float alo, ahi;
+            lip_abs(dist[2 * j], dist[2 * j + 1], &alo, &ahi);
+            float x0 = th * (alo - th), x1 = th * (ahi - th);
+            dist[2 * j] = go_minf(x0, x1);
+            dist[2 * j + 1] = go_maxf(x0, x1);
+          }
+      } else
       if (!err) for (size_t i = 0; i < n; i++) dist[i] = th * (go_absf(dist[i]) - th);
       REL_V3(t);
       return err;
@@ -399,7 +583,17 @@ static int eval3(const orc_sdf* s, uint32_t ni, const V3* pos, float* dist, size
         t[i].y = m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7];
         t[i].z = m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11];
       }
+      float* vsave = NULL;
+      if (vp->lip) {
+        float f = lip_norm3(m);
+        if (f > LIP_RIGID_TOL) {
+          f = f * LIP_ROUND_UP;
+          vsave = lip_enter(vp, n);
+          for (size_t j = 0; j < n / 2; j++) lip_stretch(vp->lip, j, f);
+        }
+      }
       err = eval3(s, CHILD(nd, 0), t, dist, n, vp);
+      if (vsave) lip_leave(vp, vsave, n);
       REL_V3(t);
       return err;
     }
@@ -441,7 +635,14 @@ static int eval3(const orc_sdf* s, uint32_t ni, const V3* pos, float* dist, size
         float sn = go_sinf(k * p.z);
         t[i].x = c * p.x - sn * p.y; t[i].y = sn * p.x + c * p.y; t[i].z = p.z;
       }
+      float* vsave = NULL;
+      if (vp->lip) {
+        lipctx* lc = vp->lip;
+        vsave = lip_enter(vp, n);
+        for (size_t j = 0; j < n / 2; j++) lip_stretch(lc, j, lip_twist(go_hypotf(pos[2 * j].x, pos[2 * j].y), lip_radius(lc, j), go_absf(k)));
+      }
       err = eval3(s, CHILD(nd, 0), t, dist, n, vp);
+      if (vsave) lip_leave(vp, vsave, n);
       REL_V3(t);
       return err;
     }
@@ -454,6 +655,7 @@ static int eval3(const orc_sdf* s, uint32_t ni, const V3* pos, float* dist, size
         for (size_t i = 0; i < n; i++) {
           float d = dist[i];
           float wy = go_absf(pos[i].z) - h;
+          if (vp->lip) { float e = lip_radius(vp->lip, i / 2); wy = (i & 1) ? wy + e : wy - e; } /* increasing in d and in wy */
           dist[i] = go_minf(0, go_maxf(d, wy)) + go_hypotf(go_maxf(d, 0), go_maxf(wy, 0));
         }
       }
@@ -485,11 +687,27 @@ static int eval3(const orc_sdf* s, uint32_t ni, const V3* pos, float* dist, size
         p0.x = pitch * (t - go_floorf(t)) - pitch / 2;
         tr[i] = p0;
       }
+      float* vsave = NULL;
+      if (vp->lip) {
+        lipctx* lc = vp->lip;
+        vsave = lip_enter(vp, n);
+        /* The profile is evaluated at the sawtooth of the axial coordinate: ONE period of it. Across a seam of the
+         * sawtooth the field is continuous only if the profile's field is the same at x = -pitch/2 and x = +pitch/2 (a
+         * profile symmetric in x: ISO, NPT, the knurl); an asymmetric one (buttress threads) jumps there, by less than the
+         * distance between the two points, i.e. the pitch. A ball whose image may reach a seam is widened by that much. */
+        float seam = lip_screw_seam(s, CHILD(nd, 0), pitch);
+        for (size_t j = 0; j < n / 2; j++) {
+          lip_stretch(lc, j, lip_screw(go_hypotf(pos[2 * j].x, pos[2 * j].y), lip_radius(lc, j), go_absf(lead), tanTaper));
+          if (go_absf(tr[2 * j].x) + lc->R[j] >= pitch / 2) lc->R[j] = lc->R[j] + seam;
+        }
+      }
       err = eval2(s, CHILD(nd, 0), tr, dist, n, vp);
+      if (vsave) lip_leave(vp, vsave, n);
       if (!err)
         for (size_t i = 0; i < n; i++) {
           float d0 = dist[i];
           float d1 = go_absf(pos[i].z) - L;
+          if (vp->lip) { float e = lip_radius(vp->lip, i / 2); d1 = (i & 1) ? d1 + e : d1 - e; } /* |z| - L in the screw's own frame */
           dist[i] = go_maxf(d0, d1);
         }
       REL_V2(tr);
@@ -500,7 +718,7 @@ static int eval3(const orc_sdf* s, uint32_t ni, const V3* pos, float* dist, size
   }
 }
 
-static int eval2(const orc_sdf* s, uint32_t ni, const V2* pos, float* dist, size_t n, orc_pool* vp) {
+static int eval2_node(const orc_sdf* s, uint32_t ni, const V2* pos, float* dist, size_t n, orc_pool* vp) {
   const gsdf_node* nd = &s->nodes[ni];
   const float* P = nd->p;
   int err = 0;
@@ -758,7 +976,10 @@ static int eval2(const orc_sdf* s, uint32_t ni, const V2* pos, float* dist, size
       float* d2 = ACQ_F(n);
       err = eval2(s, CHILD(nd, 0), pos, dist, n, vp);
       if (!err) err = eval2(s, CHILD(nd, 1), pos, d2, n, vp);
-      if (!err) binop_combine(nd->op, 0, dist, d2, n);
+      if (!err) {
+        if (vp->lip && nd->op != GSDF_INTERSECT2D) binop_combine_lip(nd->op, 0, dist, d2, n);
+        else binop_combine(nd->op, 0, dist, d2, n);
+      }
       REL_F(d2);
       return err;
     }
@@ -812,6 +1033,14 @@ static int eval2(const orc_sdf* s, uint32_t ni, const V2* pos, float* dist, size
     }
     case GSDF_ANNULUS2D: { /* :1026-1040 */
       err = eval2(s, CHILD(nd, 0), pos, dist, n, vp);
+      if (!err && vp->lip) {
+        for (size_t j = 0; j < n / 2; j++) {
+          float alo, ahi;
+          lip_abs(dist[2 * j], dist[2 * j + 1], &alo, &ahi);
+          dist[2 * j] = alo - P[0];
+          dist[2 * j + 1] = ahi - P[0];
+        }
+      } else
       if (!err) for (size_t i = 0; i < n; i++) dist[i] = go_absf(dist[i]) - P[0];
       return err;
     }
@@ -865,7 +1094,17 @@ static int eval2(const orc_sdf* s, uint32_t ni, const V2* pos, float* dist, size
         t[i].x = P[0] * p.x + P[1] * p.y;
         t[i].y = P[2] * p.x + P[3] * p.y;
       }
+      float* vsave = NULL;
+      if (vp->lip) {
+        float f = lip_norm2(P[0], P[1], P[2], P[3]);
+        if (f > LIP_RIGID_TOL) {
+          f = f * LIP_ROUND_UP;
+          vsave = lip_enter(vp, n);
+          for (size_t j = 0; j < n / 2; j++) lip_stretch(vp->lip, j, f);
+        }
+      }
       err = eval2(s, CHILD(nd, 0), t, dist, n, vp);
+      if (vsave) lip_leave(vp, vsave, n);
       REL_V2(t);
       return err;
     }
@@ -873,7 +1112,12 @@ static int eval2(const orc_sdf* s, uint32_t ni, const V2* pos, float* dist, size
       V2* t = ACQ_V2(n);
       float inv = 1.f / P[0];
       for (size_t i = 0; i < n; i++) { t[i].x = inv * pos[i].x; t[i].y = inv * pos[i].y; }
+      if (vp->lip) lip_scale(vp->lip, n, inv);
       err = eval2(s, CHILD(nd, 0), t, dist, n, vp);
+      if (vp->lip) {
+        lip_scale(vp->lip, n, P[0]);
+        if (!err) lip_mul(dist, n, P[0]);
+      } else
       if (!err) for (size_t i = 0; i < n; i++) dist[i] = dist[i] * P[0];
       REL_V2(t);
       return err;
@@ -887,6 +1131,7 @@ static int eval2(const orc_sdf* s, uint32_t ni, const V2* pos, float* dist, size
         aux[i] = go_minf(go_maxf(q.x, q.y), 0);
         t[i].x = go_maxf(q.x, 0); t[i].y = go_maxf(q.y, 0);
       }
+      if (vp->lip) lip_widen(vp->lip, aux, n);
       err = eval2(s, CHILD(nd, 0), t, dist, n, vp);
       if (!err) for (size_t i = 0; i < n; i++) dist[i] += aux[i];
       REL_F(aux);
@@ -902,6 +1147,30 @@ static int eval2(const orc_sdf* s, uint32_t ni, const V2* pos, float* dist, size
 int orc_eval3(const orc_sdf* s, orc_pool* vp, const float* pos, float* dist, size_t n) {
   if (n == 0) return -1; /* errEmptyBuffers */
   int err = eval3(s, s->root, (const V3*)pos, dist, n, vp);
+  if (err) return err;
+  if (!pool_all_released(vp)) return -4;
+  return 0;
+}
+/* Bounds lo[i] <= field <= hi[i] over the ball of radius h around pos[i] (the cube whose centre pos[i] is and whose half
+ * diagonal h is): interval evaluation of the tree, see lipctx. Not a reference function; what the octree's centre tests
+ * need in order to stay surface-preserving for fields that are not 1-Lipschitz. For a tree of
+ * exact-distance primitives under rigid motions and min / max it returns d -+ h exactly: the reference's predicate.
+ * Sector and cell seams of (circular) arrays are taken as continuous, as those nodes' own Bounds() assume. */
+int orc_eval3_bounds(const orc_sdf* s, orc_pool* vp, const float* pos, float* lo, float* hi, size_t n, float h) {
+  if (n == 0) return -1;
+  lipctx lc;
+  lc.R = (float*)malloc(sizeof(float) * n);
+  float* p2 = (float*)malloc(sizeof(float) * 6 * n);
+  float* d2 = (float*)malloc(sizeof(float) * 2 * n);
+  for (size_t i = 0; i < n; i++) {
+    lc.R[i] = h;
+    for (int k = 0; k < 3; k++) p2[6 * i + k] = p2[6 * i + 3 + k] = pos[3 * i + k];
+  }
+  vp->lip = &lc;
+  int err = eval3(s, s->root, (const V3*)p2, d2, 2 * n, vp);
+  vp->lip = NULL;
+  for (size_t i = 0; i < n && !err; i++) { lo[i] = d2[2 * i]; hi[i] = d2[2 * i + 1]; }
+  free(lc.R); free(p2); free(d2);
   if (err) return err;
   if (!pool_all_released(vp)) return -4;
   return 0;

@@ -27,6 +27,9 @@ void orc_pool_destroy(orc_pool* p);
 /* pos: n*3 floats (xyz AoS) / n*2 floats; dist: n floats. 0 on success. */
 int orc_eval3(const orc_sdf* s, orc_pool* vp, const float* pos, float* dist, size_t n);
 int orc_eval2(const orc_sdf* s, orc_pool* vp, const float* pos, float* dist, size_t n);
+/* lo[i] <= field <= hi[i] over the ball of radius h around pos[i] (interval evaluation; see orc_eval.c). Not a reference
+ * function: what the octree's centre tests need for fields that are not 1-Lipschitz. */
+int orc_eval3_bounds(const orc_sdf* s, orc_pool* vp, const float* pos, float* lo, float* hi, size_t n, float h);
 
 /* ---- renderers (orc_render.c) ---- */
 typedef struct orc_mesh {
@@ -44,7 +47,12 @@ void orc_mesh_free(orc_mesh* m);
 
 /* glrender.FlatRenderer (flatrenderer.go): batch = evalBufferSize, nthreads = numParallel. */
 int orc_render_flat(const orc_sdf* s, float res, int batch, int nthreads, orc_mesh* out);
-/* glrender.Octree (octreerenderer.go) with every Level>=3 cube centre-tested. prune=0 disables. */
+/* glrender.Octree (octreerenderer.go) with every Level>=3 cube centre-tested. prune = 0: no tests; 1: every level;
+ * else bit L = test Level L. A cube is dropped iff the field's bounds over it (orc_eval3_bounds at the centre, radius
+ * size * sqrt3/2) exclude 0 -- for a true distance field exactly the reference's |d| >= size * sqrt3/2 (:270-273), and
+ * still surface-preserving for fields that grow faster than distance (twists, screws, non-rigid transforms).
+ * ORC_PRUNE_ASSUME_SDF (bit 30): the reference's predicate verbatim, whatever the field. */
+#define ORC_PRUNE_ASSUME_SDF (1 << 30)
 int orc_render_octree(const orc_sdf* s, float res, int batch, int prune, orc_mesh* out);
 /* glrender.DualContourRenderer + DualContourLeastSquares (dual_contour.go, dual_contour_vertexplacement.go) */
 int orc_render_dualcontour(const orc_sdf* s, float res, int chiseled, orc_mesh* out);

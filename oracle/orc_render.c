@@ -273,8 +273,12 @@ int orc_render_octree(const orc_sdf* s, float res, int batch, int prune, orc_mes
   batch &= ~7;
   float* posbuf = (float*)malloc(sizeof(float) * 3 * (size_t)batch);
   float* distbuf = (float*)malloc(sizeof(float) * (size_t)batch);
+  float* hibuf = (float*)malloc(sizeof(float) * (size_t)batch);
   orc_pool* vp = orc_pool_create((size_t)batch);
   const float szMult = GLRENDER_SQRT3 / 2; /* :182 */
+  const int assume_sdf = (prune & ORC_PRUNE_ASSUME_SDF) != 0;
+  int pmask = prune & ~ORC_PRUNE_ASSUME_SDF;
+  if (assume_sdf && pmask == 0) pmask = 1;
 
   /* Level-synchronous descent. Every cube with Level >= minPrunableLvl(3) is centre-tested with the
    * reference predicate (:270-273) -- a superset of the capacity-dependent subset the reference
@@ -285,7 +289,7 @@ int orc_render_octree(const orc_sdf* s, float res, int batch, int prune, orc_mes
   double t0 = now_s();
   for (int level = levels; level >= 2; level--) {
     nxt.n = 0;
-    if (level >= 3 && (prune == 1 || (prune > 1 && ((prune >> level) & 1)))) { /* prune: 0 none, 1 every level >= 3, else a bit mask of the levels to test */
+    if (level >= 3 && (pmask == 1 || (pmask > 1 && ((pmask >> level) & 1)))) { /* prune: 0 none, 1 every level >= 3, else a bit mask of the levels to test */
       float size = cube_size(level, res);
       float maxDist = size * szMult;
       for (size_t b0 = 0; b0 < cur.n; b0 += (size_t)batch) {
@@ -296,11 +300,14 @@ int orc_render_octree(const orc_sdf* s, float res, int batch, int prune, orc_mes
           /* CubeCenter = box.Center() = Scale(0.5, Add(Min, Max)) [external] */
           posbuf[3 * i] = 0.5f * (o.x + mx.x); posbuf[3 * i + 1] = 0.5f * (o.y + mx.y); posbuf[3 * i + 2] = 0.5f * (o.z + mx.z);
         }
-        err = orc_eval3(s, vp, posbuf, distbuf, nb);
+        if (assume_sdf) err = orc_eval3(s, vp, posbuf, distbuf, nb);
+        else err = orc_eval3_bounds(s, vp, posbuf, distbuf, hibuf, nb, maxDist);
         if (err) goto done;
         out->evals += nb;
         for (size_t i = 0; i < nb; i++) {
-          int prunable = go_absf(distbuf[i]) >= maxDist;
+          /* :270-273 |d| >= maxDist, i.e. d - maxDist >= 0 or d + maxDist <= 0: with the field's bounds over the cube
+           * in place of d -+ maxDist (the same numbers when the field is a true distance) */
+          int prunable = assume_sdf ? go_absf(distbuf[i]) >= maxDist : (distbuf[i] >= 0.0f || hibuf[i] <= 0.0f);
           if (!prunable) {
             Cube c = cur.v[b0 + i];
             int h = 1 << (level - 2); /* child size in leaves */
@@ -351,7 +358,7 @@ int orc_render_octree(const orc_sdf* s, float res, int batch, int prune, orc_mes
 done:
   free(cur.v); free(nxt.v);
   orc_pool_destroy(vp);
-  free(posbuf); free(distbuf);
+  free(posbuf); free(distbuf); free(hibuf);
   return err;
 }
 

@@ -177,24 +177,31 @@ def test_full_size_other_single_gpu_configs(gpu, scene, key, levels):
 
 def test_fibonacci_showerhead_known_answer(gpu):
     """The reference's second held answer (README.md:152,166: 309,872 triangles at resdiv 350 from both of its renderers)
-    on the device: the flat renderer gives it, the octree mesher gives it with centre tests at Levels >= 4 (the reference
-    tests the top of the tree only) and loses 23 triangles to its default Level-3 tests -- exactly as the oracle does
-    (non-Lipschitz knurl field, include/gsdf_hip.h: gsdf_mesh_opts.prune)."""
+    on the device: the flat renderer gives it, and so does the octree mesher with its DEFAULT options -- every Level >= 3 cube
+    centre-tested against the field's bounds over the cube (interval mode, dev_ops.h: D_LIP_*). The field is not a distance
+    field: the buttress thread jumps across the seams of the screw's sawtooth and the knurl is a 45-degree helix, so the
+    reference's own predicate |d| >= size * sqrt3/2 applied to every level (GSDF_PRUNE_ASSUME_SDF) loses 23 triangles --
+    on the device exactly as in the oracle."""
     b = Builder()
     s = b.Scene("fibonacci-showerhead")
     res = np.float32(float(s.Diagonal()) / 350)
     assert f"{float(res):.7f}" == "0.2979682"
     ge4, every = GOLD["showerhead_resdiv350_prune_ge4"], GOLD["showerhead_resdiv350_prune_all"]
     assert ge4["n_tris"] == 309872 and every["n_tris"] == 309849
+    ref = OracleSDF(s.tree()).render_octree(res, 4096, True)
+    assert ref.n_tris == 309872 and _digest(ref.tris) == ge4["sha256_sorted"]
     for spec in (False, True):
         sdf = gpu.SDF3HIP(s)
         if spec:
             sdf.specialize()
         fl = gpu.FlatHIP(sdf, res)
         assert fl.n_tris() == 309872 and fl.Evaluations() == 1512024
-        oc = gpu.OctreeHIP(sdf, res, prune=sum(1 << l for l in range(4, 22)))
+        oc = gpu.OctreeHIP(sdf, res)                                     # the default
         assert oc.stats.levels == 9 and oc.n_tris() == 309872 and _digest(oc.RenderAll()) == ge4["sha256_sorted"]
-        oc = gpu.OctreeHIP(sdf, res)
+        assert oc.TotalPruned() == ref.pruned                            # cube for cube the oracle's decisions
+        oc = gpu.OctreeHIP(sdf, res, prune=sum(1 << l for l in range(4, 22)), assume_sdf=True)   # the reference tests the top of the tree only
+        assert oc.n_tris() == 309872 and _digest(oc.RenderAll()) == ge4["sha256_sorted"]
+        oc = gpu.OctreeHIP(sdf, res, assume_sdf=True)
         assert oc.n_tris() == 309849 and _digest(oc.RenderAll()) == every["sha256_sorted"]
         assert gpu.OctreeHIP(sdf, res, prune=False).n_tris() == 309872
 

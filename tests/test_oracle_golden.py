@@ -63,12 +63,14 @@ def test_fibonacci_showerhead_readme_known_answers():
     assert flat.evals == 1512024                          # README.md:166 prints 1,512,025 = lattice + 1 constructor probe
     assert flat.n_tris == 309872                          # README.md:166
     # Octree renderer (README.md:152: 309,872 as well). The reference centre-tests only the frontier its DecomposeBFS buffer
-    # holds -- for this 9-level tree cubes of Level 5 and some of Level 4 -- and with tests at Levels >= 4 the count is the
-    # flat renderer's. This field is NOT 1-Lipschitz (the knurl's 45-degree helix: |grad| up to sqrt 2), and testing every
-    # Level >= 3 cube, as the device does by default, drops 23 triangles at Level 3: the one tree found where the superset
-    # schedule is not result-preserving. prune = bit mask of the levels to test.
-    octree = sdf.render_octree(res, 4096, sum(1 << l for l in range(4, 10)))
+    # holds -- for this 9-level tree cubes of Level 5 and some of Level 4. This field is NOT a distance field (the buttress
+    # thread jumps across the seams of the screw's sawtooth, the knurl is a 45-degree helix): the reference's predicate
+    # |d| >= size*sqrt3/2 applied to every Level >= 3 cube drops 23 triangles at Level 3. The default tests every level against
+    # the field's bounds over the cube (orc_eval3_bounds) and keeps them all.
+    octree = sdf.render_octree(res, 4096, True)
     assert octree.levels == 9 and octree.n_tris == 309872
+    assert sdf.render_octree(res, 4096, sum(1 << l for l in range(4, 10)), assume_sdf=True).n_tris == 309872
+    assert sdf.render_octree(res, 4096, True, assume_sdf=True).n_tris == 309849
 
 
 def test_octree_resolutions_like_reference_TestOctree():
