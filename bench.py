@@ -207,7 +207,7 @@ def main():
 
     import numpy as np
     import torch
-    from gsdf_amd.builder import Builder
+    from scaffold.builder import Builder
     from gsdf_amd import hip
 
     rank = int(os.environ.get("RANK", "0"))

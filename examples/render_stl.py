@@ -26,7 +26,7 @@ def main(argv=None):
 
     import numpy as np
     from gsdf_amd import hip
-    from gsdf_amd.builder import Builder
+    from scaffold.builder import Builder
 
     hip.init(0)
     t0 = time.perf_counter()

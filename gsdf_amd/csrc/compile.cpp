@@ -12,7 +12,7 @@
 #include <string>
 #include <utility>
 
-#include "../host/ms.hpp"
+#include "host_math.h"
 #include "dev_ops.h"
 
 namespace gsdf_dev {

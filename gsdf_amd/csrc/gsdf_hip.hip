@@ -84,10 +84,11 @@ struct gsdf_program {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   void* h_ctr = nullptr;  // pinned host copy of the device counters (a pageable destination makes the D2H copy a staged, blocking one)
   uint64_t last_tris = 0;  // triangle count of the previous mesh on this handle: sizes the next output buffer
+  uint64_t rec_blocks = 0;  // 64-leaf blocks the cut-leaf record arena is sized for (0: first mesh, start with kRecBlocks0)
   uint64_t last_dc_cubes = 0;  // kept cubes of the previous dual contouring pass: sizes the next queues
   // run-time specialised kernels for this program (gsdf_hip_program_specialize): hiprtc module, else interpreter
   hipModule_t spec_mod = nullptr, spec_mod2 = nullptr, spec_mod3 = nullptr, spec_mod4 = nullptr;  // spec_mod4: leaf kernel rebuilt with a larger register budget; spec_mod2: second group, built on first use (see spec_aux); spec_mod3: eval kernel rebuilt for 3 workgroups per CU
-  hipFunction_t f_eval = nullptr, f_prune = nullptr, f_leaf = nullptr;
+  hipFunction_t f_eval = nullptr, f_prune = nullptr, f_prune_top = nullptr, f_leaf = nullptr;
   hipFunction_t f_dc_origin = nullptr, f_dc_edges = nullptr, f_dc_normals = nullptr, f_normals = nullptr, f_image = nullptr, f_flat_grid = nullptr;
   bool spec_aux_tried = false;
   int spec_eval_k = 0, spec_eval_w = 0, spec_leaf_k = 0, spec_leaf_w = 0;
@@ -473,6 +474,7 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
   names.push_back(std::string("eval_kernel<") + (p->prog.is2d ? "2" : "3") + ", " + std::to_string(ek) + ", " + std::to_string(ew) + ">");
   if (!p->prog.is2d) {
     names.push_back("prune_kernel");
+    names.push_back("prune_top_kernel");
     names.push_back(std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(lw) + (fused_leaf() ? ">" : (p->leaf_nt_in_lds() ? ", true, true>" : ", true, false>")));
     // a fifth workgroup per CU where the LDS has room for it (npt-flange's 7 slots): the 96-register build is taken if the
     // compiler reaches it without scratch (-3 % on the evaluating kernel); built beside the 128-register one, same process
@@ -502,16 +504,18 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
     }
   }
   if (!p->prog.is2d) {
-    const bool okp = fn_scratch_bytes(f[1]) == 0;
-    bool okl = fn_scratch_bytes(f[2]) == 0;
+    const bool okp = fn_scratch_bytes(f[1]) == 0, okt = fn_scratch_bytes(f[2]) == 0;
+    bool okl = fn_scratch_bytes(f[3]) == 0;
     spec_report("specialised", names[1], f[1], okp);
-    spec_report("specialised", names[2], f[2], okl);
+    spec_report("specialised", names[2], f[2], okt);
+    spec_report("specialised", names[3], f[3], okl);
     p->f_prune = okp ? f[1] : nullptr;
-    p->f_leaf = okl ? f[2] : nullptr;
-    if (f.size() > 3) {
-      const bool ok5 = fn_scratch_bytes(f[3]) == 0;
-      spec_report("specialised", names[3], f[3], ok5);
-      if (ok5) { p->f_leaf = f[3]; p->spec_leaf_w = 5; okl = true; }
+    p->f_prune_top = okt ? f[2] : nullptr;
+    p->f_leaf = okl ? f[3] : nullptr;
+    if (f.size() > 4) {
+      const bool ok5 = fn_scratch_bytes(f[4]) == 0;
+      spec_report("specialised", names[4], f[4], ok5);
+      if (ok5) { p->f_leaf = f[4]; p->spec_leaf_w = 5; okl = true; }
     }
     // the leaf kernel is where the time goes: before giving it up, trade occupancy for registers (W = workgroups per CU
     // the register budget is sized for; the launch is the same)
@@ -583,7 +587,7 @@ extern "C" int gsdf_hip_specialize_check(const gsdf_tree* tree, size_t* code_obj
     std::vector<std::string> low;
     std::string log;
     const std::vector<std::string> names = pr.is2d ? std::vector<std::string>{"eval_kernel<2, 4, 4>"}
-                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "leaf_eval_kernel<4, 4, true, true>", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
+                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "prune_top_kernel", "leaf_eval_kernel<4, 4, true, true>", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
     if (!gsdf_dev::spec_compile(pr, "gfx950", names, co, low, log)) return fail(GSDF_ERR_HIP, "specialised build failed:\n" + log);
     if (code_object_bytes) *code_object_bytes = co.size();
     return GSDF_OK;
@@ -1017,15 +1021,56 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
       const uint64_t full = (levels - lq) * 3 >= 40 ? UINT64_MAX : ((uint64_t)1 << (3 * (levels - 1)));
       if (lbound > full) lbound = full;
     }
-    const uint64_t nblk = (lbound + 63) / 64, ngrp = (nblk + MARCH_GROUP - 1) / MARCH_GROUP;
-    const bool want_two = !fused_leaf() && !(lq == 3 && lk == 4 && opts.share_corners);
+    // The record arena (2 560 B per block) is sized for the blocks a mesh of this handle actually had (+ 1/8), not for the queue
+    // capacity: a million-cube queue would ask for 2.7 GB, and each queue regrowth for four times more. First mesh: 384 K
+    // blocks (1 GB); a mesh that needs more says so through its survivor count and is repeated once with the exact size.
+    constexpr uint64_t kRecBlocks0 = (uint64_t)384 << 10;
+    const uint64_t nblk_q = (lbound + 63) / 64;
+    uint64_t nblk = p->rec_blocks ? p->rec_blocks : kRecBlocks0;
+    if (nblk > nblk_q) nblk = nblk_q;
+    const uint64_t ngrp = (nblk + MARCH_GROUP - 1) / MARCH_GROUP;
+    bool want_two = !fused_leaf() && !(lq == 3 && lk == 4 && opts.share_corners);
+    if (want_two && (p->hdr.ensure(nblk * sizeof(uint32_t)) != hipSuccess || p->rec.ensure(nblk * (size_t)REC_BLOCK * sizeof(uint32_t)) != hipSuccess)) {
+      (void)hipGetLastError();  // no room for the records: the fused kernel needs none
+      p->hdr.release(); p->rec.release();
+      want_two = false;
+    }
     const size_t clear_bytes = kCtrBytes + (want_two ? ngrp * sizeof(unsigned long long) : 0);
     HIP_TRYM(p->ctr.ensure(clear_bytes));
     d_ctr = (MeshCounters*)p->ctr.p;
     HIP_TRYM(hipMemsetAsync(d_ctr, 0, clear_bytes, s));
     HIP_TRYM(hipEventRecord(ev0, s));
     static const int prune_bpc = [] { const char* e = getenv("GSDF_HIP_PRUNE_BPC"); return e ? atoi(e) : 4; }();  // tuning knob
-    for (int level = levels; level >= lq; level--) {
+    // The top five levels (Level `levels` .. levels - 4, <= 4096 candidates at the last) by ONE workgroup in one launch
+    // (prune_top_kernel): as separate launches they are pure latency. 1024 threads where the interval columns and the two LDS
+    // queues fit the CU's 160 KB, else 512 / 256; GSDF_HIP_PRUNE_TOP=0 keeps one launch per level (cross-check in the tests).
+    static const bool use_top = [] { const char* e = getenv("GSDF_HIP_PRUNE_TOP"); return !e || atoi(e) != 0; }();
+    int first_level = levels;  // first level of the per-level chain
+    if (use_top) {
+      const int last_top = levels - 4 > lq ? levels - 4 : lq;
+      unsigned tthreads = 0;
+      size_t lds_top = 0;
+      for (unsigned t : {1024u, 512u, 256u}) {
+        const size_t need = (size_t)(prune_cols > 0 ? prune_cols : 1) * 2 * t * sizeof(float) + 2 * (size_t)PRUNE_TOP_CAP * sizeof(Cube) + 32 * sizeof(unsigned);
+        if (need <= (size_t)160 * 1024) { tthreads = t; lds_top = need; break; }
+      }
+      if (tthreads) {
+        const unsigned test_mask = pmask == 1 ? 0xffffffffu : (unsigned)pmask;
+        const int shard_level = opts.shard_count > 1 ? ls : -1;
+        if (p->f_prune_top) {
+          HIP_TRYM(launch_fn(p->f_prune_top, 1u, tthreads, lds_top, s, (const uint32_t*)p->d_code, (int)levels, (int)last_top, (int)prune_cols,
+                             (int)p->prog.nslots, ox, oy, oz, res, (unsigned)test_mask, (int)ptest, (Cube*)q[last_top & 1]->p,
+                             (unsigned long long)capq[last_top & 1], (int)shard_level, (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr));
+        } else {
+          hipLaunchKernelGGL(prune_top_kernel, dim3(1), dim3(tthreads), lds_top, s, p->d_code, levels, last_top, prune_cols, p->prog.nslots, ox,
+                             oy, oz, res, test_mask, ptest, (Cube*)q[last_top & 1]->p, (unsigned long long)capq[last_top & 1], shard_level,
+                             (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr);
+        }
+        HIP_TRYM(hipGetLastError());
+        first_level = last_top - 1;
+      }
+    }
+    for (int level = first_level; level >= lq; level--) {
       const int expand = level != levels;
       const int do_test = (level >= 3 && (pmask == 1 || (pmask > 1 && ((pmask >> level) & 1)))) ? ptest : 0;
       // upper bound of candidates at this level (for the grid only): 8^(levels-level), capped by the queue
@@ -1056,8 +1101,6 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
                      m->d_tris, tcap, d_ctr)
       if (want_two) {
         // two kernels: evaluation + cut-leaf records, then marching cubes over the records
-        HIP_TRYM(p->hdr.ensure(nblk * sizeof(uint32_t)));
-        HIP_TRYM(p->rec.ensure(nblk * (size_t)REC_BLOCK * sizeof(uint32_t)));
         uint32_t* d_hdr = (uint32_t*)p->hdr.p;
         uint32_t* d_rec = (uint32_t*)p->rec.p;
         unsigned long long* d_psum = (unsigned long long*)((char*)p->ctr.p + kCtrBytes);  // cleared with the counters
@@ -1122,6 +1165,15 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
       if (attempt >= 8) return bail(fail(GSDF_ERR_CAPACITY, "octree queue capacity exceeded"));
       qcap *= 4;
       continue;
+    }
+    if (two_kernel) {  // more blocks than the record arena holds: the blocks beyond it were skipped -- repeat with room for all
+      const uint64_t need = ((hc.n_level[lq] << (3 * (lq - 1))) + 63) / 64;
+      if (need > nblk) {
+        if (attempt >= 8) return bail(fail(GSDF_ERR_CAPACITY, "cut-leaf record arena capacity exceeded"));
+        p->rec_blocks = need + need / 8 + 1024;
+        two_kernel = false;
+        continue;
+      }
     }
     if (hc.overflow) {  // triangle buffer too small: the kernel kept counting, so the exact size is known
       if (opts.max_tris) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));

@@ -225,6 +225,96 @@ __global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict
   }
 }
 
+// The top of the octree in ONE launch: Levels `top` .. `last` (at most five: the last has <= 8^4 = 4096 candidates) by a
+// single workgroup that keeps both cube queues in LDS. Above Level ~8 a level is a few hundred cubes and its launch is
+// nothing but latency (7 us each, 10 per mesh: 10 % of npt-flange at resdiv 1600); here a level costs one evaluation and
+// two barriers. Same candidates, same test, same counters as prune_kernel level by level; the survivors of Level `last` go
+// to `out` in the order the LDS compaction leaves them (any order is fine: the next level reads a queue).
+// test_mask: bit L set = centre-test Level L (gsdf_mesh_opts.prune); ptest 1 = field bounds, 2 = the reference's predicate.
+// LDS: [2 * ncols floats per lane | 2 queues of PRUNE_TOP_CAP cubes | 2 x 16 wave totals].
+#define PRUNE_TOP_CAP 4096
+__global__ void __launch_bounds__(1024) prune_top_kernel(const uint32_t* __restrict__ code_g, int top, int last, int ncols, int lip_base,
+                                                         float ox, float oy, float oz, float res, unsigned test_mask, int ptest,
+                                                         Cube* __restrict__ out, unsigned long long out_cap, int shard_level,
+                                                         unsigned shard_rank, unsigned shard_count, MeshCounters* __restrict__ ctr) {
+  code_ptr code = as_code(code_g);
+  const unsigned nthreads = blockDim.x, nwaves = nthreads >> 6;
+  float* lds = g_smem + threadIdx.x;
+  Cube* s_qa = (Cube*)(g_smem + (size_t)(ncols > 0 ? ncols : 1) * 2 * nthreads);
+  Cube* s_qb = s_qa + PRUNE_TOP_CAP;
+  unsigned* s_w = (unsigned*)(s_qb + PRUNE_TOP_CAP);  // [0..15] kept per wave, [16..31] passed the test per wave
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  Cube* s_in = s_qa;
+  Cube* s_out = s_qb;
+  unsigned n_prev = 0;
+  for (int level = top; level >= last; level--) {  // block-uniform
+    const unsigned n_items = level == top ? 1u : n_prev * 8u;
+    const int do_test = (level >= 3 && ((test_mask >> level) & 1u)) ? ptest : 0;
+    const float size = (float)(1 << (level - 1)) * res;
+    const float maxDist = size * (1.73205080757f / 2);
+    unsigned cur = 0, passed = 0;
+    for (unsigned base = 0; base < n_items; base += nthreads) {  // block-uniform trip count
+      const unsigned i = base + threadIdx.x;
+      const bool valid = i < n_items;
+      Cube c = {0, 0, 0, 0};
+      if (valid && level != top) {
+        const Cube pc = s_in[i >> 3];
+        const unsigned k = i & 7u;
+        c.x = (uint16_t)(pc.x * 2 + ((k ^ (k >> 1)) & 1));
+        c.y = (uint16_t)(pc.y * 2 + ((k >> 1) & 1));
+        c.z = (uint16_t)(pc.z * 2 + ((k >> 2) & 1));
+      }
+      bool keep = valid;
+      if (do_test) {
+        const float cx0 = ox + size * (float)c.x, cy0 = oy + size * (float)c.y, cz0 = oz + size * (float)c.z;
+        P3 p;
+        p.x = 0.5f * (cx0 + (cx0 + size));
+        p.y = 0.5f * (cy0 + (cy0 + size));
+        p.z = 0.5f * (cz0 + (cz0 + size));
+        P3 pv[2] = {p, p};
+        float dv[2];
+        if (do_test == 2) {
+          gsdf_dev::sdf_eval<2>(code, pv, dv, lds, nthreads);
+          keep = valid && !(dm::absf(dv[0]) >= maxDist);
+        } else {
+          gsdf_dev::sdf_eval<2, 0, true>(code, pv, dv, lds, nthreads, false, maxDist, (uint32_t)lip_base);
+          keep = valid && !(dv[0] >= 0.0f || dv[1] <= 0.0f);
+        }
+      }
+      const unsigned long long pm = __ballot(keep);
+      if (level == shard_level) keep = keep && (brick_owner(c.x, c.y, c.z, shard_count) == shard_rank);
+      const unsigned long long km = __ballot(keep);
+      const unsigned lane_prefix = __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
+      if (lane == 0) { s_w[wave] = (unsigned)__builtin_popcountll(km); s_w[16 + wave] = (unsigned)__builtin_popcountll(pm); }
+      __syncthreads();
+      unsigned total = 0, wpre = 0, tpass = 0;
+      for (unsigned w = 0; w < nwaves; w++) {
+        const unsigned t = s_w[w];
+        wpre += w < wave ? t : 0u;
+        total += t;
+        tpass += s_w[16 + w];
+      }
+      if (keep && cur + wpre + lane_prefix < PRUNE_TOP_CAP) s_out[cur + wpre + lane_prefix] = c;  // (<= 8^4 by construction)
+      cur += total;
+      passed += tpass;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      ctr->n_items[level] = do_test ? (unsigned long long)n_items : 0ull;
+      ctr->n_pass[level] = (unsigned long long)passed;
+      ctr->n_level[level] = (unsigned long long)cur;
+    }
+    n_prev = cur < PRUNE_TOP_CAP ? cur : PRUNE_TOP_CAP;
+    Cube* t = s_in; s_in = s_out; s_out = t;
+  }
+  // s_in = survivors of Level `last`
+  if ((unsigned long long)n_prev <= out_cap) {
+    for (unsigned k = threadIdx.x; k < n_prev; k += nthreads) out[k] = s_in[k];
+  } else if (threadIdx.x == 0) {
+    ctr->q_overflow = 1ull;
+  }
+}
+
 // mcInterpolate (marchcubes.go:76-98) with x = 0.
 __device__ __forceinline__ void mc_interp(float ax, float ay, float az, float bx, float by, float bz, float v1, float v2,
                                           float& rx, float& ry, float& rz) {

@@ -194,6 +194,18 @@ typedef struct gsdf_mesh_stats {
   uint64_t cut_leaves;     /* leaves the surface cuts = 40-byte records handed from leaf_eval_kernel to march_records_kernel */
 } gsdf_mesh_stats;
 
+GSDF_ABI_ASSERT(sizeof(gsdf_mesh_opts) == 40, "gsdf_mesh_opts is 40 bytes");
+GSDF_ABI_ASSERT(offsetof(gsdf_mesh_opts, prune) == 0 && offsetof(gsdf_mesh_opts, shard_rank) == 4 && offsetof(gsdf_mesh_opts, shard_count) == 8, "gsdf_mesh_opts head");
+GSDF_ABI_ASSERT(offsetof(gsdf_mesh_opts, max_tris) == 16 && offsetof(gsdf_mesh_opts, stream) == 24, "gsdf_mesh_opts middle");
+GSDF_ABI_ASSERT(offsetof(gsdf_mesh_opts, share_corners) == 32 && offsetof(gsdf_mesh_opts, host_output) == 36, "gsdf_mesh_opts tail");
+GSDF_ABI_ASSERT(sizeof(gsdf_mesh_stats) == 128, "gsdf_mesh_stats is 128 bytes");
+GSDF_ABI_ASSERT(offsetof(gsdf_mesh_stats, n_tris) == 0 && offsetof(gsdf_mesh_stats, evals) == 8 && offsetof(gsdf_mesh_stats, pruned_leaves) == 16, "gsdf_mesh_stats counters");
+GSDF_ABI_ASSERT(offsetof(gsdf_mesh_stats, leaf_cubes) == 24 && offsetof(gsdf_mesh_stats, active_leaves) == 32 && offsetof(gsdf_mesh_stats, levels) == 40, "gsdf_mesh_stats counters 2");
+GSDF_ABI_ASSERT(offsetof(gsdf_mesh_stats, origin) == 44 && offsetof(gsdf_mesh_stats, res) == 56 && offsetof(gsdf_mesh_stats, ms_total) == 64, "gsdf_mesh_stats lattice");
+GSDF_ABI_ASSERT(offsetof(gsdf_mesh_stats, ms_prune) == 72 && offsetof(gsdf_mesh_stats, ms_leaf) == 80 && offsetof(gsdf_mesh_stats, ms_march) == 88, "gsdf_mesh_stats times");
+GSDF_ABI_ASSERT(offsetof(gsdf_mesh_stats, evals_prune) == 96 && offsetof(gsdf_mesh_stats, evals_leaf) == 104 && offsetof(gsdf_mesh_stats, ms_emit) == 112 && offsetof(gsdf_mesh_stats, cut_leaves) == 120, "gsdf_mesh_stats tail");
+GSDF_ABI_ASSERT(GSDF_ERR_EMPTY_BUFFERS == -1 && GSDF_ERR_LENGTH_MISMATCH == -2 && GSDF_ERR_SHORT_BUFFER == -9 && GSDF_ERR_CAPACITY == -10, "status codes are part of the ABI");
+
 int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_opts* opts, gsdf_mesh** out);
 /* Dual contouring (least-squares vertex placement; chiseled = DualContourLeastSquares.Chiseled). The result is a
  * gsdf_mesh like the octree mesher's (stats: leaf_cubes = kept cubes, active_leaves = active edges). Multi-GPU: rank

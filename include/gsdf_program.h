@@ -109,6 +109,24 @@ typedef struct gsdf_tree {
   float            bb[6];     /* Bounds(): min xyz, max xyz (2D: min xy 0, max xy 0) */
 } gsdf_tree;
 
+/* The layout cgo sees (Go mirrors C struct layout field by field; INTEGRATION.md section 1 fills these structs from Go):
+ * pinned here so that a change of this header that would silently break a Go caller breaks the build instead. */
+#ifdef __cplusplus
+#define GSDF_ABI_ASSERT(cond, msg) static_assert(cond, msg)
+#else
+#define GSDF_ABI_ASSERT(cond, msg) _Static_assert(cond, msg)
+#endif
+#include <stddef.h>
+GSDF_ABI_ASSERT(sizeof(float) == 4 && sizeof(void*) == 8, "LP64, IEEE float32");
+GSDF_ABI_ASSERT(sizeof(gsdf_node) == 48, "gsdf_node is 48 bytes");
+GSDF_ABI_ASSERT(offsetof(gsdf_node, op) == 0 && offsetof(gsdf_node, nchild) == 2 && offsetof(gsdf_node, link_off) == 4, "gsdf_node head");
+GSDF_ABI_ASSERT(offsetof(gsdf_node, aux_off) == 8 && offsetof(gsdf_node, aux_len) == 12 && offsetof(gsdf_node, p) == 16, "gsdf_node tail");
+GSDF_ABI_ASSERT(sizeof(gsdf_tree) == 72, "gsdf_tree is 72 bytes");
+GSDF_ABI_ASSERT(offsetof(gsdf_tree, nodes) == 0 && offsetof(gsdf_tree, n_nodes) == 8 && offsetof(gsdf_tree, links) == 16, "gsdf_tree head");
+GSDF_ABI_ASSERT(offsetof(gsdf_tree, n_links) == 24 && offsetof(gsdf_tree, aux) == 32 && offsetof(gsdf_tree, n_aux) == 40, "gsdf_tree middle");
+GSDF_ABI_ASSERT(offsetof(gsdf_tree, root) == 44 && offsetof(gsdf_tree, bb) == 48, "gsdf_tree tail");
+GSDF_ABI_ASSERT(GSDF_SPHERE == 1 && GSDF_UNION == 7 && GSDF_SCREW == 26 && GSDF_POLY2D == 38 && GSDF_OP_COUNT == 54, "gsdf_op numbering is part of the ABI");
+
 /* 1 if op takes 2D positions. */
 static inline int gsdf_op_is2d(int op) { return op >= GSDF_LINE2D && op < GSDF_OP_COUNT; }
 

@@ -12,7 +12,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/gsdf_program.h"
+#include "../include/gsdf_program.h"
 #include "ms.hpp"
 
 namespace gsdf {

@@ -1,4 +1,4 @@
-"""Python face of the C++ host mirror of the reference's gsdf.Builder (gsdf_amd/host/).
+"""Python face of the C++ mirror of the reference's gsdf.Builder (scaffold/: test and benchmark scaffolding, not product).
 
 Same method names and argument meaning as /root/reference/gsdf.go + primitives*.go + operations*.go
 (`bld.NewSphere(r)`, `bld.Union(a, b, ...)`, `bld.Translate(s, x, y, z)` ...), so parity tests read
@@ -9,7 +9,7 @@ import ctypes as C
 import os
 import numpy as np
 
-from ._ctypes_common import GsdfTree, OPS, FIRST_2D
+from gsdf_amd._ctypes_common import GsdfTree, OPS, FIRST_2D
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -24,7 +24,7 @@ NutCircular, NutHex, NutKnurl = 1, 2, 3
 def _lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "host", "libgsdfhost.so")
+        path = os.path.join(_HERE, "libgsdfhost.so")
         if not os.path.exists(path):
             raise ImportError(f"{path} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
         lib = C.CDLL(path)

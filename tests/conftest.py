@@ -17,7 +17,7 @@ def pytest_configure(config):
 @pytest.fixture(scope="session", autouse=True)
 def _native_libs():
     """Build the native pieces once if a fresh checkout has none (CPU-only: hipcc cross-compiles)."""
-    need = [os.path.join(ROOT, "gsdf_amd", "host", "libgsdfhost.so"), os.path.join(ROOT, "gsdf_amd", "csrc", "libgsdfhip.so"),
+    need = [os.path.join(ROOT, "scaffold", "libgsdfhost.so"), os.path.join(ROOT, "gsdf_amd", "csrc", "libgsdfhip.so"),
             os.path.join(ROOT, "oracle", "liborc.so")]
     if not all(os.path.exists(p) for p in need):
         subprocess.check_call([sys.executable, os.path.join(ROOT, "__graft_entry__.py")])

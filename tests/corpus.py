@@ -9,7 +9,7 @@ import math
 
 import numpy as np
 
-from gsdf_amd.builder import Builder, NutCircular, NutHex, NutKnurl
+from scaffold.builder import Builder, NutCircular, NutHex, NutKnurl
 
 
 def _rng():

@@ -5,7 +5,7 @@ import math
 
 import numpy as np
 
-from gsdf_amd.builder import Builder, ShapeError
+from scaffold.builder import Builder, ShapeError
 
 
 def _prim3(b, r):

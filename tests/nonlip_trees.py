@@ -4,7 +4,7 @@ tests have to survive: |grad| > 1, jumps across a screw's 
 sector seams are the one assumption the bounds make (the reference's own Bounds() of those nodes make it too)."""
 import numpy as np
 
-from gsdf_amd.builder import Builder, ShapeError
+from scaffold.builder import Builder, ShapeError
 
 
 def _base(b, r):

@@ -9,7 +9,7 @@ import pytest
 
 from gsdf_amd import hip
 from gsdf_amd._ctypes_common import GsdfNode, GsdfTree, OP
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

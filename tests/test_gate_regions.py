@@ -11,7 +11,7 @@ import corpus
 import fuzz_trees
 from gsdf_amd import hip
 from gsdf_amd._ctypes_common import GsdfTree, OPS
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from oracle.oracle import OracleSDF
 
 FIRST_2D = OPS.index("LINE2D")

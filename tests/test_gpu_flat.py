@@ -3,7 +3,7 @@ glrender/flatrenderer.go: same lattice, same evaluation count, bit-identical tri
 import numpy as np
 import pytest
 
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from oracle.oracle import OracleSDF
 
 pytestmark = pytest.mark.gpu
@@ -77,7 +77,7 @@ def test_flat_float_stream_pass_gives_the_same_triangles(gpu):
     place of the bit-plane pass; read once per process, hence the subprocess."""
     import hashlib, os, subprocess, sys
     code = ("import hashlib, numpy as np\n"
-            "from gsdf_amd.builder import Builder\n"
+            "from scaffold.builder import Builder\n"
             "from gsdf_amd import hip\n"
             "hip.init(0)\n"
             "s = Builder().Scene('npt-flange')\n"

@@ -5,7 +5,7 @@ real multi-rank gather is covered on CPU by tests/test_gather_gloo.py (same layo
 import numpy as np
 import pytest
 
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 
 pytestmark = pytest.mark.gpu
 

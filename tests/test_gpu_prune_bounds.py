@@ -7,7 +7,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from nonlip_trees import nonlip_shapes
 from oracle.oracle import OracleSDF
 

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import corpus
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from oracle.oracle import OracleSDF
 
 pytestmark = pytest.mark.gpu

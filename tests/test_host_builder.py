@@ -6,7 +6,7 @@ import pytest
 
 import corpus
 from gsdf_amd._ctypes_common import OP, OPS
-from gsdf_amd.builder import Builder, FlagNoDimensionPanic, ShapeError, NutCircular
+from scaffold.builder import Builder, FlagNoDimensionPanic, ShapeError, NutCircular
 from oracle.oracle import OracleSDF
 
 

@@ -8,7 +8,7 @@ import pytest
 
 import corpus
 from gsdf_amd import hip
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _HDR = open(os.path.join(ROOT, "gsdf_amd", "csrc", "dev_ops.h")).read()

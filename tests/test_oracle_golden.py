@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 import corpus
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from oracle import oracle
 from oracle.oracle import OracleSDF
 
@@ -251,7 +251,7 @@ def test_dualcontour_bolt_renders():
 
 def test_block_cached_wrapper_semantics():
     """gleval.BlockCachedSDF3 restatement (oracle.OracleBlockCachedSDF3): lossy per-cell cache, statistics, Reset."""
-    from gsdf_amd.builder import Builder
+    from scaffold.builder import Builder
     from oracle.oracle import OracleBlockCachedSDF3, OracleSDF
     b = Builder()
     sdf = OracleSDF(b.NewSphere(1.0).tree())

@@ -5,7 +5,7 @@ renderer's triangle count where the reference's predicate applied to every level
 import numpy as np
 import pytest
 
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from nonlip_trees import nonlip_shapes
 from oracle.oracle import OracleSDF
 

@@ -6,7 +6,7 @@ import re
 import pytest
 
 from gsdf_amd import hip
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 
 
 def _source(shader):

@@ -1,4 +1,4 @@
-"""forge/textsdf mirror (gsdf_amd/host/textsdf.hpp + ttf.hpp) on the reference's own font (tests/golden/iso-3098.ttf is
+"""forge/textsdf mirror (scaffold/textsdf.hpp + ttf.hpp) on the reference's own font (tests/golden/iso-3098.ttf is
 the data file forge/textsdf embeds and its TestABC uses, forge/textsdf/embed.go:9, glyph_test.go:13-21). No GPU."""
 import os
 import struct
@@ -6,7 +6,7 @@ import struct
 import numpy as np
 import pytest
 
-from gsdf_amd.builder import Builder, ShapeError
+from scaffold.builder import Builder, ShapeError
 from gsdf_amd._ctypes_common import OP
 from oracle.oracle import OracleSDF
 

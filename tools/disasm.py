@@ -3,7 +3,7 @@
 import os, re, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from gsdf_amd import hip
 
 src = open(os.path.join(os.path.dirname(__file__), "..", "gsdf_amd", "csrc", "dev_ops.h")).read()

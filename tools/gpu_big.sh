@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 timeout 1500 python - <<'PY' 2>&1 | tail -8
 import hashlib, time, numpy as np
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from gsdf_amd import hip
 from oracle.oracle import OracleSDF
 hip.init(0)

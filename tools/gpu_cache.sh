@@ -5,7 +5,7 @@ export GSDF_HIP_CACHE_DIR=/tmp/gsdf_cache; rm -rf $GSDF_HIP_CACHE_DIR; mkdir -p 
 for i in 1 2; do
 timeout 300 python - <<'PY'
 import hashlib, numpy as np
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from gsdf_amd import hip
 hip.init(0)
 s = Builder().Scene("bolt")

@@ -3,7 +3,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/dc_tmp; rm -rf $OUT; mkdir -p $OUT
 cat > /tmp/dc.py <<'PY'
 import sys, time, numpy as np
 sys.path.insert(0, "/root/repo")
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from gsdf_amd import hip
 hip.init(0)
 b = Builder()

@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 timeout 600 python - <<'PY' 2>&1 | tail -14
 import numpy as np, time, torch
-from gsdf_amd.builder import Builder, NutCircular
+from scaffold.builder import Builder, NutCircular
 from gsdf_amd import hip
 hip.init(0)
 b = Builder()

@@ -4,7 +4,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 timeout 1500 python -m pytest tests/test_gpu_flat.py -m gpu -x -q 2>&1 | tail -5
 timeout 600 python - <<'PY'
 import numpy as np
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from gsdf_amd import hip
 hip.init(0)
 b = Builder()

@@ -5,7 +5,7 @@ for bpc in 4 6 8 16 32; do
 GSDF_HIP_FLAT_BPC=$bpc timeout 300 python - <<'PY'
 import os
 import numpy as np
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from gsdf_amd import hip
 hip.init(0)
 b = Builder()

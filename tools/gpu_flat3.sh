@@ -7,7 +7,7 @@ for st in 0 1; do
 GSDF_HIP_FLAT_STREAM=$st timeout 600 python - <<'PY'
 import os
 import numpy as np
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from gsdf_amd import hip
 hip.init(0)
 b = Builder()

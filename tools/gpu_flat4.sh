@@ -9,7 +9,7 @@ cat > /tmp/flat_one.py <<'PY'
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from gsdf_amd import hip
 hip.init(0)
 b = Builder()

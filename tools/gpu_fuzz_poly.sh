@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT
 timeout ${2:-1500} python - "$1" <<'PY' 2>&1 | tail -8
 import sys, math, numpy as np
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from gsdf_amd import hip
 from oracle.oracle import OracleSDF
 hip.init(0)

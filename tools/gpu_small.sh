@@ -6,7 +6,7 @@ timeout 600 python - <<'PY'
 import threading, time
 import numpy as np
 import torch  # noqa: F401  (load order of the GPU box's processes)
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from gsdf_amd import hip
 from oracle.oracle import OracleSDF
 hip.init(0)

@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 timeout 900 python - <<'PY' 2>&1 | tail -12
 import numpy as np, hashlib, time
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from gsdf_amd import hip
 hip.init(0)
 b = Builder()

@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 timeout 600 python - <<'PY' 2>&1 | tail -14
 import numpy as np
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from gsdf_amd import hip
 hip.init(0)
 b = Builder()

@@ -6,7 +6,7 @@ cat > /tmp/stl.py <<'PY'
 import sys
 import numpy as np
 sys.path.insert(0, "/root/repo")
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from gsdf_amd import hip
 hip.init(0)
 b = Builder()

@@ -2,7 +2,7 @@ cd $GRAFT_REPO_ROOT
 timeout 900 python - <<'PY' 2>&1 | tail -8
 import sys, os, numpy as np
 sys.path.insert(0, "tests")
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from gsdf_amd import hip
 import test_gpu_mesh as T
 hip.init(0)

@@ -4,7 +4,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 timeout 600 python - <<'PY'
 import threading, time
 import numpy as np
-from gsdf_amd.builder import Builder
+from scaffold.builder import Builder
 from gsdf_amd import hip
 hip.init(0)
 b = Builder()

@@ -35,7 +35,7 @@ def build_shim():
 
 
 def scene(name):
-    from gsdf_amd.builder import Builder
+    from scaffold.builder import Builder
     if name.startswith("fuzzlong:"):  # the trees of tools/gpu_fuzz_long.sh: fuzzlong:<seed>:<k>
         import fuzz_trees
         _, seed, idx = name.split(":")
