@@ -57,18 +57,51 @@ def cpu_baseline(shader, scene, resdiv, threads):
         ma, dta = run(400, nt, 2)
         anchor.append({"value": ma.evals / dta, "unit": "evals/s", "cores": nt, "triangles": ma.n_tris, "triangles_per_s": ma.n_tris / dta,
                        "seconds": dta})
+    # like for like with the device's octree path: the oracle's octree renderer (same algorithm: centre tests at every level,
+    # 8 corners per leaf) on one thread at resdiv 400 -- the flat lattice above evaluates 0.7x as many points at that size
+    so = OracleSDF(shader.tree())
+    r400 = np.float32(float(shader.Diagonal()) / 400)
+    t0 = time.perf_counter()
+    mo = so.render_octree(r400, 4096, True)
+    dto = time.perf_counter() - t0
+    out["octree_single_thread"] = {"value": mo.evals / dto, "unit": "evals/s", "cores": 1, "triangles_per_s": mo.n_tris / dto,
+                                   "sample": f"{scene} resdiv 400 octree renderer: {mo.evals} evals, {mo.n_tris} triangles in {dto:.2f}s"}
     out["resdiv400"] = {"runs": anchor, "reference_published": {"value": 6711686 / 0.313, "unit": "evals/s", "cores": 11,
                                                                 "hardware": "i5-12400F (README.md:125-134)", "triangles": 423852}}
+    return out
+
+
+def host_inclusive(hip, sdf, res, reps=7):
+    """What the reference's caller ends up with (gsdfaux.RenderShader3D: triangles in host memory, glrender/glrender.go:17-36,
+    then an STL file, stl.go:15-62), timed AFTER the contract's timed loop so that it does not perturb it: one mesh + its
+    triangles by one DMA into pinned host memory (gsdf_hip_mesh_host_tris), and one mesh + the complete binary STL file built
+    on device and moved the same way (gsdf_hip_mesh_host_stl). PCIe-inclusive: never the headline value. Median of `reps`."""
+    import statistics
+    out = {}
+    for key, view in (("ms_tris_host", "triangles_view"), ("ms_stl_host", "stl_view")):
+        ts, nbytes = [], 0
+        for _ in range(reps + 1):
+            t0 = time.perf_counter()
+            oc = hip.OctreeHIP(sdf, res)
+            v = getattr(oc, view)()
+            ts.append((time.perf_counter() - t0) * 1e3)
+            nbytes = int(v.nbytes)
+            del v, oc
+        out[key] = statistics.median(ts[1:])  # (the first pass pins the host buffer)
+        out[key.replace("ms_", "bytes_")] = nbytes
+    out["note"] = ("one complete mesh + result in host memory per call (pinned buffer from the library's pool, one DMA); "
+                   "the headline stops at triangles resident in HBM")
     return out
 
 
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, one wave64 VALU op per 2 cycles, 2.4 GHz
 
 
-def pmc_summary(workload):
-    """Latest committed rocprofv3 PMC summary of THIS workload (profiles/*_pmc_summary.json carry the bench line's
-    config.workload they were collected under; the match is on scene and resdiv). None if there is none: a line never
-    carries another workload's counters."""
+def pmc_summary(workload, code=None):
+    """Latest committed rocprofv3 PMC summary of THIS workload AND THIS code (profiles/*_pmc_summary.json carry the bench
+    line's config.workload and config.code they were collected under; the match is on scene, resdiv and the kernels' code key,
+    gsdf_hip_program_kernels). {} if there is none: a line never carries another workload's counters, nor those of kernels
+    that have since been edited."""
     import glob
     import re
     key = re.match(r"examples/(\S+) resdiv (\d+)", workload or "")
@@ -81,20 +114,20 @@ def pmc_summary(workload):
             continue
         k2 = re.match(r"examples/(\S+) resdiv (\d+)", j.get("workload", ""))
         d = j.get("leaf_eval_kernel") or j.get("leaf_kernel")
-        if d and k2 and k2.groups() == key.groups():  # summaries of other commands (eval mode, flat renderer) carry no leaf_kernel entry
+        if d and k2 and k2.groups() == key.groups() and (code is None or j.get("code") == code):  # summaries of other commands (eval mode, flat renderer) carry no leaf_kernel entry
             return dict(d, source=os.path.basename(f))
     return {}
 
 
-def pmc_traffic_gb(workload):
+def pmc_traffic_gb(workload, code=None):
     """HBM bytes per leaf_kernel launch: 2*FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE, KB -> GB."""
-    return pmc_summary(workload).get("hbm_traffic_gb_per_launch")
+    return pmc_summary(workload, code).get("hbm_traffic_gb_per_launch")
 
 
-def valu_roofline(kernel_evals_per_s, workload):
+def valu_roofline(kernel_evals_per_s, workload, code=None):
     """The binding roofline of this path: VALU issue. Instructions per evaluation come from the PMC pass of the same
     workload (SQ_INSTS_VALU x 64 lanes / evaluations per launch), the rate from the live kernel timing."""
-    pm = pmc_summary(workload)
+    pm = pmc_summary(workload, code)
     per_eval = pm.get("valu_lane_instr_per_eval")
     if not per_eval:
         return None
@@ -202,6 +235,11 @@ def main():
                          "e.g. --scene glyph-plate --resdiv 800 --renderer dualcontour)")
     ap.add_argument("--preheat", type=int, default=50, help="untimed meshes run during setup, before the W warmup steps, so that the GPU clocks are up")
     ap.add_argument("--interpreter", action="store_true", help="run the generic interpreter kernels instead of kernels specialised for the tree")
+    ap.add_argument("--gather", choices=["all", "root", "none"], default="all",
+                    help="N > 1: who ends up with the triangles -- all: RCCL all-gatherv, every rank gets everything (default, what "
+                         "BASELINE.json names); root: rank 0 only (ncclSend/ncclRecv); none: every rank keeps its shard (counts only)")
+    ap.add_argument("--no-gather-pipeline", action="store_true",
+                    help="N > 1: wait for a mesh's gather before meshing the next (default: the payload of mesh i moves while mesh i+1 is made)")
     ap.add_argument("--share-corners", action="store_true", help="evaluate each bitwise-distinct lattice corner of a brick once (same triangles, fewer evals)")
     args = ap.parse_args()
 
@@ -279,6 +317,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    gmode = {"all": hip.GATHER_ALL, "root": hip.GATHER_ROOT, "none": hip.GATHER_NONE}[args.gather]
+    pipeline = comm is not None and not args.no_gather_pipeline
+    gstat = {"n": 0, "ms_counts": 0.0, "ms_payload": 0.0, "bytes_received": 0, "bytes_sent": 0}
+    pending = []  # at most one gather in flight: (PendingGather)
+
+    def finish():
+        g = None
+        while pending:
+            g, _, gs = pending.pop(0).wait()
+            gstat["n"] += 1
+            gstat["ms_counts"] += gs.ms_counts
+            gstat["ms_payload"] += gs.ms_payload
+            gstat["bytes_received"] += gs.bytes_received
+            gstat["bytes_sent"] += gs.bytes_sent
+        return g
+
     def step():
         if args.renderer == "dualcontour":  # BASELINE configs[4]: dual contouring, z-slabs of the lattice per rank
             oc = hip.DualContourHIP(sdf, res, shard_rank=rank, shard_count=world)
@@ -286,7 +340,13 @@ def main():
             oc = hip.OctreeHIP(sdf, res, shard_rank=rank, shard_count=world, share_corners=args.share_corners)
         gathered = None
         if comm is not None:
-            gathered = oc.gatherv(comm)   # every rank ends up with all triangles, device resident
+            # the counts are exchanged and the payload enqueued on the communicator's stream; with the pipeline on, the
+            # previous mesh's payload is awaited only now, i.e. it moved while this mesh was made
+            pg = oc.gatherv_start(comm, gmode, 0)
+            gathered = finish()
+            pending.append(pg)
+            if not pipeline:
+                gathered = finish()
         elif torch_gather:
             from gsdf_amd.gather import all_gatherv_triangles
             gathered = all_gatherv_triangles(oc.dev_ptr(), oc.n_tris(), dev)[0]
@@ -298,6 +358,9 @@ def main():
         step()
     for _ in range(args.warmup):
         step()
+    finish()
+    for k in gstat:
+        gstat[k] = 0
     barrier()
     t0 = time.perf_counter()
     evals = tris = 0
@@ -314,6 +377,9 @@ def main():
         emit_ms += st.ms_emit
         cut += st.cut_leaves
         last = (oc, g)
+    gl = finish()  # the last mesh's gather belongs to the timed region too
+    if gl is not None:
+        last = (last[0], gl)
     barrier()
     dt = time.perf_counter() - t0
 
@@ -346,6 +412,7 @@ def main():
                     + ("dual contouring (least-squares vertex placement) on device " if dc else "octree prune + marching cubes on device ")
                     + f"(res {float(res):.7f}, {st.levels} levels)")
         kern = sdf.info()["kernels"]
+        code = kern.get("code")
         out = {
             "metric": "sdf_evals_per_s", "value": evals_all / dt, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -353,17 +420,18 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "sharding": (("z-slabs of the lattice, halo recomputed" if dc else "octree bricks by coordinate hash")
-                                    + (", RCCL all-gatherv of triangles inside the library (gsdf_hip_mesh_gatherv)" if comm is not None else ", RCCL all-gatherv of triangles through torch.distributed (fallback)")) if world > 1 else "single GPU",
+                                    + ((", RCCL gather of triangles inside the library (gsdf_hip_mesh_gatherv_start/_wait): mode " + args.gather
+                                        + (", payload of mesh i overlapped with mesh i+1" if pipeline else ", not pipelined")) if comm is not None else ", RCCL all-gatherv of triangles through torch.distributed (fallback)")) if (world > 1 or comm is not None) else "single GPU",
                        "leaf_corners": "shared (distinct lattice points once)" if args.share_corners else "8 per leaf (as the reference)",
-                       "evaluator": spec_note,
+                       "evaluator": spec_note, "code": code,
                        "setup": f"{args.preheat} untimed meshes before the warmup steps (clock ramp)"},
             "triangles_per_s": tris_all / dt,
             "triangles_per_step": tris_all / args.steps, "evals_per_step": evals_all / args.steps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if dc else pmc_traffic_gb(workload), "traffic_unit": "GB per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if dc else pmc_traffic_gb(workload, code), "traffic_unit": "GB per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
                          "algorithmic_gb_per_launch": k_bytes / 1e9,
                          "kernel": "dc_origin/edges/normals/place/quads (whole device pass)" if dc else kern.get("leaf", "leaf_kernel"), "kernel_ms": k_ms,
-                         "kernel_evals_per_s": kernel_rate, "valu": None if dc else valu_roofline(kernel_rate, workload),
+                         "kernel_evals_per_s": kernel_rate, "valu": None if dc else valu_roofline(kernel_rate, workload, code),
                          "note": "path is fp32-VALU bound (SURVEY 8(d)): algorithmic HBM bytes are tiny by construction; "
                                  "'valu' prices the same kernel against the VALU issue peak"},
             "roofline_march": None if (dc or not two_kernel) else {
@@ -372,11 +440,24 @@ def main():
                 "note": "marching cubes over the cut-leaf records: 40 B read per record + 36 B written per triangle"},
             "phase_ms_rank0": {"prune": st.ms_prune, "leaf": st.ms_leaf, "eval_kernel": st.ms_march, "march_kernel": st.ms_emit, "total_device": st.ms_total},
         }
+        if comm is not None and gstat["n"]:
+            n = gstat["n"]
+            g_ms = (gstat["ms_counts"] + gstat["ms_payload"]) / n
+            step_ms = dt / args.steps * 1e3
+            out["phase_ms_rank0"]["gather_counts"] = gstat["ms_counts"] / n
+            out["phase_ms_rank0"]["gather"] = gstat["ms_payload"] / n
+            out["gather"] = {"mode": args.gather, "pipelined": pipeline, "bytes_received_per_rank": gstat["bytes_received"] / n,
+                             "bytes_sent_per_rank": gstat["bytes_sent"] / n, "ms": g_ms,
+                             # how much of the shorter of the two (meshing on the device, gather on the wire) hid behind the other
+                             "overlap_frac": max(0.0, min(1.0, (st.ms_total + g_ms - step_ms) / max(1e-9, min(st.ms_total, g_ms)))),
+                             "note": "rank 0, HIP events on the communicator's stream; a step = one mesh + its gather"}
         if world == 1 and not args.no_cpu_baseline and not dc:
             threads = max(1, (os.cpu_count() or 2) - 1)  # GOMAXPROCS-1 (gsdfaux/gsdfaux.go:162-164)
             # bounded sample of the SAME workload: full resdiv 1600 lattice (420 M evals) on big hosts, coarser on small ones
             cpu_rd = args.cpu_resdiv or (args.resdiv if threads >= 64 else (1000 if threads >= 16 else 600))
             out["cpu_baseline"] = cpu_baseline(shader, args.scene, cpu_rd, threads)
+        if world == 1 and not dc:
+            out["host_inclusive"] = host_inclusive(hip, sdf, res)
         print(json.dumps(out), flush=True)
     if dist is not None:
         if rank == 0 and last[1] is not None:

@@ -80,7 +80,7 @@ struct gsdf_program {
       return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-  } q0, q1, ctr, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, flat_grid, flat_bits, flat_list, rec, hdr;  // flat_bits: sign and near-surface bit planes of the flat renderer's lattice (flat_grid_kernel -> flat_cut_scan_kernel), flat_list: the cut cubes (-> flat_march_list_kernel)  // rec / hdr: cut-leaf records and block headers of the two-kernel leaf phase (the group sums follow the counters in ctr)  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
+  } q0, q1, ctr, spec_pass, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, flat_grid, flat_bits, flat_list, rec, hdr;  // flat_bits: sign and near-surface bit planes of the flat renderer's lattice (flat_grid_kernel -> flat_cut_scan_kernel), flat_list: the cut cubes (-> flat_march_list_kernel)  // rec / hdr: cut-leaf records and block headers of the two-kernel leaf phase (the group sums follow the counters in ctr)  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   void* h_ctr = nullptr;  // pinned host copy of the device counters (a pageable destination makes the D2H copy a staged, blocking one)
   uint64_t last_tris = 0;  // triangle count of the previous mesh on this handle: sizes the next output buffer
@@ -88,12 +88,13 @@ struct gsdf_program {
   uint64_t last_dc_cubes = 0;  // kept cubes of the previous dual contouring pass: sizes the next queues
   // run-time specialised kernels for this program (gsdf_hip_program_specialize): hiprtc module, else interpreter
   hipModule_t spec_mod = nullptr, spec_mod2 = nullptr, spec_mod3 = nullptr, spec_mod4 = nullptr;  // spec_mod4: leaf kernel rebuilt with a larger register budget; spec_mod2: second group, built on first use (see spec_aux); spec_mod3: eval kernel rebuilt for 3 workgroups per CU
-  hipFunction_t f_eval = nullptr, f_prune = nullptr, f_prune_top = nullptr, f_leaf = nullptr;
+  hipFunction_t f_eval = nullptr, f_prune = nullptr, f_prune_spec = nullptr, f_leaf = nullptr;
   hipFunction_t f_dc_origin = nullptr, f_dc_edges = nullptr, f_dc_normals = nullptr, f_normals = nullptr, f_image = nullptr, f_flat_grid = nullptr;
   bool spec_aux_tried = false;
   int spec_eval_k = 0, spec_eval_w = 0, spec_leaf_k = 0, spec_leaf_w = 0;
   double spec_compile_s = 0;
   std::string spec_compiler;  // hipcc | hiprtc | cache: what built the specialised kernels
+  std::string spec_key;       // key of that build (specialize.cpp: build_key)
   // leaf kernel batching: K = 4 while 3 workgroups still fit the CU's LDS (<= 11 slots); 12..15 slots run K = 2 at 4
   // waves/SIMD instead of K = 4 at 2 (knurled-cylinder: 23.3 vs 23.8 ms). A 4th wave per SIMD is worth more than the
   // ~30 VGPRs it costs (flange 3.28 -> 2.95 ms), but only if 4 workgroups fit the CU's 160 KB of LDS.
@@ -474,7 +475,7 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
   names.push_back(std::string("eval_kernel<") + (p->prog.is2d ? "2" : "3") + ", " + std::to_string(ek) + ", " + std::to_string(ew) + ">");
   if (!p->prog.is2d) {
     names.push_back("prune_kernel");
-    names.push_back("prune_top_kernel");
+    names.push_back("prune_spec_kernel");
     names.push_back(std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(lw) + (fused_leaf() ? ">" : (p->leaf_nt_in_lds() ? ", true, true>" : ", true, false>")));
     // a fifth workgroup per CU where the LDS has room for it (npt-flange's 7 slots): the 96-register build is taken if the
     // compiler reaches it without scratch (-3 % on the evaluating kernel); built beside the 128-register one, same process
@@ -486,6 +487,7 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
   if (rc != GSDF_OK) return rc;
   p->spec_mod = mod;
   p->spec_compiler = gsdf_dev::spec_last_compiler();
+  p->spec_key = gsdf_dev::spec_last_key();
   p->spec_eval_k = ek; p->spec_eval_w = ew; p->spec_leaf_k = lk; p->spec_leaf_w = lw;
   // No scratch, or not used (see fn_scratch_bytes). The eval kernel gets a second chance with the larger register
   // budget of 3 workgroups per CU before the handle falls back to the interpreter kernel for that entry point.
@@ -510,7 +512,7 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
     spec_report("specialised", names[2], f[2], okt);
     spec_report("specialised", names[3], f[3], okl);
     p->f_prune = okp ? f[1] : nullptr;
-    p->f_prune_top = okt ? f[2] : nullptr;
+    p->f_prune_spec = okt ? f[2] : nullptr;
     p->f_leaf = okl ? f[3] : nullptr;
     if (f.size() > 4) {
       const bool ok5 = fn_scratch_bytes(f[4]) == 0;
@@ -550,7 +552,7 @@ extern "C" int gsdf_hip_program_kernels(const gsdf_program* p, char* dst, size_t
   const int ew = se ? p->spec_eval_w : p->sweep_waves(ek);
   // ahead-of-time leaf kernels exist at the scratch-free occupancies only (see gsdf_hip_mesh_octree)
   const int aw = lk == 4 ? (lw == 2 ? 2 : 3) : (lk == 2 ? 3 : 4);
-  char buf[256];
+  char buf[384];
   if (p->prog.is2d)
     snprintf(buf, sizeof buf, "eval=eval_kernel<2,%d,%d>:%s", ek, ew, se ? "specialised" : "interpreter");
   else
@@ -558,6 +560,10 @@ extern "C" int gsdf_hip_program_kernels(const gsdf_program* p, char* dst, size_t
              fused_leaf() ? "leaf_kernel" : "leaf_eval_kernel", lk, sl ? p->spec_leaf_w : aw, sl ? "specialised" : "interpreter",
              p->f_prune ? "specialised" : "interpreter");
   if (p->spec_mod && strlen(buf) + 32 < sizeof buf) { strcat(buf, " compiler="); strcat(buf, p->spec_compiler.c_str()); }
+  {  // identity of the code that runs: a stored profile describes this handle's kernels only if it carries the same key
+    const std::string key = p->spec_mod ? p->spec_key : gsdf_dev::spec_library_key();
+    if (strlen(buf) + 8 + key.size() < sizeof buf) { strcat(buf, " code="); strcat(buf, key.c_str()); }
+  }
   if (strlen(buf) + 1 > dst_cap) return fail(GSDF_ERR_SHORT_BUFFER, "short buffer");
   std::memcpy(dst, buf, strlen(buf) + 1);
   return GSDF_OK;
@@ -587,7 +593,7 @@ extern "C" int gsdf_hip_specialize_check(const gsdf_tree* tree, size_t* code_obj
     std::vector<std::string> low;
     std::string log;
     const std::vector<std::string> names = pr.is2d ? std::vector<std::string>{"eval_kernel<2, 4, 4>"}
-                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "prune_top_kernel", "leaf_eval_kernel<4, 4, true, true>", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
+                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "prune_spec_kernel", "leaf_eval_kernel<4, 4, true, true>", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
     if (!gsdf_dev::spec_compile(pr, "gfx950", names, co, low, log)) return fail(GSDF_ERR_HIP, "specialised build failed:\n" + log);
     if (code_object_bytes) *code_object_bytes = co.size();
     return GSDF_OK;
@@ -1041,34 +1047,33 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     HIP_TRYM(hipMemsetAsync(d_ctr, 0, clear_bytes, s));
     HIP_TRYM(hipEventRecord(ev0, s));
     static const int prune_bpc = [] { const char* e = getenv("GSDF_HIP_PRUNE_BPC"); return e ? atoi(e) : 4; }();  // tuning knob
-    // The top five levels (Level `levels` .. levels - 4, <= 4096 candidates at the last) by ONE workgroup in one launch
-    // (prune_top_kernel): as separate launches they are pure latency. 1024 threads where the interval columns and the two LDS
-    // queues fit the CU's 160 KB, else 512 / 256; GSDF_HIP_PRUNE_TOP=0 keeps one launch per level (cross-check in the tests).
-    static const bool use_top = [] { const char* e = getenv("GSDF_HIP_PRUNE_TOP"); return !e || atoi(e) != 0; }();
+    // The first S levels (at most 7: 299,593 cubes) are centre-tested speculatively, every cube of the complete octree at once,
+    // and resolved by a second launch (kernels.h: prune_spec_kernel / prune_resolve_kernel): two launches instead of a chain of
+    // S dependent ones. GSDF_HIP_PRUNE_SPEC=0 keeps one launch per level (cross-check in the tests).
+    static const bool use_spec = [] { const char* e = getenv("GSDF_HIP_PRUNE_SPEC"); return !e || atoi(e) != 0; }();
     int first_level = levels;  // first level of the per-level chain
-    if (use_top) {
-      const int last_top = levels - 4 > lq ? levels - 4 : lq;
-      unsigned tthreads = 0;
-      size_t lds_top = 0;
-      for (unsigned t : {1024u, 512u, 256u}) {
-        const size_t need = (size_t)(prune_cols > 0 ? prune_cols : 1) * 2 * t * sizeof(float) + 2 * (size_t)PRUNE_TOP_CAP * sizeof(Cube) + 32 * sizeof(unsigned);
-        if (need <= (size_t)160 * 1024) { tthreads = t; lds_top = need; break; }
+    if (use_spec) {
+      const int S = levels - lq + 1 < 7 ? levels - lq + 1 : 7;
+      const int last_spec = levels - (S - 1);
+      unsigned n_spec = 0;
+      for (int j = 0; j < S; j++) n_spec += 1u << (3 * j);
+      HIP_TRYM(p->spec_pass.ensure(n_spec));
+      const unsigned test_mask = pmask == 1 ? 0xffffffffu : (unsigned)pmask;
+      const int shard_level = opts.shard_count > 1 ? ls : -1;
+      const unsigned sgrid = grid_for(n_spec, p->num_cu, 8);
+      if (p->f_prune_spec) {
+        HIP_TRYM(launch_fn(p->f_prune_spec, sgrid, BLOCK, lds_prune, s, (const uint32_t*)p->d_code, (int)levels, (unsigned)n_spec, (int)prune_cols,
+                           (int)p->prog.nslots, ox, oy, oz, res, (unsigned)test_mask, (int)ptest, (int)shard_level, (unsigned)opts.shard_rank,
+                           (unsigned)opts.shard_count, (uint8_t*)p->spec_pass.p));
+      } else {
+        hipLaunchKernelGGL(prune_spec_kernel, dim3(sgrid), dim3(BLOCK), lds_prune, s, p->d_code, levels, n_spec, prune_cols, p->prog.nslots, ox, oy,
+                           oz, res, test_mask, ptest, shard_level, (unsigned)opts.shard_rank, (unsigned)opts.shard_count, (uint8_t*)p->spec_pass.p);
       }
-      if (tthreads) {
-        const unsigned test_mask = pmask == 1 ? 0xffffffffu : (unsigned)pmask;
-        const int shard_level = opts.shard_count > 1 ? ls : -1;
-        if (p->f_prune_top) {
-          HIP_TRYM(launch_fn(p->f_prune_top, 1u, tthreads, lds_top, s, (const uint32_t*)p->d_code, (int)levels, (int)last_top, (int)prune_cols,
-                             (int)p->prog.nslots, ox, oy, oz, res, (unsigned)test_mask, (int)ptest, (Cube*)q[last_top & 1]->p,
-                             (unsigned long long)capq[last_top & 1], (int)shard_level, (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr));
-        } else {
-          hipLaunchKernelGGL(prune_top_kernel, dim3(1), dim3(tthreads), lds_top, s, p->d_code, levels, last_top, prune_cols, p->prog.nslots, ox,
-                             oy, oz, res, test_mask, ptest, (Cube*)q[last_top & 1]->p, (unsigned long long)capq[last_top & 1], shard_level,
-                             (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr);
-        }
-        HIP_TRYM(hipGetLastError());
-        first_level = last_top - 1;
-      }
+      HIP_TRYM(hipGetLastError());
+      hipLaunchKernelGGL(prune_resolve_kernel, dim3((n_spec + SPEC_STAGE - 1) / SPEC_STAGE), dim3(BLOCK), 0, s, (const uint8_t*)p->spec_pass.p, levels, S,
+                         n_spec, test_mask, (Cube*)q[last_spec & 1]->p, (unsigned long long)capq[last_spec & 1], d_ctr);
+      HIP_TRYM(hipGetLastError());
+      first_level = last_spec - 1;
     }
     for (int level = first_level; level >= lq; level--) {
       const int expand = level != levels;
@@ -1134,7 +1139,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
         // one wave of workgroups: each takes an equal share of the records (computed on device from the group sums)
         static const int march_bpc = [] { const char* e = getenv("GSDF_HIP_MARCH_BPC"); return e ? atoi(e) : 7; }();  // tuning knob (7 fit a CU)
         const size_t lds_march = (size_t)11 * BLOCK * 4 + 5 * BLOCK * 4 + 256 * 16 + (BLOCK + 1) * 4 + 8 * 4 + 8 + 14 * 8;
-        hipLaunchKernelGGL(march_records_kernel, dim3(grid_for(nblk, p->num_cu, march_bpc)), dim3(BLOCK), lds_march, s, d_hdr, d_rec,
+        hipLaunchKernelGGL(march_records_kernel, dim3(grid_for(nblk_q, p->num_cu, march_bpc)), dim3(BLOCK), lds_march, s, d_hdr, d_rec,
                            d_psum, (unsigned long long)nblk, lq, ox, oy, oz, res, m->d_tris, (uint64_t)tcap, d_ctr);
       } else if (lq == 3 && lk == 4 && opts.share_corners) {
         // exact corner sharing: one wave per level-3 brick
@@ -1598,6 +1603,8 @@ struct RcclApi {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -1615,6 +1622,7 @@ RcclApi* rccl() {
   if (!api.field && api.err.empty()) api.err = std::string("librccl lacks ") + sym;
     GSDF_RCCL_SYM(GetUniqueId, "ncclGetUniqueId") GSDF_RCCL_SYM(CommInitRank, "ncclCommInitRank") GSDF_RCCL_SYM(CommDestroy, "ncclCommDestroy")
     GSDF_RCCL_SYM(AllGather, "ncclAllGather") GSDF_RCCL_SYM(AllReduce, "ncclAllReduce") GSDF_RCCL_SYM(Broadcast, "ncclBroadcast")
+    GSDF_RCCL_SYM(Send, "ncclSend") GSDF_RCCL_SYM(Recv, "ncclRecv")
     GSDF_RCCL_SYM(GroupStart, "ncclGroupStart") GSDF_RCCL_SYM(GroupEnd, "ncclGroupEnd") GSDF_RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef GSDF_RCCL_SYM
   });
@@ -1628,6 +1636,17 @@ struct gsdf_comm {
   hipStream_t stream = nullptr;
   unsigned long long* d_counts = nullptr;  // [world + 1]: the gathered counts, then this rank's own
   unsigned long long* h_counts = nullptr;  // pinned mirror
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // around the counts exchange and the payload, on `stream`
+};
+
+// A gather whose payload is on its way (gsdf_hip_mesh_gatherv_start): the result mesh, the counts, and the events that time it.
+struct gsdf_gather {
+  gsdf_comm* c = nullptr;
+  gsdf_mesh* g = nullptr;  // result (NULL on the ranks that receive nothing)
+  std::vector<uint64_t> counts;
+  gsdf_gather_stats st{};
+  hipEvent_t ev_payload0 = nullptr, ev_payload1 = nullptr;
+  float ms_counts = 0;
 };
 
 #define RCCL_TRY(expr)                                                                                                   \
@@ -1654,6 +1673,7 @@ extern "C" void gsdf_hip_comm_destroy(gsdf_comm* c) {
   if (c->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(c->comm);
   if (c->d_counts) (void)hipFree(c->d_counts);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
+  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1701,54 +1721,119 @@ extern "C" int gsdf_hip_comm_allreduce_sum_u64(gsdf_comm* c, uint64_t* vals, siz
   return rc;
 }
 
-// All-gatherv of triangle buffers: the result is a mesh like any other (device-resident triangles of ALL ranks in rank
-// order: read / host views / STL / destroy as usual); counts (optional) receives the per-rank triangle counts.
-extern "C" int gsdf_hip_mesh_gatherv(const gsdf_mesh* m, gsdf_comm* c, gsdf_mesh** out, uint64_t* counts) {
+// Gather of triangle buffers. mode ALL: every rank ends up with the triangles of all ranks in rank order (ncclAllGather of the
+// counts, then ONE group of ncclBroadcast's, root r sending exactly count_r * 36 bytes straight out of its mesh into every
+// rank's result at offset sum(count_<r): no padding, no staging copies). mode ROOT: only `root` does (one group of ncclSend /
+// ncclRecv: a rank's link carries its own triangles only, 1/world of what ALL puts on it). mode NONE: the counts only -- every
+// rank keeps its shard (a caller that writes per-rank files, or consumes the shards where they are). _start returns once the
+// counts are known and the payload is enqueued on the communicator's stream: the caller may mesh the next part while it
+// moves (the source mesh must stay alive until _wait); _wait returns the result, a mesh like any other (read / host views /
+// STL / destroy as usual), NULL on ranks that received nothing.
+extern "C" int gsdf_hip_mesh_gatherv_start(const gsdf_mesh* m, gsdf_comm* c, int mode, int root, gsdf_gather** out) {
   if (!m || !c || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
   *out = nullptr;
+  if (mode != GSDF_GATHER_ALL && mode != GSDF_GATHER_ROOT && mode != GSDF_GATHER_NONE) return fail(GSDF_ERR_BAD_ARGUMENT, "bad gather mode");
+  if (mode == GSDF_GATHER_ROOT && (root < 0 || root >= c->world)) return fail(GSDF_ERR_BAD_ARGUMENT, "bad root rank");
   if (m->host_out) return fail(GSDF_ERR_BAD_ARGUMENT, "gatherv needs device-resident triangles (host_output meshes live in host memory)");
   if (m->device != c->device) return fail(GSDF_ERR_BAD_ARGUMENT, "mesh and communicator are on different devices");
   RcclApi* R = rccl();
   HIP_TRY(hipSetDevice(c->device));
+  for (auto& e : c->ev) if (!e) HIP_TRY(hipEventCreate(&e));
   const int W = c->world;
   // 1. counts
+  HIP_TRY(hipEventRecord(c->ev[0], c->stream));
   c->h_counts[W] = m->st.n_tris;
   HIP_TRY(hipMemcpyAsync(c->d_counts + W, c->h_counts + W, 8, hipMemcpyHostToDevice, c->stream));
   RCCL_TRY(R->AllGather(c->d_counts + W, c->d_counts, 1, ncclUint64, c->comm, c->stream));
   HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, 8 * (size_t)W, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipEventRecord(c->ev[1], c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  gsdf_gather* p = new (std::nothrow) gsdf_gather();
+  if (!p) return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory");
+  p->c = c;
+  p->counts.assign(c->h_counts, c->h_counts + W);
+  (void)hipEventElapsedTime(&p->ms_counts, c->ev[0], c->ev[1]);
   uint64_t total = 0;
-  for (int r = 0; r < W; r++) { if (counts) counts[r] = c->h_counts[r]; total += c->h_counts[r]; }
-  gsdf_mesh* g = new (std::nothrow) gsdf_mesh();
-  if (!g) return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory");
-  g->device = c->device;
-  g->st = m->st;  // resolution, origin, levels; per-rank counters stay per-rank (sum them with gsdf_hip_comm_allreduce_sum_u64)
-  g->st.n_tris = total;
-  auto bail = [&](int code) { gsdf_hip_mesh_destroy(g); return code; };
-  if (total) {
-    g->d_tris = pool_take(c->device, total, &g->cap);
-    if (!g->d_tris) {
-      if (hipMalloc((void**)&g->d_tris, total * 36) != hipSuccess) { (void)hipGetLastError(); return bail(fail(GSDF_ERR_HIP, "hipMalloc of the gathered triangle buffer failed")); }
-      g->cap = total;
+  for (int r = 0; r < W; r++) total += p->counts[(size_t)r];
+  auto bail = [&](int code) { if (p->g) gsdf_hip_mesh_destroy(p->g); if (p->ev_payload0) (void)hipEventDestroy(p->ev_payload0); if (p->ev_payload1) (void)hipEventDestroy(p->ev_payload1); delete p; return code; };
+  const bool receives = mode == GSDF_GATHER_ALL || (mode == GSDF_GATHER_ROOT && c->rank == root);
+  const uint64_t mine = p->counts[(size_t)c->rank];
+  if (receives) {
+    gsdf_mesh* g = new (std::nothrow) gsdf_mesh();
+    if (!g) return bail(fail(GSDF_ERR_BAD_ARGUMENT, "out of memory"));
+    p->g = g;
+    g->device = c->device;
+    g->st = m->st;  // resolution, origin, levels; per-rank counters stay per-rank (sum them with gsdf_hip_comm_allreduce_sum_u64)
+    g->st.n_tris = total;
+    if (total) {
+      g->d_tris = pool_take(c->device, total, &g->cap);
+      if (!g->d_tris) {
+        if (hipMalloc((void**)&g->d_tris, total * 36) != hipSuccess) { (void)hipGetLastError(); return bail(fail(GSDF_ERR_HIP, "hipMalloc of the gathered triangle buffer failed")); }
+        g->cap = total;
+      }
     }
-    // 2. payload: one grouped launch of world broadcasts, root r -> everyone's [offset_r, offset_r + count_r)
+    p->st.bytes_received = (total - mine) * 36;
+  }
+  if (mode == GSDF_GATHER_ALL) p->st.bytes_sent = W > 1 ? mine * 36 : 0;  // (a broadcast: the ring / tree forwards it; one copy leaves this rank)
+  else if (mode == GSDF_GATHER_ROOT) p->st.bytes_sent = c->rank == root ? 0 : mine * 36;
+  if (hipEventCreate(&p->ev_payload0) != hipSuccess || hipEventCreate(&p->ev_payload1) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipEventCreate failed"));
+  if (hipEventRecord(p->ev_payload0, c->stream) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipEventRecord failed"));
+  // 2. payload: one grouped launch
+  if (total && mode != GSDF_GATHER_NONE) {
     ncclResult_t r0 = R->GroupStart();
     if (r0 != ncclSuccess) return bail(fail(GSDF_ERR_HIP, std::string("ncclGroupStart: ") + R->GetErrorString(r0)));
     uint64_t off = 0;
     ncclResult_t rb = ncclSuccess;
     for (int r = 0; r < W && rb == ncclSuccess; r++) {
-      const uint64_t n = c->h_counts[r];
-      if (n) rb = R->Broadcast(r == c->rank ? (const void*)m->d_tris : (const void*)(g->d_tris + off * 9), g->d_tris + off * 9, (size_t)n * 9, ncclFloat32, r, c->comm, c->stream);
+      const uint64_t n = p->counts[(size_t)r];
+      if (n) {
+        if (mode == GSDF_GATHER_ALL) {
+          rb = R->Broadcast(r == c->rank ? (const void*)m->d_tris : (const void*)(p->g->d_tris + off * 9), p->g->d_tris + off * 9, (size_t)n * 9, ncclFloat32, r, c->comm, c->stream);
+        } else if (c->rank == root) {  // ROOT, on the root: its own share by a device copy, everybody else's by a receive
+          if (r == root) { if (hipMemcpyAsync(p->g->d_tris + off * 9, m->d_tris, (size_t)n * 36, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rb = ncclUnhandledCudaError; }
+          else rb = R->Recv(p->g->d_tris + off * 9, (size_t)n * 9, ncclFloat32, r, c->comm, c->stream);
+        } else if (r == c->rank) {     // ROOT, elsewhere: send mine
+          rb = R->Send(m->d_tris, (size_t)n * 9, ncclFloat32, root, c->comm, c->stream);
+        }
+      }
       off += n;
     }
     ncclResult_t r1 = R->GroupEnd();
-    if (rb != ncclSuccess) return bail(fail(GSDF_ERR_HIP, std::string("ncclBroadcast: ") + R->GetErrorString(rb)));
+    if (rb != ncclSuccess) return bail(fail(GSDF_ERR_HIP, std::string("gather payload: ") + R->GetErrorString(rb)));
     if (r1 != ncclSuccess) return bail(fail(GSDF_ERR_HIP, std::string("ncclGroupEnd: ") + R->GetErrorString(r1)));
-    hipError_t e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) return bail(fail(GSDF_ERR_HIP, std::string("gatherv: ") + hipGetErrorString(e)));
   }
-  *out = g;
+  if (hipEventRecord(p->ev_payload1, c->stream) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipEventRecord failed"));
+  *out = p;
   return GSDF_OK;
+}
+
+extern "C" int gsdf_hip_mesh_gatherv_wait(gsdf_gather* p, gsdf_mesh** out, uint64_t* counts, gsdf_gather_stats* st) {
+  if (!p) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  if (out) *out = nullptr;
+  (void)hipSetDevice(p->c->device);
+  hipError_t e = hipEventSynchronize(p->ev_payload1);
+  int rc = GSDF_OK;
+  if (e != hipSuccess) rc = fail(GSDF_ERR_HIP, std::string("gatherv: ") + hipGetErrorString(e));
+  float ms = 0;
+  if (rc == GSDF_OK) (void)hipEventElapsedTime(&ms, p->ev_payload0, p->ev_payload1);
+  p->st.ms_counts = p->ms_counts;
+  p->st.ms_payload = ms;
+  if (counts) for (size_t r = 0; r < p->counts.size(); r++) counts[r] = p->counts[r];
+  if (st) *st = p->st;
+  if (rc == GSDF_OK && out) { *out = p->g; p->g = nullptr; }
+  if (p->g) gsdf_hip_mesh_destroy(p->g);
+  (void)hipEventDestroy(p->ev_payload0);
+  (void)hipEventDestroy(p->ev_payload1);
+  delete p;
+  return rc;
+}
+
+// All-gatherv in one call (gsdf_hip_mesh_gatherv_start + _wait, mode ALL): every rank gets every triangle.
+extern "C" int gsdf_hip_mesh_gatherv(const gsdf_mesh* m, gsdf_comm* c, gsdf_mesh** out, uint64_t* counts) {
+  if (!out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  gsdf_gather* p = nullptr;
+  if (int rc = gsdf_hip_mesh_gatherv_start(m, c, GSDF_GATHER_ALL, 0, &p)) return rc;
+  return gsdf_hip_mesh_gatherv_wait(p, out, counts, nullptr);
 }
 
 extern "C" int gsdf_hip_mesh_stats_get(const gsdf_mesh* m, gsdf_mesh_stats* st) {

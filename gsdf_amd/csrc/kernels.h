@@ -225,91 +225,133 @@ __global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict
   }
 }
 
-// The top of the octree in ONE launch: Levels `top` .. `last` (at most five: the last has <= 8^4 = 4096 candidates) by a
-// single workgroup that keeps both cube queues in LDS. Above Level ~8 a level is a few hundred cubes and its launch is
-// nothing but latency (7 us each, 10 per mesh: 10 % of npt-flange at resdiv 1600); here a level costs one evaluation and
-// two barriers. Same candidates, same test, same counters as prune_kernel level by level; the survivors of Level `last` go
-// to `out` in the order the LDS compaction leaves them (any order is fine: the next level reads a queue).
-// test_mask: bit L set = centre-test Level L (gsdf_mesh_opts.prune); ptest 1 = field bounds, 2 = the reference's predicate.
-// LDS: [2 * ncols floats per lane | 2 queues of PRUNE_TOP_CAP cubes | 2 x 16 wave totals].
-#define PRUNE_TOP_CAP 4096
-__global__ void __launch_bounds__(1024) prune_top_kernel(const uint32_t* __restrict__ code_g, int top, int last, int ncols, int lip_base,
-                                                         float ox, float oy, float oz, float res, unsigned test_mask, int ptest,
-                                                         Cube* __restrict__ out, unsigned long long out_cap, int shard_level,
-                                                         unsigned shard_rank, unsigned shard_count, MeshCounters* __restrict__ ctr) {
+// The top of the octree WITHOUT its chain of dependent launches. A level is centre-tested after its parent level because a
+// dropped cube's children need no test -- an economy that is worth nothing where a level is a few thousand cubes and its launch
+// 10 us of latency (npt-flange at resdiv 1600: 10 levels, 0.1 ms of a 0.7 ms mesh). The first S levels (all the cubes of Levels
+// top .. top-S+1: (8^S - 1) / 7 of them, 299,593 for S = 7 -- 0.2 % of that mesh's evaluations) are therefore tested
+// SPECULATIVELY, every cube of the complete octree at once, in one launch (prune_spec_kernel: a byte per cube), and a second
+// launch keeps the cubes whose ancestors all passed (prune_resolve_kernel: ancestor bytes are independent loads, no
+// level-by-level pass) and compacts the survivors of the last speculative level into the queue the per-level kernels continue
+// from. Same tests on the same centres, so the survivors are exactly the per-level chain's; the counters count the cubes that
+// chain would have tested (candidates: children of survivors), not the speculative ones.
+// Cube number i of the speculative block: level top-j for off(j) <= i < off(j+1), off(j) = (8^j - 1) / 7; k = i - off(j) spells
+// the path from the top cube in base 8, most significant digit first, a digit being the child number in corner order; the
+// parent of (j, k) is (j-1, k >> 3).
+__device__ __forceinline__ unsigned spec_level_of(unsigned i, unsigned& k) {  // j and the number within the level
+  unsigned j = 0, off = 0, n = 1;
+  while (i >= off + n) { off += n; n <<= 3; j++; }  // <= 7 steps
+  k = i - off;
+  return j;
+}
+__device__ __forceinline__ Cube spec_cube(unsigned j, unsigned k) {
+  unsigned x = 0, y = 0, z = 0;
+  for (unsigned d = 0; d < j; d++) {
+    const unsigned c = (k >> (3u * (j - 1u - d))) & 7u;
+    x = 2u * x + ((c ^ (c >> 1)) & 1u);
+    y = 2u * y + ((c >> 1) & 1u);
+    z = 2u * z + ((c >> 2) & 1u);
+  }
+  Cube c = {(uint16_t)x, (uint16_t)y, (uint16_t)z, 0};
+  return c;
+}
+// pass[i]: bit 0 = the cube passed its centre test (or its level is not tested), bit 1 = this rank owns it (multi-GPU: at the
+// level where bricks are dealt to ranks; everywhere else set).
+// LDS: [2 * ncols floats per lane] (interval mode, see prune_kernel).
+__global__ void __launch_bounds__(BLOCK) prune_spec_kernel(const uint32_t* __restrict__ code_g, int top, unsigned n_spec, int ncols,
+                                                           int lip_base, float ox, float oy, float oz, float res, unsigned test_mask,
+                                                           int ptest, int shard_level, unsigned shard_rank, unsigned shard_count,
+                                                           uint8_t* __restrict__ pass) {
   code_ptr code = as_code(code_g);
-  const unsigned nthreads = blockDim.x, nwaves = nthreads >> 6;
   float* lds = g_smem + threadIdx.x;
-  Cube* s_qa = (Cube*)(g_smem + (size_t)(ncols > 0 ? ncols : 1) * 2 * nthreads);
-  Cube* s_qb = s_qa + PRUNE_TOP_CAP;
-  unsigned* s_w = (unsigned*)(s_qb + PRUNE_TOP_CAP);  // [0..15] kept per wave, [16..31] passed the test per wave
-  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  Cube* s_in = s_qa;
-  Cube* s_out = s_qb;
-  unsigned n_prev = 0;
-  for (int level = top; level >= last; level--) {  // block-uniform
-    const unsigned n_items = level == top ? 1u : n_prev * 8u;
-    const int do_test = (level >= 3 && ((test_mask >> level) & 1u)) ? ptest : 0;
+  (void)ncols;
+  const unsigned step = gridDim.x * BLOCK;
+  for (unsigned base = blockIdx.x * BLOCK; base < n_spec; base += step) {  // block-uniform trip count
+    const unsigned i = base + threadIdx.x;
+    const bool valid = i < n_spec;
+    unsigned k = 0;
+    const unsigned j = spec_level_of(valid ? i : 0u, k);
+    const int level = top - (int)j;
+    const Cube c = spec_cube(j, k);
+    const bool tested = level >= 3 && ((test_mask >> level) & 1u) != 0u;
     const float size = (float)(1 << (level - 1)) * res;
     const float maxDist = size * (1.73205080757f / 2);
-    unsigned cur = 0, passed = 0;
-    for (unsigned base = 0; base < n_items; base += nthreads) {  // block-uniform trip count
-      const unsigned i = base + threadIdx.x;
-      const bool valid = i < n_items;
-      Cube c = {0, 0, 0, 0};
-      if (valid && level != top) {
-        const Cube pc = s_in[i >> 3];
-        const unsigned k = i & 7u;
-        c.x = (uint16_t)(pc.x * 2 + ((k ^ (k >> 1)) & 1));
-        c.y = (uint16_t)(pc.y * 2 + ((k >> 1) & 1));
-        c.z = (uint16_t)(pc.z * 2 + ((k >> 2) & 1));
-      }
-      bool keep = valid;
-      if (do_test) {
-        const float cx0 = ox + size * (float)c.x, cy0 = oy + size * (float)c.y, cz0 = oz + size * (float)c.z;
-        P3 p;
-        p.x = 0.5f * (cx0 + (cx0 + size));
-        p.y = 0.5f * (cy0 + (cy0 + size));
-        p.z = 0.5f * (cz0 + (cz0 + size));
-        P3 pv[2] = {p, p};
-        float dv[2];
-        if (do_test == 2) {
-          gsdf_dev::sdf_eval<2>(code, pv, dv, lds, nthreads);
-          keep = valid && !(dm::absf(dv[0]) >= maxDist);
-        } else {
-          gsdf_dev::sdf_eval<2, 0, true>(code, pv, dv, lds, nthreads, false, maxDist, (uint32_t)lip_base);
-          keep = valid && !(dv[0] >= 0.0f || dv[1] <= 0.0f);
-        }
-      }
-      const unsigned long long pm = __ballot(keep);
-      if (level == shard_level) keep = keep && (brick_owner(c.x, c.y, c.z, shard_count) == shard_rank);
-      const unsigned long long km = __ballot(keep);
-      const unsigned lane_prefix = __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
-      if (lane == 0) { s_w[wave] = (unsigned)__builtin_popcountll(km); s_w[16 + wave] = (unsigned)__builtin_popcountll(pm); }
-      __syncthreads();
-      unsigned total = 0, wpre = 0, tpass = 0;
-      for (unsigned w = 0; w < nwaves; w++) {
-        const unsigned t = s_w[w];
-        wpre += w < wave ? t : 0u;
-        total += t;
-        tpass += s_w[16 + w];
-      }
-      if (keep && cur + wpre + lane_prefix < PRUNE_TOP_CAP) s_out[cur + wpre + lane_prefix] = c;  // (<= 8^4 by construction)
-      cur += total;
-      passed += tpass;
-      __syncthreads();
+    const float cx0 = ox + size * (float)c.x, cy0 = oy + size * (float)c.y, cz0 = oz + size * (float)c.z;
+    P3 p;
+    p.x = 0.5f * (cx0 + (cx0 + size));
+    p.y = 0.5f * (cy0 + (cy0 + size));
+    p.z = 0.5f * (cz0 + (cz0 + size));
+    P3 pv[2] = {p, p};
+    float dv[2];
+    bool keep;
+    if (ptest == 2) {
+      gsdf_dev::sdf_eval<2>(code, pv, dv, lds, BLOCK);
+      keep = !(dm::absf(dv[0]) >= maxDist);
+    } else {
+      gsdf_dev::sdf_eval<2, 0, true>(code, pv, dv, lds, BLOCK, false, maxDist, (uint32_t)lip_base);  // (maxDist differs from lane to lane: fine, it is the lane's own radius)
+      keep = !(dv[0] >= 0.0f || dv[1] <= 0.0f);
     }
-    if (threadIdx.x == 0) {
-      ctr->n_items[level] = do_test ? (unsigned long long)n_items : 0ull;
-      ctr->n_pass[level] = (unsigned long long)passed;
-      ctr->n_level[level] = (unsigned long long)cur;
-    }
-    n_prev = cur < PRUNE_TOP_CAP ? cur : PRUNE_TOP_CAP;
-    Cube* t = s_in; s_in = s_out; s_out = t;
+    if (!tested) keep = true;
+    const bool own = level != shard_level || brick_owner(c.x, c.y, c.z, shard_count) == shard_rank;
+    if (valid) pass[i] = (uint8_t)((keep ? 1u : 0u) | (own ? 2u : 0u));
   }
-  // s_in = survivors of Level `last`
-  if ((unsigned long long)n_prev <= out_cap) {
-    for (unsigned k = threadIdx.x; k < n_prev; k += nthreads) out[k] = s_in[k];
+}
+
+// Survivors of the speculative block: cube i lives on iff it and every ancestor passed (and was owned). Every thread walks its
+// own ancestor chain -- up to S independent byte loads from a table that sits in L2 -- so there is no pass per level. The
+// survivors of the LAST speculative level are staged in LDS and appended to `out` with one atomic per workgroup; per level,
+// the candidates the per-level chain would have tested (children of survivors; the top cube itself) and those that passed are
+// added to the counters with one atomic per workgroup and level that saw any.
+#define SPEC_STAGE 2048
+__global__ void __launch_bounds__(BLOCK) prune_resolve_kernel(const uint8_t* __restrict__ pass, int top, int S, unsigned n_spec,
+                                                              unsigned test_mask, Cube* __restrict__ out, unsigned long long out_cap,
+                                                              MeshCounters* __restrict__ ctr) {
+  __shared__ Cube s_q[SPEC_STAGE];
+  __shared__ unsigned s_n, s_items[8], s_pass[8];
+  __shared__ unsigned long long s_base;
+  if (threadIdx.x == 0) s_n = 0;
+  if (threadIdx.x < 8) { s_items[threadIdx.x] = 0; s_pass[threadIdx.x] = 0; }
+  __syncthreads();
+  const unsigned per = (n_spec + gridDim.x - 1) / gridDim.x;  // a contiguous slice per workgroup
+  const unsigned i0 = blockIdx.x * per, i1 = i0 + per < n_spec ? i0 + per : n_spec;
+  for (unsigned base = i0; base < i1; base += BLOCK) {
+    const unsigned i = base + threadIdx.x;
+    if (i >= i1) continue;
+    unsigned k = 0;
+    const unsigned j = spec_level_of(i, k);
+    // ancestors: (j-1, k>>3), (j-2, k>>6) ... ; off(j) = (8^j - 1) / 7
+    unsigned anc = 1u;  // every proper ancestor passed and was owned (no short circuit: the loads are independent)
+    unsigned kk = k, off = i - k;
+    for (unsigned a = j; a > 0; a--) {
+      kk >>= 3;
+      off = (off - 1u) >> 3;  // off(a-1) = (off(a) - 1) / 8
+      anc &= pass[off + kk] == 3u ? 1u : 0u;
+    }
+    const unsigned me = pass[i];
+    if (anc) {  // a candidate of the per-level chain
+      atomicAdd(&s_items[j], 1u);
+      if (me & 1u) atomicAdd(&s_pass[j], 1u);
+      if (me == 3u && (int)j == S - 1) {
+        const unsigned slot = atomicAdd(&s_n, 1u);
+        if (slot < SPEC_STAGE) s_q[slot] = spec_cube(j, k);
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned n = s_n;
+  if (threadIdx.x == 0) {
+    s_base = n ? atomicAdd(&ctr->n_level[top - (S - 1)], (unsigned long long)n) : 0ull;
+    for (int j = 0; j < S && j < 8; j++) {
+      const int level = top - j;
+      const bool tested = level >= 3 && ((test_mask >> level) & 1u) != 0u;
+      if (s_items[j] && tested) atomicAdd(&ctr->n_items[level], (unsigned long long)s_items[j]);
+      if (s_pass[j]) atomicAdd(&ctr->n_pass[level], (unsigned long long)s_pass[j]);
+    }
+    if (n > SPEC_STAGE) ctr->q_overflow = 1ull;  // cannot happen: the host sizes the grid so that a slice is at most SPEC_STAGE cubes
+  }
+  __syncthreads();
+  const unsigned long long fb = s_base;
+  if (fb + n <= out_cap) {
+    for (unsigned q = threadIdx.x; q < n && q < SPEC_STAGE; q += BLOCK) out[fb + q] = s_q[q];
   } else if (threadIdx.x == 0) {
     ctr->q_overflow = 1ull;
   }

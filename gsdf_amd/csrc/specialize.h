@@ -23,5 +23,10 @@ bool spec_compile(const Program& p, const std::string& arch, const std::vector<s
 // "hipcc" (out-of-process build with the installed compiler), "hiprtc" (the process's run-time compiler) or "cache": how
 // the calling thread's last successful spec_compile got its code object.
 const char* spec_last_compiler();
+// Key of the last spec_compile of this thread (hash of generated source, device headers, options, compiler identity), and of
+// the ahead-of-time kernels of this library (hash of its device sources): what a stored profile must match to describe the code
+// that runs now.
+const char* spec_last_key();
+std::string spec_library_key();
 
 }  // namespace gsdf_dev

@@ -21,13 +21,20 @@ ErrMismatchBufferLength = "position and distance buffer length mismatch"
 
 # every symbol include/gsdf_hip.h declares
 SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "gsdf_hip_program_destroy",
-           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_lower_region", "gsdf_hip_eval3_submit", "gsdf_hip_eval_wait", "gsdf_hip_host_alloc", "gsdf_hip_host_register", "gsdf_hip_host_release", "gsdf_hip_comm_unique_id", "gsdf_hip_comm_create", "gsdf_hip_comm_rank", "gsdf_hip_comm_world", "gsdf_hip_comm_allreduce_sum_u64", "gsdf_hip_mesh_gatherv", "gsdf_hip_comm_destroy", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_selftest_circ", "gsdf_hip_blockcache_create", "gsdf_hip_blockcache_reset", "gsdf_hip_blockcache_eval3", "gsdf_hip_blockcache_hits", "gsdf_hip_blockcache_evaluations", "gsdf_hip_blockcache_destroy", "gsdf_hip_program_specialize", "gsdf_hip_program_is_specialized", "gsdf_hip_program_kernels", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
+           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_lower_region", "gsdf_hip_eval3_submit", "gsdf_hip_eval_wait", "gsdf_hip_host_alloc", "gsdf_hip_host_register", "gsdf_hip_host_release", "gsdf_hip_comm_unique_id", "gsdf_hip_comm_create", "gsdf_hip_comm_rank", "gsdf_hip_comm_world", "gsdf_hip_comm_allreduce_sum_u64", "gsdf_hip_mesh_gatherv", "gsdf_hip_mesh_gatherv_start", "gsdf_hip_mesh_gatherv_wait", "gsdf_hip_comm_destroy", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_selftest_circ", "gsdf_hip_blockcache_create", "gsdf_hip_blockcache_reset", "gsdf_hip_blockcache_eval3", "gsdf_hip_blockcache_hits", "gsdf_hip_blockcache_evaluations", "gsdf_hip_blockcache_destroy", "gsdf_hip_program_specialize", "gsdf_hip_program_is_specialized", "gsdf_hip_program_kernels", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
            "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3", "gsdf_hip_image2",
            "gsdf_hip_mesh_octree", "gsdf_hip_mesh_dualcontour", "gsdf_hip_mesh_flat", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
            "gsdf_hip_mesh_stl", "gsdf_hip_mesh_host_tris", "gsdf_hip_mesh_host_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner", "gsdf_hip_slab_range"]
 
 
 PRUNE_ASSUME_SDF = 1 << 30  # gsdf_hip.h: GSDF_PRUNE_ASSUME_SDF
+
+
+GATHER_ALL, GATHER_ROOT, GATHER_NONE = 0, 1, 2  # gsdf_hip.h
+
+
+class GatherStats(C.Structure):
+    _fields_ = [("ms_counts", C.c_double), ("ms_payload", C.c_double), ("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64)]
 
 
 class MeshOpts(C.Structure):
@@ -73,6 +80,8 @@ def lib():
         L.gsdf_hip_comm_world.argtypes = [C.c_void_p]
         L.gsdf_hip_comm_allreduce_sum_u64.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]
         L.gsdf_hip_mesh_gatherv.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.gsdf_hip_mesh_gatherv_start.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.gsdf_hip_mesh_gatherv_wait.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(GatherStats)]
         L.gsdf_hip_comm_destroy.argtypes = [C.c_void_p]
         L.gsdf_hip_eval3_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
         L.gsdf_hip_eval_wait.argtypes = [C.c_void_p, C.c_int]
@@ -183,8 +192,8 @@ class SDFHIP:
         _check(lib().gsdf_hip_program_info(self._h, C.byref(a), C.byref(b)))
         t = C.c_double()
         sp = lib().gsdf_hip_program_is_specialized(self._h, C.byref(t))
-        buf = C.create_string_buffer(256)
-        _check(lib().gsdf_hip_program_kernels(self._h, buf, 256))
+        buf = C.create_string_buffer(512)
+        _check(lib().gsdf_hip_program_kernels(self._h, buf, 512))
         kern = dict(kv.split("=") for kv in buf.value.decode().split())
         return {"code_words": a.value, "lds_slots": b.value, "specialized": bool(sp), "specialize_s": t.value, "kernels": kern}
 
@@ -462,6 +471,47 @@ def _gatherv(self, comm):
 
 
 OctreeHIP.gatherv = _gatherv
+
+
+class PendingGather:
+    """A gather whose payload is moving (gsdf_hip_mesh_gatherv_start): wait() returns (GatheredMeshHIP or None, counts,
+    GatherStats). Keeps the source renderer alive until then."""
+
+    def __init__(self, src, comm, handle):
+        self._src, self._comm, self._h = src, comm, handle
+
+    def wait(self):
+        out = C.c_void_p()
+        counts = (C.c_uint64 * self._comm.world)()
+        gs = GatherStats()
+        h, self._h = self._h, None
+        _check(lib().gsdf_hip_mesh_gatherv_wait(h, C.byref(out), counts, C.byref(gs)))
+        self._src = None
+        g = None
+        if out.value:
+            st = MeshStats()
+            _check(lib().gsdf_hip_mesh_stats_get(out, C.byref(st)))
+            g = GatheredMeshHIP(out, [int(c) for c in counts], st)
+        return g, [int(c) for c in counts], gs
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().gsdf_hip_mesh_gatherv_wait(self._h, None, None, None)
+                self._h = None
+        except Exception:
+            pass
+
+
+def _gatherv_start(self, comm, mode=GATHER_ALL, root=0):
+    """Collective. Exchanges the counts, enqueues the payload (ALL: everyone gets everything, ROOT: only `root`, NONE: counts
+    only) and returns a PendingGather; mesh the next part, then .wait()."""
+    h = C.c_void_p()
+    _check(lib().gsdf_hip_mesh_gatherv_start(self._mesh, comm._h, int(mode), int(root), C.byref(h)))
+    return PendingGather(self, comm, h)
+
+
+OctreeHIP.gatherv_start = _gatherv_start
 
 
 class DualContourHIP(OctreeHIP):

@@ -85,8 +85,10 @@ int gsdf_hip_selftest_circ(float ncirc, uint64_t* mismatches, uint64_t* fast_pat
 int gsdf_hip_program_specialize(gsdf_program* p);
 int gsdf_hip_program_is_specialized(const gsdf_program* p, double* compile_seconds);
 /* Names of the kernels this handle launches, as a profiler shows them: "eval=eval_kernel<3,4,4>:specialised
- * leaf=leaf_eval_kernel<4,4>:specialised prune=prune_kernel:specialised compiler=hipcc" (":interpreter" = the ahead-of-time
- * kernels; compiler = what built the specialised ones: the installed hipcc out of process, or the process's hiprtc). */
+ * leaf=leaf_eval_kernel<4,4>:specialised prune=prune_kernel:specialised compiler=hipcc code=<32 hex digits>" (":interpreter" =
+ * the ahead-of-time kernels; compiler = what built the specialised ones: the installed hipcc out of process, or the process's
+ * hiprtc; code = key of the code that runs: generated source + device headers + options + compiler identity for specialised
+ * kernels, the library's device sources otherwise -- a stored profile describes this handle only if it carries the same key). */
 int gsdf_hip_program_kernels(const gsdf_program* p, char* dst, size_t dst_cap);
 /* Host-only (run without a GPU): text of the generated evaluator, and a gfx950 hiprtc build of the specialised kernels
  * that stops before loading them. dst may be NULL to query the length. */
@@ -256,6 +258,27 @@ int gsdf_hip_comm_world(const gsdf_comm* c);
 int gsdf_hip_comm_allreduce_sum_u64(gsdf_comm* c, uint64_t* vals, size_t n);
 /* counts (optional): world entries, triangles contributed by each rank. */
 int gsdf_hip_mesh_gatherv(const gsdf_mesh* m, gsdf_comm* c, gsdf_mesh** out, uint64_t* counts);
+/* The same with a choice of who receives, and in two halves so that the payload can move while the caller meshes its next
+ * part. Every rank of an all-gather INGESTS (world-1)/world of the whole mesh over its xGMI links -- 214 MB of npt-flange's
+ * 245 MB at resdiv 1600 on 8 GPUs, several times what one rank takes to mesh its eighth -- so the gather, not the meshing,
+ * bounds a step that ends in one (DESIGN.md section 7 has the numbers):
+ *   GSDF_GATHER_ALL   every rank gets everything (grouped ncclBroadcast's);
+ *   GSDF_GATHER_ROOT  only `root` does (grouped ncclSend / ncclRecv; the other ranks' links carry their own shard only);
+ *   GSDF_GATHER_NONE  counts only: every rank keeps its shard where it is.
+ * _start: collective; returns when the counts are exchanged and the payload is enqueued on the communicator's own stream
+ * (`m` must stay alive until _wait). _wait: blocks until the payload has arrived; *out = the gathered mesh (NULL on ranks that
+ * receive nothing), counts[world], st (all optional). */
+enum { GSDF_GATHER_ALL = 0, GSDF_GATHER_ROOT = 1, GSDF_GATHER_NONE = 2 };
+typedef struct gsdf_gather gsdf_gather;
+typedef struct gsdf_gather_stats {
+  double ms_counts;         /* the counts exchange (ncclAllGather of one u64 + readback), HIP events on the communicator's stream */
+  double ms_payload;        /* the triangle payload, first byte enqueued to last byte arrived */
+  uint64_t bytes_sent;      /* of this rank's own triangles */
+  uint64_t bytes_received;  /* of the other ranks' triangles */
+} gsdf_gather_stats;
+GSDF_ABI_ASSERT(sizeof(gsdf_gather_stats) == 32, "gsdf_gather_stats is 32 bytes");
+int gsdf_hip_mesh_gatherv_start(const gsdf_mesh* m, gsdf_comm* c, int mode, int root, gsdf_gather** pending);
+int gsdf_hip_mesh_gatherv_wait(gsdf_gather* pending, gsdf_mesh** out, uint64_t* counts, gsdf_gather_stats* st);
 void gsdf_hip_comm_destroy(gsdf_comm* c);
 
 /* Host-only helper (runs without a GPU): owner rank of octree brick (x,y,z) under the multi-GPU partition

@@ -25,7 +25,7 @@ b = json.loads(open(out + "/bench.json").read().strip().splitlines()[-1])
 ev = b["evals_per_step"] - 0  # leaf + prune evaluations; prune share is < 1 %
 kms = b["roofline"]["kernel_ms"]
 s = subprocess.check_output([sys.executable, "tools/pmc_summarize.py", out, "--evals-per-launch", str(ev), "--kernel-ms", str(kms),
-                             "--workload", b["config"]["workload"]])
+                             "--workload", b["config"]["workload"], "--code", b["config"].get("code") or ""])
 open(out + "/pmc_summary.json", "wb").write(s)
 print(s.decode()[:1500])
 PY

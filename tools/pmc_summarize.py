@@ -15,6 +15,7 @@ ap.add_argument("dir")
 ap.add_argument("--evals-per-launch", type=float, default=0)
 ap.add_argument("--kernel-ms", type=float, default=0)
 ap.add_argument("--workload", default="")
+ap.add_argument("--code", default="", help="config.code of the bench line: the key of the kernels that were profiled")
 ap.add_argument("--command", default="python bench.py --steps 5 --warmup 1 --no-cpu-baseline")
 a = ap.parse_args()
 
@@ -31,7 +32,7 @@ for f in glob.glob(os.path.join(a.dir, "**", "*counter_collection.csv"), recursi
         acc[k][name][0] += v
         acc[k][name][1] += 1
 out = {"command": "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- " + a.command,
-       "note": "separate --pmc passes; values are averages per dispatch", "workload": a.workload}
+       "note": "separate --pmc passes; values are averages per dispatch", "workload": a.workload, "code": a.code}
 for k in KERNELS:
     if not acc[k]:
         continue
