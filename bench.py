@@ -290,7 +290,19 @@ def main():
             torch_gather = True
 
     bld = Builder()
-    shader = bld.NewSphere(1.0) if args.scene == "sphere" else bld.Scene(args.scene)
+    if args.scene == "sphere":
+        shader = bld.NewSphere(1.0)
+    elif args.scene == "text-plate":
+        # BASELINE configs[4]'s tree from the reference's own font (forge/textsdf mirror over tests/golden/iso-3098.ttf, the data
+        # file forge/textsdf/embed.go embeds): TextLine -> Extrude -> Union with a base plate (examples/ui-text/uitext.go:30-42)
+        ttf = open(os.path.join(ROOT, "tests", "golden", "iso-3098.ttf"), "rb").read()
+        t2 = bld.TextLine(ttf, "gsdf MI355X")
+        tb = t2.Bounds()
+        w, h = float(tb[3] - tb[0]), float(tb[4] - tb[1])
+        plate = bld.Translate(bld.NewBox(w + 0.3, h + 0.3, 0.06, 0.01), float(tb[0] + tb[3]) / 2, float(tb[1] + tb[4]) / 2, -0.08)
+        shader = bld.Union(bld.Extrude(t2, 0.12), plate)
+    else:
+        shader = bld.Scene(args.scene)
     res = np.float32(float(shader.Diagonal()) / args.resdiv)
     sdf = hip.SDF3HIP(shader)
     spec_note = "interpreter kernels"

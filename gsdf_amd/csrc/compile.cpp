@@ -337,7 +337,8 @@ bool lower_region(Ctx& c, uint32_t i, Region& out, int depth = 0, bool* solid = 
     }
     case GSDF_SCALE: case GSDF_SCALE2D: {  // f(p) = s * g(p / s): LB_f(p) = s * LB_g(p / s) = LB of the scaled region
       if (n.nchild != 1 || !(P[0] > 0) || !child_region(0, out)) return false;
-      for (int j = 0; j < (out.kind == Region::BOX ? 6 : 5); j++) out.b[j] *= P[0];
+      for (int j = 0; j < (out.kind == Region::BOX ? 6 : 5); j++)
+        if (std::fabs(out.b[j]) < 3.0e38f) out.b[j] *= P[0];  // (not the +-3e38 "unbounded" sentinels of 2-D regions)
       if (out.kind == Region::ZCYL) out.b[6] *= P[0];
       return true;
     }
@@ -366,9 +367,13 @@ bool lower_region(Ctx& c, uint32_t i, Region& out, int depth = 0, bool* solid = 
         const double lx = (double)lr.b[0] - b[0], ly = (double)lr.b[1] - b[1];
         out = lr;
         out.b[0] = (float)(A[0][0] * lx + A[1][0] * ly); out.b[1] = (float)(A[0][1] * lx + A[1][1] * ly);
-        double ext = std::fabs((double)out.b[0]) + std::fabs((double)out.b[1]) + std::fabs((double)lr.b[2]) + std::fabs((double)lr.b[3]) + std::fabs((double)lr.b[4]) + std::fabs((double)b[2]);
+        // (a 2-D region's z range is the sentinel +-3e38 = "unbounded": it is neither part of the padding nor moved)
+        const bool zfree = lr.b[3] <= -3.0e38f && lr.b[4] >= 3.0e38f;
+        double ext = std::fabs((double)out.b[0]) + std::fabs((double)out.b[1]) + std::fabs((double)lr.b[2]) + std::fabs((double)b[2]);
+        if (!zfree) ext += std::fabs((double)lr.b[3]) + std::fabs((double)lr.b[4]);
         const float pad = (float)(ext * 4e-5 + 1e-30);
-        out.b[2] += pad; out.b[3] = lr.b[3] - b[2] - pad; out.b[4] = lr.b[4] - b[2] + pad;
+        out.b[2] += pad;
+        if (!zfree) { out.b[3] = lr.b[3] - b[2] - pad; out.b[4] = lr.b[4] - b[2] + pad; }
         out.b[6] = std::fmax(0.f, lr.b[6] - pad);
         return true;
       }

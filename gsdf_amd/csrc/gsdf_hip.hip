@@ -48,7 +48,7 @@ struct gsdf_program {
   int device = 0;
   uint32_t* d_code = nullptr;
   hipStream_t stream = nullptr;
-  uint64_t evals = 0;
+  std::atomic<uint64_t> evals{0};  // (atomic: host-buffer calls of several threads and a mesher may count at the same time)
   // staging for the host-buffer API
   void* d_pos = nullptr;
   float* d_dist = nullptr;
@@ -59,7 +59,7 @@ struct gsdf_program {
   // Staging slots of the host-buffer API: pinned, device-mapped position / distance buffers with a stream each, so that
   // several host threads (glrender.FlatRenderer evaluates from numParallel goroutines, flatrenderer.go:120-129) -- or one
   // caller pipelining gsdf_hip_eval3_submit / gsdf_hip_eval_wait -- have calls in flight at the same time.
-  struct Slot { void* h_pos = nullptr; float* h_dist = nullptr; hipStream_t s = nullptr; bool busy = false; float* user_dist = nullptr; size_t n = 0; bool zero_copy = false; };
+  struct Slot { void* h_pos = nullptr; float* h_dist = nullptr; hipStream_t s = nullptr; bool busy = false; bool waiting = false; unsigned gen = 0; float* user_dist = nullptr; size_t n = 0; bool zero_copy = false; };  // gen: bumped at every acquisition; a ticket is slot | gen << 8, so a stale or repeated wait is refused instead of releasing somebody else's call
   static constexpr int kSlots = 4;
   Slot slot[kSlots];
   std::mutex slot_mu;
@@ -749,7 +749,7 @@ static int slot_acquire(gsdf_program* p, int* idx) {
   std::unique_lock<std::mutex> lk(p->slot_mu);
   for (;;) {
     for (int i = 0; i < gsdf_program::kSlots; i++)
-      if (!p->slot[i].busy) { p->slot[i].busy = true; *idx = i; return GSDF_OK; }
+      if (!p->slot[i].busy) { p->slot[i].busy = true; p->slot[i].waiting = false; p->slot[i].gen = (p->slot[i].gen + 1u) & 0x7fffffu; *idx = i; return GSDF_OK; }
     p->slot_cv.wait(lk);
   }
 }
@@ -791,11 +791,18 @@ static int eval_submit(gsdf_program* p, int dim, const void* pos, size_t stride,
   rc = eval_dev(p, dim, dp, stride, (float*)dd, n_pos, sl.s, /*count=*/false);
   if (rc) return bail(rc);
   p->evals_host.fetch_add(n_pos);
-  *ticket = si;
+  *ticket = si | (int)(sl.gen << 8);
   return GSDF_OK;
 }
-static int eval_wait(gsdf_program* p, int ticket) {
-  if (!p || ticket < 0 || ticket >= gsdf_program::kSlots || !p->slot[ticket].busy) return fail(GSDF_ERR_BAD_ARGUMENT, "bad evaluation ticket");
+static int eval_wait(gsdf_program* p, int tk) {
+  const int ticket = tk & 0xff;
+  if (!p || tk < 0 || ticket >= gsdf_program::kSlots) return fail(GSDF_ERR_BAD_ARGUMENT, "bad evaluation ticket");
+  {  // the slot must be in flight for THIS ticket, and nobody else may be waiting on it
+    std::lock_guard<std::mutex> lk(p->slot_mu);
+    gsdf_program::Slot& s0 = p->slot[ticket];
+    if (!s0.busy || s0.waiting || s0.gen != ((unsigned)tk >> 8)) return fail(GSDF_ERR_BAD_ARGUMENT, "bad evaluation ticket (stale, or waited for twice)");
+    s0.waiting = true;
+  }
   gsdf_program::Slot& sl = p->slot[ticket];
   hipError_t e = hipStreamSynchronize(sl.s);
   if (e == hipSuccess && !sl.zero_copy) std::memcpy(sl.user_dist, sl.h_dist, sl.n * sizeof(float));
@@ -1267,7 +1274,9 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
   const float longAxis = fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));
   const int levels = (int)std::ceil((float)std::log2((double)(longAxis / res))) + 1;
   if (levels <= 1) return fail(GSDF_ERR_RESOLUTION, "resolution not fine enough for marching cubes");
-  if (levels > 11) return fail(GSDF_ERR_RESOLUTION, "dual contouring lattice too large: more than 11 octree levels");
+  // the neighbour lookup is a dense int32 index grid over the 2^(levels-1) cube lattice: 4.3 GB at 11 levels, 34 GB at 12 --
+  // what one 288 GB device holds beside the rest of the workspace (13 levels would be 275 GB)
+  if (levels > 12) return fail(GSDF_ERR_RESOLUTION, "dual contouring lattice too large: more than 12 octree levels");
   const int nshift = levels - 1;
   const uint64_t ncell = (uint64_t)1 << (3 * nshift);
   const float ox = mn[0], oy = mn[1], oz = mn[2];

@@ -813,7 +813,11 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
       float dall[8];  // distances of rows 0..7; static shift register
 #pragma unroll
       for (int j = 0; j < 8; j++) dall[j] = 0.f;
+#ifdef GSDF_EXP_UNROLL_PASSES  // developer experiment: both passes of a column brick in one body, so that what depends on x and y alone is computed once
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
       for (unsigned c0 = 0; c0 < 8; c0 += K) {
         P3 pk[K];
         float dk[K];

@@ -149,6 +149,15 @@ def test_screw_and_rotational_regions():
     t = b.Scene("knurled-cylinder").tree()
     rins = [_region(t, i)[1][6] for i in _reachable(t) if OPS[t.nodes[i].op] in ("TWIST", "CIRCARRAY")]
     assert rins and all(8.9 < r < 8.94 for r in rins)
+    # 2-D circular arrays and annuli carry an "unbounded" z range; turned (Rotate2D) or scaled they keep their radii instead of
+    # being padded by it (the pad was 2.4e34, the gate could never fire)
+    r2 = b.Translate2D(b.NewRectangle(1.0, 0.6), 3.0, 0.0)
+    for sh2 in (b.Rotate2D(b.CircularArray2D(r2, 8, 8), 0.4), b.Scale2D(b.CircularArray2D(r2, 8, 8), 1.5),
+                b.Rotate2D(b.Scale2D(b.CircularArray2D(r2, 6, 6), 0.5), -1.1)):
+        t = sh2.tree()
+        k, g = _region(t, int(t.root))
+        assert k == 2 and 1.0 < g[2] < 6.0 and g[6] > 0.5 and g[3] <= -3e38 and g[4] >= 3e38, (k, g)
+        assert check_tree(t, rng, 3000) > 1000
     # a z-cylinder does not survive a rotation about another axis: no claim
     t = b.Rotate(b.Twist(box, 0.3), 0.7, (1, 0, 0)).tree()
     assert _region(t, int(t.root))[0] == 0

@@ -348,13 +348,23 @@ def test_registered_buffers_pipelined_and_concurrent_host_calls(gpu):
             src = (bb[:3] + rng.random((n, 3), np.float32) * (bb[3:] - bb[:3])).astype(np.float32)
             batches.append((src, np.full(n, np.nan, np.float32), ref.Evaluate(src)))
         tickets = [sdf.submit(p_, d_) for p_, d_, _ in batches]
-        assert sorted(tickets) == [0, 1, 2, 3]
+        assert sorted(t & 0xff for t in tickets) == [0, 1, 2, 3]       # a ticket = staging slot | generation << 8
         for k in (2, 0, 3, 1):
             sdf.wait(tickets[k])
             assert _mismatch(batches[k][1], batches[k][2]) == 0
         total += 4 * n
         with pytest.raises(gpu.HipError):
             sdf.wait(tickets[0])                                       # already waited for
+        # a stale ticket must not release (or copy into) the call that has since taken its slot
+        d_new = np.full(n, np.nan, np.float32)
+        t_new = sdf.submit(batches[0][0], d_new)
+        stale = [t for t in tickets if (t & 0xff) == (t_new & 0xff)][0]
+        assert stale != t_new
+        with pytest.raises(gpu.HipError):
+            sdf.wait(stale)
+        sdf.wait(t_new)
+        assert _mismatch(d_new, batches[0][2]) == 0
+        total += n
         with pytest.raises(gpu.HipError):
             sdf.submit(np.zeros((1 << 19, 3), np.float32), np.zeros(1 << 19, np.float32))   # too large for a staging slot
         # concurrent callers

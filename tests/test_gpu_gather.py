@@ -44,6 +44,45 @@ def test_rccl_gatherv_world_size_one(gpu):
         gpu.CommHIP(gpu.CommHIP.unique_id(), 3, 2)                     # rank out of range
 
 
+def test_gather_modes_and_pipelining_world_size_one(gpu):
+    """gsdf_hip_mesh_gatherv_start / _wait: ALL, ROOT (rank 0 copies its own share, nobody else sends) and NONE (counts only) at
+    world size 1, and two gathers in flight while the next mesh is made -- the loop bench.py --gpus N runs."""
+    b = Builder()
+    comm = gpu.CommHIP(gpu.CommHIP.unique_id(), 0, 1)
+    sh = b.Scene("npt-flange")
+    sdf = gpu.SDF3HIP(sh)
+    sdf.specialize()
+    res = np.float32(float(sh.Diagonal()) / 300)
+    want = gpu.OctreeHIP(sdf, res)
+    ref = want.RenderAll().copy()
+    srt = lambda t: t.reshape(-1, 9)[np.lexsort(t.reshape(-1, 9).view(np.uint32).T[::-1])]
+    for mode in (gpu.GATHER_ALL, gpu.GATHER_ROOT):
+        g, counts, gs = want.gatherv_start(comm, mode, 0).wait()
+        assert counts == [want.n_tris()] and g.n_tris() == want.n_tris()
+        assert (g.RenderAll().view(np.uint32) == ref.view(np.uint32)).all()
+        assert gs.bytes_received == 0 and gs.bytes_sent == 0 and gs.ms_payload >= 0 and gs.ms_counts > 0
+    g, counts, gs = want.gatherv_start(comm, gpu.GATHER_NONE, 0).wait()
+    assert g is None and counts == [want.n_tris()]
+    with pytest.raises(gpu.HipError):
+        want.gatherv_start(comm, 7, 0)
+    with pytest.raises(gpu.HipError):
+        want.gatherv_start(comm, gpu.GATHER_ROOT, 3)
+    # pipelined: the payload of mesh i moves while mesh i+1 is made; results identical to the unpipelined ones
+    pend, got = None, []
+    for i in range(4):
+        oc = gpu.OctreeHIP(sdf, res)
+        nxt = oc.gatherv_start(comm, gpu.GATHER_ALL, 0)
+        if pend is not None:
+            got.append(pend.wait()[0])
+        pend = nxt
+    got.append(pend.wait()[0])
+    for g in got:
+        assert g.n_tris() == want.n_tris() and (srt(g.RenderAll()).view(np.uint32) == srt(ref).view(np.uint32)).all()
+    # a pending gather that is dropped without wait() is completed and released by its finaliser
+    gpu.OctreeHIP(sdf, res).gatherv_start(comm, gpu.GATHER_ALL, 0)
+    comm.close()
+
+
 def test_mesh_outlives_its_program(gpu):
     """A mesh owns what it needs to be read: destroying the program handle first (Go finalisers / Python GC run in any
     order) must not break later reads or the on-device STL build."""

@@ -387,6 +387,26 @@ def _text_plate(b, text="gsdf MI355X"):
     return b.Union(t3, plate)
 
 
+def test_dualcontour_twelve_levels(gpu):
+    """The largest lattice dual contouring takes: 12 octree levels, a 2048^3 lattice, a 34 GB int32 index grid (sized for one
+    288 GB device; 11 levels until round 2). Too large for the oracle: the unit sphere at res 2/1500 is checked on its own terms --
+    vertices within a cell of the sphere, quads in pairs of triangles, and the union of three z-slabs bit-identical to the whole."""
+    b = Builder()
+    sdf = gpu.SDF3HIP(b.NewSphere(1.0))
+    res = np.float32(2.0 / 1500)
+    dc = gpu.DualContourHIP(sdf, res)
+    assert dc.stats.levels == 12 and dc.n_tris() > 10_000_000 and dc.n_tris() % 2 == 0
+    t = dc.RenderAll()
+    r = np.linalg.norm(t.reshape(-1, 3).astype(np.float64), axis=1)
+    assert np.abs(r - 1.0).max() < 2 * float(res)
+    whole = _digest(t)
+    del t
+    parts = np.concatenate([gpu.DualContourHIP(sdf, res, shard_rank=k, shard_count=3).RenderAll() for k in range(3)])
+    assert _digest(parts) == whole
+    with pytest.raises(gpu.HipError):
+        gpu.DualContourHIP(sdf, np.float32(2.0 / 2100))                        # 13 levels: refused, not attempted
+
+
 def test_text_plate_from_reference_font(gpu):
     """forge/textsdf (host mirror) -> HIP evaluator / octree mesher / dual contouring, bit-identical to the oracle on
     the same tree, interpreter and specialised kernels. Wide 2-D union of translated glyph polygons (far-child skip)."""
