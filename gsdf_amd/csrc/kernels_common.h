@@ -1,0 +1,67 @@
+// kernels_common.h -- what every kernel file of the MI355X SDF backend shares: the workgroup size, the dynamic LDS block, the
+// octree cube and the mesher's device counters, wave-level append, the multi-GPU brick owner. Device code only (compiled ahead
+// of time by hipcc and at run time for one lowered program, see kernels.h).
+#pragma once
+#include "interp.h"
+#include "mc_tables.h"
+
+using gsdf_dev::code_ptr;
+using gsdf_dev::P3;
+
+#define BLOCK 256
+
+// ---------------------------------------------------------------------------------------------
+// device side
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ code_ptr as_code(const uint32_t* p) { return (code_ptr)(uintptr_t)p; }
+
+extern __shared__ __attribute__((aligned(16))) float g_smem[];
+
+// Octree cube: level-index coordinates (leaf coordinate >> (level-1)).
+struct __attribute__((aligned(8))) Cube {
+  uint16_t x, y, z, w;
+};
+
+#define MAX_LEVELS 24
+struct MeshCounters {
+  unsigned long long n_level[MAX_LEVELS];  // [L]: cubes of level L handed to the next stage (survivors kept by this rank)
+  unsigned long long n_items[MAX_LEVELS];  // [L]: candidate cubes centre-tested at level L (0 if the level was not tested)
+  unsigned long long n_pass[MAX_LEVELS];   // [L]: candidates that passed the prune predicate (before shard filter)
+  unsigned long long n_active;             // leaves passing the corner-0 test
+  unsigned long long pad0[16];             // the triangle append counter gets a cache line (L2 atomic unit) of its own
+  unsigned long long n_tris;
+  unsigned long long pad1[15];
+  unsigned long long overflow;             // triangle buffer overflow flag
+  unsigned long long n_cont;               // leaves whose wave went on to the remaining corners
+  unsigned long long q_overflow;           // cube queue capacity exceeded
+  unsigned long long n_points;             // lattice points evaluated by leaf_brick_kernel
+  unsigned long long n_cut;                // leaves the surface cuts (records written by leaf_eval_kernel)
+};
+
+// wave64 compaction: returns the global slot for lanes with keep=true (others undefined).
+__device__ __forceinline__ unsigned long long wave_append(bool keep, unsigned long long* counter) {
+  const unsigned long long mask = __ballot(keep);
+  const unsigned int lane_prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+  unsigned long long base = 0;
+  if (mask != 0ull) {
+    const int leader = __builtin_ctzll(mask);
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, (unsigned long long)__builtin_popcountll(mask));
+    base = __shfl(base, leader, 64);
+  }
+  return base + lane_prefix;
+}
+
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// Owner rank of a brick for multi-GPU sharding: a pure function of the brick coordinates, so every
+// rank derives the same partition with no communication and no ordering dependence.
+__host__ __device__ __forceinline__ unsigned brick_owner(unsigned x, unsigned y, unsigned z, unsigned count) {
+  unsigned h = (x * 73856093u) ^ (y * 19349663u) ^ (z * 83492791u);
+  h ^= h >> 15;
+  h *= 0x2c1b3c6du;
+  h ^= h >> 12;
+  return h % count;
+}

@@ -1,0 +1,357 @@
+// kernels_dc.h -- dual contouring on device (glrender/dual_contour.go:26-293, dual_contour_vertexplacement.go:26-223).
+#pragma once
+#include "kernels_common.h"
+
+// =================================================================================================
+// Dual contouring on device (glrender/dual_contour.go, dual_contour_vertexplacement.go).
+// The reference keeps a map[i3.Vec]int over a full BFS decomposition; here the lattice is a dense
+// int32 index grid in HBM (levels <= 11 -> <= 4.3 GB, trivial against 288 GB), so neighbour lookups
+// are single loads and every stage is one lane per cube / per active edge.
+// =================================================================================================
+struct DCCounters {
+  unsigned long long n_cubes, n_edges, n_tris, q_overflow, t_overflow;
+  unsigned long long n_origin_evals;  // lattice cells whose origin was actually evaluated (the rest were outside the exact box)
+};
+
+// Stage 1 (Reset :26-83): evaluate every cube origin; keep iff |d| < 2*size (octreePrunea szMult=2, origin).
+template <int K, int W = 3>
+__global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __restrict__ code_g, int nslots, int nshift, float ox, float oy,
+                                                             float oz, float res, int* __restrict__ grid, Cube* __restrict__ cubes,
+                                                             unsigned long long cube_cap, unsigned zlo, unsigned zhi,
+                                                             int use_box, float bx0, float by0, float bz0, float bx1, float by1,
+                                                             float bz1, unsigned tx0, unsigned ty0, unsigned tz0, unsigned ntx,
+                                                             unsigned nty, unsigned ntz, DCCounters* __restrict__ ctr) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  unsigned* s_w = (unsigned*)(g_smem + (size_t)(nslots > 0 ? nslots : 1) * K * BLOCK);  // 4 wave totals
+  unsigned long long* s_base = (unsigned long long*)(s_w + 4);
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // multi-GPU: this rank evaluates the z-slab [zlo, zhi) of the lattice (its own slab plus a one-cube halo).
+  // Work tile = a compact 8 x 8 x 4K brick of cells (a wave = one 8x8 patch at K z-levels), not a K*256-long row:
+  // spatially coherent waves are what lets D_SKIPFAR* drop the far children of a wide union for the whole wave.
+  // The host hands over the range of tiles to sweep: all of the slab, or -- for trees with an exact box -- the tiles
+  // that can hold a kept cube or a neighbour of one (box grown by the keep radius and two cells); cells outside that
+  // range are neither written here nor read by the later stages.
+  const unsigned n = 1u << nshift;
+  const uint64_t ntiles = (uint64_t)ntx * nty * ntz;
+  const float maxDist = res * 2;
+  unsigned long long my_evals = 0;
+  for (uint64_t T = blockIdx.x; T < ntiles; T += gridDim.x) {  // block-uniform trip count
+    const unsigned tx = tx0 + (unsigned)(T % ntx), ty = ty0 + (unsigned)((T / ntx) % nty), tz = tz0 + (unsigned)(T / ((uint64_t)ntx * nty));
+    P3 p[K];
+    float d[K];
+    unsigned cx[K], cy[K], cz[K];
+    bool valid[K];
+#pragma unroll
+    for (int kp = 0; kp < K; kp++) {
+      const unsigned j = (unsigned)kp * BLOCK + threadIdx.x;
+      cx[kp] = tx * 8u + (j & 7u);
+      cy[kp] = ty * 8u + ((j >> 3) & 7u);
+      cz[kp] = zlo + tz * (4u * K) + (j >> 6);
+      valid[kp] = cx[kp] < n && cy[kp] < n && cz[kp] < zhi;
+      p[kp] = P3{ox + res * (float)cx[kp], oy + res * (float)cy[kp], oz + res * (float)cz[kp]};  // CubeOrigin, size = res
+    }
+    // Trees whose field is >= the distance to a known box (use_box): a wave whose cells all lie outside that box by
+    // more than the keep radius needs no evaluation -- |d| >= distance to the box > 2*res decides "not kept" exactly.
+    // (The reference sweeps its cubic lattice unconditionally; a long thin part fills a few percent of it.)
+    bool far = use_box != 0;
+#pragma unroll
+    for (int kp = 0; kp < K; kp++) {
+      const float L = dm::maxf(dm::maxf(dm::maxf(bx0 - p[kp].x, p[kp].x - bx1), dm::maxf(by0 - p[kp].y, p[kp].y - by1)),
+                               dm::maxf(bz0 - p[kp].z, p[kp].z - bz1));
+      far = far && (!valid[kp] || L > maxDist * 1.001f);
+    }
+    if (__all(far)) {
+#pragma unroll
+      for (int kp = 0; kp < K; kp++) d[kp] = 3.0e38f;
+    } else {
+      gsdf_dev::sdf_eval<K, 2>(code, p, d, lds, BLOCK);  // COLUMN mode: the lane's K cells are one x,y column (z = wave + 4 kp)
+#pragma unroll
+      for (int kp = 0; kp < K; kp++) {  // count the lattice cells (tiles overhang the lattice edge)
+        const unsigned long long vm = __ballot(valid[kp]);
+        if (lane == 0) my_evals += (unsigned long long)__builtin_popcountll(vm);
+      }
+    }
+    // Block-wide append: ONE global atomic per workgroup pass (K*256 cells) instead of one per wave and point --
+    // at ~88 atomics/us on a single word the per-wave form was a co-bottleneck for cheap trees (1e9 cells / 64).
+    bool keep[K];
+    unsigned mine = 0;
+#pragma unroll
+    for (int kp = 0; kp < K; kp++) {
+      keep[kp] = valid[kp] && !(dm::absf(d[kp]) >= maxDist);
+      mine += keep[kp] ? 1u : 0u;
+    }
+    unsigned incl = mine;  // wave inclusive scan of per-lane counts
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned v = __shfl_up(incl, off, 64);
+      if (lane >= (unsigned)off) incl += v;
+    }
+    __syncthreads();  // previous pass finished reading s_w / s_base
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    const unsigned w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+    const unsigned total = w0 + w1 + w2 + w3;
+    if (threadIdx.x == 0 && total) *s_base = atomicAdd(&ctr->n_cubes, (unsigned long long)total);
+    __syncthreads();
+    unsigned long long slot = (total ? *s_base : 0ull) + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + (incl - mine);
+#pragma unroll
+    for (int kp = 0; kp < K; kp++) {
+      const uint64_t c = (uint64_t)cx[kp] + ((uint64_t)cy[kp] << nshift) + ((uint64_t)cz[kp] << (2 * nshift));
+      if (keep[kp]) {
+        if (slot < cube_cap) {
+          cubes[slot] = Cube{(uint16_t)cx[kp], (uint16_t)cy[kp], (uint16_t)cz[kp], 0};
+          grid[c] = (int)slot;
+        } else {
+          ctr->q_overflow = 1ull;
+          grid[c] = -1;
+        }
+        slot++;
+      } else if (valid[kp]) {
+        grid[c] = -1;
+      }
+    }
+  }
+  if (lane == 0 && my_evals) atomicAdd(&ctr->n_origin_evals, my_evals);
+}
+
+// Stage 2 (RenderAll :85-108): origin, +x, +y, +z distances of every kept cube (one 4-point pass per
+// lane); default FinalVertex = cube origin; active edges (sign BIT differs, :261-269) are compacted.
+__global__ void __launch_bounds__(BLOCK, 3) dc_edges_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
+                                                            unsigned long long cube_cap, float ox, float oy, float oz, float res,
+                                                            float4* __restrict__ dists, float* __restrict__ fv,
+                                                            unsigned* __restrict__ edges, unsigned long long edge_cap,
+                                                            DCCounters* __restrict__ ctr) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  unsigned long long n = uniform_u64(ctr->n_cubes);
+  if (n > cube_cap) n = cube_cap;
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {
+    const uint64_t i = base + threadIdx.x;
+    const bool valid = i < n;
+    Cube c = {0, 0, 0, 0};
+    if (valid) c = cubes[i];
+    const float x0 = ox + res * (float)c.x, y0 = oy + res * (float)c.y, z0 = oz + res * (float)c.z;
+    P3 p[4] = {{x0, y0, z0}, {x0 + res, y0 + 0.f, z0 + 0.f}, {x0 + 0.f, y0 + res, z0 + 0.f}, {x0 + 0.f, y0 + 0.f, z0 + res}};
+    float d[4];
+    gsdf_dev::sdf_eval<4>(code, p, d, lds, BLOCK);
+    if (valid) {
+      dists[i] = make_float4(d[0], d[1], d[2], d[3]);
+      fv[3 * i] = x0; fv[3 * i + 1] = y0; fv[3 * i + 2] = z0;
+    }
+    const unsigned s0 = __float_as_uint(d[0]) >> 31;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const bool act = valid && ((__float_as_uint(d[1 + a]) >> 31) != s0);
+      const unsigned long long slot = wave_append(act, &ctr->n_edges);
+      if (act) {
+        if (slot < edge_cap) edges[slot] = ((unsigned)i << 2) | (unsigned)a;
+        else ctr->q_overflow = 1ull;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float dc_isect(float o, float e) { return -o / (e - o); }
+
+// Stage 3 (PlaceVertices :28-50 + gleval.NormalsCentralDiff): raw central-difference normals at the
+// linear intersection of every ACTIVE edge (inactive edges' normals are never read by the reference).
+__global__ void __launch_bounds__(BLOCK, 3) dc_normals_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
+                                                              const float4* __restrict__ dists, const unsigned* __restrict__ edges,
+                                                              unsigned long long edge_cap, float ox, float oy, float oz, float res,
+                                                              float h, float* __restrict__ nrm, DCCounters* __restrict__ ctr) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  unsigned long long n = uniform_u64(ctr->n_edges);
+  if (n > edge_cap) n = edge_cap;
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {
+    const uint64_t i = base + threadIdx.x;
+    const bool valid = i < n;
+    float px = 0, py = 0, pz = 0;
+    unsigned e = 0;
+    if (valid) {
+      e = edges[i];
+      const unsigned ci = e >> 2, a = e & 3u;
+      const Cube c = cubes[ci];
+      const float4 d = dists[ci];
+      const float t = res * dc_isect(d.x, a == 0 ? d.y : (a == 1 ? d.z : d.w));
+      px = (ox + res * (float)c.x) + (a == 0 ? t : 0.f);
+      py = (oy + res * (float)c.y) + (a == 1 ? t : 0.f);
+      pz = (oz + res * (float)c.z) + (a == 2 ? t : 0.f);
+    }
+    float out[3];
+#pragma unroll 1
+    for (int dim = 0; dim < 3; dim++) {
+      P3 ab[2] = {{px + (dim == 0 ? h : 0.f), py + (dim == 1 ? h : 0.f), pz + (dim == 2 ? h : 0.f)},
+                  {px - (dim == 0 ? h : 0.f), py - (dim == 1 ? h : 0.f), pz - (dim == 2 ? h : 0.f)}};
+      float dd[2];
+      gsdf_dev::sdf_eval<2>(code, ab, dd, lds, BLOCK);
+      const float v = dd[0] - dd[1];
+      if (dim == 0) out[0] = v; else if (dim == 1) out[1] = v; else out[2] = v;
+    }
+    if (valid) {
+      const size_t o = ((size_t)(e >> 2) * 3 + (e & 3u)) * 3;
+      nrm[o] = out[0]; nrm[o + 1] = out[1]; nrm[o + 2] = out[2];
+    }
+  }
+}
+
+#define DC_ROWS 18  // <= 3 own + 12 contributed (own edges appear again among them) + 3 regularisation rows
+#define DC_BLOCK 64
+// Stage 4 (PlaceVertices :52-141, leastSquaresMGS64 :152-223): per cube, rows = own active edges, then the
+// edges of the (up to 12) contributing cubes in lattice order (z,y,x) and axis order, 3 regularisation rows;
+// float64 modified Gram-Schmidt with the rows staged in LDS ([row][col][lane]; zero rows are exact no-ops).
+__global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restrict__ cubes, unsigned long long cube_cap,
+                                                            const float4* __restrict__ dists, const int* __restrict__ grid,
+                                                            const float* __restrict__ nrm, int nshift, float ox, float oy, float oz,
+                                                            float res, float sqrtLambda, float* __restrict__ fv, unsigned zplace_hi,
+                                                            DCCounters* __restrict__ ctr) {
+  __shared__ double sQ[DC_ROWS][3][DC_BLOCK];
+  __shared__ double sB[DC_ROWS][DC_BLOCK];
+  unsigned long long n = uniform_u64(ctr->n_cubes);
+  if (n > cube_cap) n = cube_cap;
+  const int nn = 1 << nshift;
+  const unsigned t = threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * DC_BLOCK;
+  for (uint64_t base = (uint64_t)blockIdx.x * DC_BLOCK; base < n; base += step) {
+    const uint64_t i = base + t;
+    if (i >= n) continue;  // no block-level sync below: each lane owns column t of the LDS arrays
+    const Cube c = cubes[i];
+    if (c.z >= zplace_hi) continue;  // top halo layer: only its distances/normals are needed
+    const float cox = ox + res * (float)c.x, coy = oy + res * (float)c.y, coz = oz + res * (float)c.z;
+    const float invRes = 1.0f / res;
+    int nr = 0, nnb = 0;
+    float mx = 0.f, my = 0.f, mz = 0.f;
+    auto add_row = [&](float bx, float by, float bz, float nx, float ny, float nz) {
+      const float qx = invRes * (bx - cox), qy = invRes * (by - coy), qz = invRes * (bz - coz);
+      sQ[nr][0][t] = (double)nx; sQ[nr][1][t] = (double)ny; sQ[nr][2][t] = (double)nz;
+      sB[nr][t] = (double)(nx * qx + ny * qy + nz * qz);
+      mx = mx + bx; my = my + by; mz = mz + bz;
+      nr++;
+    };
+    auto edge_row = [&](unsigned ci, int a) {
+      const Cube u = cubes[ci];
+      const float4 d = dists[ci];
+      const float tt = res * dc_isect(d.x, a == 0 ? d.y : (a == 1 ? d.z : d.w));
+      const float ux = ox + res * (float)u.x, uy = oy + res * (float)u.y, uz = oz + res * (float)u.z;
+      const size_t o = ((size_t)ci * 3 + (size_t)a) * 3;
+      add_row(ux + (a == 0 ? tt : 0.f), uy + (a == 1 ? tt : 0.f), uz + (a == 2 ? tt : 0.f), nrm[o], nrm[o + 1], nrm[o + 2]);
+    };
+    // neighbour records first decide whether this cube is placed at all (len(cube.Neighbors) == 0 -> skip)
+    unsigned contrib[12];
+    unsigned char caxis[12];
+    for (int dz = 0; dz < 2; dz++)
+      for (int dy = 0; dy < 2; dy++)
+        for (int dx = 0; dx < 2; dx++) {
+          const int ux = c.x + dx, uy = c.y + dy, uz = c.z + dz;
+          if (ux >= nn || uy >= nn || uz >= nn) continue;
+          const int ui = grid[((size_t)uz * nn + uy) * nn + ux];
+          if (ui < 0) continue;
+          const float4 d = dists[ui];
+          const unsigned s0 = __float_as_uint(d.x) >> 31;
+          if (dx == 0 && ((__float_as_uint(d.y) >> 31) != s0)) { contrib[nnb] = (unsigned)ui; caxis[nnb++] = 0; }
+          if (dy == 0 && ((__float_as_uint(d.z) >> 31) != s0)) { contrib[nnb] = (unsigned)ui; caxis[nnb++] = 1; }
+          if (dz == 0 && ((__float_as_uint(d.w) >> 31) != s0)) { contrib[nnb] = (unsigned)ui; caxis[nnb++] = 2; }
+        }
+    if (nnb == 0) continue;
+    {
+      const float4 d = dists[i];
+      const unsigned s0 = __float_as_uint(d.x) >> 31;
+      if ((__float_as_uint(d.y) >> 31) != s0) edge_row((unsigned)i, 0);
+      if ((__float_as_uint(d.z) >> 31) != s0) edge_row((unsigned)i, 1);
+      if ((__float_as_uint(d.w) >> 31) != s0) edge_row((unsigned)i, 2);
+    }
+    for (int k = 0; k < nnb; k++) edge_row(contrib[k], caxis[k]);
+    const float im = 1.f / (float)nr;
+    const float bsx = invRes * (im * mx - cox), bsy = invRes * (im * my - coy), bsz = invRes * (im * mz - coz);
+    sQ[nr][0][t] = (double)sqrtLambda; sQ[nr][1][t] = 0.0; sQ[nr][2][t] = 0.0; sB[nr][t] = (double)(sqrtLambda * bsx); nr++;
+    sQ[nr][0][t] = 0.0; sQ[nr][1][t] = (double)sqrtLambda; sQ[nr][2][t] = 0.0; sB[nr][t] = (double)(sqrtLambda * bsy); nr++;
+    sQ[nr][0][t] = 0.0; sQ[nr][1][t] = 0.0; sQ[nr][2][t] = (double)sqrtLambda; sB[nr][t] = (double)(sqrtLambda * bsz); nr++;
+    const int K = nr;
+    double R[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int j = 0; j < 3; j++) {
+      for (int ii = 0; ii < j; ii++) {
+        double dot = 0;
+        for (int k = 0; k < K; k++) dot += sQ[k][ii][t] * sQ[k][j][t];
+        R[ii][j] = dot;
+        for (int k = 0; k < K; k++) sQ[k][j][t] -= dot * sQ[k][ii][t];
+      }
+      double nsq = 0;
+      for (int k = 0; k < K; k++) nsq += sQ[k][j][t] * sQ[k][j][t];
+      const double norm = __builtin_sqrt(nsq);
+      R[j][j] = norm;
+      if (norm > 1e-14) {
+        const double inv = 1.0 / norm;
+        for (int k = 0; k < K; k++) sQ[k][j][t] *= inv;
+      }
+    }
+    double Qtb[3] = {0, 0, 0};
+    for (int j = 0; j < 3; j++)
+      for (int k = 0; k < K; k++) Qtb[j] += sQ[k][j][t] * sB[k][t];
+    double x[3];
+    for (int ii = 2; ii >= 0; ii--) {
+      x[ii] = Qtb[ii];
+      for (int k = ii + 1; k < 3; k++) x[ii] -= R[ii][k] * x[k];
+      if (R[ii][ii] > 1e-14) x[ii] /= R[ii][ii];
+      else x[ii] = 0;
+    }
+    const float xf = dm::clampf((float)x[0], -0.1f, 1.1f), yf = dm::clampf((float)x[1], -0.1f, 1.1f), zf = dm::clampf((float)x[2], -0.1f, 1.1f);
+    fv[3 * i] = res * xf + cox; fv[3 * i + 1] = res * yf + coy; fv[3 * i + 2] = res * zf + coz;
+  }
+}
+
+// Stage 5 (RenderAll :143-219): one quad (2 triangles) per active edge whose 4 surrounding cubes exist.
+__global__ void __launch_bounds__(BLOCK) dc_quads_kernel(const Cube* __restrict__ cubes, const float4* __restrict__ dists,
+                                                         const unsigned* __restrict__ edges, unsigned long long edge_cap,
+                                                         const int* __restrict__ grid, const float* __restrict__ fv, int nshift,
+                                                         unsigned zown_lo, unsigned zown_hi, float* __restrict__ tris,
+                                                         unsigned long long tri_cap, DCCounters* __restrict__ ctr) {
+  unsigned long long n = uniform_u64(ctr->n_edges);
+  if (n > edge_cap) n = edge_cap;
+  const int nn = 1 << nshift;
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {
+    const uint64_t i = base + threadIdx.x;
+    bool ok = i < n;
+    int q[4] = {-1, -1, -1, -1};
+    bool flip = false;
+    if (ok) {
+      const unsigned e = edges[i];
+      const unsigned ci = e >> 2, a = e & 3u;
+      const Cube c = cubes[ci];
+      const float4 d = dists[ci];
+      ok = ok && c.z >= zown_lo && c.z < zown_hi;  // quads are emitted by the rank that owns the edge's cube
+      flip = ((a == 0 ? d.y : (a == 1 ? d.z : d.w)) - d.x) < 0.f;
+      // EdgeNeighborsX/Y/Z (:271-287): offsets in cube units
+      const int off[3][4][3] = {{{0, -1, -1}, {0, 0, -1}, {0, 0, 0}, {0, -1, 0}},
+                                {{-1, 0, -1}, {-1, 0, 0}, {0, 0, 0}, {0, 0, -1}},
+                                {{-1, -1, 0}, {0, -1, 0}, {0, 0, 0}, {-1, 0, 0}}};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int x = c.x + off[a][k][0], y = c.y + off[a][k][1], z = c.z + off[a][k][2];
+        int idx = -1;
+        if (x >= 0 && y >= 0 && z >= 0 && x < nn && y < nn && z < nn) idx = grid[((size_t)z * nn + y) * nn + x];
+        q[k] = idx;
+        ok = ok && idx >= 0;
+      }
+    }
+    const unsigned long long slot = wave_append(ok, &ctr->n_tris);
+    if (ok) {
+      if (2 * slot + 2 <= tri_cap) {
+        int o[4] = {q[0], q[1], q[2], q[3]};
+        if (flip) { o[0] = q[3]; o[1] = q[2]; o[2] = q[1]; o[3] = q[0]; }
+        float* dst = tris + 18 * slot;
+        const int order[6] = {0, 1, 2, 2, 3, 0};
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const float* v = fv + 3 * (size_t)o[order[k]];
+          dst[3 * k] = v[0]; dst[3 * k + 1] = v[1]; dst[3 * k + 2] = v[2];
+        }
+      } else {
+        ctr->t_overflow = 1ull;
+      }
+    }
+  }
+}

@@ -1,0 +1,1167 @@
+// kernels_octree.h -- the octree mesher: centre tests of the cube levels (prune_kernel; the speculative top: prune_spec_kernel +
+// prune_resolve_kernel), the leaf phase (leaf_eval_kernel -> cut-leaf records -> march_records_kernel; the fused leaf_kernel and
+// the corner-sharing leaf_brick_kernel) and the marching-cubes emission helpers the flat renderer's kernels use too.
+//   glrender/octreerenderer.go:43-284, glrender/marchcubes.go:14-98
+#pragma once
+#include "kernels_common.h"
+
+// One octree level, chained on the stream with NO host round trip: the candidate count is read from the
+// previous level's survivor counter in device memory. expand=1: item i is child (i&7) of in[i>>3];
+// expand=0: the single top cube. Survivors are compacted block-wide (ballot + mbcnt prefix per wave, 4 wave totals
+// through LDS) into an LDS stage of PRUNE_STAGE cubes and appended to `out` with ONE global atomic per flush: a
+// single counter word takes ~88 atomics/us on MI355X, so the per-wave appends of the first version bounded the two
+// big levels (8940 waves at level 3 = 100 us of a 124 us kernel).
+// The test (do_test = 1): the field's bounds over the cube's bounding ball, by interval evaluation at the centre (interp.h: LIP;
+// two "points" per lane), exclude 0 -- for a true distance field exactly the reference's |d| >= size * sqrt3/2, and still
+// surface-preserving for twists, screws and non-rigid transforms (dev_ops.h: D_LIP_*). do_test = 2: the reference's predicate
+// verbatim on the centre value, whatever the field (gsdf_mesh_opts.prune: GSDF_PRUNE_ASSUME_SDF).
+// LDS: [2 * ncols floats per lane (ncols = program slots + interval stack) | PRUNE_STAGE cubes | 4 wave totals | base].
+#define PRUNE_STAGE 1024
+__global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ in,
+                                                      unsigned long long in_cap, int expand, int level, int ncols, int lip_base, float ox,
+                                                      float oy, float oz, float res,
+                                                      int do_test, Cube* __restrict__ out, unsigned long long out_cap,
+                                                      int shard_here, unsigned shard_rank, unsigned shard_count,
+                                                      MeshCounters* __restrict__ ctr) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  Cube* s_q = (Cube*)(g_smem + (size_t)(ncols > 0 ? ncols : 1) * 2 * BLOCK);
+  unsigned* s_w = (unsigned*)(s_q + PRUNE_STAGE);  // [0..3] wave totals, [4..7] per-wave "passed the test" counts
+  unsigned long long* s_base = (unsigned long long*)(s_w + 8);
+  // the previous level counts every survivor, also those its queue had no room for (the host then grows the queues
+  // and reruns): never read past what was stored
+  unsigned long long n_in = expand ? uniform_u64(ctr->n_level[level + 1]) : 0ull;
+  if (n_in > in_cap) n_in = in_cap;
+  const unsigned long long n_items = expand ? n_in * 8ull : 1ull;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_items[level] = do_test ? n_items : 0ull;
+  const float size = (float)(1 << (level - 1)) * res;  // i3.Cube size at this level
+  const float maxDist = size * (1.73205080757f / 2);    // szDistMult = sqrt3/2 (octreerenderer.go:182)
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long my_pass = 0;
+  unsigned cur = 0;  // cubes staged so far (block-uniform: every thread derives it from the same LDS totals)
+  auto flush = [&]() {  // block-uniform
+    if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_level[level], (unsigned long long)cur);
+    __syncthreads();
+    const unsigned long long fb = *s_base;
+    if (fb + cur <= out_cap) {
+      for (unsigned k = threadIdx.x; k < cur; k += BLOCK) out[fb + k] = s_q[k];
+    } else if (threadIdx.x == 0) {
+      ctr->q_overflow = 1ull;
+    }
+    __syncthreads();
+    cur = 0;
+  };
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_items; base += step) {  // block-uniform trip count
+    const uint64_t i = base + threadIdx.x;
+    const bool valid = i < n_items;
+    Cube c = {0, 0, 0, 0};
+    if (valid && expand) {
+      const Cube pc = in[i >> 3];
+      const unsigned k = (unsigned)(i & 7);
+      // children in corner order: 0:(0,0,0) 1:(+x) 2:(+x,+y) 3:(+y) 4..7 same at +z
+      c.x = (uint16_t)(pc.x * 2 + ((k ^ (k >> 1)) & 1));
+      c.y = (uint16_t)(pc.y * 2 + ((k >> 1) & 1));
+      c.z = (uint16_t)(pc.z * 2 + ((k >> 2) & 1));
+    }
+    bool keep = valid;
+    if (do_test) {
+      const float cx0 = ox + size * (float)c.x, cy0 = oy + size * (float)c.y, cz0 = oz + size * (float)c.z;
+      P3 p;  // CubeCenter = Scale(0.5, Add(min, max)), max = min + size
+      p.x = 0.5f * (cx0 + (cx0 + size));
+      p.y = 0.5f * (cy0 + (cy0 + size));
+      p.z = 0.5f * (cz0 + (cz0 + size));
+      P3 pv[2] = {p, p};
+      float dv[2];
+      if (do_test == 2) {
+        gsdf_dev::sdf_eval<2>(code, pv, dv, lds, BLOCK);
+        keep = valid && !(dm::absf(dv[0]) >= maxDist);
+      } else {
+        gsdf_dev::sdf_eval<2, 0, true>(code, pv, dv, lds, BLOCK, false, maxDist, (uint32_t)lip_base);
+        keep = valid && !(dv[0] >= 0.0f || dv[1] <= 0.0f);
+      }
+    }
+    const unsigned long long pm = __ballot(keep);
+    if (lane == 0) my_pass += (unsigned long long)__builtin_popcountll(pm);
+    if (shard_here) keep = keep && (brick_owner(c.x, c.y, c.z, shard_count) == shard_rank);
+    const unsigned long long km = __ballot(keep);
+    const unsigned lane_prefix = __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
+    if (lane == 0) s_w[wave] = (unsigned)__builtin_popcountll(km);
+    __syncthreads();
+    const unsigned w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+    const unsigned total = w0 + w1 + w2 + w3;
+    const unsigned wpre = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
+    if (cur + total > PRUNE_STAGE) flush();  // total <= 256 always fits afterwards
+    if (keep) s_q[cur + wpre + lane_prefix] = c;
+    cur += total;
+    __syncthreads();  // s_w is rewritten next iteration; s_q complete before a flush reads it
+  }
+  if (cur) flush();
+  // statistics: one atomic per workgroup (the kernel cannot retire before its atomics do: 4 per workgroup on one
+  // word were 46 us of the level-3 launch)
+  if (lane == 0) s_w[4 + wave] = (unsigned)my_pass;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = (unsigned long long)s_w[4] + s_w[5] + s_w[6] + s_w[7];
+    if (t) atomicAdd(&ctr->n_pass[level], t);
+  }
+}
+
+// The top of the octree WITHOUT its chain of dependent launches. A level is centre-tested after its parent level because a
+// dropped cube's children need no test -- an economy that is worth nothing where a level is a few thousand cubes and its launch
+// 10 us of latency (npt-flange at resdiv 1600: 10 levels, 0.1 ms of a 0.7 ms mesh). The first S levels (all the cubes of Levels
+// top .. top-S+1: (8^S - 1) / 7 of them, 299,593 for S = 7 -- 0.2 % of that mesh's evaluations) are therefore tested
+// SPECULATIVELY, every cube of the complete octree at once, in one launch (prune_spec_kernel: a byte per cube), and a second
+// launch keeps the cubes whose ancestors all passed (prune_resolve_kernel: ancestor bytes are independent loads, no
+// level-by-level pass) and compacts the survivors of the last speculative level into the queue the per-level kernels continue
+// from. Same tests on the same centres, so the survivors are exactly the per-level chain's; the counters count the cubes that
+// chain would have tested (candidates: children of survivors), not the speculative ones.
+// Cube number i of the speculative block: level top-j for off(j) <= i < off(j+1), off(j) = (8^j - 1) / 7; k = i - off(j) spells
+// the path from the top cube in base 8, most significant digit first, a digit being the child number in corner order; the
+// parent of (j, k) is (j-1, k >> 3).
+__device__ __forceinline__ unsigned spec_level_of(unsigned i, unsigned& k) {  // j and the number within the level
+  unsigned j = 0, off = 0, n = 1;
+  while (i >= off + n) { off += n; n <<= 3; j++; }  // <= 7 steps
+  k = i - off;
+  return j;
+}
+__device__ __forceinline__ Cube spec_cube(unsigned j, unsigned k) {
+  unsigned x = 0, y = 0, z = 0;
+  for (unsigned d = 0; d < j; d++) {
+    const unsigned c = (k >> (3u * (j - 1u - d))) & 7u;
+    x = 2u * x + ((c ^ (c >> 1)) & 1u);
+    y = 2u * y + ((c >> 1) & 1u);
+    z = 2u * z + ((c >> 2) & 1u);
+  }
+  Cube c = {(uint16_t)x, (uint16_t)y, (uint16_t)z, 0};
+  return c;
+}
+// pass[i]: bit 0 = the cube passed its centre test (or its level is not tested), bit 1 = this rank owns it (multi-GPU: at the
+// level where bricks are dealt to ranks; everywhere else set).
+// LDS: [2 * ncols floats per lane] (interval mode, see prune_kernel).
+__global__ void __launch_bounds__(BLOCK) prune_spec_kernel(const uint32_t* __restrict__ code_g, int top, unsigned n_spec, int ncols,
+                                                           int lip_base, float ox, float oy, float oz, float res, unsigned test_mask,
+                                                           int ptest, int shard_level, unsigned shard_rank, unsigned shard_count,
+                                                           uint8_t* __restrict__ pass) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  (void)ncols;
+  const unsigned step = gridDim.x * BLOCK;
+  for (unsigned base = blockIdx.x * BLOCK; base < n_spec; base += step) {  // block-uniform trip count
+    const unsigned i = base + threadIdx.x;
+    const bool valid = i < n_spec;
+    unsigned k = 0;
+    const unsigned j = spec_level_of(valid ? i : 0u, k);
+    const int level = top - (int)j;
+    const Cube c = spec_cube(j, k);
+    const bool tested = level >= 3 && ((test_mask >> level) & 1u) != 0u;
+    const float size = (float)(1 << (level - 1)) * res;
+    const float maxDist = size * (1.73205080757f / 2);
+    const float cx0 = ox + size * (float)c.x, cy0 = oy + size * (float)c.y, cz0 = oz + size * (float)c.z;
+    P3 p;
+    p.x = 0.5f * (cx0 + (cx0 + size));
+    p.y = 0.5f * (cy0 + (cy0 + size));
+    p.z = 0.5f * (cz0 + (cz0 + size));
+    P3 pv[2] = {p, p};
+    float dv[2];
+    bool keep;
+    if (ptest == 2) {
+      gsdf_dev::sdf_eval<2>(code, pv, dv, lds, BLOCK);
+      keep = !(dm::absf(dv[0]) >= maxDist);
+    } else {
+      gsdf_dev::sdf_eval<2, 0, true>(code, pv, dv, lds, BLOCK, false, maxDist, (uint32_t)lip_base);  // (maxDist differs from lane to lane: fine, it is the lane's own radius)
+      keep = !(dv[0] >= 0.0f || dv[1] <= 0.0f);
+    }
+    if (!tested) keep = true;
+    const bool own = level != shard_level || brick_owner(c.x, c.y, c.z, shard_count) == shard_rank;
+    if (valid) pass[i] = (uint8_t)((keep ? 1u : 0u) | (own ? 2u : 0u));
+  }
+}
+
+// Survivors of the speculative block: cube i lives on iff it and every ancestor passed (and was owned). Every thread walks its
+// own ancestor chain -- up to S independent byte loads from a table that sits in L2 -- so there is no pass per level. The
+// survivors of the LAST speculative level are staged in LDS and appended to `out` with one atomic per workgroup; per level,
+// the candidates the per-level chain would have tested (children of survivors; the top cube itself) and those that passed are
+// added to the counters with one atomic per workgroup and level that saw any.
+#define SPEC_STAGE 2048
+__global__ void __launch_bounds__(BLOCK) prune_resolve_kernel(const uint8_t* __restrict__ pass, int top, int S, unsigned n_spec,
+                                                              unsigned test_mask, Cube* __restrict__ out, unsigned long long out_cap,
+                                                              MeshCounters* __restrict__ ctr) {
+  __shared__ Cube s_q[SPEC_STAGE];
+  __shared__ unsigned s_n, s_items[8], s_pass[8];
+  __shared__ unsigned long long s_base;
+  if (threadIdx.x == 0) s_n = 0;
+  if (threadIdx.x < 8) { s_items[threadIdx.x] = 0; s_pass[threadIdx.x] = 0; }
+  __syncthreads();
+  const unsigned per = (n_spec + gridDim.x - 1) / gridDim.x;  // a contiguous slice per workgroup
+  const unsigned i0 = blockIdx.x * per, i1 = i0 + per < n_spec ? i0 + per : n_spec;
+  for (unsigned base = i0; base < i1; base += BLOCK) {
+    const unsigned i = base + threadIdx.x;
+    if (i >= i1) continue;
+    unsigned k = 0;
+    const unsigned j = spec_level_of(i, k);
+    // ancestors: (j-1, k>>3), (j-2, k>>6) ... ; off(j) = (8^j - 1) / 7
+    unsigned anc = 1u;  // every proper ancestor passed and was owned (no short circuit: the loads are independent)
+    unsigned kk = k, off = i - k;
+    for (unsigned a = j; a > 0; a--) {
+      kk >>= 3;
+      off = (off - 1u) >> 3;  // off(a-1) = (off(a) - 1) / 8
+      anc &= pass[off + kk] == 3u ? 1u : 0u;
+    }
+    const unsigned me = pass[i];
+    if (anc) {  // a candidate of the per-level chain
+      atomicAdd(&s_items[j], 1u);
+      if (me & 1u) atomicAdd(&s_pass[j], 1u);
+      if (me == 3u && (int)j == S - 1) {
+        const unsigned slot = atomicAdd(&s_n, 1u);
+        if (slot < SPEC_STAGE) s_q[slot] = spec_cube(j, k);
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned n = s_n;
+  if (threadIdx.x == 0) {
+    s_base = n ? atomicAdd(&ctr->n_level[top - (S - 1)], (unsigned long long)n) : 0ull;
+    for (int j = 0; j < S && j < 8; j++) {
+      const int level = top - j;
+      const bool tested = level >= 3 && ((test_mask >> level) & 1u) != 0u;
+      if (s_items[j] && tested) atomicAdd(&ctr->n_items[level], (unsigned long long)s_items[j]);
+      if (s_pass[j]) atomicAdd(&ctr->n_pass[level], (unsigned long long)s_pass[j]);
+    }
+    if (n > SPEC_STAGE) ctr->q_overflow = 1ull;  // cannot happen: the host sizes the grid so that a slice is at most SPEC_STAGE cubes
+  }
+  __syncthreads();
+  const unsigned long long fb = s_base;
+  if (fb + n <= out_cap) {
+    for (unsigned q = threadIdx.x; q < n && q < SPEC_STAGE; q += BLOCK) out[fb + q] = s_q[q];
+  } else if (threadIdx.x == 0) {
+    ctr->q_overflow = 1ull;
+  }
+}
+
+// mcInterpolate (marchcubes.go:76-98) with x = 0.
+__device__ __forceinline__ void mc_interp(float ax, float ay, float az, float bx, float by, float bz, float v1, float v2,
+                                          float& rx, float& ry, float& rz) {
+  const float eps = 1e-12f;
+  const bool c1 = dm::absf(0.f - v1) < eps, c2 = dm::absf(0.f - v2) < eps;
+  float t = 0.5f;
+  if (!c1 || !c2) t = (0.f - v1) / (v2 - v1);
+  float x = ax + t * (bx - ax), y = ay + t * (by - ay), z = az + t * (bz - az);
+  if (c1 && !c2) { x = ax; y = ay; z = az; }
+  if (c2 && !c1) { x = bx; y = by; z = bz; }
+  rx = x; ry = y; rz = z;
+}
+
+#define LEAF_MIN_COLS 14  // leaf_kernel's LDS columns per lane: 8 corner distances + 3 origin + 3 for the owner list / cube indices
+#define TRI_STAGE 128  // triangles staged in LDS per workgroup before one coalesced flush (4.5 KB: lets 4 workgroups of a 7-slot program share a CU)
+
+// Marching cubes of one leaf per lane + block-wide triangle emission (shared by both leaf kernels).
+// vslot: the lane's 8 corner distances in its LDS column; index: the 8-bit inside mask (0 = no triangles).
+// Block-uniform control flow: every thread of the workgroup must call this the same number of times.
+template <int STAGE = TRI_STAGE, typename CornerDist>
+__device__ __forceinline__ void mc_emit_block(unsigned index, float x0, float y0, float z0, float x1, float y1, float z1,
+                                              CornerDist vdist, const int8_t* s_tri, float* s_stage, unsigned* s_misc,
+                                              unsigned long long* s_base, float* __restrict__ tris, uint64_t tri_cap,
+                                              MeshCounters* __restrict__ ctr) {
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned nt = 0;
+  {
+    const int8_t* row = s_tri + index * 16;
+    while (nt < 5 && row[3 * nt] >= 0) nt++;
+  }
+  // block exclusive scan of nt: wave scan + 4 wave totals through LDS
+  unsigned incl = nt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned v = __shfl_up(incl, off, 64);
+    if (lane >= (unsigned)off) incl += v;
+  }
+  if (lane == 63) s_misc[wave] = incl;
+  __syncthreads();  // (A)
+  const unsigned w0 = s_misc[0], w1 = s_misc[1], w2 = s_misc[2], w3 = s_misc[3];
+  const unsigned total = w0 + w1 + w2 + w3;
+  const unsigned wpre = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
+  unsigned cur = s_misc[4];
+  const bool direct = total > STAGE;  // block-uniform
+  unsigned long long gbase = 0;
+  if (!direct && cur + total > STAGE) {  // flush the stage first (block-uniform)
+    if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)cur);
+    __syncthreads();
+    const unsigned long long fb = *s_base;
+    if (fb + cur <= tri_cap) {
+      float* dst = tris + fb * 9;
+      for (unsigned k = threadIdx.x; k < cur * 9; k += BLOCK) dst[k] = s_stage[k];
+    } else if (threadIdx.x == 0) {
+      ctr->overflow = 1ull;
+    }
+    __syncthreads();
+    cur = 0;
+  }
+  if (direct) {
+    if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)total);
+    __syncthreads();
+    gbase = *s_base;
+    if (gbase + total > tri_cap) {
+      if (threadIdx.x == 0) ctr->overflow = 1ull;
+      nt = 0;
+    }
+  }
+  if (nt) {
+    const unsigned first = wpre + (incl - nt);
+    float* dst = direct ? (tris + (gbase + first) * 9) : (s_stage + (size_t)(cur + first) * 9);
+    const int8_t* row = s_tri + index * 16;
+    for (unsigned t = 0; t < nt; t++) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int e = row[3 * t + (2 - k)];  // reversed winding (marchcubes.go:64-68)
+        const unsigned a = GSDF_MC_PAIR_A(e), b = GSDF_MC_PAIR_B(e);
+        const float va = vdist(a), vb = vdist(b);
+        const float pax = ((a ^ (a >> 1)) & 1u) ? x1 : x0, pay = ((a >> 1) & 1u) ? y1 : y0, paz = ((a >> 2) & 1u) ? z1 : z0;
+        const float pbx = ((b ^ (b >> 1)) & 1u) ? x1 : x0, pby = ((b >> 1) & 1u) ? y1 : y0, pbz = ((b >> 2) & 1u) ? z1 : z0;
+        float rx, ry, rz;
+        mc_interp(pax, pay, paz, pbx, pby, pbz, va, vb, rx, ry, rz);
+        dst[9 * t + 3 * k + 0] = rx;
+        dst[9 * t + 3 * k + 1] = ry;
+        dst[9 * t + 3 * k + 2] = rz;
+      }
+    }
+  }
+  __syncthreads();  // (B)
+  if (threadIdx.x == 0 && !direct) s_misc[4] = cur + total;
+}
+
+// Final flush of the LDS triangle stage (all threads of the workgroup).
+__device__ __forceinline__ void mc_final_flush(float* s_stage, unsigned* s_misc, unsigned long long* s_base,
+                                               float* __restrict__ tris, uint64_t tri_cap, MeshCounters* __restrict__ ctr) {
+  __syncthreads();
+  const unsigned cur = s_misc[4];
+  if (cur) {
+    if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)cur);
+    __syncthreads();
+    const unsigned long long fb = *s_base;
+    if (fb + cur <= tri_cap) {
+      float* dst = tris + fb * 9;
+      for (unsigned k = threadIdx.x; k < cur * 9; k += BLOCK) dst[k] = s_stage[k];
+    } else if (threadIdx.x == 0) {
+      ctr->overflow = 1ull;
+    }
+  }
+}
+
+
+// Balanced marching-cubes emission of one workgroup pass: ONE TRIANGLE PER LANE instead of one cube per lane.
+// Every lane brings NC cubes (index[c] = 8-bit inside mask; 0 and 255 give no triangles). The block prefix sum of the
+// per-cube triangle counts gives every triangle a slot; the cubes write an owner list (cube id = c*BLOCK + thread,
+// triangle number) into LDS, and lane t builds triangle t from its owner's data: corner(id, 0..7) = corner distances,
+// origin(id, x0, y0, z0) = min corner (max corner = min + res, as Box{origin, origin+size}). With ~1 cube in 5 cut by
+// the surface and up to five triangles per cube, the cube-per-lane loop of mc_emit_block keeps a wave busy for five
+// rounds on behalf of a few lanes; here all lanes work for ceil(total/BLOCK) rounds.
+// Triangles are staged in LDS (`cur` = staged count: block-uniform, held in a register by every thread) and flushed
+// coalesced with ONE append on the global counter per STAGE triangles.
+// Block-uniform control flow: every thread of the workgroup calls this together. Ends with a barrier, so the caller
+// may overwrite whatever corner()/origin() read. LDS: s_owner[5*BLOCK*NC] u16, s_index[BLOCK*NC] u8.
+template <int STAGE>
+__device__ __forceinline__ void mc_stage_flush(float* s_stage, unsigned long long* s_base, unsigned& cur, float* __restrict__ tris,
+                                               uint64_t tri_cap, MeshCounters* __restrict__ ctr) {
+#ifdef GSDF_EXP_NO_FLUSH  // developer experiment: emission without the global append (timing only)
+  __syncthreads();
+  cur = 0;
+  return;
+#endif
+  if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_tris, (unsigned long long)cur);
+  __syncthreads();
+  const unsigned long long fb = *s_base;
+  if (fb + cur <= tri_cap) {
+    float* dst = tris + fb * 9;
+    for (unsigned k = threadIdx.x; k < cur * 9; k += BLOCK) dst[k] = s_stage[k];
+  } else if (threadIdx.x == 0) {
+    ctr->overflow = 1ull;  // the counter keeps counting: the host learns the exact size and reruns
+  }
+  __syncthreads();
+  cur = 0;
+}
+
+template <int NC, int STAGE, typename Corner, typename Origin>
+__device__ __forceinline__ void mc_emit_balanced(const unsigned (&index)[NC], uint16_t* s_owner, uint8_t* s_index, const int8_t* s_tri,
+                                                 float* s_stage, unsigned* s_misc, unsigned long long* s_base, unsigned& cur,
+                                                 float res, Corner corner, Origin origin, float* __restrict__ tris, uint64_t tri_cap,
+                                                 MeshCounters* __restrict__ ctr) {
+  constexpr unsigned ID_BITS = NC == 1 ? 8 : (NC == 2 ? 9 : (NC <= 4 ? 10 : 11));
+  static_assert(NC <= 8, "owner entries are 16 bits: 3 bits of triangle number + 11 bits of cube id");
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned nt[NC], ntl = 0;
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    unsigned n = 0;
+    if (index[c]) {  // row 0 is empty anyway; saves the LDS walk for the common case
+      const int8_t* row = s_tri + index[c] * 16;
+      while (n < 5 && row[3 * n] >= 0) n++;
+    }
+    nt[c] = n;
+    ntl += n;
+  }
+  if (!__syncthreads_or((int)ntl)) return;  // no triangles anywhere in this pass (block-uniform)
+  unsigned incl = ntl;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned u = __shfl_up(incl, off, 64);
+    if (lane >= (unsigned)off) incl += u;
+  }
+  if (lane == 63) s_misc[wave] = incl;
+  __syncthreads();
+  // block-uniform values read back from LDS: pin them to SGPRs (the compiler cannot know they are uniform)
+  const unsigned w0 = __builtin_amdgcn_readfirstlane(s_misc[0]), w1 = __builtin_amdgcn_readfirstlane(s_misc[1]),
+                 w2 = __builtin_amdgcn_readfirstlane(s_misc[2]), w3 = __builtin_amdgcn_readfirstlane(s_misc[3]);
+  const unsigned total = w0 + w1 + w2 + w3;
+  const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+  unsigned first = (wave_u > 0 ? w0 : 0u) + (wave_u > 1 ? w1 : 0u) + (wave_u > 2 ? w2 : 0u) + (incl - ntl);
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    if (nt[c]) {
+      const unsigned id = (unsigned)c * BLOCK + threadIdx.x;
+      s_index[id] = (uint8_t)index[c];
+      for (unsigned k = 0; k < nt[c]; k++) s_owner[first + k] = (uint16_t)(id | (k << ID_BITS));
+      first += nt[c];
+    }
+  }
+  __syncthreads();
+  for (unsigned done = 0; done < total;) {  // block-uniform
+    const unsigned room = STAGE - cur, left = total - done;
+    const unsigned n = left < room ? left : room;
+#ifndef GSDF_EXP_NO_BUILD  // developer experiment: emission without building the triangles (timing only)
+    for (unsigned t = threadIdx.x; t < n; t += BLOCK) {
+      const unsigned o = s_owner[done + t];
+      const unsigned k = o >> ID_BITS, id = o & ((1u << ID_BITS) - 1u);
+      float x0, y0, z0;
+      origin(id, x0, y0, z0);
+      const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;
+      const int8_t* row = s_tri + (unsigned)s_index[id] * 16 + 3 * k;
+      float* dst = s_stage + (size_t)(cur + t) * 9;
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int e = row[2 - j];  // reversed winding (marchcubes.go:64-68)
+        const unsigned ca = GSDF_MC_PAIR_A(e), cb = GSDF_MC_PAIR_B(e);
+        const bool ax = ((ca ^ (ca >> 1)) & 1u) != 0u, ay = ((ca >> 1) & 1u) != 0u, az = ((ca >> 2) & 1u) != 0u;
+        const bool bx = ((cb ^ (cb >> 1)) & 1u) != 0u, by = ((cb >> 1) & 1u) != 0u, bz = ((cb >> 2) & 1u) != 0u;
+        float rx, ry, rz;
+        mc_interp(ax ? x1 : x0, ay ? y1 : y0, az ? z1 : z0, bx ? x1 : x0, by ? y1 : y0, bz ? z1 : z0, corner(id, ca), corner(id, cb),
+                  rx, ry, rz);
+        dst[3 * j + 0] = rx;
+        dst[3 * j + 1] = ry;
+        dst[3 * j + 2] = rz;
+      }
+    }
+#endif
+    cur += n;
+    done += n;
+    __syncthreads();
+    if (cur == STAGE) mc_stage_flush<STAGE>(s_stage, s_base, cur, tris, tri_cap, ctr);
+  }
+}
+
+// Leaf kernel: one lane per leaf cube of every surviving level-lq cube (64 leaves of a level-3 cube
+// = one wave). Corner 0 first; the wave runs the other 7 corners only if some lane passes the
+// reference's |d0| <= 2*sqrt3*res test (marchcubes.go:20-23). Marching cubes reads the triangle
+// table from LDS; triangles are staged in LDS and flushed with ONE global atomic per flush
+// (a single counter word saturates at ~88 atomics/us on MI355X, so per-wave appends do not scale).
+// LDS: [max(nslots*K, LEAF_MIN_COLS) floats per lane | tri table 256x16 i8 | TRI_STAGE*9 floats | 8 words]. The lane's 8 corner
+// distances reuse the interpreter's slot columns: the distances of the earlier passes ride in registers until the
+// last pass has finished with the slots, then all 8 are stored for marching cubes' dynamically indexed reads.
+template <int K, int WAVES>
+__global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
+                                                     unsigned long long cube_cap, int lq, int nslots, float ox, float oy, float oz,
+                                                     float res, float* __restrict__ tris, uint64_t tri_cap,
+                                                     MeshCounters* __restrict__ ctr) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  float* vslot = lds;  // 8 per-lane corner distances, written after the last interpreter pass (aliases the slots)
+  // columns 8..10: the lane's cube origin; columns 11..13 (3 KB, block-shared): owner list + cube indices of the
+  // balanced emission -- all of it aliases slot columns, which are idle between the last evaluation and the barrier
+  // that ends the emission
+  uint16_t* s_owner = (uint16_t*)(g_smem + 11 * BLOCK);  // [5 * BLOCK]
+  uint8_t* s_index = (uint8_t*)(s_owner + 5 * BLOCK);    // [BLOCK]
+  int8_t* s_tri = (int8_t*)(g_smem + (size_t)(nslots * K > LEAF_MIN_COLS ? nslots * K : LEAF_MIN_COLS) * BLOCK);
+  float* s_stage = (float*)(s_tri + 256 * 16);
+  unsigned* s_misc = (unsigned*)(s_stage + TRI_STAGE * 9);  // [0..3] wave sums
+  unsigned long long* s_base = (unsigned long long*)(s_misc + 6);
+  for (int k = threadIdx.x; k < 256 * 16; k += BLOCK) s_tri[k] = GSDF_MC_TRI[k >> 4][k & 15];
+  __syncthreads();
+  unsigned cur = 0;  // triangles in the LDS stage (block-uniform)
+
+  const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
+  const int sh = lq - 1;
+  unsigned long long n_cubes = uniform_u64(ctr->n_level[lq]);  // survivors of the last prune level (device-side count)
+  if (n_cubes > cube_cap) n_cubes = cube_cap;                  // queue overflowed: host reruns with larger queues
+  const uint64_t n_leaves = uniform_u64(n_cubes << (3 * sh));  // wave-uniform: keep it in SGPRs (the clamp above is a per-lane select otherwise)
+  unsigned my_active = 0, my_cont = 0;  // per wave, < 2^32: a workgroup visits at most 2^32 / BLOCK iterations
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_leaves; base += step) {
+    const uint64_t i = base + threadIdx.x;
+    const bool valid = i < n_leaves;
+    Cube lf = {0, 0, 0, 0};
+    if (valid) {
+      const Cube pc = cubes[i >> (3 * sh)];
+      const unsigned l = (unsigned)(i & ((1u << (3 * sh)) - 1u));
+      const unsigned m = (1u << sh) - 1u;
+      lf.x = (uint16_t)((pc.x << sh) + (l & m));
+      lf.y = (uint16_t)((pc.y << sh) + ((l >> sh) & m));
+      lf.z = (uint16_t)((pc.z << sh) + ((l >> (2 * sh)) & m));
+    }
+    const float x0 = ox + res * (float)lf.x, y0 = oy + res * (float)lf.y, z0 = oz + res * (float)lf.z;
+    const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;  // Box max = origin + size
+    // Single interpreter call site, K corners per pass (corner 0 is in the first pass); the wave goes on
+    // to the remaining corners only if some lane passes the reference's corner-0 test.
+    unsigned index = 0;
+    bool pass = false;
+    float dall[8];  // distances in evaluation order; shifted so that the final contents sit at static positions
+#pragma unroll
+    for (int j = 0; j < 8; j++) dall[j] = 0.f;
+#pragma unroll 1
+    for (unsigned c0 = 0; c0 < 8; c0 += K) {
+      P3 pk[K];
+      float dk[K];
+      // Corner order {0,4,1,5 | 3,7,2,6}: consecutive points share x,y and (K = 4) points j, j+2 share z, which is
+      // what the interpreter's PAIRED mode needs to compute hypot/atan2(x,y) and twist sin/cos(z) once per pair.
+#pragma unroll
+      for (int kp = 0; kp < K; kp++) {
+        const unsigned c = (0x62735140u >> (4u * (c0 + kp))) & 7u;
+        pk[kp].x = ((c ^ (c >> 1)) & 1u) ? x1 : x0;
+        pk[kp].y = ((c >> 1) & 1u) ? y1 : y0;
+        pk[kp].z = ((c >> 2) & 1u) ? z1 : z0;
+      }
+      gsdf_dev::sdf_eval<K, true>(code, pk, dk, lds, BLOCK, /*brick=*/sh == 2);  // lq == 3: one wave = one 4x4x4 brick
+#pragma unroll
+      for (int j = 0; j < 8 - K; j++) dall[j] = dall[j + K];  // static shift register: no dynamic register index
+#pragma unroll
+      for (int kp = 0; kp < K; kp++) {
+        const unsigned c = (0x62735140u >> (4u * (c0 + kp))) & 7u;
+        dall[8 - K + kp] = dk[kp];
+        index |= (dk[kp] < 0.f ? 1u : 0u) << c;
+      }
+      if (c0 == 0) {
+        pass = valid && (dm::absf(dk[0]) <= cubeDiag);
+        const unsigned long long pmask = __ballot(pass);
+        if (pmask == 0ull) break;  // wave-uniform
+        const unsigned long long vmask = __ballot(valid);
+        // wave-uniform counters (every lane adds the same scalar): they live in SGPRs, not in four VGPRs
+        my_active += (unsigned)__builtin_popcountll(pmask);
+        my_cont += (unsigned)__builtin_popcountll(vmask);
+      }
+    }
+    if (!pass || index == 255u) index = 0;
+#ifdef GSDF_EXP_NO_EMIT  // developer experiment (GSDF_HIP_SPEC_FLAGS=-DGSDF_EXP_NO_EMIT): evaluation cost alone
+    index = 0;
+#endif
+    // after the last pass dall[j] is the distance of corner order[j] (an early exit leaves index == 0: nothing is read)
+    if (index) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) vslot[((0x62735140u >> (4u * j)) & 7u) * BLOCK] = dall[j];
+      lds[8 * BLOCK] = x0;
+      lds[9 * BLOCK] = y0;
+      lds[10 * BLOCK] = z0;
+    }
+    const unsigned index1[1] = {index};
+    mc_emit_balanced<1, TRI_STAGE>(
+        index1, s_owner, s_index, s_tri, s_stage, s_misc, s_base, cur, res,
+        [&](unsigned id, unsigned cc) { return g_smem[cc * BLOCK + id]; },
+        [&](unsigned id, float& ax, float& ay, float& az) {
+          ax = g_smem[8 * BLOCK + id];
+          ay = g_smem[9 * BLOCK + id];
+          az = g_smem[10 * BLOCK + id];
+        },
+        tris, tri_cap, ctr);
+  }
+  __syncthreads();
+  if (cur) mc_stage_flush<TRI_STAGE>(s_stage, s_base, cur, tris, tri_cap, ctr);
+  // statistics: two atomics per workgroup, not per wave (they share the L2 atomic unit with the triangle appends)
+  __syncthreads();
+  unsigned* s_stat = (unsigned*)s_stage;
+  if ((threadIdx.x & 63u) == 0u) { s_stat[2 * (threadIdx.x >> 6)] = my_active; s_stat[2 * (threadIdx.x >> 6) + 1] = my_cont; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long a = (unsigned long long)s_stat[0] + s_stat[2] + s_stat[4] + s_stat[6];
+    const unsigned long long c = (unsigned long long)s_stat[1] + s_stat[3] + s_stat[5] + s_stat[7];
+    if (c) { atomicAdd(&ctr->n_active, a); atomicAdd(&ctr->n_cont, c); }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Two-kernel leaf phase (default): leaf_eval_kernel evaluates, march_records_kernel builds the triangles.
+//
+// The fused leaf_kernel above spends 45 % of its time in the emission (block scan, owner list, LDS stage, four workgroup
+// barriers per pass and a global append every ~1.4 passes): the four waves of a workgroup stall together at every barrier
+// and at the atomic's round trip, with only 3-4 waves per SIMD to cover for them. Here the evaluating kernel has NO
+// barrier and NO atomic in its loop -- its waves are independent -- and leaves, per 64-leaf block (one wave pass), the leaves
+// the surface cuts as compact records in HBM:
+//     hdr[block]                    = number of records (0..64) | number of triangles << 8
+//     rec[block][r][c], c < 10      = the block's records side by side (r = rank among the wave's cut lanes): 8 corner distances
+//                                     (corner order 0..7), leaf x | y << 16, leaf z | index << 16 (40 B per cut leaf, ~16 % of
+//                                     the leaves). A block holds ~10 records: 420 contiguous bytes -- four cache lines; a
+//                                     column-major block (tried first) spread them over ten lines and made the marching
+//                                     kernel fetch 2.2x the bytes it used.
+// Sized for the worst case (64 records per block: no overflow path); only the cut leaves' lines are ever touched.
+// march_records_kernel then runs marching cubes over the records alone (see there): it needs no append counter, because the
+// evaluating kernel also leaves the triangle count of every block (hdr, bits 8..) and the sums of both counts per group of
+// MARCH_GROUP blocks (psum).
+// Same float operations on the same values as the fused kernel: the leaf origin is recomputed from the stored leaf
+// coordinates by the expression the evaluation used.
+// ---------------------------------------------------------------------------------------------------------------------
+#define REC_WORDS 10            // dwords per record
+#define REC_BLOCK (64 * REC_WORDS)  // dwords per 64-leaf block
+#define MARCH_GROUP 64              // blocks per entry of the group sums (records, triangles) the evaluating kernel accumulates
+
+// UCUBE: lq == 3 (every mesh of three levels or more): the 64 leaves of a wave pass are one level-3 cube.
+// NTLDS: the triangles-per-case table sits in LDS behind the interpreter's columns; false when exactly those 256 bytes would
+// cost a workgroup per CU (the host decides): the counts are then read from the table in global memory. A template argument
+// and not a run-time flag: a select between an LDS and a global load makes the compiler form a flat pointer, and ROCm
+// 7.0-7.2's backend then dies on some trees ("Illegal instruction detected ... V_CMP_NE_U32_e32 0, $src_shared_base").
+template <int K, int WAVES, bool UCUBE = true, bool NTLDS = true>
+__global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
+                                                          unsigned long long cube_cap, int lq, int nslots, float ox, float oy, float oz,
+                                                          float res, uint32_t* __restrict__ hdr, uint32_t* __restrict__ rec,
+                                                          unsigned long long* __restrict__ psum, unsigned long long n_blocks_cap,
+                                                          MeshCounters* __restrict__ ctr) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  // triangles per marching-cubes case, behind the interpreter's columns (256 B)
+  uint8_t* s_nt = (uint8_t*)(g_smem + (size_t)(nslots * K > 8 ? nslots * K : 8) * BLOCK);  // (8 rows at least: the brick's distances)
+  const int sh = lq - 1;
+  // The three loads a wave starts with -- table byte, cube count, first cube -- are issued together (one trip to memory, not
+  // three in a row: a workgroup lives for ~5 passes only). The first cube is read before the count is known: its index is
+  // clamped into the queue, and the pass is skipped below if the count says so.
+  const uint8_t nt0 = NTLDS ? GSDF_MC_NTRI[threadIdx.x] : (uint8_t)0;
+  unsigned long long cw_first = 0ull;
+  if (UCUBE) {
+    uint64_t ci = uniform_u64(((uint64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63u)) >> (3 * sh));
+    if (ci >= cube_cap) ci = cube_cap - 1;
+    cw_first = *(const unsigned long long*)(cubes + ci);
+  }
+  unsigned long long n_cubes = ctr->n_level[lq];  // survivors of the last prune level (device-side count)
+  cw_first = uniform_u64(cw_first);
+  n_cubes = uniform_u64(n_cubes);
+  if (NTLDS) {
+    s_nt[threadIdx.x] = nt0;
+    __syncthreads();
+  }
+  const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
+  if (n_cubes > cube_cap) n_cubes = cube_cap;                  // queue overflowed: host reruns with larger queues
+  const uint64_t n_leaves = uniform_u64(n_cubes << (3 * sh));
+  unsigned my_active = 0, my_cont = 0, my_cut = 0;  // wave-uniform (SGPRs)
+  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+  // UCUBE: the 64 leaves of a wave pass belong to ONE cube (and n_leaves is a multiple of 64), so the cube is a scalar load --
+  // issued one pass ahead: a wave has ~5 passes and the load is a trip to L2/HBM it would otherwise sit out at every start
+  auto cube_word = [&](uint64_t b) -> unsigned long long {
+    const uint64_t li = uniform_u64(b + (threadIdx.x & ~63u));
+    if (li >= n_leaves) return 0ull;
+    return *(const unsigned long long*)(cubes + (li >> (3 * sh)));
+  };
+  unsigned long long cw_next = cw_first;
+  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n_leaves; base += step) {
+    const uint64_t i = base + threadIdx.x;
+    const bool valid = UCUBE ? uniform_u64(base + (threadIdx.x & ~63u)) < n_leaves : i < n_leaves;
+    Cube lf = {0, 0, 0, 0};
+    const unsigned long long cw = cw_next;
+    if (UCUBE) {
+      cw_next = cube_word(base + step);
+      if (!valid) continue;  // wave-uniform: nothing of this pass is read by anyone
+    }
+    if (valid) {
+      Cube pc;
+      if (UCUBE) { pc.x = (uint16_t)cw; pc.y = (uint16_t)(cw >> 16); pc.z = (uint16_t)(cw >> 32); pc.w = 0; }
+      else pc = cubes[i >> (3 * sh)];
+      const unsigned l = (unsigned)(i & ((1u << (3 * sh)) - 1u));
+      const unsigned m = (1u << sh) - 1u;
+      lf.x = (uint16_t)((pc.x << sh) + (l & m));
+      lf.y = (uint16_t)((pc.y << sh) + ((l >> sh) & m));
+      lf.z = (uint16_t)((pc.z << sh) + ((l >> (2 * sh)) & m));
+    }
+    unsigned index = 0;
+    bool pass = false;
+    float dc[8];  // the leaf's corner distances, by corner number
+    if (UCUBE) {
+      // COLUMN BRICK. The 512 evaluations of a brick -- 64 leaves x 8 corners -- are the product of eight x, eight y and eight z
+      // coordinates (leaf i of an axis contributes min_i = origin + res*i and max_i = min_i + res, Box{origin, origin+size}):
+      // the lane is the (x, y) COLUMN (lane & 7, lane >> 3), its points the eight z. All points of a lane enter the evaluator
+      // with the same x, y registers (SHARE = 2), so every subexpression of x and y alone is computed once per lane instead of
+      // once per point -- flagged hypot / atan2 in the interpreter, and in the specialised build whatever the compiler's value
+      // numbering finds (2-D profiles under an extrusion, sector folds of circular arrays, ...). Same points, same operations on
+      // the same values, same bits as one leaf per lane; only the assignment of points to lanes differs. The distances then
+      // change hands through the wave's own (now idle) interpreter columns: leaf (i, j, k) = lane i + 4j + 16k reads corner
+      // (cx, cy, cz) from column (2i + cx, 2j + cy), row 2k + cz.
+      const unsigned lane = threadIdx.x & 63u;
+      const unsigned bx = ((unsigned)(cw & 0xffffu)) << 2, by = ((unsigned)((cw >> 16) & 0xffffu)) << 2, bz = ((unsigned)((cw >> 32) & 0xffffu)) << 2;
+      const float xa = ox + res * (float)(uint16_t)(bx + ((lane & 7u) >> 1)), ya = oy + res * (float)(uint16_t)(by + (lane >> 4));
+      const float px = (lane & 1u) ? xa + res : xa, py = (lane & 8u) ? ya + res : ya;
+      float dall[8];  // distances of rows 0..7; static shift register
+#pragma unroll
+      for (int j = 0; j < 8; j++) dall[j] = 0.f;
+#ifdef GSDF_EXP_UNROLL_PASSES  // developer experiment: both passes of a column brick in one body, so that what depends on x and y alone is computed once
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+      for (unsigned c0 = 0; c0 < 8; c0 += K) {
+        P3 pk[K];
+        float dk[K];
+#pragma unroll
+        for (int kp = 0; kp < K; kp++) {
+          const unsigned r = c0 + kp;  // wave-uniform
+          const float za = oz + res * (float)(uint16_t)(bz + (r >> 1));
+          pk[kp].x = px;
+          pk[kp].y = py;
+          pk[kp].z = (r & 1u) ? za + res : za;
+        }
+        gsdf_dev::sdf_eval<K, 2>(code, pk, dk, lds, BLOCK, /*brick=*/true);
+#pragma unroll
+        for (int j = 0; j < 8 - K; j++) dall[j] = dall[j + K];
+#pragma unroll
+        for (int kp = 0; kp < K; kp++) dall[8 - K + kp] = dk[kp];
+      }
+      float* D = g_smem + (threadIdx.x & ~63u);  // rows of BLOCK floats; this wave's 64 columns of each
+#pragma unroll
+      for (int r = 0; r < 8; r++) D[r * BLOCK + lane] = dall[r];
+      __builtin_amdgcn_wave_barrier();  // (the wave's LDS operations execute in order; this only pins the compiler's schedule)
+      const unsigned li = lane & 3u, lj = (lane >> 2) & 3u, lk = lane >> 4;
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const unsigned cx = (c ^ (c >> 1)) & 1u, cy = (c >> 1) & 1u, cz = (c >> 2) & 1u;
+        dc[c] = D[(2u * lk + cz) * BLOCK + (2u * lj + cy) * 8u + 2u * li + cx];
+        index |= (dc[c] < 0.f ? 1u : 0u) << c;
+      }
+      pass = dm::absf(dc[0]) <= cubeDiag;
+      my_active += (unsigned)__builtin_popcountll(__ballot(pass));
+      my_cont += 64u;
+    } else {
+      const float x0 = ox + res * (float)lf.x, y0 = oy + res * (float)lf.y, z0 = oz + res * (float)lf.z;
+      const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;  // Box max = origin + size
+      float dall[8];  // distances in evaluation order {0,4,1,5,3,7,2,6}; static shift register
+#pragma unroll
+      for (int j = 0; j < 8; j++) dall[j] = 0.f;
+#pragma unroll 1
+      for (unsigned c0 = 0; c0 < 8; c0 += K) {
+        P3 pk[K];
+        float dk[K];
+#pragma unroll
+        for (int kp = 0; kp < K; kp++) {
+          const unsigned c = (0x62735140u >> (4u * (c0 + kp))) & 7u;
+          pk[kp].x = ((c ^ (c >> 1)) & 1u) ? x1 : x0;
+          pk[kp].y = ((c >> 1) & 1u) ? y1 : y0;
+          pk[kp].z = ((c >> 2) & 1u) ? z1 : z0;
+        }
+        gsdf_dev::sdf_eval<K, true>(code, pk, dk, lds, BLOCK, /*brick=*/false);
+#pragma unroll
+        for (int j = 0; j < 8 - K; j++) dall[j] = dall[j + K];
+#pragma unroll
+        for (int kp = 0; kp < K; kp++) {
+          const unsigned c = (0x62735140u >> (4u * (c0 + kp))) & 7u;
+          dall[8 - K + kp] = dk[kp];
+          index |= (dk[kp] < 0.f ? 1u : 0u) << c;
+        }
+        if (c0 == 0) {
+          pass = valid && (dm::absf(dk[0]) <= cubeDiag);
+          const unsigned long long pmask = __ballot(pass);
+          if (pmask == 0ull) break;  // wave-uniform
+          const unsigned long long vmask = __ballot(valid);
+          my_active += (unsigned)__builtin_popcountll(pmask);
+          my_cont += (unsigned)__builtin_popcountll(vmask);
+        }
+      }
+      // dall[j] is the distance of corner order[j], order = {0,4,1,5,3,7,2,6}
+      dc[0] = dall[0]; dc[1] = dall[2]; dc[2] = dall[6]; dc[3] = dall[4]; dc[4] = dall[1]; dc[5] = dall[3]; dc[6] = dall[7]; dc[7] = dall[5];
+    }
+    const bool cut = pass && index != 0u && index != 255u;
+    // compact the cut leaves of this wave's block: rank among the cut lanes, one header word per block
+    const unsigned long long cm = __ballot(cut);
+    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+    const uint64_t blk = uniform_u64((base + (uint64_t)(threadIdx.x & ~63u)) >> 6);  // block = wave pass = 64 consecutive leaves
+    my_cut += (unsigned)__builtin_popcountll(cm);
+    if (blk < n_blocks_cap) {
+      // header word: records | triangles << 8; the same pair is added to the sum of the block's group of MARCH_GROUP
+      // blocks (low / high half of one 64-bit word: a fire-and-forget atomic, one per wave pass the surface cuts), from which
+      // march_records_kernel derives every workgroup's share of the records and its triangles' place in the output
+      unsigned ntri = 0;
+#ifndef GSDF_EXP_NO_NTRI  // developer experiments (GSDF_HIP_SPEC_FLAGS=-DGSDF_EXP_NO_NTRI / _NO_PSUM): what the counts cost (timing only)
+      if (cm != 0ull) {  // wave-uniform
+        unsigned nt = 0u;  // 0..5
+        if (NTLDS) { if (cut) nt = (unsigned)s_nt[index]; }
+        else { if (cut) nt = (unsigned)GSDF_MC_NTRI[index]; }
+        ntri = (unsigned)__builtin_popcountll(__ballot((nt & 1u) != 0u)) + 2u * (unsigned)__builtin_popcountll(__ballot((nt & 2u) != 0u)) +
+               4u * (unsigned)__builtin_popcountll(__ballot((nt & 4u) != 0u));
+      }
+#endif
+      if ((threadIdx.x & 63u) == 0u) {
+        const uint32_t nrec = (uint32_t)__builtin_popcountll(cm);
+        hdr[blk] = nrec | (ntri << 8);
+#ifndef GSDF_EXP_NO_PSUM
+        if (nrec) atomicAdd(&psum[blk / MARCH_GROUP], (unsigned long long)nrec | ((unsigned long long)ntri << 32));
+#endif
+      }
+      if (cut) {
+        uint2* w = (uint2*)(rec + blk * REC_BLOCK + rank * REC_WORDS);  // 40-byte records: 8-byte aligned, five 8-byte stores
+        w[0] = make_uint2(__float_as_uint(dc[0]), __float_as_uint(dc[1]));
+        w[1] = make_uint2(__float_as_uint(dc[2]), __float_as_uint(dc[3]));
+        w[2] = make_uint2(__float_as_uint(dc[4]), __float_as_uint(dc[5]));
+        w[3] = make_uint2(__float_as_uint(dc[6]), __float_as_uint(dc[7]));
+        w[4] = make_uint2((uint32_t)lf.x | ((uint32_t)lf.y << 16), (uint32_t)lf.z | (index << 16));
+      }
+    }
+  }
+  // statistics: three atomics per workgroup
+  unsigned* s_stat = (unsigned*)g_smem;
+  __syncthreads();  // everyone is done with the interpreter columns
+  if ((threadIdx.x & 63u) == 0u) {
+    s_stat[3 * (threadIdx.x >> 6)] = my_active; s_stat[3 * (threadIdx.x >> 6) + 1] = my_cont; s_stat[3 * (threadIdx.x >> 6) + 2] = my_cut;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long a = (unsigned long long)s_stat[0] + s_stat[3] + s_stat[6] + s_stat[9];
+    const unsigned long long c = (unsigned long long)s_stat[1] + s_stat[4] + s_stat[7] + s_stat[10];
+    const unsigned long long u = (unsigned long long)s_stat[2] + s_stat[5] + s_stat[8] + s_stat[11];
+    if (c) { atomicAdd(&ctr->n_active, a); atomicAdd(&ctr->n_cont, c); }
+    if (u) atomicAdd(&ctr->n_cut, u);
+  }
+}
+
+// Inclusive prefix sum over the workgroup (thread order) of a 64-bit value; *total = the workgroup's sum. s_w: 4 words of LDS.
+__device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long v, unsigned long long* s_w, unsigned long long* total) {
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned lo = __shfl_up((unsigned)incl, off, 64), hi = __shfl_up((unsigned)(incl >> 32), off, 64);
+    if (lane >= (unsigned)off) incl += ((unsigned long long)hi << 32) | lo;
+  }
+  __syncthreads();  // s_w may still be read from an earlier call
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  const unsigned long long a = s_w[0], b = s_w[1], c = s_w[2], d = s_w[3];
+  *total = uniform_u64(a + b + c + d);
+  return incl + (wave > 0 ? a : 0ull) + (wave > 1 ? b : 0ull) + (wave > 2 ? c : 0ull);
+}
+
+// Marching cubes over the cut-leaf records. NO atomic, NO staging.
+//  * Where things go: the evaluating kernel left, per group of MARCH_GROUP blocks, the number of records and of triangles
+//    (psum); every workgroup sums those (a few KB from L2), takes an equal share of the RECORDS -- a contiguous range of
+//    blocks, cut at block granularity -- and knows from the same sums where its first triangle goes. Triangles appear in
+//    block order, record order, table order (a pure function of the survivor queue's order).
+//  * Who computes what: records are taken 256 at a time (one per lane, 8 distances + origin into LDS columns); a prefix sum of
+//    their triangle counts gives an owner list (triangle -> record, table row); then ONE OUTPUT VERTEX PER LANE: lane k of a
+//    round computes vertex k % 3 of triangle k / 3 and stores its 12 bytes at out*36 + 12 k -- one store instruction of a wave
+//    is 768 contiguous bytes, nothing is staged, and the rounds of a chunk are independent of each other (no barrier between
+//    them). (One output FLOAT per lane -- 256-byte stores, the edge parameter computed three times -- was slower: 0.127 ms.)
+//  (History: the first version appended LDS stages of 896 triangles through the one counter word, ~88 appends/us: three
+//  workgroups per CU, and a static deal of 256-block passes of which a workgroup got one or two -- it ran for two pass times
+//  with half its slots idle in the second: 0.158 ms. Known offsets + equal shares + a 512-triangle stage: 0.115 ms.)
+// LDS: [11 record columns of BLOCK floats | owner list 5*BLOCK u32 | tri table | prefix BLOCK+1 | misc] = 21.7 KB: 7 workgroups per CU
+__global__ void __launch_bounds__(BLOCK, 7) march_records_kernel(const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ rec,
+                                                              const unsigned long long* __restrict__ psum,
+                                                              unsigned long long n_blocks_cap, int lq, float ox, float oy, float oz,
+                                                              float res, float* __restrict__ tris, uint64_t tri_cap,
+                                                              MeshCounters* __restrict__ ctr) {
+  float* s_col = g_smem;                                       // [BLOCK][11]: 8 distances + origin of the chunk's records (odd stride:
+                                                               // the values of one record, read together by neighbouring lanes, sit in 11 banks)
+  uint32_t* s_own = (uint32_t*)(s_col + 11 * BLOCK);           // [5 * BLOCK] triangle -> table offset (index*16 + 3*number) | record << 12
+  int8_t* s_tri = (int8_t*)(s_own + 5 * BLOCK);
+  unsigned* s_pre = (unsigned*)(s_tri + 256 * 16);             // [BLOCK + 1] exclusive prefix of the pass's record counts
+  unsigned* s_misc = s_pre + BLOCK + 1;                        // [0..3] wave sums of the triangle counts, [4..7] of the record counts
+  unsigned long long* s_u64 = (unsigned long long*)(((uintptr_t)(s_misc + 8) + 7) & ~(uintptr_t)7);  // [0..3] scan, [4..9] found, [10..13] result
+  for (int k = threadIdx.x; k < 256 * 4; k += BLOCK) {  // the table by dwords; a row's spare byte 15 takes its triangle count
+    uint32_t w = ((const uint32_t*)&GSDF_MC_TRI[0][0])[k];
+    if ((k & 3) == 3) w = (w & 0x00ffffffu) | ((uint32_t)GSDF_MC_NTRI[k >> 2] << 24);
+    ((uint32_t*)s_tri)[k] = w;
+  }
+  unsigned long long n_cubes = uniform_u64(ctr->n_level[lq]);
+  const uint64_t n_leaves = n_cubes << (3 * (lq - 1));
+  uint64_t n_blocks = (n_leaves + 63) >> 6;
+  if (n_blocks > n_blocks_cap) n_blocks = n_blocks_cap;  // (the cube queue overflowed: the host reruns)
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+
+  // ---- this workgroup's share of the records, and where its triangles go
+  const uint64_t n_grp = (n_blocks + MARCH_GROUP - 1) / MARCH_GROUP;
+  const uint64_t per = (n_grp + BLOCK - 1) / BLOCK;  // groups per thread (contiguous)
+  uint64_t e0 = (uint64_t)threadIdx.x * per, e1 = e0 + per;
+  if (e0 > n_grp) e0 = n_grp;
+  if (e1 > n_grp) e1 = n_grp;
+  unsigned long long lr = 0, lt = 0;
+#pragma unroll 4
+  for (uint64_t e = e0; e < e1; e++) {
+    const unsigned long long v = psum[e];
+    lr += (unsigned)v;
+    lt += v >> 32;
+  }
+  unsigned long long R, T;
+  const unsigned long long br = block_scan_u64(lr, s_u64, &R) - lr, bt = block_scan_u64(lt, s_u64, &T) - lt;
+  if (R == 0ull) return;  // no surface here (n_tris stays 0)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ctr->n_tris = T;
+    if (T > tri_cap) ctr->overflow = 1ull;  // the host learns the exact size and reruns
+  }
+  if (T > tri_cap) return;
+  const unsigned long long X0 = R * blockIdx.x / gridDim.x, X1 = R * (blockIdx.x + 1ull) / gridDim.x;  // records [X0, X1)
+  if (X0 == X1) return;
+  // the group in which the running record count reaches X (X > 0): found by the one thread whose groups straddle it
+#pragma unroll
+  for (int w = 0; w < 2; w++) {
+    const unsigned long long X = w ? X1 : X0;
+    if (br < X && X <= br + lr) {
+      unsigned long long acc = br, tacc = bt;
+      for (uint64_t e = e0; e < e1; e++) {
+        const unsigned long long v = psum[e];
+        if (acc + (unsigned)v >= X) {
+          s_u64[4 + 3 * w] = e; s_u64[5 + 3 * w] = acc; s_u64[6 + 3 * w] = tacc;
+          break;
+        }
+        acc += (unsigned)v;
+        tacc += v >> 32;
+      }
+    }
+  }
+  __syncthreads();
+  // first block whose exclusive record prefix is >= X, and the triangles before it (waves 0 and 1: X0 and X1)
+  if (wave < 2) {
+    const unsigned long long X = wave ? X1 : X0;
+    unsigned long long B = 0, tb = 0;
+    if (X != 0ull) {
+      const unsigned long long e = s_u64[4 + 3 * wave], acc = s_u64[5 + 3 * wave], tacc = s_u64[6 + 3 * wave];
+      const uint64_t b = e * MARCH_GROUP + lane;
+      const uint32_t h = b < n_blocks ? hdr[b] : 0u;
+      const unsigned nr = h & 255u, ntr = h >> 8;
+      unsigned ir = nr, it = ntr;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned ur = __shfl_up(ir, off, 64), ut = __shfl_up(it, off, 64);
+        if (lane >= (unsigned)off) { ir += ur; it += ut; }
+      }
+      const unsigned long long m = __ballot(acc + (ir - nr) >= X);
+      if (m != 0ull) {
+        const int j = __builtin_ctzll(m);
+        B = e * MARCH_GROUP + (unsigned)j;
+        tb = tacc + (unsigned)__shfl(it - ntr, j, 64);
+      } else {
+        B = (e + 1) * MARCH_GROUP;
+        tb = tacc + (unsigned)__shfl(it, 63, 64);
+      }
+    }
+    if (lane == 0) { s_u64[10 + 2 * wave] = B; s_u64[11 + 2 * wave] = tb; }
+  }
+  __syncthreads();
+  const uint64_t b_begin = uniform_u64(s_u64[10]);
+  uint64_t b_end = uniform_u64(s_u64[12]);
+  if (b_end > n_blocks) b_end = n_blocks;
+  unsigned long long out = uniform_u64(s_u64[11]);
+
+  for (uint64_t b0 = b_begin; b0 < b_end; b0 += BLOCK) {  // block-uniform
+    // exclusive prefix of the record counts of blocks b0 .. b0+255
+    const uint64_t b = b0 + threadIdx.x;
+    const unsigned nr = b < b_end ? (hdr[b] & 255u) : 0u;
+    unsigned incl = nr;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned u = __shfl_up(incl, off, 64);
+      if (lane >= (unsigned)off) incl += u;
+    }
+    if (lane == 63) s_misc[4 + wave] = incl;
+    __syncthreads();
+    const unsigned p0 = s_misc[4], p1 = s_misc[5], p2 = s_misc[6], p3 = s_misc[7];
+    const unsigned wpre = (wave > 0 ? p0 : 0u) + (wave > 1 ? p1 : 0u) + (wave > 2 ? p2 : 0u);
+    s_pre[threadIdx.x] = wpre + incl - nr;
+    const unsigned Rp = __builtin_amdgcn_readfirstlane(p0 + p1 + p2 + p3);  // records of this pass (block-uniform)
+    if (threadIdx.x == 0) s_pre[BLOCK] = Rp;
+    __syncthreads();
+    // One record per lane in chunks of 256. The next chunk's record is fetched into registers BEFORE the current chunk is
+    // marched: a dependent global load is ~2 us.
+    uint32_t rw[REC_WORDS];
+    auto fetch = [&](unsigned q) {
+#pragma unroll
+      for (int c = 0; c < REC_WORDS; c++) rw[c] = 0u;
+      if (q < Rp) {
+        // the block holding record q: largest j with s_pre[j] <= q (blocks without records share their successor's prefix)
+        unsigned lo = 0, hi = BLOCK;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+          const unsigned mid = (lo + hi) >> 1;
+          if (s_pre[mid] <= q) lo = mid; else hi = mid;
+        }
+        struct __attribute__((packed, aligned(8))) Rec { uint32_t w[REC_WORDS]; };  // 40 bytes, 8-byte aligned: wide loads
+#ifdef GSDF_EXP_MARCH_ONE_LINE  // developer experiment: every lane reads the FIRST record of its block (a third of the record traffic)
+        const Rec v = *(const Rec*)(rec + (b0 + lo) * REC_BLOCK);
+#else
+        const Rec v = *(const Rec*)(rec + (b0 + lo) * REC_BLOCK + (q - s_pre[lo]) * REC_WORDS);
+#endif
+#pragma unroll
+        for (int c = 0; c < REC_WORDS; c++) rw[c] = v.w[c];
+      }
+    };
+    fetch(threadIdx.x);
+    for (unsigned q0 = 0; q0 < Rp; q0 += BLOCK) {  // block-uniform
+      const unsigned q = q0 + threadIdx.x;
+      unsigned index = 0;
+      if (q < Rp) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) s_col[threadIdx.x * 11u + c] = __uint_as_float(rw[c]);
+        const uint32_t xy = rw[8], zi = rw[9];
+        index = zi >> 16;
+        // the leaf origin exactly as the evaluating kernel formed it
+        s_col[threadIdx.x * 11u + 8u] = ox + res * (float)(xy & 0xffffu);
+        s_col[threadIdx.x * 11u + 9u] = oy + res * (float)(xy >> 16);
+        s_col[threadIdx.x * 11u + 10u] = oz + res * (float)(zi & 0xffffu);
+      }
+      fetch(q + BLOCK);  // in flight while this chunk is marched
+      // owner list: prefix sum of the records' triangle counts (the table's spare byte holds the row's count)
+      const unsigned nt = index ? (unsigned)s_tri[index * 16 + 15] : 0u;
+      unsigned ti = nt;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned u = __shfl_up(ti, off, 64);
+        if (lane >= (unsigned)off) ti += u;
+      }
+      if (lane == 63) s_misc[wave] = ti;
+      __syncthreads();
+      const unsigned w0 = __builtin_amdgcn_readfirstlane(s_misc[0]), w1 = __builtin_amdgcn_readfirstlane(s_misc[1]),
+                     w2 = __builtin_amdgcn_readfirstlane(s_misc[2]), w3 = __builtin_amdgcn_readfirstlane(s_misc[3]);
+      const unsigned total = w0 + w1 + w2 + w3;
+      const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+      const unsigned first = (wave_u > 0 ? w0 : 0u) + (wave_u > 1 ? w1 : 0u) + (wave_u > 2 ? w2 : 0u) + (ti - nt);
+      for (unsigned k = 0; k < nt; k++) s_own[first + k] = (index * 16u + 3u * k) | (threadIdx.x << 12);
+      __syncthreads();
+      // one output VERTEX per lane: a wave's store is 768 contiguous bytes
+      struct __attribute__((packed, aligned(4))) V3 { float x, y, z; };
+      V3* dst = (V3*)(tris + out * 9);
+      const unsigned n3 = total * 3u;
+#pragma unroll 2
+      for (unsigned k = threadIdx.x; k < n3; k += BLOCK) {
+        const unsigned t = k / 3u, j = k - 3u * t;
+        const uint32_t o = s_own[t];
+        const float* col = s_col + (o >> 12) * 11u;
+        const int e = s_tri[(o & 4095u) + (2u - j)];  // reversed winding (marchcubes.go:64-68)
+        const unsigned ca = GSDF_MC_PAIR_A(e), cb = GSDF_MC_PAIR_B(e);
+        const float x0 = col[8], y0 = col[9], z0 = col[10];
+        const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;  // Box max = origin + size
+        const bool ax = ((ca ^ (ca >> 1)) & 1u) != 0u, ay = ((ca >> 1) & 1u) != 0u, az = ((ca >> 2) & 1u) != 0u;
+        const bool bx = ((cb ^ (cb >> 1)) & 1u) != 0u, by = ((cb >> 1) & 1u) != 0u, bz = ((cb >> 2) & 1u) != 0u;
+        V3 r;
+        mc_interp(ax ? x1 : x0, ay ? y1 : y0, az ? z1 : z0, bx ? x1 : x0, by ? y1 : y0, bz ? z1 : z0, col[ca], col[cb], r.x, r.y, r.z);
+#ifdef GSDF_EXP_MARCH_NO_STORE  // developer experiment (library built with -D...): the kernel without its output stream (timing only)
+        if (r.x == 1.2345678e-30f) dst[k] = r;
+#else
+        dst[k] = r;
+#endif
+      }
+      out += total;
+      __syncthreads();  // the next chunk rewrites the columns, the owner list and s_misc
+    }
+  }
+}
+
+// Leaf kernel with exact corner sharing (level-3 bricks: one wave = one brick of 4x4x4 leaves).
+// The reference evaluates 8 corners per leaf: 512 evaluations per brick. Neighbouring leaves share lattice
+// planes, but the two coordinate expressions of a plane -- A(i) = O + res*i (min corner of leaf i) and
+// B(i) = A(i-1) + res (max corner of leaf i-1) -- are only sometimes the same float (64-73 % of planes at
+// resdiv 1600). Per axis the brick therefore has 5..8 bitwise-distinct coordinates (A0, {B1,A1}, {B2,A2},
+// {B3,A3}, B4 with equal pairs merged); every distinct point is evaluated ONCE (typically ~6x6x6 = 216
+// instead of 512: one 4-points-per-lane pass instead of two) and each leaf corner reads the value of
+// exactly the coordinates the reference would have evaluated, so distances, signs and triangles stay
+// bit-identical.
+// LDS: [nslots*K floats per lane | tri table | triangle stage | misc | 4 x 512 distances | 4 x 24 coordinates].
+template <int K, int WAVES>
+__global__ void __launch_bounds__(BLOCK, WAVES) leaf_brick_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
+                                                                  unsigned long long cube_cap, int nslots, float ox, float oy, float oz,
+                                                                  float res, float* __restrict__ tris, uint64_t tri_cap,
+                                                                  MeshCounters* __restrict__ ctr) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  int8_t* s_tri = (int8_t*)(g_smem + (size_t)(nslots * K) * BLOCK);
+  float* s_stage = (float*)(s_tri + 256 * 16);
+  unsigned* s_misc = (unsigned*)(s_stage + TRI_STAGE * 9);
+  unsigned long long* s_base = (unsigned long long*)(s_misc + 6);
+  float* s_D = (float*)(s_base + 1);
+  float* s_val = s_D + 4 * 512;
+  for (int k = threadIdx.x; k < 256 * 16; k += BLOCK) s_tri[k] = GSDF_MC_TRI[k >> 4][k & 15];
+  if (threadIdx.x == 0) s_misc[4] = 0;
+  __syncthreads();
+
+  const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
+  unsigned long long n_cubes = uniform_u64(ctr->n_level[3]);
+  if (n_cubes > cube_cap) n_cubes = cube_cap;
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* D = s_D + wave * 512;
+  float* val = s_val + wave * 24;
+  const float org[3] = {ox, oy, oz};
+  unsigned long long my_active = 0, my_points = 0;
+  const uint64_t step = (uint64_t)gridDim.x * 4;
+  for (uint64_t base = (uint64_t)blockIdx.x * 4; base < n_cubes; base += step) {  // block-uniform trip count
+    const uint64_t brick = base + wave;
+    const bool bvalid = brick < n_cubes;
+    Cube pc = {0, 0, 0, 0};
+    if (bvalid) pc = cubes[brick];
+    const unsigned pidx[3] = {pc.x, pc.y, pc.z};
+    // per-axis mismatch bits m_p (p = 1..3): plane p has two distinct floats
+    unsigned mb[3], nax[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+      const unsigned i0 = pidx[ax] * 4u;
+      float A[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) A[k] = org[ax] + res * (float)(i0 + k);  // CubeOrigin of leaf i0+k
+      unsigned m = 0;
+#pragma unroll
+      for (int k = 1; k < 4; k++) m |= ((A[k - 1] + res) != A[k] ? 1u : 0u) << (k - 1);
+      mb[ax] = m;
+      nax[ax] = 5u + __builtin_popcount(m);
+    }
+    if (lane < 12) {  // coordinate table: lane (axis, a) writes A_a and B_{a+1} at their distinct-value slots
+      const unsigned ax = lane >> 2, a = lane & 3u;
+      const float Aa = org[ax] + res * (float)(pidx[ax] * 4u + a);
+      const unsigned u = a + __builtin_popcount(mb[ax] & ((1u << a) - 1u));
+      val[ax * 8 + u] = Aa;
+      val[ax * 8 + u + 1] = Aa + res;  // Box max = origin + size
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned nx = nax[0], nxy = nax[0] * nax[1], N = nxy * nax[2];
+    const float inx = 1.0f / (float)nx, inxy = 1.0f / (float)nxy;
+    if (bvalid && lane == 0) my_points += N;
+#pragma unroll 1
+    for (unsigned t0 = 0; t0 < N; t0 += 64 * K) {  // wave-uniform: 1 pass when N <= 256
+      P3 pk[K];
+      float dk[K];
+#pragma unroll
+      for (int kp = 0; kp < K; kp++) {
+        unsigned t = t0 + kp * 64 + lane;
+        if (t >= N) t = N - 1;  // idle slots re-evaluate the last point (result discarded)
+        const unsigned uz = (unsigned)(((float)t + 0.5f) * inxy);
+        const unsigned r = t - uz * nxy;
+        const unsigned uy = (unsigned)(((float)r + 0.5f) * inx);
+        const unsigned ux = r - uy * nx;
+        pk[kp] = P3{val[ux], val[8 + uy], val[16 + uz]};
+      }
+      gsdf_dev::sdf_eval<K>(code, pk, dk, lds, BLOCK);
+#pragma unroll
+      for (int kp = 0; kp < K; kp++) {
+        const unsigned t = t0 + kp * 64 + lane;
+        if (t < N) D[t] = dk[kp];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // this lane's leaf (a,b,c) and its corner 0 index in the distinct-point lattice
+    const unsigned la = lane & 3u, lb = (lane >> 2) & 3u, lc = lane >> 4;
+    const unsigned ux0 = la + __builtin_popcount(mb[0] & ((1u << la) - 1u));
+    const unsigned uy0 = lb + __builtin_popcount(mb[1] & ((1u << lb) - 1u));
+    const unsigned uz0 = lc + __builtin_popcount(mb[2] & ((1u << lc) - 1u));
+    const unsigned tb = ux0 + nx * uy0 + nxy * uz0;
+    auto vdist = [&](unsigned cc) { return D[tb + ((cc ^ (cc >> 1)) & 1u) + nx * ((cc >> 1) & 1u) + nxy * ((cc >> 2) & 1u)]; };
+    const float x0 = val[ux0], x1 = val[ux0 + 1], y0 = val[8 + uy0], y1 = val[8 + uy0 + 1], z0 = val[16 + uz0], z1 = val[16 + uz0 + 1];
+    unsigned index = 0;
+#pragma unroll
+    for (unsigned cc = 0; cc < 8; cc++) index |= (vdist(cc) < 0.f ? 1u : 0u) << cc;
+    const bool pass = bvalid && (dm::absf(vdist(0)) <= cubeDiag);
+    const unsigned long long pmask = __ballot(pass);
+    if (lane == 0) my_active += (unsigned long long)__builtin_popcountll(pmask);
+    if (!pass) index = 0;
+    mc_emit_block(index, x0, y0, z0, x1, y1, z1, vdist, s_tri, s_stage, s_misc, s_base, tris, tri_cap, ctr);
+  }
+  mc_final_flush(s_stage, s_misc, s_base, tris, tri_cap, ctr);
+  if (lane == 0 && my_points) {
+    atomicAdd(&ctr->n_active, my_active);
+    atomicAdd(&ctr->n_points, my_points);
+  }
+}
