@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -230,17 +231,46 @@ void gen(Ctx& c, uint32_t i, int depth);
 //   uniform scaling and plain unions.
 // ---------------------------------------------------------------------------------------------------------------------
 struct Region {
-  enum Kind { NONE = 0, BOX = 1, ZCYL = 2 } kind = NONE;
-  float b[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // BOX: min xyz, max xyz (2-D: z = 0) | ZCYL: cx cy r z0 z1 rs rin
+  enum Kind { NONE = 0, BOX = 1, ZCYL = 2, OBOX = 3 } kind = NONE;
+  float b[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // BOX: min xyz, max xyz (2-D: z = 0) | ZCYL: cx cy r z0 z1 rs rin | OBOX: cx cy c s hx hy z0 z1
+  // OBOX: a box turned about z -- centre (cx, cy), own x axis (c, s), half extents hx, hy, z range; what a rotation about z makes
+  // of a BOX (3-D only). Bound outside: the Chebyshev distance in the box's frame. Everything that cannot keep the orientation
+  // (hulls, mirrors, cylinders) goes through its axis-aligned hull, obox_aabb.
   // ZCYL's rin (0: solid): additionally S(p) >= rs * (rin - rho) for rho < rin at ANY z -- the shape keeps at least rin away
   // from the axis (an annulus: boxes on a circle around the axis; lets a gate fire for points near the axis)
 };
 
+// Axis-aligned hull of a turned box (padded by the rounding of its corners).
+Region obox_aabb(const Region& g) {
+  if (g.kind != Region::OBOX) return g;
+  const double ex = std::fabs((double)g.b[2]) * g.b[4] + std::fabs((double)g.b[3]) * g.b[5], ey = std::fabs((double)g.b[3]) * g.b[4] + std::fabs((double)g.b[2]) * g.b[5];
+  const double pad = (std::fabs((double)g.b[0]) + std::fabs((double)g.b[1]) + ex + ey) * 1e-6 + 1e-30;
+  Region o;
+  o.kind = Region::BOX;
+  o.b[0] = (float)(g.b[0] - ex - pad); o.b[3] = (float)(g.b[0] + ex + pad);
+  o.b[1] = (float)(g.b[1] - ey - pad); o.b[4] = (float)(g.b[1] + ey + pad);
+  o.b[2] = g.b[6]; o.b[5] = g.b[7];
+  return o;
+}
+
 // The z-axis cylinder (about the axis through (cx, cy)) that encloses a region: what survives a rotation about z.
-Region enclose_zcyl(const Region& g, float cx, float cy, bool is2d) {
+Region enclose_zcyl(const Region& gin, float cx, float cy, bool is2d) {
   Region o;
   o.kind = Region::ZCYL;
   o.b[0] = cx; o.b[1] = cy;
+  if (gin.kind == Region::OBOX) {
+    // farthest corner and nearest point of the turned rectangle, in its own frame (the axis at q = R^T (axis - centre))
+    const double dx = (double)cx - gin.b[0], dy = (double)cy - gin.b[1];
+    const double qx = gin.b[2] * dx + gin.b[3] * dy, qy = gin.b[2] * dy - gin.b[3] * dx;
+    const double fx = std::fabs(qx) + gin.b[4], fy = std::fabs(qy) + gin.b[5];
+    const double nx = std::fmax(std::fabs(qx) - gin.b[4], 0.0), ny = std::fmax(std::fabs(qy) - gin.b[5], 0.0);
+    const double ext = std::fabs(dx) + std::fabs(dy) + gin.b[4] + gin.b[5];
+    o.b[2] = (float)(std::sqrt(fx * fx + fy * fy) * (1 + 1e-6) + ext * 4e-6 + 1e-30);
+    o.b[3] = gin.b[6]; o.b[4] = gin.b[7]; o.b[5] = 1.0f;
+    o.b[6] = (float)std::fmax(0.0, std::sqrt(nx * nx + ny * ny) * (1 - 1e-6) - ext * 4e-6 - 1e-30);
+    return o;
+  }
+  const Region& g = gin;
   if (g.kind == Region::BOX) {
     double r = 0;
     for (int k = 0; k < 4; k++) {
@@ -264,8 +294,9 @@ Region enclose_zcyl(const Region& g, float cx, float cy, bool is2d) {
 }
 
 // Smallest region of a common kind holding both (what a minimum of the two fields is bounded by).
-bool hull(const Region& a, const Region& b, bool is2d, Region& o) {
-  if (a.kind == Region::NONE || b.kind == Region::NONE) return false;
+bool hull(const Region& a_in, const Region& b_in, bool is2d, Region& o) {
+  if (a_in.kind == Region::NONE || b_in.kind == Region::NONE) return false;
+  const Region a = obox_aabb(a_in), b = obox_aabb(b_in);
   if (a.kind == Region::BOX && b.kind == Region::BOX) {
     o.kind = Region::BOX;
     for (int j = 0; j < 3; j++) { o.b[j] = std::fmin(a.b[j], b.b[j]); o.b[j + 3] = std::fmax(a.b[j + 3], b.b[j + 3]); }
@@ -285,7 +316,9 @@ bool hull(const Region& a, const Region& b, bool is2d, Region& o) {
 
 // field - d (d >= 0): the region grows by d (ZCYL: radially by d / rs, since the radial term carries the factor rs)
 void inflate(Region& g, float d, bool is2d) {
-  if (g.kind == Region::BOX) {
+  if (g.kind == Region::OBOX) {
+    g.b[4] += d; g.b[5] += d; g.b[6] -= d; g.b[7] += d;
+  } else if (g.kind == Region::BOX) {
     for (int j = 0; j < (is2d ? 2 : 3); j++) { g.b[j] -= d; g.b[j + 3] += d; }
   } else if (g.kind == Region::ZCYL) {
     g.b[2] += d / g.b[5];
@@ -332,11 +365,17 @@ bool lower_region(Ctx& c, uint32_t i, Region& out, int depth = 0, bool* solid = 
       if (n.nchild != 1 || !child_region(0, out)) return false;
       const float tz = n.op == GSDF_TRANSLATE ? P[2] : 0.f;
       if (out.kind == Region::BOX) { out.b[0] += P[0]; out.b[3] += P[0]; out.b[1] += P[1]; out.b[4] += P[1]; out.b[2] += tz; out.b[5] += tz; }
+      else if (out.kind == Region::OBOX) { out.b[0] += P[0]; out.b[1] += P[1]; out.b[6] += tz; out.b[7] += tz; }
       else { out.b[0] += P[0]; out.b[1] += P[1]; out.b[3] += tz; out.b[4] += tz; }
       return true;
     }
     case GSDF_SCALE: case GSDF_SCALE2D: {  // f(p) = s * g(p / s): LB_f(p) = s * LB_g(p / s) = LB of the scaled region
       if (n.nchild != 1 || !(P[0] > 0) || !child_region(0, out)) return false;
+      if (out.kind == Region::OBOX) {
+        out.b[0] *= P[0]; out.b[1] *= P[0];
+        for (int j = 4; j < 8; j++) out.b[j] *= P[0];
+        return true;
+      }
       for (int j = 0; j < (out.kind == Region::BOX ? 6 : 5); j++)
         if (std::fabs(out.b[j]) < 3.0e38f) out.b[j] *= P[0];  // (not the +-3e38 "unbounded" sentinels of 2-D regions)
       if (out.kind == Region::ZCYL) out.b[6] *= P[0];
@@ -377,6 +416,30 @@ bool lower_region(Ctx& c, uint32_t i, Region& out, int depth = 0, bool* solid = 
         out.b[6] = std::fmax(0.f, lr.b[6] - pad);
         return true;
       }
+      const bool about_z = n.op == GSDF_TRANSFORM && std::fabs((double)A[2][2] - 1.0) <= 1e-6 && std::fabs(A[0][2]) <= 1e-6 && std::fabs(A[1][2]) <= 1e-6 &&
+                           std::fabs(A[2][0]) <= 1e-6 && std::fabs(A[2][1]) <= 1e-6;
+      if (about_z && std::fabs((double)A[0][0] * A[0][1]) > 1e-3) {
+        // A rotation about z (not by a multiple of 90 degrees: those stay axis-aligned below) keeps a box a box, turned: world =
+        // A^T (local - b). The local box (or turned box) centre cl, own axis ul -> centre A^T (cl - b), axis A^T ul.
+        double clx, cly, ulx, uly, hx, hy, z0, z1;
+        if (lr.kind == Region::OBOX) { clx = lr.b[0]; cly = lr.b[1]; ulx = lr.b[2]; uly = lr.b[3]; hx = lr.b[4]; hy = lr.b[5]; z0 = lr.b[6]; z1 = lr.b[7]; }
+        else { clx = 0.5 * ((double)lr.b[0] + lr.b[3]); cly = 0.5 * ((double)lr.b[1] + lr.b[4]); ulx = 1; uly = 0; hx = 0.5 * ((double)lr.b[3] - lr.b[0]); hy = 0.5 * ((double)lr.b[4] - lr.b[1]); z0 = lr.b[2]; z1 = lr.b[5]; }
+        const double dx = clx - b[0], dy = cly - b[1];
+        double wx = A[0][0] * dx + A[1][0] * dy, wy = A[0][1] * dx + A[1][1] * dy;
+        double ux = A[0][0] * ulx + A[1][0] * uly, uy = A[0][1] * ulx + A[1][1] * uly;
+        const double un = std::sqrt(ux * ux + uy * uy);
+        if (un > 0.5) {
+          ux /= un; uy /= un;
+          const double ext = std::fabs(wx) + std::fabs(wy) + hx + hy + std::fabs(z0) + std::fabs(z1) + std::fabs((double)b[2]);
+          const double pad = ext * 4e-5 + 1e-30;  // the matrix is orthonormal to 1e-5 only
+          out.kind = Region::OBOX;
+          out.b[0] = (float)wx; out.b[1] = (float)wy; out.b[2] = (float)ux; out.b[3] = (float)uy;
+          out.b[4] = (float)(hx + pad); out.b[5] = (float)(hy + pad);
+          out.b[6] = (float)(z0 - b[2] - pad); out.b[7] = (float)(z1 - b[2] + pad);
+          return true;
+        }
+      }
+      if (lr.kind == Region::OBOX) lr = obox_aabb(lr);
       const float* lb = lr.b;
       float bb[6];
       for (int j = 0; j < 3; j++) { bb[j] = 3.0e38f; bb[j + 3] = -3.0e38f; }
@@ -400,6 +463,7 @@ bool lower_region(Ctx& c, uint32_t i, Region& out, int depth = 0, bool* solid = 
       if (n.nchild != 1 || !child_region(0, out)) return false;
       *solid = false;
       const int bits = (int)P[0];
+      out = obox_aabb(out);
       if (out.kind == Region::ZCYL) {
         if ((bits & 3) && (out.b[0] != 0.f || out.b[1] != 0.f)) out = enclose_zcyl(out, 0.f, 0.f, is2d);
         if (bits & 4) { const float m = std::fmax(std::fabs(out.b[3]), std::fabs(out.b[4])); out.b[3] = -m; out.b[4] = m; }
@@ -496,7 +560,9 @@ bool lower_region(Ctx& c, uint32_t i, Region& out, int depth = 0, bool* solid = 
 // The box form only (Program::exact_bb, D_UBOUND*).
 bool exact_box(Ctx& c, uint32_t i, float bb[6], bool* solid = nullptr) {
   Region g;
-  if (!lower_region(c, i, g, 0, solid) || g.kind != Region::BOX) return false;
+  if (!lower_region(c, i, g, 0, solid)) return false;
+  g = obox_aabb(g);
+  if (g.kind != Region::BOX) return false;
   std::memcpy(bb, g.b, 6 * sizeof(float));
   return true;
 }
@@ -623,6 +689,9 @@ void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int dept
         c.op(is2d ? D_GATE2D : D_GATE3D, slotD);
         if (is2d) { c.f(g.b[0]); c.f(g.b[1]); c.f(g.b[3]); c.f(g.b[4]); }
         else { for (int j = 0; j < 6; j++) c.f(g.b[j]); }
+      } else if (g.kind == Region::OBOX) {
+        c.op(D_GATEOB, slotD);
+        for (int j = 0; j < 8; j++) c.f(g.b[j]);
       } else {
         // hypot(P.x, P.y) already in the register (and the cylinder about the origin): the exact radius instead of the estimate
         const bool centred = g.b[0] == 0.f && g.b[1] == 0.f;
@@ -751,6 +820,20 @@ void gen(Ctx& c, uint32_t i, int depth) {
       }
       c.op(D_TRANSFORM);
       for (int k = 0; k < 12; k++) c.f(c.t->aux[n.aux_off + k]);
+      {  // zero / one pattern (dev_ops.h: the short form). Worth it from three zeros on; a row of zeros only has no short form.
+        uint32_t sp = 0;
+        int zeros = 0;
+        bool rows_ok = true;
+        for (int k = 0; k < 12; k++) {
+          const float m = c.t->aux[n.aux_off + k];
+          if (m == 0.0f) { sp |= 1u << k; zeros++; }
+          else if (m == 1.0f && (k & 3) != 3) sp |= 1u << (12 + k);
+        }
+        for (int r = 0; r < 3; r++) rows_ok = rows_ok && ((sp >> (4 * r)) & 15u) != 15u;
+        static const bool sparse_off = [] { const char* e = getenv("GSDF_HIP_NO_SPARSE_TRANSFORM"); return e && atoi(e) != 0; }();  // developer knob (A/B timing)
+        if (zeros >= 3 && rows_ok && !sparse_off) sp |= 1u << 24; else sp = 0;
+        c.u(sp);
+      }
       c.bump();
       gen(c, c.child(n, 0), depth + 1);
       if (lipd >= 0) c.lip_pop(lipd);
@@ -774,11 +857,44 @@ void gen(Ctx& c, uint32_t i, int depth) {
       // evaluations per point (same float32 routine and the same float32 product, computed here)
       c.tables.push_back({c.code.size(), (float)(2 * gsdf::kPi) / P[1], (int)P[1]});
       c.u(0);
-      gen(c, c.child(n, 0), depth + 1);  // pos1 first
+      // The two copies are a union: the farther one cannot matter where the child's bound outside its region exceeds the
+      // nearer one's value (gen_combine's rule for min). Worth it for a child that costs and has a (turned) box for a
+      // region: the wave starts with the copy nearer that box (D_CIRC_ORDER) and tests the other (D_GATEOB).
+      Region cg;
+      static const bool sector_off = [] { const char* e = getenv("GSDF_HIP_NO_SECTOR_GATE"); return e && atoi(e) != 0; }();  // developer knob (A/B timing)
+      // kSectorGateMinCost: order + gate cost ~26 instructions per point and fire for ~40 % of knurled-cylinder's surface bricks
+      // (on the lands between its grooves both copies are equally near): at that scene's 95-instruction child the gate costs
+      // what it saves (3.375 vs 3.370 ms, profiles/r3b_*), so it is reserved for children that cost several times the test
+      constexpr double kSectorGateMinCost = 150.0;
+      const bool sector_gate = !sector_off && !is2d && subtree_cost(c, c.child(n, 0)) >= kSectorGateMinCost && lower_region(c, c.child(n, 0), cg) &&
+                               (cg.kind == Region::BOX || cg.kind == Region::OBOX);
+      if (sector_gate && cg.kind == Region::BOX) {
+        Region o;
+        o.kind = Region::OBOX;
+        o.b[0] = 0.5f * (cg.b[0] + cg.b[3]); o.b[1] = 0.5f * (cg.b[1] + cg.b[4]); o.b[2] = 1.f; o.b[3] = 0.f;
+        o.b[4] = 0.5f * (cg.b[3] - cg.b[0]) * 1.000001f; o.b[5] = 0.5f * (cg.b[4] - cg.b[1]) * 1.000001f; o.b[6] = cg.b[2]; o.b[7] = cg.b[5];
+        cg = o;
+      }
+      if (sector_gate) { c.op(D_CIRC_ORDER, slotP); for (int j = 0; j < 6; j++) c.f(cg.b[j]); }
+      gen(c, c.child(n, 0), depth + 1);  // pos1 first (or whichever D_CIRC_ORDER put there)
       c.op(D_SAVER, slotD);
       c.load_saved(slotP, is2d);
       if (is2d) c.slotpver[(size_t)slotP] = c.pver;
+      long skip_at = -1, gate_pc = -1;
+      const uint32_t hxy_before = c.hxyver;
+      if (sector_gate) {
+        gate_pc = (long)c.code.size();
+        c.op(D_GATEOB, slotD);
+        for (int j = 0; j < 8; j++) c.f(cg.b[j]);
+        c.f(1.0f); c.f(0.0f); c.u(0xffffu); c.f(0.0f); c.f(0.0f);
+        skip_at = (long)c.code.size();
+        c.u(0);
+      }
       gen(c, c.child(n, 0), depth + 1);  // pos0
+      if (skip_at >= 0) {
+        if (c.hxyver != hxy_before) c.hxyver = 0;  // a child that may be skipped may not have refreshed the hypot register
+        c.code[(size_t)skip_at] = (uint32_t)((long)c.code.size() - gate_pc);
+      }
       c.op(D_COMBINE_MIN, slotD);
       c.live.pop_back();
       c.release(is2d ? 3 : 4);

@@ -59,7 +59,12 @@ enum DevOp : uint32_t {
   D_TRANSLATE,     // tx ty tz
   D_SCALE_PRE,     // inv
   D_SYMMETRY,      // bits
-  D_TRANSFORM,     // m00 m01 m02 m03 m10 .. m23 (12)
+  D_TRANSFORM,     // m00 m01 m02 m03 m10 .. m23 (12), sp. sp != 0: the matrix has coefficients that are exactly 0 (bit k) or 1 (bit
+                   // 12 + k) and bit 24 says the short form is worth taking: a row ((a x + b y) + c z) + d (Mat4.MulPosition, left
+                   // to right) equals the sum of its non-zero terms bit for bit as long as every partial sum a dropped +-0 would
+                   // have been added to is non-zero (x + +-0 = x for x != 0) and x, y, z are finite (0 * Inf = NaN); 1 * v = v
+                   // always. The wave takes the short form if that holds for all its points, else the full one (same bits).
+                   // A rotation about z with no translation: 7 operations instead of 21.
   D_TWIST,         // k
   D_ROT2D,         // x00 x01 x10 x11
   D_EXTRUDE_PRE,   // h/2            slot <- |z|-h/2
@@ -113,6 +118,17 @@ enum DevOp : uint32_t {
   //      reaches the result (it is >= the nearest child's value, which is always evaluated: its L <= bound).
   D_UBOUND2D,   // nb then nb x {minx miny maxx maxy}
   D_UBOUND3D,   // nb then nb x {minx miny minz maxx maxy maxz}
+  //      D_GATEOB: the same gate for a region that is a box turned about z (compile.cpp: Region::OBOX -- what a rotation about
+  //      z makes of a box; an axis-aligned hull of it would be up to sqrt 2 wider): (c, s) = the box's own x axis in the
+  //      current frame, L = max(|c dx + s dy| - hx, |c dy - s dx| - hy, z0 - z, z - z1) with (dx, dy) = P.xy - (cx, cy),
+  //      the Chebyshev distance in the box's frame, a lower bound of the Euclidean one.
+  //      D_CIRC_ORDER (after D_CIRC_PRE, when the array's child has such a region): a circular array evaluates its child in
+  //      the point's own sector and in the next one and keeps the minimum (cpu_evaluators.go:1082-1090) -- min is
+  //      commutative bit for bit, so the wave may start with whichever copy is nearer: if for most of its lanes the copy at
+  //      lds[slot..slot+1] (p0) lies nearer the child's region than the one in P (p1), the two change places. The farther
+  //      copy then comes second, behind a D_GATEOB against the value of the first (the union rule: L > a).
+  D_GATEOB,     // cx cy c s hx hy z0 z1 sg kk oslot ok k4 skip
+  D_CIRC_ORDER, // cx cy c s hx hy   (slot = the D_CIRC_PRE's)
   // ---- interval mode (sdf_eval<2, 0, LIP = true>; prune_kernel only -- every other kernel steps over these four).
   //      The octree drops a cube when the field cannot vanish inside it. The reference decides that from the centre value
   //      alone, |d| >= size * sqrt3/2 (octreerenderer.go:270-273): right for true distance fields, wrong for fields that grow
@@ -138,12 +154,12 @@ static const uint8_t kDevOpParams[D_OP_COUNT] = {
     /*SPHERE*/ 1, /*BOX*/ 4, /*BOXFRAME*/ 4, /*TORUS*/ 2, /*CYL0*/ 2, /*CYLR*/ 3, /*HEX*/ 3,
     /*LINE2D*/ 6, /*ARC2D*/ 6, /*QUADBEZIER*/ 13, /*CIRCLE*/ 1, /*EQTRI*/ 2, /*RECT*/ 2, /*DIAMOND*/ 6, /*X2D*/ 2,
     /*HEX2D*/ 2, /*OCT2D*/ 2, /*ELLIPSE*/ 2, /*POLY*/ 3, /*LINES*/ 2,
-    /*TRANSLATE*/ 3, /*SCALE_PRE*/ 1, /*SYMMETRY*/ 1, /*TRANSFORM*/ 12, /*TWIST*/ 1, /*ROT2D*/ 4,
+    /*TRANSLATE*/ 3, /*SCALE_PRE*/ 1, /*SYMMETRY*/ 1, /*TRANSFORM*/ 13, /*TWIST*/ 1, /*ROT2D*/ 4,
     /*EXTRUDE_PRE*/ 1, /*REVOLVE_PRE*/ 1, /*SCREW_PRE*/ 6, /*ELONGATE_PRE*/ 3, /*ELONGATE2D_PRE*/ 2,
     /*ARRAY_PRE*/ 9, /*ARRAY2D_PRE*/ 6, /*CIRC_PRE*/ 4, /*LOADP2_SUB*/ 2,
     /*MULR*/ 1, /*SHELL_POST*/ 1, /*ADDR*/ 1, /*ANNULUS*/ 1, /*EXTRUDE_POST*/ 0, /*MAXR_SLOT*/ 0, /*ADDR_SLOT*/ 0,
     /*SAVEP3*/ 0, /*LOADP3*/ 0, /*SAVEP2*/ 0, /*LOADP2*/ 0, /*SAVER*/ 0, /*SETSLOT*/ 1, /*SETR*/ 1,
     /*MIN*/ 0, /*MAX*/ 0, /*DIFF*/ 0, /*XOR*/ 0, /*SUNION*/ 2, /*SDIFF*/ 2, /*SINTER*/ 2,
-    /*GATE2D*/ 10, /*GATE3D*/ 12, /*GATEZC*/ 13, /*UBOUND2D*/ 1, /*UBOUND3D*/ 1,
+    /*GATE2D*/ 10, /*GATE3D*/ 12, /*GATEZC*/ 13, /*UBOUND2D*/ 1, /*UBOUND3D*/ 1, /*GATEOB*/ 14, /*CIRC_ORDER*/ 6,
     /*LIP_PUSH*/ 0, /*LIP_POP*/ 0, /*LIP_MUL*/ 1, /*LIP_WRAP*/ 2,
 };

@@ -81,7 +81,16 @@ struct gsdf_program {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
   } q0, q1, ctr, spec_pass, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, flat_grid, flat_bits, flat_list, rec, hdr;  // flat_bits: sign and near-surface bit planes of the flat renderer's lattice (flat_grid_kernel -> flat_cut_scan_kernel), flat_list: the cut cubes (-> flat_march_list_kernel)  // rec / hdr: cut-leaf records and block headers of the two-kernel leaf phase (the group sums follow the counters in ctr)  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // The octree mesher leaves its counters cleared for the NEXT mesh (a memset enqueued behind the readback, executed while
+  // the host is between calls) instead of clearing them at the head of its own chain, where the memset and the gap behind it
+  // cost ~10 us of every mesh: ctr_clean = bytes of `ctr` known to be zero for work enqueued on ctr_clean_stream (0: unknown).
+  size_t ctr_clean = 0;
+  hipStream_t ctr_clean_stream = nullptr;
+  void ctr_settle() {  // before anyone else writes `ctr`: the pending clear must have run (the stream may be a caller's, and gone)
+    if (ctr_clean && hipStreamSynchronize(ctr_clean_stream) != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }
+    ctr_clean = 0;
+  }
   void* h_ctr = nullptr;  // pinned host copy of the device counters (a pageable destination makes the D2H copy a staged, blocking one)
   uint64_t last_tris = 0;  // triangle count of the previous mesh on this handle: sizes the next output buffer
   uint64_t rec_blocks = 0;  // 64-leaf blocks the cut-leaf record arena is sized for (0: first mesh, start with kRecBlocks0)
@@ -92,6 +101,7 @@ struct gsdf_program {
   hipFunction_t f_dc_origin = nullptr, f_dc_edges = nullptr, f_dc_normals = nullptr, f_normals = nullptr, f_image = nullptr, f_flat_grid = nullptr;
   bool spec_aux_tried = false;
   int spec_eval_k = 0, spec_eval_w = 0, spec_leaf_k = 0, spec_leaf_w = 0;
+  bool spec_leaf_both = false;  // the specialised leaf kernel has both column passes in one body (kernels_octree.h: BOTH)
   double spec_compile_s = 0;
   std::string spec_compiler;  // hipcc | hiprtc | cache: what built the specialised kernels
   std::string spec_key;       // key of that build (specialize.cpp: build_key)
@@ -471,15 +481,23 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
   p->leaf_config(&lk, &lw, &lds_m);
   const int ek = p->batch_k();
   std::vector<std::string> names;
+  int both_at = -1;
   const int ew = p->sweep_waves(ek);
   names.push_back(std::string("eval_kernel<") + (p->prog.is2d ? "2" : "3") + ", " + std::to_string(ek) + ", " + std::to_string(ew) + ">");
   if (!p->prog.is2d) {
     names.push_back("prune_kernel");
     names.push_back("prune_spec_kernel");
-    names.push_back(std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(lw) + (fused_leaf() ? ">" : (p->leaf_nt_in_lds() ? ", true, true>" : ", true, false>")));
+    names.push_back(std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(lw) + (fused_leaf() ? ">" : (p->leaf_nt_in_lds() ? ", true, true, false>" : ", true, false, false>")));
     // a fifth workgroup per CU where the LDS has room for it (npt-flange's 7 slots): the 96-register build is taken if the
     // compiler reaches it without scratch (-3 % on the evaluating kernel); built beside the 128-register one, same process
-    if (!fused_leaf() && lk == 4 && lw == 4 && 5 * lds_m <= (size_t)160 * 1024) names.push_back("leaf_eval_kernel<4, 5, true, true>");
+    if (!fused_leaf() && lk == 4 && lw == 4 && 5 * lds_m <= (size_t)160 * 1024) names.push_back("leaf_eval_kernel<4, 5, true, true, false>");
+    // both passes of a column brick in one body where enough of the program depends on x and y alone (an atan2 or several
+    // hypots: npt-flange) -- taken, ahead of the others, if the compiler reaches it without scratch (-4 % on that kernel)
+    static const bool both_off = [] { const char* e = getenv("GSDF_HIP_NO_BOTH_PASSES"); return e && atoi(e) != 0; }();  // developer knob (A/B timing)
+    if (!fused_leaf() && !both_off && lk == 4 && gsdf_dev::spec_xy_shared_weight(p->prog) >= 4) {
+      both_at = (int)names.size();
+      names.push_back(std::string("leaf_eval_kernel<4, ") + std::to_string(lw) + (p->leaf_nt_in_lds() ? ", true, true, true>" : ", true, false, true>"));
+    }
   }
   std::vector<hipFunction_t> f;
   hipModule_t mod = nullptr;
@@ -514,17 +532,22 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
     p->f_prune = okp ? f[1] : nullptr;
     p->f_prune_spec = okt ? f[2] : nullptr;
     p->f_leaf = okl ? f[3] : nullptr;
-    if (f.size() > 4) {
+    if (f.size() > 4 && both_at != 4) {
       const bool ok5 = fn_scratch_bytes(f[4]) == 0;
       spec_report("specialised", names[4], f[4], ok5);
       if (ok5) { p->f_leaf = f[4]; p->spec_leaf_w = 5; okl = true; }
+    }
+    if (both_at >= 0) {
+      const bool okb = fn_scratch_bytes(f[(size_t)both_at]) == 0;
+      spec_report("specialised", names[(size_t)both_at], f[(size_t)both_at], okb);
+      if (okb) { p->f_leaf = f[(size_t)both_at]; p->spec_leaf_w = lw; p->spec_leaf_both = true; okl = true; }
     }
     // the leaf kernel is where the time goes: before giving it up, trade occupancy for registers (W = workgroups per CU
     // the register budget is sized for; the launch is the same)
     for (int w2 = lw - 1; !okl && w2 >= 2; w2--) {
       std::vector<hipFunction_t> fl;
       hipModule_t m2 = nullptr;
-      const std::string nl = std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(w2) + (fused_leaf() ? ">" : (p->leaf_nt_in_lds() ? ", true, true>" : ", true, false>"));
+      const std::string nl = std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(w2) + (fused_leaf() ? ">" : (p->leaf_nt_in_lds() ? ", true, true, false>" : ", true, false, false>"));
       if (spec_build(p, {nl}, &m2, fl, &p->spec_compile_s) != GSDF_OK) break;
       okl = fn_scratch_bytes(fl[0]) == 0;
       spec_report("specialised", nl, fl[0], okl);
@@ -556,8 +579,8 @@ extern "C" int gsdf_hip_program_kernels(const gsdf_program* p, char* dst, size_t
   if (p->prog.is2d)
     snprintf(buf, sizeof buf, "eval=eval_kernel<2,%d,%d>:%s", ek, ew, se ? "specialised" : "interpreter");
   else
-    snprintf(buf, sizeof buf, "eval=eval_kernel<3,%d,%d>:%s leaf=%s<%d,%d>:%s prune=prune_kernel:%s", ek, ew, se ? "specialised" : "interpreter",
-             fused_leaf() ? "leaf_kernel" : "leaf_eval_kernel", lk, sl ? p->spec_leaf_w : aw, sl ? "specialised" : "interpreter",
+    snprintf(buf, sizeof buf, "eval=eval_kernel<3,%d,%d>:%s leaf=%s<%d,%d%s>:%s prune=prune_kernel:%s", ek, ew, se ? "specialised" : "interpreter",
+             fused_leaf() ? "leaf_kernel" : "leaf_eval_kernel", lk, sl ? p->spec_leaf_w : aw, sl && p->spec_leaf_both ? ",both" : "", sl ? "specialised" : "interpreter",
              p->f_prune ? "specialised" : "interpreter");
   if (p->spec_mod && strlen(buf) + 32 < sizeof buf) { strcat(buf, " compiler="); strcat(buf, p->spec_compiler.c_str()); }
   {  // identity of the code that runs: a stored profile describes this handle's kernels only if it carries the same key
@@ -593,7 +616,7 @@ extern "C" int gsdf_hip_specialize_check(const gsdf_tree* tree, size_t* code_obj
     std::vector<std::string> low;
     std::string log;
     const std::vector<std::string> names = pr.is2d ? std::vector<std::string>{"eval_kernel<2, 4, 4>"}
-                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "prune_spec_kernel", "leaf_eval_kernel<4, 4, true, true>", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
+                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "prune_spec_kernel", "leaf_eval_kernel<4, 4, true, true, false>", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
     if (!gsdf_dev::spec_compile(pr, "gfx950", names, co, low, log)) return fail(GSDF_ERR_HIP, "specialised build failed:\n" + log);
     if (code_object_bytes) *code_object_bytes = co.size();
     return GSDF_OK;
@@ -1049,9 +1072,15 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
       want_two = false;
     }
     const size_t clear_bytes = kCtrBytes + (want_two ? ngrp * sizeof(unsigned long long) : 0);
-    HIP_TRYM(p->ctr.ensure(clear_bytes));
+    {
+      const void* before = p->ctr.p;
+      HIP_TRYM(p->ctr.ensure(clear_bytes));
+      if (p->ctr.p != before) p->ctr_clean = 0;
+    }
     d_ctr = (MeshCounters*)p->ctr.p;
-    HIP_TRYM(hipMemsetAsync(d_ctr, 0, clear_bytes, s));
+    if (p->ctr_clean && p->ctr_clean_stream != s) p->ctr_settle();  // cleared on another stream: let that finish, do not rely on it
+    if (p->ctr_clean < clear_bytes) HIP_TRYM(hipMemsetAsync(d_ctr, 0, clear_bytes, s));
+    p->ctr_clean = 0;  // dirty from here on
     HIP_TRYM(hipEventRecord(ev0, s));
     static const int prune_bpc = [] { const char* e = getenv("GSDF_HIP_PRUNE_BPC"); return e ? atoi(e) : 4; }();  // tuning knob
     // The first S levels (at most 7: 299,593 cubes) are centre-tested speculatively, every cube of the complete octree at once,
@@ -1172,7 +1201,12 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     }
     HIP_TRYM(hipEventRecord(ev2, s));
     HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));
-    HIP_TRYM(hipStreamSynchronize(s));
+    hipEvent_t evr = p->ev[4];
+    HIP_TRYM(hipEventRecord(evr, s));
+    static const bool clear_ahead = [] { const char* e = getenv("GSDF_HIP_CLEAR_AHEAD"); return !e || atoi(e) != 0; }();
+    if (clear_ahead) HIP_TRYM(hipMemsetAsync(d_ctr, 0, clear_bytes, s));  // for the next mesh (or the rerun below); not waited for
+    HIP_TRYM(hipEventSynchronize(evr));
+    if (clear_ahead) { p->ctr_clean = clear_bytes; p->ctr_clean_stream = s; }
     if (hc.q_overflow) {  // a cube queue was too small: double and redo (exact: nothing was dropped silently)
       if (attempt >= 8) return bail(fail(GSDF_ERR_CAPACITY, "octree queue capacity exceeded"));
       qcap *= 4;
@@ -1306,6 +1340,7 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
   // hipMalloc/hipFree pair of that size per mesh cost more wall time than the whole device pass.
   gsdf_program::Arena &grid = p->dc_grid, &d2 = p->dc_dist, &f2 = p->dc_fv, &n2 = p->dc_nrm, &e2 = p->dc_edge;
   HIP_TRYM(grid.ensure(ncell * sizeof(int)));
+  p->ctr_settle();  // (the octree mesher's clear-ahead)
   HIP_TRYM(p->ctr.ensure(sizeof(MeshCounters) > sizeof(DCCounters) ? sizeof(MeshCounters) : sizeof(DCCounters)));
   DCCounters* d_ctr = (DCCounters*)p->ctr.p;
   const int lk = p->batch_k();
@@ -1452,6 +1487,7 @@ extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, in
   if (ncz == 0) { *out = m; return GSDF_OK; }  // more ranks than cube planes: nothing for this one
   for (auto& e : p->ev)
     if (!e) HIP_TRYM(hipEventCreate(&e));
+  p->ctr_settle();  // (the octree mesher's clear-ahead)
   HIP_TRYM(p->ctr.ensure(sizeof(MeshCounters)));
   MeshCounters* d_ctr = (MeshCounters*)p->ctr.p;
   {

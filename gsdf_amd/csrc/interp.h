@@ -237,6 +237,18 @@ __device__ __forceinline__ void region_lb_zcyl(const P3 (&pv)[K], const float (&
     L[kp] = l;
   }
 }
+// box turned about z: Chebyshev distance in the box's own frame (its x axis = (c, s) in the current frame)
+template <int K, int DIM>
+__device__ __forceinline__ void region_lb_obox(const P3 (&pv)[K], float cx, float cy, float c, float s, float hx, float hy, float z0,
+                                               float z1, float (&L)[K]) {
+  using namespace dm;
+  KLOOP {
+    const float dx = pv[kp].x - cx, dy = pv[kp].y - cy;
+    float l = maxf(absf(c * dx + s * dy) - hx, absf(c * dy - s * dx) - hy);
+    if (DIM == 3) l = maxf(l, maxf(z0 - pv[kp].z, pv[kp].z - z1));
+    L[kp] = l;
+  }
+}
 // The gate's verdict: true (wave-uniform) if EVERY point of the wave passes: L > 0 and L > sg * a + kk by the margin (the
 // child cannot change its own combine), or -- with the context of the enclosing difference, c = its other operand -- the
 // upper bound U = max(a, -L) + k4 of the inner result is negative and c + U <= -ok by the margin (the enclosing combine
@@ -756,15 +768,55 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       case D_TRANSFORM: {
-        KLOOP {
-          [[maybe_unused]] P3& p = pv[kp];
-          [[maybe_unused]] float& R = Rv[kp];
-          float x = PF(0) * p.x + PF(1) * p.y + PF(2) * p.z + PF(3);
-          float y = PF(4) * p.x + PF(5) * p.y + PF(6) * p.z + PF(7);
-          float z = PF(8) * p.x + PF(9) * p.y + PF(10) * p.z + PF(11);
-          p.x = x; p.y = y; p.z = z;
+        const uint32_t sp = PU(12);  // zero / one pattern of the matrix (dev_ops.h)
+        bool done = false;
+        if ((sp >> 24) != 0u) {
+          // short form: the non-zero terms of each row, in the reference's order; `ok` collects what makes it exact
+          P3 n[K];
+          bool ok = true;
+          KLOOP {
+            const P3& p = pv[kp];
+            ok = ok && (maxf(maxf(absf(p.x), absf(p.y)), absf(p.z)) <= 3.0e38f);
+            float o3[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+              float acc = 0.0f;
+              bool have = false, lead = false;
+#pragma unroll
+              for (int j = 0; j < 3; j++) {
+                const uint32_t bit = 4u * (uint32_t)r + (uint32_t)j;
+                const float v = j == 0 ? p.x : (j == 1 ? p.y : p.z);
+                if ((sp >> bit) & 1u) {  // +-0 * v is +-0: adding it changes nothing unless the sum so far is a zero
+                  if (have) ok = ok && (acc != 0.0f); else lead = true;
+                } else {
+                  const float t = ((sp >> (12u + bit)) & 1u) ? v : PF(bit) * v;
+                  if (have) acc = acc + t;
+                  else { acc = t; have = true; if (lead) ok = ok && (acc != 0.0f); }
+                }
+              }
+              const uint32_t bd = 4u * (uint32_t)r + 3u;
+              if ((sp >> bd) & 1u) { if (have) ok = ok && (acc != 0.0f); }
+              else acc = have ? acc + PF(bd) : PF(bd);
+              o3[r] = acc;
+            }
+            n[kp].x = o3[0]; n[kp].y = o3[1]; n[kp].z = o3[2];
+          }
+          if (__all(ok)) {  // wave-uniform
+            KLOOP pv[kp] = n[kp];
+            done = true;
+          }
         }
-        pc += 13;
+        if (!done) {
+          KLOOP {
+            [[maybe_unused]] P3& p = pv[kp];
+            [[maybe_unused]] float& R = Rv[kp];
+            float x = PF(0) * p.x + PF(1) * p.y + PF(2) * p.z + PF(3);
+            float y = PF(4) * p.x + PF(5) * p.y + PF(6) * p.z + PF(7);
+            float z = PF(8) * p.x + PF(9) * p.y + PF(10) * p.z + PF(11);
+            p.x = x; p.y = y; p.z = z;
+          }
+        }
+        pc += 14;
         break;
       }
       case D_TWIST: {
@@ -1190,6 +1242,40 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         } else {
           pc += 14;
         }
+        break;
+      }
+      case D_GATEOB: {
+        float a[K], L[K], cc[K];
+        const uint32_t oslot = PU(10);
+        const bool has_outer = oslot != 0xffffu;
+        KLOOP { a[kp] = LDSF(slot); cc[kp] = has_outer ? LDSF(oslot) : 0.0f; }
+        region_lb_obox<K, 3>(pv, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5), PF(6), PF(7), L);
+        if (!LIP && gate_far<K, 3>(pv, a, L, PF(8), PF(9), cc, has_outer, PF(11), PF(12))) {
+          KLOOP Rv[kp] = L[kp];
+          pc += PU(13);
+        } else {
+          pc += 15;
+        }
+        break;
+      }
+      case D_CIRC_ORDER: {
+        // which of the circular array's two copies lies nearer the child's region, for most lanes of the wave: that one first
+        // (min is commutative bit for bit), so that the gate in front of the second has the best chance (dev_ops.h). Both
+        // copies are equally far from the axis, so the nearer one to the region's centre is the one with the larger
+        // projection on it; one point per lane votes (a heuristic: either order gives the same bits).
+        if (!LIP) {
+          const float d1 = pv[0].x * PF(0) + pv[0].y * PF(1);
+          const float d0 = lds[((slot) * K) * nthreads] * PF(0) + lds[((slot + 1) * K) * nthreads] * PF(1);
+          const uint64_t v0 = __builtin_amdgcn_ballot_w64(d0 > d1), v1 = __builtin_amdgcn_ballot_w64(d1 > d0);
+          if (__builtin_popcountll(v0) > __builtin_popcountll(v1)) {  // wave-uniform
+            KLOOP {
+              const float tx = LDSF(slot), ty = LDSF(slot + 1);
+              LDSF(slot) = pv[kp].x; LDSF(slot + 1) = pv[kp].y;
+              pv[kp].x = tx; pv[kp].y = ty;
+            }
+          }
+        }
+        pc += 7;
         break;
       }
       // ------------------------------------------------ interval mode bookkeeping (no-ops elsewhere)

@@ -615,7 +615,11 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
 // cost a workgroup per CU (the host decides): the counts are then read from the table in global memory. A template argument
 // and not a run-time flag: a select between an LDS and a global load makes the compiler form a flat pointer, and ROCm
 // 7.0-7.2's backend then dies on some trees ("Illegal instruction detected ... V_CMP_NE_U32_e32 0, $src_shared_base").
-template <int K, int WAVES, bool UCUBE = true, bool NTLDS = true>
+// BOTH (specialised builds of programs with work that depends on x and y alone): the two passes of a column brick are laid out
+// in one body, so the compiler's value numbering computes such subexpressions once per lane for all eight z instead of once per
+// pass (npt-flange: hypot, atan2 and the thread's x,y terms; -4 % kernel time at the same register budget). Same statements on
+// the same values.
+template <int K, int WAVES, bool UCUBE = true, bool NTLDS = true, bool BOTH = false>
 __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
                                                           unsigned long long cube_cap, int lq, int nslots, float ox, float oy, float oz,
                                                           float res, uint32_t* __restrict__ hdr, uint32_t* __restrict__ rec,
@@ -695,28 +699,29 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
       float dall[8];  // distances of rows 0..7; static shift register
 #pragma unroll
       for (int j = 0; j < 8; j++) dall[j] = 0.f;
-#ifdef GSDF_EXP_UNROLL_PASSES  // developer experiment: both passes of a column brick in one body, so that what depends on x and y alone is computed once
+#define GSDF_COLUMN_PASS                                                     \
+  {                                                                          \
+    P3 pk[K];                                                                \
+    float dk[K];                                                             \
+    _Pragma("unroll") for (int kp = 0; kp < K; kp++) {                       \
+      const unsigned r = c0 + kp; /* wave-uniform */                         \
+      const float za = oz + res * (float)(uint16_t)(bz + (r >> 1));          \
+      pk[kp].x = px;                                                         \
+      pk[kp].y = py;                                                         \
+      pk[kp].z = (r & 1u) ? za + res : za;                                   \
+    }                                                                        \
+    gsdf_dev::sdf_eval<K, 2>(code, pk, dk, lds, BLOCK, /*brick=*/true);      \
+    _Pragma("unroll") for (int j = 0; j < 8 - K; j++) dall[j] = dall[j + K]; \
+    _Pragma("unroll") for (int kp = 0; kp < K; kp++) dall[8 - K + kp] = dk[kp]; \
+  }
+      if (BOTH) {
 #pragma unroll
-#else
+        for (unsigned c0 = 0; c0 < 8; c0 += K) GSDF_COLUMN_PASS
+      } else {
 #pragma unroll 1
-#endif
-      for (unsigned c0 = 0; c0 < 8; c0 += K) {
-        P3 pk[K];
-        float dk[K];
-#pragma unroll
-        for (int kp = 0; kp < K; kp++) {
-          const unsigned r = c0 + kp;  // wave-uniform
-          const float za = oz + res * (float)(uint16_t)(bz + (r >> 1));
-          pk[kp].x = px;
-          pk[kp].y = py;
-          pk[kp].z = (r & 1u) ? za + res : za;
-        }
-        gsdf_dev::sdf_eval<K, 2>(code, pk, dk, lds, BLOCK, /*brick=*/true);
-#pragma unroll
-        for (int j = 0; j < 8 - K; j++) dall[j] = dall[j + K];
-#pragma unroll
-        for (int kp = 0; kp < K; kp++) dall[8 - K + kp] = dk[kp];
+        for (unsigned c0 = 0; c0 < 8; c0 += K) GSDF_COLUMN_PASS
       }
+#undef GSDF_COLUMN_PASS
       float* D = g_smem + (threadIdx.x & ~63u);  // rows of BLOCK floats; this wave's 64 columns of each
 #pragma unroll
       for (int r = 0; r < 8; r++) D[r * BLOCK + lane] = dall[r];

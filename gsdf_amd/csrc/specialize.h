@@ -13,6 +13,9 @@ std::string spec_source(const Program& p);
 
 // Number of instructions of the program (excluding D_END).
 int spec_instruction_count(const Program& p);
+// How much of the program depends on the entry x and y alone (instructions flagged D_FLAG_SHXY; an atan2 counts 4, a hypot 1):
+// decides whether the column-brick leaf kernel is also built with both passes in one body (kernels_octree.h: BOTH).
+int spec_xy_shared_weight(const Program& p);
 
 // Compile kernels.h with the specialised evaluator for `arch` (e.g. "gfx950") and instantiate `name_exprs`
 // ("leaf_kernel<4, 4>", "prune_kernel", ...). On success returns true and fills the code object and the lowered

@@ -54,6 +54,10 @@ def _lower_bound(kind, g, pos, is2d):
         if not is2d:
             L = np.maximum(L, np.maximum(g[2] - z, z - g[5]))
         return L
+    if kind == 3:                      # box turned about z: cx cy c s hx hy z0 z1 (Chebyshev distance in its own frame)
+        dx, dy = x - g[0], y - g[1]
+        L = np.maximum(np.abs(g[2] * dx + g[3] * dy) - g[4], np.abs(g[2] * dy - g[3] * dx) - g[5])
+        return np.maximum(L, np.maximum(g[6] - z, z - g[7]))
     rad = np.hypot(x - g[0], y - g[1])
     L = g[5] * (rad - g[2])
     if not is2d:
@@ -73,6 +77,9 @@ def check_tree(t, rng, npts=3000):
         is2d = t.nodes[node].op >= FIRST_2D
         if kind == 1:
             lo, hi = g[:3].copy(), g[3:6].copy()
+        elif kind == 3:
+            r = float(np.hypot(g[4], g[5]))
+            lo, hi = np.array([g[0] - r, g[1] - r, g[6]]), np.array([g[0] + r, g[1] + r, g[7]])
         else:
             lo = np.array([g[0] - g[2], g[1] - g[2], max(g[3], -1e3)])
             hi = np.array([g[0] + g[2], g[1] + g[2], min(g[4], 1e3)])
@@ -176,3 +183,26 @@ def test_cyclic_node_graph_is_refused():
     n, sl = C.c_uint32(), C.c_uint32()
     assert hip.lib().gsdf_hip_lower(C.byref(bad), None, 0, C.byref(n), C.byref(sl)) != 0
     assert b"cycle" in hip.lib().gsdf_hip_last_error()
+
+
+def test_turned_boxes_keep_their_orientation():
+    """A rotation about z makes a box a TURNED box (kind 3) instead of its sqrt-2-wider axis-aligned hull: what lets a circular
+    array skip the farther of its two sector copies (knurled-cylinder's cutters: a 45-degree box 16 from the axis, 24 sectors
+    of 15 degrees). The claim is checked like every other; nested rotations, translations, scalings and offsets keep the kind,
+    mirrors / unions / twists fall back to hulls that still hold."""
+    b = Builder()
+    rng = np.random.default_rng(17)
+    box = b.NewBox(2.0, 1.0, 3.0, 0.0)
+    t1 = b.Translate(b.Rotate(box, 0.6, (0, 0, 1)), 4.0, -1.0, 0.5)
+    k, g = _region(t1.tree(), t1.tree().root)
+    assert k == 3 and abs(g[0] - 4.0) < 1e-5 and abs(np.hypot(g[2], g[3]) - 1) < 1e-6 and abs(abs(g[2]) - np.cos(0.6)) < 1e-5
+    shapes = [t1,
+              b.Rotate(b.Translate(b.Rotate(box, 0.6, (0, 0, 1)), 4.0, -1.0, 0.5), -1.1, (0, 0, 1)),
+              b.Scale(b.Offset(t1, -0.2), 1.7),
+              b.Rotate(box, np.pi / 2, (0, 0, 1)),                      # a quarter turn stays axis-aligned (kind 1)
+              b.Union(t1, b.NewSphere(1.0)), b.Symmetry(t1, True, False, False), b.Twist(t1, 0.2),
+              b.CircularArray(b.Translate(b.Rotate(b.NewBox(3, 3, 8, 0), np.pi / 4, (0, 0, 1)), 6, 0, 0), 12, 12),
+              b.Rotate(t1, 0.8, (1, 0, 0.2))]
+    kinds = [_region(s.tree(), s.tree().root)[0] for s in shapes]
+    assert kinds[:4] == [3, 3, 3, 1] and kinds[4] == 1 and kinds[5] == 1 and kinds[6] == 2 and kinds[7] == 2 and kinds[8] == 1
+    assert sum(check_tree(s.tree(), rng, 2000) for s in shapes) > 10000

@@ -38,6 +38,7 @@ def test_random_trees_distances_and_meshes(gpu, seed):
         sdf = gpu.SDF3HIP(sh)
         pos = _points(sh, rng)
         dref = ref.Evaluate(pos)
+        assert not np.isnan(dref).any(), (seed, k)   # trees the constructors accept, finite positions: no NaN, so _mismatch masks nothing (the NaN relation: tests/test_gpu_nan.py)
         assert _mismatch(sdf.Evaluate(pos), dref) == 0, (seed, k, "interpreter")
         if k % 3 == 0:
             sdf.specialize()

@@ -549,6 +549,40 @@ def test_polygon_edge_culling_is_exact(gpu, nv, inner, offset):
     assert (sdf.Evaluate(pos).view(np.uint32) == ref.Evaluate(pos).view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("turn,ncopies,twist", [(0.5, 9, 0.0), (np.pi / 4, 16, 0.15), (0.0, 7, 0.0)])
+def test_circular_array_sector_gate_is_exact(gpu, turn, ncopies, twist):
+    """D_CIRC_ORDER / D_GATEOB (compile.cpp: the circular array's sector gate): the wave evaluates the nearer of the array's two
+    sector copies first and skips the other where its turned-box bound exceeds the first one's value. Gears of extruded star
+    teeth (an expensive child with a turned box for a region), plain, twisted and with an axis-aligned tooth: distances and
+    meshes bit-identical to the oracle, interpreter and specialised kernels (that the lowering contains the gate for such a
+    child: tests/test_lowering.py::test_sector_gate_of_circular_arrays)."""
+    b = Builder()
+    star = b.NewPolygon([(1.2 * np.cos(t) * (1 if i % 2 else 0.5), 0.8 * np.sin(t) * (1 if i % 2 else 0.5)) for i, t in enumerate(np.linspace(0, 2 * np.pi, 12, endpoint=False))])
+    tooth = b.Extrude(star, 3.0)
+    if turn:
+        tooth = b.Rotate(tooth, turn, (0, 0, 1))
+    gear = b.CircularArray(b.Translate(tooth, 6.0, 0, 0), ncopies, ncopies)
+    if twist:
+        gear = b.Twist(gear, twist)
+    part = b.SmoothUnion(0.2, b.NewCylinder(5.6, 2.0, 0.1), gear)
+    ref = OracleSDF(part.tree())
+    sdf = gpu.SDF3HIP(part)
+    rng = np.random.default_rng(ncopies)
+    bb = part.Bounds()
+    pos = (bb[:3] + rng.random((40000, 3), np.float32) * (bb[3:] - bb[:3])).astype(np.float32)
+    pos[:2000, :2] *= np.float32(0.02)                      # near the axis, where every sector is close
+    dref = ref.Evaluate(pos)
+    res = np.float32(float(part.Diagonal()) / 300)
+    want = _sorted(ref.render_octree(res, 4096, True).tris)
+    for spec in (False, True):
+        if spec:
+            sdf.specialize()
+        assert (sdf.Evaluate(pos).view(np.uint32) == dref.view(np.uint32)).all(), spec
+        got = _sorted(gpu.OctreeHIP(sdf, res).RenderAll())
+        assert got.shape == want.shape and (got.view(np.uint32) == want.view(np.uint32)).all(), spec
+    assert len(want) > 20000
+
+
 def test_example_render_stl(gpu, tmp_path):
     """examples/render_stl.py: the reference's example flow (part -> mesh -> binary STL file) end to end."""
     import importlib.util

@@ -333,3 +333,33 @@ def test_bad_trees_raise():
     with pytest.raises(hip.HipError) as e:
         hip.lower(t)
     assert e.value.code == -4 and "dimension" in e.value.msg
+
+
+def test_sector_gate_of_circular_arrays():
+    """A circular array evaluates its child in two neighbouring sectors and keeps the minimum (cpu_evaluators.go:1082-1090).
+    Where the child is expensive (>= 150 estimated instructions) and has a (turned) box for a region, the lowering puts
+    D_CIRC_ORDER behind D_CIRC_PRE (the wave starts with the copy nearer that box) and a D_GATEOB in front of the second copy,
+    against the first one's value: the union rule, sg = 1, kk = 0, no context, skip target = the array's D_COMBINE_MIN."""
+    b = Builder()
+    star = b.NewPolygon([(1.2 * np.cos(t) * (1 if i % 2 else 0.5), 1.2 * np.sin(t) * (1 if i % 2 else 0.5)) for i, t in enumerate(np.linspace(0, 2 * np.pi, 12, endpoint=False))])
+    tooth = b.Translate(b.Rotate(b.Extrude(star, 3.0), 0.5, (0, 0, 1)), 6.0, 0, 0)
+    code, _ = hip.lower(b.Union(b.NewCylinder(5.5, 2.0, 0.0), b.CircularArray(tooth, 9, 9)))
+    f = code.view(np.float32)
+    ins = decode(code)
+    names = [i[0] for i in ins]
+    assert names.count("D_CIRC_PRE") == 1 and names.count("D_CIRC_ORDER") == 1 and names.count("D_GATEOB") == 1
+    for k, i in enumerate(ins):
+        if i[0] == "D_CIRC_PRE":
+            assert ins[k + 1][0] == "D_CIRC_ORDER" and ins[k + 1][3] == i[3]         # same slots: p0 lives there
+        if i[0] == "D_GATEOB":
+            pc = i[4]
+            cx, cy, c, s, hx, hy, z0, z1, sg, kk = f[pc + 1:pc + 11]
+            assert abs(cx - 6) < 1e-4 and cy == 0 and abs(c - np.cos(0.5)) < 1e-5 and abs(abs(s) - np.sin(0.5)) < 1e-5   # the tooth's box, turned by 0.5 rad
+            assert 1.0 < hx < 1.3 and 1.0 < hy < 1.3 and abs(z0 + 1.5) < 0.01 and abs(z1 - 1.5) < 0.01
+            assert sg == 1.0 and kk == 0.0 and int(code[pc + 11]) == 0xffff
+            assert [j[0] for j in ins if j[4] == pc + int(code[pc + 14])] == ["D_COMBINE_MIN"]
+            assert ins[k - 1][0] == "D_LOADP3" and ins[k - 2][0] == "D_SAVER" and ins[k - 2][3] == i[3]  # a = the first copy's value
+    # cheaper children (knurled-cylinder's cutter: a turned box, 95 instructions) or children without a box (a torus) get neither
+    for tree in (b.Scene("knurled-cylinder"), b.CircularArray(b.Translate(b.NewTorus(1.0, 0.3), 3, 0, 0), 8, 8)):
+        nm = [i[0] for i in decode(hip.lower(tree)[0])]
+        assert "D_CIRC_ORDER" not in nm and "D_GATEOB" not in nm
