@@ -94,6 +94,43 @@ def host_inclusive(hip, sdf, res, reps=7):
     return out
 
 
+def batch_throughput(hip, shader, res, specialised, meshes=40, handles=2):
+    """Meshes per second when a caller has several parts to mesh: `handles` independent program handles (own stream and
+    workspace each), one host thread per handle, the same mesh `meshes` times each. One mesh's launch-latency-bound top of the
+    octree and its host tail then run under the other's leaf kernel. Measured AFTER the contract's timed loop; not the headline
+    (which is one mesh at a time, start to finish)."""
+    import threading
+    sdfs = []
+    for _ in range(handles):
+        s = hip.SDF3HIP(shader)
+        if specialised:
+            try:
+                s.specialize()
+            except hip.HipError:
+                pass
+        sdfs.append(s)
+    stats = [None] * handles
+
+    def work(i, n):
+        oc = None
+        for _ in range(n):
+            oc = hip.OctreeHIP(sdfs[i], res)
+        stats[i] = oc.stats
+    for i in range(handles):
+        work(i, 5)  # warm: buffers sized, pools filled
+    th = [threading.Thread(target=work, args=(i, meshes)) for i in range(handles)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    n = meshes * handles
+    return {"handles": handles, "meshes": n, "meshes_per_s": n / dt, "ms_per_mesh": dt / n * 1e3,
+            "evals_per_s": float(stats[0].evals) * n / dt, "triangles_per_s": float(stats[0].n_tris) * n / dt,
+            "note": "independent handles meshing concurrently from host threads (throughput of a batch of parts); the headline is one mesh at a time"}
+
+
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, one wave64 VALU op per 2 cycles, 2.4 GHz
 
 
@@ -226,6 +263,7 @@ def main():
     ap.add_argument("--scene", default="npt-flange")
     ap.add_argument("--cpu-resdiv", type=int, default=0, help="resdiv of the bounded CPU sample (0 = pick ~10-30 s of CPU work from the core count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch-throughput", action="store_true", help="skip the two-handle throughput measurement that follows the timed loop")
     ap.add_argument("--mode", choices=["mesh", "eval", "flat"], default="mesh",
                     help="mesh (default, BASELINE configs[1]) or eval: the gleval.SDF3.Evaluate micro-benchmark (SURVEY 8(d) M1) on "
                          "HBM-resident positions: 2^24-point chunks of the flat lattice of the scene at --resdiv; flat: the reference's other "
@@ -470,6 +508,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(shader, args.scene, cpu_rd, threads)
         if world == 1 and not dc:
             out["host_inclusive"] = host_inclusive(hip, sdf, res)
+        if world == 1 and not dc and not args.no_batch_throughput and not args.no_cpu_baseline:
+            out["batch_throughput"] = batch_throughput(hip, shader, res, not args.interpreter)
         print(json.dumps(out), flush=True)
     if dist is not None:
         if rank == 0 and last[1] is not None:

@@ -820,20 +820,6 @@ void gen(Ctx& c, uint32_t i, int depth) {
       }
       c.op(D_TRANSFORM);
       for (int k = 0; k < 12; k++) c.f(c.t->aux[n.aux_off + k]);
-      {  // zero / one pattern (dev_ops.h: the short form). Worth it from three zeros on; a row of zeros only has no short form.
-        uint32_t sp = 0;
-        int zeros = 0;
-        bool rows_ok = true;
-        for (int k = 0; k < 12; k++) {
-          const float m = c.t->aux[n.aux_off + k];
-          if (m == 0.0f) { sp |= 1u << k; zeros++; }
-          else if (m == 1.0f && (k & 3) != 3) sp |= 1u << (12 + k);
-        }
-        for (int r = 0; r < 3; r++) rows_ok = rows_ok && ((sp >> (4 * r)) & 15u) != 15u;
-        static const bool sparse_off = [] { const char* e = getenv("GSDF_HIP_NO_SPARSE_TRANSFORM"); return e && atoi(e) != 0; }();  // developer knob (A/B timing)
-        if (zeros >= 3 && rows_ok && !sparse_off) sp |= 1u << 24; else sp = 0;
-        c.u(sp);
-      }
       c.bump();
       gen(c, c.child(n, 0), depth + 1);
       if (lipd >= 0) c.lip_pop(lipd);

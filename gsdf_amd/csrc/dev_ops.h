@@ -59,12 +59,7 @@ enum DevOp : uint32_t {
   D_TRANSLATE,     // tx ty tz
   D_SCALE_PRE,     // inv
   D_SYMMETRY,      // bits
-  D_TRANSFORM,     // m00 m01 m02 m03 m10 .. m23 (12), sp. sp != 0: the matrix has coefficients that are exactly 0 (bit k) or 1 (bit
-                   // 12 + k) and bit 24 says the short form is worth taking: a row ((a x + b y) + c z) + d (Mat4.MulPosition, left
-                   // to right) equals the sum of its non-zero terms bit for bit as long as every partial sum a dropped +-0 would
-                   // have been added to is non-zero (x + +-0 = x for x != 0) and x, y, z are finite (0 * Inf = NaN); 1 * v = v
-                   // always. The wave takes the short form if that holds for all its points, else the full one (same bits).
-                   // A rotation about z with no translation: 7 operations instead of 21.
+  D_TRANSFORM,     // m00 m01 m02 m03 m10 .. m23 (12)
   D_TWIST,         // k
   D_ROT2D,         // x00 x01 x10 x11
   D_EXTRUDE_PRE,   // h/2            slot <- |z|-h/2
@@ -154,7 +149,7 @@ static const uint8_t kDevOpParams[D_OP_COUNT] = {
     /*SPHERE*/ 1, /*BOX*/ 4, /*BOXFRAME*/ 4, /*TORUS*/ 2, /*CYL0*/ 2, /*CYLR*/ 3, /*HEX*/ 3,
     /*LINE2D*/ 6, /*ARC2D*/ 6, /*QUADBEZIER*/ 13, /*CIRCLE*/ 1, /*EQTRI*/ 2, /*RECT*/ 2, /*DIAMOND*/ 6, /*X2D*/ 2,
     /*HEX2D*/ 2, /*OCT2D*/ 2, /*ELLIPSE*/ 2, /*POLY*/ 3, /*LINES*/ 2,
-    /*TRANSLATE*/ 3, /*SCALE_PRE*/ 1, /*SYMMETRY*/ 1, /*TRANSFORM*/ 13, /*TWIST*/ 1, /*ROT2D*/ 4,
+    /*TRANSLATE*/ 3, /*SCALE_PRE*/ 1, /*SYMMETRY*/ 1, /*TRANSFORM*/ 12, /*TWIST*/ 1, /*ROT2D*/ 4,
     /*EXTRUDE_PRE*/ 1, /*REVOLVE_PRE*/ 1, /*SCREW_PRE*/ 6, /*ELONGATE_PRE*/ 3, /*ELONGATE2D_PRE*/ 2,
     /*ARRAY_PRE*/ 9, /*ARRAY2D_PRE*/ 6, /*CIRC_PRE*/ 4, /*LOADP2_SUB*/ 2,
     /*MULR*/ 1, /*SHELL_POST*/ 1, /*ADDR*/ 1, /*ANNULUS*/ 1, /*EXTRUDE_POST*/ 0, /*MAXR_SLOT*/ 0, /*ADDR_SLOT*/ 0,

@@ -1023,9 +1023,11 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   hc = MeshCounters{};
   MeshCounters* d_ctr = nullptr;
   constexpr size_t kCtrBytes = (sizeof(MeshCounters) + 255) & ~(size_t)255;  // the group sums follow the counters: one memset clears both
-  bool used_brick = false, two_kernel = false;
+  bool used_brick = false, two_kernel = false, ctr_on_host = false;
+  static const bool ctr_from_kernel = [] { const char* e = getenv("GSDF_HIP_CTR_FROM_KERNEL"); return !e || atoi(e) != 0; }();  // developer knob (A/B timing)
   float ms01 = 0, ms12 = 0, ms13 = 0;
   for (int attempt = 0;; attempt++) {
+    ctr_on_host = false;
     HIP_TRYM(p->q0.ensure(qcap * sizeof(Cube)));
     HIP_TRYM(p->q1.ensure(qcap * sizeof(Cube)));
     const uint64_t cap0 = p->q0.cap / sizeof(Cube), cap1 = p->q1.cap / sizeof(Cube);
@@ -1176,7 +1178,9 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
         static const int march_bpc = [] { const char* e = getenv("GSDF_HIP_MARCH_BPC"); return e ? atoi(e) : 7; }();  // tuning knob (7 fit a CU)
         const size_t lds_march = (size_t)11 * BLOCK * 4 + 5 * BLOCK * 4 + 256 * 16 + (BLOCK + 1) * 4 + 8 * 4 + 8 + 14 * 8;
         hipLaunchKernelGGL(march_records_kernel, dim3(grid_for(nblk_q, p->num_cu, march_bpc)), dim3(BLOCK), lds_march, s, d_hdr, d_rec,
-                           d_psum, (unsigned long long)nblk, lq, ox, oy, oz, res, m->d_tris, (uint64_t)tcap, d_ctr);
+                           d_psum, (unsigned long long)nblk, lq, ox, oy, oz, res, m->d_tris, (uint64_t)tcap, d_ctr,
+                           ctr_from_kernel ? (MeshCounters*)p->h_ctr : (MeshCounters*)nullptr);
+        ctr_on_host = ctr_from_kernel;
       } else if (lq == 3 && lk == 4 && opts.share_corners) {
         // exact corner sharing: one wave per level-3 brick
         const size_t lds_b = (size_t)(p->prog.nslots * 4) * BLOCK * sizeof(float) + 4096 + TRI_STAGE * 36 + 32 + 4 * 512 * 4 + 4 * 24 * 4;
@@ -1200,7 +1204,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
       HIP_TRYM(hipGetLastError());
     }
     HIP_TRYM(hipEventRecord(ev2, s));
-    HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));
+    if (!ctr_on_host) HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));  // (else march_records_kernel wrote them)
     hipEvent_t evr = p->ev[4];
     HIP_TRYM(hipEventRecord(evr, s));
     static const bool clear_ahead = [] { const char* e = getenv("GSDF_HIP_CLEAR_AHEAD"); return !e || atoi(e) != 0; }();

@@ -862,7 +862,7 @@ __global__ void __launch_bounds__(BLOCK, 7) march_records_kernel(const uint32_t*
                                                               const unsigned long long* __restrict__ psum,
                                                               unsigned long long n_blocks_cap, int lq, float ox, float oy, float oz,
                                                               float res, float* __restrict__ tris, uint64_t tri_cap,
-                                                              MeshCounters* __restrict__ ctr) {
+                                                              MeshCounters* __restrict__ ctr, MeshCounters* __restrict__ host_ctr) {
   float* s_col = g_smem;                                       // [BLOCK][11]: 8 distances + origin of the chunk's records (odd stride:
                                                                // the values of one record, read together by neighbouring lanes, sit in 11 banks)
   uint32_t* s_own = (uint32_t*)(s_col + 11 * BLOCK);           // [5 * BLOCK] triangle -> table offset (index*16 + 3*number) | record << 12
@@ -896,6 +896,18 @@ __global__ void __launch_bounds__(BLOCK, 7) march_records_kernel(const uint32_t*
   }
   unsigned long long R, T;
   const unsigned long long br = block_scan_u64(lr, s_u64, &R) - lr, bt = block_scan_u64(lt, s_u64, &T) - lt;
+  // This is the mesh's last kernel: its first workgroup hands the counters to the host itself (pinned, device-mapped memory;
+  // visible when the kernel has completed) -- the D2H copy that used to follow cost 4 us plus the gap in front of it.
+  if (host_ctr != nullptr && blockIdx.x == 0) {
+    const unsigned long long* src = (const unsigned long long*)ctr;
+    unsigned long long* dst = (unsigned long long*)host_ctr;
+    for (unsigned k = threadIdx.x; k < (unsigned)(sizeof(MeshCounters) / 8); k += BLOCK) {
+      unsigned long long v = src[k];
+      if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_tris) / 8)) v = T;
+      if (k == (unsigned)(__builtin_offsetof(MeshCounters, overflow) / 8) && T > tri_cap) v = 1ull;
+      dst[k] = v;
+    }
+  }
   if (R == 0ull) return;  // no surface here (n_tris stays 0)
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     ctr->n_tris = T;

@@ -395,41 +395,3 @@ def test_registered_buffers_pipelined_and_concurrent_host_calls(gpu):
     with pytest.raises(ValueError):
         gpu.SDF3HIP(b.NewSphere(1)).Evaluate(np.zeros((4, 3), np.float32), np.zeros(4, np.float64))   # wrong dist dtype: refused
 
-
-def test_sparse_transforms_short_form_is_exact(gpu):
-    """D_TRANSFORM's short form (dev_ops.h): a matrix with exact zeros / ones (a rotation about an axis, a quarter turn, a pure
-    translation, an axis scaling) is applied as the sum of its non-zero terms where that provably equals Mat4.MulPosition's
-    ((a x + b y) + c z) + d bit for bit -- every partial sum a dropped +-0 would have joined is non-zero -- and in full
-    otherwise (wave vote). Points with exact zeros, signed zeros and cancelling coordinates force the fallback; distances and
-    the sign of every zero that reaches the child (atan2 of a circular array, a screw) must match the oracle."""
-    b = Builder()
-    box = b.NewBox(1.0, 0.6, 0.8, 0.05)
-    screw_like = b.CircularArray(b.Translate(b.NewCylinder(0.2, 1.0, 0.0), 0.8, 0, 0), 5, 6)   # atan2 sees the signs of zeros
-    eye = np.eye(4, dtype=np.float32)
-    tr = eye.copy(); tr[:3, 3] = [0.3, -0.2, 0.1]
-    sc = eye.copy(); sc[0, 0], sc[2, 2] = 2.0, 0.5
-    shear = eye.copy(); shear[0, 1] = 0.4
-    shapes = [b.Rotate(box, 0.7, (0, 0, 1)), b.Rotate(box, -1.1, (1, 0, 0)), b.Rotate(box, 2.3, (0, 1, 0)),
-              b.Rotate(screw_like, np.pi / 2, (1, 0, 0)), b.Rotate(screw_like, np.pi, (0, 0, 1)), b.Rotate(screw_like, 0.4, (0, 0, 1)),
-              b.Transform(screw_like, tr.reshape(-1)), b.Transform(box, sc.reshape(-1)), b.Transform(screw_like, shear.reshape(-1)),
-              b.Translate(b.Rotate(b.Translate(screw_like, 0.5, 0, 0), 0.9, (0, 0, 1)), -0.5, 0.2, 0),
-              b.Scene("knurled-cylinder")]
-    sparse = 0
-    rng = np.random.default_rng(77)
-    for k, sh in enumerate(shapes):
-        code, _ = gpu.lower(sh)
-        bb = sh.Bounds().astype(np.float32)
-        c, h = (bb[:3] + bb[3:]) / 2, (bb[3:] - bb[:3]) / 2 * np.float32(1.2)
-        p = (c + (rng.random((20000, 3), np.float32) * 2 - 1) * h).astype(np.float32)
-        g = np.float32(0.25) * rng.integers(-8, 9, (12000, 3)).astype(np.float32)        # zeros, ties, x = -y ...
-        g[::7, rng.integers(0, 3)] = np.float32(-0.0)
-        pos = np.concatenate([p, g, g[:4000] * np.float32([1, -1, 1])]).astype(np.float32)
-        dref = OracleSDF(sh.tree()).Evaluate(pos)
-        sdf = gpu.SDF3HIP(sh)
-        assert _mismatch(sdf.Evaluate(pos), dref) == 0, (k, "interpreter")
-        sdf.specialize()
-        assert _mismatch(sdf.Evaluate(pos), dref) == 0, (k, "specialised")
-        # the lowering did take the short form for this matrix? (bit 24 of the 13th parameter word)
-        from test_lowering import decode
-        sparse += sum(1 for i in decode(code) if i[0] == "D_TRANSFORM" and (int(code[i[4] + 13]) >> 24) & 1)
-    assert sparse >= 10
