@@ -141,13 +141,20 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_edges_kernel(const uint32_t* __re
       fv[3 * i] = x0; fv[3 * i + 1] = y0; fv[3 * i + 2] = z0;
     }
     const unsigned s0 = __float_as_uint(d[0]) >> 31;
+    bool act[3];
+    unsigned mine = 0;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-      const bool act = valid && ((__float_as_uint(d[1 + a]) >> 31) != s0);
-      const unsigned long long slot = wave_append(act, &ctr->n_edges);
-      if (act) {
+      act[a] = valid && ((__float_as_uint(d[1 + a]) >> 31) != s0);
+      mine += act[a] ? 1u : 0u;
+    }
+    unsigned long long slot = block_append_n(mine, &ctr->n_edges);  // one atomic per workgroup pass (was: three per wave)
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      if (act[a]) {
         if (slot < edge_cap) edges[slot] = ((unsigned)i << 2) | (unsigned)a;
         else ctr->q_overflow = 1ull;
+        slot++;
       }
     }
   }
@@ -202,14 +209,19 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_normals_kernel(const uint32_t* __
 #define DC_BLOCK 64
 // Stage 4 (PlaceVertices :52-141, leastSquaresMGS64 :152-223): per cube, rows = own active edges, then the
 // edges of the (up to 12) contributing cubes in lattice order (z,y,x) and axis order, 3 regularisation rows;
-// float64 modified Gram-Schmidt with the rows staged in LDS ([row][col][lane]; zero rows are exact no-ops).
+// float64 modified Gram-Schmidt over rows staged in LDS ([row][col][lane]; zero rows are exact no-ops). Every entry of the
+// system is a float32 value (normals, products formed in float32), so the rows are STORED as float32 -- 16 bytes per row and
+// lane instead of 32 -- and the orthonormalised columns the reference keeps in place (A[k][j] -= dot * A[k][i]; A[k][j] *= inv)
+// are recomputed from them wherever they are read: the same float64 operations on the same operands in the same order, hence
+// the same bits, for a few more multiply-adds in a kernel that waits on occupancy (36.9 -> 18.4 KB of LDS per 64 lanes:
+// 8 workgroups per CU instead of 4).
 __global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restrict__ cubes, unsigned long long cube_cap,
                                                             const float4* __restrict__ dists, const int* __restrict__ grid,
                                                             const float* __restrict__ nrm, int nshift, float ox, float oy, float oz,
                                                             float res, float sqrtLambda, float* __restrict__ fv, unsigned zplace_hi,
                                                             DCCounters* __restrict__ ctr) {
-  __shared__ double sQ[DC_ROWS][3][DC_BLOCK];
-  __shared__ double sB[DC_ROWS][DC_BLOCK];
+  __shared__ float sA[DC_ROWS][3][DC_BLOCK];
+  __shared__ float sB[DC_ROWS][DC_BLOCK];
   unsigned long long n = uniform_u64(ctr->n_cubes);
   if (n > cube_cap) n = cube_cap;
   const int nn = 1 << nshift;
@@ -226,8 +238,8 @@ __global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restri
     float mx = 0.f, my = 0.f, mz = 0.f;
     auto add_row = [&](float bx, float by, float bz, float nx, float ny, float nz) {
       const float qx = invRes * (bx - cox), qy = invRes * (by - coy), qz = invRes * (bz - coz);
-      sQ[nr][0][t] = (double)nx; sQ[nr][1][t] = (double)ny; sQ[nr][2][t] = (double)nz;
-      sB[nr][t] = (double)(nx * qx + ny * qy + nz * qz);
+      sA[nr][0][t] = nx; sA[nr][1][t] = ny; sA[nr][2][t] = nz;
+      sB[nr][t] = nx * qx + ny * qy + nz * qz;
       mx = mx + bx; my = my + by; mz = mz + bz;
       nr++;
     };
@@ -266,30 +278,56 @@ __global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restri
     for (int k = 0; k < nnb; k++) edge_row(contrib[k], caxis[k]);
     const float im = 1.f / (float)nr;
     const float bsx = invRes * (im * mx - cox), bsy = invRes * (im * my - coy), bsz = invRes * (im * mz - coz);
-    sQ[nr][0][t] = (double)sqrtLambda; sQ[nr][1][t] = 0.0; sQ[nr][2][t] = 0.0; sB[nr][t] = (double)(sqrtLambda * bsx); nr++;
-    sQ[nr][0][t] = 0.0; sQ[nr][1][t] = (double)sqrtLambda; sQ[nr][2][t] = 0.0; sB[nr][t] = (double)(sqrtLambda * bsy); nr++;
-    sQ[nr][0][t] = 0.0; sQ[nr][1][t] = 0.0; sQ[nr][2][t] = (double)sqrtLambda; sB[nr][t] = (double)(sqrtLambda * bsz); nr++;
+    sA[nr][0][t] = sqrtLambda; sA[nr][1][t] = 0.0f; sA[nr][2][t] = 0.0f; sB[nr][t] = sqrtLambda * bsx; nr++;
+    sA[nr][0][t] = 0.0f; sA[nr][1][t] = sqrtLambda; sA[nr][2][t] = 0.0f; sB[nr][t] = sqrtLambda * bsy; nr++;
+    sA[nr][0][t] = 0.0f; sA[nr][1][t] = 0.0f; sA[nr][2][t] = sqrtLambda; sB[nr][t] = sqrtLambda * bsz; nr++;
     const int K = nr;
     double R[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    for (int j = 0; j < 3; j++) {
-      for (int ii = 0; ii < j; ii++) {
-        double dot = 0;
-        for (int k = 0; k < K; k++) dot += sQ[k][ii][t] * sQ[k][j][t];
-        R[ii][j] = dot;
-        for (int k = 0; k < K; k++) sQ[k][j][t] -= dot * sQ[k][ii][t];
-      }
-      double nsq = 0;
-      for (int k = 0; k < K; k++) nsq += sQ[k][j][t] * sQ[k][j][t];
-      const double norm = __builtin_sqrt(nsq);
-      R[j][j] = norm;
-      if (norm > 1e-14) {
-        const double inv = 1.0 / norm;
-        for (int k = 0; k < K; k++) sQ[k][j][t] *= inv;
-      }
-    }
+    // leastSquaresMGS64 :152-223, column by column; qJ(k) = what the reference's A[k][J] holds once column J is done
+    // column 0: normalise
+    double nsq = 0;
+    for (int k = 0; k < K; k++) { const double a = (double)sA[k][0][t]; nsq += a * a; }
+    const double norm0 = __builtin_sqrt(nsq);
+    R[0][0] = norm0;
+    const bool have0 = norm0 > 1e-14;
+    const double inv0 = 1.0 / norm0;
+#define DC_Q0(k) (have0 ? (double)sA[k][0][t] * inv0 : (double)sA[k][0][t])
+    // column 1: minus its projection on q0, then normalise
+    double dot01 = 0;
+    for (int k = 0; k < K; k++) dot01 += DC_Q0(k) * (double)sA[k][1][t];
+    R[0][1] = dot01;
+#define DC_V1(k) ((double)sA[k][1][t] - dot01 * DC_Q0(k))
+    nsq = 0;
+    for (int k = 0; k < K; k++) { const double v = DC_V1(k); nsq += v * v; }
+    const double norm1 = __builtin_sqrt(nsq);
+    R[1][1] = norm1;
+    const bool have1 = norm1 > 1e-14;
+    const double inv1 = 1.0 / norm1;
+#define DC_Q1(k) (have1 ? DC_V1(k) * inv1 : DC_V1(k))
+    // column 2: minus its projections on q0 and (what is left) on q1, then normalise
+    double dot02 = 0;
+    for (int k = 0; k < K; k++) dot02 += DC_Q0(k) * (double)sA[k][2][t];
+    R[0][2] = dot02;
+#define DC_W2(k) ((double)sA[k][2][t] - dot02 * DC_Q0(k))
+    double dot12 = 0;
+    for (int k = 0; k < K; k++) dot12 += DC_Q1(k) * DC_W2(k);
+    R[1][2] = dot12;
+#define DC_V2(k) (DC_W2(k) - dot12 * DC_Q1(k))
+    nsq = 0;
+    for (int k = 0; k < K; k++) { const double v = DC_V2(k); nsq += v * v; }
+    const double norm2 = __builtin_sqrt(nsq);
+    R[2][2] = norm2;
+    const bool have2 = norm2 > 1e-14;
+    const double inv2 = 1.0 / norm2;
     double Qtb[3] = {0, 0, 0};
-    for (int j = 0; j < 3; j++)
-      for (int k = 0; k < K; k++) Qtb[j] += sQ[k][j][t] * sB[k][t];
+    for (int k = 0; k < K; k++) Qtb[0] += DC_Q0(k) * (double)sB[k][t];
+    for (int k = 0; k < K; k++) Qtb[1] += DC_Q1(k) * (double)sB[k][t];
+    for (int k = 0; k < K; k++) { const double v = DC_V2(k); Qtb[2] += (have2 ? v * inv2 : v) * (double)sB[k][t]; }
+#undef DC_Q0
+#undef DC_V1
+#undef DC_Q1
+#undef DC_W2
+#undef DC_V2
     double x[3];
     for (int ii = 2; ii >= 0; ii--) {
       x[ii] = Qtb[ii];
@@ -337,7 +375,7 @@ __global__ void __launch_bounds__(BLOCK) dc_quads_kernel(const Cube* __restrict_
         ok = ok && idx >= 0;
       }
     }
-    const unsigned long long slot = wave_append(ok, &ctr->n_tris);
+    const unsigned long long slot = block_append_n(ok ? 1u : 0u, &ctr->n_tris);  // one atomic per workgroup pass
     if (ok) {
       if (2 * slot + 2 <= tri_cap) {
         int o[4] = {q[0], q[1], q[2], q[3]};
