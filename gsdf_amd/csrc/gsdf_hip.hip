@@ -1024,6 +1024,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   MeshCounters* d_ctr = nullptr;
   constexpr size_t kCtrBytes = (sizeof(MeshCounters) + 255) & ~(size_t)255;  // the group sums follow the counters: one memset clears both
   bool used_brick = false, two_kernel = false, ctr_on_host = false;
+  int chain_first = levels;  // levels <= chain_first were tested by prune_kernel (one launch per level), the ones above speculatively
   static const bool ctr_from_kernel = [] { const char* e = getenv("GSDF_HIP_CTR_FROM_KERNEL"); return !e || atoi(e) != 0; }();  // developer knob (A/B timing)
   float ms01 = 0, ms12 = 0, ms13 = 0;
   for (int attempt = 0;; attempt++) {
@@ -1090,13 +1091,27 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     // S dependent ones. GSDF_HIP_PRUNE_SPEC=0 keeps one launch per level (cross-check in the tests).
     static const bool use_spec = [] { const char* e = getenv("GSDF_HIP_PRUNE_SPEC"); return !e || atoi(e) != 0; }();
     int first_level = levels;  // first level of the per-level chain
+    chain_first = levels;
+    unsigned* spec_part = nullptr;  // statistics rows of the speculative top, for the first per-level launch to add up
+    unsigned spec_rows = 0, spec_mask = 0;
+    int spec_top_S = 0;
+    auto test_mask_of = [](int pm) { return pm == 1 ? 0xffffffffu : (unsigned)pm; };
     if (use_spec) {
       const int S = levels - lq + 1 < 7 ? levels - lq + 1 : 7;
       const int last_spec = levels - (S - 1);
       unsigned n_spec = 0;
       for (int j = 0; j < S; j++) n_spec += 1u << (3 * j);
-      HIP_TRYM(p->spec_pass.ensure(n_spec));
-      const unsigned test_mask = pmask == 1 ? 0xffffffffu : (unsigned)pmask;
+      // the resolve stage's statistics: a row of 16 counts per workgroup behind the pass bytes, added up by the first per-level
+      // launch -- if there is one (else the resolve stage issues its atomics itself)
+      const unsigned rrows = (n_spec + SPEC_STAGE - 1) / SPEC_STAGE;
+      const size_t part_off = ((size_t)n_spec + 63) & ~(size_t)63;
+      HIP_TRYM(p->spec_pass.ensure(part_off + (size_t)rrows * 16 * sizeof(unsigned)));
+      const bool chain_follows = last_spec - 1 >= lq;
+      spec_part = chain_follows ? (unsigned*)((char*)p->spec_pass.p + part_off) : nullptr;
+      spec_rows = rrows;
+      spec_top_S = levels | (S << 8);
+      spec_mask = test_mask_of(pmask);
+      const unsigned test_mask = test_mask_of(pmask);
       const int shard_level = opts.shard_count > 1 ? ls : -1;
       const unsigned sgrid = grid_for(n_spec, p->num_cu, 8);
       if (p->f_prune_spec) {
@@ -1109,9 +1124,10 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
       }
       HIP_TRYM(hipGetLastError());
       hipLaunchKernelGGL(prune_resolve_kernel, dim3((n_spec + SPEC_STAGE - 1) / SPEC_STAGE), dim3(BLOCK), 0, s, (const uint8_t*)p->spec_pass.p, levels, S,
-                         n_spec, test_mask, (Cube*)q[last_spec & 1]->p, (unsigned long long)capq[last_spec & 1], d_ctr);
+                         n_spec, test_mask, (Cube*)q[last_spec & 1]->p, (unsigned long long)capq[last_spec & 1], d_ctr, spec_part);
       HIP_TRYM(hipGetLastError());
       first_level = last_spec - 1;
+      chain_first = first_level;
     }
     for (int level = first_level; level >= lq; level--) {
       const int expand = level != levels;
@@ -1124,13 +1140,15 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
                            (const Cube*)q[(level + 1) & 1]->p, (unsigned long long)capq[(level + 1) & 1], (int)expand, (int)level,
                            (int)prune_cols, (int)p->prog.nslots, ox, oy, oz, res, (int)do_test,
                            (Cube*)q[level & 1]->p, (unsigned long long)capq[level & 1], (int)((opts.shard_count > 1 && level == ls) ? 1 : 0),
-                           (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr));
+                           (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr, (const unsigned*)(level == first_level ? spec_part : nullptr),
+                           (unsigned)spec_rows, (int)spec_top_S, (unsigned)spec_mask));
       } else
       hipLaunchKernelGGL(prune_kernel, dim3(grid_for(bound, p->num_cu, prune_bpc)), dim3(BLOCK), lds_prune, s, p->d_code,
                          (const Cube*)q[(level + 1) & 1]->p, (unsigned long long)capq[(level + 1) & 1], expand, level, prune_cols,
                          p->prog.nslots, ox, oy, oz, res, do_test, (Cube*)q[level & 1]->p,
                          (unsigned long long)capq[level & 1], (opts.shard_count > 1 && level == ls) ? 1 : 0,
-                         (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr);
+                         (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr, (const unsigned*)(level == first_level ? spec_part : nullptr),
+                         spec_rows, spec_top_S, spec_mask);
       HIP_TRYM(hipGetLastError());
     }
     HIP_TRYM(hipEventRecord(ev1, s));
@@ -1240,11 +1258,14 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   uint64_t evals_prune = 0, pruned = 0;
   for (int level = levels; level >= lq; level--) {
     evals_prune += hc.n_items[level];
-    if (hc.n_items[level]) pruned += (hc.n_items[level] - hc.n_pass[level]) << (3 * (level - 1));  // DecomposesTo(1) = 8^(level-1)
+    // cubes that passed their test: counted apart only where "passed" and "kept by this rank" differ (prune_kernel)
+    const bool dealt_here = opts.shard_count > 1 && level == ls;
+    const uint64_t passed = (level <= chain_first && !dealt_here) ? hc.n_level[level] : hc.n_pass[level];
+    if (hc.n_items[level]) pruned += (hc.n_items[level] - passed) << (3 * (level - 1));  // DecomposesTo(1) = 8^(level-1)
   }
   const uint64_t n_leaves = hc.n_level[lq] << (3 * (lq - 1));
   const uint64_t evals_leaf = used_brick ? hc.n_points  // distinct lattice points evaluated once each
-                                         : n_leaves * (uint64_t)lk + (uint64_t)(8 - lk) * hc.n_cont;  // evaluations actually executed
+                                         : n_leaves * (uint64_t)lk + (uint64_t)(8 - lk) * (two_kernel && lq == 3 ? n_leaves : hc.n_cont);  // evaluations actually executed (a column brick always evaluates all eight rows: leaf_eval_kernel counts nothing)
   m->st.n_tris = hc.n_tris;
   m->st.evals = evals_prune + evals_leaf;
   m->st.evals_prune = evals_prune;

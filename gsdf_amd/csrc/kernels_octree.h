@@ -22,9 +22,29 @@ __global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict
                                                       float oy, float oz, float res,
                                                       int do_test, Cube* __restrict__ out, unsigned long long out_cap,
                                                       int shard_here, unsigned shard_rank, unsigned shard_count,
-                                                      MeshCounters* __restrict__ ctr) {
+                                                      MeshCounters* __restrict__ ctr, const unsigned* __restrict__ spec_part,
+                                                      unsigned spec_rows, int spec_top_S, unsigned spec_mask) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
+  // The first launch behind the speculative top also adds up that stage's statistics: prune_resolve_kernel leaves them as one
+  // row of 16 counts per workgroup (items and passes of up to 8 levels) instead of issuing 14 atomics per workgroup on two
+  // cache lines (1 000 of its 1 200 atomics, 9 of its 14 us). One workgroup, off the other workgroups' critical path.
+  if (spec_part != nullptr && blockIdx.x == 0) {  // block-uniform
+    __shared__ unsigned s_sum[16];
+    if (threadIdx.x < 16u) s_sum[threadIdx.x] = 0u;
+    __syncthreads();
+    unsigned acc = 0;  // column threadIdx.x & 15 of rows threadIdx.x >> 4, + 16, ...: independent loads (a serial walk of the rows by 16 threads took 15 us)
+    for (unsigned r = threadIdx.x >> 4; r < spec_rows; r += BLOCK / 16) acc += spec_part[r * 16u + (threadIdx.x & 15u)];
+    if (acc) atomicAdd(&s_sum[threadIdx.x & 15u], acc);
+    __syncthreads();
+    if (threadIdx.x < 16u) {
+      const int j = (int)(threadIdx.x >> 1), top = spec_top_S & 0xff, S = spec_top_S >> 8, lv = top - j;
+      if (j < S) {
+        if (threadIdx.x & 1u) ctr->n_pass[lv] = (unsigned long long)s_sum[threadIdx.x];
+        else if (lv >= 3 && ((spec_mask >> lv) & 1u) != 0u) ctr->n_items[lv] = (unsigned long long)s_sum[threadIdx.x];
+      }
+    }
+  }
   Cube* s_q = (Cube*)(g_smem + (size_t)(ncols > 0 ? ncols : 1) * 2 * BLOCK);
   unsigned* s_w = (unsigned*)(s_q + PRUNE_STAGE);  // [0..3] wave totals, [4..7] per-wave "passed the test" counts
   unsigned long long* s_base = (unsigned long long*)(s_w + 8);
@@ -97,13 +117,17 @@ __global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict
     __syncthreads();  // s_w is rewritten next iteration; s_q complete before a flush reads it
   }
   if (cur) flush();
-  // statistics: one atomic per workgroup (the kernel cannot retire before its atomics do: 4 per workgroup on one
-  // word were 46 us of the level-3 launch)
-  if (lane == 0) s_w[4 + wave] = (unsigned)my_pass;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned long long t = (unsigned long long)s_w[4] + s_w[5] + s_w[6] + s_w[7];
-    if (t) atomicAdd(&ctr->n_pass[level], t);
+  // statistics. "Passed the test" differs from "kept" (n_level, counted by the flushes) only at the level where bricks are
+  // dealt to ranks; everywhere else the host takes n_level for it and this atomic is not issued: a counter word serves ~70-90
+  // returning or retiring atomics per microsecond, and one flush + one statistics atomic per workgroup were what the level
+  // kernels' time consisted of (Level 3: 1024 workgroups, 2 x 1024 atomics, 24.6 us).
+  if (shard_here) {
+    if (lane == 0) s_w[4 + wave] = (unsigned)my_pass;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned long long t = (unsigned long long)s_w[4] + s_w[5] + s_w[6] + s_w[7];
+      if (t) atomicAdd(&ctr->n_pass[level], t);
+    }
   }
 }
 
@@ -186,7 +210,7 @@ __global__ void __launch_bounds__(BLOCK) prune_spec_kernel(const uint32_t* __res
 #define SPEC_STAGE 2048
 __global__ void __launch_bounds__(BLOCK) prune_resolve_kernel(const uint8_t* __restrict__ pass, int top, int S, unsigned n_spec,
                                                               unsigned test_mask, Cube* __restrict__ out, unsigned long long out_cap,
-                                                              MeshCounters* __restrict__ ctr) {
+                                                              MeshCounters* __restrict__ ctr, unsigned* __restrict__ part) {
   __shared__ Cube s_q[SPEC_STAGE];
   __shared__ unsigned s_n, s_items[8], s_pass[8];
   __shared__ unsigned long long s_base;
@@ -222,11 +246,15 @@ __global__ void __launch_bounds__(BLOCK) prune_resolve_kernel(const uint8_t* __r
   const unsigned n = s_n;
   if (threadIdx.x == 0) {
     s_base = n ? atomicAdd(&ctr->n_level[top - (S - 1)], (unsigned long long)n) : 0ull;
-    for (int j = 0; j < S && j < 8; j++) {
-      const int level = top - j;
-      const bool tested = level >= 3 && ((test_mask >> level) & 1u) != 0u;
-      if (s_items[j] && tested) atomicAdd(&ctr->n_items[level], (unsigned long long)s_items[j]);
-      if (s_pass[j]) atomicAdd(&ctr->n_pass[level], (unsigned long long)s_pass[j]);
+    if (part != nullptr) {  // statistics as a row of counts; the next launch adds the rows up (prune_kernel)
+      for (int j = 0; j < 8; j++) { part[blockIdx.x * 16u + 2u * j] = s_items[j]; part[blockIdx.x * 16u + 2u * j + 1u] = s_pass[j]; }
+    } else {
+      for (int j = 0; j < S && j < 8; j++) {
+        const int level = top - j;
+        const bool tested = level >= 3 && ((test_mask >> level) & 1u) != 0u;
+        if (s_items[j] && tested) atomicAdd(&ctr->n_items[level], (unsigned long long)s_items[j]);
+        if (s_pass[j]) atomicAdd(&ctr->n_pass[level], (unsigned long long)s_pass[j]);
+      }
     }
     if (n > SPEC_STAGE) ctr->q_overflow = 1ull;  // cannot happen: the host sizes the grid so that a slice is at most SPEC_STAGE cubes
   }
@@ -608,7 +636,16 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
 // ---------------------------------------------------------------------------------------------------------------------
 #define REC_WORDS 10            // dwords per record
 #define REC_BLOCK (64 * REC_WORDS)  // dwords per 64-leaf block
-#define MARCH_GROUP 64              // blocks per entry of the group sums (records, triangles) the evaluating kernel accumulates
+#define MARCH_GROUP 64              // blocks per entry of the group sums (records, triangles, active leaves) the evaluating kernel accumulates
+// One 64-bit word per group: records in bits 0..19 (<= 64 blocks x 64), triangles in bits 20..41 (<= 5 per record), leaves
+// that passed the corner-0 test in bits 42..63 (<= 4096): the fields cannot carry into each other. The statistics ride on the
+// same fire-and-forget atomic as the offsets -- spread over thousands of words -- because as three atomics per workgroup on
+// two counter lines they were what bounded the kernel for a cheap tree: 16 384 workgroups x 3 at ~9 ns each = npt-flange's
+// whole 0.46 ms (without them 0.42 ms, and the instruction savings of this round finally show).
+#define PSUM_PACK(r, t, a) ((unsigned long long)(r) | ((unsigned long long)(t) << 20) | ((unsigned long long)(a) << 42))
+#define PSUM_REC(v) ((unsigned)((v) & 0xfffffull))
+#define PSUM_TRI(v) ((unsigned)(((v) >> 20) & 0x3fffffull))
+#define PSUM_ACT(v) ((unsigned)((v) >> 42))
 
 // UCUBE: lq == 3 (every mesh of three levels or more): the 64 leaves of a wave pass are one level-3 cube.
 // NTLDS: the triangles-per-case table sits in LDS behind the interpreter's columns; false when exactly those 256 bytes would
@@ -650,7 +687,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
   const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
   if (n_cubes > cube_cap) n_cubes = cube_cap;                  // queue overflowed: host reruns with larger queues
   const uint64_t n_leaves = uniform_u64(n_cubes << (3 * sh));
-  unsigned my_active = 0, my_cont = 0, my_cut = 0;  // wave-uniform (SGPRs)
+  unsigned my_cont = 0;  // wave-uniform (SGPR); only the leaf-per-lane form (!UCUBE) counts it: a column brick always goes on
   const uint64_t step = (uint64_t)gridDim.x * BLOCK;
   // UCUBE: the 64 leaves of a wave pass belong to ONE cube (and n_leaves is a multiple of 64), so the cube is a scalar load --
   // issued one pass ahead: a wave has ~5 passes and the load is a trip to L2/HBM it would otherwise sit out at every start
@@ -664,6 +701,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
     const uint64_t i = base + threadIdx.x;
     const bool valid = UCUBE ? uniform_u64(base + (threadIdx.x & ~63u)) < n_leaves : i < n_leaves;
     Cube lf = {0, 0, 0, 0};
+    unsigned nact = 0;  // leaves of this wave pass that pass the corner-0 test (wave-uniform)
     const unsigned long long cw = cw_next;
     if (UCUBE) {
       cw_next = cube_word(base + step);
@@ -734,8 +772,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
         index |= (dc[c] < 0.f ? 1u : 0u) << c;
       }
       pass = dm::absf(dc[0]) <= cubeDiag;
-      my_active += (unsigned)__builtin_popcountll(__ballot(pass));
-      my_cont += 64u;
+      nact = (unsigned)__builtin_popcountll(__ballot(pass));
     } else {
       const float x0 = ox + res * (float)lf.x, y0 = oy + res * (float)lf.y, z0 = oz + res * (float)lf.z;
       const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;  // Box max = origin + size
@@ -767,7 +804,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
           const unsigned long long pmask = __ballot(pass);
           if (pmask == 0ull) break;  // wave-uniform
           const unsigned long long vmask = __ballot(valid);
-          my_active += (unsigned)__builtin_popcountll(pmask);
+          nact = (unsigned)__builtin_popcountll(pmask);
           my_cont += (unsigned)__builtin_popcountll(vmask);
         }
       }
@@ -779,7 +816,6 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
     const unsigned long long cm = __ballot(cut);
     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
     const uint64_t blk = uniform_u64((base + (uint64_t)(threadIdx.x & ~63u)) >> 6);  // block = wave pass = 64 consecutive leaves
-    my_cut += (unsigned)__builtin_popcountll(cm);
     if (blk < n_blocks_cap) {
       // header word: records | triangles << 8; the same pair is added to the sum of the block's group of MARCH_GROUP
       // blocks (low / high half of one 64-bit word: a fire-and-forget atomic, one per wave pass the surface cuts), from which
@@ -798,7 +834,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
         const uint32_t nrec = (uint32_t)__builtin_popcountll(cm);
         hdr[blk] = nrec | (ntri << 8);
 #ifndef GSDF_EXP_NO_PSUM
-        if (nrec) atomicAdd(&psum[blk / MARCH_GROUP], (unsigned long long)nrec | ((unsigned long long)ntri << 32));
+        if (nact) atomicAdd(&psum[blk / MARCH_GROUP], PSUM_PACK(nrec, ntri, nact));  // (a cut leaf is an active one: nrec <= nact)
 #endif
       }
       if (cut) {
@@ -811,19 +847,18 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
       }
     }
   }
-  // statistics: three atomics per workgroup
-  unsigned* s_stat = (unsigned*)g_smem;
-  __syncthreads();  // everyone is done with the interpreter columns
-  if ((threadIdx.x & 63u) == 0u) {
-    s_stat[3 * (threadIdx.x >> 6)] = my_active; s_stat[3 * (threadIdx.x >> 6) + 1] = my_cont; s_stat[3 * (threadIdx.x >> 6) + 2] = my_cut;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned long long a = (unsigned long long)s_stat[0] + s_stat[3] + s_stat[6] + s_stat[9];
-    const unsigned long long c = (unsigned long long)s_stat[1] + s_stat[4] + s_stat[7] + s_stat[10];
-    const unsigned long long u = (unsigned long long)s_stat[2] + s_stat[5] + s_stat[8] + s_stat[11];
-    if (c) { atomicAdd(&ctr->n_active, a); atomicAdd(&ctr->n_cont, c); }
-    if (u) atomicAdd(&ctr->n_cut, u);
+  // statistics: active and cut leaves travel in the group sums (PSUM_PACK) and are totalled by march_records_kernel; "leaves
+  // whose wave went on to the remaining corners" is every leaf for column bricks (the host knows) and counted here only for
+  // the leaf-per-lane form of meshes with fewer than three levels (a handful of workgroups)
+  if (!UCUBE) {
+    unsigned* s_stat = (unsigned*)g_smem;
+    __syncthreads();  // everyone is done with the interpreter columns
+    if ((threadIdx.x & 63u) == 0u) s_stat[threadIdx.x >> 6] = my_cont;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned long long c = (unsigned long long)s_stat[0] + s_stat[1] + s_stat[2] + s_stat[3];
+      if (c) atomicAdd(&ctr->n_cont, c);
+    }
   }
 }
 
@@ -887,15 +922,20 @@ __global__ void __launch_bounds__(BLOCK, 7) march_records_kernel(const uint32_t*
   uint64_t e0 = (uint64_t)threadIdx.x * per, e1 = e0 + per;
   if (e0 > n_grp) e0 = n_grp;
   if (e1 > n_grp) e1 = n_grp;
-  unsigned long long lr = 0, lt = 0;
+  unsigned long long lr = 0, lt = 0, la = 0;
 #pragma unroll 4
   for (uint64_t e = e0; e < e1; e++) {
     const unsigned long long v = psum[e];
-    lr += (unsigned)v;
-    lt += v >> 32;
+    lr += PSUM_REC(v);
+    lt += PSUM_TRI(v);
+    la += PSUM_ACT(v);
   }
-  unsigned long long R, T;
+  unsigned long long R, T, A = 0;
   const unsigned long long br = block_scan_u64(lr, s_u64, &R) - lr, bt = block_scan_u64(lt, s_u64, &T) - lt;
+  if (blockIdx.x == 0) {  // the statistics the evaluating kernel sent along: cut leaves = records, active leaves
+    (void)block_scan_u64(la, s_u64, &A);
+    if (threadIdx.x == 0) { ctr->n_cut = R; ctr->n_active = A; }
+  }
   // This is the mesh's last kernel: its first workgroup hands the counters to the host itself (pinned, device-mapped memory;
   // visible when the kernel has completed) -- the D2H copy that used to follow cost 4 us plus the gap in front of it.
   if (host_ctr != nullptr && blockIdx.x == 0) {
@@ -904,6 +944,8 @@ __global__ void __launch_bounds__(BLOCK, 7) march_records_kernel(const uint32_t*
     for (unsigned k = threadIdx.x; k < (unsigned)(sizeof(MeshCounters) / 8); k += BLOCK) {
       unsigned long long v = src[k];
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_tris) / 8)) v = T;
+      if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_cut) / 8)) v = R;
+      if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_active) / 8)) v = A;
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, overflow) / 8) && T > tri_cap) v = 1ull;
       dst[k] = v;
     }
@@ -924,12 +966,12 @@ __global__ void __launch_bounds__(BLOCK, 7) march_records_kernel(const uint32_t*
       unsigned long long acc = br, tacc = bt;
       for (uint64_t e = e0; e < e1; e++) {
         const unsigned long long v = psum[e];
-        if (acc + (unsigned)v >= X) {
+        if (acc + PSUM_REC(v) >= X) {
           s_u64[4 + 3 * w] = e; s_u64[5 + 3 * w] = acc; s_u64[6 + 3 * w] = tacc;
           break;
         }
-        acc += (unsigned)v;
-        tacc += v >> 32;
+        acc += PSUM_REC(v);
+        tacc += PSUM_TRI(v);
       }
     }
   }
