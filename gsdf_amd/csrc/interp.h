@@ -1172,7 +1172,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         const bool has_outer = oslot != 0xffffu;  // wave-uniform
         KLOOP { a[kp] = LDSF(slot); cc[kp] = has_outer ? LDSF(oslot) : 0.0f; }
         region_lb_box<K, 2>(pv, PF(0), PF(1), 0.f, PF(2), PF(3), 0.f, L);
-        if (!LIP && gate_far<K, 2>(pv, a, L, PF(4), PF(5), cc, has_outer, PF(7), PF(8))) {  // (a skip decided at the centre says nothing about the cube)
+        if (LIP) KLOOP L[kp] = L[kp] - lipR;  // interval mode: the bound over the whole ball (L is 1-Lipschitz), against both ends of a
+        if (gate_far<K, 2>(pv, a, L, PF(4), PF(5), cc, has_outer, PF(7), PF(8))) {
           KLOOP Rv[kp] = L[kp];
           pc += PU(9);
         } else {
@@ -1186,7 +1187,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         const bool has_outer = oslot != 0xffffu;
         KLOOP { a[kp] = LDSF(slot); cc[kp] = has_outer ? LDSF(oslot) : 0.0f; }
         region_lb_box<K, 3>(pv, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5), L);
-        if (!LIP && gate_far<K, 3>(pv, a, L, PF(6), PF(7), cc, has_outer, PF(9), PF(10))) {
+        if (LIP) KLOOP L[kp] = L[kp] - lipR;
+        if (gate_far<K, 3>(pv, a, L, PF(6), PF(7), cc, has_outer, PF(9), PF(10))) {
           KLOOP Rv[kp] = L[kp];
           pc += PU(11);
         } else {
@@ -1200,7 +1202,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         const bool has_outer = oslot != 0xffffu;
         KLOOP { a[kp] = LDSF(slot); cc[kp] = has_outer ? LDSF(oslot) : 0.0f; }
         region_lb_zcyl<K>(pv, hxy, use_hxy, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5), PF(6), L);
-        if (!LIP && gate_far<K, 3>(pv, a, L, PF(7), PF(8), cc, has_outer, PF(10), PF(11))) {
+        if (LIP) KLOOP L[kp] = L[kp] - lipR;
+        if (gate_far<K, 3>(pv, a, L, PF(7), PF(8), cc, has_outer, PF(10), PF(11))) {
           KLOOP Rv[kp] = L[kp];
           pc += PU(12);
         } else {
@@ -1214,7 +1217,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         const bool has_outer = oslot != 0xffffu;
         KLOOP { a[kp] = LDSF(slot); cc[kp] = has_outer ? LDSF(oslot) : 0.0f; }
         region_lb_obox<K, 3>(pv, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5), PF(6), PF(7), L);
-        if (!LIP && gate_far<K, 3>(pv, a, L, PF(8), PF(9), cc, has_outer, PF(11), PF(12))) {
+        if (LIP) KLOOP L[kp] = L[kp] - lipR;
+        if (gate_far<K, 3>(pv, a, L, PF(8), PF(9), cc, has_outer, PF(11), PF(12))) {
           KLOOP Rv[kp] = L[kp];
           pc += PU(13);
         } else {

