@@ -135,6 +135,10 @@ enum DevOp : uint32_t {
   //      distances, yield value -+ lipR; monotone instructions act on the two points unchanged; the rest cross them
   //      (difference, xor, |d|). For a tree of primitives under rigid motions and min / max the bounds are d -+ h exactly,
   //      i.e. the reference's predicate. The oracle does the same with doubled batches (oracle/orc_eval.c: lipctx).
+  //      Gates work in interval mode too, on the bound over the whole ball: a region's lower bound L is 1-Lipschitz, so the
+  //      child is >= L(centre) - lipR everywhere in the ball; the test runs on that against both ends of `a` (the two points),
+  //      and the substitute (both ends = L - lipR) leaves the combine's interval what the ungated evaluation gives, bit for
+  //      bit (min / max select a's ends; a clamped blend weight multiplies the substitute by 0) -- the oracle has no gates.
   D_LIP_PUSH,   // (slot = nesting depth)  interval stack[depth] <- lipR           (before a map that stretches)
   D_LIP_POP,    // (slot = nesting depth)  lipR <- interval stack[depth]           (after its subtree)
   D_LIP_MUL,    // f : lipR *= f  (non-rigid D_TRANSFORM / D_ROT2D: largest singular value, rounded up)

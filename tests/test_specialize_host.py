@@ -34,7 +34,7 @@ def test_generated_source_follows_the_program():
                                       "D_GATE3D", "D_CYL0", "D_SAVER", "D_GATEZC", "D_LIP_PUSH", "D_SCREW_PRE", "D_LIP_WRAP", "D_POLY2D", "D_LIP_POP", "D_MAXR_SLOT",
                                       "D_COMBINE_DIFF", "D_COMBINE_SUNION", "D_COMBINE_DIFF", "D_MULR"]
     # the two gates are structured ifs around their children: `if (gate_far) R = L; else { child }`, closed before the combine
-    assert src.count("if (!LIP && gate_far<K, 3>(") == 2 and src.count("}}  // end of gated child") == 2
+    assert src.count("if (gate_far<K, 3>(") == 2 and src.count("if (LIP) KLOOP L[kp] = L[kp] - lipR;") == 2 and src.count("}}  // end of gated child") == 2
     assert src.index("// end of gated child") < src.index("D_COMBINE_DIFF")
     assert [int(p) for p, _ in blocks] == sorted(int(p) for p, _ in blocks)
     assert "switch (op)" not in src and "readfirstlane" not in src
