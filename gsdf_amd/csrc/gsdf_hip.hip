@@ -491,10 +491,11 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
     // a fifth workgroup per CU where the LDS has room for it (npt-flange's 7 slots): the 96-register build is taken if the
     // compiler reaches it without scratch (-3 % on the evaluating kernel); built beside the 128-register one, same process
     if (!fused_leaf() && lk == 4 && lw == 4 && 5 * lds_m <= (size_t)160 * 1024) names.push_back("leaf_eval_kernel<4, 5, true, true, false>");
-    // both passes of a column brick in one body where enough of the program depends on x and y alone (an atan2 or several
-    // hypots: npt-flange) -- taken, ahead of the others, if the compiler reaches it without scratch (-4 % on that kernel)
+    // both passes of a column brick in one body -- taken, ahead of the others, if the compiler reaches it without scratch: -7 %
+    // where much of the program depends on x and y alone (an atan2, several hypots: npt-flange), -1..2 % elsewhere
     static const bool both_off = [] { const char* e = getenv("GSDF_HIP_NO_BOTH_PASSES"); return e && atoi(e) != 0; }();  // developer knob (A/B timing)
-    if (!fused_leaf() && !both_off && lk == 4 && gsdf_dev::spec_xy_shared_weight(p->prog) >= 4) {
+    static const int both_min = [] { const char* e = getenv("GSDF_HIP_BOTH_MIN_WEIGHT"); return e ? atoi(e) : 0; }();  // developer knob. 0: always -- programs without x,y-only work gain 1-2 % too (bolt 1.029 -> 1.007 ms, knurled-cylinder 3.19 -> 3.16: one body of eight points schedules a little better than two of four)
+    if (!fused_leaf() && !both_off && lk == 4 && gsdf_dev::spec_xy_shared_weight(p->prog) >= both_min) {
       both_at = (int)names.size();
       names.push_back(std::string("leaf_eval_kernel<4, ") + std::to_string(lw) + (p->leaf_nt_in_lds() ? ", true, true, true>" : ", true, false, true>"));
     }
