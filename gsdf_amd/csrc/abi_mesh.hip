@@ -1,0 +1,921 @@
+// abi_mesh.hip -- C ABI (include/gsdf_hip.h), mesher side: glrender.Octree + marchCubes, FlatRenderer and
+// DualContourRenderer on device, and the accessors of the resulting mesh (ReadTriangles drain, STL, pinned host views).
+// Kernels: kernels_octree.h, kernels_flat.h, kernels_dc.h, kernels_stl.h.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "kernels_common.h"
+#include "kernels_octree.h"
+#include "kernels_flat.h"
+#include "kernels_dc.h"
+#include "kernels_stl.h"
+#include "abi_program.h"
+
+extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_opts* opts_in, gsdf_mesh** out) {
+  if (!p || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
+  if (!(res > 0) || std::isnan(res) || std::isinf(res)) return fail(GSDF_ERR_RESOLUTION, "invalid renderer cube resolution");
+  gsdf_mesh_opts opts{};
+  opts.prune = 1; opts.shard_rank = 0; opts.shard_count = 1; opts.share_corners = 0;
+  if (opts_in) opts = *opts_in;
+  if (opts.shard_count < 1 || opts.shard_rank < 0 || opts.shard_rank >= opts.shard_count) return fail(GSDF_ERR_BAD_ARGUMENT, "bad shard rank/count");
+  if (opts.payload != GSDF_PAYLOAD_TRIANGLES && opts.payload != GSDF_PAYLOAD_RECORDS) return fail(GSDF_ERR_BAD_ARGUMENT, "bad payload kind");
+  const bool want_recs = opts.payload == GSDF_PAYLOAD_RECORDS;
+  if (want_recs && (opts.host_output || opts.share_corners || opts.max_tris || fused_leaf()))
+    return fail(GSDF_ERR_BAD_ARGUMENT, "payload = records goes with the default leaf phase only (no host_output, share_corners, max_tris, fused leaf kernel)");
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t s = opts.stream ? (hipStream_t)opts.stream : p->stream;
+
+  // Octree.Reset (octreerenderer.go:71-128) + makeICube (:222-235)
+  float mn[3], mx[3];
+  scale_centered(p->prog.bb, 1.01f, mn, mx);
+  const float longAxis = fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));
+  const float l2 = (float)std::log2((double)(longAxis / res));
+  const int levels = (int)std::ceil(l2) + 1;
+  if (levels <= 1) return fail(GSDF_ERR_RESOLUTION, "resolution not fine enough for marching cubes");
+  if (levels > 17) return fail(GSDF_ERR_RESOLUTION, "resolution too fine: more than 17 octree levels");
+  const float ox = mn[0], oy = mn[1], oz = mn[2];
+
+  gsdf_mesh* m = new (std::nothrow) gsdf_mesh();
+  if (!m) return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory");
+  m->device = p->device;
+  m->stream = s;
+  m->num_cu = p->num_cu;
+  m->st.levels = levels;
+  m->st.res = res;
+  m->st.origin[0] = ox; m->st.origin[1] = oy; m->st.origin[2] = oz;
+  auto bail = [&](int code) { gsdf_hip_mesh_destroy(m); return code; };
+#define HIP_TRYM(expr)                                                                                          \
+  do {                                                                                                          \
+    hipError_t _e = (expr);                                                                                     \
+    if (_e != hipSuccess) return bail(fail(GSDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
+  } while (0)
+
+  if (!p->h_ctr) HIP_TRYM(hipHostMalloc(&p->h_ctr, 4096, hipHostMallocDefault));
+  static_assert(sizeof(MeshCounters) <= 2048, "counters: first half of the pinned block (second half: DCCounters)");
+  for (auto& e : p->ev)
+    if (!e) HIP_TRYM(hipEventCreate(&e));
+  hipEvent_t ev0 = p->ev[0], ev1 = p->ev[1], ev2 = p->ev[2];
+
+  // ---- level-synchronous descent from the top cube to level lq = min(levels, 3). The whole chain
+  // (memset, one prune launch per level, the leaf kernel) is enqueued without a host round trip: each
+  // kernel reads its input count from the previous level's counter in device memory.
+  const int lq = levels < 3 ? levels : 3;
+  // multi-GPU: bricks of level ls are dealt to ranks by a hash of their coordinates (brick_owner).
+  const int ls = levels < lq + 2 ? levels : lq + 2;
+  const int prune_cols = p->prog.nslots + p->prog.lip_depth;  // interval mode: two points per lane + the interval stack
+  const size_t lds_prune = (size_t)(prune_cols > 0 ? prune_cols : 1) * 2 * BLOCK * sizeof(float) + PRUNE_STAGE * sizeof(Cube) + 64;
+  int pmask = opts.prune & ~GSDF_PRUNE_ASSUME_SDF;  // levels to test: 0 none, 1 all, else bit L = Level L
+  if ((opts.prune & GSDF_PRUNE_ASSUME_SDF) && pmask == 0) pmask = 1;
+  const int ptest = (opts.prune & GSDF_PRUNE_ASSUME_SDF) ? 2 : 1;
+  int lk, lw;
+  size_t lds_m;
+  p->leaf_config(&lk, &lw, &lds_m);
+  uint64_t qcap = p->q0.cap / sizeof(Cube);
+  {
+    // 1 M cubes (8 MB) per queue to start with; GSDF_HIP_QCAP_MIN lowers it so that tests can drive the
+    // overflow -> grow -> rerun path (the arenas only ever grow, so a handle that already meshed keeps its size)
+    const char* e = getenv("GSDF_HIP_QCAP_MIN");
+    const uint64_t qmin = e ? (uint64_t)strtoull(e, nullptr, 10) : ((uint64_t)1 << 20);
+    if (qcap < qmin) qcap = qmin;
+    if (qcap < 64) qcap = 64;
+  }
+  uint64_t want = opts.max_tris;
+  uint64_t want_rec_n = 0;  // records payload: exact record count after an overflow
+  MeshCounters& hc = *(MeshCounters*)p->h_ctr;
+  hc = MeshCounters{};
+  MeshCounters* d_ctr = nullptr;
+  constexpr size_t kCtrBytes = (sizeof(MeshCounters) + 255) & ~(size_t)255;  // the group sums follow the counters: one memset clears both
+  bool used_brick = false, two_kernel = false, ctr_on_host = false;
+  int chain_first = levels;  // levels <= chain_first were tested by prune_kernel (one launch per level), the ones above speculatively
+  static const bool ctr_from_kernel = [] { const char* e = getenv("GSDF_HIP_CTR_FROM_KERNEL"); return !e || atoi(e) != 0; }();  // developer knob (A/B timing)
+  float ms01 = 0, ms12 = 0, ms13 = 0;
+  for (int attempt = 0;; attempt++) {
+    ctr_on_host = false;
+    HIP_TRYM(p->q0.ensure(qcap * sizeof(Cube)));
+    HIP_TRYM(p->q1.ensure(qcap * sizeof(Cube)));
+    const uint64_t cap0 = p->q0.cap / sizeof(Cube), cap1 = p->q1.cap / sizeof(Cube);
+    gsdf_program::Arena* q[2] = {&p->q0, &p->q1};
+    const uint64_t capq[2] = {cap0, cap1};
+    // records payload: room for the packed records instead (sized like the triangles: previous mesh, else a guess + one exact rerun)
+    if (want_recs && !m->d_recs) {
+      const uint64_t nrec = want_rec_n ? want_rec_n : (p->last_recs ? p->last_recs + p->last_recs / 16 + 1024 : (uint64_t)1 << 20);
+      const uint64_t units = (dense_bytes(nrec) + 35) / 36;
+      m->d_recs = (uint8_t*)pool_take(p->device, units, &m->recs_cap36);
+      if (!m->d_recs) { HIP_TRYM(hipMalloc((void**)&m->d_recs, units * 36)); m->recs_cap36 = units; }
+    }
+    // triangle buffer: caller's size, else a pooled buffer, else a guess that is corrected by one exact rerun
+    if (!want_recs && !m->d_tris) {
+      uint64_t need = want ? want : (p->last_tris ? p->last_tris + p->last_tris / 16 + 1024 : (uint64_t)1 << 20);
+      if (opts.host_output) {
+        // triangles straight into pinned host memory: the stage flushes of leaf_kernel are 4.6 KB coalesced bursts,
+        // which PCIe takes well; the transfer then overlaps the kernel instead of following it
+        void* hb = nullptr;
+        size_t hcap = 0;
+        if (int rc = host_buf(&hb, &hcap, (size_t)need * 36)) return bail(rc);
+        m->d_tris = (float*)hb;
+        m->cap = hcap / 36;
+        m->host_out = true;
+      } else {
+        m->d_tris = pool_take(p->device, need, &m->cap);
+        if (!m->d_tris) {
+          HIP_TRYM(hipMalloc((void**)&m->d_tris, need * 36));
+          m->cap = need;
+        }
+      }
+    }
+    // 64-leaf blocks the queue capacity allows for, and their groups (two-kernel leaf phase)
+    uint64_t lbound = capq[lq & 1] << (3 * (lq - 1));
+    {
+      const uint64_t full = (levels - lq) * 3 >= 40 ? UINT64_MAX : ((uint64_t)1 << (3 * (levels - 1)));
+      if (lbound > full) lbound = full;
+    }
+    // The record arena (2 560 B per block) is sized for the blocks a mesh of this handle actually had (+ 1/8), not for the queue
+    // capacity: a million-cube queue would ask for 2.7 GB, and each queue regrowth for four times more. First mesh: 384 K
+    // blocks (1 GB); a mesh that needs more says so through its survivor count and is repeated once with the exact size.
+    constexpr uint64_t kRecBlocks0 = (uint64_t)384 << 10;
+    const uint64_t nblk_q = (lbound + 63) / 64;
+    uint64_t nblk = p->rec_blocks ? p->rec_blocks : kRecBlocks0;
+    if (nblk > nblk_q) nblk = nblk_q;
+    const uint64_t ngrp = (nblk + MARCH_GROUP - 1) / MARCH_GROUP;
+    bool want_two = !fused_leaf() && !(lq == 3 && lk == 4 && opts.share_corners);
+    if (want_two && (p->hdr.ensure(nblk * sizeof(uint32_t)) != hipSuccess || p->rec.ensure(nblk * (size_t)REC_BLOCK * sizeof(uint32_t)) != hipSuccess)) {
+      (void)hipGetLastError();  // no room for the records: the fused kernel needs none
+      p->hdr.release(); p->rec.release();
+      want_two = false;
+    }
+    if (want_recs && (!want_two || p->grp.ensure(ngrp * sizeof(unsigned long long)) != hipSuccess)) {
+      (void)hipGetLastError();
+      return bail(fail(GSDF_ERR_CAPACITY, "no device memory for the cut-leaf record arena (payload = records needs it)"));
+    }
+    const size_t clear_bytes = kCtrBytes + (want_two ? ngrp * sizeof(unsigned long long) : 0);
+    {
+      const void* before = p->ctr.p;
+      HIP_TRYM(p->ctr.ensure(clear_bytes));
+      if (p->ctr.p != before) p->ctr_clean = 0;
+    }
+    d_ctr = (MeshCounters*)p->ctr.p;
+    // cleared on another stream: let that finish, do not rely on it. On a caller's stream of the same handle value: it may be a
+    // NEW stream that got a destroyed one's handle -- order this chain behind the clear's event (free if it is the same stream)
+    if (p->ctr_clean && p->ctr_clean_stream != s) p->ctr_settle();
+    else if (p->ctr_clean && s != p->stream && p->ev_clean) HIP_TRYM(hipStreamWaitEvent(s, p->ev_clean, 0));
+    if (p->ctr_clean < clear_bytes) HIP_TRYM(hipMemsetAsync(d_ctr, 0, clear_bytes, s));
+    p->ctr_clean = 0;  // dirty from here on
+    HIP_TRYM(hipEventRecord(ev0, s));
+    static const int prune_bpc = [] { const char* e = getenv("GSDF_HIP_PRUNE_BPC"); return e ? atoi(e) : 4; }();  // tuning knob
+    // The first S levels (at most 7: 299,593 cubes) are centre-tested speculatively, every cube of the complete octree at once,
+    // and resolved by a second launch (kernels.h: prune_spec_kernel / prune_resolve_kernel): two launches instead of a chain of
+    // S dependent ones. GSDF_HIP_PRUNE_SPEC=0 keeps one launch per level (cross-check in the tests).
+    static const bool use_spec = [] { const char* e = getenv("GSDF_HIP_PRUNE_SPEC"); return !e || atoi(e) != 0; }();
+    int first_level = levels;  // first level of the per-level chain
+    chain_first = levels;
+    unsigned* spec_part = nullptr;  // statistics rows of the speculative top, for the first per-level launch to add up
+    unsigned spec_rows = 0, spec_mask = 0;
+    int spec_top_S = 0;
+    auto test_mask_of = [](int pm) { return pm == 1 ? 0xffffffffu : (unsigned)pm; };
+    if (use_spec) {
+      const int S = levels - lq + 1 < 7 ? levels - lq + 1 : 7;
+      const int last_spec = levels - (S - 1);
+      unsigned n_spec = 0;
+      for (int j = 0; j < S; j++) n_spec += 1u << (3 * j);
+      // the resolve stage's statistics: a row of 16 counts per workgroup behind the pass bytes, added up by the first per-level
+      // launch -- if there is one (else the resolve stage issues its atomics itself)
+      const unsigned rrows = (n_spec + SPEC_STAGE - 1) / SPEC_STAGE;
+      const size_t part_off = ((size_t)n_spec + 63) & ~(size_t)63;
+      HIP_TRYM(p->spec_pass.ensure(part_off + (size_t)rrows * 16 * sizeof(unsigned)));
+      const bool chain_follows = last_spec - 1 >= lq;
+      spec_part = chain_follows ? (unsigned*)((char*)p->spec_pass.p + part_off) : nullptr;
+      spec_rows = rrows;
+      spec_top_S = levels | (S << 8);
+      spec_mask = test_mask_of(pmask);
+      const unsigned test_mask = test_mask_of(pmask);
+      const int shard_level = opts.shard_count > 1 ? ls : -1;
+      const unsigned sgrid = grid_for(n_spec, p->num_cu, 8);
+      if (p->f_prune_spec) {
+        HIP_TRYM(launch_fn(p->f_prune_spec, sgrid, BLOCK, lds_prune, s, (const uint32_t*)p->d_code, (int)levels, (unsigned)n_spec, (int)prune_cols,
+                           (int)p->prog.nslots, ox, oy, oz, res, (unsigned)test_mask, (int)ptest, (int)shard_level, (unsigned)opts.shard_rank,
+                           (unsigned)opts.shard_count, (uint8_t*)p->spec_pass.p));
+      } else {
+        hipLaunchKernelGGL(prune_spec_kernel, dim3(sgrid), dim3(BLOCK), lds_prune, s, p->d_code, levels, n_spec, prune_cols, p->prog.nslots, ox, oy,
+                           oz, res, test_mask, ptest, shard_level, (unsigned)opts.shard_rank, (unsigned)opts.shard_count, (uint8_t*)p->spec_pass.p);
+      }
+      HIP_TRYM(hipGetLastError());
+      hipLaunchKernelGGL(prune_resolve_kernel, dim3((n_spec + SPEC_STAGE - 1) / SPEC_STAGE), dim3(BLOCK), 0, s, (const uint8_t*)p->spec_pass.p, levels, S,
+                         n_spec, test_mask, (Cube*)q[last_spec & 1]->p, (unsigned long long)capq[last_spec & 1], d_ctr, spec_part);
+      HIP_TRYM(hipGetLastError());
+      first_level = last_spec - 1;
+      chain_first = first_level;
+    }
+    for (int level = first_level; level >= lq; level--) {
+      const int expand = level != levels;
+      const int do_test = (level >= 3 && (pmask == 1 || (pmask > 1 && ((pmask >> level) & 1)))) ? ptest : 0;
+      // upper bound of candidates at this level (for the grid only): 8^(levels-level), capped by the queue
+      uint64_t bound = (levels - level) * 3 >= 40 ? UINT64_MAX : ((uint64_t)1 << (3 * (levels - level)));
+      if (bound > capq[(level + 1) & 1] * 8) bound = capq[(level + 1) & 1] * 8;
+      if (p->f_prune) {
+        HIP_TRYM(launch_fn(p->f_prune, grid_for(bound, p->num_cu, prune_bpc), BLOCK, lds_prune, s, (const uint32_t*)p->d_code,
+                           (const Cube*)q[(level + 1) & 1]->p, (unsigned long long)capq[(level + 1) & 1], (int)expand, (int)level,
+                           (int)prune_cols, (int)p->prog.nslots, ox, oy, oz, res, (int)do_test,
+                           (Cube*)q[level & 1]->p, (unsigned long long)capq[level & 1], (int)((opts.shard_count > 1 && level == ls) ? 1 : 0),
+                           (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr, (const unsigned*)(level == first_level ? spec_part : nullptr),
+                           (unsigned)spec_rows, (int)spec_top_S, (unsigned)spec_mask));
+      } else
+      hipLaunchKernelGGL(prune_kernel, dim3(grid_for(bound, p->num_cu, prune_bpc)), dim3(BLOCK), lds_prune, s, p->d_code,
+                         (const Cube*)q[(level + 1) & 1]->p, (unsigned long long)capq[(level + 1) & 1], expand, level, prune_cols,
+                         p->prog.nslots, ox, oy, oz, res, do_test, (Cube*)q[level & 1]->p,
+                         (unsigned long long)capq[level & 1], (opts.shard_count > 1 && level == ls) ? 1 : 0,
+                         (unsigned)opts.shard_rank, (unsigned)opts.shard_count, d_ctr, (const unsigned*)(level == first_level ? spec_part : nullptr),
+                         spec_rows, spec_top_S, spec_mask);
+      HIP_TRYM(hipGetLastError());
+    }
+    HIP_TRYM(hipEventRecord(ev1, s));
+    {
+      const uint64_t bound = lbound;
+      const unsigned long long tcap = opts.max_tris ? opts.max_tris : m->cap;
+      static const int leaf_bpc = [] { const char* e = getenv("GSDF_HIP_LEAF_BPC"); return e ? atoi(e) : 64; }();  // grid = up to 64 workgroups per CU (4 resident): a few grid-stride iterations each, so the CUs drain evenly at the end (8 per CU: +8 % kernel time; one iteration per workgroup: +10 %)
+#define LAUNCH_LEAF(KK, WW)                                                                                           \
+  hipLaunchKernelGGL((leaf_kernel<KK, WW>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), lds_m, s, p->d_code,      \
+                     (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res,  \
+                     m->d_tris, tcap, d_ctr)
+      if (want_two) {
+        // two kernels: evaluation + cut-leaf records, then marching cubes over the records
+        uint32_t* d_hdr = (uint32_t*)p->hdr.p;
+        uint32_t* d_rec = (uint32_t*)p->rec.p;
+        unsigned long long* d_psum = (unsigned long long*)((char*)p->ctr.p + kCtrBytes);  // cleared with the counters
+#define LAUNCH_LEAF_EVAL_U(KK, WW, UU, NN, LDS)                                                                                    \
+  hipLaunchKernelGGL((leaf_eval_kernel<KK, WW, UU, NN>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), LDS, s, p->d_code, \
+                     (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res, d_hdr,   \
+                     d_rec, d_psum, (unsigned long long)nblk, d_ctr)
+        // lq == 3 (three levels or more): a wave pass is one level-3 cube (column bricks, scalar prefetched cube load), its
+        // case-count table in LDS unless that costs a workgroup per CU; else a few leaves (occupancy is no concern: table in LDS)
+#define LAUNCH_LEAF_EVAL(KK, WW)                                                             \
+  do {                                                                                       \
+    if (lq != 3) LAUNCH_LEAF_EVAL_U(KK, WW, false, true, lds_m + 256);                       \
+    else if (p->leaf_nt_in_lds()) LAUNCH_LEAF_EVAL_U(KK, WW, true, true, lds_m);             \
+    else LAUNCH_LEAF_EVAL_U(KK, WW, true, false, lds_m);                                     \
+  } while (0)
+        if (p->f_leaf && p->spec_leaf_k == lk && lq == 3) {
+          HIP_TRYM(launch_fn(p->f_leaf, grid_for(bound, p->num_cu, leaf_bpc), BLOCK, lds_m, s, (const uint32_t*)p->d_code, (const Cube*)q[lq & 1]->p,
+                             (unsigned long long)capq[lq & 1], (int)lq, (int)p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec, d_psum,
+                             (unsigned long long)nblk, d_ctr));
+        } else {
+          // ahead-of-time kernels exist at the scratch-free occupancies only (tests/test_kernel_resources.py)
+          if (lk == 4) { if (lw == 2) LAUNCH_LEAF_EVAL(4, 2); else LAUNCH_LEAF_EVAL(4, 3); }
+          else if (lk == 2) LAUNCH_LEAF_EVAL(2, 3);
+          else LAUNCH_LEAF_EVAL(1, 4);
+        }
+#undef LAUNCH_LEAF_EVAL
+#undef LAUNCH_LEAF_EVAL_U
+        HIP_TRYM(hipGetLastError());
+        HIP_TRYM(hipEventRecord(p->ev[3], s));
+        two_kernel = true;
+        if (want_recs) {
+          // no marching here: the records are packed for the gather (scan_groups_kernel + pack_records_kernel), marching cubes
+          // runs where they arrive (march_dense_kernel)
+          uint64_t rec_cap = m->recs_cap36 * 36 / 41;  // 40 B per record + 4 B per 256 of them, rounded: stays inside the buffer
+          if (rec_cap > 2) rec_cap -= 2;
+          hipLaunchKernelGGL(scan_groups_kernel, dim3(1), dim3(1024), 0, s, (const unsigned long long*)d_psum, (unsigned long long)nblk, lq, d_ctr,
+                             (unsigned long long*)p->grp.p, m->d_recs, (unsigned long long)rec_cap,
+                             ctr_from_kernel ? (MeshCounters*)p->h_ctr : (MeshCounters*)nullptr);
+          HIP_TRYM(hipGetLastError());
+          const uint64_t ngrp_q = (nblk_q + MARCH_GROUP - 1) / MARCH_GROUP;
+          const uint64_t gmax = (uint64_t)p->num_cu * 8;
+          hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)(ngrp_q < gmax ? (ngrp_q ? ngrp_q : 1) : gmax)), dim3(BLOCK), 0, s, (const uint32_t*)d_hdr,
+                             (const uint32_t*)d_rec, (const unsigned long long*)p->grp.p, (unsigned long long)nblk, lq, (const MeshCounters*)d_ctr,
+                             m->d_recs, (unsigned long long)rec_cap);
+          ctr_on_host = ctr_from_kernel;
+        } else {
+        // one wave of workgroups: each takes an equal share of the records (computed on device from the group sums)
+        static const int march_bpc = [] { const char* e = getenv("GSDF_HIP_MARCH_BPC"); return e ? atoi(e) : 7; }();  // tuning knob (7 fit a CU)
+        const size_t lds_march = (size_t)11 * BLOCK * 4 + 5 * BLOCK * 4 + 256 * 16 + (BLOCK + 1) * 4 + 8 * 4 + 8 + 14 * 8;
+        hipLaunchKernelGGL(march_records_kernel, dim3(grid_for(nblk_q, p->num_cu, march_bpc)), dim3(BLOCK), lds_march, s, d_hdr, d_rec,
+                           d_psum, (unsigned long long)nblk, lq, ox, oy, oz, res, m->d_tris, (uint64_t)tcap, d_ctr,
+                           ctr_from_kernel ? (MeshCounters*)p->h_ctr : (MeshCounters*)nullptr);
+        ctr_on_host = ctr_from_kernel;
+        }
+      } else if (lq == 3 && lk == 4 && opts.share_corners) {
+        // exact corner sharing: one wave per level-3 brick
+        const size_t lds_b = (size_t)(p->prog.nslots * 4) * BLOCK * sizeof(float) + 4096 + TRI_STAGE * 36 + 32 + 4 * 512 * 4 + 4 * 24 * 4;
+        hipLaunchKernelGGL((leaf_brick_kernel<4, 2>), dim3(grid_for(capq[lq & 1] * 64 < bound ? capq[lq & 1] * 64 : bound, p->num_cu, 8)),
+                           dim3(BLOCK), lds_b, s, p->d_code, (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1],
+                           p->prog.nslots, ox, oy, oz, res, m->d_tris, tcap, d_ctr);
+        used_brick = true;
+      } else if (p->f_leaf && p->spec_leaf_k == lk) {  // whichever W it was built for: same launch
+        HIP_TRYM(launch_fn(p->f_leaf, grid_for(bound, p->num_cu, leaf_bpc), BLOCK, lds_m, s, (const uint32_t*)p->d_code, (const Cube*)q[lq & 1]->p,
+                           (unsigned long long)capq[lq & 1], (int)lq, (int)p->prog.nslots, ox, oy, oz, res, m->d_tris,
+                           (unsigned long)tcap, d_ctr));
+      } else {
+        // Ahead-of-time (interpreter) leaf kernels exist only at occupancies the compiler reaches WITHOUT scratch
+        // (tests/test_kernel_resources.py reads the shipped code object): at 4 workgroups per CU (128 VGPRs) the K = 4 and
+        // K = 2 interpreter builds spill, and a spilling build is not trusted (see fn_scratch_bytes).
+        if (lk == 4) { if (lw == 2) LAUNCH_LEAF(4, 2); else LAUNCH_LEAF(4, 3); }
+        else if (lk == 2) LAUNCH_LEAF(2, 3);
+        else LAUNCH_LEAF(1, 4);
+      }
+#undef LAUNCH_LEAF
+      HIP_TRYM(hipGetLastError());
+    }
+    HIP_TRYM(hipEventRecord(ev2, s));
+    if (!ctr_on_host) HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));  // (else march_records_kernel wrote them)
+    hipEvent_t evr = p->ev[4];
+    HIP_TRYM(hipEventRecord(evr, s));
+    static const bool clear_ahead = [] { const char* e = getenv("GSDF_HIP_CLEAR_AHEAD"); return !e || atoi(e) != 0; }();
+    if (clear_ahead) {  // for the next mesh (or the rerun below); not waited for
+      if (!p->ev_clean) HIP_TRYM(hipEventCreateWithFlags(&p->ev_clean, hipEventDisableTiming));
+      HIP_TRYM(hipMemsetAsync(d_ctr, 0, clear_bytes, s));
+      HIP_TRYM(hipEventRecord(p->ev_clean, s));
+    }
+    HIP_TRYM(hipEventSynchronize(evr));
+    if (clear_ahead) { p->ctr_clean = clear_bytes; p->ctr_clean_stream = s; }
+    if (hc.q_overflow) {  // a cube queue was too small: double and redo (exact: nothing was dropped silently)
+      if (attempt >= 8) return bail(fail(GSDF_ERR_CAPACITY, "octree queue capacity exceeded"));
+      qcap *= 4;
+      continue;
+    }
+    if (two_kernel) {  // more blocks than the record arena holds: the blocks beyond it were skipped -- repeat with room for all
+      const uint64_t need = ((hc.n_level[lq] << (3 * (lq - 1))) + 63) / 64;
+      if (need > nblk) {
+        if (attempt >= 8) return bail(fail(GSDF_ERR_CAPACITY, "cut-leaf record arena capacity exceeded"));
+        p->rec_blocks = need + need / 8 + 1024;
+        two_kernel = false;
+        continue;
+      }
+    }
+    if (hc.overflow && want_recs) {  // record payload too small: the scan knows the exact count
+      if (attempt >= 8) return bail(fail(GSDF_ERR_CAPACITY, "device record buffer capacity exceeded"));
+      pool_give(p->device, (float*)m->d_recs, m->recs_cap36);
+      m->d_recs = nullptr; m->recs_cap36 = 0;
+      want_rec_n = hc.n_cut + hc.n_cut / 16 + 1024;
+      continue;
+    }
+    if (hc.overflow) {  // triangle buffer too small: the kernel kept counting, so the exact size is known
+      if (opts.max_tris) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
+      if (attempt >= 8) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
+      release_tris(m);
+      want = hc.n_tris + hc.n_tris / 16 + 1024;
+      continue;
+    }
+    break;
+  }
+  HIP_TRYM(hipEventElapsedTime(&ms01, ev0, ev1));
+  HIP_TRYM(hipEventElapsedTime(&ms12, ev1, ev2));
+  if (two_kernel) HIP_TRYM(hipEventElapsedTime(&ms13, ev1, p->ev[3]));  // the evaluating kernel alone
+  uint64_t evals_prune = 0, pruned = 0;
+  for (int level = levels; level >= lq; level--) {
+    evals_prune += hc.n_items[level];
+    // cubes that passed their test: counted apart only where "passed" and "kept by this rank" differ (prune_kernel)
+    const bool dealt_here = opts.shard_count > 1 && level == ls;
+    const uint64_t passed = (level <= chain_first && !dealt_here) ? hc.n_level[level] : hc.n_pass[level];
+    if (hc.n_items[level]) pruned += (hc.n_items[level] - passed) << (3 * (level - 1));  // DecomposesTo(1) = 8^(level-1)
+  }
+  const uint64_t n_leaves = hc.n_level[lq] << (3 * (lq - 1));
+  const uint64_t evals_leaf = used_brick ? hc.n_points  // distinct lattice points evaluated once each
+                                         : n_leaves * (uint64_t)lk + (uint64_t)(8 - lk) * (two_kernel && lq == 3 ? n_leaves : hc.n_cont);  // evaluations actually executed (a column brick always evaluates all eight rows: leaf_eval_kernel counts nothing)
+  m->st.n_tris = hc.n_tris;
+  m->st.evals = evals_prune + evals_leaf;
+  m->st.evals_prune = evals_prune;
+  m->st.evals_leaf = evals_leaf;
+  m->st.pruned_leaves = pruned;
+  m->st.leaf_cubes = n_leaves;
+  m->st.active_leaves = hc.n_active;
+  m->st.ms_prune = ms01;
+  m->st.ms_leaf = ms12;
+  m->st.ms_march = two_kernel ? ms13 : ms12;
+  m->st.ms_emit = two_kernel ? ms12 - ms13 : 0.0;
+  m->st.cut_leaves = hc.n_cut;
+  m->st.ms_total = (double)ms01 + (double)ms12;
+  p->evals += m->st.evals;
+  p->last_tris = hc.n_tris;
+  if (want_recs) { m->payload = GSDF_PAYLOAD_RECORDS; m->n_recs = hc.n_cut; p->last_recs = hc.n_cut; }
+  *out = m;
+  return GSDF_OK;
+#undef HIP_TRYM
+}
+
+// ---- packed cut-leaf records -> triangles (kernels_octree.h: march_dense_kernel) ------------------------------------------
+static_assert(sizeof(gsdf_dense_part) == sizeof(DensePart) && kDenseMaxParts == DENSE_MAX_PARTS, "abi_host.h mirrors kernels_octree.h");
+size_t dense_parts_bytes() { return sizeof(DenseParts); }
+int mesh_march_dense(const uint8_t* d_buf, const gsdf_dense_part* parts, int nparts, void* d_parts, float ox, float oy, float oz, float res,
+                     float* d_tris, int num_cu, hipStream_t s) {
+  if (nparts < 1 || nparts > DENSE_MAX_PARTS) return fail(GSDF_ERR_BAD_ARGUMENT, "march over packed records: 1 to 64 parts");
+  DenseParts h{};
+  h.n = nparts;
+  uint64_t chunks = 0;
+  for (int i = 0; i < nparts; i++) {
+    h.p[i].off = parts[i].off; h.p[i].n_recs = parts[i].n_recs; h.p[i].tri0 = parts[i].tri0;
+    chunks += (parts[i].n_recs + DENSE_CHUNK - 1) / DENSE_CHUNK;
+    if (dense_bytes(parts[i].n_recs) != dense_payload_bytes(parts[i].n_recs)) return fail(GSDF_ERR_BAD_ARGUMENT, "internal: payload layouts differ");
+  }
+  if (chunks == 0) return GSDF_OK;
+  // the table is small and the copy's source is this stack frame: hipMemcpyAsync from pageable memory stages it before returning
+  HIP_TRY(hipMemcpyAsync(d_parts, &h, sizeof h, hipMemcpyHostToDevice, s));
+  static const int march_bpc = [] { const char* e = getenv("GSDF_HIP_MARCH_BPC"); return e ? atoi(e) : 7; }();  // tuning knob (7 fit a CU)
+  const uint64_t gmax = (uint64_t)num_cu * (uint64_t)(march_bpc > 0 ? march_bpc : 7);
+  const size_t lds = (size_t)11 * BLOCK * 4 + 5 * BLOCK * 4 + 256 * 16 + 8 * 4 + 8 + 4 * 8;
+  hipLaunchKernelGGL(march_dense_kernel, dim3((unsigned)(chunks < gmax ? chunks : gmax)), dim3(BLOCK), lds, s, d_buf, (const DenseParts*)d_parts, ox, oy, oz, res, d_tris);
+  HIP_TRY(hipGetLastError());
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_hip_mesh_payload(const gsdf_mesh* m, uint64_t* n_records, uint64_t* payload_bytes) {
+  if (!m) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  const bool r = m->payload == GSDF_PAYLOAD_RECORDS;
+  if (n_records) *n_records = r ? m->n_recs : 0;
+  if (payload_bytes) *payload_bytes = r ? dense_bytes(m->n_recs) : 0;
+  return m->payload;
+}
+
+extern "C" int gsdf_hip_mesh_march(gsdf_mesh* m) {
+  if (!m) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  if (m->payload != GSDF_PAYLOAD_RECORDS) return GSDF_OK;
+  if (m->inflight.load() > 0) return fail(GSDF_ERR_BAD_ARGUMENT, "the mesh is being gathered: wait for the gather first");
+  HIP_TRY(hipSetDevice(m->device));
+  const uint64_t n = m->st.n_tris;
+  if (n) {
+    const uint64_t units = n + (dense_parts_bytes() + 35) / 36;  // the parts table rides behind the triangles
+    m->d_tris = pool_take(m->device, units, &m->cap);
+    if (!m->d_tris) {
+      if (hipMalloc((void**)&m->d_tris, units * 36) != hipSuccess) { (void)hipGetLastError(); return fail(GSDF_ERR_HIP, "hipMalloc of the triangle buffer failed"); }
+      m->cap = units;
+    }
+    const gsdf_dense_part part{0, m->n_recs, 0};
+    hipStream_t rs = mesh_stream(m);
+    const int rc = mesh_march_dense(m->d_recs, &part, 1, m->d_tris + n * 9, m->st.origin[0], m->st.origin[1], m->st.origin[2], m->st.res, m->d_tris,
+                                    m->num_cu, rs);
+    if (rc) { release_tris(m); return rc; }
+    hipError_t e = hipStreamSynchronize(rs);
+    if (e != hipSuccess) { release_tris(m); return fail(GSDF_ERR_HIP, std::string("march over the records: ") + hipGetErrorString(e)); }
+  }
+  pool_give(m->device, (float*)m->d_recs, m->recs_cap36);
+  m->d_recs = nullptr; m->recs_cap36 = 0; m->n_recs = 0;
+  m->payload = GSDF_PAYLOAD_TRIANGLES;
+  return GSDF_OK;
+}
+
+// glrender.DualContourRenderer.Reset + RenderAll with DualContourLeastSquares on device.
+extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chiseled, int shard_rank, int shard_count, void* stream,
+                                         gsdf_mesh** out) {
+  if (!p || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
+  if (!(res > 0) || std::isnan(res) || std::isinf(res)) return fail(GSDF_ERR_RESOLUTION, "invalid renderer cube resolution");
+  if (shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return fail(GSDF_ERR_BAD_ARGUMENT, "bad shard rank/count");
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  // Reset (dual_contour.go:26-41): bounds shifted by -res/2, makeICube
+  const float sub = res / 2;
+  float mn[3], mx[3];
+  for (int a = 0; a < 3; a++) { mn[a] = p->prog.bb[a] + -sub; mx[a] = p->prog.bb[a + 3] + -sub; }
+  const float longAxis = fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));
+  const int levels = (int)std::ceil((float)std::log2((double)(longAxis / res))) + 1;
+  if (levels <= 1) return fail(GSDF_ERR_RESOLUTION, "resolution not fine enough for marching cubes");
+  // the neighbour lookup is a dense int32 index grid over the 2^(levels-1) cube lattice: 4.3 GB at 11 levels, 34 GB at 12 --
+  // what one 288 GB device holds beside the rest of the workspace (13 levels would be 275 GB)
+  if (levels > 12) return fail(GSDF_ERR_RESOLUTION, "dual contouring lattice too large: more than 12 octree levels");
+  const int nshift = levels - 1;
+  const uint64_t ncell = (uint64_t)1 << (3 * nshift);
+  const float ox = mn[0], oy = mn[1], oz = mn[2];
+  // multi-GPU: z-slabs. A rank owns the quads of cubes with z in [zown_lo, zown_hi); their vertices need the cubes of
+  // [zown_lo-1, zown_hi) placed, which in turn need the distances and normals of [zown_lo-1, zown_hi+1). Every stage is
+  // a pure function of the lattice cell, so the halo is recomputed instead of exchanged (no data-path collective).
+  const unsigned nz = 1u << nshift;
+  uint32_t zown_lo = 0, zown_hi = 0;
+  gsdf_hip_slab_range(nz, (uint32_t)shard_rank, (uint32_t)shard_count, &zown_lo, &zown_hi);
+  const unsigned zlo = zown_lo > 0 ? zown_lo - 1 : 0, zhi = zown_hi < nz ? zown_hi + 1 : nz;
+  const uint64_t nslab = (uint64_t)(zhi - zlo) << (2 * nshift);
+
+  gsdf_mesh* m = new (std::nothrow) gsdf_mesh();
+  if (!m) return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory");
+  m->device = p->device; m->stream = s;
+  m->st.levels = levels; m->st.res = res;
+  m->st.origin[0] = ox; m->st.origin[1] = oy; m->st.origin[2] = oz;
+  auto bail = [&](int code) { gsdf_hip_mesh_destroy(m); return code; };
+#define HIP_TRYM(expr)                                                                                          \
+  do {                                                                                                          \
+    hipError_t _e = (expr);                                                                                     \
+    if (_e != hipSuccess) return bail(fail(GSDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
+  } while (0)
+  for (auto& e : p->ev)
+    if (!e) HIP_TRYM(hipEventCreate(&e));
+  // Workspace lives in the program handle (grow-only): the index grid alone is 4.3 GB at 1024^3 cells, and a
+  // hipMalloc/hipFree pair of that size per mesh cost more wall time than the whole device pass.
+  gsdf_program::Arena &grid = p->dc_grid, &d2 = p->dc_dist, &f2 = p->dc_fv, &n2 = p->dc_nrm, &e2 = p->dc_edge;
+  HIP_TRYM(grid.ensure(ncell * sizeof(int)));
+  p->ctr_settle();  // (the octree mesher's clear-ahead)
+  HIP_TRYM(p->ctr.ensure(sizeof(MeshCounters) > sizeof(DCCounters) ? sizeof(MeshCounters) : sizeof(DCCounters)));
+  DCCounters* d_ctr = (DCCounters*)p->ctr.p;
+  const int lk = p->batch_k();
+  // Kept cubes hug the surface: ~ c * n^2 of the n^3 lattice. Start from the previous pass on this handle, else from
+  // 12 n^2 (an overflow repeats the full-lattice origin pass, so be generous: 84 B per cube).
+  uint64_t ccap = p->last_dc_cubes ? p->last_dc_cubes + p->last_dc_cubes / 8 + 4096 : (uint64_t)12 << (2 * nshift);
+  if (ccap < (1u << 20)) ccap = 1u << 20;
+  DCCounters hc{};
+  const float h = (chiseled ? (float)1e-4 : (float)2e-8) * 0.5f;  // NormalsCentralDiff: step *= 0.5
+  const float sqrtLambda = chiseled ? (float)(std::sqrt(1e-5) * 1e-4) : (float)std::sqrt(1e-5);
+  for (int attempt = 0;; attempt++) {
+    if (ccap > nslab) ccap = nslab;
+    const uint64_t ecap = 3 * ccap, tcap = 2 * ecap;
+    HIP_TRYM(p->q0.ensure(ccap * sizeof(Cube)));
+    HIP_TRYM(d2.ensure(ccap * sizeof(float4)));
+    HIP_TRYM(f2.ensure(ccap * 12));
+    HIP_TRYM(n2.ensure(ccap * 36));
+    HIP_TRYM(e2.ensure(ecap * sizeof(unsigned)));
+    if (!m->d_tris || m->cap < tcap) {
+      pool_give(p->device, m->d_tris, m->cap);
+      m->d_tris = pool_take(p->device, tcap, &m->cap);
+      if (!m->d_tris) { HIP_TRYM(hipMalloc((void**)&m->d_tris, tcap * 36)); m->cap = tcap; }
+    }
+    HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(DCCounters), s));
+    if (shard_count > 1) HIP_TRYM(hipMemsetAsync(grid.p, 0xff, ncell * sizeof(int), s));  // cells outside the slab read as empty
+    HIP_TRYM(hipEventRecord(p->ev[0], s));
+    const unsigned g1 = grid_for((nslab + lk - 1) / lk, p->num_cu, 32);
+#define LAUNCH_O(KK, WW) hipLaunchKernelGGL((dc_origin_kernel<KK, WW>), dim3(g1), dim3(BLOCK), p->lds_bytes(KK) + 32, s, p->d_code, p->prog.nslots, nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, zlo, zhi, ub, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], t0[0], t0[1], t0[2], tn[0], tn[1], tn[2], d_ctr)
+    spec_aux(p);
+    const int ub = p->prog.has_exact_bb ? 1 : 0;
+    const float* eb = p->prog.exact_bb;
+    // tile range of the origin sweep (8 x 8 x 4K cells per tile, z tiles counted from zlo)
+    const unsigned ncell1 = 1u << nshift, tzk = 4u * (unsigned)lk;
+    unsigned t0[3] = {0, 0, 0}, tn[3] = {(ncell1 + 7u) >> 3, (ncell1 + 7u) >> 3, (zhi - zlo + tzk - 1u) / tzk};
+    if (ub) {
+      const float org[3] = {ox, oy, oz}, grow = res * 2 * 1.001f + 2 * res;
+      const unsigned lo_lim[3] = {0, 0, zlo}, hi_lim[3] = {ncell1, ncell1, zhi}, tsz[3] = {8, 8, tzk};
+      for (int a = 0; a < 3; a++) {
+        double c0 = std::floor(((double)eb[a] - grow - org[a]) / res) - 1, c1 = std::ceil(((double)eb[a + 3] + grow - org[a]) / res) + 2;
+        if (c0 < lo_lim[a]) c0 = lo_lim[a];
+        if (c1 > hi_lim[a]) c1 = hi_lim[a];
+        if (c1 <= c0) { c0 = lo_lim[a]; c1 = lo_lim[a]; }  // nothing of the box in this slab
+        const unsigned first = ((unsigned)c0 - lo_lim[a]) / tsz[a], last = ((unsigned)c1 - lo_lim[a] + tsz[a] - 1) / tsz[a];
+        t0[a] = first;
+        tn[a] = last > first ? last - first : 0;
+      }
+    }
+    if (p->f_dc_origin) HIP_TRYM(launch_fn(p->f_dc_origin, g1, BLOCK, p->lds_bytes(lk) + 32, s, (const uint32_t*)p->d_code, (int)p->prog.nslots, (int)nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, (unsigned)zlo, (unsigned)zhi, ub, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], t0[0], t0[1], t0[2], tn[0], tn[1], tn[2], d_ctr));
+    else
+    if (lk == 4) LAUNCH_O(4, 3);  // <4, 4> needs scratch: not built (see fn_scratch_bytes)
+    else if (lk == 2) { if (p->sweep_waves(2) == 4) LAUNCH_O(2, 4); else LAUNCH_O(2, 3); }
+    else LAUNCH_O(1, 4);
+#undef LAUNCH_O
+    HIP_TRYM(hipGetLastError());
+    if (p->lds_bytes(4) > 150 * 1024) return bail(fail(GSDF_ERR_BAD_TREE, "tree needs too much LDS scratch for the dual contouring edge pass"));
+    if (p->f_dc_edges) HIP_TRYM(launch_fn(p->f_dc_edges, grid_for(ccap, p->num_cu, 8), BLOCK, p->lds_bytes(4), s, (const uint32_t*)p->d_code, (const Cube*)p->q0.p,
+                       (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, d_ctr));
+    else
+    hipLaunchKernelGGL(dc_edges_kernel, dim3(grid_for(ccap, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(4), s, p->d_code, (const Cube*)p->q0.p,
+                       (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, d_ctr);
+    HIP_TRYM(hipGetLastError());
+    if (p->f_dc_normals) HIP_TRYM(launch_fn(p->f_dc_normals, grid_for(ecap, p->num_cu, 8), BLOCK, p->lds_bytes(2), s, (const uint32_t*)p->d_code, (const Cube*)p->q0.p,
+                       (const float4*)d2.p, (const unsigned*)e2.p, (unsigned long long)ecap, ox, oy, oz, res, h, (float*)n2.p, d_ctr));
+    else
+    hipLaunchKernelGGL(dc_normals_kernel, dim3(grid_for(ecap, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(2), s, p->d_code, (const Cube*)p->q0.p,
+                       (const float4*)d2.p, (const unsigned*)e2.p, (unsigned long long)ecap, ox, oy, oz, res, h, (float*)n2.p, d_ctr);
+    HIP_TRYM(hipGetLastError());
+    hipLaunchKernelGGL(dc_place_kernel, dim3(grid_for(ccap * 4, p->num_cu, 16)), dim3(DC_BLOCK), 0, s, (const Cube*)p->q0.p,
+                       (unsigned long long)ccap, (const float4*)d2.p, (const int*)grid.p, (const float*)n2.p, nshift, ox, oy, oz, res,
+                       sqrtLambda, (float*)f2.p, zown_hi, d_ctr);
+    HIP_TRYM(hipGetLastError());
+    hipLaunchKernelGGL(dc_quads_kernel, dim3(grid_for(ecap, p->num_cu, 8)), dim3(BLOCK), 0, s, (const Cube*)p->q0.p, (const float4*)d2.p,
+                       (const unsigned*)e2.p, (unsigned long long)ecap, (const int*)grid.p, (const float*)f2.p, nshift, zown_lo, zown_hi,
+                       m->d_tris, (unsigned long long)m->cap, d_ctr);
+    HIP_TRYM(hipGetLastError());
+    HIP_TRYM(hipEventRecord(p->ev[1], s));
+    HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));
+    HIP_TRYM(hipStreamSynchronize(s));
+    if (hc.q_overflow || hc.t_overflow) {
+      if (attempt >= 8 || ccap >= nslab) return bail(fail(GSDF_ERR_CAPACITY, "dual contouring queue capacity exceeded"));
+      // the origin pass keeps counting past the capacity, so the exact number of kept cubes is known
+      ccap = hc.n_cubes > ccap ? hc.n_cubes + hc.n_cubes / 16 + 4096 : ccap * 2;
+      continue;
+    }
+    break;
+  }
+  float ms = 0;
+  HIP_TRYM(hipEventElapsedTime(&ms, p->ev[0], p->ev[1]));
+  p->last_dc_cubes = hc.n_cubes;
+  m->st.n_tris = 2 * hc.n_tris;  // quads -> 2 triangles
+  m->st.evals = hc.n_origin_evals + 4 * hc.n_cubes + 6 * hc.n_edges;
+  m->st.evals_prune = hc.n_origin_evals;  // of the nslab lattice cells; the rest lay outside the exact box by > 2 res
+  m->st.evals_leaf = 4 * hc.n_cubes + 6 * hc.n_edges;
+  m->st.pruned_leaves = nslab - hc.n_cubes;
+  m->st.leaf_cubes = hc.n_cubes;
+  m->st.active_leaves = hc.n_edges;
+  m->st.ms_total = ms;
+  p->evals += m->st.evals;
+  *out = m;
+  return GSDF_OK;
+#undef HIP_TRYM
+}
+
+// glrender.FlatRenderer (flatrenderer.go:36-256) on device: Reset's lattice, evalGrid into a dense grid in HBM,
+// ReadTriangles as one marching-cubes pass over every cube. Multi-GPU: z-slabs of cubes like the reference's goroutines
+// (:120-122); a rank evaluates the planes its cubes touch (one shared plane per boundary is recomputed, nothing exchanged).
+extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, int shard_count, void* stream, gsdf_mesh** out) {
+  if (!p || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
+  if (!(res > 0) || std::isnan(res) || std::isinf(res)) return fail(GSDF_ERR_RESOLUTION, "invalid renderer cube resolution");
+  if (shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return fail(GSDF_ERR_BAD_ARGUMENT, "bad shard rank/count");
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  // Reset (:36-80)
+  float mn[3], mx[3];
+  scale_centered(p->prog.bb, 1.01f, mn, mx);
+  double nd[3];
+  for (int a = 0; a < 3; a++) nd[a] = (double)std::ceil((mx[a] - mn[a]) / res);
+  if (!(nd[0] > 0) || !(nd[1] > 0) || !(nd[2] > 0)) return fail(GSDF_ERR_RESOLUTION, "resolution not fine enough for marching cubes");
+  if (nd[0] > 65534 || nd[1] > 65534 || nd[2] > 1e9 || (nd[0] + 1) * (nd[1] + 1) >= 4294967296.0)
+    return fail(GSDF_ERR_RESOLUTION, "resolution too fine for the flat renderer's lattice");
+  const unsigned nx = (unsigned)nd[0], ny = (unsigned)nd[1], nz = (unsigned)nd[2];
+  const unsigned sx = nx + 1, sy = ny + 1;
+  const uint64_t sxy = (uint64_t)sx * sy;
+  const uint64_t pxy = (uint64_t)FLAT_PITCH(sx) * sy;  // the grid's rows are padded to 256 bytes
+  const float ox = mn[0], oy = mn[1], oz = mn[2];
+  // this rank's cubes in z and the lattice planes they touch
+  uint32_t c0 = 0, c1 = 0;
+  gsdf_hip_slab_range(nz, (uint32_t)shard_rank, (uint32_t)shard_count, &c0, &c1);
+  const unsigned ncz = c1 - c0, nk = ncz ? ncz + 1 : 0;
+
+  gsdf_mesh* m = new (std::nothrow) gsdf_mesh();
+  if (!m) return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory");
+  m->device = p->device; m->stream = s;
+  m->st.levels = 0; m->st.res = res;
+  m->st.origin[0] = ox; m->st.origin[1] = oy; m->st.origin[2] = oz;
+  auto bail = [&](int code) { gsdf_hip_mesh_destroy(m); return code; };
+#define HIP_TRYM(expr)                                                                                          \
+  do {                                                                                                          \
+    hipError_t _e = (expr);                                                                                     \
+    if (_e != hipSuccess) return bail(fail(GSDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
+  } while (0)
+  if (ncz == 0) { *out = m; return GSDF_OK; }  // more ranks than cube planes: nothing for this one
+  for (auto& e : p->ev)
+    if (!e) HIP_TRYM(hipEventCreate(&e));
+  p->ctr_settle();  // (the octree mesher's clear-ahead)
+  HIP_TRYM(p->ctr.ensure(sizeof(MeshCounters)));
+  MeshCounters* d_ctr = (MeshCounters*)p->ctr.p;
+  {
+    // refuse up front what cannot fit (a failed multi-hundred-GB hipMalloc is slow and leaves the allocator fragmented)
+    size_t mfree = 0, mtotal = 0;
+    const double need = (double)pxy * (double)nk * sizeof(float);
+    if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && need > (double)mfree + (double)p->flat_grid.cap)
+      return bail(fail(GSDF_ERR_CAPACITY, "flat renderer: the distance grid (" + std::to_string((unsigned long long)(need / 1e9)) +
+                                              " GB) does not fit the device memory; use the octree renderer at this resolution"));
+  }
+  if (p->flat_grid.ensure(pxy * nk * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();
+    return bail(fail(GSDF_ERR_CAPACITY, "flat renderer: no device memory for the distance grid (" + std::to_string(pxy * nk * 4) + " bytes)"));
+  }
+  float* grid = (float*)p->flat_grid.p;
+  // two bit planes per lattice plane beside it (1/32 + 1/32 of the grid's size): "d < 0" and "|d| <= 2 sqrt3 res" per corner,
+  // in whole words per flat_grid_kernel pass (BLOCK corners = BLOCK / 64 words)
+  const unsigned wpp = (unsigned)((sxy + (uint64_t)BLOCK - 1) / (uint64_t)BLOCK) * (BLOCK / 64);
+  if (p->flat_bits.ensure((size_t)2 * wpp * nk * sizeof(unsigned long long)) != hipSuccess) {
+    (void)hipGetLastError();
+    return bail(fail(GSDF_ERR_CAPACITY, "flat renderer: no device memory for the lattice's bit planes"));
+  }
+  unsigned long long* negbits = (unsigned long long*)p->flat_bits.p;
+  unsigned long long* nearbits = negbits + (size_t)wpp * nk;
+  const int ek = p->batch_k();
+  spec_aux(p);
+  HIP_TRYM(hipEventRecord(p->ev[0], s));
+  {
+    const uint64_t npass = ((sxy + (uint64_t)BLOCK - 1) / (uint64_t)BLOCK) * ((nk + ek - 1) / ek);
+    static const int bpc = [] { const char* e = getenv("GSDF_HIP_EVAL_BPC"); return e ? atoi(e) : 64; }();
+    const uint64_t gmax = (uint64_t)p->num_cu * (uint64_t)(bpc > 0 ? bpc : 64);
+    const unsigned g = (unsigned)(npass < gmax ? npass : gmax);
+    if (p->f_flat_grid) HIP_TRYM(launch_fn(p->f_flat_grid, g, BLOCK, p->lds_bytes(ek), s, (const uint32_t*)p->d_code, ox, oy, oz, res, sx, sy, c0, nk, grid, negbits, nearbits));
+#define LAUNCH_FG(KK, WW) hipLaunchKernelGGL((flat_grid_kernel<KK, WW>), dim3(g), dim3(BLOCK), p->lds_bytes(KK), s, p->d_code, ox, oy, oz, res, sx, sy, c0, nk, grid, negbits, nearbits)
+    else if (ek == 4) { if (p->sweep_waves(4) == 4) LAUNCH_FG(4, 4); else LAUNCH_FG(4, 3); }
+    else if (ek == 2) { if (p->sweep_waves(2) == 4) LAUNCH_FG(2, 4); else LAUNCH_FG(2, 3); }
+    else LAUNCH_FG(1, 4);
+#undef LAUNCH_FG
+    HIP_TRYM(hipGetLastError());
+  }
+  HIP_TRYM(hipEventRecord(p->ev[1], s));
+  // ReadTriangles: the triangle count is not known in advance; the pass is cheap (HBM-bound over the grid), so a
+  // buffer that turns out too small is replaced by one of the exact size and only this pass is repeated.
+  MeshCounters hc{};
+  uint64_t want = p->last_tris ? p->last_tris + p->last_tris / 16 + 1024 : (uint64_t)1 << 20;
+  float ms_march = 0;
+  for (int attempt = 0;; attempt++) {
+    if (!m->d_tris) {
+      m->d_tris = pool_take(p->device, want, &m->cap);
+      if (!m->d_tris) { HIP_TRYM(hipMalloc((void**)&m->d_tris, want * 36)); m->cap = want; }
+    }
+    HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(MeshCounters), s));
+    HIP_TRYM(hipEventRecord(p->ev[2], s));
+    // default: the marching pass over the bit planes (flat_cut_scan_kernel + flat_march_list_kernel); GSDF_HIP_FLAT_STREAM=1:
+    // the pass that streams the float grid (flat_march_kernel, the kernel of rounds 1-2), kept for comparison -- same triangles
+    static const bool stream_march = [] { const char* e = getenv("GSDF_HIP_FLAT_STREAM"); return e && atoi(e) != 0; }();
+    if (nx >= 65536u || ny >= 65536u || (uint64_t)c0 + ncz >= 65536u)  // record coordinates are 16-bit
+      return bail(fail(GSDF_ERR_RESOLUTION, "resolution too fine for the flat renderer's lattice"));
+    if (stream_march) {
+      const uint64_t npass = (uint64_t)((nx + FLAT_TX - 1) / FLAT_TX) * ((ny + FLAT_ROWS - 1) / FLAT_ROWS) * ncz;  // wave passes: FLAT_TX x FLAT_ROWS cubes each
+      if ((double)npass + 1e6 >= 4294967296.0) return bail(fail(GSDF_ERR_RESOLUTION, "resolution too fine for the flat renderer's lattice"));
+      // four workgroups per CU are resident (36 KB of LDS each): a grid of exactly those, ~200 passes per wave, measured best
+      // (0.63 ms; 8 per CU 0.66, 32 per CU 0.74, 6 per CU 0.82 -- the stride between a wave's passes matters)
+      static const int mbpc = [] { const char* e = getenv("GSDF_HIP_FLAT_BPC"); return e ? atoi(e) : 4; }();  // tuning knob
+      const uint64_t gmax = (uint64_t)p->num_cu * (uint64_t)(mbpc > 0 ? mbpc : 4);
+      const uint64_t nwg = (npass + 3) / 4;
+      const size_t lds = (size_t)256 * 16 + (size_t)4 * FLAT_WAVE_RECS * REC_WORDS * 4 + (size_t)4 * 5 * FLAT_WAVE_RECS * 2;
+      hipLaunchKernelGGL(flat_march_kernel, dim3((unsigned)(nwg < gmax ? (nwg ? nwg : 1) : gmax)), dim3(BLOCK), lds, s, (const float*)grid, nx, ny, ncz, c0,
+                         ox, oy, oz, res, m->d_tris, (uint64_t)m->cap, d_ctr);
+    } else {
+      // a cut cube has at least one triangle: a list of the triangle buffer's capacity overflows only if that does
+      if (p->flat_list.ensure((size_t)m->cap * sizeof(unsigned long long)) != hipSuccess) {
+        (void)hipGetLastError();
+        return bail(fail(GSDF_ERR_CAPACITY, "flat renderer: no device memory for the list of cut cubes"));
+      }
+      unsigned long long* list = (unsigned long long*)p->flat_list.p;
+      const uint64_t npass = (((uint64_t)sx * ny + 4095u) >> 12) * ncz;  // wave passes of the scan: 4096 cubes each
+      static const int sbpc = [] { const char* e = getenv("GSDF_HIP_FLAT_SCAN_BPC"); return e ? atoi(e) : 16; }();   // tuning knobs
+      static const int lbpc = [] { const char* e = getenv("GSDF_HIP_FLAT_LIST_BPC"); return e ? atoi(e) : 6; }();
+      const uint64_t gmax = (uint64_t)p->num_cu * (uint64_t)(sbpc > 0 ? sbpc : 16), nwg = (npass + 3) / 4;
+      hipLaunchKernelGGL(flat_cut_scan_kernel, dim3((unsigned)(nwg < gmax ? (nwg ? nwg : 1) : gmax)), dim3(BLOCK), 0, s, (const unsigned long long*)negbits,
+                         (const unsigned long long*)nearbits, wpp, nx, ny, ncz, list, (uint64_t)m->cap, d_ctr);
+      hipLaunchKernelGGL(flat_march_list_kernel, dim3((unsigned)p->num_cu * (unsigned)(lbpc > 0 ? lbpc : 6)), dim3(BLOCK), FLATB_LDS_BYTES, s, (const float*)grid,
+                         (const unsigned long long*)list, (uint64_t)m->cap, nx, ny, c0, ox, oy, oz, res, m->d_tris, (uint64_t)m->cap, d_ctr);
+    }
+    HIP_TRYM(hipGetLastError());
+    HIP_TRYM(hipEventRecord(p->ev[3], s));
+    HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));
+    HIP_TRYM(hipStreamSynchronize(s));
+    if (hc.overflow) {
+      // The float-stream pass keeps counting: n_tris is exact. So does the bit-plane pass as long as its cut-cube list held
+      // every cut cube (n_cut <= capacity); if not, n_cut is still exact and n_tris covers the listed cubes only: a cut cube
+      // has 1 to 5 triangles (2.2 on the configs' surfaces), so room for 3 per cut cube holds the list for certain and
+      // the triangles nearly always -- one more exact rerun otherwise.
+      if (attempt >= 5) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
+      const bool list_short = hc.n_cut > m->cap;
+      pool_give(p->device, m->d_tris, m->cap);
+      m->d_tris = nullptr; m->cap = 0;
+      want = hc.n_tris + hc.n_tris / 16 + 1024;
+      if (list_short && want < 3 * hc.n_cut) want = 3 * hc.n_cut;
+      continue;
+    }
+    break;
+  }
+  float ms_grid = 0;
+  HIP_TRYM(hipEventElapsedTime(&ms_march, p->ev[2], p->ev[3]));  // the last (successful) marching pass
+  HIP_TRYM(hipEventElapsedTime(&ms_grid, p->ev[0], p->ev[1]));
+  m->st.n_tris = hc.n_tris;
+  m->st.evals = sxy * nk;  // FlatRenderer.Evaluations(): every lattice corner once
+  m->st.evals_prune = 0;
+  m->st.evals_leaf = m->st.evals;
+  m->st.pruned_leaves = 0;
+  m->st.leaf_cubes = (uint64_t)nx * ny * ncz;
+  m->st.active_leaves = hc.n_active;
+  m->st.ms_prune = 0;
+  m->st.ms_leaf = ms_grid;
+  m->st.ms_march = ms_march;
+  m->st.ms_total = (double)ms_grid + (double)ms_march;
+  p->evals += m->st.evals;
+  p->last_tris = hc.n_tris;
+  *out = m;
+  return GSDF_OK;
+#undef HIP_TRYM
+}
+
+// Pure host helper (no GPU): owner rank of the brick (x,y,z) under the multi-GPU partition that
+// gsdf_hip_mesh_octree applies on device (same function, SURVEY 8(e): no data-path collective).
+// Pure host helper (no GPU): the z-slab [lo, hi) of n lattice planes that rank `rank` of `count` owns in the flat
+// renderer and in dual contouring -- contiguous, disjoint, covering [0, n); ranks beyond n get empty slabs.
+extern "C" void gsdf_hip_slab_range(uint32_t n, uint32_t rank, uint32_t count, uint32_t* lo, uint32_t* hi) {
+  if (!count || rank >= count) { if (lo) *lo = 0; if (hi) *hi = 0; return; }
+  if (lo) *lo = (uint32_t)(((uint64_t)n * (uint64_t)rank) / (uint64_t)count);
+  if (hi) *hi = (uint32_t)(((uint64_t)n * (uint64_t)(rank + 1)) / (uint64_t)count);
+}
+
+extern "C" uint32_t gsdf_hip_brick_owner(uint32_t x, uint32_t y, uint32_t z, uint32_t count) {
+  return count ? brick_owner(x, y, z, count) : 0;
+}
+
+static const char* const kRecordsMsg = "the mesh holds cut-leaf records, not triangles yet: gsdf_hip_mesh_march it, or gather it";
+extern "C" int gsdf_hip_mesh_stats_get(const gsdf_mesh* m, gsdf_mesh_stats* st) {
+  if (!m || !st) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *st = m->st;
+  return GSDF_OK;
+}
+extern "C" int gsdf_hip_mesh_read(const gsdf_mesh* m, uint64_t first, uint64_t count, float* dst) {
+  if (!m || (!dst && count)) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  if (m->payload == GSDF_PAYLOAD_RECORDS) return fail(GSDF_ERR_BAD_ARGUMENT, kRecordsMsg);
+  if (first + count > m->st.n_tris) return fail(GSDF_ERR_BAD_ARGUMENT, "triangle range out of bounds");
+  if (count == 0) return GSDF_OK;
+  // The reference's pull loop (glrender.RenderAll: 4096 triangles per ReadTriangles call) would issue ~1700 small
+  // device-to-host copies at resdiv 1600. Partial reads are served from the mesh's pinned host copy instead: one DMA
+  // on the first call, plain memcpy afterwards.
+  // A read of (nearly) everything takes the same route, with a multi-threaded copy out of the pinned buffer (a pageable
+  // hipMemcpy is staged by the runtime at ~12 GB/s).
+  {
+    const float* h = nullptr;
+    if (gsdf_hip_mesh_host_tris(const_cast<gsdf_mesh*>(m), &h) == GSDF_OK) {
+      big_memcpy(dst, h + first * 9, count * 36);  // single memcpy below 32 MB
+      return GSDF_OK;
+    }
+  }
+  HIP_TRY(hipSetDevice(m->device));  // no pinned memory to be had: plain copy from the device
+  HIP_TRY(hipMemcpy(dst, m->d_tris + first * 9, count * 36, hipMemcpyDeviceToHost));
+  return GSDF_OK;
+}
+extern "C" const float* gsdf_hip_mesh_dev_tris(const gsdf_mesh* m) { return m ? m->d_tris : nullptr; }
+
+extern "C" int gsdf_hip_mesh_stl(const gsdf_mesh* m, uint8_t* dst, size_t dst_cap) {
+  if (!m || !dst) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  const uint64_t n = m->st.n_tris;
+  if (n == 0) return fail(GSDF_ERR_EMPTY_BUFFERS, "empty triangle slice");
+  if (n > 0xffffffffull) return fail(GSDF_ERR_BAD_ARGUMENT, "amount of triangles in model exceeds STL design limits");
+  const size_t bytes = 84 + 50 * (size_t)n;
+  if (dst_cap < bytes) return fail(GSDF_ERR_SHORT_BUFFER, "short buffer");
+  // built on device and moved into the mesh's pinned host buffer (gsdf_hip_mesh_host_stl), then copied out
+  const uint8_t* h = nullptr;
+  size_t len = 0;
+  const int rc = gsdf_hip_mesh_host_stl(const_cast<gsdf_mesh*>(m), &h, &len);
+  if (rc) return rc;
+  big_memcpy(dst, h, len);
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_hip_mesh_host_tris(gsdf_mesh* m, const float** tris) {
+  if (!m || !tris) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *tris = nullptr;
+  if (m->payload == GSDF_PAYLOAD_RECORDS) return fail(GSDF_ERR_BAD_ARGUMENT, kRecordsMsg);
+  const uint64_t n = m->st.n_tris;
+  if (n == 0) return GSDF_OK;
+  if (m->host_out) {  // the mesher wrote them there
+    *tris = m->d_tris;
+    return GSDF_OK;
+  }
+  HIP_TRY(hipSetDevice(m->device));
+  if (!m->h_tris) {
+    const int rc = host_buf(&m->h_tris, &m->h_tris_cap, (size_t)n * 36);
+    if (rc) return rc;
+    hipStream_t rs = mesh_stream(m);
+    hipError_t e = hipMemcpyAsync(m->h_tris, m->d_tris, (size_t)n * 36, hipMemcpyDeviceToHost, rs);
+    if (e == hipSuccess) e = hipStreamSynchronize(rs);
+    if (e != hipSuccess) { hpool_give(m->h_tris, m->h_tris_cap); m->h_tris = nullptr; m->h_tris_cap = 0; return fail(GSDF_ERR_HIP, std::string("D2H triangles: ") + hipGetErrorString(e)); }
+  }
+  *tris = (const float*)m->h_tris;
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_hip_mesh_host_stl(gsdf_mesh* m, const uint8_t** stl, size_t* len) {
+  if (!m || !stl || !len) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *stl = nullptr; *len = 0;
+  if (m->payload == GSDF_PAYLOAD_RECORDS) return fail(GSDF_ERR_BAD_ARGUMENT, kRecordsMsg);
+  const uint64_t n = m->st.n_tris;
+  if (n == 0) return fail(GSDF_ERR_EMPTY_BUFFERS, "empty triangle slice");
+  if (n > 0xffffffffull) return fail(GSDF_ERR_BAD_ARGUMENT, "amount of triangles in model exceeds STL design limits");
+  const size_t bytes = 84 + 50 * (size_t)n;
+  HIP_TRY(hipSetDevice(m->device));
+  if (!m->h_stl) {
+    int rc = host_buf(&m->h_stl, &m->h_stl_cap, bytes);
+    if (rc) return rc;
+    // device scratch for the records from the triangle-buffer pool (sized in 36-byte units)
+    const uint64_t units = (bytes + 4 + 35) / 36;
+    uint64_t dcap = 0;
+    float* d_out = pool_take(m->device, units, &dcap);
+    if (!d_out) {
+      if (hipMalloc((void**)&d_out, units * 36) != hipSuccess) { (void)hipGetLastError(); return fail(GSDF_ERR_HIP, "hipMalloc of the STL scratch failed"); }
+      dcap = units;
+    }
+    uint8_t* hdr = (uint8_t*)m->h_stl;  // pinned: a valid source for the async header upload
+    std::memset(hdr, 0, 84);
+    const uint32_t cnt = (uint32_t)n;
+    std::memcpy(hdr + 80, &cnt, 4);
+    hipStream_t rs = mesh_stream(m);
+    hipError_t e = hipMemcpyAsync(d_out, hdr, 84, hipMemcpyHostToDevice, rs);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(stl_kernel, dim3(grid_for(n, 256, 8)), dim3(BLOCK), 0, rs, m->d_tris, n, (uint8_t*)d_out);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(m->h_stl, d_out, bytes, hipMemcpyDeviceToHost, rs);
+    if (e == hipSuccess) e = hipStreamSynchronize(rs);
+    pool_give(m->device, d_out, dcap);
+    if (e != hipSuccess) { hpool_give(m->h_stl, m->h_stl_cap); m->h_stl = nullptr; m->h_stl_cap = 0; return fail(GSDF_ERR_HIP, std::string("STL build/transfer: ") + hipGetErrorString(e)); }
+  }
+  *stl = (const uint8_t*)m->h_stl;
+  *len = bytes;
+  return GSDF_OK;
+}
+
+static void mesh_free(gsdf_mesh* m) {
+  release_tris(m);
+  pool_give(m->device, (float*)m->d_recs, m->recs_cap36);
+  hpool_give(m->h_tris, m->h_tris_cap);
+  hpool_give(m->h_stl, m->h_stl_cap);
+  if (m->rstream) (void)hipStreamDestroy(m->rstream);
+  delete m;
+}
+extern "C" void gsdf_hip_mesh_destroy(gsdf_mesh* m) {
+  if (!m) return;
+  // a gather is still reading the buffers (gsdf_hip_mesh_gatherv_start .. _wait): the gather's end frees them
+  m->zombie.store(true);
+  if (m->inflight.load() > 0) return;
+  if (m->zombie.exchange(false)) mesh_free(m);
+}
+void mesh_inflight_done(gsdf_mesh* m) {
+  if (m->inflight.fetch_sub(1) == 1 && m->zombie.exchange(false)) mesh_free(m);
+}

@@ -164,8 +164,8 @@ float lip_norm2(float a, float b, float c, float d) {  // 2x2 [[a b][c d]]
   if (disc < 0) disc = 0;
   return (float)std::sqrt(0.5 * (S + std::sqrt(disc)));
 }
-constexpr float kLipRigidTol = 1.00001f;  // a linear map counts as rigid (factor 1) up to this;
-constexpr float kLipRoundUp = 1.000001f;  // beyond it the factor is rounded up
+constexpr float kLipRigidTol = 1.0f;       // a linear map of norm <= 1 keeps the ball's radius; anything above (also the 1.0000001 of a
+constexpr float kLipRoundUp = 1.000001f;  // rotation built from rounded sines) stretches it, and the factor is rounded up
 // How much a screw's field may jump across a seam of its sawtooth: the profile is evaluated at ONE period of the axial
 // coordinate, so its field at (+pitch/2, y) meets its field at (-pitch/2, y) there. They differ by less than the distance
 // between the two points, the pitch; if the profile is a polygon that is its own mirror image in x up to d (vertex i of the
@@ -771,7 +771,7 @@ void gen(Ctx& c, uint32_t i, int depth) {
     case GSDF_SMOOTH_INTERSECT: need_children(2); child_dim(false); gen_combine(c, n, D_COMBINE_SINTER, true, depth); break;
     // ------------------------------- 3D unary -------------------------------
     case GSDF_SCALE: need_children(1); child_dim(false);                                           // :288-312
-      c.op(D_SCALE_PRE); c.f(1.f / P[0]); c.bump(); gen(c, c.child(n, 0), depth + 1); c.op(D_MULR); c.f(P[0]); break;
+      { const int ld = c.lip_push(); c.op(D_SCALE_PRE); c.f(1.f / P[0]); c.bump(); gen(c, c.child(n, 0), depth + 1); c.op(D_MULR); c.f(P[0]); c.lip_pop(ld); } break;  // (push / pop: the outer radius comes back exactly, not as (R / s) * s)
     case GSDF_SYMMETRY: need_children(1); child_dim(false);                                        // :314-343
       c.op(D_SYMMETRY); c.u((uint32_t)(int)P[0]); if ((int)P[0] & 3) c.bump(); gen(c, c.child(n, 0), depth + 1); break;
     case GSDF_ARRAY: {                                                                             // :345-397
@@ -803,7 +803,7 @@ void gen(Ctx& c, uint32_t i, int depth) {
       break;
     }
     case GSDF_SHELL: need_children(1); child_dim(false);                                           // :428-452
-      c.op(D_SCALE_PRE); c.f(1 / P[0]); c.bump(); gen(c, c.child(n, 0), depth + 1); c.op(D_SHELL_POST); c.f(P[0]); break;
+      { const int ld = c.lip_push(); c.op(D_SCALE_PRE); c.f(1 / P[0]); c.bump(); gen(c, c.child(n, 0), depth + 1); c.op(D_SHELL_POST); c.f(P[0]); c.lip_pop(ld); } break;
     case GSDF_OFFSET: need_children(1); child_dim(false);                                          // :454-468
       gen(c, c.child(n, 0), depth + 1); c.op(D_ADDR); c.f(P[0]); break;
     case GSDF_TRANSLATE: need_children(1); child_dim(false);                                       // :470-486
@@ -1049,7 +1049,7 @@ void gen(Ctx& c, uint32_t i, int depth) {
       break;
     }
     case GSDF_SCALE2D: need_children(1); child_dim(true);                                          // :1205-1226
-      c.op(D_SCALE_PRE); c.f(1.f / P[0]); c.bump(); gen(c, c.child(n, 0), depth + 1); c.op(D_MULR); c.f(P[0]); break;
+      { const int ld = c.lip_push(); c.op(D_SCALE_PRE); c.f(1.f / P[0]); c.bump(); gen(c, c.child(n, 0), depth + 1); c.op(D_MULR); c.f(P[0]); c.lip_pop(ld); } break;
     case GSDF_ELONGATE2D: {                                                                        // :1228-1255
       need_children(1); child_dim(true);
       int s = c.alloc(1);

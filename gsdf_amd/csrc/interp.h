@@ -751,7 +751,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
           const float f = PF(0);
           p.x = f * p.x; p.y = f * p.y; p.z = f * p.z;
         }
-        if (LIP) lipR = lipR * PF(0);
+        if (LIP) lipR = lipR * absf(PF(0));  // (a negative factor mirrors: the radius scales by its magnitude)
         pc += 2;
         break;
       }
@@ -985,7 +985,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       // ------------------------------------------------ distance post-ops
       case D_MULR: {
         if (LIP) {  // the scale nodes' d * f on an interval (f of either sign); the ball's image is back in the outer frame
-          lipR = lipR * PF(0);
+          lipR = lipR * absf(PF(0));
           const float x0 = Rv[LIP_LO] * PF(0), x1 = Rv[LIP_HI] * PF(0);
           Rv[LIP_LO] = minf(x0, x1); Rv[LIP_HI] = maxf(x0, x1);
         } else {
@@ -997,7 +997,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       case D_SHELL_POST: {
         const float th = PF(0);
         if (LIP) {
-          lipR = lipR * th;
+          lipR = lipR * absf(th);
           float alo, ahi;
           lip_abs(Rv[LIP_LO], Rv[LIP_HI], alo, ahi);
           const float x0 = th * (alo - th), x1 = th * (ahi - th);

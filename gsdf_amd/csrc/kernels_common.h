@@ -9,6 +9,8 @@ using gsdf_dev::code_ptr;
 using gsdf_dev::P3;
 
 #define BLOCK 256
+#define LEAF_MIN_COLS 14  // leaf_kernel's LDS columns per lane: 8 corner distances + 3 origin + 3 for the owner list / cube indices
+#define TRI_STAGE 128  // triangles staged in LDS per workgroup before one coalesced flush (4.5 KB: lets 4 workgroups of a 7-slot program share a CU)
 
 // ---------------------------------------------------------------------------------------------
 // device side

@@ -280,8 +280,7 @@ __device__ __forceinline__ void mc_interp(float ax, float ay, float az, float bx
   rx = x; ry = y; rz = z;
 }
 
-#define LEAF_MIN_COLS 14  // leaf_kernel's LDS columns per lane: 8 corner distances + 3 origin + 3 for the owner list / cube indices
-#define TRI_STAGE 128  // triangles staged in LDS per workgroup before one coalesced flush (4.5 KB: lets 4 workgroups of a 7-slot program share a CU)
+// (LEAF_MIN_COLS and TRI_STAGE, which the host's LDS arithmetic needs too, are in kernels_common.h)
 
 // Marching cubes of one leaf per lane + block-wide triangle emission (shared by both leaf kernels).
 // vslot: the lane's 8 corner distances in its LDS column; index: the 8-bit inside mask (0 = no triangles).
@@ -879,6 +878,84 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
   return incl + (wave > 0 ? a : 0ull) + (wave > 1 ? b : 0ull) + (wave > 2 ? c : 0ull);
 }
 
+// One chunk of at most BLOCK cut-leaf records, one per lane (rw: the lane's record, `has`: it has one), marched into triangles
+// number out, out + 1, ...: returns the chunk's triangle count (block-uniform). Shared by march_records_kernel (records where
+// leaf_eval_kernel left them) and march_dense_kernel (packed records, after a gather). `prefetch` runs once the lane's record is
+// in LDS -- the caller's load of its NEXT record, in flight while this chunk is marched (a dependent global load is ~2 us).
+// Ends with a barrier: the caller may rewrite the columns, the owner list and s_misc.
+//   s_col [BLOCK][11]: 8 distances + origin (odd stride: one record's values, read together by neighbouring lanes, sit in 11 banks)
+//   s_own [5 * BLOCK]: triangle -> table offset (index*16 + 3*number) | record << 12
+//   s_tri: the triangle table, a row's spare byte 15 = its triangle count;  s_misc[0..3]: wave sums
+template <typename Prefetch>
+__device__ __forceinline__ unsigned march_chunk_emit(const uint32_t (&rw)[10], bool has, Prefetch prefetch, float ox, float oy, float oz,
+                                                     float res, float* s_col, uint32_t* s_own, const int8_t* s_tri, unsigned* s_misc,
+                                                     float* __restrict__ tris, unsigned long long out) {
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  unsigned index = 0;
+  if (has) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) s_col[threadIdx.x * 11u + c] = __uint_as_float(rw[c]);
+    const uint32_t xy = rw[8], zi = rw[9];
+    index = zi >> 16;
+    // the leaf origin exactly as the evaluating kernel formed it
+    s_col[threadIdx.x * 11u + 8u] = ox + res * (float)(xy & 0xffffu);
+    s_col[threadIdx.x * 11u + 9u] = oy + res * (float)(xy >> 16);
+    s_col[threadIdx.x * 11u + 10u] = oz + res * (float)(zi & 0xffffu);
+  }
+  prefetch();
+  // owner list: prefix sum of the records' triangle counts (the table's spare byte holds the row's count)
+  const unsigned nt = index ? (unsigned)s_tri[index * 16 + 15] : 0u;
+  unsigned ti = nt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned u = __shfl_up(ti, off, 64);
+    if (lane >= (unsigned)off) ti += u;
+  }
+  if (lane == 63) s_misc[wave] = ti;
+  __syncthreads();
+  const unsigned w0 = __builtin_amdgcn_readfirstlane(s_misc[0]), w1 = __builtin_amdgcn_readfirstlane(s_misc[1]),
+                 w2 = __builtin_amdgcn_readfirstlane(s_misc[2]), w3 = __builtin_amdgcn_readfirstlane(s_misc[3]);
+  const unsigned total = w0 + w1 + w2 + w3;
+  const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned first = (wave_u > 0 ? w0 : 0u) + (wave_u > 1 ? w1 : 0u) + (wave_u > 2 ? w2 : 0u) + (ti - nt);
+  for (unsigned k = 0; k < nt; k++) s_own[first + k] = (index * 16u + 3u * k) | (threadIdx.x << 12);
+  __syncthreads();
+  // one output VERTEX per lane: a wave's store is 768 contiguous bytes
+  struct __attribute__((packed, aligned(4))) V3 { float x, y, z; };
+  V3* dst = (V3*)(tris + out * 9);
+  const unsigned n3 = total * 3u;
+#pragma unroll 2
+  for (unsigned k = threadIdx.x; k < n3; k += BLOCK) {
+    const unsigned t = k / 3u, j = k - 3u * t;
+    const uint32_t o = s_own[t];
+    const float* col = s_col + (o >> 12) * 11u;
+    const int e = s_tri[(o & 4095u) + (2u - j)];  // reversed winding (marchcubes.go:64-68)
+    const unsigned ca = GSDF_MC_PAIR_A(e), cb = GSDF_MC_PAIR_B(e);
+    const float x0 = col[8], y0 = col[9], z0 = col[10];
+    const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;  // Box max = origin + size
+    const bool ax = ((ca ^ (ca >> 1)) & 1u) != 0u, ay = ((ca >> 1) & 1u) != 0u, az = ((ca >> 2) & 1u) != 0u;
+    const bool bx = ((cb ^ (cb >> 1)) & 1u) != 0u, by = ((cb >> 1) & 1u) != 0u, bz = ((cb >> 2) & 1u) != 0u;
+    V3 r;
+    mc_interp(ax ? x1 : x0, ay ? y1 : y0, az ? z1 : z0, bx ? x1 : x0, by ? y1 : y0, bz ? z1 : z0, col[ca], col[cb], r.x, r.y, r.z);
+#ifdef GSDF_EXP_MARCH_NO_STORE  // developer experiment (library built with -D...): the kernel without its output stream (timing only)
+    if (r.x == 1.2345678e-30f) dst[k] = r;
+#else
+    dst[k] = r;
+#endif
+  }
+  __syncthreads();  // the next chunk rewrites the columns, the owner list and s_misc
+  return total;
+}
+
+// The triangle table as the marching kernels keep it in LDS: by dwords, a row's spare byte 15 takes its triangle count.
+__device__ __forceinline__ void march_load_table(int8_t* s_tri) {
+  for (int k = threadIdx.x; k < 256 * 4; k += BLOCK) {
+    uint32_t w = ((const uint32_t*)&GSDF_MC_TRI[0][0])[k];
+    if ((k & 3) == 3) w = (w & 0x00ffffffu) | ((uint32_t)GSDF_MC_NTRI[k >> 2] << 24);
+    ((uint32_t*)s_tri)[k] = w;
+  }
+}
+
 // Marching cubes over the cut-leaf records. NO atomic, NO staging.
 //  * Where things go: the evaluating kernel left, per group of MARCH_GROUP blocks, the number of records and of triangles
 //    (psum); every workgroup sums those (a few KB from L2), takes an equal share of the RECORDS -- a contiguous range of
@@ -905,11 +982,7 @@ __global__ void __launch_bounds__(BLOCK, 7) march_records_kernel(const uint32_t*
   unsigned* s_pre = (unsigned*)(s_tri + 256 * 16);             // [BLOCK + 1] exclusive prefix of the pass's record counts
   unsigned* s_misc = s_pre + BLOCK + 1;                        // [0..3] wave sums of the triangle counts, [4..7] of the record counts
   unsigned long long* s_u64 = (unsigned long long*)(((uintptr_t)(s_misc + 8) + 7) & ~(uintptr_t)7);  // [0..3] scan, [4..9] found, [10..13] result
-  for (int k = threadIdx.x; k < 256 * 4; k += BLOCK) {  // the table by dwords; a row's spare byte 15 takes its triangle count
-    uint32_t w = ((const uint32_t*)&GSDF_MC_TRI[0][0])[k];
-    if ((k & 3) == 3) w = (w & 0x00ffffffu) | ((uint32_t)GSDF_MC_NTRI[k >> 2] << 24);
-    ((uint32_t*)s_tri)[k] = w;
-  }
+  march_load_table(s_tri);
   unsigned long long n_cubes = uniform_u64(ctr->n_level[lq]);
   const uint64_t n_leaves = n_cubes << (3 * (lq - 1));
   uint64_t n_blocks = (n_leaves + 63) >> 6;
@@ -1054,61 +1127,231 @@ __global__ void __launch_bounds__(BLOCK, 7) march_records_kernel(const uint32_t*
     fetch(threadIdx.x);
     for (unsigned q0 = 0; q0 < Rp; q0 += BLOCK) {  // block-uniform
       const unsigned q = q0 + threadIdx.x;
-      unsigned index = 0;
-      if (q < Rp) {
-#pragma unroll
-        for (int c = 0; c < 8; c++) s_col[threadIdx.x * 11u + c] = __uint_as_float(rw[c]);
-        const uint32_t xy = rw[8], zi = rw[9];
-        index = zi >> 16;
-        // the leaf origin exactly as the evaluating kernel formed it
-        s_col[threadIdx.x * 11u + 8u] = ox + res * (float)(xy & 0xffffu);
-        s_col[threadIdx.x * 11u + 9u] = oy + res * (float)(xy >> 16);
-        s_col[threadIdx.x * 11u + 10u] = oz + res * (float)(zi & 0xffffu);
-      }
-      fetch(q + BLOCK);  // in flight while this chunk is marched
-      // owner list: prefix sum of the records' triangle counts (the table's spare byte holds the row's count)
-      const unsigned nt = index ? (unsigned)s_tri[index * 16 + 15] : 0u;
-      unsigned ti = nt;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const unsigned u = __shfl_up(ti, off, 64);
-        if (lane >= (unsigned)off) ti += u;
-      }
-      if (lane == 63) s_misc[wave] = ti;
-      __syncthreads();
-      const unsigned w0 = __builtin_amdgcn_readfirstlane(s_misc[0]), w1 = __builtin_amdgcn_readfirstlane(s_misc[1]),
-                     w2 = __builtin_amdgcn_readfirstlane(s_misc[2]), w3 = __builtin_amdgcn_readfirstlane(s_misc[3]);
-      const unsigned total = w0 + w1 + w2 + w3;
-      const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
-      const unsigned first = (wave_u > 0 ? w0 : 0u) + (wave_u > 1 ? w1 : 0u) + (wave_u > 2 ? w2 : 0u) + (ti - nt);
-      for (unsigned k = 0; k < nt; k++) s_own[first + k] = (index * 16u + 3u * k) | (threadIdx.x << 12);
-      __syncthreads();
-      // one output VERTEX per lane: a wave's store is 768 contiguous bytes
-      struct __attribute__((packed, aligned(4))) V3 { float x, y, z; };
-      V3* dst = (V3*)(tris + out * 9);
-      const unsigned n3 = total * 3u;
-#pragma unroll 2
-      for (unsigned k = threadIdx.x; k < n3; k += BLOCK) {
-        const unsigned t = k / 3u, j = k - 3u * t;
-        const uint32_t o = s_own[t];
-        const float* col = s_col + (o >> 12) * 11u;
-        const int e = s_tri[(o & 4095u) + (2u - j)];  // reversed winding (marchcubes.go:64-68)
-        const unsigned ca = GSDF_MC_PAIR_A(e), cb = GSDF_MC_PAIR_B(e);
-        const float x0 = col[8], y0 = col[9], z0 = col[10];
-        const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;  // Box max = origin + size
-        const bool ax = ((ca ^ (ca >> 1)) & 1u) != 0u, ay = ((ca >> 1) & 1u) != 0u, az = ((ca >> 2) & 1u) != 0u;
-        const bool bx = ((cb ^ (cb >> 1)) & 1u) != 0u, by = ((cb >> 1) & 1u) != 0u, bz = ((cb >> 2) & 1u) != 0u;
-        V3 r;
-        mc_interp(ax ? x1 : x0, ay ? y1 : y0, az ? z1 : z0, bx ? x1 : x0, by ? y1 : y0, bz ? z1 : z0, col[ca], col[cb], r.x, r.y, r.z);
-#ifdef GSDF_EXP_MARCH_NO_STORE  // developer experiment (library built with -D...): the kernel without its output stream (timing only)
-        if (r.x == 1.2345678e-30f) dst[k] = r;
-#else
-        dst[k] = r;
-#endif
-      }
-      out += total;
-      __syncthreads();  // the next chunk rewrites the columns, the owner list and s_misc
+      out += march_chunk_emit(rw, q < Rp, [&] { fetch(q + BLOCK); }, ox, oy, oz, res, s_col, s_own, s_tri, s_misc, tris, out);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Packed cut-leaf records: the mesh as a rank hands it to a gather (gsdf_mesh_opts.payload = GSDF_PAYLOAD_RECORDS).
+//
+// A triangle is 36 bytes; the cut leaf it came from is a 40-byte record that yields 2.0 triangles on the configs' surfaces --
+// 20 bytes per triangle. Over xGMI (one ~60 GB/s link per peer) an all-gather of npt-flange's 6.8 M triangles at resdiv 1600 is
+// 245 MB of wire per rank, several times what a rank takes to mesh its share; as records it is 136 MB, and marching cubes runs
+// AFTER the gather, on every rank that receives, over everybody's records (march_dense_kernel: HBM-bound, ~0.1 ms for the whole
+// mesh). Same records, same arithmetic, same triangles as march_records_kernel makes of them; only their order differs.
+//
+// Payload of n records (dense_payload_bytes(n)):   [n x 40-byte records, in block order][u32 per chunk of DENSE_CHUNK records:
+// the chunk's triangle count], padded to 8 bytes -- so a receiver knows where every chunk's triangles go without a pass of its own.
+//   scan_groups_kernel   (one workgroup) exclusive prefix of the groups' record counts; totals to the counters and to the host
+//   pack_records_kernel  the sparse record slots of leaf_eval_kernel -> the payload; chunk triangle counts by wave-level atomics
+//   march_dense_kernel   marching cubes over a buffer holding the payloads of several ranks side by side (or of one)
+// ---------------------------------------------------------------------------------------------------------------------
+#define DENSE_CHUNK 256
+#define DENSE_MAX_PARTS 64
+__host__ __device__ __forceinline__ unsigned long long dense_payload_bytes(unsigned long long n) {
+  return n * 40ull + ((((n + DENSE_CHUNK - 1ull) / DENSE_CHUNK) * 4ull + 7ull) & ~7ull);
+}
+struct DensePart {
+  unsigned long long off;     // where this rank's payload starts in the buffer (bytes, a multiple of 8)
+  unsigned long long n_recs;  // its records
+  unsigned long long tri0;    // triangles of the parts before it
+};
+struct DenseParts {
+  int n;
+  int pad;
+  DensePart p[DENSE_MAX_PARTS];
+};
+
+// Exclusive prefix of the record counts of the groups (psum) -> grp_base; totals -> ctr (n_cut, n_tris, n_active) and, as the
+// mesh's counters for the host, host_ctr (pinned, device-mapped: visible when the chain has completed); the payload's chunk
+// counts are cleared for pack_records_kernel's atomics. ONE workgroup of 1024 threads: a few thousand to a few hundred thousand
+// 8-byte words from L2.
+__global__ void __launch_bounds__(1024) scan_groups_kernel(const unsigned long long* __restrict__ psum, unsigned long long n_blocks_cap, int lq,
+                                                           MeshCounters* __restrict__ ctr, unsigned long long* __restrict__ grp_base,
+                                                           uint8_t* __restrict__ payload, unsigned long long rec_cap,
+                                                           MeshCounters* __restrict__ host_ctr) {
+  __shared__ unsigned long long s_r[16], s_t[16], s_a[16];
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  unsigned long long n_cubes = uniform_u64(ctr->n_level[lq]);
+  const uint64_t n_leaves = n_cubes << (3 * (lq - 1));
+  uint64_t n_blocks = (n_leaves + 63) >> 6;
+  if (n_blocks > n_blocks_cap) n_blocks = n_blocks_cap;
+  const uint64_t n_grp = (n_blocks + MARCH_GROUP - 1) / MARCH_GROUP;
+  const uint64_t per = (n_grp + 1023) / 1024;
+  uint64_t e0 = (uint64_t)tid * per, e1 = e0 + per;
+  if (e0 > n_grp) e0 = n_grp;
+  if (e1 > n_grp) e1 = n_grp;
+  unsigned long long lr = 0, lt = 0, la = 0;
+  for (uint64_t e = e0; e < e1; e++) {
+    const unsigned long long v = psum[e];
+    lr += PSUM_REC(v); lt += PSUM_TRI(v); la += PSUM_ACT(v);
+  }
+  unsigned long long ir = lr, it = lt, ia = la;  // wave inclusive scans (only the records' is needed per thread; the others as totals)
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned rl = __shfl_up((unsigned)ir, off, 64), rh = __shfl_up((unsigned)(ir >> 32), off, 64);
+    const unsigned tl = __shfl_up((unsigned)it, off, 64), th = __shfl_up((unsigned)(it >> 32), off, 64);
+    const unsigned al = __shfl_up((unsigned)ia, off, 64), ah = __shfl_up((unsigned)(ia >> 32), off, 64);
+    if (lane >= (unsigned)off) { ir += ((unsigned long long)rh << 32) | rl; it += ((unsigned long long)th << 32) | tl; ia += ((unsigned long long)ah << 32) | al; }
+  }
+  if (lane == 63u) { s_r[wave] = ir; s_t[wave] = it; s_a[wave] = ia; }
+  __syncthreads();
+  unsigned long long R = 0, T = 0, A = 0, before = 0;
+  for (unsigned w = 0; w < 16u; w++) {
+    if (w < wave) before += s_r[w];
+    R += s_r[w]; T += s_t[w]; A += s_a[w];
+  }
+  unsigned long long acc = before + ir - lr;
+  for (uint64_t e = e0; e < e1; e++) {
+    grp_base[e] = acc;
+    acc += PSUM_REC(psum[e]);
+  }
+  const bool fits = R <= rec_cap;
+  if (fits) {
+    uint32_t* chunk_tri = (uint32_t*)(payload + R * 40ull);
+    const unsigned long long nch = (R + DENSE_CHUNK - 1ull) / DENSE_CHUNK;
+    for (unsigned long long k = tid; k < ((nch + 1ull) & ~1ull); k += 1024) chunk_tri[k] = 0u;  // (+ the padding word)
+  }
+  if (tid == 0) {
+    ctr->n_cut = R; ctr->n_tris = T; ctr->n_active = A;
+    if (!fits) ctr->overflow = 1ull;  // the host learns the exact size and reruns
+  }
+  if (host_ctr != nullptr) {
+    const unsigned long long* src = (const unsigned long long*)ctr;
+    unsigned long long* dst = (unsigned long long*)host_ctr;
+    for (unsigned k = tid; k < (unsigned)(sizeof(MeshCounters) / 8); k += 1024) {
+      unsigned long long v = src[k];
+      if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_tris) / 8)) v = T;
+      if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_cut) / 8)) v = R;
+      if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_active) / 8)) v = A;
+      if (k == (unsigned)(__builtin_offsetof(MeshCounters, overflow) / 8) && !fits) v = 1ull;
+      dst[k] = v;
+    }
+  }
+}
+
+// The record slots of leaf_eval_kernel (a 2 560-byte slot per 64-leaf block, its first hdr & 255 records used) -> the payload.
+// One workgroup per group of MARCH_GROUP blocks (grid-stride), a wave per 16 of them: 8-byte copies, a lane per piece; then a
+// lane per record adds its triangle count to its chunk's word -- per block at most two chunks, so two wave-level atomics.
+__global__ void __launch_bounds__(BLOCK) pack_records_kernel(const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ rec,
+                                                             const unsigned long long* __restrict__ grp_base, unsigned long long n_blocks_cap,
+                                                             int lq, const MeshCounters* __restrict__ ctr, uint8_t* __restrict__ payload,
+                                                             unsigned long long rec_cap) {
+  __shared__ uint8_t s_nt[256];
+  s_nt[threadIdx.x] = GSDF_MC_NTRI[threadIdx.x];
+  __syncthreads();
+  const unsigned long long R = uniform_u64(ctr->n_cut);
+  if (R > rec_cap || R == 0ull) return;
+  unsigned long long n_cubes = uniform_u64(ctr->n_level[lq]);
+  const uint64_t n_leaves = n_cubes << (3 * (lq - 1));
+  uint64_t n_blocks = (n_leaves + 63) >> 6;
+  if (n_blocks > n_blocks_cap) n_blocks = n_blocks_cap;
+  const uint64_t n_grp = (n_blocks + MARCH_GROUP - 1) / MARCH_GROUP;
+  uint32_t* chunk_tri = (uint32_t*)(payload + R * 40ull);
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (uint64_t g = blockIdx.x; g < n_grp; g += gridDim.x) {
+    const uint64_t b_lane = g * MARCH_GROUP + lane;
+    const unsigned nr = b_lane < n_blocks ? (hdr[b_lane] & 255u) : 0u;
+    unsigned incl = nr;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned u = __shfl_up(incl, off, 64);
+      if (lane >= (unsigned)off) incl += u;
+    }
+    const unsigned long long base = uniform_u64(grp_base[g]);
+    for (unsigned j = 0; j < 16u; j++) {
+      const unsigned b = wave * 16u + j;
+      const unsigned nrb = (unsigned)__shfl((int)nr, (int)b, 64);
+      if (nrb == 0u) continue;  // wave-uniform
+      const unsigned long long d0 = base + (unsigned long long)((unsigned)__shfl((int)incl, (int)b, 64) - nrb);  // first dense record of the block
+      const uint32_t* src_w = rec + (g * MARCH_GROUP + b) * REC_BLOCK;
+      const uint2* src = (const uint2*)src_w;
+      uint2* dst = (uint2*)(payload + d0 * 40ull);
+      for (unsigned i = lane; i < nrb * 5u; i += 64u) dst[i] = src[i];
+      unsigned nt = 0u;
+      bool second = false;
+      const unsigned long long ch0 = d0 / DENSE_CHUNK;
+      if (lane < nrb) {
+        nt = (unsigned)s_nt[src_w[lane * REC_WORDS + 9u] >> 16];
+        second = (d0 + lane) / DENSE_CHUNK != ch0;
+      }
+      const unsigned long long m1 = __ballot((nt & 1u) != 0u), m2 = __ballot((nt & 2u) != 0u), m4 = __ballot((nt & 4u) != 0u);
+      const unsigned long long sm = __ballot(second);
+      const unsigned sA = (unsigned)__builtin_popcountll(m1 & ~sm) + 2u * (unsigned)__builtin_popcountll(m2 & ~sm) + 4u * (unsigned)__builtin_popcountll(m4 & ~sm);
+      const unsigned sB = (unsigned)__builtin_popcountll(m1 & sm) + 2u * (unsigned)__builtin_popcountll(m2 & sm) + 4u * (unsigned)__builtin_popcountll(m4 & sm);
+      if (lane == 0u) {
+        if (sA) atomicAdd(&chunk_tri[ch0], sA);
+        if (sB) atomicAdd(&chunk_tri[ch0 + 1ull], sB);
+      }
+    }
+  }
+}
+
+// Marching cubes over packed records: `buf` holds the payloads of parts->n ranks (a gather's receive buffer; or one rank's own).
+// The chunks of all parts form one list; a workgroup takes an equal, contiguous share of it and knows from the chunk counts
+// where its first triangle goes (the part's tri0 + the counts of the part's chunks before it: a few KB from L2). Triangles
+// come out part-major, in record order. The chunk body is march_records_kernel's (march_chunk_emit): one record per lane, the
+// next chunk's record in flight while this one is marched, one output vertex per lane.
+// LDS: [11 record columns | owner list | tri table | misc] = 20.7 KB: 7 workgroups per CU.
+__global__ void __launch_bounds__(BLOCK, 7) march_dense_kernel(const uint8_t* __restrict__ buf, const DenseParts* __restrict__ parts, float ox, float oy, float oz,
+                                                               float res, float* __restrict__ tris) {
+  float* s_col = g_smem;
+  uint32_t* s_own = (uint32_t*)(s_col + 11 * BLOCK);
+  int8_t* s_tri = (int8_t*)(s_own + 5 * BLOCK);
+  unsigned* s_misc = (unsigned*)(s_tri + 256 * 16);
+  unsigned long long* s_u64 = (unsigned long long*)(((uintptr_t)(s_misc + 8) + 7) & ~(uintptr_t)7);
+  march_load_table(s_tri);
+  const int np = parts->n;
+  auto chunks_of = [&](int p) -> unsigned long long { return (parts->p[p].n_recs + DENSE_CHUNK - 1ull) / DENSE_CHUNK; };
+  unsigned long long G = 0;
+  for (int p = 0; p < np; p++) G += chunks_of(p);
+  const unsigned long long g0 = G * blockIdx.x / gridDim.x, g1 = G * (blockIdx.x + 1ull) / gridDim.x;
+  if (g0 == g1) return;
+  // the part and the chunk within it where this workgroup starts
+  int p = 0;
+  unsigned long long c = g0;
+  while (p < np && c >= chunks_of(p)) { c -= chunks_of(p); p++; }
+  // triangles before it
+  unsigned long long before = 0;
+  {
+    const uint32_t* ct = (const uint32_t*)(buf + parts->p[p].off + parts->p[p].n_recs * 40ull);
+    unsigned long long acc = 0;
+    for (unsigned long long k = threadIdx.x; k < c; k += BLOCK) acc += ct[k];
+    unsigned long long tot;
+    (void)block_scan_u64(acc, s_u64, &tot);
+    before = parts->p[p].tri0 + tot;
+  }
+  unsigned long long out = before;
+  struct __attribute__((packed, aligned(8))) Rec { uint32_t w[REC_WORDS]; };
+  uint32_t rw[REC_WORDS];
+  bool has = false;
+  auto fetch = [&](int fp, unsigned long long fc, bool in_range) {
+#pragma unroll
+    for (int k = 0; k < REC_WORDS; k++) rw[k] = 0u;
+    has = false;
+    if (in_range) {
+      const unsigned long long q = fc * DENSE_CHUNK + threadIdx.x;
+      if (q < parts->p[fp].n_recs) {
+        const Rec v = *(const Rec*)(buf + parts->p[fp].off + q * 40ull);
+#pragma unroll
+        for (int k = 0; k < REC_WORDS; k++) rw[k] = v.w[k];
+        has = true;
+      }
+    }
+  };
+  fetch(p, c, true);
+  for (unsigned long long g = g0; g < g1; g++) {  // block-uniform
+    // the chunk after this one (possibly the first of the next part that has any)
+    int pn = p;
+    unsigned long long cn = c + 1;
+    while (pn < np && cn >= chunks_of(pn)) { cn = 0; pn++; }
+    const bool more = g + 1 < g1;
+    const bool has_now = has;
+    const unsigned n = march_chunk_emit(rw, has_now, [&] { fetch(pn, cn, more); }, ox, oy, oz, res, s_col, s_own, s_tri, s_misc, tris, out);
+    out += n;
+    if (pn != p && pn < np) out = parts->p[pn].tri0;  // (the same number, unless a payload's counts are damaged)
+    p = pn; c = cn;
   }
 }
 

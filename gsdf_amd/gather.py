@@ -1,16 +1,20 @@
-"""Variable-length gather of per-rank triangle buffers over torch.distributed -- the gloo-testable REFERENCE of the
-rank-major layout. The product's multi-GPU exchange is gsdf_hip_mesh_gatherv (include/gsdf_hip.h): RCCL called directly
-inside libgsdfhip.so, no padding and no staging copies; bench.py --gpus N uses that. This module remains for CPU tests
-of the ordering (tests/test_gather_gloo.py) and for callers that already hold torch tensors.
+"""The library's gather plan (gsdf_hip_gather_plan, include/gsdf_hip.h) executed over torch.distributed point-to-point
+transfers instead of the library's own RCCL communicator.
 
-The mesher shards octree bricks across ranks with no data-path communication; the only exchange is
-this final gather. RCCL has no all-gatherv: exchange the counts (one all_gather of
-world int64), pad every rank's payload to the maximum count and run ONE all_gather_into_tensor (one
-large collective; bricks are dealt by a coordinate hash so counts are balanced and padding is small), then
-compact on device.
+The product's multi-GPU exchange is gsdf_hip_mesh_gatherv_start / _wait: RCCL called directly inside libgsdfhip.so, which
+runs exactly the list of copies / sends / receives that gsdf_hip_gather_plan returns for the ranks' payload sizes. This module
+runs THE SAME LIST with dist.isend / dist.irecv -- on gloo for the CPU tests of the schedule and the rank-major layout
+(tests/test_gather_gloo.py, world sizes 2 and 3, ragged and empty ranks, all three modes), and on torch's RCCL process group
+as bench.py's fallback when the library's communicator cannot be had. Nothing is padded: the counts are exchanged (one
+all_gather of world int64) and every transfer has its exact size.
+
+The mesher shards octree bricks across ranks with no data-path communication; the only exchange is this final gather
+(SURVEY.md 8(e)).
 """
 import torch
 import torch.distributed as dist
+
+from . import hip
 
 
 class _DevArray:
@@ -26,27 +30,38 @@ def tensor_from_dev_ptr(ptr, n_tris, device):
     return torch.as_tensor(_DevArray(ptr, n_tris * 9), device=device).view(n_tris, 9)
 
 
+def run_plan(payload, mode=hip.GATHER_ALL, root=0, group=None):
+    """payload: 1-D uint8 tensor (this rank's bytes). Exchanges the sizes, asks the library for this rank's plan and runs it.
+    Returns (gathered uint8 tensor -- empty on ranks that receive nothing --, bytes per rank, the plan)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = payload.device
+    n = torch.tensor([payload.numel()], dtype=torch.int64, device=dev)
+    sizes = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, n, group=group)
+    sizes_l = [int(c) for c in sizes.tolist()]
+    ops, total = hip.gather_plan(sizes_l, rank, mode, root)
+    out = torch.empty(total, dtype=torch.uint8, device=dev)
+    reqs = []
+    for kind, peer, src_off, dst_off, nbytes in ops:
+        if kind == hip.GOP_COPY:
+            out[dst_off:dst_off + nbytes] = payload[src_off:src_off + nbytes]
+        elif kind == hip.GOP_SEND:
+            reqs.append(dist.isend(payload[src_off:src_off + nbytes].contiguous(), peer, group=group))
+        else:
+            reqs.append(dist.irecv(out[dst_off:dst_off + nbytes], peer, group=group))
+    for r in reqs:
+        r.wait()
+    return out, sizes_l, ops
+
+
 def all_gatherv(local, group=None):
-    """local: (n_i, 9) float32 tensor on this rank's device. Returns ((sum n_i, 9) tensor, counts list),
-    rank-major order, identical on every rank."""
-    world = dist.get_world_size(group)
-    dev = local.device
-    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
-    counts = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts, n, group=group)
-    counts_l = [int(c) for c in counts.tolist()]
-    mx = max(counts_l)
-    if mx == 0:
-        return torch.empty((0, 9), dtype=torch.float32, device=dev), counts_l
-    # The collective always works on torch-owned memory: `local` may be a view of a buffer that another HIP runtime
-    # instance allocated (libgsdfhip.so links the system runtime, PyTorch bundles its own), and one device copy of a
-    # rank's share (30 MB at 8 ranks) is cheap insurance against RCCL's pointer bookkeeping.
-    send = torch.empty((mx, 9), dtype=torch.float32, device=dev)   # the padding rows are never read back
-    send[: local.shape[0]] = local
-    recv = torch.empty((world, mx, 9), dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
-    out = torch.cat([recv[r, : counts_l[r]] for r in range(world)], dim=0)
-    return out, counts_l
+    """local: (n_i, 9) float32 tensor on this rank's device. Returns ((sum n_i, 9) tensor, counts list), rank-major order,
+    identical on every rank: mode ALL of the library's plan."""
+    # (the transfers work on torch-owned memory: `local` may be a view of a buffer that another HIP runtime instance
+    # allocated -- libgsdfhip.so links the system runtime, PyTorch bundles its own)
+    payload = local.contiguous().view(torch.uint8).reshape(-1).clone()
+    out, sizes, _ = run_plan(payload, hip.GATHER_ALL, 0, group)
+    return out.view(torch.float32).view(-1, 9), [s // 36 for s in sizes]
 
 
 def all_gatherv_triangles(dev_ptr, n_tris, device, group=None):

@@ -24,22 +24,30 @@ SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "g
            "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_lower_region", "gsdf_hip_eval3_submit", "gsdf_hip_eval_wait", "gsdf_hip_host_alloc", "gsdf_hip_host_register", "gsdf_hip_host_release", "gsdf_hip_comm_unique_id", "gsdf_hip_comm_create", "gsdf_hip_comm_rank", "gsdf_hip_comm_world", "gsdf_hip_comm_allreduce_sum_u64", "gsdf_hip_mesh_gatherv", "gsdf_hip_mesh_gatherv_start", "gsdf_hip_mesh_gatherv_wait", "gsdf_hip_comm_destroy", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_selftest_circ", "gsdf_hip_blockcache_create", "gsdf_hip_blockcache_reset", "gsdf_hip_blockcache_eval3", "gsdf_hip_blockcache_hits", "gsdf_hip_blockcache_evaluations", "gsdf_hip_blockcache_destroy", "gsdf_hip_program_specialize", "gsdf_hip_program_is_specialized", "gsdf_hip_program_kernels", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
            "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3", "gsdf_hip_image2",
            "gsdf_hip_mesh_octree", "gsdf_hip_mesh_dualcontour", "gsdf_hip_mesh_flat", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
-           "gsdf_hip_mesh_stl", "gsdf_hip_mesh_host_tris", "gsdf_hip_mesh_host_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner", "gsdf_hip_slab_range"]
+           "gsdf_hip_mesh_stl", "gsdf_hip_mesh_host_tris", "gsdf_hip_mesh_host_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner", "gsdf_hip_slab_range",
+           "gsdf_hip_mesh_payload", "gsdf_hip_mesh_march", "gsdf_hip_comm_transport", "gsdf_hip_gather_plan"]
 
 
 PRUNE_ASSUME_SDF = 1 << 30  # gsdf_hip.h: GSDF_PRUNE_ASSUME_SDF
 
 
 GATHER_ALL, GATHER_ROOT, GATHER_NONE = 0, 1, 2  # gsdf_hip.h
+PAYLOAD_TRIANGLES, PAYLOAD_RECORDS = 0, 1            # gsdf_hip.h: gsdf_mesh_opts.payload
+GOP_COPY, GOP_SEND, GOP_RECV = 0, 1, 2               # gsdf_hip.h: gsdf_gather_op.kind
+
+
+class GatherOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("peer", C.c_int32), ("src_off", C.c_uint64), ("dst_off", C.c_uint64), ("bytes", C.c_uint64)]
 
 
 class GatherStats(C.Structure):
-    _fields_ = [("ms_counts", C.c_double), ("ms_payload", C.c_double), ("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64)]
+    _fields_ = [("ms_counts", C.c_double), ("ms_payload", C.c_double), ("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64),
+                ("ms_march", C.c_double)]
 
 
 class MeshOpts(C.Structure):
     _fields_ = [("prune", C.c_int), ("shard_rank", C.c_int), ("shard_count", C.c_int), ("max_tris", C.c_uint64),
-                ("stream", C.c_void_p), ("share_corners", C.c_int), ("host_output", C.c_int)]
+                ("stream", C.c_void_p), ("share_corners", C.c_int), ("host_output", C.c_int), ("payload", C.c_int), ("reserved", C.c_int)]
 
 
 class MeshStats(C.Structure):
@@ -83,6 +91,12 @@ def lib():
         L.gsdf_hip_mesh_gatherv_start.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.gsdf_hip_mesh_gatherv_wait.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(GatherStats)]
         L.gsdf_hip_comm_destroy.argtypes = [C.c_void_p]
+        L.gsdf_hip_comm_transport.restype = C.c_char_p
+        L.gsdf_hip_comm_transport.argtypes = [C.c_void_p]
+        L.gsdf_hip_gather_plan.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GatherOp), C.c_size_t,
+                                           C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]
+        L.gsdf_hip_mesh_payload.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.gsdf_hip_mesh_march.argtypes = [C.c_void_p]
         L.gsdf_hip_eval3_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
         L.gsdf_hip_eval_wait.argtypes = [C.c_void_p, C.c_int]
         L.gsdf_hip_host_alloc.restype = C.c_void_p
@@ -315,7 +329,7 @@ class OctreeHIP:
     argument has no meaning here (positions are generated on device)."""
 
     def __init__(self, sdf, res, evalBufferSize=64, prune=True, shard_rank=0, shard_count=1, max_tris=0, stream=None,
-                 share_corners=False, host_output=False, assume_sdf=False):
+                 share_corners=False, host_output=False, assume_sdf=False, payload=PAYLOAD_TRIANGLES):
         if evalBufferSize < 64:
             raise ValueError("bad octree eval buffer size")
         self.sdf = sdf
@@ -323,7 +337,7 @@ class OctreeHIP:
         self._cursor = 0
         # prune: True / False, or an int bit mask of the octree levels to centre-test (bit L = Level L >= 3);
         # assume_sdf: the reference's predicate verbatim instead of the field's bounds over the cube (gsdf_hip.h)
-        self._opts = MeshOpts(int(prune) | (PRUNE_ASSUME_SDF if assume_sdf else 0), shard_rank, shard_count, max_tris, stream, int(share_corners), int(host_output))
+        self._opts = MeshOpts(int(prune) | (PRUNE_ASSUME_SDF if assume_sdf else 0), shard_rank, shard_count, max_tris, stream, int(share_corners), int(host_output), int(payload), 0)
         self.Reset(sdf, res)
 
     def Reset(self, sdf, res):
@@ -350,6 +364,18 @@ class OctreeHIP:
 
     def TotalPruned(self):
         return int(self.stats.pruned_leaves)
+
+    def payload(self):
+        """(kind, records, payload bytes): PAYLOAD_TRIANGLES, or PAYLOAD_RECORDS -- packed cut-leaf records, no triangles yet."""
+        n, b = C.c_uint64(), C.c_uint64()
+        k = lib().gsdf_hip_mesh_payload(self._mesh, C.byref(n), C.byref(b))
+        _check(min(k, 0))
+        return k, int(n.value), int(b.value)
+
+    def march(self):
+        """Marching cubes over a records mesh, in place: afterwards it reads like any mesh (gsdf_hip_mesh_march)."""
+        _check(lib().gsdf_hip_mesh_march(self._mesh))
+        return self
 
     def n_tris(self):
         return int(self.stats.n_tris)
@@ -426,6 +452,10 @@ class CommHIP:
         _check(lib().gsdf_hip_comm_create(buf, rank, world, C.byref(h)))
         self._h, self.rank, self.world = h, rank, world
 
+    def transport(self):
+        """"rccl" or "loopback" (GSDF_HIP_COMM=loopback at unique_id() time: ranks are threads of one process)."""
+        return lib().gsdf_hip_comm_transport(self._h).decode()
+
     def allreduce_sum(self, values):
         """Sum of each of `values` (ints) over all ranks. Collective."""
         arr = (C.c_uint64 * len(values))(*[int(v) for v in values])
@@ -475,7 +505,8 @@ OctreeHIP.gatherv = _gatherv
 
 class PendingGather:
     """A gather whose payload is moving (gsdf_hip_mesh_gatherv_start): wait() returns (GatheredMeshHIP or None, counts,
-    GatherStats). Keeps the source renderer alive until then."""
+    GatherStats). The source renderer may be Reset or freed meanwhile: the library keeps the buffers the gather reads until
+    the payload has moved (a destroy in between is deferred)."""
 
     def __init__(self, src, comm, handle):
         self._src, self._comm, self._h = src, comm, handle
@@ -569,3 +600,14 @@ class FlatHIP(OctreeHIP):
 
     def Evaluations(self):
         return int(self.stats.evals)
+
+
+def gather_plan(bytes_per_rank, rank, mode=GATHER_ALL, root=0):
+    """gsdf_hip_gather_plan (host only, pure): ([(kind, peer, src_off, dst_off, bytes), ...], total_bytes) -- the transfers rank
+    `rank` performs in a gather of payloads of bytes_per_rank[r] bytes, and the size of its gathered buffer."""
+    world = len(bytes_per_rank)
+    arr = (C.c_uint64 * world)(*[int(b) for b in bytes_per_rank])
+    ops = (GatherOp * (2 * world + 1))()
+    n, total = C.c_size_t(), C.c_uint64()
+    _check(lib().gsdf_hip_gather_plan(arr, world, int(rank), int(mode), int(root), ops, len(ops), C.byref(n), C.byref(total)))
+    return [(o.kind, o.peer, int(o.src_off), int(o.dst_off), int(o.bytes)) for o in ops[:n.value]], int(total.value)

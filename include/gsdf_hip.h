@@ -174,7 +174,15 @@ typedef struct gsdf_mesh_opts {
                          while it runs (gsdf_hip_mesh_host_tris then returns that buffer: mesh + transfer 4.x ms instead
                          of 1.7 + 4.4 ms at npt-flange resdiv 1600). For results that are consumed on the host only:
                          device-side consumers (gsdf_hip_mesh_stl, RCCL gathers) would read back over PCIe. */
+  int payload;        /* what the mesh holds when the call returns: GSDF_PAYLOAD_TRIANGLES (0, default), or GSDF_PAYLOAD_RECORDS:
+                         the 40-byte records of the leaves the surface cuts (8 corner distances, leaf coordinates, marching-cubes
+                         case), packed, and no triangles yet -- the form a rank hands to gsdf_hip_mesh_gatherv_start, which then
+                         moves 20 bytes per triangle instead of 36 and runs marching cubes on the receiving ranks, over everybody's
+                         records. gsdf_hip_mesh_march turns such a mesh into triangles where it is. Same triangles either way. */
+  int reserved;       /* 0 */
 } gsdf_mesh_opts;
+#define GSDF_PAYLOAD_TRIANGLES 0
+#define GSDF_PAYLOAD_RECORDS 1
 
 typedef struct gsdf_mesh_stats {
   uint64_t n_tris;
@@ -196,10 +204,10 @@ typedef struct gsdf_mesh_stats {
   uint64_t cut_leaves;     /* leaves the surface cuts = 40-byte records handed from leaf_eval_kernel to march_records_kernel */
 } gsdf_mesh_stats;
 
-GSDF_ABI_ASSERT(sizeof(gsdf_mesh_opts) == 40, "gsdf_mesh_opts is 40 bytes");
+GSDF_ABI_ASSERT(sizeof(gsdf_mesh_opts) == 48, "gsdf_mesh_opts is 48 bytes");
 GSDF_ABI_ASSERT(offsetof(gsdf_mesh_opts, prune) == 0 && offsetof(gsdf_mesh_opts, shard_rank) == 4 && offsetof(gsdf_mesh_opts, shard_count) == 8, "gsdf_mesh_opts head");
 GSDF_ABI_ASSERT(offsetof(gsdf_mesh_opts, max_tris) == 16 && offsetof(gsdf_mesh_opts, stream) == 24, "gsdf_mesh_opts middle");
-GSDF_ABI_ASSERT(offsetof(gsdf_mesh_opts, share_corners) == 32 && offsetof(gsdf_mesh_opts, host_output) == 36, "gsdf_mesh_opts tail");
+GSDF_ABI_ASSERT(offsetof(gsdf_mesh_opts, share_corners) == 32 && offsetof(gsdf_mesh_opts, host_output) == 36 && offsetof(gsdf_mesh_opts, payload) == 40, "gsdf_mesh_opts tail");
 GSDF_ABI_ASSERT(sizeof(gsdf_mesh_stats) == 128, "gsdf_mesh_stats is 128 bytes");
 GSDF_ABI_ASSERT(offsetof(gsdf_mesh_stats, n_tris) == 0 && offsetof(gsdf_mesh_stats, evals) == 8 && offsetof(gsdf_mesh_stats, pruned_leaves) == 16, "gsdf_mesh_stats counters");
 GSDF_ABI_ASSERT(offsetof(gsdf_mesh_stats, leaf_cubes) == 24 && offsetof(gsdf_mesh_stats, active_leaves) == 32 && offsetof(gsdf_mesh_stats, levels) == 40, "gsdf_mesh_stats counters 2");
@@ -223,6 +231,12 @@ int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chiseled, int shar
  * :120-122), nothing exchanged. */
 int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, int shard_count, void* stream, gsdf_mesh** out);
 int gsdf_hip_mesh_stats_get(const gsdf_mesh* m, gsdf_mesh_stats* st);
+/* What the mesh holds: GSDF_PAYLOAD_TRIANGLES or GSDF_PAYLOAD_RECORDS (gsdf_mesh_opts.payload); *n_records / *payload_bytes
+ * (optional) = its cut-leaf records and the size of their packed form (0 for a mesh of triangles). */
+int gsdf_hip_mesh_payload(const gsdf_mesh* m, uint64_t* n_records, uint64_t* payload_bytes);
+/* Marching cubes over a mesh's packed records, in place: afterwards it holds triangles (stats.n_tris was known before) and
+ * every accessor below works. No-op on a mesh of triangles. glrender/marchcubes.go:14-98. */
+int gsdf_hip_mesh_march(gsdf_mesh* m);
 /* Copy triangles [first, first+count) to host memory: 9 floats (36 B) each = ms3.Triangle. */
 int gsdf_hip_mesh_read(const gsdf_mesh* m, uint64_t first, uint64_t count, float* dst);
 /* Device pointer to the triangle array (for RCCL gathers / further device work). */
@@ -239,47 +253,76 @@ int gsdf_hip_mesh_host_stl(gsdf_mesh* m, const uint8_t** stl, size_t* len);
 void gsdf_hip_mesh_destroy(gsdf_mesh* m);
 
 /* ---- multi-GPU (one process per GPU). The meshers shard with NO data-path collective (shard_rank / shard_count above); the
- * one exchange is the final variable-length gather of the ranks' triangle buffers, on RCCL over xGMI, inside this library:
- * a Go caller needs no Python for it. Replaces nothing in the reference (single device); SURVEY.md section 8(e).
+ * one exchange is the final variable-length gather of the ranks' results, over xGMI, inside this library: a Go caller needs no
+ * Python for it. Replaces nothing in the reference (single device; its analogue of the split is the goroutine split of
+ * glrender/flatrenderer.go:120-122); SURVEY.md section 8(e).
  *   rank 0: gsdf_hip_comm_unique_id(id) -> ship the 128 bytes to the other ranks by any means (file, socket, MPI, env)
  *   every rank (after gsdf_hip_init(device)): gsdf_hip_comm_create(id, rank, world, &comm)            [collective]
  *   per mesh: gsdf_hip_mesh_gatherv(local_mesh, comm, &all, counts)                                   [collective]
- * gatherv = ncclAllGather of the counts + one ncclGroup of ncclBroadcast's, root r sending exactly count_r x 36 bytes from
- * its mesh into every rank's result at offset sum(count_<r): no padding, no staging copies. The result is a gsdf_mesh
- * holding the triangles of ALL ranks in rank order (device resident; every mesh accessor works on it). librccl is loaded
- * at first use; without it these calls fail with GSDF_ERR_HIP and everything else works. */
+ * A gather = an all-gather of four counts per rank, then the transfers gsdf_hip_gather_plan lists for those counts as ONE group
+ * of point-to-point sends / receives (ncclSend / ncclRecv: xGMI is one link per peer, every rank feeds all its links at once),
+ * every rank's payload landing at offset sum(bytes of the ranks before it): no padding, no staging copies. What moves is the
+ * meshes' payload (gsdf_mesh_opts.payload): triangles, or packed cut-leaf records -- 20 instead of 36 bytes per triangle on the
+ * wire -- which the receiving ranks march into triangles behind the transfer. The result is a gsdf_mesh holding the triangles of
+ * ALL ranks in rank order (device resident; every mesh accessor works on it). librccl is loaded at first use; without it these
+ * calls fail with GSDF_ERR_HIP and everything else works. GSDF_HIP_COMM=loopback (environment, read by gsdf_hip_comm_unique_id)
+ * selects an in-process transport instead -- the ranks are threads of one process on one GPU, a transfer is a device copy
+ * ordered by events -- with which the whole path runs at any world size on a one-GPU box (the tests use it). World size <= 64. */
 typedef struct gsdf_comm gsdf_comm;
 #define GSDF_COMM_ID_BYTES 128
 int gsdf_hip_comm_unique_id(uint8_t id[GSDF_COMM_ID_BYTES]);
 int gsdf_hip_comm_create(const uint8_t id[GSDF_COMM_ID_BYTES], int rank, int world, gsdf_comm** out);
 int gsdf_hip_comm_rank(const gsdf_comm* c);
 int gsdf_hip_comm_world(const gsdf_comm* c);
+const char* gsdf_hip_comm_transport(const gsdf_comm* c); /* "rccl" or "loopback" */
 /* Sum over all ranks, in place, of n host values (Evaluations(), TotalPruned(), triangle totals). Collective. */
 int gsdf_hip_comm_allreduce_sum_u64(gsdf_comm* c, uint64_t* vals, size_t n);
 /* counts (optional): world entries, triangles contributed by each rank. */
 int gsdf_hip_mesh_gatherv(const gsdf_mesh* m, gsdf_comm* c, gsdf_mesh** out, uint64_t* counts);
 /* The same with a choice of who receives, and in two halves so that the payload can move while the caller meshes its next
- * part. Every rank of an all-gather INGESTS (world-1)/world of the whole mesh over its xGMI links -- 214 MB of npt-flange's
- * 245 MB at resdiv 1600 on 8 GPUs, several times what one rank takes to mesh its eighth -- so the gather, not the meshing,
- * bounds a step that ends in one (DESIGN.md section 7 has the numbers):
- *   GSDF_GATHER_ALL   every rank gets everything (grouped ncclBroadcast's);
- *   GSDF_GATHER_ROOT  only `root` does (grouped ncclSend / ncclRecv; the other ranks' links carry their own shard only);
+ * part. Every rank of an all-gather INGESTS (world-1)/world of the whole mesh over its xGMI links -- several times what a rank
+ * takes to mesh its share -- so the gather, not the meshing, bounds a step that ends in one (DESIGN.md section 7 has the numbers):
+ *   GSDF_GATHER_ALL   every rank gets everything;
+ *   GSDF_GATHER_ROOT  only `root` does (the other ranks' links carry their own shard only);
  *   GSDF_GATHER_NONE  counts only: every rank keeps its shard where it is.
- * _start: collective; returns when the counts are exchanged and the payload is enqueued on the communicator's own stream
- * (`m` must stay alive until _wait). _wait: blocks until the payload has arrived; *out = the gathered mesh (NULL on ranks that
- * receive nothing), counts[world], st (all optional). */
+ * _start: collective; returns when the counts are exchanged and the payload (and, for records, the marching pass behind it) is
+ * enqueued on the communicator's own stream. `m` may be destroyed right away: its buffers are kept until the payload has moved.
+ * _wait: blocks until the result is complete; *out = the gathered mesh (NULL on ranks that receive nothing), counts[world]
+ * (triangles per rank), st (all optional). */
 enum { GSDF_GATHER_ALL = 0, GSDF_GATHER_ROOT = 1, GSDF_GATHER_NONE = 2 };
 typedef struct gsdf_gather gsdf_gather;
 typedef struct gsdf_gather_stats {
-  double ms_counts;         /* the counts exchange (ncclAllGather of one u64 + readback), HIP events on the communicator's stream */
-  double ms_payload;        /* the triangle payload, first byte enqueued to last byte arrived */
-  uint64_t bytes_sent;      /* of this rank's own triangles */
-  uint64_t bytes_received;  /* of the other ranks' triangles */
+  double ms_counts;         /* the counts exchange (all-gather of four u64 + readback), HIP events on the communicator's stream */
+  double ms_payload;        /* the payload, first byte enqueued to last byte arrived */
+  uint64_t bytes_sent;      /* of this rank's own payload, over all its links */
+  uint64_t bytes_received;  /* of the other ranks' payloads */
+  double ms_march;          /* records payload: marching cubes over the gathered records (0 for triangles) */
 } gsdf_gather_stats;
-GSDF_ABI_ASSERT(sizeof(gsdf_gather_stats) == 32, "gsdf_gather_stats is 32 bytes");
+GSDF_ABI_ASSERT(sizeof(gsdf_gather_stats) == 40, "gsdf_gather_stats is 40 bytes");
 int gsdf_hip_mesh_gatherv_start(const gsdf_mesh* m, gsdf_comm* c, int mode, int root, gsdf_gather** pending);
 int gsdf_hip_mesh_gatherv_wait(gsdf_gather* pending, gsdf_mesh** out, uint64_t* counts, gsdf_gather_stats* st);
 void gsdf_hip_comm_destroy(gsdf_comm* c);
+
+/* Host-only (runs without a GPU), pure: the transfers rank `rank` of `world` performs in a gather of payloads of
+ * bytes_per_rank[r] bytes -- what gsdf_hip_mesh_gatherv_start executes as one group. Layout of the gathered buffer: rank-major,
+ * payload r at offset sum(bytes_per_rank[< r]). ops (ops_cap entries; NULL to count) receives
+ *   GSDF_GOP_COPY  this rank's own payload [src_off, +bytes) -> gathered buffer at dst_off   (a device copy)
+ *   GSDF_GOP_SEND  this rank's own payload [src_off, +bytes) -> rank `peer`
+ *   GSDF_GOP_RECV  bytes from rank `peer` -> gathered buffer at dst_off
+ * in an order in which, executed entry by entry with non-blocking sends, the ranks' lists match up (peers are visited in
+ * rotated order: rank+1, rank+2, ...). Ranks with nothing to contribute appear in nobody's list. *total_bytes = size of this
+ * rank's gathered buffer (0 if it receives nothing). tests/test_gather_gloo.py runs these lists with gloo on CPU. */
+enum { GSDF_GOP_COPY = 0, GSDF_GOP_SEND = 1, GSDF_GOP_RECV = 2 };
+typedef struct gsdf_gather_op {
+  int32_t kind;
+  int32_t peer;
+  uint64_t src_off;
+  uint64_t dst_off;
+  uint64_t bytes;
+} gsdf_gather_op;
+GSDF_ABI_ASSERT(sizeof(gsdf_gather_op) == 32, "gsdf_gather_op is 32 bytes");
+int gsdf_hip_gather_plan(const uint64_t* bytes_per_rank, int world, int rank, int mode, int root, gsdf_gather_op* ops, size_t ops_cap,
+                         size_t* n_ops, uint64_t* total_bytes);
 
 /* Host-only helper (runs without a GPU): owner rank of octree brick (x,y,z) under the multi-GPU partition
  * gsdf_hip_mesh_octree applies on device -- a pure function of the coordinates, so ranks never communicate. */

@@ -208,13 +208,15 @@ static float lip_norm2(float a, float b, float c, float d) { /* 2x2 [[a b][c d]]
   if (disc < 0) disc = 0;
   return (float)sqrt(0.5 * (S + sqrt(disc)));
 }
-/* a linear map counts as rigid (factor 1) up to this; beyond it the factor is rounded up */
-#define LIP_RIGID_TOL 1.00001f
+/* a linear map whose largest singular value is at most 1 shrinks or keeps the ball (factor 1); anything above -- also the
+ * 1.0000001 of a rotation built from rounded sines -- stretches it, and the factor is rounded up */
+#define LIP_RIGID_TOL 1.0f
 #define LIP_ROUND_UP 1.000001f
 
 /* radius of the ball's image in the current frame, pair j */
 static inline float lip_radius(const lipctx* lc, size_t j) { return lc->R[j]; }
-static void lip_scale(lipctx* lc, size_t n, float f) { for (size_t j = 0; j < n / 2; j++) lc->R[j] = lc->R[j] * f; }
+/* (a negative factor mirrors the ball: its radius scales by the magnitude) */
+static void lip_scale(lipctx* lc, size_t n, float f) { for (size_t j = 0; j < n / 2; j++) lc->R[j] = lc->R[j] * fabsf(f); }
 /* value -+ radius: an exact distance (or any 1-Lipschitz term of the current frame) over the ball */
 static void lip_widen(const lipctx* lc, float* d, size_t n) {
   for (size_t j = 0; j < n / 2; j++) {
@@ -476,10 +478,11 @@ static int eval3_node(const orc_sdf* s, uint32_t ni, const V3* pos, float* dist,
       float factor = P[0];
       float inv = 1.f / P[0];
       for (size_t i = 0; i < n; i++) { sc[i].x = inv * pos[i].x; sc[i].y = inv * pos[i].y; sc[i].z = inv * pos[i].z; }
+      float* lsave = vp->lip ? lip_enter(vp, n) : NULL; /* the outer radius comes back exactly (not (R * inv) * factor) */
       if (vp->lip) lip_scale(vp->lip, n, inv);
       err = eval3(s, CHILD(nd, 0), sc, dist, n, vp);
       if (vp->lip) {
-        lip_scale(vp->lip, n, factor);
+        lip_leave(vp, lsave, n);
         if (!err) lip_mul(dist, n, factor);
       } else
       if (!err) for (size_t i = 0; i < n; i++) dist[i] *= factor;
@@ -544,10 +547,11 @@ static int eval3_node(const orc_sdf* s, uint32_t ni, const V3* pos, float* dist,
       V3* t = ACQ_V3(n);
       float th = P[0];
       for (size_t i = 0; i < n; i++) { float f = 1 / th; t[i].x = f * pos[i].x; t[i].y = f * pos[i].y; t[i].z = f * pos[i].z; }
+      float* lsave = vp->lip ? lip_enter(vp, n) : NULL;
       if (vp->lip) lip_scale(vp->lip, n, 1 / th);
       err = eval3(s, CHILD(nd, 0), t, dist, n, vp);
       if (vp->lip) {
-        lip_scale(vp->lip, n, th);
+        lip_leave(vp, lsave, n);
         if (!err)
           for (size_t j = 0; j < n / 2; j++) {
             float alo, ahi;
@@ -1112,10 +1116,11 @@ static int eval2_node(const orc_sdf* s, uint32_t ni, const V2* pos, float* dist,
       V2* t = ACQ_V2(n);
       float inv = 1.f / P[0];
       for (size_t i = 0; i < n; i++) { t[i].x = inv * pos[i].x; t[i].y = inv * pos[i].y; }
+      float* lsave = vp->lip ? lip_enter(vp, n) : NULL;
       if (vp->lip) lip_scale(vp->lip, n, inv);
       err = eval2(s, CHILD(nd, 0), t, dist, n, vp);
       if (vp->lip) {
-        lip_scale(vp->lip, n, P[0]);
+        lip_leave(vp, lsave, n);
         if (!err) lip_mul(dist, n, P[0]);
       } else
       if (!err) for (size_t i = 0; i < n; i++) dist[i] = dist[i] * P[0];

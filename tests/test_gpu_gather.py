@@ -1,7 +1,14 @@
-"""Multi-GPU exchange through the C ABI on RCCL (gsdf_hip_comm_* / gsdf_hip_mesh_gatherv, include/gsdf_hip.h), exercised
-at world size 1 -- what one GPU allows: the communicator, the count all-gather, the grouped broadcast of the payload and
-the reduction all run through librccl, so the `nccl` path executes at least once per round. The rank-major ordering of a
-real multi-rank gather is covered on CPU by tests/test_gather_gloo.py (same layout, gloo)."""
+"""Multi-GPU exchange through the C ABI (gsdf_hip_comm_* / gsdf_hip_mesh_gatherv*, include/gsdf_hip.h).
+  * on RCCL at world size 1 -- what one GPU allows of librccl: the communicator, the count all-gather, the plan's copy, the
+    reduction, so the `nccl` path executes at least once per round;
+  * on the in-process loopback transport (GSDF_HIP_COMM=loopback: the ranks are threads, a transfer is a device copy ordered by
+    events) at world sizes 2, 3 and 8: the SHIPPING code of gsdf_hip_mesh_gatherv_start -- counts, plan, one group of sends and
+    receives, marching cubes over gathered records -- with every rank meshing its own shard, all modes, both payloads, pipelined;
+  * the records payload against the triangle payload: same triangle set, bit for bit.
+The plan itself is checked as data and executed over gloo on CPU (tests/test_gather_gloo.py)."""
+import os
+import threading
+
 import numpy as np
 import pytest
 
@@ -97,3 +104,170 @@ def test_mesh_outlives_its_program(gpu):
     assert (srt(oc2.RenderAll()) == srt(want)).all()                   # first read of oc2: DMA on the mesh's own stream
     assert len(oc2.WriteBinarySTL()) == 84 + 50 * oc2.n_tris()      # stl_kernel on the mesh's own stream
     assert oc2.triangles_view().shape == want.shape
+
+
+def _srt(t):
+    t = np.ascontiguousarray(t, np.float32).reshape(-1, 9)
+    return t[np.lexsort(t.view(np.uint32).T[::-1])]
+
+
+def test_records_payload_gives_the_same_triangles(gpu):
+    """gsdf_mesh_opts.payload = records: the mesher stops at the packed cut-leaf records (scan_groups_kernel + pack_records_kernel);
+    gsdf_hip_mesh_march (march_dense_kernel) makes the triangles afterwards -- the same set as the default path's, and the
+    accessors refuse a mesh that has none yet."""
+    b = Builder()
+    for name, rd, spec in (("npt-flange", 300, True), ("bolt", 150, False), ("knurled-cylinder", 120, True)):
+        sh = b.Scene(name)
+        sdf = gpu.SDF3HIP(sh)
+        if spec:
+            sdf.specialize()
+        res = np.float32(float(sh.Diagonal()) / rd)
+        want = gpu.OctreeHIP(sdf, res)
+        for shard in ((0, 1), (1, 3)):
+            ref = gpu.OctreeHIP(sdf, res, shard_rank=shard[0], shard_count=shard[1])
+            rec = gpu.OctreeHIP(sdf, res, shard_rank=shard[0], shard_count=shard[1], payload=gpu.PAYLOAD_RECORDS)
+            kind, nrec, nbytes = rec.payload()
+            assert kind == gpu.PAYLOAD_RECORDS and nrec == ref.stats.cut_leaves == rec.stats.cut_leaves
+            assert nbytes == nrec * 40 + (((nrec + 255) // 256 * 4 + 7) & ~7)
+            assert rec.n_tris() == ref.n_tris() and rec.stats.evals == ref.stats.evals and rec.TotalPruned() == ref.TotalPruned()
+            with pytest.raises(gpu.HipError):
+                rec.RenderAll()
+            with pytest.raises(gpu.HipError):
+                rec.triangles_view()
+            rec.march()
+            assert rec.payload() == (gpu.PAYLOAD_TRIANGLES, 0, 0)
+            assert (_srt(rec.RenderAll()).view(np.uint32) == _srt(ref.RenderAll()).view(np.uint32)).all(), (name, shard)
+            assert rec.march() is rec                                   # no-op on triangles
+        assert want.n_tris() > 10000
+    # a mesh without surface: no records, no triangles, still a mesh
+    small = gpu.SDF3HIP(b.NewSphere(1.0))
+    shards = [gpu.OctreeHIP(small, np.float32(0.25), shard_rank=r, shard_count=64, payload=gpu.PAYLOAD_RECORDS) for r in range(64)]
+    empty = next(m for m in shards if m.n_tris() == 0)
+    assert empty.payload() == (gpu.PAYLOAD_RECORDS, 0, 0) and empty.march().RenderAll().shape == (0, 3, 3)
+    # small record buffers overflow once and are repeated with the exact size (the handle remembers the last mesh's count)
+    sdf = gpu.SDF3HIP(b.Scene("npt-flange"))
+    r1 = gpu.OctreeHIP(sdf, np.float32(float(b.Scene("npt-flange").Diagonal()) / 60), payload=gpu.PAYLOAD_RECORDS)
+    r2 = gpu.OctreeHIP(sdf, np.float32(float(b.Scene("npt-flange").Diagonal()) / 400), payload=gpu.PAYLOAD_RECORDS)
+    assert r2.stats.cut_leaves > 17 * r1.stats.cut_leaves / 16 + 1024
+    assert r2.march().n_tris() == 423852
+
+
+def _loopback_world(gpu, world, work):
+    """Run work(rank, comm) on `world` threads, each a rank of one loopback communicator; returns the per-rank results."""
+    old = os.environ.get("GSDF_HIP_COMM")
+    os.environ["GSDF_HIP_COMM"] = "loopback"
+    try:
+        uid = gpu.CommHIP.unique_id()
+    finally:
+        if old is None:
+            del os.environ["GSDF_HIP_COMM"]
+        else:
+            os.environ["GSDF_HIP_COMM"] = old
+    out, err = [None] * world, [None] * world
+
+    def run(r):
+        try:
+            gpu.init(0)
+            comm = gpu.CommHIP(uid, r, world)
+            assert comm.transport() == "loopback"
+            out[r] = work(r, comm)
+            comm.close()
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            err[r] = e
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not any(t.is_alive() for t in th), "a rank hangs"
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_gatherv_across_ranks_on_the_loopback_transport(gpu, world):
+    """Every rank meshes its own shard (brick_owner partition) and the ranks gather: the gathered mesh is the whole mesh --
+    bit-identical triangle set -- on every receiving rank, rank-major with the ranks' own counts, for both payloads and all
+    three modes; the statistics add up through the all-reduce."""
+    b = Builder()
+    sh = b.Scene("npt-flange")
+    res = np.float32(float(sh.Diagonal()) / 260)
+    whole = gpu.OctreeHIP(gpu.SDF3HIP(sh), res)
+    want = _srt(whole.RenderAll())
+    want_evals_leaf, want_tris = int(whole.stats.evals_leaf), whole.n_tris()
+
+    def work(r, comm):
+        sdf = gpu.SDF3HIP(sh)
+        if r % 2:
+            sdf.specialize()
+        res_r = {}
+        for payload in (gpu.PAYLOAD_TRIANGLES, gpu.PAYLOAD_RECORDS):
+            mine = gpu.OctreeHIP(sdf, res, shard_rank=r, shard_count=world, payload=payload)
+            tot = comm.allreduce_sum([mine.n_tris(), int(mine.stats.evals_leaf)])
+            for mode, root in ((gpu.GATHER_ALL, 0), (gpu.GATHER_ROOT, world - 1), (gpu.GATHER_NONE, 0)):
+                g, counts, gs = mine.gatherv_start(comm, mode, root).wait()
+                recv = mode == gpu.GATHER_ALL or (mode == gpu.GATHER_ROOT and r == root)
+                assert (g is not None) == recv
+                assert counts[r] == mine.n_tris() and sum(counts) == want_tris
+                unit = None if payload == gpu.PAYLOAD_RECORDS else 36
+                if recv:
+                    t = g.RenderAll()
+                    assert (_srt(t).view(np.uint32) == want.view(np.uint32)).all()
+                    if unit:                                           # triangles: rank-major, each rank's block in its own order
+                        o = sum(counts[:r])
+                        assert (t.reshape(-1, 9)[o:o + counts[r]].view(np.uint32) == mine.RenderAll().reshape(-1, 9).view(np.uint32)).all()
+                        assert gs.bytes_received == 36 * (want_tris - counts[r])
+                    else:
+                        assert 0 < gs.bytes_received < 36 * (want_tris - counts[r]) * 0.62 and gs.ms_march > 0
+                if mode == gpu.GATHER_ALL and unit:
+                    assert gs.bytes_sent == 36 * counts[r] * (world - 1)
+                if mode == gpu.GATHER_NONE:
+                    assert gs.bytes_sent == 0 and gs.bytes_received == 0
+            res_r[payload] = tot
+        return res_r
+
+    for tot in _loopback_world(gpu, world, work):
+        for payload in (gpu.PAYLOAD_TRIANGLES, gpu.PAYLOAD_RECORDS):
+            assert tot[payload] == [want_tris, want_evals_leaf]        # the shards partition the leaf work exactly
+
+
+def test_pipelined_gathers_and_early_release_on_the_loopback_transport(gpu):
+    """bench.py's loop at world size 3: the payload of mesh i moves while mesh i+1 is made, on the SAME renderer handle
+    (Reset under a gather in flight: the library keeps the gathered buffers until the payload has moved), records payload."""
+    b = Builder()
+    sh = b.Scene("bolt")
+    res = np.float32(float(sh.Diagonal()) / 170)
+    want = _srt(gpu.OctreeHIP(gpu.SDF3HIP(sh), res).RenderAll())
+
+    def work(r, comm):
+        sdf = gpu.SDF3HIP(sh)
+        sdf.specialize()
+        oc = gpu.OctreeHIP(sdf, res, shard_rank=r, shard_count=3, payload=gpu.PAYLOAD_RECORDS)
+        pend, got = None, []
+        for i in range(5):
+            nxt = oc.gatherv_start(comm, gpu.GATHER_ALL, 0)
+            oc.Reset(sdf, res)                                        # the next mesh, on the same handle, under the gather
+            if pend is not None:
+                got.append(pend.wait()[0])
+            pend = nxt
+        got.append(pend.wait()[0])
+        return [bool((_srt(g.RenderAll()).view(np.uint32) == want.view(np.uint32)).all()) for g in got]
+
+    for oks in _loopback_world(gpu, 3, work):
+        assert oks == [True] * 5
+
+
+def test_gather_rejects_mixed_payloads(gpu):
+    b = Builder()
+    sh = b.NewSphere(1.0)
+
+    def work(r, comm):
+        sdf = gpu.SDF3HIP(sh)
+        m = gpu.OctreeHIP(sdf, np.float32(0.05), shard_rank=r, shard_count=2, payload=gpu.PAYLOAD_RECORDS if r else gpu.PAYLOAD_TRIANGLES)
+        with pytest.raises(gpu.HipError):
+            m.gatherv_start(comm, gpu.GATHER_ALL, 0)
+        return True
+
+    assert _loopback_world(gpu, 2, work) == [True, True]

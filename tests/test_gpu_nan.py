@@ -25,28 +25,9 @@ import corpus
 from gsdf_amd._ctypes_common import GsdfNode, GsdfTree, OP
 from oracle.oracle import OracleSDF
 from scaffold.builder import Builder
+from tree_edit import clone, first
 
 pytestmark = pytest.mark.gpu
-
-
-def clone(t):
-    """A tree blob in memory of its own, free to be made degenerate."""
-    nodes = (GsdfNode * t.n_nodes)(*[t.nodes[i] for i in range(t.n_nodes)])
-    links = (C.c_uint32 * max(1, t.n_links))(*[t.links[i] for i in range(t.n_links)])
-    aux = (C.c_float * max(1, t.n_aux))(*[t.aux[i] for i in range(t.n_aux)])
-    o = GsdfTree()
-    o.nodes, o.n_nodes = C.cast(nodes, C.POINTER(GsdfNode)), t.n_nodes
-    o.links, o.n_links = C.cast(links, C.POINTER(C.c_uint32)), t.n_links
-    o.aux, o.n_aux = C.cast(aux, C.POINTER(C.c_float)), t.n_aux
-    o.root = t.root
-    for k in range(6):
-        o.bb[k] = t.bb[k]
-    o._keep = (nodes, links, aux)
-    return o
-
-
-def first(t, op):
-    return next(i for i in range(t.n_nodes) if t.nodes[i].op == OP[op])
 
 
 def degenerate_trees():

@@ -52,3 +52,20 @@ def test_buttress_cap_known_counts(gpu):
             sdf.specialize()
         assert gpu.OctreeHIP(sdf, res).n_tris() == 54752 == gpu.FlatHIP(sdf, res).n_tris()
         assert gpu.OctreeHIP(sdf, res, assume_sdf=True).n_tris() == 54293
+
+
+def test_negative_scale_factors_prune_like_the_oracle(gpu):
+    """Scale by a negative factor around a twist, a screw, a non-rigid transform (tests/tree_edit.py): the device's interval
+    radius scales by the magnitude like the oracle's -- same decisions, same triangles, nothing lost against the unpruned octree."""
+    from tree_edit import negative_scale_trees
+    for k, (name, t) in enumerate(negative_scale_trees()):
+        bb = np.array(t.bb[:], np.float32)
+        res = np.float32(float(np.linalg.norm(bb[3:] - bb[:3])) / 70)
+        ref = OracleSDF(t).render_octree(res, 4096, True)
+        sdf = gpu.SDFHIP(t)
+        if k % 2:
+            sdf.specialize()
+        oc = gpu.OctreeHIP(sdf, res)
+        assert oc.n_tris() == ref.n_tris and oc.TotalPruned() == ref.pruned, name
+        assert (_sorted(oc.RenderAll()).view(np.uint32) == _sorted(ref.tris).view(np.uint32)).all(), name
+        assert gpu.OctreeHIP(sdf, res, prune=False).n_tris() == oc.n_tris(), name

@@ -49,7 +49,8 @@ def test_npt_flange_program():
     code, slots = hip.lower(b.Scene("npt-flange"))
     ins = decode(code)
     names = [i[0] for i in ins]
-    assert names[0] == "D_SCALE_PRE" and names[-2:] == ["D_MULR", "D_END"]
+    # (the root Scale sits between an interval-stack push and pop: the cube's radius comes back exactly after the node)
+    assert names[:2] == ["D_LIP_PUSH", "D_SCALE_PRE"] and names[-3:] == ["D_MULR", "D_LIP_POP", "D_END"]
     assert names.count("D_POLY2D") == 1 and names.count("D_SCREW_PRE") == 1
     assert names.count("D_CYL0") + names.count("D_CYLR") == 3
     # the hole cylinder is evaluated first (position-preserving), so the root difference needs no position save

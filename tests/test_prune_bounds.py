@@ -80,3 +80,20 @@ def test_default_octree_equals_flat_where_the_reference_predicate_does_not():
             assert o.render_octree(res, 4096, True).n_tris == full, (seed, i)
             lost += o.render_octree(res, 4096, True, assume_sdf=True).n_tris != full
     assert lost >= 5   # the family does defeat the plain predicate
+
+
+def test_negative_scale_factors_keep_the_bounds_sound():
+    """A Scale node with a negative factor mirrors the shape through the origin; the ball's radius scales by the factor's
+    MAGNITUDE (with the signed factor the radius turns negative inside the subtree and every interval inside out: the twist's
+    rho + r, the screw's seam test, the gates' L - r). Bounds hold over sampled balls and the pruned octree keeps every cube
+    that holds surface."""
+    from tree_edit import negative_scale_trees
+    rng = np.random.default_rng(77)
+    for name, t in negative_scale_trees():
+        o = OracleSDF(t)
+        assert _violations(o, rng, ncentres=150) <= 0, name
+        bb = np.array(t.bb[:], np.float32)
+        res = np.float32(float(np.linalg.norm(bb[3:] - bb[:3])) / 60)
+        full = o.render_octree(res, 4096, False)
+        pruned = o.render_octree(res, 4096, True)
+        assert full.n_tris > 500 and pruned.n_tris == full.n_tris and pruned.pruned > 0, (name, full.n_tris, pruned.n_tris)

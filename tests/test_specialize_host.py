@@ -30,9 +30,9 @@ def test_generated_source_follows_the_program():
     assert words == [int(w) for w in code]
     # one block per instruction, in program order, named after the interpreter's cases; no D_END block, no dispatch loop
     blocks = re.findall(r"\{  // (\d+) (D_[A-Z0-9_]+)", src)
-    assert [n for _, n in blocks] == ["D_SCALE_PRE", "D_CYL0", "D_SAVER", "D_SAVEP3", "D_TRANSLATE", "D_CYLR", "D_SAVER", "D_LOADP3",
+    assert [n for _, n in blocks] == ["D_LIP_PUSH", "D_SCALE_PRE", "D_CYL0", "D_SAVER", "D_SAVEP3", "D_TRANSLATE", "D_CYLR", "D_SAVER", "D_LOADP3",
                                       "D_GATE3D", "D_CYL0", "D_SAVER", "D_GATEZC", "D_LIP_PUSH", "D_SCREW_PRE", "D_LIP_WRAP", "D_POLY2D", "D_LIP_POP", "D_MAXR_SLOT",
-                                      "D_COMBINE_DIFF", "D_COMBINE_SUNION", "D_COMBINE_DIFF", "D_MULR"]
+                                      "D_COMBINE_DIFF", "D_COMBINE_SUNION", "D_COMBINE_DIFF", "D_MULR", "D_LIP_POP"]
     # the two gates are structured ifs around their children: `if (gate_far) R = L; else { child }`, closed before the combine
     assert src.count("if (gate_far<K, 3>(") == 2 and src.count("if (LIP) KLOOP L[kp] = L[kp] - lipR;") == 2 and src.count("}}  // end of gated child") == 2
     assert src.index("// end of gated child") < src.index("D_COMBINE_DIFF")
