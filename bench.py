@@ -47,7 +47,8 @@ def cpu_baseline(shader, scene, resdiv, threads):
     m, dt = run(resdiv, threads)
     out = {"value": m.evals / dt, "unit": "evals/s", "cores": threads, "kind": "port",
            "sample": f"{scene} resdiv {resdiv} flat lattice {m.grid[0]+1}x{m.grid[1]+1}x{m.grid[2]+1} = {m.evals} evals, "
-                     f"{m.n_tris} triangles in {dt:.2f}s (FlatRenderer+batch-recursive evaluators, batch 4096)",
+                     f"{m.n_tris} triangles in {dt:.2f}s (FlatRenderer+batch-recursive evaluators, batch 4096; the FLAT lattice forms a corner "
+                     f"as O+res*i, the octree as (O+res*(i-1))+res -- an ulp apart on some planes, hence 6818304 flat vs 6818282 octree triangles at resdiv 1600: DESIGN.md section 6)",
            "triangles_per_s": m.n_tris / dt, "eval_only_evals_per_s": m.evals / m.t_eval_s}
     m1, dt1 = run(400, 1, 2)
     out["single_thread"] = {"value": m1.evals / dt1, "unit": "evals/s", "cores": 1, "triangles_per_s": m1.n_tris / dt1,
@@ -91,6 +92,64 @@ def host_inclusive(hip, sdf, res, reps=7):
         out[key.replace("ms_", "bytes_")] = nbytes
     out["note"] = ("one complete mesh + result in host memory per call (pinned buffer from the library's pool, one DMA); "
                    "the headline stops at triangles resident in HBM")
+    return out
+
+
+def evaluate_dropin(hip, sdf, shader, n=32768, calls=300):
+    """The literal drop-in seam, measured AFTER the contract's timed loop: gleval.SDF3.Evaluate as the reference's own renderers
+    call it -- one blocking call per <= 32 768 host points (gsdfaux/gsdfaux.go:108-113,170; glrender/octreerenderer.go:154-176;
+    upload / dispatch / readback per call in the reference, gleval/gpu_cgo.go:194-258) -- through gsdf_hip_eval3 from pageable
+    host buffers, then the same from registered (pinned, device-mapped) buffers and as pipelined submit / wait pairs. Points:
+    the npt-flange lattice at resdiv 400 (the reference's published case), 32 768 per call. PCIe- and launch-latency-bound by
+    construction: never the headline value. The loop is Python over raw ctypes calls (~2 us of the per-call figure)."""
+    import ctypes as C
+    import numpy as np
+    L = hip.lib()
+    bb = shader.Bounds().astype(np.float64)
+    res = float(shader.Diagonal()) / 400
+    rng = np.random.default_rng(5)
+    base = (bb[:3] + rng.random((n, 3)) * (bb[3:] - bb[:3])).astype(np.float32)
+    base = (np.floor(base / res) * res).astype(np.float32)  # lattice-like coordinates (exact multiples share x, y, z values as a renderer's batches do)
+    out = {"points_per_call": n, "calls": calls, "unit": "evals/s"}
+
+    def run(label, bufs, pipelined):
+        h = sdf._h
+        ptrs = [(p_.ctypes.data, d_.ctypes.data) for p_, d_ in bufs]
+        tick = [C.c_int(), C.c_int()]
+        rc = 0
+        for rep in range(2):  # the first pass warms the slots' staging buffers
+            t0 = time.perf_counter()
+            if not pipelined:
+                pp, dp = ptrs[0]
+                for _ in range(calls):
+                    rc |= L.gsdf_hip_eval3(h, pp, 12, n, dp, n)
+            else:  # two calls in flight: submit the next batch, then wait for the previous one
+                live = [False, False]
+                for k in range(calls):
+                    i = k & 1
+                    if live[i]:
+                        rc |= L.gsdf_hip_eval_wait(h, tick[i])
+                    rc |= L.gsdf_hip_eval3_submit(h, ptrs[i][0], 12, n, ptrs[i][1], n, C.byref(tick[i]))
+                    live[i] = True
+                for i in range(2):
+                    if live[i]:
+                        rc |= L.gsdf_hip_eval_wait(h, tick[i])
+            dt = time.perf_counter() - t0
+        assert rc == 0, L.gsdf_hip_last_error()
+        out[label] = {"evals_per_s": n * calls / dt, "us_per_call": dt / calls * 1e6}
+
+    page = [(base.copy(), np.empty(n, np.float32)) for _ in range(2)]
+    reg = [(hip.host_array((n, 3)), hip.host_array((n,))) for _ in range(2)]
+    for p_, _ in reg:
+        p_[:] = base
+    run("blocking_pageable", page, False)
+    run("blocking_registered", reg, False)
+    assert (page[0][1].view(np.uint32) == np.asarray(reg[0][1]).view(np.uint32)).all()
+    run("pipelined_pageable", page, True)
+    run("pipelined_registered", reg, True)
+    assert (page[1][1].view(np.uint32) == np.asarray(reg[1][1]).view(np.uint32)).all() and (page[1][1].view(np.uint32) == page[0][1].view(np.uint32)).all()
+    out["note"] = ("gleval.SDF3.Evaluate through gsdf_hip_eval3, one call per 32768 host points as the reference's renderers issue them; "
+                   "PCIe- and launch-latency-inclusive, never the headline")
     return out
 
 
@@ -276,6 +335,11 @@ def main():
     ap.add_argument("--gather", choices=["all", "root", "none"], default="all",
                     help="N > 1: who ends up with the triangles -- all: RCCL all-gatherv, every rank gets everything (default, what "
                          "BASELINE.json names); root: rank 0 only (ncclSend/ncclRecv); none: every rank keeps its shard (counts only)")
+    ap.add_argument("--payload", choices=["records", "triangles"], default="records",
+                    help="N > 1, gather all / root, octree renderer: what a rank puts on the wire -- records: its packed cut-leaf records "
+                         "(40 B per cut leaf = 20 B per triangle; the receiving ranks run marching cubes over everybody's records, default) "
+                         "or triangles (36 B each, marched where they were made)")
+    ap.add_argument("--no-evaluate-dropin", action="store_true", help="skip the 32768-point host-buffer Evaluate measurement that follows the timed loop")
     ap.add_argument("--no-gather-pipeline", action="store_true",
                     help="N > 1: wait for a mesh's gather before meshing the next (default: the payload of mesh i moves while mesh i+1 is made)")
     ap.add_argument("--share-corners", action="store_true", help="evaluate each bitwise-distinct lattice corner of a brick once (same triangles, fewer evals)")
@@ -369,7 +433,10 @@ def main():
 
     gmode = {"all": hip.GATHER_ALL, "root": hip.GATHER_ROOT, "none": hip.GATHER_NONE}[args.gather]
     pipeline = comm is not None and not args.no_gather_pipeline
-    gstat = {"n": 0, "ms_counts": 0.0, "ms_payload": 0.0, "bytes_received": 0, "bytes_sent": 0}
+    # what moves in the gather: packed cut-leaf records by default (marching cubes then runs on the receiving ranks)
+    records = (comm is not None and args.payload == "records" and args.gather != "none" and args.renderer == "octree" and not args.share_corners)
+    payload = hip.PAYLOAD_RECORDS if records else hip.PAYLOAD_TRIANGLES
+    gstat = {"n": 0, "ms_counts": 0.0, "ms_payload": 0.0, "ms_march": 0.0, "bytes_received": 0, "bytes_sent": 0}
     pending = []  # at most one gather in flight: (PendingGather)
 
     def finish():
@@ -379,6 +446,7 @@ def main():
             gstat["n"] += 1
             gstat["ms_counts"] += gs.ms_counts
             gstat["ms_payload"] += gs.ms_payload
+            gstat["ms_march"] += gs.ms_march
             gstat["bytes_received"] += gs.bytes_received
             gstat["bytes_sent"] += gs.bytes_sent
         return g
@@ -387,7 +455,7 @@ def main():
         if args.renderer == "dualcontour":  # BASELINE configs[4]: dual contouring, z-slabs of the lattice per rank
             oc = hip.DualContourHIP(sdf, res, shard_rank=rank, shard_count=world)
         else:
-            oc = hip.OctreeHIP(sdf, res, shard_rank=rank, shard_count=world, share_corners=args.share_corners)
+            oc = hip.OctreeHIP(sdf, res, shard_rank=rank, shard_count=world, share_corners=args.share_corners, payload=payload)
         gathered = None
         if comm is not None:
             # the counts are exchanged and the payload enqueued on the communicator's stream; with the pipeline on, the
@@ -440,6 +508,13 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[2])
     evals_all, tris_all = float(tot[0]), float(tot[1])
+    evals_minmax = None
+    if dist is not None:  # load balance of the brick partition: evaluations per step of the least and the most loaded rank
+        lo = torch.tensor([float(evals)], dtype=torch.float64, device=tot.device)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        evals_minmax = (float(lo[0]) / args.steps, float(hi[0]) / args.steps)
 
     if rank == 0:
         oc, g = last
@@ -468,9 +543,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "evaluator_build": "interpreter" if (args.interpreter or "specialised" not in spec_note) else "specialised",
             "config": {"workload": workload,
                        "sharding": (("z-slabs of the lattice, halo recomputed" if dc else "octree bricks by coordinate hash")
-                                    + ((", RCCL gather of triangles inside the library (gsdf_hip_mesh_gatherv_start/_wait): mode " + args.gather
+                                    + ((", gather of " + ("packed cut-leaf records (marching cubes after the gather)" if records else "triangles") + " inside the library over " + comm.transport() + " (gsdf_hip_mesh_gatherv_start/_wait): mode " + args.gather
                                         + (", payload of mesh i overlapped with mesh i+1" if pipeline else ", not pipelined")) if comm is not None else ", RCCL all-gatherv of triangles through torch.distributed (fallback)")) if (world > 1 or comm is not None) else "single GPU",
                        "leaf_corners": "shared (distinct lattice points once)" if args.share_corners else "8 per leaf (as the reference)",
                        "evaluator": spec_note, "code": code,
@@ -484,7 +560,7 @@ def main():
                          "kernel_evals_per_s": kernel_rate, "valu": None if dc else valu_roofline(kernel_rate, workload, code),
                          "note": "path is fp32-VALU bound (SURVEY 8(d)): algorithmic HBM bytes are tiny by construction; "
                                  "'valu' prices the same kernel against the VALU issue peak"},
-            "roofline_march": None if (dc or not two_kernel) else {
+            "roofline_march": None if (dc or not two_kernel or records) else {
                 "bound": "hbm", "kernel": "march_records_kernel", "kernel_ms": e_ms, "algorithmic_gb_per_launch": e_bytes / 1e9,
                 "achieved": e_bytes / (e_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": e_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "marching cubes over the cut-leaf records: 40 B read per record + 36 B written per triangle"},
@@ -496,8 +572,12 @@ def main():
             step_ms = dt / args.steps * 1e3
             out["phase_ms_rank0"]["gather_counts"] = gstat["ms_counts"] / n
             out["phase_ms_rank0"]["gather"] = gstat["ms_payload"] / n
-            out["gather"] = {"mode": args.gather, "pipelined": pipeline, "bytes_received_per_rank": gstat["bytes_received"] / n,
-                             "bytes_sent_per_rank": gstat["bytes_sent"] / n, "ms": g_ms,
+            out["phase_ms_rank0"]["gather_march"] = gstat["ms_march"] / n
+            g_ms += gstat["ms_march"] / n
+            out["gather"] = {"mode": args.gather, "pipelined": pipeline, "payload": "records" if records else "triangles",
+                             "transport": comm.transport(), "bytes_received_per_rank": gstat["bytes_received"] / n,
+                             "bytes_sent_per_rank": gstat["bytes_sent"] / n, "ms": g_ms, "ms_march_after_gather": gstat["ms_march"] / n,
+                             "evals_per_step_min_max_over_ranks": evals_minmax,
                              # how much of the shorter of the two (meshing on the device, gather on the wire) hid behind the other
                              "overlap_frac": max(0.0, min(1.0, (st.ms_total + g_ms - step_ms) / max(1e-9, min(st.ms_total, g_ms)))),
                              "note": "rank 0, HIP events on the communicator's stream; a step = one mesh + its gather"}
@@ -510,6 +590,8 @@ def main():
             out["host_inclusive"] = host_inclusive(hip, sdf, res)
         if world == 1 and not dc and not args.no_batch_throughput and not args.no_cpu_baseline:
             out["batch_throughput"] = batch_throughput(hip, shader, res, not args.interpreter)
+        if world == 1 and not dc and not args.no_evaluate_dropin and args.scene != "text-plate":
+            out["evaluate_dropin"] = evaluate_dropin(hip, sdf, shader)
         print(json.dumps(out), flush=True)
     if dist is not None:
         if rank == 0 and last[1] is not None:

@@ -395,6 +395,7 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   for (auto& sl : p->slot) {
     if (sl.h_pos) (void)hipHostFree(sl.h_pos);
     if (sl.h_dist) (void)hipHostFree(sl.h_dist);
+    if (sl.h_flag) (void)hipHostFree(sl.h_flag);
     if (sl.s) (void)hipStreamDestroy(sl.s);
   }
   if (p->spec_mod) (void)hipModuleUnload(p->spec_mod);
@@ -546,6 +547,22 @@ static int eval_submit(gsdf_program* p, int dim, const void* pos, size_t stride,
   }
   rc = eval_dev(p, dim, dp, stride, (float*)dd, n_pos, sl.s, /*count=*/false);
   if (rc) return bail(rc);
+  // completion flag behind the kernel (eval_wait polls it; hipStreamSynchronize remains the fallback)
+  static const bool use_flag = [] { const char* e = getenv("GSDF_HIP_EVAL_FLAG"); return !e || atoi(e) != 0; }();  // developer knob (A/B timing)
+  sl.flagged = false;
+  if (use_flag) {
+    if (!sl.h_flag) {
+      void* hf = nullptr; void* df = nullptr;
+      if (hipHostMalloc(&hf, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && hipHostGetDevicePointer(&df, hf, 0) == hipSuccess) {
+        sl.h_flag = (unsigned*)hf; sl.d_flag = (unsigned*)df; *sl.h_flag = 0u;
+      } else { (void)hipGetLastError(); if (hf) (void)hipHostFree(hf); }
+    }
+    if (sl.h_flag) {
+      sl.flag_val = sl.flag_val + 1u ? sl.flag_val + 1u : 1u;
+      hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(1), 0, sl.s, sl.d_flag, sl.flag_val);
+      if (hipGetLastError() == hipSuccess) sl.flagged = true;
+    }
+  }
   p->evals_host.fetch_add(n_pos);
   *ticket = si | (int)(sl.gen << 8);
   return GSDF_OK;
@@ -560,7 +577,19 @@ static int eval_wait(gsdf_program* p, int tk) {
     s0.waiting = true;
   }
   gsdf_program::Slot& sl = p->slot[ticket];
-  hipError_t e = hipStreamSynchronize(sl.s);
+  hipError_t e = hipSuccess;
+  bool done = false;
+  if (sl.flagged) {  // poll the flag the stream writes behind the kernel: ~100 us of spinning at most, then the blocking wait
+    const volatile unsigned* f = sl.h_flag;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; spin++) {
+      if (*f == sl.flag_val) { done = true; break; }
+      __builtin_ia32_pause();
+      if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (!done) e = hipStreamSynchronize(sl.s);
   if (e == hipSuccess && !sl.zero_copy) std::memcpy(sl.user_dist, sl.h_dist, sl.n * sizeof(float));
   slot_release(p, ticket);
   if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));

@@ -14,6 +14,7 @@
 #include "kernels_dc.h"
 #include "kernels_stl.h"
 #include "abi_program.h"
+#include "host_math.h"
 
 extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_opts* opts_in, gsdf_mesh** out) {
   if (!p || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
@@ -35,7 +36,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   float mn[3], mx[3];
   scale_centered(p->prog.bb, 1.01f, mn, mx);
   const float longAxis = fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));
-  const float l2 = (float)std::log2((double)(longAxis / res));
+  const float l2 = gsdf::log2f32(longAxis / res);
   const int levels = (int)std::ceil(l2) + 1;
   if (levels <= 1) return fail(GSDF_ERR_RESOLUTION, "resolution not fine enough for marching cubes");
   if (levels > 17) return fail(GSDF_ERR_RESOLUTION, "resolution too fine: more than 17 octree levels");
@@ -472,7 +473,7 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
   float mn[3], mx[3];
   for (int a = 0; a < 3; a++) { mn[a] = p->prog.bb[a] + -sub; mx[a] = p->prog.bb[a + 3] + -sub; }
   const float longAxis = fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));
-  const int levels = (int)std::ceil((float)std::log2((double)(longAxis / res))) + 1;
+  const int levels = (int)std::ceil(gsdf::log2f32(longAxis / res)) + 1;
   if (levels <= 1) return fail(GSDF_ERR_RESOLUTION, "resolution not fine enough for marching cubes");
   // the neighbour lookup is a dense int32 index grid over the 2^(levels-1) cube lattice: 4.3 GB at 11 levels, 34 GB at 12 --
   // what one 288 GB device holds beside the rest of the workspace (13 levels would be 275 GB)

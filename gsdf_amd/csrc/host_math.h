@@ -39,7 +39,46 @@ inline void sincosf32(float x, float& s_out, float& c_out) {
   if (sinSign) s = -s;
   s_out = s; c_out = c;
 }
-// float32(math.Tan(float64)) (math32 doc.go); libm double is within 1 ulp(double) of Go's.
-inline float tanf32(float x) { return (float)std::tan((double)x); }
+// float32(math.Tan(float64)) (math32 doc.go): Go's own routine (go/src/math/tan.go; Cephes), arguments below the Payne-Hanek
+// threshold (a thread's taper angle), evaluated in double and rounded once.
+inline float tanf32(float x) {
+  static const double P[3] = {-1.30936939181383777646e4, 1.15351664838587416140e6, -1.79565251976484877988e7};
+  static const double Q[5] = {1.0, 1.36812963470692954678e4, -1.32089234440210967447e6, 2.50083801823357915839e7, -5.38695755929454629881e7};
+  const double PI4A = 7.85398125648498535156e-1, PI4B = 3.77489470793079817668e-8, PI4C = 2.69515142907905952645e-15;
+  double v = (double)x;
+  if (v == 0 || v != v) return x;
+  if (std::isinf(v)) return NAN;
+  bool sign = false;
+  if (v < 0) { v = -v; sign = true; }
+  uint64_t j = (uint64_t)(v * (4 / kPi));
+  double y = (double)j;
+  if (j & 1) { j++; y++; }
+  const double z = ((v - y * PI4A) - y * PI4B) - y * PI4C, zz = z * z;
+  if (zz > 1e-14) y = z + z * (zz * (((P[0] * zz) + P[1]) * zz + P[2]) / ((((zz + Q[1]) * zz + Q[2]) * zz + Q[3]) * zz + Q[4]));
+  else y = z;
+  if (j & 2) y = -1 / y;
+  return (float)(sign ? -y : y);
+}
+// float32(math.Log2(float64)) for finite x > 0 (makeICube's level count, octreerenderer.go:222-235): go/src/math/log10.go over
+// log.go (FreeBSD e_log.c) -- Frexp first, so powers of two are exact.
+inline float log2f32(float x) {
+  static const double Ln2Hi = 6.93147180369123816490e-01, Ln2Lo = 1.90821492927058770002e-10, L1 = 6.666666666666735130e-01,
+                      L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01, L4 = 2.222219843214978396e-01,
+                      L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01, L7 = 1.479819860511658591e-01;
+  const double v = (double)x;
+  if (!(v > 0) || std::isinf(v)) return (float)std::log2(v);  // special values: as IEEE says
+  int e;
+  const double frac = std::frexp(v, &e);
+  if (frac == 0.5) return (float)(e - 1);
+  int ki;
+  double f1 = std::frexp(frac, &ki);
+  if (f1 < 1.41421356237309504880168872420969808 / 2) { f1 *= 2; ki--; }
+  const double f = f1 - 1, k = (double)ki;
+  const double s = f / (2 + f), s2 = s * s, s4 = s2 * s2;
+  const double t1 = s2 * (L1 + s4 * (L3 + s4 * (L5 + s4 * L7))), t2 = s4 * (L2 + s4 * (L4 + s4 * L6));
+  const double R = t1 + t2, hfsq = 0.5 * f * f;
+  const double lg = k * Ln2Hi - ((hfsq - (s * (hfsq + R) + k * Ln2Lo)) - f);
+  return (float)(lg * (1 / 0.693147180559945309417232121458176568) + (double)e);
+}
 
 }  // namespace gsdf

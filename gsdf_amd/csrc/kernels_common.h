@@ -40,6 +40,25 @@ struct MeshCounters {
   unsigned long long n_cut;                // leaves the surface cuts (records written by leaf_eval_kernel)
 };
 
+// Decisions on a value that may be NaN (a distance of a degenerate tree, tests/test_gpu_nan.py), as CLASS / INTEGER tests on its
+// bits. The specialised kernels are built with -fno-honor-nans (specialize.cpp), under which a float comparison with a NaN
+// operand is whatever is cheapest: `!(|d| >= m)` came out as `|d| < m` and dropped the cubes the reference keeps, `v != v` was
+// folded away. These say what IEEE comparisons say (false for NaN) in every build, at the same instruction count
+// (v_cmp_class_f32; one v_and + v_cmp_u32 for the magnitude tests).
+namespace nb {
+// v_cmp_class_f32 mask bits: 0 sNaN, 1 qNaN, 2 -inf, 3 -normal, 4 -subnormal, 5 -0, 6 +0, 7 +subnormal, 8 +normal, 9 +inf
+__device__ __forceinline__ bool lt0(float v) { return __builtin_amdgcn_classf(v, 0x01c); }   // v <  0
+__device__ __forceinline__ bool le0(float v) { return __builtin_amdgcn_classf(v, 0x07c); }   // v <= 0
+__device__ __forceinline__ bool ge0(float v) { return __builtin_amdgcn_classf(v, 0x3e0); }   // v >= 0
+__device__ __forceinline__ bool nan_or_inf(float v) { return __builtin_amdgcn_classf(v, 0x207); }
+// |v| <= lim and |v| >= lim for a finite lim >= 0: non-negative floats order like their bit patterns
+__device__ __forceinline__ bool abs_le(float v, float lim) { return (__float_as_uint(v) & 0x7fffffffu) <= __float_as_uint(lim); }
+__device__ __forceinline__ bool abs_ge(float v, float lim) {
+  const unsigned a = __float_as_uint(v) & 0x7fffffffu;
+  return a >= __float_as_uint(lim) && a <= 0x7f800000u;
+}
+}  // namespace nb
+
 // wave64 compaction: returns the global slot for lanes with keep=true (others undefined).
 __device__ __forceinline__ unsigned long long wave_append(bool keep, unsigned long long* counter) {
   const unsigned long long mask = __ballot(keep);

@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __r
     unsigned mine = 0;
 #pragma unroll
     for (int kp = 0; kp < K; kp++) {
-      keep[kp] = valid[kp] && !(dm::absf(d[kp]) >= maxDist);
+      keep[kp] = valid[kp] && !nb::abs_ge(d[kp], maxDist);
       mine += keep[kp] ? 1u : 0u;
     }
     unsigned incl = mine;  // wave inclusive scan of per-lane counts
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(BLOCK) dc_quads_kernel(const Cube* __restrict_
       const Cube c = cubes[ci];
       const float4 d = dists[ci];
       ok = ok && c.z >= zown_lo && c.z < zown_hi;  // quads are emitted by the rank that owns the edge's cube
-      flip = ((a == 0 ? d.y : (a == 1 ? d.z : d.w)) - d.x) < 0.f;
+      flip = nb::lt0((a == 0 ? d.y : (a == 1 ? d.z : d.w)) - d.x);
       // EdgeNeighborsX/Y/Z (:271-287): offsets in cube units
       const int off[3][4][3] = {{{0, -1, -1}, {0, 0, -1}, {0, 0, 0}, {0, -1, 0}},
                                 {{-1, 0, -1}, {-1, 0, 0}, {0, 0, 0}, {0, 0, -1}},

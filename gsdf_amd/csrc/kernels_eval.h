@@ -63,12 +63,17 @@ __global__ void __launch_bounds__(BLOCK, 3) image2_kernel(const uint32_t* __rest
       if (i < n) {
         const float v = d[kp];
         if (dist) dist[i] = v;
-        const bool bad = (v != v) || (dm::absf(v) == __builtin_inff());
+        const bool bad = nb::nan_or_inf(v);
         if (rgba) rgba[i] = bad ? 0xff0000ffu : (v > 0.f ? 0xffffffffu : 0xff000000u);  // R,G,B,A bytes little-endian
       }
     }
   }
 }
+
+// Completion flag of a host-buffer call (abi_eval.hip: eval_submit / eval_wait): runs behind the evaluating kernel on its
+// stream and writes `v` to a word of pinned host memory the waiting thread polls. (The evaluating kernel's own stores to the
+// caller's mapped buffers are released at its end; PCIe keeps posted writes in order, so the host sees them before the flag.)
+__global__ void signal_kernel(unsigned* flag, unsigned v) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // Exhaustive self-test of dm::sqrt_1to2 over every float in [1, 2].
 __global__ void __launch_bounds__(BLOCK) sqrt_selftest_kernel(unsigned long long* __restrict__ bad) {

@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(BLOCK, W) flat_grid_kernel(const uint32_t* __r
       if (ok) grid[(uint64_t)k * FLAT_PITCH(sx) * sy + (uint64_t)j * FLAT_PITCH(sx) + i] = d[z];
       // the two things the marching pass wants to know about most corners, one bit each (see flat_cut_scan_kernel):
       // word (t * 4 + wave) of plane k, bit = lane, i.e. bit (i + sx * j) of the plane in the UNPADDED corner order
-      const unsigned long long ng = __ballot(ok && d[z] < 0.f), nr = __ballot(ok && dm::absf(d[z]) <= cubeDiag);
+      const unsigned long long ng = __ballot(ok && nb::lt0(d[z])), nr = __ballot(ok && nb::abs_le(d[z], cubeDiag));
       if (k < nk && (threadIdx.x & 63u) == 0u) {
         const uint64_t wi = (uint64_t)k * (tpg * (BLOCK / 64)) + (uint64_t)t * (BLOCK / 64) + (threadIdx.x >> 6);
         negbits[wi] = ng;
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(BLOCK, 4) flat_march_kernel(const float* __res
     for (int r = 0; r < FLAT_ROWS; r++) {
       d0[r] = dn1[r];
       dn1[r] = dn2[r];
-      any_act = any_act || (cube_x && cy0 + (unsigned)r < ny && dm::absf(d0[r]) <= cubeDiag);
+      any_act = any_act || (cube_x && cy0 + (unsigned)r < ny && nb::abs_le(d0[r], cubeDiag));
     }
     t1x = t2x; t1y = t2y; t1z = t2z;
     if ((uint64_t)w + 2ull * wstride < npass) {
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(BLOCK, 4) flat_march_kernel(const float* __res
     const float d8 = (corner_x && cy0 + FLAT_ROWS <= ny) ? g0[(uint64_t)FLAT_ROWS * sx] : __builtin_inff();  // plane z, row 8
 #pragma unroll
     for (int r = 0; r < FLAT_ROWS; r++) {
-      const bool act = cube_x && cy0 + (unsigned)r < ny && dm::absf(d0[r]) <= cubeDiag;  // the reference's |d0| <= 2*sqrt3*res test (:207-209)
+      const bool act = cube_x && cy0 + (unsigned)r < ny && nb::abs_le(d0[r], cubeDiag);  // the reference's |d0| <= 2*sqrt3*res test (:207-209)
       const unsigned long long am = __ballot(act);
       if (am == 0ull) continue;  // wave-uniform
       my_active += (unsigned)__builtin_popcountll(am);
@@ -229,8 +229,8 @@ __global__ void __launch_bounds__(BLOCK, 4) flat_march_kernel(const float* __res
       const float c4 = up[r], c7 = up[r + 1], c5 = __shfl_down(c4, 1, 64), c6 = __shfl_down(c7, 1, 64);
       unsigned ix = 0;
       if (act) {
-        ix = (d0[r] < 0.f ? 1u : 0u) | (c1 < 0.f ? 2u : 0u) | (c2 < 0.f ? 4u : 0u) | (c3 < 0.f ? 8u : 0u) | (c4 < 0.f ? 16u : 0u) |
-             (c5 < 0.f ? 32u : 0u) | (c6 < 0.f ? 64u : 0u) | (c7 < 0.f ? 128u : 0u);
+        ix = (nb::lt0(d0[r]) ? 1u : 0u) | (nb::lt0(c1) ? 2u : 0u) | (nb::lt0(c2) ? 4u : 0u) | (nb::lt0(c3) ? 8u : 0u) | (nb::lt0(c4) ? 16u : 0u) |
+             (nb::lt0(c5) ? 32u : 0u) | (nb::lt0(c6) ? 64u : 0u) | (nb::lt0(c7) ? 128u : 0u);
         if (ix == 255u) ix = 0u;
       }
       const unsigned long long cm = __ballot(ix != 0u);

@@ -95,10 +95,10 @@ __global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict
       float dv[2];
       if (do_test == 2) {
         gsdf_dev::sdf_eval<2>(code, pv, dv, lds, BLOCK);
-        keep = valid && !(dm::absf(dv[0]) >= maxDist);
+        keep = valid && !nb::abs_ge(dv[0], maxDist);
       } else {
         gsdf_dev::sdf_eval<2, 0, true>(code, pv, dv, lds, BLOCK, false, maxDist, (uint32_t)lip_base);
-        keep = valid && !(dv[0] >= 0.0f || dv[1] <= 0.0f);
+        keep = valid && !(nb::ge0(dv[0]) || nb::le0(dv[1]));
       }
     }
     const unsigned long long pm = __ballot(keep);
@@ -191,10 +191,10 @@ __global__ void __launch_bounds__(BLOCK) prune_spec_kernel(const uint32_t* __res
     bool keep;
     if (ptest == 2) {
       gsdf_dev::sdf_eval<2>(code, pv, dv, lds, BLOCK);
-      keep = !(dm::absf(dv[0]) >= maxDist);
+      keep = !nb::abs_ge(dv[0], maxDist);
     } else {
       gsdf_dev::sdf_eval<2, 0, true>(code, pv, dv, lds, BLOCK, false, maxDist, (uint32_t)lip_base);  // (maxDist differs from lane to lane: fine, it is the lane's own radius)
-      keep = !(dv[0] >= 0.0f || dv[1] <= 0.0f);
+      keep = !(nb::ge0(dv[0]) || nb::le0(dv[1]));
     }
     if (!tested) keep = true;
     const bool own = level != shard_level || brick_owner(c.x, c.y, c.z, shard_count) == shard_rank;
@@ -563,10 +563,10 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
       for (int kp = 0; kp < K; kp++) {
         const unsigned c = (0x62735140u >> (4u * (c0 + kp))) & 7u;
         dall[8 - K + kp] = dk[kp];
-        index |= (dk[kp] < 0.f ? 1u : 0u) << c;
+        index |= (nb::lt0(dk[kp]) ? 1u : 0u) << c;
       }
       if (c0 == 0) {
-        pass = valid && (dm::absf(dk[0]) <= cubeDiag);
+        pass = valid && nb::abs_le(dk[0], cubeDiag);
         const unsigned long long pmask = __ballot(pass);
         if (pmask == 0ull) break;  // wave-uniform
         const unsigned long long vmask = __ballot(valid);
@@ -768,9 +768,9 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
       for (int c = 0; c < 8; c++) {
         const unsigned cx = (c ^ (c >> 1)) & 1u, cy = (c >> 1) & 1u, cz = (c >> 2) & 1u;
         dc[c] = D[(2u * lk + cz) * BLOCK + (2u * lj + cy) * 8u + 2u * li + cx];
-        index |= (dc[c] < 0.f ? 1u : 0u) << c;
+        index |= (nb::lt0(dc[c]) ? 1u : 0u) << c;
       }
-      pass = dm::absf(dc[0]) <= cubeDiag;
+      pass = nb::abs_le(dc[0], cubeDiag);
       nact = (unsigned)__builtin_popcountll(__ballot(pass));
     } else {
       const float x0 = ox + res * (float)lf.x, y0 = oy + res * (float)lf.y, z0 = oz + res * (float)lf.z;
@@ -796,10 +796,10 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
         for (int kp = 0; kp < K; kp++) {
           const unsigned c = (0x62735140u >> (4u * (c0 + kp))) & 7u;
           dall[8 - K + kp] = dk[kp];
-          index |= (dk[kp] < 0.f ? 1u : 0u) << c;
+          index |= (nb::lt0(dk[kp]) ? 1u : 0u) << c;
         }
         if (c0 == 0) {
-          pass = valid && (dm::absf(dk[0]) <= cubeDiag);
+          pass = valid && nb::abs_le(dk[0], cubeDiag);
           const unsigned long long pmask = __ballot(pass);
           if (pmask == 0ull) break;  // wave-uniform
           const unsigned long long vmask = __ballot(valid);
@@ -1454,8 +1454,8 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_brick_kernel(const uint32_t
     const float x0 = val[ux0], x1 = val[ux0 + 1], y0 = val[8 + uy0], y1 = val[8 + uy0 + 1], z0 = val[16 + uz0], z1 = val[16 + uz0 + 1];
     unsigned index = 0;
 #pragma unroll
-    for (unsigned cc = 0; cc < 8; cc++) index |= (vdist(cc) < 0.f ? 1u : 0u) << cc;
-    const bool pass = bvalid && (dm::absf(vdist(0)) <= cubeDiag);
+    for (unsigned cc = 0; cc < 8; cc++) index |= (nb::lt0(vdist(cc)) ? 1u : 0u) << cc;
+    const bool pass = bvalid && nb::abs_le(vdist(0), cubeDiag);
     const unsigned long long pmask = __ballot(pass);
     if (lane == 0) my_active += (unsigned long long)__builtin_popcountll(pmask);
     if (!pass) index = 0;

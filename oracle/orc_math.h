@@ -233,11 +233,52 @@ static inline double go_cbrt64(double x) {
 }
 static inline float go_cbrtf(float x) { return (float)go_cbrt64((double)x); }
 
-/* Host-only constants (tan/atan/log2 of build-time scalars): wrappers over float64; libm's double
- * results round to the same float32 as Go's except with probability ~2^-29 per call. */
-static inline float go_tanf(float x) { return (float)tan((double)x); }
+/* math.Tan (go/src/math/tan.go; Cephes tan.c), arguments below the Payne-Hanek threshold (the call sites pass a thread's taper
+ * angle: a fraction of a radian). */
+static inline double go_tan64(double x) {
+  static const double P[3] = {-1.30936939181383777646e4, 1.15351664838587416140e6, -1.79565251976484877988e7};
+  static const double Q[5] = {1.0, 1.36812963470692954678e4, -1.32089234440210967447e6, 2.50083801823357915839e7, -5.38695755929454629881e7};
+  if (x == 0 || x != x) return x;
+  if (isinf(x)) return NAN;
+  int sign = 0;
+  if (x < 0) { x = -x; sign = 1; }
+  uint64_t j = (uint64_t)(x * (4 / ORC_PI)); /* integer part of x / (Pi/4) */
+  double y = (double)j;
+  if (j & 1) { j++; y++; } /* map zeros and singularities to origin */
+  double z = ((x - y * GO_PI4A) - y * GO_PI4B) - y * GO_PI4C;
+  double zz = z * z;
+  if (zz > 1e-14) y = z + z * (zz * (((P[0] * zz) + P[1]) * zz + P[2]) / ((((zz + Q[1]) * zz + Q[2]) * zz + Q[3]) * zz + Q[4]));
+  else y = z;
+  if (j & 2) y = -1 / y;
+  return sign ? -y : y;
+}
+/* math.Log (go/src/math/log.go; FreeBSD e_log.c) for finite x > 0, and math.Log2 (log10.go: Frexp, exact for powers of two). */
+static inline double go_log64(double x) {
+  static const double Ln2Hi = 6.93147180369123816490e-01, Ln2Lo = 1.90821492927058770002e-10, L1 = 6.666666666666735130e-01,
+                      L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01, L4 = 2.222219843214978396e-01,
+                      L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01, L7 = 1.479819860511658591e-01;
+  if (x != x || isinf(x)) return x > 0 || x != x ? x : NAN;
+  if (x < 0) return NAN;
+  if (x == 0) return -INFINITY;
+  int ki;
+  double f1 = frexp(x, &ki);
+  if (f1 < 1.41421356237309504880168872420969808 / 2) { f1 *= 2; ki--; }
+  double f = f1 - 1, k = (double)ki;
+  double s = f / (2 + f), s2 = s * s, s4 = s2 * s2;
+  double t1 = s2 * (L1 + s4 * (L3 + s4 * (L5 + s4 * L7))), t2 = s4 * (L2 + s4 * (L4 + s4 * L6));
+  double R = t1 + t2, hfsq = 0.5 * f * f;
+  return k * Ln2Hi - ((hfsq - (s * (hfsq + R) + k * Ln2Lo)) - f);
+}
+static inline double go_log2_64(double x) {
+  int e;
+  double frac = frexp(x, &e);
+  if (frac == 0.5) return (double)(e - 1); /* exact for powers of two */
+  return go_log64(frac) * (1 / 0.693147180559945309417232121458176568) + (double)e;
+}
+/* math32's float32(math.XXX(float64(x))) wrappers, as everywhere in this file: Go's own float64 routines, rounded once */
+static inline float go_tanf(float x) { return (float)go_tan64((double)x); }
 static inline float go_atanf(float x) { return (float)go_atan64((double)x); }
-static inline float go_log2f(float x) { return (float)log2((double)x); }
+static inline float go_log2f(float x) { return (float)go_log2_64((double)x); }
 
 /* math32.Pow(x, y) for the only call site (gsdf.go:183, y = 1/3, x >= 0): float32 port of
  * go/src/math/pow.go: yi,yf = Modf(y) -> yi=0, yf=1/3 ; a1 = Exp(yf*Log(x)) ; then Frexp/Ldexp

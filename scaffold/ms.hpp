@@ -37,12 +37,11 @@ inline float hypotf32(float p, float q) {  // math32.Hypot (float32 port of go/s
   q = q / p;
   return p * std::sqrt(1 + q * q);
 }
-// math32.Sincos, math32.Tan, kPi: ../gsdf_amd/csrc/host_math.h (the lowering needs them too)
+// math32.Sincos, math32.Tan, math32.Log2, kPi: ../gsdf_amd/csrc/host_math.h (the lowering and the meshers need them too)
 // float32(math.X(float64)) wrappers (math32 doc.go); libm double is within 1 ulp(double) of Go's.
 inline float atanf32(float x) { return (float)std::atan((double)x); }
 inline float cosf32(float x) { return (float)std::cos((double)x); }
 inline float acosf32(float x) { return (float)std::acos((double)x); }
-inline float log2f32(float x) { return (float)std::log2((double)x); }
 
 // ---- ms2 / ms3 ----
 struct Vec2 { float X = 0, Y = 0; };

@@ -143,3 +143,56 @@ def test_non_finite_positions_differ_only_where_the_reference_is_not_finite(gpu)
         total += int((~np.isfinite(dref)).sum())
     assert not failures, failures
     assert total > 1000 and checked >= 25
+
+
+def _sorted_bits(t):
+    t = np.ascontiguousarray(t, np.float32).reshape(-1, 9).view(np.uint32)
+    return t[np.lexsort(t.T[::-1])]
+
+
+def test_degenerate_trees_mesh_and_image_the_same_from_both_builds(gpu):
+    """The specialised kernels are built with -fno-honor-nans; what DECIDES -- a cube kept or dropped, a leaf marched or not, a
+    corner inside or outside, a pixel flagged as not finite -- is a class / integer test on the value's bits in every kernel
+    (kernels_common.h: nb::), not a float comparison the flag would let the compiler bend: on the degenerate trees, whose fields
+    hold NaN, the specialised octree / flat meshes and the image are the interpreter's. The reference's own decisions on a NaN:
+    the cube is kept (|d| >= maxDist is false, octreerenderer.go:270-273), the leaf is not marched (|d0| <= cubeDiag is false,
+    marchcubes.go:20-23), the corner is outside (d < 0 is false)."""
+    checked = 0
+    for name, t in degenerate_trees():
+        bb = np.array(t.bb[:], np.float32)
+        res = np.float32(float(np.linalg.norm(bb[3:] - bb[:3])) / 48)
+        a, b = gpu.SDFHIP(t), gpu.SDFHIP(t)
+        b.specialize()
+        for mk in (lambda s: gpu.OctreeHIP(s, res), lambda s: gpu.OctreeHIP(s, res, assume_sdf=True), lambda s: gpu.FlatHIP(s, res)):
+            ma, mb = mk(a), mk(b)
+            assert ma.n_tris() == mb.n_tris() and ma.TotalPruned() == mb.TotalPruned() and ma.stats.active_leaves == mb.stats.active_leaves, name
+            assert (_sorted_bits(ma.RenderAll()) == _sorted_bits(mb.RenderAll())).all(), name
+            checked += ma.n_tris()
+    assert checked > 10000
+    # 2-D: the same nodes under the image renderer (NaN / Inf pixels are red, image.go:104-112)
+    b2 = Builder()
+    trees = []
+    t = clone(b2.NewLine2D(0.2, 0.1, 1.0, 0.5, 0.2).tree())
+    n = t.nodes[first(t, "LINE2D")]
+    n.p[2], n.p[3] = n.p[0], n.p[1]
+    trees.append(("line-of-length-zero", t))
+    t = clone(b2.NewEllipse(1.0, 0.5).tree())
+    n = t.nodes[first(t, "ELLIPSE2D")]
+    n.p[1] = n.p[0]
+    trees.append(("ellipse-circle", t))
+    t = clone(b2.NewPolygon([(0, 0), (2, 0), (2, 1), (1, 1.5), (0, 1)]).tree())
+    n = t.nodes[first(t, "POLY2D")]
+    t.aux[n.aux_off + 4], t.aux[n.aux_off + 5] = t.aux[n.aux_off + 2], t.aux[n.aux_off + 3]
+    trees.append(("polygon-repeated-vertex", t))
+    red = 0
+    for name, t in trees:
+        a, b = gpu.SDFHIP(t), gpu.SDFHIP(t)
+        b.specialize()
+        (da, ia), (db, ib) = a.render_image(96, 64), b.render_image(96, 64)
+        same = da.view(np.uint32) == db.view(np.uint32)
+        assert (same | (np.isnan(da) & np.isnan(db))).all(), name               # the distances, NaN where both are NaN
+        assert (np.asarray(ia) == np.asarray(ib)).all(), name                   # the pixels
+        bad = ~np.isfinite(da)
+        assert (np.asarray(ia).reshape(-1, 4)[bad.reshape(-1)] == [255, 0, 0, 255]).all(), name
+        red += int(bad.sum())
+    assert red > 0
