@@ -340,6 +340,10 @@ def main():
                          "(40 B per cut leaf = 20 B per triangle; the receiving ranks run marching cubes over everybody's records, default) "
                          "or triangles (36 B each, marched where they were made)")
     ap.add_argument("--no-evaluate-dropin", action="store_true", help="skip the 32768-point host-buffer Evaluate measurement that follows the timed loop")
+    ap.add_argument("--no-mesh-pipeline", action="store_true",
+                    help="N = 1: one blocking gsdf_hip_mesh_octree call per step (default: gsdf_hip_mesh_octree_start / _wait, the next mesh's "
+                         "chain of kernels is enqueued before the previous mesh is waited for; every one of the K meshes is started and "
+                         "finished inside the timed region)")
     ap.add_argument("--no-gather-pipeline", action="store_true",
                     help="N > 1: wait for a mesh's gather before meshing the next (default: the payload of mesh i moves while mesh i+1 is made)")
     ap.add_argument("--share-corners", action="store_true", help="evaluate each bitwise-distinct lattice corner of a brick once (same triangles, fewer evals)")
@@ -484,8 +488,22 @@ def main():
     evals = tris = 0
     march_ms = march_evals = march_tris = emit_ms = cut = 0.0
     last = None
-    for _ in range(args.steps):
-        oc, g = step()
+    mesh_pipeline = (comm is None and not torch_gather and args.renderer == "octree" and not args.no_mesh_pipeline)
+    started = [None]
+
+    def next_mesh(k):
+        """(mesh, gathered) number k of the timed loop. Pipelined: mesh k + 1 is started (its kernels enqueued) before mesh k is
+        waited for -- all K are started and finished between the two barriers."""
+        if not mesh_pipeline:
+            return step()
+        if started[0] is None:
+            started[0] = hip.OctreeHIP.start(sdf, res, share_corners=args.share_corners)
+        cur = started[0]
+        started[0] = hip.OctreeHIP.start(sdf, res, share_corners=args.share_corners) if k + 1 < args.steps else None
+        return cur.wait(), None
+
+    for k in range(args.steps):
+        oc, g = next_mesh(k)
         st = oc.stats
         evals += st.evals
         tris += st.n_tris
@@ -550,7 +568,9 @@ def main():
                                         + (", payload of mesh i overlapped with mesh i+1" if pipeline else ", not pipelined")) if comm is not None else ", RCCL all-gatherv of triangles through torch.distributed (fallback)")) if (world > 1 or comm is not None) else "single GPU",
                        "leaf_corners": "shared (distinct lattice points once)" if args.share_corners else "8 per leaf (as the reference)",
                        "evaluator": spec_note, "code": code,
-                       "setup": f"{args.preheat} untimed meshes before the warmup steps (clock ramp)"},
+                       "setup": f"{args.preheat} untimed meshes before the warmup steps (clock ramp)",
+                       "steps": ("meshes pipelined two deep on one handle (gsdf_hip_mesh_octree_start / _wait): mesh k+1's kernels are enqueued before mesh k "
+                                 "is waited for; all K started and finished inside the timed region") if mesh_pipeline else "one blocking mesh call per step"},
             "triangles_per_s": tris_all / dt,
             "triangles_per_step": tris_all / args.steps, "evals_per_step": evals_all / args.steps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -406,7 +406,7 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   p->rec.release(); p->hdr.release(); p->grp.release();
   p->flat_grid.release(); p->flat_bits.release(); p->flat_list.release(); p->dc_grid.release(); p->dc_dist.release(); p->dc_fv.release(); p->dc_nrm.release(); p->dc_edge.release();
   for (auto e : p->ev) if (e) (void)hipEventDestroy(e);
-  if (p->ev_clean) (void)hipEventDestroy(p->ev_clean);
+  for (auto e : p->ev_b) if (e) (void)hipEventDestroy(e);
   if (p->h_ctr) (void)hipHostFree(p->h_ctr);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;

@@ -16,88 +16,53 @@
 #include "abi_program.h"
 #include "host_math.h"
 
-extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_opts* opts_in, gsdf_mesh** out) {
-  if (!p || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
-  *out = nullptr;
-  if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
-  if (!(res > 0) || std::isnan(res) || std::isinf(res)) return fail(GSDF_ERR_RESOLUTION, "invalid renderer cube resolution");
-  gsdf_mesh_opts opts{};
-  opts.prune = 1; opts.shard_rank = 0; opts.shard_count = 1; opts.share_corners = 0;
-  if (opts_in) opts = *opts_in;
-  if (opts.shard_count < 1 || opts.shard_rank < 0 || opts.shard_rank >= opts.shard_count) return fail(GSDF_ERR_BAD_ARGUMENT, "bad shard rank/count");
-  if (opts.payload != GSDF_PAYLOAD_TRIANGLES && opts.payload != GSDF_PAYLOAD_RECORDS) return fail(GSDF_ERR_BAD_ARGUMENT, "bad payload kind");
-  const bool want_recs = opts.payload == GSDF_PAYLOAD_RECORDS;
-  if (want_recs && (opts.host_output || opts.share_corners || opts.max_tris || fused_leaf()))
-    return fail(GSDF_ERR_BAD_ARGUMENT, "payload = records goes with the default leaf phase only (no host_output, share_corners, max_tris, fused leaf kernel)");
-  HIP_TRY(hipSetDevice(p->device));
-  hipStream_t s = opts.stream ? (hipStream_t)opts.stream : p->stream;
+// ---- glrender.Octree on device ----------------------------------------------------------------------------------------------
+// One mesh = one chain of launches with no host round trip (each kernel reads its input count from the previous one's counter in
+// device memory), then one wait. The chain and the wait are two entry points -- gsdf_hip_mesh_octree_start / _wait -- so that a
+// caller with several meshes to make enqueues the next chain before it waits for the previous one: the ~30 us between the last
+// kernel of a mesh and the first kernel of the next (completion wake-up, the caller's own bookkeeping, launch latency) then pass
+// under a running chain instead of an idle GPU. Up to two chains per handle; they run back to back on the handle's stream, so the
+// workspace arenas are reused in stream order and only the pinned counter block and the timing events exist twice.
+namespace {
+constexpr size_t kCtrBytes = (sizeof(MeshCounters) + 255) & ~(size_t)255;  // the group sums follow the counters: one memset clears both
+const bool ctr_from_kernel = [] { const char* e = getenv("GSDF_HIP_CTR_FROM_KERNEL"); return !e || atoi(e) != 0; }();  // developer knobs (A/B timing)
+}  // namespace
 
-  // Octree.Reset (octreerenderer.go:71-128) + makeICube (:222-235)
-  float mn[3], mx[3];
-  scale_centered(p->prog.bb, 1.01f, mn, mx);
-  const float longAxis = fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));
-  const float l2 = gsdf::log2f32(longAxis / res);
-  const int levels = (int)std::ceil(l2) + 1;
-  if (levels <= 1) return fail(GSDF_ERR_RESOLUTION, "resolution not fine enough for marching cubes");
-  if (levels > 17) return fail(GSDF_ERR_RESOLUTION, "resolution too fine: more than 17 octree levels");
-  const float ox = mn[0], oy = mn[1], oz = mn[2];
-
-  gsdf_mesh* m = new (std::nothrow) gsdf_mesh();
-  if (!m) return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory");
-  m->device = p->device;
-  m->stream = s;
-  m->num_cu = p->num_cu;
-  m->st.levels = levels;
-  m->st.res = res;
-  m->st.origin[0] = ox; m->st.origin[1] = oy; m->st.origin[2] = oz;
-  auto bail = [&](int code) { gsdf_hip_mesh_destroy(m); return code; };
-#define HIP_TRYM(expr)                                                                                          \
-  do {                                                                                                          \
-    hipError_t _e = (expr);                                                                                     \
-    if (_e != hipSuccess) return bail(fail(GSDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
+#define HIP_TRYM(expr)                                                                                   \
+  do {                                                                                                   \
+    hipError_t _e = (expr);                                                                              \
+    if (_e != hipSuccess) return fail(GSDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
 
-  if (!p->h_ctr) HIP_TRYM(hipHostMalloc(&p->h_ctr, 4096, hipHostMallocDefault));
-  static_assert(sizeof(MeshCounters) <= 2048, "counters: first half of the pinned block (second half: DCCounters)");
-  for (auto& e : p->ev)
-    if (!e) HIP_TRYM(hipEventCreate(&e));
-  hipEvent_t ev0 = p->ev[0], ev1 = p->ev[1], ev2 = p->ev[2];
-
-  // ---- level-synchronous descent from the top cube to level lq = min(levels, 3). The whole chain
-  // (memset, one prune launch per level, the leaf kernel) is enqueued without a host round trip: each
-  // kernel reads its input count from the previous level's counter in device memory.
-  const int lq = levels < 3 ? levels : 3;
-  // multi-GPU: bricks of level ls are dealt to ranks by a hash of their coordinates (brick_owner).
-  const int ls = levels < lq + 2 ? levels : lq + 2;
-  const int prune_cols = p->prog.nslots + p->prog.lip_depth;  // interval mode: two points per lane + the interval stack
-  const size_t lds_prune = (size_t)(prune_cols > 0 ? prune_cols : 1) * 2 * BLOCK * sizeof(float) + PRUNE_STAGE * sizeof(Cube) + 64;
-  int pmask = opts.prune & ~GSDF_PRUNE_ASSUME_SDF;  // levels to test: 0 none, 1 all, else bit L = Level L
-  if ((opts.prune & GSDF_PRUNE_ASSUME_SDF) && pmask == 0) pmask = 1;
-  const int ptest = (opts.prune & GSDF_PRUNE_ASSUME_SDF) ? 2 : 1;
-  int lk, lw;
-  size_t lds_m;
-  p->leaf_config(&lk, &lw, &lds_m);
-  uint64_t qcap = p->q0.cap / sizeof(Cube);
-  {
-    // 1 M cubes (8 MB) per queue to start with; GSDF_HIP_QCAP_MIN lowers it so that tests can drive the
-    // overflow -> grow -> rerun path (the arenas only ever grow, so a handle that already meshed keeps its size)
-    const char* e = getenv("GSDF_HIP_QCAP_MIN");
-    const uint64_t qmin = e ? (uint64_t)strtoull(e, nullptr, 10) : ((uint64_t)1 << 20);
-    if (qcap < qmin) qcap = qmin;
-    if (qcap < 64) qcap = 64;
-  }
-  uint64_t want = opts.max_tris;
-  uint64_t want_rec_n = 0;  // records payload: exact record count after an overflow
-  MeshCounters& hc = *(MeshCounters*)p->h_ctr;
-  hc = MeshCounters{};
-  MeshCounters* d_ctr = nullptr;
-  constexpr size_t kCtrBytes = (sizeof(MeshCounters) + 255) & ~(size_t)255;  // the group sums follow the counters: one memset clears both
+struct gsdf_mesh_job {
+  gsdf_program* p = nullptr;
+  gsdf_mesh* m = nullptr;
+  gsdf_mesh_opts opts{};
+  float res = 0, ox = 0, oy = 0, oz = 0;
+  hipStream_t s = nullptr;
+  int levels = 0, lq = 0, ls = 0, prune_cols = 0, pmask = 0, ptest = 0, lk = 0, lw = 0;
+  size_t lds_prune = 0, lds_m = 0;
+  bool want_recs = false;
+  uint64_t qcap = 0, want = 0, want_rec_n = 0;  // capacities of the next attempt
+  // the attempt in flight
+  int attempt = 0, slot = 0;
   bool used_brick = false, two_kernel = false, ctr_on_host = false;
-  int chain_first = levels;  // levels <= chain_first were tested by prune_kernel (one launch per level), the ones above speculatively
-  static const bool ctr_from_kernel = [] { const char* e = getenv("GSDF_HIP_CTR_FROM_KERNEL"); return !e || atoi(e) != 0; }();  // developer knob (A/B timing)
-  float ms01 = 0, ms12 = 0, ms13 = 0;
-  for (int attempt = 0;; attempt++) {
+  int chain_first = 0;  // levels <= chain_first were tested by prune_kernel (one launch per level), the ones above speculatively
+  uint64_t nblk = 0;
+  size_t clear_bytes = 0;
+  MeshCounters* d_ctr = nullptr;
+  MeshCounters* hcp = nullptr;  // this job's pinned counter block
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, evr = nullptr, ev_done = nullptr;
+
+  int enqueue();            // one attempt: the whole chain onto the stream, nothing waited for
+  int finish(bool* again);  // waits for it; *again: a capacity was short -- enqueue() once more (nothing was dropped silently)
+  int stats();              // the mesh's statistics from the counters
+};
+
+int gsdf_mesh_job::enqueue() {
     ctr_on_host = false;
+    MeshCounters& hc = *hcp;
+    (void)hc;
     HIP_TRYM(p->q0.ensure(qcap * sizeof(Cube)));
     HIP_TRYM(p->q1.ensure(qcap * sizeof(Cube)));
     const uint64_t cap0 = p->q0.cap / sizeof(Cube), cap1 = p->q1.cap / sizeof(Cube);
@@ -118,7 +83,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
         // which PCIe takes well; the transfer then overlaps the kernel instead of following it
         void* hb = nullptr;
         size_t hcap = 0;
-        if (int rc = host_buf(&hb, &hcap, (size_t)need * 36)) return bail(rc);
+        if (int rc = host_buf(&hb, &hcap, (size_t)need * 36)) return rc;
         m->d_tris = (float*)hb;
         m->cap = hcap / 36;
         m->host_out = true;
@@ -141,7 +106,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     // blocks (1 GB); a mesh that needs more says so through its survivor count and is repeated once with the exact size.
     constexpr uint64_t kRecBlocks0 = (uint64_t)384 << 10;
     const uint64_t nblk_q = (lbound + 63) / 64;
-    uint64_t nblk = p->rec_blocks ? p->rec_blocks : kRecBlocks0;
+    nblk = p->rec_blocks ? p->rec_blocks : kRecBlocks0;
     if (nblk > nblk_q) nblk = nblk_q;
     const uint64_t ngrp = (nblk + MARCH_GROUP - 1) / MARCH_GROUP;
     bool want_two = !fused_leaf() && !(lq == 3 && lk == 4 && opts.share_corners);
@@ -152,27 +117,19 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
     }
     if (want_recs && (!want_two || p->grp.ensure(ngrp * sizeof(unsigned long long)) != hipSuccess)) {
       (void)hipGetLastError();
-      return bail(fail(GSDF_ERR_CAPACITY, "no device memory for the cut-leaf record arena (payload = records needs it)"));
+      return (fail(GSDF_ERR_CAPACITY, "no device memory for the cut-leaf record arena (payload = records needs it)"));
     }
-    const size_t clear_bytes = kCtrBytes + (want_two ? ngrp * sizeof(unsigned long long) : 0);
-    {
-      const void* before = p->ctr.p;
-      HIP_TRYM(p->ctr.ensure(clear_bytes));
-      if (p->ctr.p != before) p->ctr_clean = 0;
-    }
+    clear_bytes = kCtrBytes + (want_two ? ngrp * sizeof(unsigned long long) : 0);
+    HIP_TRYM(p->ctr.ensure(clear_bytes));
     d_ctr = (MeshCounters*)p->ctr.p;
-    // cleared on another stream: let that finish, do not rely on it. On a caller's stream of the same handle value: it may be a
-    // NEW stream that got a destroyed one's handle -- order this chain behind the clear's event (free if it is the same stream)
-    if (p->ctr_clean && p->ctr_clean_stream != s) p->ctr_settle();
-    else if (p->ctr_clean && s != p->stream && p->ev_clean) HIP_TRYM(hipStreamWaitEvent(s, p->ev_clean, 0));
-    if (p->ctr_clean < clear_bytes) HIP_TRYM(hipMemsetAsync(d_ctr, 0, clear_bytes, s));
-    p->ctr_clean = 0;  // dirty from here on
+    // the counters and the group sums are cleared by the chain's first kernel (prune_spec_kernel); one launch per level: a memset
+    static const bool use_spec = [] { const char* e = getenv("GSDF_HIP_PRUNE_SPEC"); return !e || atoi(e) != 0; }();
+    if (!use_spec) HIP_TRYM(hipMemsetAsync(d_ctr, 0, clear_bytes, s));
     HIP_TRYM(hipEventRecord(ev0, s));
     static const int prune_bpc = [] { const char* e = getenv("GSDF_HIP_PRUNE_BPC"); return e ? atoi(e) : 4; }();  // tuning knob
     // The first S levels (at most 7: 299,593 cubes) are centre-tested speculatively, every cube of the complete octree at once,
     // and resolved by a second launch (kernels.h: prune_spec_kernel / prune_resolve_kernel): two launches instead of a chain of
     // S dependent ones. GSDF_HIP_PRUNE_SPEC=0 keeps one launch per level (cross-check in the tests).
-    static const bool use_spec = [] { const char* e = getenv("GSDF_HIP_PRUNE_SPEC"); return !e || atoi(e) != 0; }();
     int first_level = levels;  // first level of the per-level chain
     chain_first = levels;
     unsigned* spec_part = nullptr;  // statistics rows of the speculative top, for the first per-level launch to add up
@@ -200,10 +157,11 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
       if (p->f_prune_spec) {
         HIP_TRYM(launch_fn(p->f_prune_spec, sgrid, BLOCK, lds_prune, s, (const uint32_t*)p->d_code, (int)levels, (unsigned)n_spec, (int)prune_cols,
                            (int)p->prog.nslots, ox, oy, oz, res, (unsigned)test_mask, (int)ptest, (int)shard_level, (unsigned)opts.shard_rank,
-                           (unsigned)opts.shard_count, (uint8_t*)p->spec_pass.p));
+                           (unsigned)opts.shard_count, (uint8_t*)p->spec_pass.p, (unsigned*)d_ctr, (unsigned)(clear_bytes / 4)));
       } else {
         hipLaunchKernelGGL(prune_spec_kernel, dim3(sgrid), dim3(BLOCK), lds_prune, s, p->d_code, levels, n_spec, prune_cols, p->prog.nslots, ox, oy,
-                           oz, res, test_mask, ptest, shard_level, (unsigned)opts.shard_rank, (unsigned)opts.shard_count, (uint8_t*)p->spec_pass.p);
+                           oz, res, test_mask, ptest, shard_level, (unsigned)opts.shard_rank, (unsigned)opts.shard_count, (uint8_t*)p->spec_pass.p,
+                           (unsigned*)d_ctr, (unsigned)(clear_bytes / 4));
       }
       HIP_TRYM(hipGetLastError());
       hipLaunchKernelGGL(prune_resolve_kernel, dim3((n_spec + SPEC_STAGE - 1) / SPEC_STAGE), dim3(BLOCK), 0, s, (const uint8_t*)p->spec_pass.p, levels, S,
@@ -273,7 +231,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
 #undef LAUNCH_LEAF_EVAL
 #undef LAUNCH_LEAF_EVAL_U
         HIP_TRYM(hipGetLastError());
-        HIP_TRYM(hipEventRecord(p->ev[3], s));
+        HIP_TRYM(hipEventRecord(ev3, s));
         two_kernel = true;
         if (want_recs) {
           // no marching here: the records are packed for the gather (scan_groups_kernel + pack_records_kernel), marching cubes
@@ -282,7 +240,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
           if (rec_cap > 2) rec_cap -= 2;
           hipLaunchKernelGGL(scan_groups_kernel, dim3(1), dim3(1024), 0, s, (const unsigned long long*)d_psum, (unsigned long long)nblk, lq, d_ctr,
                              (unsigned long long*)p->grp.p, m->d_recs, (unsigned long long)rec_cap,
-                             ctr_from_kernel ? (MeshCounters*)p->h_ctr : (MeshCounters*)nullptr);
+                             ctr_from_kernel ? hcp : (MeshCounters*)nullptr);
           HIP_TRYM(hipGetLastError());
           const uint64_t ngrp_q = (nblk_q + MARCH_GROUP - 1) / MARCH_GROUP;
           const uint64_t gmax = (uint64_t)p->num_cu * 8;
@@ -296,7 +254,7 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
         const size_t lds_march = (size_t)11 * BLOCK * 4 + 5 * BLOCK * 4 + 256 * 16 + (BLOCK + 1) * 4 + 8 * 4 + 8 + 14 * 8;
         hipLaunchKernelGGL(march_records_kernel, dim3(grid_for(nblk_q, p->num_cu, march_bpc)), dim3(BLOCK), lds_march, s, d_hdr, d_rec,
                            d_psum, (unsigned long long)nblk, lq, ox, oy, oz, res, m->d_tris, (uint64_t)tcap, d_ctr,
-                           ctr_from_kernel ? (MeshCounters*)p->h_ctr : (MeshCounters*)nullptr);
+                           ctr_from_kernel ? hcp : (MeshCounters*)nullptr);
         ctr_on_host = ctr_from_kernel;
         }
       } else if (lq == 3 && lk == 4 && opts.share_corners) {
@@ -322,50 +280,60 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
       HIP_TRYM(hipGetLastError());
     }
     HIP_TRYM(hipEventRecord(ev2, s));
-    if (!ctr_on_host) HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));  // (else march_records_kernel wrote them)
-    hipEvent_t evr = p->ev[4];
-    HIP_TRYM(hipEventRecord(evr, s));
-    static const bool clear_ahead = [] { const char* e = getenv("GSDF_HIP_CLEAR_AHEAD"); return !e || atoi(e) != 0; }();
-    if (clear_ahead) {  // for the next mesh (or the rerun below); not waited for
-      if (!p->ev_clean) HIP_TRYM(hipEventCreateWithFlags(&p->ev_clean, hipEventDisableTiming));
-      HIP_TRYM(hipMemsetAsync(d_ctr, 0, clear_bytes, s));
-      HIP_TRYM(hipEventRecord(p->ev_clean, s));
+    // the completion event: ev2 itself when the last kernel has handed the counters to the host (nothing sits between them)
+    if (!ctr_on_host) {
+      HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));
+      HIP_TRYM(hipEventRecord(evr, s));
     }
-    HIP_TRYM(hipEventSynchronize(evr));
-    if (clear_ahead) { p->ctr_clean = clear_bytes; p->ctr_clean_stream = s; }
+    ev_done = ctr_on_host ? ev2 : evr;
+    return GSDF_OK;
+}
+
+int gsdf_mesh_job::finish(bool* again) {
+    MeshCounters& hc = *hcp;
+    HIP_TRYM(hipEventSynchronize(ev_done));
     if (hc.q_overflow) {  // a cube queue was too small: double and redo (exact: nothing was dropped silently)
-      if (attempt >= 8) return bail(fail(GSDF_ERR_CAPACITY, "octree queue capacity exceeded"));
+      if (attempt >= 8) return (fail(GSDF_ERR_CAPACITY, "octree queue capacity exceeded"));
       qcap *= 4;
-      continue;
+      *again = true;
+      return GSDF_OK;
     }
     if (two_kernel) {  // more blocks than the record arena holds: the blocks beyond it were skipped -- repeat with room for all
       const uint64_t need = ((hc.n_level[lq] << (3 * (lq - 1))) + 63) / 64;
       if (need > nblk) {
-        if (attempt >= 8) return bail(fail(GSDF_ERR_CAPACITY, "cut-leaf record arena capacity exceeded"));
+        if (attempt >= 8) return (fail(GSDF_ERR_CAPACITY, "cut-leaf record arena capacity exceeded"));
         p->rec_blocks = need + need / 8 + 1024;
         two_kernel = false;
-        continue;
+        *again = true;
+      return GSDF_OK;
       }
     }
     if (hc.overflow && want_recs) {  // record payload too small: the scan knows the exact count
-      if (attempt >= 8) return bail(fail(GSDF_ERR_CAPACITY, "device record buffer capacity exceeded"));
+      if (attempt >= 8) return (fail(GSDF_ERR_CAPACITY, "device record buffer capacity exceeded"));
       pool_give(p->device, (float*)m->d_recs, m->recs_cap36);
       m->d_recs = nullptr; m->recs_cap36 = 0;
       want_rec_n = hc.n_cut + hc.n_cut / 16 + 1024;
-      continue;
+      *again = true;
+      return GSDF_OK;
     }
     if (hc.overflow) {  // triangle buffer too small: the kernel kept counting, so the exact size is known
-      if (opts.max_tris) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
-      if (attempt >= 8) return bail(fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
+      if (opts.max_tris) return (fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
+      if (attempt >= 8) return (fail(GSDF_ERR_CAPACITY, "device triangle buffer capacity exceeded"));
       release_tris(m);
       want = hc.n_tris + hc.n_tris / 16 + 1024;
-      continue;
+      *again = true;
+      return GSDF_OK;
     }
-    break;
-  }
+    *again = false;
+    return GSDF_OK;
+}
+
+int gsdf_mesh_job::stats() {
+  MeshCounters& hc = *hcp;
+  float ms01 = 0, ms12 = 0, ms13 = 0;
   HIP_TRYM(hipEventElapsedTime(&ms01, ev0, ev1));
   HIP_TRYM(hipEventElapsedTime(&ms12, ev1, ev2));
-  if (two_kernel) HIP_TRYM(hipEventElapsedTime(&ms13, ev1, p->ev[3]));  // the evaluating kernel alone
+  if (two_kernel) HIP_TRYM(hipEventElapsedTime(&ms13, ev1, ev3));  // the evaluating kernel alone
   uint64_t evals_prune = 0, pruned = 0;
   for (int level = levels; level >= lq; level--) {
     evals_prune += hc.n_items[level];
@@ -393,9 +361,125 @@ extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_
   p->evals += m->st.evals;
   p->last_tris = hc.n_tris;
   if (want_recs) { m->payload = GSDF_PAYLOAD_RECORDS; m->n_recs = hc.n_cut; p->last_recs = hc.n_cut; }
-  *out = m;
   return GSDF_OK;
+}
 #undef HIP_TRYM
+
+static void job_release(gsdf_mesh_job* j) {
+  if (!j) return;
+  if (j->p) j->p->job_busy[j->slot] = false;
+  if (j->m) gsdf_hip_mesh_destroy(j->m);
+  delete j;
+}
+
+extern "C" int gsdf_hip_mesh_octree_start(gsdf_program* p, float res, const gsdf_mesh_opts* opts_in, gsdf_mesh_job** out) {
+  if (!p || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
+  if (!(res > 0) || std::isnan(res) || std::isinf(res)) return fail(GSDF_ERR_RESOLUTION, "invalid renderer cube resolution");
+  gsdf_mesh_opts opts{};
+  opts.prune = 1; opts.shard_rank = 0; opts.shard_count = 1; opts.share_corners = 0;
+  if (opts_in) opts = *opts_in;
+  if (opts.shard_count < 1 || opts.shard_rank < 0 || opts.shard_rank >= opts.shard_count) return fail(GSDF_ERR_BAD_ARGUMENT, "bad shard rank/count");
+  if (opts.payload != GSDF_PAYLOAD_TRIANGLES && opts.payload != GSDF_PAYLOAD_RECORDS) return fail(GSDF_ERR_BAD_ARGUMENT, "bad payload kind");
+  const bool want_recs = opts.payload == GSDF_PAYLOAD_RECORDS;
+  if (want_recs && (opts.host_output || opts.share_corners || opts.max_tris || fused_leaf()))
+    return fail(GSDF_ERR_BAD_ARGUMENT, "payload = records goes with the default leaf phase only (no host_output, share_corners, max_tris, fused leaf kernel)");
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t s = opts.stream ? (hipStream_t)opts.stream : p->stream;
+
+  // Octree.Reset (octreerenderer.go:71-128) + makeICube (:222-235)
+  float mn[3], mx[3];
+  scale_centered(p->prog.bb, 1.01f, mn, mx);
+  const float longAxis = fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));
+  const float l2 = gsdf::log2f32(longAxis / res);
+  const int levels = (int)std::ceil(l2) + 1;
+  if (levels <= 1) return fail(GSDF_ERR_RESOLUTION, "resolution not fine enough for marching cubes");
+  if (levels > 17) return fail(GSDF_ERR_RESOLUTION, "resolution too fine: more than 17 octree levels");
+
+  int slot = -1;
+  for (int k = 0; k < gsdf_program::kJobs; k++) if (!p->job_busy[k]) { slot = k; break; }
+  if (slot < 0) return fail(GSDF_ERR_BAD_ARGUMENT, "two meshes of this program are in flight already: wait for one (gsdf_hip_mesh_octree_wait)");
+  // a second chain may follow the first only on the same stream: the workspace is shared and reused in stream order
+  for (int k = 0; k < gsdf_program::kJobs; k++)
+    if (p->job_busy[k] && p->job_stream[k] != s) return fail(GSDF_ERR_BAD_ARGUMENT, "a mesh of this program is in flight on another stream");
+  gsdf_mesh_job* j = new (std::nothrow) gsdf_mesh_job();
+  gsdf_mesh* m = new (std::nothrow) gsdf_mesh();
+  if (!j || !m) { delete j; delete m; return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory"); }
+  j->p = p; j->m = m; j->opts = opts; j->res = res; j->s = s; j->slot = slot; j->levels = levels; j->want_recs = want_recs;
+  j->ox = mn[0]; j->oy = mn[1]; j->oz = mn[2];
+  p->job_busy[slot] = true;
+  p->job_stream[slot] = s;
+  m->device = p->device;
+  m->stream = s;
+  m->num_cu = p->num_cu;
+  m->st.levels = levels;
+  m->st.res = res;
+  m->st.origin[0] = j->ox; m->st.origin[1] = j->oy; m->st.origin[2] = j->oz;
+  auto bail = [&](int code) { job_release(j); return code; };
+  static_assert(sizeof(MeshCounters) <= 2048, "counters: a 2 KB slot of the pinned block each (slot 1: DCCounters of dual contouring)");
+  if (!p->h_ctr && hipHostMalloc(&p->h_ctr, 8192, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return bail(fail(GSDF_ERR_HIP, "hipHostMalloc of the counter block failed")); }
+  j->hcp = (MeshCounters*)((char*)p->h_ctr + (slot == 0 ? 0 : 4096));
+  for (auto& e : p->ev)
+    if (!e && hipEventCreate(&e) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipEventCreate failed"));
+  for (auto& e : p->ev_b)
+    if (slot == 1 && !e && hipEventCreate(&e) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipEventCreate failed"));
+  hipEvent_t* evs = slot == 0 ? p->ev : p->ev_b;
+  j->ev0 = evs[0]; j->ev1 = evs[1]; j->ev2 = evs[2]; j->ev3 = evs[3]; j->evr = evs[4];
+
+  // ---- level-synchronous descent from the top cube to level lq = min(levels, 3). The whole chain
+  // (memset, one prune launch per level, the leaf kernel) is enqueued without a host round trip: each
+  // kernel reads its input count from the previous level's counter in device memory.
+  j->lq = levels < 3 ? levels : 3;
+  // multi-GPU: bricks of level ls are dealt to ranks by a hash of their coordinates (brick_owner).
+  j->ls = levels < j->lq + 2 ? levels : j->lq + 2;
+  j->prune_cols = p->prog.nslots + p->prog.lip_depth;  // interval mode: two points per lane + the interval stack
+  j->lds_prune = (size_t)(j->prune_cols > 0 ? j->prune_cols : 1) * 2 * BLOCK * sizeof(float) + PRUNE_STAGE * sizeof(Cube) + 64;
+  j->pmask = opts.prune & ~GSDF_PRUNE_ASSUME_SDF;  // levels to test: 0 none, 1 all, else bit L = Level L
+  if ((opts.prune & GSDF_PRUNE_ASSUME_SDF) && j->pmask == 0) j->pmask = 1;
+  j->ptest = (opts.prune & GSDF_PRUNE_ASSUME_SDF) ? 2 : 1;
+  p->leaf_config(&j->lk, &j->lw, &j->lds_m);
+  j->qcap = p->q0.cap / sizeof(Cube);
+  {
+    // 1 M cubes (8 MB) per queue to start with; GSDF_HIP_QCAP_MIN lowers it so that tests can drive the
+    // overflow -> grow -> rerun path (the arenas only ever grow, so a handle that already meshed keeps its size)
+    const char* e = getenv("GSDF_HIP_QCAP_MIN");
+    const uint64_t qmin = e ? (uint64_t)strtoull(e, nullptr, 10) : ((uint64_t)1 << 20);
+    if (j->qcap < qmin) j->qcap = qmin;
+    if (j->qcap < 64) j->qcap = 64;
+  }
+  j->want = opts.max_tris;
+  *j->hcp = MeshCounters{};
+  j->chain_first = levels;
+  if (int rc = j->enqueue()) return bail(rc);
+  *out = j;
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_hip_mesh_octree_wait(gsdf_mesh_job* j, gsdf_mesh** out) {
+  if (!j || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  (void)hipSetDevice(j->p->device);
+  for (;;) {
+    bool again = false;
+    if (int rc = j->finish(&again)) { job_release(j); return rc; }
+    if (!again) break;
+    j->attempt++;
+    if (int rc = j->enqueue()) { job_release(j); return rc; }
+  }
+  if (int rc = j->stats()) { job_release(j); return rc; }
+  *out = j->m;
+  j->m = nullptr;
+  job_release(j);
+  return GSDF_OK;
+}
+
+extern "C" int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_opts* opts_in, gsdf_mesh** out) {
+  if (!out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  gsdf_mesh_job* j = nullptr;
+  if (int rc = gsdf_hip_mesh_octree_start(p, res, opts_in, &j)) return rc;
+  return gsdf_hip_mesh_octree_wait(j, out);
 }
 
 // ---- packed cut-leaf records -> triangles (kernels_octree.h: march_dense_kernel) ------------------------------------------
@@ -466,6 +550,7 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
   if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
   if (!(res > 0) || std::isnan(res) || std::isinf(res)) return fail(GSDF_ERR_RESOLUTION, "invalid renderer cube resolution");
   if (shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return fail(GSDF_ERR_BAD_ARGUMENT, "bad shard rank/count");
+  if (p->mesh_in_flight()) return fail(GSDF_ERR_BAD_ARGUMENT, "an octree mesh of this program is in flight: wait for it first (shared workspace)");
   HIP_TRY(hipSetDevice(p->device));
   hipStream_t s = stream ? (hipStream_t)stream : p->stream;
   // Reset (dual_contour.go:26-41): bounds shifted by -res/2, makeICube
@@ -507,7 +592,6 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
   // hipMalloc/hipFree pair of that size per mesh cost more wall time than the whole device pass.
   gsdf_program::Arena &grid = p->dc_grid, &d2 = p->dc_dist, &f2 = p->dc_fv, &n2 = p->dc_nrm, &e2 = p->dc_edge;
   HIP_TRYM(grid.ensure(ncell * sizeof(int)));
-  p->ctr_settle();  // (the octree mesher's clear-ahead)
   HIP_TRYM(p->ctr.ensure(sizeof(MeshCounters) > sizeof(DCCounters) ? sizeof(MeshCounters) : sizeof(DCCounters)));
   DCCounters* d_ctr = (DCCounters*)p->ctr.p;
   const int lk = p->batch_k();
@@ -620,6 +704,7 @@ extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, in
   if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
   if (!(res > 0) || std::isnan(res) || std::isinf(res)) return fail(GSDF_ERR_RESOLUTION, "invalid renderer cube resolution");
   if (shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return fail(GSDF_ERR_BAD_ARGUMENT, "bad shard rank/count");
+  if (p->mesh_in_flight()) return fail(GSDF_ERR_BAD_ARGUMENT, "an octree mesh of this program is in flight: wait for it first (shared workspace)");
   HIP_TRY(hipSetDevice(p->device));
   hipStream_t s = stream ? (hipStream_t)stream : p->stream;
   // Reset (:36-80)
@@ -654,7 +739,6 @@ extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, in
   if (ncz == 0) { *out = m; return GSDF_OK; }  // more ranks than cube planes: nothing for this one
   for (auto& e : p->ev)
     if (!e) HIP_TRYM(hipEventCreate(&e));
-  p->ctr_settle();  // (the octree mesher's clear-ahead)
   HIP_TRYM(p->ctr.ensure(sizeof(MeshCounters)));
   MeshCounters* d_ctr = (MeshCounters*)p->ctr.p;
   {

@@ -50,16 +50,11 @@ struct gsdf_program {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
   } q0, q1, ctr, spec_pass, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, flat_grid, flat_bits, flat_list, rec, hdr, grp;  // flat_bits: sign and near-surface bit planes of the flat renderer's lattice (flat_grid_kernel -> flat_cut_scan_kernel), flat_list: the cut cubes (-> flat_march_list_kernel)  // rec / hdr: cut-leaf records and block headers of the two-kernel leaf phase (the group sums follow the counters in ctr)  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  // The octree mesher leaves its counters cleared for the NEXT mesh (a memset enqueued behind the readback, executed while
-  // the host is between calls) instead of clearing them at the head of its own chain, where the memset and the gap behind it
-  // cost ~10 us of every mesh: ctr_clean = bytes of `ctr` known to be zero for work enqueued on ctr_clean_stream (0: unknown).
-  size_t ctr_clean = 0;
-  hipStream_t ctr_clean_stream = nullptr;  // compared only, never used: it may be a caller's stream, destroyed since
-  hipEvent_t ev_clean = nullptr;           // recorded behind the clear-ahead memset: what later work waits on
-  void ctr_settle() {  // before anyone else writes `ctr`: the pending clear must have run
-    if (ctr_clean && ev_clean && hipEventSynchronize(ev_clean) != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }
-    ctr_clean = 0;
-  }
+  hipEvent_t ev_b[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // second set: the octree mesher has up to two chains in flight (gsdf_hip_mesh_octree_start)
+  static constexpr int kJobs = 2;
+  bool job_busy[kJobs] = {false, false};
+  hipStream_t job_stream[kJobs] = {nullptr, nullptr};
+  bool mesh_in_flight() const { return job_busy[0] || job_busy[1]; }
   void* h_ctr = nullptr;  // pinned host copy of the device counters (a pageable destination makes the D2H copy a staged, blocking one)
   uint64_t last_tris = 0;  // triangle count of the previous mesh on this handle: sizes the next output buffer
   uint64_t last_recs = 0;  // cut leaves of the previous mesh with payload = records: sizes the next payload buffer

@@ -166,11 +166,14 @@ __device__ __forceinline__ Cube spec_cube(unsigned j, unsigned k) {
 __global__ void __launch_bounds__(BLOCK) prune_spec_kernel(const uint32_t* __restrict__ code_g, int top, unsigned n_spec, int ncols,
                                                            int lip_base, float ox, float oy, float oz, float res, unsigned test_mask,
                                                            int ptest, int shard_level, unsigned shard_rank, unsigned shard_count,
-                                                           uint8_t* __restrict__ pass) {
+                                                           uint8_t* __restrict__ pass, unsigned* __restrict__ clear_p, unsigned clear_words) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
   (void)ncols;
   const unsigned step = gridDim.x * BLOCK;
+  // This is the chain's first kernel and touches neither the counters nor the group sums: it clears them for the kernels behind
+  // it (a memset in front of the chain, or behind the previous one, is a launch of its own: ~5 us of every mesh).
+  for (unsigned k = blockIdx.x * BLOCK + threadIdx.x; k < clear_words; k += step) clear_p[k] = 0u;
   for (unsigned base = blockIdx.x * BLOCK; base < n_spec; base += step) {  // block-uniform trip count
     const unsigned i = base + threadIdx.x;
     const bool valid = i < n_spec;

@@ -25,7 +25,7 @@ SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "g
            "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3", "gsdf_hip_image2",
            "gsdf_hip_mesh_octree", "gsdf_hip_mesh_dualcontour", "gsdf_hip_mesh_flat", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
            "gsdf_hip_mesh_stl", "gsdf_hip_mesh_host_tris", "gsdf_hip_mesh_host_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner", "gsdf_hip_slab_range",
-           "gsdf_hip_mesh_payload", "gsdf_hip_mesh_march", "gsdf_hip_comm_transport", "gsdf_hip_gather_plan"]
+           "gsdf_hip_mesh_payload", "gsdf_hip_mesh_march", "gsdf_hip_mesh_octree_start", "gsdf_hip_mesh_octree_wait", "gsdf_hip_comm_transport", "gsdf_hip_gather_plan"]
 
 
 PRUNE_ASSUME_SDF = 1 << 30  # gsdf_hip.h: GSDF_PRUNE_ASSUME_SDF
@@ -129,6 +129,8 @@ def lib():
         L.gsdf_hip_normals3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]
         L.gsdf_hip_image2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.gsdf_hip_mesh_octree.argtypes = [C.c_void_p, C.c_float, C.POINTER(MeshOpts), C.POINTER(C.c_void_p)]
+        L.gsdf_hip_mesh_octree_start.argtypes = [C.c_void_p, C.c_float, C.POINTER(MeshOpts), C.POINTER(C.c_void_p)]
+        L.gsdf_hip_mesh_octree_wait.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.gsdf_hip_mesh_dualcontour.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.gsdf_hip_mesh_flat.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.gsdf_hip_mesh_stats_get.argtypes = [C.c_void_p, C.POINTER(MeshStats)]
@@ -345,11 +347,28 @@ class OctreeHIP:
         self.sdf = sdf
         m = C.c_void_p()
         _check(lib().gsdf_hip_mesh_octree(sdf._h, np.float32(res), C.byref(self._opts), C.byref(m)))
+        self._adopt(m)
+
+    def _adopt(self, m):
         self._mesh = m
         self._cursor = 0
         st = MeshStats()
         _check(lib().gsdf_hip_mesh_stats_get(m, C.byref(st)))
         self.stats = st
+
+    @classmethod
+    def start(cls, sdf, res, **kw):
+        """gsdf_hip_mesh_octree_start: enqueue the mesh and return a PendingMesh; .wait() gives the OctreeHIP. Up to two per
+        program in flight -- start the next one before waiting for the previous one and the GPU never idles between meshes."""
+        self = cls.__new__(cls)
+        self.sdf, self._mesh, self._cursor = sdf, None, 0
+        kw.setdefault("prune", True)
+        self._opts = MeshOpts(int(kw["prune"]) | (PRUNE_ASSUME_SDF if kw.get("assume_sdf") else 0), kw.get("shard_rank", 0), kw.get("shard_count", 1),
+                              kw.get("max_tris", 0), kw.get("stream"), int(kw.get("share_corners", False)), int(kw.get("host_output", False)),
+                              int(kw.get("payload", PAYLOAD_TRIANGLES)), 0)
+        j = C.c_void_p()
+        _check(lib().gsdf_hip_mesh_octree_start(sdf._h, np.float32(res), C.byref(self._opts), C.byref(j)))
+        return PendingMesh(self, j)
 
     def _free(self):
         if getattr(self, "_mesh", None):
@@ -430,6 +449,30 @@ class OctreeHIP:
         p, ln = C.c_void_p(), C.c_size_t()
         _check(lib().gsdf_hip_mesh_host_stl(self._mesh, C.byref(p), C.byref(ln)))
         return self._view(p.value, ln.value, np.uint8)
+
+
+class PendingMesh:
+    """A mesh whose chain of kernels is enqueued (OctreeHIP.start): wait() returns the finished OctreeHIP."""
+
+    def __init__(self, oc, job):
+        self._oc, self._j = oc, job
+
+    def wait(self):
+        j, self._j = self._j, None
+        m = C.c_void_p()
+        _check(lib().gsdf_hip_mesh_octree_wait(j, C.byref(m)))
+        self._oc._adopt(m)
+        return self._oc
+
+    def __del__(self):
+        try:
+            if self._j:
+                m = C.c_void_p()
+                if lib().gsdf_hip_mesh_octree_wait(self._j, C.byref(m)) == 0 and m.value:
+                    lib().gsdf_hip_mesh_destroy(m)
+                self._j = None
+        except Exception:
+            pass
 
 
 class CommHIP:

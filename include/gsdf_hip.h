@@ -217,6 +217,15 @@ GSDF_ABI_ASSERT(offsetof(gsdf_mesh_stats, evals_prune) == 96 && offsetof(gsdf_me
 GSDF_ABI_ASSERT(GSDF_ERR_EMPTY_BUFFERS == -1 && GSDF_ERR_LENGTH_MISMATCH == -2 && GSDF_ERR_SHORT_BUFFER == -9 && GSDF_ERR_CAPACITY == -10, "status codes are part of the ABI");
 
 int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_opts* opts, gsdf_mesh** out);
+/* The same in two halves, for a caller with several meshes to make (a part at several resolutions, a batch of parts on one
+ * program): _start enqueues the whole chain of kernels and returns; _wait blocks until that mesh is complete. Up to two meshes
+ * of a program may be in flight (on the same stream: they run back to back and share the workspace in stream order) -- the next
+ * chain is then enqueued while the previous one runs, and the ~30 us a blocking call spends between a mesh's last kernel and the
+ * next mesh's first (completion wake-up, the caller's bookkeeping, launch latency) pass under a busy GPU. gsdf_hip_mesh_octree is
+ * _start followed by _wait. No other mesher call on the program while a job is in flight. */
+typedef struct gsdf_mesh_job gsdf_mesh_job;
+int gsdf_hip_mesh_octree_start(gsdf_program* p, float res, const gsdf_mesh_opts* opts, gsdf_mesh_job** job);
+int gsdf_hip_mesh_octree_wait(gsdf_mesh_job* job, gsdf_mesh** out);
 /* Dual contouring (least-squares vertex placement; chiseled = DualContourLeastSquares.Chiseled). The result is a
  * gsdf_mesh like the octree mesher's (stats: leaf_cubes = kept cubes, active_leaves = active edges). Multi-GPU: rank
  * shard_rank of shard_count emits the quads of its z-slab of the lattice (one-cube halo recomputed, nothing exchanged). */

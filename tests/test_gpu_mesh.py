@@ -600,3 +600,44 @@ def test_example_render_stl(gpu, tmp_path):
     rec = np.frombuffer(blob, np.uint8, offset=84).reshape(-1, 50)
     tris = np.ascontiguousarray(rec[:, 12:48]).view(np.float32).reshape(-1, 9)
     assert (_sorted(tris).view(np.uint32) == _sorted(ref.tris).view(np.uint32)).all()
+
+
+def test_octree_start_wait_two_in_flight(gpu):
+    """gsdf_hip_mesh_octree_start / _wait: the next mesh's chain of kernels is enqueued while the previous mesh runs (two per
+    program, back to back on its stream, one shared workspace). Same meshes as the blocking call, at mixed resolutions and
+    payloads, through capacity reruns (first meshes of a handle), interpreter and specialised; a third job and the other meshers
+    are refused while jobs are in flight."""
+    b = Builder()
+    sh = b.Scene("npt-flange")
+    for spec in (False, True):
+        sdf = gpu.SDF3HIP(sh)
+        if spec:
+            sdf.specialize()
+        rds = [90, 260, 140, 260, 400, 90]
+        ress = [np.float32(float(sh.Diagonal()) / rd) for rd in rds]
+        want = [gpu.OctreeHIP(gpu.SDF3HIP(sh), r) for r in ress[:3]]
+        want = {float(r): (w.n_tris(), w.TotalPruned(), int(w.stats.evals), _digest(w.RenderAll())) for r, w in zip(ress[:3], want)}
+        want[float(ress[4])] = (423852, None, None, None)
+        pend, got = None, []
+        for k, r in enumerate(ress):
+            nxt = gpu.OctreeHIP.start(sdf, r, payload=gpu.PAYLOAD_RECORDS if k == 3 else gpu.PAYLOAD_TRIANGLES)
+            if pend is not None:
+                if k == 2:                                            # two in flight: a third is refused, so are the other meshers
+                    with pytest.raises(gpu.HipError):
+                        gpu.OctreeHIP.start(sdf, r)
+                    with pytest.raises(gpu.HipError):
+                        gpu.FlatHIP(sdf, r)
+                    with pytest.raises(gpu.HipError):
+                        gpu.DualContourHIP(sdf, r)
+                got.append(pend.wait())
+            pend = nxt
+        got.append(pend.wait())
+        assert got[3].payload()[0] == gpu.PAYLOAD_RECORDS
+        got[3].march()
+        for r, oc in zip(ress, got):
+            n, pr, ev, dg = want[float(r)]
+            assert oc.n_tris() == n
+            if dg is not None:
+                assert oc.TotalPruned() == pr and int(oc.stats.evals) == ev and _digest(oc.RenderAll()) == dg
+        gpu.OctreeHIP.start(sdf, ress[0])                             # dropped without wait(): completed and released by its finaliser
+        assert gpu.FlatHIP(sdf, ress[0]).n_tris() > 0                 # ... after which the handle is free again
