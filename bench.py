@@ -476,43 +476,48 @@ def main():
 
     # Setup, untimed: bring the GPU out of its idle clock state before the W warmup steps. The first ~20 meshes after
     # start-up run 5 % slower (1.70 vs 1.61 ms leaf kernel), and with the contract's small W they would be the ones timed.
-    for _ in range(args.preheat):
-        step()
-    for _ in range(args.warmup):
-        step()
+    mesh_pipeline = (comm is None and not torch_gather and args.renderer == "octree" and not args.no_mesh_pipeline)
+
+    def run_meshes(n, account=None):
+        """n meshes, every one started and finished inside this call. Pipelined (N = 1): mesh k + 1 is started -- its chain of kernels
+        enqueued, on the handle's other workspace and stream -- before mesh k is waited for."""
+        last = None
+        if not mesh_pipeline:
+            for _ in range(n):
+                last = step()
+                if account:
+                    account(last[0])
+            return last
+        pend = hip.OctreeHIP.start(sdf, res, share_corners=args.share_corners) if n > 0 else None
+        for k in range(n):
+            nxt = hip.OctreeHIP.start(sdf, res, share_corners=args.share_corners) if k + 1 < n else None
+            last = (pend.wait(), None)
+            if account:
+                account(last[0])
+            pend = nxt
+        return last
+
+    run_meshes(args.preheat)
+    run_meshes(args.warmup)
     finish()
     for k in gstat:
         gstat[k] = 0
+    acc = {"evals": 0, "tris": 0, "march_ms": 0.0, "march_evals": 0.0, "march_tris": 0.0, "emit_ms": 0.0, "cut": 0.0}
+
+    def account(oc):
+        st = oc.stats
+        acc["evals"] += st.evals
+        acc["tris"] += st.n_tris
+        acc["march_ms"] += st.ms_march
+        acc["march_evals"] += st.evals_leaf
+        acc["march_tris"] += st.n_tris
+        acc["emit_ms"] += st.ms_emit
+        acc["cut"] += st.cut_leaves
+
     barrier()
     t0 = time.perf_counter()
-    evals = tris = 0
-    march_ms = march_evals = march_tris = emit_ms = cut = 0.0
-    last = None
-    mesh_pipeline = (comm is None and not torch_gather and args.renderer == "octree" and not args.no_mesh_pipeline)
-    started = [None]
-
-    def next_mesh(k):
-        """(mesh, gathered) number k of the timed loop. Pipelined: mesh k + 1 is started (its kernels enqueued) before mesh k is
-        waited for -- all K are started and finished between the two barriers."""
-        if not mesh_pipeline:
-            return step()
-        if started[0] is None:
-            started[0] = hip.OctreeHIP.start(sdf, res, share_corners=args.share_corners)
-        cur = started[0]
-        started[0] = hip.OctreeHIP.start(sdf, res, share_corners=args.share_corners) if k + 1 < args.steps else None
-        return cur.wait(), None
-
-    for k in range(args.steps):
-        oc, g = next_mesh(k)
-        st = oc.stats
-        evals += st.evals
-        tris += st.n_tris
-        march_ms += st.ms_march
-        march_evals += st.evals_leaf
-        march_tris += st.n_tris
-        emit_ms += st.ms_emit
-        cut += st.cut_leaves
-        last = (oc, g)
+    last = run_meshes(args.steps, account)
+    evals, tris, march_ms, march_evals, march_tris, emit_ms, cut = (acc[k] for k in ("evals", "tris", "march_ms", "march_evals", "march_tris", "emit_ms", "cut"))
     gl = finish()  # the last mesh's gather belongs to the timed region too
     if gl is not None:
         last = (last[0], gl)
@@ -586,6 +591,16 @@ def main():
                 "note": "marching cubes over the cut-leaf records: 40 B read per record + 36 B written per triangle"},
             "phase_ms_rank0": {"prune": st.ms_prune, "leaf": st.ms_leaf, "eval_kernel": st.ms_march, "march_kernel": st.ms_emit, "total_device": st.ms_total},
         }
+        if mesh_pipeline and not dc:
+            # The two chains in flight share the CUs: the evaluating kernel's event-to-event time above includes what the other
+            # chain's centre tests and marching kernel took from it. Its duration ALONE, from blocking meshes after the timed loop:
+            alone = [hip.OctreeHIP(sdf, res, share_corners=args.share_corners).stats for _ in range(8)][2:]
+            a_ms = sum(a.ms_march for a in alone) / len(alone)
+            a_gbs = k_bytes / (a_ms * 1e-3) / 1e9
+            out["roofline"]["alone"] = {"kernel_ms": a_ms, "achieved": a_gbs, "frac": a_gbs / HBM_PEAK_GBS, "ms_per_mesh_device": sum(a.ms_total for a in alone) / len(alone),
+                                        "note": "one blocking mesh at a time (measured after the timed loop): the kernel with the GPU to itself"}
+            out["roofline"]["note"] += ("; the timed loop keeps two meshes in flight on two streams, so kernel_ms / achieved / frac above are the kernel's "
+                                        "duration while it shares the CUs with the other mesh's kernels -- 'alone' is the same kernel by itself")
         if comm is not None and gstat["n"]:
             n = gstat["n"]
             g_ms = (gstat["ms_counts"] + gstat["ms_payload"]) / n

@@ -45,7 +45,7 @@ struct gsdf_mesh_job {
   bool want_recs = false;
   uint64_t qcap = 0, want = 0, want_rec_n = 0;  // capacities of the next attempt
   // the attempt in flight
-  int attempt = 0, slot = 0;
+  int attempt = 0, slot;
   bool used_brick = false, two_kernel = false, ctr_on_host = false;
   int chain_first = 0;  // levels <= chain_first were tested by prune_kernel (one launch per level), the ones above speculatively
   uint64_t nblk = 0;
@@ -53,6 +53,13 @@ struct gsdf_mesh_job {
   MeshCounters* d_ctr = nullptr;
   MeshCounters* hcp = nullptr;  // this job's pinned counter block
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, evr = nullptr, ev_done = nullptr;
+  // this job's workspace: the handle has two, so that two chains in flight do not share one (they run on two streams, the
+  // latency-bound top and tail of one under the leaf kernel of the other)
+  struct Ws { gsdf_program::Arena &q0, &q1, &ctr, &spec_pass, &rec, &hdr, &grp; };
+  Ws w;
+  explicit gsdf_mesh_job(gsdf_program* pp, int sl)
+      : p(pp), slot(sl), w(sl == 0 ? Ws{pp->q0, pp->q1, pp->ctr, pp->spec_pass, pp->rec, pp->hdr, pp->grp}
+                                   : Ws{pp->b_q0, pp->b_q1, pp->b_ctr, pp->b_spec_pass, pp->b_rec, pp->b_hdr, pp->b_grp}) {}
 
   int enqueue();            // one attempt: the whole chain onto the stream, nothing waited for
   int finish(bool* again);  // waits for it; *again: a capacity was short -- enqueue() once more (nothing was dropped silently)
@@ -63,10 +70,10 @@ int gsdf_mesh_job::enqueue() {
     ctr_on_host = false;
     MeshCounters& hc = *hcp;
     (void)hc;
-    HIP_TRYM(p->q0.ensure(qcap * sizeof(Cube)));
-    HIP_TRYM(p->q1.ensure(qcap * sizeof(Cube)));
-    const uint64_t cap0 = p->q0.cap / sizeof(Cube), cap1 = p->q1.cap / sizeof(Cube);
-    gsdf_program::Arena* q[2] = {&p->q0, &p->q1};
+    HIP_TRYM(w.q0.ensure(qcap * sizeof(Cube)));
+    HIP_TRYM(w.q1.ensure(qcap * sizeof(Cube)));
+    const uint64_t cap0 = w.q0.cap / sizeof(Cube), cap1 = w.q1.cap / sizeof(Cube);
+    gsdf_program::Arena* q[2] = {&w.q0, &w.q1};
     const uint64_t capq[2] = {cap0, cap1};
     // records payload: room for the packed records instead (sized like the triangles: previous mesh, else a guess + one exact rerun)
     if (want_recs && !m->d_recs) {
@@ -110,18 +117,18 @@ int gsdf_mesh_job::enqueue() {
     if (nblk > nblk_q) nblk = nblk_q;
     const uint64_t ngrp = (nblk + MARCH_GROUP - 1) / MARCH_GROUP;
     bool want_two = !fused_leaf() && !(lq == 3 && lk == 4 && opts.share_corners);
-    if (want_two && (p->hdr.ensure(nblk * sizeof(uint32_t)) != hipSuccess || p->rec.ensure(nblk * (size_t)REC_BLOCK * sizeof(uint32_t)) != hipSuccess)) {
+    if (want_two && (w.hdr.ensure(nblk * sizeof(uint32_t)) != hipSuccess || w.rec.ensure(nblk * (size_t)REC_BLOCK * sizeof(uint32_t)) != hipSuccess)) {
       (void)hipGetLastError();  // no room for the records: the fused kernel needs none
-      p->hdr.release(); p->rec.release();
+      w.hdr.release(); w.rec.release();
       want_two = false;
     }
-    if (want_recs && (!want_two || p->grp.ensure(ngrp * sizeof(unsigned long long)) != hipSuccess)) {
+    if (want_recs && (!want_two || w.grp.ensure(ngrp * sizeof(unsigned long long)) != hipSuccess)) {
       (void)hipGetLastError();
       return (fail(GSDF_ERR_CAPACITY, "no device memory for the cut-leaf record arena (payload = records needs it)"));
     }
     clear_bytes = kCtrBytes + (want_two ? ngrp * sizeof(unsigned long long) : 0);
-    HIP_TRYM(p->ctr.ensure(clear_bytes));
-    d_ctr = (MeshCounters*)p->ctr.p;
+    HIP_TRYM(w.ctr.ensure(clear_bytes));
+    d_ctr = (MeshCounters*)w.ctr.p;
     // the counters and the group sums are cleared by the chain's first kernel (prune_spec_kernel); one launch per level: a memset
     static const bool use_spec = [] { const char* e = getenv("GSDF_HIP_PRUNE_SPEC"); return !e || atoi(e) != 0; }();
     if (!use_spec) HIP_TRYM(hipMemsetAsync(d_ctr, 0, clear_bytes, s));
@@ -145,9 +152,9 @@ int gsdf_mesh_job::enqueue() {
       // launch -- if there is one (else the resolve stage issues its atomics itself)
       const unsigned rrows = (n_spec + SPEC_STAGE - 1) / SPEC_STAGE;
       const size_t part_off = ((size_t)n_spec + 63) & ~(size_t)63;
-      HIP_TRYM(p->spec_pass.ensure(part_off + (size_t)rrows * 16 * sizeof(unsigned)));
+      HIP_TRYM(w.spec_pass.ensure(part_off + (size_t)rrows * 16 * sizeof(unsigned)));
       const bool chain_follows = last_spec - 1 >= lq;
-      spec_part = chain_follows ? (unsigned*)((char*)p->spec_pass.p + part_off) : nullptr;
+      spec_part = chain_follows ? (unsigned*)((char*)w.spec_pass.p + part_off) : nullptr;
       spec_rows = rrows;
       spec_top_S = levels | (S << 8);
       spec_mask = test_mask_of(pmask);
@@ -157,14 +164,14 @@ int gsdf_mesh_job::enqueue() {
       if (p->f_prune_spec) {
         HIP_TRYM(launch_fn(p->f_prune_spec, sgrid, BLOCK, lds_prune, s, (const uint32_t*)p->d_code, (int)levels, (unsigned)n_spec, (int)prune_cols,
                            (int)p->prog.nslots, ox, oy, oz, res, (unsigned)test_mask, (int)ptest, (int)shard_level, (unsigned)opts.shard_rank,
-                           (unsigned)opts.shard_count, (uint8_t*)p->spec_pass.p, (unsigned*)d_ctr, (unsigned)(clear_bytes / 4)));
+                           (unsigned)opts.shard_count, (uint8_t*)w.spec_pass.p, (unsigned*)d_ctr, (unsigned)(clear_bytes / 4)));
       } else {
         hipLaunchKernelGGL(prune_spec_kernel, dim3(sgrid), dim3(BLOCK), lds_prune, s, p->d_code, levels, n_spec, prune_cols, p->prog.nslots, ox, oy,
-                           oz, res, test_mask, ptest, shard_level, (unsigned)opts.shard_rank, (unsigned)opts.shard_count, (uint8_t*)p->spec_pass.p,
+                           oz, res, test_mask, ptest, shard_level, (unsigned)opts.shard_rank, (unsigned)opts.shard_count, (uint8_t*)w.spec_pass.p,
                            (unsigned*)d_ctr, (unsigned)(clear_bytes / 4));
       }
       HIP_TRYM(hipGetLastError());
-      hipLaunchKernelGGL(prune_resolve_kernel, dim3((n_spec + SPEC_STAGE - 1) / SPEC_STAGE), dim3(BLOCK), 0, s, (const uint8_t*)p->spec_pass.p, levels, S,
+      hipLaunchKernelGGL(prune_resolve_kernel, dim3((n_spec + SPEC_STAGE - 1) / SPEC_STAGE), dim3(BLOCK), 0, s, (const uint8_t*)w.spec_pass.p, levels, S,
                          n_spec, test_mask, (Cube*)q[last_spec & 1]->p, (unsigned long long)capq[last_spec & 1], d_ctr, spec_part);
       HIP_TRYM(hipGetLastError());
       first_level = last_spec - 1;
@@ -203,9 +210,9 @@ int gsdf_mesh_job::enqueue() {
                      m->d_tris, tcap, d_ctr)
       if (want_two) {
         // two kernels: evaluation + cut-leaf records, then marching cubes over the records
-        uint32_t* d_hdr = (uint32_t*)p->hdr.p;
-        uint32_t* d_rec = (uint32_t*)p->rec.p;
-        unsigned long long* d_psum = (unsigned long long*)((char*)p->ctr.p + kCtrBytes);  // cleared with the counters
+        uint32_t* d_hdr = (uint32_t*)w.hdr.p;
+        uint32_t* d_rec = (uint32_t*)w.rec.p;
+        unsigned long long* d_psum = (unsigned long long*)((char*)w.ctr.p + kCtrBytes);  // cleared with the counters
 #define LAUNCH_LEAF_EVAL_U(KK, WW, UU, NN, LDS)                                                                                    \
   hipLaunchKernelGGL((leaf_eval_kernel<KK, WW, UU, NN>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), LDS, s, p->d_code, \
                      (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res, d_hdr,   \
@@ -239,13 +246,13 @@ int gsdf_mesh_job::enqueue() {
           uint64_t rec_cap = m->recs_cap36 * 36 / 41;  // 40 B per record + 4 B per 256 of them, rounded: stays inside the buffer
           if (rec_cap > 2) rec_cap -= 2;
           hipLaunchKernelGGL(scan_groups_kernel, dim3(1), dim3(1024), 0, s, (const unsigned long long*)d_psum, (unsigned long long)nblk, lq, d_ctr,
-                             (unsigned long long*)p->grp.p, m->d_recs, (unsigned long long)rec_cap,
+                             (unsigned long long*)w.grp.p, m->d_recs, (unsigned long long)rec_cap,
                              ctr_from_kernel ? hcp : (MeshCounters*)nullptr);
           HIP_TRYM(hipGetLastError());
           const uint64_t ngrp_q = (nblk_q + MARCH_GROUP - 1) / MARCH_GROUP;
           const uint64_t gmax = (uint64_t)p->num_cu * 8;
           hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)(ngrp_q < gmax ? (ngrp_q ? ngrp_q : 1) : gmax)), dim3(BLOCK), 0, s, (const uint32_t*)d_hdr,
-                             (const uint32_t*)d_rec, (const unsigned long long*)p->grp.p, (unsigned long long)nblk, lq, (const MeshCounters*)d_ctr,
+                             (const uint32_t*)d_rec, (const unsigned long long*)w.grp.p, (unsigned long long)nblk, lq, (const MeshCounters*)d_ctr,
                              m->d_recs, (unsigned long long)rec_cap);
           ctr_on_host = ctr_from_kernel;
         } else {
@@ -386,7 +393,6 @@ extern "C" int gsdf_hip_mesh_octree_start(gsdf_program* p, float res, const gsdf
   if (want_recs && (opts.host_output || opts.share_corners || opts.max_tris || fused_leaf()))
     return fail(GSDF_ERR_BAD_ARGUMENT, "payload = records goes with the default leaf phase only (no host_output, share_corners, max_tris, fused leaf kernel)");
   HIP_TRY(hipSetDevice(p->device));
-  hipStream_t s = opts.stream ? (hipStream_t)opts.stream : p->stream;
 
   // Octree.Reset (octreerenderer.go:71-128) + makeICube (:222-235)
   float mn[3], mx[3];
@@ -400,13 +406,21 @@ extern "C" int gsdf_hip_mesh_octree_start(gsdf_program* p, float res, const gsdf
   int slot = -1;
   for (int k = 0; k < gsdf_program::kJobs; k++) if (!p->job_busy[k]) { slot = k; break; }
   if (slot < 0) return fail(GSDF_ERR_BAD_ARGUMENT, "two meshes of this program are in flight already: wait for one (gsdf_hip_mesh_octree_wait)");
-  // a second chain may follow the first only on the same stream: the workspace is shared and reused in stream order
-  for (int k = 0; k < gsdf_program::kJobs; k++)
-    if (p->job_busy[k] && p->job_stream[k] != s) return fail(GSDF_ERR_BAD_ARGUMENT, "a mesh of this program is in flight on another stream");
-  gsdf_mesh_job* j = new (std::nothrow) gsdf_mesh_job();
+  // Each slot has a workspace and a stream of its own: two chains in flight run beside each other (a caller's stream takes both).
+  // Measured at npt-flange resdiv 1600, per mesh: one blocking call at a time 0.59 ms; two chains back to back on ONE stream 0.58;
+  // on TWO streams 0.50 -- the centre tests and the marching kernel of one mesh (latency- and HBM-bound) run under the evaluating
+  // kernel of the other. Tried and dropped: one stream for the evaluating kernels of all meshes and side streams for the stages
+  // around them, ordered by events (a three-stage pipeline): 0.54, and a blocking call 0.61 -- every cross-stream event wait is
+  // ~10 us on this runtime.
+  if (slot == 1 && !opts.stream && !p->stream_b && hipStreamCreateWithFlags(&p->stream_b, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(GSDF_ERR_HIP, "hipStreamCreate failed");
+  }
+  hipStream_t s = opts.stream ? (hipStream_t)opts.stream : (slot == 0 ? p->stream : p->stream_b);
+  gsdf_mesh_job* j = new (std::nothrow) gsdf_mesh_job(p, slot);
   gsdf_mesh* m = new (std::nothrow) gsdf_mesh();
   if (!j || !m) { delete j; delete m; return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory"); }
-  j->p = p; j->m = m; j->opts = opts; j->res = res; j->s = s; j->slot = slot; j->levels = levels; j->want_recs = want_recs;
+  j->m = m; j->opts = opts; j->res = res; j->s = s; j->levels = levels; j->want_recs = want_recs;
   j->ox = mn[0]; j->oy = mn[1]; j->oz = mn[2];
   p->job_busy[slot] = true;
   p->job_stream[slot] = s;
@@ -439,7 +453,7 @@ extern "C" int gsdf_hip_mesh_octree_start(gsdf_program* p, float res, const gsdf
   if ((opts.prune & GSDF_PRUNE_ASSUME_SDF) && j->pmask == 0) j->pmask = 1;
   j->ptest = (opts.prune & GSDF_PRUNE_ASSUME_SDF) ? 2 : 1;
   p->leaf_config(&j->lk, &j->lw, &j->lds_m);
-  j->qcap = p->q0.cap / sizeof(Cube);
+  j->qcap = j->w.q0.cap / sizeof(Cube);
   {
     // 1 M cubes (8 MB) per queue to start with; GSDF_HIP_QCAP_MIN lowers it so that tests can drive the
     // overflow -> grow -> rerun path (the arenas only ever grow, so a handle that already meshed keeps its size)

@@ -192,6 +192,48 @@ int main(void) {
   CHECK(gsdf_hip_comm_allreduce_sum_u64(comm, sums, 2) == 0 && sums[0] == before && sums[1] == 7);
   CHECK(gsdf_hip_mesh_read(gathered, 0, 1, buf) == 0 && memcmp(buf, all, 36) == 0);
 
+  /* NewOctreeShardHIP (payload = records) + GatherStart / GatherWait, the source closed right after the start; and the plan the
+   * gather runs, asked for directly */
+  {
+    gsdf_mesh_opts ro;
+    memset(&ro, 0, sizeof ro);
+    ro.prune = 1; ro.shard_count = 1; ro.payload = GSDF_PAYLOAD_RECORDS;
+    gsdf_mesh* shard = NULL;
+    CHECK(gsdf_hip_mesh_octree(s.h, 1.0f / 33, &ro, &shard) == 0);
+    uint64_t nrec = 0, nbytes = 0;
+    CHECK(gsdf_hip_mesh_payload(shard, &nrec, &nbytes) == GSDF_PAYLOAD_RECORDS && nrec > 10000 && nbytes > 40 * nrec);
+    CHECK(gsdf_hip_mesh_read(shard, 0, 1, buf) != 0); /* no triangles yet */
+    gsdf_gather* pending = NULL;
+    CHECK(gsdf_hip_mesh_gatherv_start(shard, comm, GSDF_GATHER_ALL, 0, &pending) == 0);
+    gsdf_hip_mesh_destroy(shard); /* deferred by the library until the payload has moved */
+    gsdf_mesh* g2 = NULL;
+    gsdf_gather_stats gs;
+    CHECK(gsdf_hip_mesh_gatherv_wait(pending, &g2, counts, &gs) == 0 && g2 != NULL && counts[0] == 41072 && gs.ms_march > 0);
+    CHECK(gsdf_hip_mesh_stats_get(g2, &gst) == 0 && gst.n_tris == 41072);
+    CHECK(gsdf_hip_mesh_read(g2, 41071, 1, buf) == 0);
+    gsdf_hip_mesh_destroy(g2);
+    const uint64_t sizes[3] = {72, 0, 36};
+    gsdf_gather_op ops[8];
+    size_t n_ops = 0;
+    uint64_t total = 0;
+    CHECK(gsdf_hip_gather_plan(sizes, 3, 2, GSDF_GATHER_ALL, 0, ops, 8, &n_ops, &total) == 0 && total == 108 && n_ops == 4);
+    CHECK(ops[0].kind == GSDF_GOP_COPY && ops[0].dst_off == 72 && ops[0].bytes == 36);
+  }
+  /* two meshes of one program in flight (gsdf_hip_mesh_octree_start / _wait) */
+  {
+    gsdf_mesh_opts po;
+    memset(&po, 0, sizeof po);
+    po.prune = 1; po.shard_count = 1;
+    gsdf_mesh_job *ja = NULL, *jb = NULL, *jc = NULL;
+    CHECK(gsdf_hip_mesh_octree_start(s.h, 1.0f / 33, &po, &ja) == 0 && gsdf_hip_mesh_octree_start(s.h, 1.0f / 20, &po, &jb) == 0);
+    CHECK(gsdf_hip_mesh_octree_start(s.h, 1.0f / 20, &po, &jc) != 0); /* a third is refused */
+    gsdf_mesh *ma = NULL, *mb = NULL;
+    CHECK(gsdf_hip_mesh_octree_wait(ja, &ma) == 0 && gsdf_hip_mesh_octree_wait(jb, &mb) == 0);
+    CHECK(gsdf_hip_mesh_stats_get(ma, &gst) == 0 && gst.n_tris == 41072);
+    CHECK(gsdf_hip_mesh_stats_get(mb, &gst) == 0 && gst.n_tris > 1000);
+    gsdf_hip_mesh_destroy(ma); gsdf_hip_mesh_destroy(mb);
+  }
+
   /* the CSG program meshes too, through the specialised kernels, and pruning does not change its surface */
   OctreeHIP oc2, oc3;
   CHECK(NewOctreeRendererHIP(&csg, 0.02f, &oc2) == GoNil && oc2.n > 10000);
