@@ -133,7 +133,7 @@ int gsdf_mesh_job::enqueue() {
     static const bool use_spec = [] { const char* e = getenv("GSDF_HIP_PRUNE_SPEC"); return !e || atoi(e) != 0; }();
     if (!use_spec) HIP_TRYM(hipMemsetAsync(d_ctr, 0, clear_bytes, s));
     HIP_TRYM(hipEventRecord(ev0, s));
-    static const int prune_bpc = [] { const char* e = getenv("GSDF_HIP_PRUNE_BPC"); return e ? atoi(e) : 4; }();  // tuning knob
+    static const int prune_bpc = [] { const char* e = getenv("GSDF_HIP_PRUNE_BPC"); return e ? atoi(e) : 2; }();  // tuning knob: 2 workgroups per CU (round 4: 4 -> 2 is -3 us on a blocking mesh and leaves the CUs to the other mesh in flight: 0.503 -> 0.486 ms per mesh, two in flight)
     // The first S levels (at most 7: 299,593 cubes) are centre-tested speculatively, every cube of the complete octree at once,
     // and resolved by a second launch (kernels.h: prune_spec_kernel / prune_resolve_kernel): two launches instead of a chain of
     // S dependent ones. GSDF_HIP_PRUNE_SPEC=0 keeps one launch per level (cross-check in the tests).
@@ -203,7 +203,7 @@ int gsdf_mesh_job::enqueue() {
     {
       const uint64_t bound = lbound;
       const unsigned long long tcap = opts.max_tris ? opts.max_tris : m->cap;
-      static const int leaf_bpc = [] { const char* e = getenv("GSDF_HIP_LEAF_BPC"); return e ? atoi(e) : 64; }();  // grid = up to 64 workgroups per CU (4 resident): a few grid-stride iterations each, so the CUs drain evenly at the end (8 per CU: +8 % kernel time; one iteration per workgroup: +10 %)
+      static const int leaf_bpc = [] { const char* e = getenv("GSDF_HIP_LEAF_BPC"); return e ? atoi(e) : 32; }();  // (round 4: 32 -- the same for one mesh at a time, 0.503 -> 0.475 ms per mesh with two in flight: the other chain's small kernels are dispatched sooner behind a shorter queue of workgroups; the sentence that follows describes the round-3 sweep)  // grid = up to 64 workgroups per CU (4 resident): a few grid-stride iterations each, so the CUs drain evenly at the end (8 per CU: +8 % kernel time; one iteration per workgroup: +10 %)
 #define LAUNCH_LEAF(KK, WW)                                                                                           \
   hipLaunchKernelGGL((leaf_kernel<KK, WW>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), lds_m, s, p->d_code,      \
                      (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res,  \
@@ -257,7 +257,7 @@ int gsdf_mesh_job::enqueue() {
           ctr_on_host = ctr_from_kernel;
         } else {
         // one wave of workgroups: each takes an equal share of the records (computed on device from the group sums)
-        static const int march_bpc = [] { const char* e = getenv("GSDF_HIP_MARCH_BPC"); return e ? atoi(e) : 7; }();  // tuning knob (7 fit a CU)
+        static const int march_bpc = [] { const char* e = getenv("GSDF_HIP_MARCH_BPC"); return e ? atoi(e) : 4; }();  // tuning knob (7 fit a CU; 4 leave LDS and wave slots to the other mesh in flight: 0.503 -> 0.495 ms per mesh, and a blocking mesh loses nothing)
         const size_t lds_march = (size_t)11 * BLOCK * 4 + 5 * BLOCK * 4 + 256 * 16 + (BLOCK + 1) * 4 + 8 * 4 + 8 + 14 * 8;
         hipLaunchKernelGGL(march_records_kernel, dim3(grid_for(nblk_q, p->num_cu, march_bpc)), dim3(BLOCK), lds_march, s, d_hdr, d_rec,
                            d_psum, (unsigned long long)nblk, lq, ox, oy, oz, res, m->d_tris, (uint64_t)tcap, d_ctr,
@@ -513,8 +513,8 @@ int mesh_march_dense(const uint8_t* d_buf, const gsdf_dense_part* parts, int npa
   if (chunks == 0) return GSDF_OK;
   // the table is small and the copy's source is this stack frame: hipMemcpyAsync from pageable memory stages it before returning
   HIP_TRY(hipMemcpyAsync(d_parts, &h, sizeof h, hipMemcpyHostToDevice, s));
-  static const int march_bpc = [] { const char* e = getenv("GSDF_HIP_MARCH_BPC"); return e ? atoi(e) : 7; }();  // tuning knob (7 fit a CU)
-  const uint64_t gmax = (uint64_t)num_cu * (uint64_t)(march_bpc > 0 ? march_bpc : 7);
+  static const int march_bpc = [] { const char* e = getenv("GSDF_HIP_MARCH_BPC"); return e ? atoi(e) : 4; }();  // tuning knob (7 fit a CU; 4 leave LDS and wave slots to the other mesh in flight: 0.503 -> 0.495 ms per mesh, and a blocking mesh loses nothing)
+  const uint64_t gmax = (uint64_t)num_cu * (uint64_t)(march_bpc > 0 ? march_bpc : 4);
   const size_t lds = (size_t)11 * BLOCK * 4 + 5 * BLOCK * 4 + 256 * 16 + 8 * 4 + 8 + 4 * 8;
   hipLaunchKernelGGL(march_dense_kernel, dim3((unsigned)(chunks < gmax ? chunks : gmax)), dim3(BLOCK), lds, s, d_buf, (const DenseParts*)d_parts, ox, oy, oz, res, d_tris);
   HIP_TRY(hipGetLastError());
