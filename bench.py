@@ -153,43 +153,6 @@ def evaluate_dropin(hip, sdf, shader, n=32768, calls=300):
     return out
 
 
-def batch_throughput(hip, shader, res, specialised, meshes=40, handles=2):
-    """Meshes per second when a caller has several parts to mesh: `handles` independent program handles (own stream and
-    workspace each), one host thread per handle, the same mesh `meshes` times each. One mesh's launch-latency-bound top of the
-    octree and its host tail then run under the other's leaf kernel. Measured AFTER the contract's timed loop; not the headline
-    (which is one mesh at a time, start to finish)."""
-    import threading
-    sdfs = []
-    for _ in range(handles):
-        s = hip.SDF3HIP(shader)
-        if specialised:
-            try:
-                s.specialize()
-            except hip.HipError:
-                pass
-        sdfs.append(s)
-    stats = [None] * handles
-
-    def work(i, n):
-        oc = None
-        for _ in range(n):
-            oc = hip.OctreeHIP(sdfs[i], res)
-        stats[i] = oc.stats
-    for i in range(handles):
-        work(i, 5)  # warm: buffers sized, pools filled
-    th = [threading.Thread(target=work, args=(i, meshes)) for i in range(handles)]
-    t0 = time.perf_counter()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
-    n = meshes * handles
-    return {"handles": handles, "meshes": n, "meshes_per_s": n / dt, "ms_per_mesh": dt / n * 1e3,
-            "evals_per_s": float(stats[0].evals) * n / dt, "triangles_per_s": float(stats[0].n_tris) * n / dt,
-            "note": "independent handles meshing concurrently from host threads (throughput of a batch of parts); the headline is one mesh at a time"}
-
-
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, one wave64 VALU op per 2 cycles, 2.4 GHz
 
 
@@ -322,7 +285,7 @@ def main():
     ap.add_argument("--scene", default="npt-flange")
     ap.add_argument("--cpu-resdiv", type=int, default=0, help="resdiv of the bounded CPU sample (0 = pick ~10-30 s of CPU work from the core count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-batch-throughput", action="store_true", help="skip the two-handle throughput measurement that follows the timed loop")
+    ap.add_argument("--no-batch-throughput", action="store_true", help="(accepted, ignored: the timed loop itself keeps two meshes in flight since round 4)")
     ap.add_argument("--mode", choices=["mesh", "eval", "flat"], default="mesh",
                     help="mesh (default, BASELINE configs[1]) or eval: the gleval.SDF3.Evaluate micro-benchmark (SURVEY 8(d) M1) on "
                          "HBM-resident positions: 2^24-point chunks of the flat lattice of the scene at --resdiv; flat: the reference's other "
@@ -545,13 +508,25 @@ def main():
         # dominant kernel: leaf_eval_kernel (fused mode: leaf_kernel). ALGORITHMIC bytes per launch = 16 B per evaluation it performs
         # (12 B position + 4 B distance; positions are generated on device but counted) + 36 B per triangle.
         dc = args.renderer == "dualcontour"
-        if dc:  # no single dominant kernel is timed apart: price the whole device pass (origin sweep + 4 follow-up kernels)
-            march_ms, march_evals, march_tris = st.ms_total * args.steps, float(st.evals) * args.steps, float(st.n_tris) * args.steps
+        dc_stages = None
+        if dc:  # five stages, timed apart by HIP events (gsdf_hip_mesh_stage_ms): the roofline line is the longest one's
+            sm = oc.stage_ms()
+            nc, ne, nq, no = float(st.leaf_cubes), float(st.active_leaves), float(st.n_tris) / 2, float(st.evals_prune)
+            alg = {"dc_origin": 16.0 * no + 4.0 * no,            # position + distance per evaluated cell, + its index-grid word
+                   "dc_edges": 16.0 * 4 * nc + 8.0 * nc + 28.0 * nc + 4.0 * ne,  # 4 evaluations per kept cube, its cube word in, distances + default vertex out, an edge word per active edge
+                   "dc_normals": 16.0 * 6 * ne + 36.0 * ne,       # 6 evaluations per active edge (central differences), crossing + normal out
+                   "dc_place": (16.0 + 8.0 + 12.0) * nc + 36.0 * ne,  # distances, cube word, vertex out; the crossings / normals of its edges in
+                   "dc_quads": 72.0 * nq + 4.0 * ne + 4 * 12.0 * nq}  # two triangles out per quad, four vertices + an edge word in
+            dc_stages = {k: {"ms": v, "algorithmic_gb": alg[k] / 1e9, "gb_per_s": alg[k] / 1e9 / (v * 1e-3) if v > 0 else 0.0} for k, v in sm.items()}
+            kmax = max(sm, key=sm.get)
+            march_ms, march_evals, march_tris = sm[kmax] * args.steps, float(st.evals) * args.steps, float(st.n_tris) * args.steps
         k_ms = march_ms / max(1, args.steps)
         two_kernel = emit_ms > 0  # leaf phase = leaf_eval_kernel (dominant) + march_records_kernel
         # ALGORITHMIC bytes of the dominant kernel: 16 B per evaluation; the fused kernel also emits the
         # triangles (36 B each), the evaluating kernel of the two-kernel phase hands 40-byte cut-leaf records on instead
         k_bytes = (march_evals * 16.0 + (cut * 40.0 if two_kernel else march_tris * 36.0)) / max(1, args.steps)
+        if dc:
+            k_bytes = dc_stages[kmax]["algorithmic_gb"] * 1e9
         e_ms = emit_ms / max(1, args.steps)
         e_bytes = (cut * 40.0 + march_tris * 36.0) / max(1, args.steps)
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
@@ -581,7 +556,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None if dc else pmc_traffic_gb(workload, code), "traffic_unit": "GB per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
                          "algorithmic_gb_per_launch": k_bytes / 1e9,
-                         "kernel": "dc_origin/edges/normals/place/quads (whole device pass)" if dc else kern.get("leaf", "leaf_kernel"), "kernel_ms": k_ms,
+                         "kernel": (kmax + "_kernel (the longest of the five stages; all of them under 'stages')") if dc else kern.get("leaf", "leaf_kernel"), "kernel_ms": k_ms,
                          "kernel_evals_per_s": kernel_rate, "valu": None if dc else valu_roofline(kernel_rate, workload, code),
                          "note": "path is fp32-VALU bound (SURVEY 8(d)): algorithmic HBM bytes are tiny by construction; "
                                  "'valu' prices the same kernel against the VALU issue peak"},
@@ -589,6 +564,7 @@ def main():
                 "bound": "hbm", "kernel": "march_records_kernel", "kernel_ms": e_ms, "algorithmic_gb_per_launch": e_bytes / 1e9,
                 "achieved": e_bytes / (e_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": e_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "marching cubes over the cut-leaf records: 40 B read per record + 36 B written per triangle"},
+            "stages": dc_stages,
             "phase_ms_rank0": {"prune": st.ms_prune, "leaf": st.ms_leaf, "eval_kernel": st.ms_march, "march_kernel": st.ms_emit, "total_device": st.ms_total},
         }
         if mesh_pipeline and not dc:
@@ -597,6 +573,11 @@ def main():
             alone = [hip.OctreeHIP(sdf, res, share_corners=args.share_corners).stats for _ in range(8)][2:]
             a_ms = sum(a.ms_march for a in alone) / len(alone)
             a_gbs = k_bytes / (a_ms * 1e-3) / 1e9
+            if out.get("roofline_march"):
+                m_ms = sum(a.ms_emit for a in alone) / len(alone)
+                m_gbs = e_bytes / (m_ms * 1e-3) / 1e9
+                out["roofline_march"]["alone"] = {"kernel_ms": m_ms, "achieved": m_gbs, "frac": m_gbs / HBM_PEAK_GBS}
+            out["roofline"]["valu_alone"] = valu_roofline((march_evals / max(1, args.steps)) / (a_ms * 1e-3), workload, code)
             out["roofline"]["alone"] = {"kernel_ms": a_ms, "achieved": a_gbs, "frac": a_gbs / HBM_PEAK_GBS, "ms_per_mesh_device": sum(a.ms_total for a in alone) / len(alone),
                                         "note": "one blocking mesh at a time (measured after the timed loop): the kernel with the GPU to itself"}
             out["roofline"]["note"] += ("; the timed loop keeps two meshes in flight on two streams, so kernel_ms / achieved / frac above are the kernel's "
@@ -623,8 +604,6 @@ def main():
             out["cpu_baseline"] = cpu_baseline(shader, args.scene, cpu_rd, threads)
         if world == 1 and not dc:
             out["host_inclusive"] = host_inclusive(hip, sdf, res)
-        if world == 1 and not dc and not args.no_batch_throughput and not args.no_cpu_baseline:
-            out["batch_throughput"] = batch_throughput(hip, shader, res, not args.interpreter)
         if world == 1 and not dc and not args.no_evaluate_dropin and args.scene != "text-plate":
             out["evaluate_dropin"] = evaluate_dropin(hip, sdf, shader)
         print(json.dumps(out), flush=True)

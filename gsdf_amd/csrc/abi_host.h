@@ -45,6 +45,10 @@ struct gsdf_mesh {
   uint64_t recs_cap36 = 0;
   uint64_t n_recs = 0;
   int num_cu = 256;
+  // device time per stage, where a mesher records it (dual contouring: five stages; gsdf_hip_mesh_stage_ms)
+  int n_stages = 0;
+  double stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const char* stage_name[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // A gather in flight reads this mesh's buffers on the communicator's stream (gsdf_hip_mesh_gatherv_start .. _wait): a
   // destroy in between is deferred to the gather's end instead of handing the buffers to the next mesh under it.
   std::atomic<int> inflight{0};

@@ -521,6 +521,16 @@ int mesh_march_dense(const uint8_t* d_buf, const gsdf_dense_part* parts, int npa
   return GSDF_OK;
 }
 
+extern "C" int gsdf_hip_mesh_stage_ms(const gsdf_mesh* m, double* ms, const char** names, int cap, int* n) {
+  if (!m || !n) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *n = m->n_stages;
+  for (int k = 0; k < m->n_stages && k < cap; k++) {
+    if (ms) ms[k] = m->stage_ms[k];
+    if (names) names[k] = m->stage_name[k];
+  }
+  return GSDF_OK;
+}
+
 extern "C" int gsdf_hip_mesh_payload(const gsdf_mesh* m, uint64_t* n_records, uint64_t* payload_bytes) {
   if (!m) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
   const bool r = m->payload == GSDF_PAYLOAD_RECORDS;
@@ -602,6 +612,8 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
   } while (0)
   for (auto& e : p->ev)
     if (!e) HIP_TRYM(hipEventCreate(&e));
+  for (auto& e : p->ev_b)
+    if (!e) HIP_TRYM(hipEventCreate(&e));
   // Workspace lives in the program handle (grow-only): the index grid alone is 4.3 GB at 1024^3 cells, and a
   // hipMalloc/hipFree pair of that size per mesh cost more wall time than the whole device pass.
   gsdf_program::Arena &grid = p->dc_grid, &d2 = p->dc_dist, &f2 = p->dc_fv, &n2 = p->dc_nrm, &e2 = p->dc_edge;
@@ -660,6 +672,7 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     else LAUNCH_O(1, 4);
 #undef LAUNCH_O
     HIP_TRYM(hipGetLastError());
+    HIP_TRYM(hipEventRecord(p->ev_b[0], s));  // origin sweep done
     if (p->lds_bytes(4) > 150 * 1024) return bail(fail(GSDF_ERR_BAD_TREE, "tree needs too much LDS scratch for the dual contouring edge pass"));
     if (p->f_dc_edges) HIP_TRYM(launch_fn(p->f_dc_edges, grid_for(ccap, p->num_cu, 8), BLOCK, p->lds_bytes(4), s, (const uint32_t*)p->d_code, (const Cube*)p->q0.p,
                        (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, d_ctr));
@@ -667,16 +680,19 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     hipLaunchKernelGGL(dc_edges_kernel, dim3(grid_for(ccap, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(4), s, p->d_code, (const Cube*)p->q0.p,
                        (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, d_ctr);
     HIP_TRYM(hipGetLastError());
+    HIP_TRYM(hipEventRecord(p->ev_b[1], s));  // edges done
     if (p->f_dc_normals) HIP_TRYM(launch_fn(p->f_dc_normals, grid_for(ecap, p->num_cu, 8), BLOCK, p->lds_bytes(2), s, (const uint32_t*)p->d_code, (const Cube*)p->q0.p,
                        (const float4*)d2.p, (const unsigned*)e2.p, (unsigned long long)ecap, ox, oy, oz, res, h, (float*)n2.p, d_ctr));
     else
     hipLaunchKernelGGL(dc_normals_kernel, dim3(grid_for(ecap, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(2), s, p->d_code, (const Cube*)p->q0.p,
                        (const float4*)d2.p, (const unsigned*)e2.p, (unsigned long long)ecap, ox, oy, oz, res, h, (float*)n2.p, d_ctr);
     HIP_TRYM(hipGetLastError());
+    HIP_TRYM(hipEventRecord(p->ev_b[2], s));  // normals done
     hipLaunchKernelGGL(dc_place_kernel, dim3(grid_for(ccap * 4, p->num_cu, 16)), dim3(DC_BLOCK), 0, s, (const Cube*)p->q0.p,
                        (unsigned long long)ccap, (const float4*)d2.p, (const int*)grid.p, (const float*)n2.p, nshift, ox, oy, oz, res,
                        sqrtLambda, (float*)f2.p, zown_hi, d_ctr);
     HIP_TRYM(hipGetLastError());
+    HIP_TRYM(hipEventRecord(p->ev_b[3], s));  // placement done
     hipLaunchKernelGGL(dc_quads_kernel, dim3(grid_for(ecap, p->num_cu, 8)), dim3(BLOCK), 0, s, (const Cube*)p->q0.p, (const float4*)d2.p,
                        (const unsigned*)e2.p, (unsigned long long)ecap, (const int*)grid.p, (const float*)f2.p, nshift, zown_lo, zown_hi,
                        m->d_tris, (unsigned long long)m->cap, d_ctr);
@@ -694,6 +710,17 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
   }
   float ms = 0;
   HIP_TRYM(hipEventElapsedTime(&ms, p->ev[0], p->ev[1]));
+  {  // per stage (gsdf_hip_mesh_stage_ms): origin sweep, edges, normals, placement, quads
+    hipEvent_t cut[6] = {p->ev[0], p->ev_b[0], p->ev_b[1], p->ev_b[2], p->ev_b[3], p->ev[1]};
+    static const char* const names[5] = {"dc_origin", "dc_edges", "dc_normals", "dc_place", "dc_quads"};
+    m->n_stages = 5;
+    for (int k = 0; k < 5; k++) {
+      float t = 0;
+      HIP_TRYM(hipEventElapsedTime(&t, cut[k], cut[k + 1]));
+      m->stage_ms[k] = t;
+      m->stage_name[k] = names[k];
+    }
+  }
   p->last_dc_cubes = hc.n_cubes;
   m->st.n_tris = 2 * hc.n_tris;  // quads -> 2 triangles
   m->st.evals = hc.n_origin_evals + 4 * hc.n_cubes + 6 * hc.n_edges;

@@ -25,7 +25,7 @@ SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "g
            "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3", "gsdf_hip_image2",
            "gsdf_hip_mesh_octree", "gsdf_hip_mesh_dualcontour", "gsdf_hip_mesh_flat", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
            "gsdf_hip_mesh_stl", "gsdf_hip_mesh_host_tris", "gsdf_hip_mesh_host_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner", "gsdf_hip_slab_range",
-           "gsdf_hip_mesh_payload", "gsdf_hip_mesh_march", "gsdf_hip_mesh_octree_start", "gsdf_hip_mesh_octree_wait", "gsdf_hip_comm_transport", "gsdf_hip_gather_plan"]
+           "gsdf_hip_mesh_payload", "gsdf_hip_mesh_march", "gsdf_hip_mesh_stage_ms", "gsdf_hip_mesh_octree_start", "gsdf_hip_mesh_octree_wait", "gsdf_hip_comm_transport", "gsdf_hip_gather_plan"]
 
 
 PRUNE_ASSUME_SDF = 1 << 30  # gsdf_hip.h: GSDF_PRUNE_ASSUME_SDF
@@ -97,6 +97,7 @@ def lib():
                                            C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]
         L.gsdf_hip_mesh_payload.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.gsdf_hip_mesh_march.argtypes = [C.c_void_p]
+        L.gsdf_hip_mesh_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int)]
         L.gsdf_hip_eval3_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
         L.gsdf_hip_eval_wait.argtypes = [C.c_void_p, C.c_int]
         L.gsdf_hip_host_alloc.restype = C.c_void_p
@@ -390,6 +391,12 @@ class OctreeHIP:
         k = lib().gsdf_hip_mesh_payload(self._mesh, C.byref(n), C.byref(b))
         _check(min(k, 0))
         return k, int(n.value), int(b.value)
+
+    def stage_ms(self):
+        """{kernel name: device milliseconds} of the mesher's stages, where it records them (dual contouring)."""
+        ms, names, n = (C.c_double * 8)(), (C.c_char_p * 8)(), C.c_int()
+        _check(lib().gsdf_hip_mesh_stage_ms(self._mesh, ms, names, 8, C.byref(n)))
+        return {names[k].decode(): float(ms[k]) for k in range(n.value)}
 
     def march(self):
         """Marching cubes over a records mesh, in place: afterwards it reads like any mesh (gsdf_hip_mesh_march)."""

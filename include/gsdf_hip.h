@@ -241,6 +241,9 @@ int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chiseled, int shar
  * :120-122), nothing exchanged. */
 int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, int shard_count, void* stream, gsdf_mesh** out);
 int gsdf_hip_mesh_stats_get(const gsdf_mesh* m, gsdf_mesh_stats* st);
+/* Device time of the mesher's stages, where it records them (dual contouring: dc_origin, dc_edges, dc_normals, dc_place, dc_quads;
+ * HIP events between the stages): *n = number of stages, ms / names (optional, cap entries) = milliseconds and kernel names. */
+int gsdf_hip_mesh_stage_ms(const gsdf_mesh* m, double* ms, const char** names, int cap, int* n);
 /* What the mesh holds: GSDF_PAYLOAD_TRIANGLES or GSDF_PAYLOAD_RECORDS (gsdf_mesh_opts.payload); *n_records / *payload_bytes
  * (optional) = its cut-leaf records and the size of their packed form (0 for a mesh of triangles). */
 int gsdf_hip_mesh_payload(const gsdf_mesh* m, uint64_t* n_records, uint64_t* payload_bytes);
