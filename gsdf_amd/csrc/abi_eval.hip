@@ -212,7 +212,7 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
   p->leaf_config(&lk, &lw, &lds_m);
   const int ek = p->batch_k();
   std::vector<std::string> names;
-  int both_at = -1;
+  int both_at = -1, both5_at = -1;
   const int ew = p->sweep_waves(ek);
   names.push_back(std::string("eval_kernel<") + (p->prog.is2d ? "2" : "3") + ", " + std::to_string(ek) + ", " + std::to_string(ew) + ">");
   if (!p->prog.is2d) {
@@ -229,6 +229,12 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
     if (!fused_leaf() && !both_off && lk == 4 && gsdf_dev::spec_xy_shared_weight(p->prog) >= both_min) {
       both_at = (int)names.size();
       names.push_back(std::string("leaf_eval_kernel<4, ") + std::to_string(lw) + (p->leaf_nt_in_lds() ? ", true, true, true>" : ", true, false, true>"));
+      // ... and at five workgroups per CU (96 registers) where the LDS has room: taken if it builds without scratch
+      static const bool both5_off = [] { const char* e = getenv("GSDF_HIP_NO_BOTH5"); return e && atoi(e) != 0; }();  // developer knob (A/B timing)
+      if (!both5_off && lw == 4 && 5 * lds_m <= (size_t)160 * 1024) {
+        both5_at = (int)names.size();
+        names.push_back(std::string("leaf_eval_kernel<4, 5") + (p->leaf_nt_in_lds() ? ", true, true, true>" : ", true, false, true>"));
+      }
     }
   }
   std::vector<hipFunction_t> f;
@@ -273,6 +279,11 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
       const bool okb = fn_scratch_bytes(f[(size_t)both_at]) == 0;
       spec_report("specialised", names[(size_t)both_at], f[(size_t)both_at], okb);
       if (okb) { p->f_leaf = f[(size_t)both_at]; p->spec_leaf_w = lw; p->spec_leaf_both = true; okl = true; }
+      if (both5_at >= 0) {
+        const bool ok5b = fn_scratch_bytes(f[(size_t)both5_at]) == 0;
+        spec_report("specialised", names[(size_t)both5_at], f[(size_t)both5_at], ok5b);
+        if (ok5b) { p->f_leaf = f[(size_t)both5_at]; p->spec_leaf_w = 5; p->spec_leaf_both = true; okl = true; }
+      }
     }
     // the leaf kernel is where the time goes: before giving it up, trade occupancy for registers (W = workgroups per CU
     // the register budget is sized for; the launch is the same)

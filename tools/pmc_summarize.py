@@ -49,6 +49,26 @@ for k in KERNELS:
                 d["valu_lane_instr_per_s"] = rate
                 # 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md: SIMD-32, 2 cycles per wave64 VALU op)
                 d["valu_issue_frac_of_peak"] = rate / (256 * 4 * 32 * 2.4e9)
+    # What the kernel's instruction MIX allows: VALU issue rates differ by class on gfx950 (tools/ubench/class_rate.hip, profiles/
+    # r4_valu_class_rates.txt, 4-8 waves per SIMD): f32 add / mul / fma with register, literal or inline operands 2.6-3.0 cycles per
+    # wave-instruction and SIMD; min / max / med3, compares, selects, shifts, conversions, DPP, anything with an SGPR operand 4.2-4.6;
+    # f64 4.5-5.1; rcp / sqrt 8.2. Lower bound of the kernel's duration = sum over classes of count x cycles / (1024 SIMDs x 2.4 GHz),
+    # the unclassified instructions (moves, logic, selects, compares, min / max) priced at the 4.4 of the majority among them.
+    need = ("SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32")
+    if all(n in d for n in need):
+        fast = d["SQ_INSTS_VALU_ADD_F32"] + d["SQ_INSTS_VALU_MUL_F32"] + d["SQ_INSTS_VALU_FMA_F32"]
+        f64 = sum(d.get(n, 0.0) for n in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"))
+        trans = d["SQ_INSTS_VALU_TRANS_F32"]
+        other = max(0.0, d["SQ_INSTS_VALU"] - fast - f64 - trans)
+        cyc = fast * 2.7 + f64 * 4.8 + trans * 8.2 + other * 4.4
+        d["valu_mix"] = {"f32_add_mul_fma": fast / d["SQ_INSTS_VALU"], "f64": f64 / d["SQ_INSTS_VALU"], "trans": trans / d["SQ_INSTS_VALU"],
+                         "other (min/max, compare, select, move, logic, int, cvt, dpp)": other / d["SQ_INSTS_VALU"],
+                         "cycles_per_instr_by_class": cyc / d["SQ_INSTS_VALU"], "roof_ms": cyc / (1024 * 2.4e9) * 1e3}
+        if a.kernel_ms:
+            d["valu_mix"]["kernel_ms"] = a.kernel_ms
+            d["valu_mix"]["frac_of_mix_roof"] = d["valu_mix"]["roof_ms"] / a.kernel_ms
+    if "SQ_THREAD_CYCLES_VALU" in d and d.get("SQ_ACTIVE_INST_VALU"):
+        d["valu_active_lanes_of_64"] = d["SQ_THREAD_CYCLES_VALU"] / d["SQ_ACTIVE_INST_VALU"]
     if "GRBM_GUI_ACTIVE" in d:
         d["clock_ghz_est"] = None
     if "SQ_WAIT_ANY" in d and "SQ_WAVE_CYCLES" in d:
