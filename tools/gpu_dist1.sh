@@ -12,4 +12,5 @@ try:
 except Exception as e: print('FAILED', e)"
 }
 FB="" ; for m in all root none; do echo "== gather $m"; run --gather $m; echo "== gather $m, not pipelined"; run --gather $m --no-gather-pipeline; done
+echo "== gather all, payload triangles"; run --gather all --payload triangles
 FB=1; echo "== torch.distributed fallback"; run
