@@ -237,8 +237,6 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
       }
     }
   }
-  int all_at = -1;  // the prune phase as one persistent launch (kernels_octree.h: prune_all_kernel); last in the list
-  if (!p->prog.is2d) { all_at = (int)names.size(); names.push_back("prune_all_kernel"); }
   std::vector<hipFunction_t> f;
   hipModule_t mod = nullptr;
   const int rc = spec_build(p, names, &mod, f, &p->spec_compile_s);
@@ -271,14 +269,8 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
     spec_report("specialised", names[3], f[3], okl);
     p->f_prune = okp ? f[1] : nullptr;
     p->f_prune_spec = okt ? f[2] : nullptr;
-    {
-      const bool oka = fn_scratch_bytes(f[(size_t)all_at]) == 0;
-      spec_report("specialised", names[(size_t)all_at], f[(size_t)all_at], oka);
-      p->f_prune_all = oka ? f[(size_t)all_at] : nullptr;
-      p->prune_all_grid = 0;  // sized again for this kernel at the next mesh
-    }
     p->f_leaf = okl ? f[3] : nullptr;
-    if (f.size() > 4 && both_at != 4 && all_at != 4) {
+    if (f.size() > 4 && both_at != 4) {
       const bool ok5 = fn_scratch_bytes(f[4]) == 0;
       spec_report("specialised", names[4], f[4], ok5);
       if (ok5) { p->f_leaf = f[4]; p->spec_leaf_w = 5; okl = true; }
@@ -367,7 +359,7 @@ extern "C" int gsdf_hip_specialize_check(const gsdf_tree* tree, size_t* code_obj
     std::vector<std::string> low;
     std::string log;
     const std::vector<std::string> names = pr.is2d ? std::vector<std::string>{"eval_kernel<2, 4, 4>"}
-                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "prune_spec_kernel", "prune_all_kernel", "leaf_eval_kernel<4, 4, true, true, false>", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
+                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "prune_spec_kernel", "leaf_eval_kernel<4, 4, true, true, false>", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
     if (!gsdf_dev::spec_compile(pr, "gfx950", names, co, low, log)) return fail(GSDF_ERR_HIP, "specialised build failed:\n" + log);
     if (code_object_bytes) *code_object_bytes = co.size();
     return GSDF_OK;
@@ -423,7 +415,6 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (p->spec_mod4) (void)hipModuleUnload(p->spec_mod4);
   p->q0.release(); p->q1.release(); p->ctr.release();
   p->rec.release(); p->hdr.release(); p->grp.release();
-  p->bar.release(); p->b_bar.release();
   p->b_q0.release(); p->b_q1.release(); p->b_ctr.release(); p->b_spec_pass.release(); p->b_rec.release(); p->b_hdr.release(); p->b_grp.release();
   if (p->stream_b) (void)hipStreamDestroy(p->stream_b);
   p->flat_grid.release(); p->flat_bits.release(); p->flat_list.release(); p->dc_grid.release(); p->dc_dist.release(); p->dc_fv.release(); p->dc_nrm.release(); p->dc_edge.release();

@@ -46,7 +46,7 @@ struct gsdf_mesh_job {
   uint64_t qcap = 0, want = 0, want_rec_n = 0;  // capacities of the next attempt
   // the attempt in flight
   int attempt = 0, slot;
-  bool used_brick = false, two_kernel = false, ctr_on_host = false, used_all = false;
+  bool used_brick = false, two_kernel = false, ctr_on_host = false;
   int chain_first = 0;  // levels <= chain_first were tested by prune_kernel (one launch per level), the ones above speculatively
   uint64_t nblk = 0;
   size_t clear_bytes = 0;
@@ -55,11 +55,11 @@ struct gsdf_mesh_job {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, evr = nullptr, ev_done = nullptr;
   // this job's workspace: the handle has two, so that two chains in flight do not share one (they run on two streams, the
   // latency-bound top and tail of one under the leaf kernel of the other)
-  struct Ws { gsdf_program::Arena &q0, &q1, &ctr, &spec_pass, &rec, &hdr, &grp, &bar; };
+  struct Ws { gsdf_program::Arena &q0, &q1, &ctr, &spec_pass, &rec, &hdr, &grp; };
   Ws w;
   explicit gsdf_mesh_job(gsdf_program* pp, int sl)
-      : p(pp), slot(sl), w(sl == 0 ? Ws{pp->q0, pp->q1, pp->ctr, pp->spec_pass, pp->rec, pp->hdr, pp->grp, pp->bar}
-                                   : Ws{pp->b_q0, pp->b_q1, pp->b_ctr, pp->b_spec_pass, pp->b_rec, pp->b_hdr, pp->b_grp, pp->b_bar}) {}
+      : p(pp), slot(sl), w(sl == 0 ? Ws{pp->q0, pp->q1, pp->ctr, pp->spec_pass, pp->rec, pp->hdr, pp->grp}
+                                   : Ws{pp->b_q0, pp->b_q1, pp->b_ctr, pp->b_spec_pass, pp->b_rec, pp->b_hdr, pp->b_grp}) {}
 
   int enqueue();            // one attempt: the whole chain onto the stream, nothing waited for
   int finish(bool* again);  // waits for it; *again: a capacity was short -- enqueue() once more (nothing was dropped silently)
@@ -68,7 +68,6 @@ struct gsdf_mesh_job {
 
 int gsdf_mesh_job::enqueue() {
     ctr_on_host = false;
-    used_all = false;
     MeshCounters& hc = *hcp;
     (void)hc;
     HIP_TRYM(w.q0.ensure(qcap * sizeof(Cube)));
@@ -151,30 +150,7 @@ int gsdf_mesh_job::enqueue() {
       for (int j = 0; j < S; j++) n_spec += 1u << (3 * j);
       // the resolve stage's statistics: a row of 16 counts per workgroup behind the pass bytes, added up by the first per-level
       // launch -- if there is one (else the resolve stage issues its atomics itself)
-      // One persistent launch for the whole prune phase (kernels_octree.h: prune_all_kernel) where its grid can be resident at
-      // once: G = workgroups per CU the kernel's registers and LDS allow (at most GSDF_HIP_PRUNE_ALL_BPC, default 2) x CUs.
-      // GSDF_HIP_PRUNE_ALL=0 keeps the chain of launches (cross-check in the tests); a handle on which a barrier ever timed out
-      // keeps it too.
-      static const bool use_all = [] { const char* e = getenv("GSDF_HIP_PRUNE_ALL"); return !e || atoi(e) != 0; }();
-      static const int all_bpc = [] { const char* e = getenv("GSDF_HIP_PRUNE_ALL_BPC"); return e ? atoi(e) : 2; }();
-      unsigned G = 0;
-      if (use_all && !p->prune_all_broken) {
-        if (p->prune_all_grid == 0) {
-          int nb = 0;
-          const hipError_t oe = p->f_prune_all ? hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, p->f_prune_all, BLOCK, lds_prune)
-                                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, prune_all_kernel, BLOCK, lds_prune);
-          if (oe != hipSuccess) { (void)hipGetLastError(); nb = 0; }
-          if (nb > all_bpc) nb = all_bpc;
-          p->prune_all_grid = nb >= 1 ? nb * p->num_cu : -1;
-        }
-        if (p->prune_all_grid > 0) G = (unsigned)p->prune_all_grid;
-      }
-      if (G) {
-        const bool fresh = w.bar.p == nullptr;
-        HIP_TRYM(w.bar.ensure(sizeof(GridBar)));
-        if (fresh) HIP_TRYM(hipMemsetAsync(w.bar.p, 0, sizeof(GridBar), s));
-      }
-      const unsigned rrows = G ? G : (n_spec + SPEC_STAGE - 1) / SPEC_STAGE;
+      const unsigned rrows = (n_spec + SPEC_STAGE - 1) / SPEC_STAGE;
       const size_t part_off = ((size_t)n_spec + 63) & ~(size_t)63;
       HIP_TRYM(w.spec_pass.ensure(part_off + (size_t)rrows * 16 * sizeof(unsigned)));
       const bool chain_follows = last_spec - 1 >= lq;
@@ -184,41 +160,22 @@ int gsdf_mesh_job::enqueue() {
       spec_mask = test_mask_of(pmask);
       const unsigned test_mask = test_mask_of(pmask);
       const int shard_level = opts.shard_count > 1 ? ls : -1;
-      if (G) {
-        const unsigned all_mask = (unsigned)pmask;  // 0 none, 1 all, else bit L = Level L (the kernel widens 1 itself)
-        if (p->f_prune_all) {
-          HIP_TRYM(launch_fn(p->f_prune_all, G, BLOCK, lds_prune, s, (const uint32_t*)p->d_code, (int)levels, (int)S, (int)lq, (unsigned)n_spec, (int)prune_cols,
-                             (int)p->prog.nslots, ox, oy, oz, res, (unsigned)all_mask, (int)ptest, (int)shard_level, (unsigned)opts.shard_rank,
-                             (unsigned)opts.shard_count, (uint8_t*)w.spec_pass.p, (unsigned*)spec_part, (Cube*)q[0]->p, (Cube*)q[1]->p,
-                             (unsigned long long)capq[0], (unsigned long long)capq[1], d_ctr, (unsigned)(clear_bytes / 4), (GridBar*)w.bar.p));
-        } else {
-          hipLaunchKernelGGL(prune_all_kernel, dim3(G), dim3(BLOCK), lds_prune, s, p->d_code, levels, S, lq, n_spec, prune_cols, p->prog.nslots, ox, oy, oz, res,
-                             all_mask, ptest, shard_level, (unsigned)opts.shard_rank, (unsigned)opts.shard_count, (uint8_t*)w.spec_pass.p, spec_part,
-                             (Cube*)q[0]->p, (Cube*)q[1]->p, (unsigned long long)capq[0], (unsigned long long)capq[1], d_ctr, (unsigned)(clear_bytes / 4),
-                             (GridBar*)w.bar.p);
-        }
-        HIP_TRYM(hipGetLastError());
-        used_all = true;
-        first_level = lq - 1;  // nothing left for the per-level launches
-        chain_first = last_spec - 1;
+      const unsigned sgrid = grid_for(n_spec, p->num_cu, 8);
+      if (p->f_prune_spec) {
+        HIP_TRYM(launch_fn(p->f_prune_spec, sgrid, BLOCK, lds_prune, s, (const uint32_t*)p->d_code, (int)levels, (unsigned)n_spec, (int)prune_cols,
+                           (int)p->prog.nslots, ox, oy, oz, res, (unsigned)test_mask, (int)ptest, (int)shard_level, (unsigned)opts.shard_rank,
+                           (unsigned)opts.shard_count, (uint8_t*)w.spec_pass.p, (unsigned*)d_ctr, (unsigned)(clear_bytes / 4)));
       } else {
-        const unsigned sgrid = grid_for(n_spec, p->num_cu, 8);
-        if (p->f_prune_spec) {
-          HIP_TRYM(launch_fn(p->f_prune_spec, sgrid, BLOCK, lds_prune, s, (const uint32_t*)p->d_code, (int)levels, (unsigned)n_spec, (int)prune_cols,
-                             (int)p->prog.nslots, ox, oy, oz, res, (unsigned)test_mask, (int)ptest, (int)shard_level, (unsigned)opts.shard_rank,
-                             (unsigned)opts.shard_count, (uint8_t*)w.spec_pass.p, (unsigned*)d_ctr, (unsigned)(clear_bytes / 4)));
-        } else {
-          hipLaunchKernelGGL(prune_spec_kernel, dim3(sgrid), dim3(BLOCK), lds_prune, s, p->d_code, levels, n_spec, prune_cols, p->prog.nslots, ox, oy,
-                             oz, res, test_mask, ptest, shard_level, (unsigned)opts.shard_rank, (unsigned)opts.shard_count, (uint8_t*)w.spec_pass.p,
-                             (unsigned*)d_ctr, (unsigned)(clear_bytes / 4));
-        }
-        HIP_TRYM(hipGetLastError());
-        hipLaunchKernelGGL(prune_resolve_kernel, dim3((n_spec + SPEC_STAGE - 1) / SPEC_STAGE), dim3(BLOCK), 0, s, (const uint8_t*)w.spec_pass.p, levels, S,
-                           n_spec, test_mask, (Cube*)q[last_spec & 1]->p, (unsigned long long)capq[last_spec & 1], d_ctr, spec_part);
-        HIP_TRYM(hipGetLastError());
+        hipLaunchKernelGGL(prune_spec_kernel, dim3(sgrid), dim3(BLOCK), lds_prune, s, p->d_code, levels, n_spec, prune_cols, p->prog.nslots, ox, oy,
+                           oz, res, test_mask, ptest, shard_level, (unsigned)opts.shard_rank, (unsigned)opts.shard_count, (uint8_t*)w.spec_pass.p,
+                           (unsigned*)d_ctr, (unsigned)(clear_bytes / 4));
+      }
+      HIP_TRYM(hipGetLastError());
+      hipLaunchKernelGGL(prune_resolve_kernel, dim3((n_spec + SPEC_STAGE - 1) / SPEC_STAGE), dim3(BLOCK), 0, s, (const uint8_t*)w.spec_pass.p, levels, S,
+                         n_spec, test_mask, (Cube*)q[last_spec & 1]->p, (unsigned long long)capq[last_spec & 1], d_ctr, spec_part);
+      HIP_TRYM(hipGetLastError());
       first_level = last_spec - 1;
       chain_first = first_level;
-      }
     }
     for (int level = first_level; level >= lq; level--) {
       const int expand = level != levels;
@@ -342,12 +299,6 @@ int gsdf_mesh_job::enqueue() {
 int gsdf_mesh_job::finish(bool* again) {
     MeshCounters& hc = *hcp;
     HIP_TRYM(hipEventSynchronize(ev_done));
-    if (used_all && hc.bar_fail) {  // a device-wide barrier of prune_all_kernel timed out: this handle goes back to the chain of launches
-      if (attempt >= 8) return (fail(GSDF_ERR_HIP, "prune_all_kernel: device-wide barrier timed out"));
-      p->prune_all_broken = true;
-      *again = true;
-      return GSDF_OK;
-    }
     if (hc.q_overflow) {  // a cube queue was too small: double and redo (exact: nothing was dropped silently)
       if (attempt >= 8) return (fail(GSDF_ERR_CAPACITY, "octree queue capacity exceeded"));
       qcap *= 4;

@@ -49,7 +49,7 @@ struct gsdf_program {
       return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-  } q0, q1, ctr, spec_pass, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, flat_grid, flat_bits, flat_list, rec, hdr, grp, bar, b_q0, b_q1, b_ctr, b_spec_pass, b_rec, b_hdr, b_grp, b_bar;  // bar: prune_all_kernel's device-wide barrier words (zeroed once, when allocated)   // b_*: the octree mesher's second workspace (its second chain in flight runs on stream_b, beside the first: gsdf_hip_mesh_octree_start)  // flat_bits: sign and near-surface bit planes of the flat renderer's lattice (flat_grid_kernel -> flat_cut_scan_kernel), flat_list: the cut cubes (-> flat_march_list_kernel)  // rec / hdr: cut-leaf records and block headers of the two-kernel leaf phase (the group sums follow the counters in ctr)  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
+  } q0, q1, ctr, spec_pass, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, flat_grid, flat_bits, flat_list, rec, hdr, grp, b_q0, b_q1, b_ctr, b_spec_pass, b_rec, b_hdr, b_grp;  // b_*: the octree mesher's second workspace (its second chain in flight runs on stream_b, beside the first: gsdf_hip_mesh_octree_start)  // flat_bits: sign and near-surface bit planes of the flat renderer's lattice (flat_grid_kernel -> flat_cut_scan_kernel), flat_list: the cut cubes (-> flat_march_list_kernel)  // rec / hdr: cut-leaf records and block headers of the two-kernel leaf phase (the group sums follow the counters in ctr)  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_b[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // second set: the octree mesher has up to two chains in flight (gsdf_hip_mesh_octree_start)
   static constexpr int kJobs = 2;
@@ -63,9 +63,7 @@ struct gsdf_program {
   uint64_t last_dc_cubes = 0;  // kept cubes of the previous dual contouring pass: sizes the next queues
   // run-time specialised kernels for this program (gsdf_hip_program_specialize): hiprtc module, else interpreter
   hipModule_t spec_mod = nullptr, spec_mod2 = nullptr, spec_mod3 = nullptr, spec_mod4 = nullptr;  // spec_mod4: leaf kernel rebuilt with a larger register budget; spec_mod2: second group, built on first use (see spec_aux); spec_mod3: eval kernel rebuilt for 3 workgroups per CU
-  hipFunction_t f_eval = nullptr, f_prune = nullptr, f_prune_spec = nullptr, f_prune_all = nullptr, f_leaf = nullptr;
-  int prune_all_grid = 0;   // workgroups of the one-launch prune phase (all resident: from the kernel's occupancy); -1: not available on this handle
-  bool prune_all_broken = false;  // a barrier of prune_all_kernel timed out on this handle: the chain of launches from here on
+  hipFunction_t f_eval = nullptr, f_prune = nullptr, f_prune_spec = nullptr, f_leaf = nullptr;
   hipFunction_t f_dc_origin = nullptr, f_dc_edges = nullptr, f_dc_normals = nullptr, f_normals = nullptr, f_image = nullptr, f_flat_grid = nullptr;
   bool spec_aux_tried = false;
   int spec_eval_k = 0, spec_eval_w = 0, spec_leaf_k = 0, spec_leaf_w = 0;

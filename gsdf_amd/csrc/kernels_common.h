@@ -38,7 +38,6 @@ struct MeshCounters {
   unsigned long long q_overflow;           // cube queue capacity exceeded
   unsigned long long n_points;             // lattice points evaluated by leaf_brick_kernel
   unsigned long long n_cut;                // leaves the surface cuts (records written by leaf_eval_kernel)
-  unsigned long long bar_fail;             // prune_all_kernel: a device-wide barrier timed out (the host reruns the mesh through the chain of launches)
 };
 
 // Decisions on a value that may be NaN (a distance of a degenerate tree, tests/test_gpu_nan.py), as CLASS / INTEGER tests on its

@@ -270,253 +270,6 @@ __global__ void __launch_bounds__(BLOCK) prune_resolve_kernel(const uint8_t* __r
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The whole prune phase in ONE launch (round 4). The chain above is five dependent launches for npt-flange at resdiv 1600
-// (speculative top, resolve, Levels 5, 4, 3): ~60 us of which little is work -- every launch pays its start (wave launch, the
-// first trip to the counters, a cold instruction cache for a few thousand lines of straight-line code) and the gap in front of
-// it. prune_all_kernel is the same stages as PHASES of one persistent grid -- G workgroups, all resident (the host sizes G from
-// the kernel's occupancy) -- separated by a device-wide barrier:
-//     clear + speculative tests | resolve | Level last_spec-1 | ... | Level lq
-// Same tests on the same centres, same queues, same counters as the chain; the survivors' order in the queues differs (it
-// differs from run to run in the chain too: the appends are atomic).
-// The barrier: arrivals are counted per group of workgroups (blockIdx & 7: eight words on eight cache lines -- a single word
-// takes ~88 atomics per microsecond, 512 arrivals on one word would be 6 us), the last arrival of a group reports to the root,
-// the last group publishes the generation everybody polls. One thread per workgroup, agent-scope fences on both sides
-// (release: L2 write-back, acquire: invalidate -- the XCDs' L2s are not coherent with each other), as a cooperative launch's
-// grid sync does. The words reset themselves; `gen` only ever counts up, so the buffer is zeroed once, when it is allocated.
-// A workgroup that waits longer than ~1 s gives up and flags the mesh (bar_fail): the host then reruns it through the chain.
-// The other kernels' progress never depends on this one, so a grid that is only partly resident (another mesh's evaluating
-// kernel holds the CUs) waits, it does not deadlock.
-struct GridBar {
-  unsigned cnt[8][32];  // arrivals per group, a 128-byte line each
-  unsigned root[32];    // groups complete
-  unsigned gen[32];     // barriers completed since the buffer was zeroed
-  unsigned broken[32];  // a wait timed out: everybody leaves
-};
-__device__ __forceinline__ bool grid_barrier(GridBar* b, unsigned G, unsigned& gen, unsigned* s_flag) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();  // release: this workgroup's stores and atomics are visible device-wide before it arrives
-    const unsigned grp = blockIdx.x & 7u;
-    const unsigned members = (G - grp + 7u) / 8u, groups = G < 8u ? G : 8u, want = gen + 1u;
-    if (atomicAdd(&b->cnt[grp][0], 1u) == members - 1u) {
-      atomicExch(&b->cnt[grp][0], 0u);  // (nobody of this group arrives again before the generation has moved on)
-      if (atomicAdd(&b->root[0], 1u) == groups - 1u) {
-        atomicExch(&b->root[0], 0u);
-        __threadfence();
-        atomicExch(&b->gen[0], want);
-      }
-    }
-    unsigned ok = 1u;
-    for (unsigned spin = 0; __hip_atomic_load(&b->gen[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want; spin++) {
-      if (spin > (1u << 20) || __hip_atomic_load(&b->broken[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-        atomicExch(&b->broken[0], 1u);
-        ok = 0u;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(4);
-    }
-    __threadfence();  // acquire: what the others stored before they arrived is what this workgroup reads from here on
-    *s_flag = ok;
-  }
-  __syncthreads();
-  gen = gen + 1u;
-  return *s_flag != 0u;
-}
-
-// LDS: prune_kernel's [2 * ncols floats per lane | PRUNE_STAGE cubes | 8 words | base]. Queues, pass bytes and counters are
-// written and read inside this one kernel: no const, no __restrict__ on them (a scalar or read-only-cache load would be stale).
-__global__ void __launch_bounds__(BLOCK) prune_all_kernel(const uint32_t* __restrict__ code_g, int top, int S, int lq, unsigned n_spec, int ncols,
-                                                          int lip_base, float ox, float oy, float oz, float res, unsigned pmask, int ptest,
-                                                          int shard_level, unsigned shard_rank, unsigned shard_count, uint8_t* pass,
-                                                          unsigned* part, Cube* qa, Cube* qb, unsigned long long cap_a,
-                                                          unsigned long long cap_b, MeshCounters* ctr, unsigned clear_words, GridBar* bar) {
-  code_ptr code = as_code(code_g);
-  float* lds = g_smem + threadIdx.x;
-  Cube* s_q = (Cube*)(g_smem + (size_t)(ncols > 0 ? ncols : 1) * 2 * BLOCK);
-  unsigned* s_w = (unsigned*)(s_q + PRUNE_STAGE);  // [0..3] wave totals, [4..7] per-wave "passed the test" counts
-  unsigned long long* s_base = (unsigned long long*)(s_w + 8);
-  __shared__ unsigned s_n, s_items[8], s_pass[8], s_flag, s_sum[16];
-  const unsigned G = gridDim.x;
-  const unsigned step = G * BLOCK;
-  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned gen = __hip_atomic_load(&bar->gen[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (no barrier completes before every workgroup has read it)
-  const unsigned test_mask = pmask == 1u ? 0xffffffffu : pmask;
-  const int last_spec = top - (S - 1);
-  // the chain's first kernel: it clears the counters and the group sums for everything behind it
-  for (unsigned k = blockIdx.x * BLOCK + threadIdx.x; k < clear_words; k += step) ((unsigned*)ctr)[k] = 0u;
-
-  for (int ph = 0;; ph++) {  // phase 0: the speculative block; phase k: Level last_spec - k
-    const bool spec = ph == 0;
-    const int level_u = spec ? top : last_spec - ph;
-    Cube* in = ((level_u + 1) & 1) ? qb : qa;
-    Cube* out = (level_u & 1) ? qb : qa;
-    const unsigned long long in_cap = ((level_u + 1) & 1) ? cap_b : cap_a, out_cap = (level_u & 1) ? cap_b : cap_a;
-    const int do_test = spec ? ptest : ((level_u >= 3 && ((test_mask >> level_u) & 1u) != 0u) ? ptest : 0);
-    const bool shard_here = !spec && shard_count > 1u && level_u == shard_level;
-    unsigned long long n_items = n_spec;
-    if (!spec) {
-      unsigned long long n_in = uniform_u64(__hip_atomic_load(&ctr->n_level[level_u + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      if (n_in > in_cap) n_in = in_cap;  // (the queue overflowed: the host grows the queues and reruns)
-      n_items = n_in * 8ull;
-      if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_items[level_u] = do_test ? n_items : 0ull;
-      if (ph == 1 && part != nullptr && blockIdx.x == 0) {  // the resolve stage's statistics, a row of 16 counts per workgroup (see prune_kernel)
-        if (threadIdx.x < 16u) s_sum[threadIdx.x] = 0u;
-        __syncthreads();
-        unsigned acc = 0;
-        for (unsigned r = threadIdx.x >> 4; r < G; r += BLOCK / 16) acc += part[r * 16u + (threadIdx.x & 15u)];
-        if (acc) atomicAdd(&s_sum[threadIdx.x & 15u], acc);
-        __syncthreads();
-        if (threadIdx.x < 16u) {
-          const int j = (int)(threadIdx.x >> 1), lv = top - j;
-          if (j < S) {
-            if (threadIdx.x & 1u) ctr->n_pass[lv] = (unsigned long long)s_sum[threadIdx.x];
-            else if (lv >= 3 && ((test_mask >> lv) & 1u) != 0u) ctr->n_items[lv] = (unsigned long long)s_sum[threadIdx.x];
-          }
-        }
-      }
-    }
-    unsigned long long my_pass = 0;
-    unsigned cur = 0;  // cubes staged so far (block-uniform)
-    // where a flush appends: this phase's level; the resolve pass below appends the survivors of the last speculative level
-    const int fl_level = spec ? last_spec : level_u;
-    Cube* fl_out = spec ? ((last_spec & 1) ? qb : qa) : out;
-    const unsigned long long fl_cap = spec ? ((last_spec & 1) ? cap_b : cap_a) : out_cap;
-    auto flush = [&]() {  // block-uniform
-      if (threadIdx.x == 0) *s_base = atomicAdd(&ctr->n_level[fl_level], (unsigned long long)cur);
-      __syncthreads();
-      const unsigned long long fb = *s_base;
-      if (fb + cur <= fl_cap) {
-        for (unsigned k = threadIdx.x; k < cur; k += BLOCK) fl_out[fb + k] = s_q[k];
-      } else if (threadIdx.x == 0) {
-        ctr->q_overflow = 1ull;
-      }
-      __syncthreads();
-      cur = 0;
-    };
-    for (unsigned long long base = (unsigned long long)blockIdx.x * BLOCK; base < n_items; base += step) {  // block-uniform trip count
-      const unsigned long long i = base + threadIdx.x;
-      const bool valid = i < n_items;
-      Cube c = {0, 0, 0, 0};
-      int level = level_u;
-      if (spec) {
-        unsigned k = 0;
-        const unsigned j = spec_level_of(valid ? (unsigned)i : 0u, k);
-        level = top - (int)j;
-        c = spec_cube(j, k);
-      } else if (valid) {
-        const Cube pc = in[i >> 3];
-        const unsigned k = (unsigned)(i & 7);
-        c.x = (uint16_t)(pc.x * 2 + ((k ^ (k >> 1)) & 1));
-        c.y = (uint16_t)(pc.y * 2 + ((k >> 1) & 1));
-        c.z = (uint16_t)(pc.z * 2 + ((k >> 2) & 1));
-      }
-      bool keep = true;
-      if (do_test) {  // block-uniform
-        const float size = (float)(1 << (level - 1)) * res;  // i3.Cube size at this level
-        const float maxDist = size * (1.73205080757f / 2);    // szDistMult = sqrt3/2 (octreerenderer.go:182)
-        const float cx0 = ox + size * (float)c.x, cy0 = oy + size * (float)c.y, cz0 = oz + size * (float)c.z;
-        P3 p;  // CubeCenter = Scale(0.5, Add(min, max)), max = min + size
-        p.x = 0.5f * (cx0 + (cx0 + size));
-        p.y = 0.5f * (cy0 + (cy0 + size));
-        p.z = 0.5f * (cz0 + (cz0 + size));
-        P3 pv[2] = {p, p};
-        float dv[2];
-        if (do_test == 2) {
-          gsdf_dev::sdf_eval<2>(code, pv, dv, lds, BLOCK);
-          keep = !nb::abs_ge(dv[0], maxDist);
-        } else {
-          gsdf_dev::sdf_eval<2, 0, true>(code, pv, dv, lds, BLOCK, false, maxDist, (uint32_t)lip_base);
-          keep = !(nb::ge0(dv[0]) || nb::le0(dv[1]));
-        }
-      }
-      if (spec) {
-        const bool tested = level >= 3 && ((test_mask >> level) & 1u) != 0u;
-        if (!tested) keep = true;
-        const bool own = level != shard_level || shard_count <= 1u || brick_owner(c.x, c.y, c.z, shard_count) == shard_rank;
-        if (valid) pass[i] = (uint8_t)((keep ? 1u : 0u) | (own ? 2u : 0u));
-        continue;
-      }
-      keep = keep && valid;
-      const unsigned long long pm = __ballot(keep);
-      if (lane == 0) my_pass += (unsigned long long)__builtin_popcountll(pm);
-      if (shard_here) keep = keep && (brick_owner(c.x, c.y, c.z, shard_count) == shard_rank);
-      const unsigned long long km = __ballot(keep);
-      const unsigned lane_prefix = __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
-      if (lane == 0) s_w[wave] = (unsigned)__builtin_popcountll(km);
-      __syncthreads();
-      const unsigned w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
-      const unsigned total = w0 + w1 + w2 + w3;
-      const unsigned wpre = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
-      if (cur + total > PRUNE_STAGE) flush();  // total <= 256 always fits afterwards
-      if (keep) s_q[cur + wpre + lane_prefix] = c;
-      cur += total;
-      __syncthreads();  // s_w is rewritten next iteration; s_q complete before a flush reads it
-    }
-    if (!spec) {
-      if (cur) flush();
-      if (shard_here) {  // "passed" differs from "kept" only where bricks are dealt to ranks (see prune_kernel)
-        if (lane == 0) s_w[4 + wave] = (unsigned)my_pass;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-          const unsigned long long t = (unsigned long long)s_w[4] + s_w[5] + s_w[6] + s_w[7];
-          if (t) atomicAdd(&ctr->n_pass[level_u], t);
-        }
-      }
-      if (level_u <= lq) return;  // the last level: the evaluating kernel follows on the stream
-      if (!grid_barrier(bar, G, gen, &s_flag)) { if (threadIdx.x == 0) ctr->bar_fail = 1ull; return; }
-      continue;
-    }
-    // ---- resolve (prune_resolve_kernel's pass): cube i of the speculative block lives on iff it and every ancestor passed
-    if (!grid_barrier(bar, G, gen, &s_flag)) { if (threadIdx.x == 0) ctr->bar_fail = 1ull; return; }
-    if (threadIdx.x < 8) { s_items[threadIdx.x] = 0; s_pass[threadIdx.x] = 0; }
-    const unsigned per = (n_spec + G - 1u) / G;  // a contiguous slice per workgroup, PRUNE_STAGE cubes at a time
-    const unsigned i0 = blockIdx.x * per < n_spec ? blockIdx.x * per : n_spec, i1 = i0 + per < n_spec ? i0 + per : n_spec;
-    for (unsigned sub = i0; sub < i1; sub += PRUNE_STAGE) {  // block-uniform
-      if (threadIdx.x == 0) s_n = 0;
-      __syncthreads();
-      const unsigned lim = sub + PRUNE_STAGE < i1 ? sub + PRUNE_STAGE : i1;
-      for (unsigned b2 = sub; b2 < lim; b2 += BLOCK) {
-        const unsigned i = b2 + threadIdx.x;
-        if (i >= lim) continue;
-        unsigned k = 0;
-        const unsigned j = spec_level_of(i, k);
-        unsigned anc = 1u;  // every proper ancestor passed and was owned (no short circuit: the loads are independent)
-        unsigned kk = k, off = i - k;
-        for (unsigned a = j; a > 0; a--) {
-          kk >>= 3;
-          off = (off - 1u) >> 3;  // off(a-1) = (off(a) - 1) / 8
-          anc &= pass[off + kk] == 3u ? 1u : 0u;
-        }
-        const unsigned me = pass[i];
-        if (anc) {  // a candidate of the per-level chain
-          atomicAdd(&s_items[j], 1u);
-          if (me & 1u) atomicAdd(&s_pass[j], 1u);
-          if (me == 3u && (int)j == S - 1) s_q[atomicAdd(&s_n, 1u)] = spec_cube(j, k);  // (at most PRUNE_STAGE per sub-slice)
-        }
-      }
-      __syncthreads();
-      cur = s_n;
-      if (cur) flush(); else __syncthreads();
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      if (part != nullptr) {  // statistics as a row of counts; the first level phase adds the rows up
-        for (int j = 0; j < 8; j++) { part[blockIdx.x * 16u + 2u * j] = s_items[j]; part[blockIdx.x * 16u + 2u * j + 1u] = s_pass[j]; }
-      } else {
-        for (int j = 0; j < S && j < 8; j++) {
-          const int lv = top - j;
-          const bool tested = lv >= 3 && ((test_mask >> lv) & 1u) != 0u;
-          if (s_items[j] && tested) atomicAdd(&ctr->n_items[lv], (unsigned long long)s_items[j]);
-          if (s_pass[j]) atomicAdd(&ctr->n_pass[lv], (unsigned long long)s_pass[j]);
-        }
-      }
-    }
-    if (last_spec <= lq) return;  // no level below the speculative block
-    if (!grid_barrier(bar, G, gen, &s_flag)) { if (threadIdx.x == 0) ctr->bar_fail = 1ull; return; }
-  }
-}
-
 // mcInterpolate (marchcubes.go:76-98) with x = 0.
 __device__ __forceinline__ void mc_interp(float ax, float ay, float az, float bx, float by, float bz, float v1, float v2,
                                           float& rx, float& ry, float& rz) {
