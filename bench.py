@@ -309,7 +309,9 @@ def main():
                          "finished inside the timed region)")
     ap.add_argument("--no-gather-pipeline", action="store_true",
                     help="N > 1: wait for a mesh's gather before meshing the next (default: the payload of mesh i moves while mesh i+1 is made)")
-    ap.add_argument("--share-corners", action="store_true", help="evaluate each bitwise-distinct lattice corner of a brick once (same triangles, fewer evals)")
+    ap.add_argument("--share-corners", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2],
+                    help="0: every corner of every leaf, as the reference (headline); 1: each bitwise-distinct lattice corner of a brick once (older fused kernel); "
+                         "2: the bitwise-distinct z rows of a brick once each (same kernels, same triangles, a quarter fewer evaluations)")
     args = ap.parse_args()
 
     import numpy as np
@@ -401,7 +403,7 @@ def main():
     gmode = {"all": hip.GATHER_ALL, "root": hip.GATHER_ROOT, "none": hip.GATHER_NONE}[args.gather]
     pipeline = comm is not None and not args.no_gather_pipeline
     # what moves in the gather: packed cut-leaf records by default (marching cubes then runs on the receiving ranks)
-    records = (comm is not None and args.payload == "records" and args.gather != "none" and args.renderer == "octree" and not args.share_corners)
+    records = (comm is not None and args.payload == "records" and args.gather != "none" and args.renderer == "octree" and args.share_corners != 1)
     payload = hip.PAYLOAD_RECORDS if records else hip.PAYLOAD_TRIANGLES
     gstat = {"n": 0, "ms_counts": 0.0, "ms_payload": 0.0, "ms_march": 0.0, "bytes_received": 0, "bytes_sent": 0}
     pending = []  # at most one gather in flight: (PendingGather)
@@ -441,19 +443,20 @@ def main():
     # start-up run 5 % slower (1.70 vs 1.61 ms leaf kernel), and with the contract's small W they would be the ones timed.
     mesh_pipeline = (comm is None and not torch_gather and args.renderer == "octree" and not args.no_mesh_pipeline)
 
-    def run_meshes(n, account=None):
+    def run_meshes(n, account=None, sc=None):
         """n meshes, every one started and finished inside this call. Pipelined (N = 1): mesh k + 1 is started -- its chain of kernels
         enqueued, on the handle's other workspace and stream -- before mesh k is waited for."""
         last = None
+        sc = args.share_corners if sc is None else sc
         if not mesh_pipeline:
             for _ in range(n):
                 last = step()
                 if account:
                     account(last[0])
             return last
-        pend = hip.OctreeHIP.start(sdf, res, share_corners=args.share_corners) if n > 0 else None
+        pend = hip.OctreeHIP.start(sdf, res, share_corners=sc) if n > 0 else None
         for k in range(n):
-            nxt = hip.OctreeHIP.start(sdf, res, share_corners=args.share_corners) if k + 1 < n else None
+            nxt = hip.OctreeHIP.start(sdf, res, share_corners=sc) if k + 1 < n else None
             last = (pend.wait(), None)
             if account:
                 account(last[0])
@@ -546,7 +549,8 @@ def main():
                        "sharding": (("z-slabs of the lattice, halo recomputed" if dc else "octree bricks by coordinate hash")
                                     + ((", gather of " + ("packed cut-leaf records (marching cubes after the gather)" if records else "triangles") + " inside the library over " + comm.transport() + " (gsdf_hip_mesh_gatherv_start/_wait): mode " + args.gather
                                         + (", payload of mesh i overlapped with mesh i+1" if pipeline else ", not pipelined")) if comm is not None else ", RCCL all-gatherv of triangles through torch.distributed (fallback)")) if (world > 1 or comm is not None) else "single GPU",
-                       "leaf_corners": "shared (distinct lattice points once)" if args.share_corners else "8 per leaf (as the reference)",
+                       "leaf_corners": {0: "8 per leaf (as the reference)", 1: "shared (distinct lattice points once)",
+                                        2: "the bitwise-distinct z rows of a brick once each (evals_per_step counts the evaluations performed)"}[args.share_corners],
                        "evaluator": spec_note, "code": code,
                        "setup": f"{args.preheat} untimed meshes before the warmup steps (clock ramp)",
                        "steps": ("meshes pipelined two deep on one handle (gsdf_hip_mesh_octree_start / _wait): mesh k+1's kernels are enqueued before mesh k "
@@ -582,6 +586,25 @@ def main():
                                         "note": "one blocking mesh at a time (measured after the timed loop): the kernel with the GPU to itself"}
             out["roofline"]["note"] += ("; the timed loop keeps two meshes in flight on two streams, so kernel_ms / achieved / frac above are the kernel's "
                                         "duration while it shares the CUs with the other mesh's kernels -- 'alone' is the same kernel by itself")
+        if mesh_pipeline and not dc and args.share_corners == 0:
+            # Beside the headline, not in it: the same mesh with every bitwise-distinct z row of a brick evaluated once
+            # (gsdf_mesh_opts.share_corners = 2; the triangle set is bit-identical, tests/test_gpu_mesh.py) -- time to mesh for a
+            # caller who does not need the reference's evaluation count. Same pipelined loop, after the timed region.
+            run_meshes(5, sc=2)
+            dacc = {"evals": 0, "tris": 0}
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_meshes(args.steps, lambda o: (dacc.__setitem__("evals", dacc["evals"] + o.stats.evals), dacc.__setitem__("tris", dacc["tris"] + o.stats.n_tris)), sc=2)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            al2 = [hip.OctreeHIP(sdf, res, share_corners=2).stats for _ in range(8)][2:]
+            out["distinct_rows"] = {"ms_per_step": dt2 / args.steps * 1e3, "triangles_per_s": dacc["tris"] / dt2, "triangles_per_step": dacc["tris"] / args.steps,
+                                    "evals_performed_per_step": dacc["evals"] / args.steps, "evals_performed_per_s": dacc["evals"] / dt2,
+                                    "reference_evals_per_s": evals_all / dt2,
+                                    "kernel": sdf.info()["kernels"].get("leaf_rows"),
+                                    "alone": {"kernel_ms": sum(a.ms_march for a in al2) / len(al2), "ms_per_mesh_device": sum(a.ms_total for a in al2) / len(al2)},
+                                    "note": "gsdf_mesh_opts.share_corners = 2: rows 2k-1 and 2k of a brick's eight z rows of corners are the same plane and mostly the same float; "
+                                            "each distinct row is evaluated once. Bit-identical triangle set; not the headline, which performs every evaluation the reference performs"}
         if comm is not None and gstat["n"]:
             n = gstat["n"]
             g_ms = (gstat["ms_counts"] + gstat["ms_payload"]) / n

@@ -196,6 +196,36 @@ void spec_aux(gsdf_program* p) {
   }
 }
 
+// leaf_eval_kernel with distinct z rows (kernels_octree.h: DZ) for a specialised handle whose leaf phase runs four points per
+// lane: the one-body form at the occupancy the handle's evaluating kernel has, then at four workgroups per CU, then the two-site
+// form; the first that builds without scratch is taken. Failure leaves the interpreter's DZ kernel in use.
+void spec_leaf_dz(gsdf_program* p) {
+  if (!p->spec_mod || p->spec_dz_tried || p->prog.is2d) return;
+  p->spec_dz_tried = true;
+  int lk, lw;
+  size_t lds_m;
+  p->leaf_config(&lk, &lw, &lds_m);
+  if (fused_leaf() || lk != 4 || !p->f_leaf || p->spec_leaf_k != 4) return;
+  const std::string nt = p->leaf_nt_in_lds() ? "true" : "false";
+  std::vector<std::string> names;
+  std::vector<int> ws;
+  std::vector<bool> both;
+  auto add = [&](int w, bool b) {
+    for (size_t i = 0; i < ws.size(); i++) if (ws[i] == w && both[i] == b) return;
+    names.push_back("leaf_eval_kernel<4, " + std::to_string(w) + ", true, " + nt + (b ? ", true, true>" : ", false, true>"));
+    ws.push_back(w); both.push_back(b);
+  };
+  if (p->spec_leaf_both) { add(p->spec_leaf_w, true); add(lw, true); }
+  add(p->spec_leaf_w, false); add(lw, false);
+  std::vector<hipFunction_t> f;
+  if (spec_build(p, names, &p->spec_mod_dz, f, &p->spec_compile_s) != GSDF_OK) return;
+  for (size_t i = 0; i < names.size(); i++) {
+    const bool ok = fn_scratch_bytes(f[i]) == 0;
+    spec_report("specialised", names[i], f[i], ok && !p->f_leaf_dz);
+    if (ok && !p->f_leaf_dz) { p->f_leaf_dz = f[i]; p->spec_leaf_dz_w = ws[i]; p->spec_leaf_dz_both = both[i]; }
+  }
+}
+
 // Compile and load kernels specialised for this handle's program (specialize.cpp): eval, prune and leaf kernels of
 // the configuration the mesher would pick. Afterwards gsdf_hip_eval*/gsdf_hip_mesh_octree launch them instead of the
 // interpreter kernels; results are bit-identical (same statements, same compiler flags). Idempotent.
@@ -318,13 +348,15 @@ extern "C" int gsdf_hip_program_kernels(const gsdf_program* p, char* dst, size_t
   const int ew = se ? p->spec_eval_w : p->sweep_waves(ek);
   // ahead-of-time leaf kernels exist at the scratch-free occupancies only (see gsdf_hip_mesh_octree)
   const int aw = lk == 4 ? (lw == 2 ? 2 : 3) : (lk == 2 ? 3 : 4);
-  char buf[384];
+  char buf[512];
   if (p->prog.is2d)
     snprintf(buf, sizeof buf, "eval=eval_kernel<2,%d,%d>:%s", ek, ew, se ? "specialised" : "interpreter");
   else
     snprintf(buf, sizeof buf, "eval=eval_kernel<3,%d,%d>:%s leaf=%s<%d,%d%s>:%s prune=prune_kernel:%s", ek, ew, se ? "specialised" : "interpreter",
              fused_leaf() ? "leaf_kernel" : "leaf_eval_kernel", lk, sl ? p->spec_leaf_w : aw, sl && p->spec_leaf_both ? ",both" : "", sl ? "specialised" : "interpreter",
              p->f_prune ? "specialised" : "interpreter");
+  if (p->f_leaf_dz && strlen(buf) + 64 < sizeof buf)  // the evaluating kernel of share_corners = 2, once it has been built
+    snprintf(buf + strlen(buf), sizeof buf - strlen(buf), " leaf_rows=leaf_eval_kernel<4,%d%s,rows>:specialised", p->spec_leaf_dz_w, p->spec_leaf_dz_both ? ",both" : "");
   if (p->spec_mod && strlen(buf) + 32 < sizeof buf) { strcat(buf, " compiler="); strcat(buf, p->spec_compiler.c_str()); }
   {  // identity of the code that runs: a stored profile describes this handle's kernels only if it carries the same key
     const std::string key = p->spec_mod ? p->spec_key : gsdf_dev::spec_library_key();
@@ -413,6 +445,7 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (p->spec_mod2) (void)hipModuleUnload(p->spec_mod2);
   if (p->spec_mod3) (void)hipModuleUnload(p->spec_mod3);
   if (p->spec_mod4) (void)hipModuleUnload(p->spec_mod4);
+  if (p->spec_mod_dz) (void)hipModuleUnload(p->spec_mod_dz);
   p->q0.release(); p->q1.release(); p->ctr.release();
   p->rec.release(); p->hdr.release(); p->grp.release();
   p->b_q0.release(); p->b_q1.release(); p->b_ctr.release(); p->b_spec_pass.release(); p->b_rec.release(); p->b_hdr.release(); p->b_grp.release();

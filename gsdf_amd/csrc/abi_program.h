@@ -68,6 +68,11 @@ struct gsdf_program {
   bool spec_aux_tried = false;
   int spec_eval_k = 0, spec_eval_w = 0, spec_leaf_k = 0, spec_leaf_w = 0;
   bool spec_leaf_both = false;  // the specialised leaf kernel has both column passes in one body (kernels_octree.h: BOTH)
+  // distinct z rows (gsdf_mesh_opts.share_corners = 2; kernels_octree.h: DZ): built the first time a mesh asks for it (spec_leaf_dz)
+  hipModule_t spec_mod_dz = nullptr;
+  hipFunction_t f_leaf_dz = nullptr;
+  bool spec_dz_tried = false, spec_leaf_dz_both = false;
+  int spec_leaf_dz_w = 0;
   double spec_compile_s = 0;
   std::string spec_compiler;  // hipcc | hiprtc | cache: what built the specialised kernels
   std::string spec_key;       // key of that build (specialize.cpp: build_key)
@@ -148,6 +153,8 @@ inline unsigned grid_for(uint64_t n, int num_cu, int blocks_per_cu) {
 // Second group of a specialised handle (dual contouring, normals, flat lattice pass, image renderer), built on first use:
 // abi_eval.hip.
 void spec_aux(gsdf_program* p);
+// The evaluating kernel with distinct z rows for a specialised handle, built on first use: abi_eval.hip.
+void spec_leaf_dz(gsdf_program* p);
 
 namespace {
 // ms3.Box.ScaleCentered(1.01) = NewCenteredBox(Center(), MulElem(scale, Size())) [external]; float32, unfused.

@@ -104,33 +104,59 @@ __device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t n
 // an edge that cannot hold the minimum for ANY point of the wave, or that no point of the wave can cross, does not
 // change a single bit of the result. With B = the bounding box of the wave's K*64 points (centre c, half diagonal rb)
 // and dc(e) = distance from c to edge e, every point p of the wave has dist(p, e) in [dc(e) - rb, dc(e) + rb]; so with
-// U = min over e of dc(e) + rb, an edge with dc(e) - rb > U + margin is never the nearest one. The margin (1e-5 of the
-// largest |p - v|, |e|, |c| magnitude entering any of these sums -- the float error of the compared quantities is < 1e-6
-// of that) keeps the decision on the safe side: a doubtful edge is evaluated. The winding predicates of an edge are
+// U = min over e of dc(e) + rb, an edge with dc(e) - rb > U is never the nearest one. Both sides are padded by a margin (1e-5 of
+// the largest |p - v|, |e|, |c| magnitude entering the edge's own sums -- the float error of the compared quantities is < 1e-6
+// of that) that keeps the decision on the safe side: a doubtful edge is evaluated. The winding predicates of an edge are
 // (p.y >= v1.y, p.y < v2.y, cross > 0) and flip the sign only when all three agree: if the whole box lies at or above
 // both endpoints the first two are (true, false), if it lies below both (false, true), for every point -- no flip,
 // decided with exact comparisons. Lane e works out edge e (nv <= 64); NaN/Inf anywhere makes every test fail towards
 // "evaluate". For the npt-flange thread profile (12 edges) a brick's wave keeps 2-4 edges.
-// Wave64 min / max with DPP row shifts and row broadcasts (v_min/max_f32 with a DPP operand: no LDS crossbar, no address
-// registers, no lgkmcnt wait -- a ds_bpermute butterfly costs about three times as much). Inclusive scan within each row of
-// 16 lanes (row_shr 1, 2, 4, 8; lanes without a source keep their own value), then lane 15 of rows 0 and 2 into rows 1
-// and 3 (row_bcast:15), then lane 31 into rows 2 and 3 (row_bcast:31): lane 63 holds the result, read back as a scalar.
-// All 64 lanes must be active.
+// Wave64 min / max with DPP row shifts and row broadcasts: v_min / v_max_f32 WITH the DPP operand, one instruction per step (no
+// LDS crossbar, no address registers, no lgkmcnt wait). Inclusive scan within each row of 16 lanes (row_shr 1, 2, 4, 8; lanes
+// without a source are disabled and keep their own value), then lane 15 of rows 0 and 2 into rows 1 and 3 (row_bcast:15), then
+// lane 31 into rows 2 and 3 (row_bcast:31): lane 63 holds the result, read back as a scalar. All 64 lanes must be active.
+// Written as assembly because the compiler does not fold a DPP move into a float min / max (its combiner knows identities for
+// the integer operations only): v_mov + v_mov_dpp + v_min per step -- three instructions and a wait state where one does, and
+// the polygon culling below is six such reductions per brick and pass (round 4: 250 of the ~700 instructions a threaded brick
+// of npt-flange costs per pass). A DPP operand needs two wait states behind the instruction that wrote its register: the four
+// reductions of a box are interleaved (three independent instructions between a step and the next of the same chain), a single
+// reduction pays s_nop 1 per step.
+#define GSDF_DPP4(op_a, op_b, op_c, op_d, ctrl)          \
+  op_a "_dpp %0, %0, %0 " ctrl "\n\t" op_b "_dpp %1, %1, %1 " ctrl "\n\t" op_c "_dpp %2, %2, %2 " ctrl "\n\t" op_d "_dpp %3, %3, %3 " ctrl "\n\t"
+// a, c: minima; b, d: maxima -- over the wave, returned in every lane's copy as wave-uniform values
+__device__ __forceinline__ void wave_box(float& a, float& b, float& c, float& d) {
+  asm volatile("s_nop 1\n\t"
+               GSDF_DPP4("v_min_f32", "v_max_f32", "v_min_f32", "v_max_f32", "row_shr:1 row_mask:0xf bank_mask:0xf")
+               GSDF_DPP4("v_min_f32", "v_max_f32", "v_min_f32", "v_max_f32", "row_shr:2 row_mask:0xf bank_mask:0xf")
+               GSDF_DPP4("v_min_f32", "v_max_f32", "v_min_f32", "v_max_f32", "row_shr:4 row_mask:0xf bank_mask:0xf")
+               GSDF_DPP4("v_min_f32", "v_max_f32", "v_min_f32", "v_max_f32", "row_shr:8 row_mask:0xf bank_mask:0xf")
+               GSDF_DPP4("v_min_f32", "v_max_f32", "v_min_f32", "v_max_f32", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+               GSDF_DPP4("v_min_f32", "v_max_f32", "v_min_f32", "v_max_f32", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+               "s_nop 1"
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  a = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(a), 63));
+  b = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(b), 63));
+  c = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(c), 63));
+  d = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d), 63));
+}
+#undef GSDF_DPP4
 template <bool MAX>
 __device__ __forceinline__ float wave_minmax(float v) {
-#define GSDF_DPP_STEP(ctrl, rmask)                                                                                          \
-  {                                                                                                                         \
-    const float o = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), \
-                                                                          (ctrl), (rmask), 0xf, false));                     \
-    v = MAX ? dm::maxf(v, o) : dm::minf(v, o);                                                                              \
+  if (MAX) {
+#define GSDF_DPP_CHAIN(op)                                                                                                   \
+  asm volatile("s_nop 1\n\t" op "_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                  \
+               "s_nop 1\n\t" op "_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                                  \
+               "s_nop 1\n\t" op "_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                                  \
+               "s_nop 1\n\t" op "_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                                  \
+               "s_nop 1\n\t" op "_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                               \
+               "s_nop 1\n\t" op "_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                               \
+               "s_nop 1"                                                                                                     \
+               : "+v"(v))
+    GSDF_DPP_CHAIN("v_max_f32");
+  } else {
+    GSDF_DPP_CHAIN("v_min_f32");
   }
-  GSDF_DPP_STEP(0x111, 0xf)  // row_shr:1
-  GSDF_DPP_STEP(0x112, 0xf)  // row_shr:2
-  GSDF_DPP_STEP(0x114, 0xf)  // row_shr:4
-  GSDF_DPP_STEP(0x118, 0xf)  // row_shr:8
-  GSDF_DPP_STEP(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
-  GSDF_DPP_STEP(0x143, 0xc)  // row_bcast:31 into rows 2 and 3
-#undef GSDF_DPP_STEP
+#undef GSDF_DPP_CHAIN
   return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
 }
 
@@ -143,8 +169,7 @@ __device__ __forceinline__ void poly_cull(code_ptr code, uint32_t q0, uint32_t n
     x0 = minf(x0, pv[kp].x); x1 = maxf(x1, pv[kp].x);
     y0 = minf(y0, pv[kp].y); y1 = maxf(y1, pv[kp].y);
   }
-  x0 = wave_minmax<false>(x0); x1 = wave_minmax<true>(x1);
-  y0 = wave_minmax<false>(y0); y1 = wave_minmax<true>(y1);
+  wave_box(x0, x1, y0, y1);
   const uint32_t lane = lane_id();
   const bool valid = lane < nv;
   const v4f* rec = (const v4f*)((const float*)(uintptr_t)code + q0 + 8u * (valid ? lane : 0u));  // this lane's edge record (32-byte aligned)
@@ -156,13 +181,13 @@ __device__ __forceinline__ void poly_cull(code_ptr code, uint32_t q0, uint32_t n
   const float t = __builtin_amdgcn_fmed3f((wx * ex + wy * ey) / n2e, 0.f, 1.f);
   const float bx = wx - t * ex, by = wy - t * ey;
   const float dc = sqrtf_(bx * bx + by * by);
-  float U = valid ? dc + rb : __builtin_inff();
-  // (|c| too: the rounded centre may sit half an ulp of its own magnitude off the box's true centre)
-  float S = valid ? sqrtf_(wx * wx + wy * wy) + sqrtf_(n2e) + rb + absf(cx) + absf(cy) : 0.0f;
-  U = wave_minmax<false>(U);
-  S = wave_minmax<true>(S);
-  const float margin = 1.0e-5f * S;
-  keepd = __builtin_amdgcn_ballot_w64(valid && !(dc - rb > U + margin));
+  // Each edge pads its OWN interval by its OWN error bound: m = 1e-5 of the largest magnitude entering its sums, |w|, |e|, rb, |c|
+  // in the 1-norm (no square roots; |c| too: the rounded centre may sit half an ulp of its own magnitude off the box's true
+  // centre) -- the float error of dc -+ rb is below 1e-6 of that. Edge e is never the nearest one if its padded lower bound lies
+  // above the smallest padded upper bound. (Round 3 padded every edge by the largest m of the wave: one more reduction.)
+  const float m = 1.0e-5f * (absf(wx) + absf(wy) + absf(ex) + absf(ey) + rb + absf(cx) + absf(cy));
+  const float U = wave_minmax<false>(valid ? (dc + rb) + m : __builtin_inff());
+  keepd = __builtin_amdgcn_ballot_w64(valid && !((dc - rb) - m > U));
   keeps = __builtin_amdgcn_ballot_w64(valid && !((y0 >= v1y && y0 >= v2y) || (y1 < v1y && y1 < v2y)));
 }
 

@@ -639,15 +639,17 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
 #define REC_WORDS 10            // dwords per record
 #define REC_BLOCK (64 * REC_WORDS)  // dwords per 64-leaf block
 #define MARCH_GROUP 64              // blocks per entry of the group sums (records, triangles, active leaves) the evaluating kernel accumulates
-// One 64-bit word per group: records in bits 0..19 (<= 64 blocks x 64), triangles in bits 20..41 (<= 5 per record), leaves
-// that passed the corner-0 test in bits 42..63 (<= 4096): the fields cannot carry into each other. The statistics ride on the
+// One 64-bit word per group: records in bits 0..19 (<= 64 blocks x 64 = 4096), triangles in bits 20..35 (<= 5 per record: 20 480),
+// leaves that passed the corner-0 test in bits 36..49 (<= 4096), z rows evaluated in bits 50..63 (distinct-row bricks, DZ: <= 8
+// per block, 512): the fields cannot carry into each other. The statistics ride on the
 // same fire-and-forget atomic as the offsets -- spread over thousands of words -- because as three atomics per workgroup on
 // two counter lines they were what bounded the kernel for a cheap tree: 16 384 workgroups x 3 at ~9 ns each = npt-flange's
 // whole 0.46 ms (without them 0.42 ms, and the instruction savings of this round finally show).
-#define PSUM_PACK(r, t, a) ((unsigned long long)(r) | ((unsigned long long)(t) << 20) | ((unsigned long long)(a) << 42))
+#define PSUM_PACK(r, t, a, z) ((unsigned long long)(r) | ((unsigned long long)(t) << 20) | ((unsigned long long)(a) << 36) | ((unsigned long long)(z) << 50))
 #define PSUM_REC(v) ((unsigned)((v) & 0xfffffull))
-#define PSUM_TRI(v) ((unsigned)(((v) >> 20) & 0x3fffffull))
-#define PSUM_ACT(v) ((unsigned)((v) >> 42))
+#define PSUM_TRI(v) ((unsigned)(((v) >> 20) & 0xffffull))
+#define PSUM_ACT(v) ((unsigned)(((v) >> 36) & 0x3fffull))
+#define PSUM_ROWS(v) ((unsigned)((v) >> 50))
 
 // UCUBE: lq == 3 (every mesh of three levels or more): the 64 leaves of a wave pass are one level-3 cube.
 // NTLDS: the triangles-per-case table sits in LDS behind the interpreter's columns; false when exactly those 256 bytes would
@@ -658,7 +660,15 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_kernel(const uint32_t* __re
 // in one body, so the compiler's value numbering computes such subexpressions once per lane for all eight z instead of once per
 // pass (npt-flange: hypot, atan2 and the thread's x,y terms; -4 % kernel time at the same register budget). Same statements on
 // the same values.
-template <int K, int WAVES, bool UCUBE = true, bool NTLDS = true, bool BOTH = false>
+// DZ (gsdf_mesh_opts.share_corners = 2; K = 4 column bricks): DISTINCT Z ROWS. The eight z rows of a brick are A0, A0+res, A1,
+// A1+res, A2, ... with A_k = oz + res * (bz + k): row 2k-1 (the far corners of leaf layer k-1, (O + res*(i-1)) + res) and row 2k (the
+// near corners of layer k, O + res*i) are the same plane, and the SAME FLOAT on 64-73 % of the planes at resdiv 1600. Equal bits
+// in, equal bits out: a brick has 5..8 distinct rows (wave-uniform: the z of a brick is), only those are evaluated -- four in a
+// first pass, the remaining 1, 2 or 4 in a second pass with as many points per lane -- and every leaf corner reads the row that
+// holds its coordinate's value. Same distances, same records, same triangles; 24 % fewer evaluations on average. The reference
+// evaluates every corner of every leaf (marchcubes.go:24-31), so this is an option, not the default; the rows evaluated travel in
+// the group sums (statistics: MeshCounters.n_points).
+template <int K, int WAVES, bool UCUBE = true, bool NTLDS = true, bool BOTH = false, bool DZ = false>
 __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
                                                           unsigned long long cube_cap, int lq, int nslots, float ox, float oy, float oz,
                                                           float res, uint32_t* __restrict__ hdr, uint32_t* __restrict__ rec,
@@ -704,6 +714,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
     const bool valid = UCUBE ? uniform_u64(base + (threadIdx.x & ~63u)) < n_leaves : i < n_leaves;
     Cube lf = {0, 0, 0, 0};
     unsigned nact = 0;  // leaves of this wave pass that pass the corner-0 test (wave-uniform)
+    unsigned zrows = 8u;  // z rows of the brick that were evaluated (wave-uniform; fewer than 8 with DZ)
     const unsigned long long cw = cw_next;
     if (UCUBE) {
       cw_next = cube_word(base + step);
@@ -754,7 +765,62 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
     _Pragma("unroll") for (int j = 0; j < 8 - K; j++) dall[j] = dall[j + K]; \
     _Pragma("unroll") for (int kp = 0; kp < K; kp++) dall[8 - K + kp] = dk[kp]; \
   }
-      if (BOTH) {
+      unsigned rowmask = 0xffu, nrows = 8u;  // rows evaluated (bit r), wave-uniform
+      if (DZ && K == 4) {
+        // rows 2k-1 and 2k (k = 1..3): the same float? (bits, not ==: -0 and +0 are different points to an evaluator)
+        unsigned mism = 0u;
+#pragma unroll
+        for (unsigned k = 1; k < 4; k++) {
+          const float far = (oz + res * (float)(uint16_t)(bz + k - 1u)) + res, near = oz + res * (float)(uint16_t)(bz + k);
+          mism |= (__float_as_uint(far) != __float_as_uint(near) ? 1u : 0u) << (k - 1u);
+        }
+        mism = __builtin_amdgcn_readfirstlane(mism);
+        rowmask = 0xabu | ((mism & 1u) << 2) | ((mism & 2u) << 3) | ((mism & 4u) << 4);  // rows 0, 1, 3, 5, 7 always; 2, 4, 6 where they differ
+        nrows = (unsigned)__builtin_popcount(rowmask);
+        zrows = nrows;
+        // slot s (s-th distinct row) -> its row number, a nibble each; slots beyond nrows repeat row 7 (evaluated with a tail pass, never read)
+        unsigned rowsw = 0u, mr = rowmask;
+#pragma unroll
+        for (unsigned sl = 0; sl < 8; sl++) {
+          const unsigned r = mr ? (unsigned)__builtin_ctz(mr) : 7u;
+          mr &= mr - 1u;
+          rowsw |= r << (4u * sl);
+        }
+#define GSDF_ROWS_PASS(KK, NIB0, D0)                                                        \
+  {                                                                                          \
+    P3 pk[KK];                                                                               \
+    float dk[KK];                                                                            \
+    _Pragma("unroll") for (int kp = 0; kp < KK; kp++) {                                      \
+      const unsigned r = (rowsw >> (4u * ((NIB0) + (unsigned)kp))) & 7u; /* wave-uniform */  \
+      const float za = oz + res * (float)(uint16_t)(bz + (r >> 1));                          \
+      pk[kp].x = px;                                                                         \
+      pk[kp].y = py;                                                                         \
+      pk[kp].z = (r & 1u) ? za + res : za;                                                   \
+    }                                                                                        \
+    gsdf_dev::sdf_eval<KK, 2>(code, pk, dk, lds, BLOCK, /*brick=*/true);                     \
+    _Pragma("unroll") for (int kp = 0; kp < KK; kp++) dall[(D0) + kp] = dk[kp];              \
+  }
+        if (BOTH) {  // one body: what depends on x and y alone is computed once for all the rows
+          GSDF_ROWS_PASS(4, 0u, 0)
+          if (nrows <= 5u) GSDF_ROWS_PASS(1, 4u, 4)
+          else if (nrows == 6u) GSDF_ROWS_PASS(2, 4u, 4)
+          else GSDF_ROWS_PASS(4, 4u, 4)
+        } else {  // one site per pass width (the interpreter's body is large): four rows once or twice, then a pass of two
+          const unsigned np4 = nrows > 6u ? 2u : 1u;
+#pragma unroll 1
+          for (unsigned pz = 0; pz < np4; pz++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) dall[j] = dall[j + 4];
+            GSDF_ROWS_PASS(4, 4u * pz, 4)
+          }
+          if (np4 == 1u) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) dall[j] = dall[j + 4];
+            GSDF_ROWS_PASS(2, 4u, 4)
+          }
+        }
+#undef GSDF_ROWS_PASS
+      } else if (BOTH) {
 #pragma unroll
         for (unsigned c0 = 0; c0 < 8; c0 += K) GSDF_COLUMN_PASS
       } else {
@@ -770,7 +836,9 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
 #pragma unroll
       for (int c = 0; c < 8; c++) {
         const unsigned cx = (c ^ (c >> 1)) & 1u, cy = (c >> 1) & 1u, cz = (c >> 2) & 1u;
-        dc[c] = D[(2u * lk + cz) * BLOCK + (2u * lj + cy) * 8u + 2u * li + cx];
+        unsigned row = 2u * lk + cz;
+        if (DZ && K == 4) row = (unsigned)__builtin_popcount(rowmask & ((2u << row) - 1u)) - 1u;  // the slot that holds this row's value (a row left out = the row before it)
+        dc[c] = D[row * BLOCK + (2u * lj + cy) * 8u + 2u * li + cx];
         index |= (nb::lt0(dc[c]) ? 1u : 0u) << c;
       }
       pass = nb::abs_le(dc[0], cubeDiag);
@@ -836,7 +904,8 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
         const uint32_t nrec = (uint32_t)__builtin_popcountll(cm);
         hdr[blk] = nrec | (ntri << 8);
 #ifndef GSDF_EXP_NO_PSUM
-        if (nact) atomicAdd(&psum[blk / MARCH_GROUP], PSUM_PACK(nrec, ntri, nact));  // (a cut leaf is an active one: nrec <= nact)
+        if (DZ && UCUBE && K == 4) atomicAdd(&psum[blk / MARCH_GROUP], PSUM_PACK(nrec, ntri, nact, zrows));  // (every brick: its rows are counted)
+        else if (nact) atomicAdd(&psum[blk / MARCH_GROUP], PSUM_PACK(nrec, ntri, nact, 0u));  // (a cut leaf is an active one: nrec <= nact)
 #endif
       }
       if (cut) {
@@ -1004,13 +1073,15 @@ __global__ void __launch_bounds__(BLOCK, 7) march_records_kernel(const uint32_t*
     const unsigned long long v = psum[e];
     lr += PSUM_REC(v);
     lt += PSUM_TRI(v);
-    la += PSUM_ACT(v);
+    la += (unsigned long long)PSUM_ACT(v) | ((unsigned long long)PSUM_ROWS(v) << 32);  // (the z rows evaluated ride in the high half: both sums stay below 2^32)
   }
-  unsigned long long R, T, A = 0;
+  unsigned long long R, T, A = 0, Z = 0;
   const unsigned long long br = block_scan_u64(lr, s_u64, &R) - lr, bt = block_scan_u64(lt, s_u64, &T) - lt;
-  if (blockIdx.x == 0) {  // the statistics the evaluating kernel sent along: cut leaves = records, active leaves
+  if (blockIdx.x == 0) {  // the statistics the evaluating kernel sent along: cut leaves = records, active leaves, z rows evaluated (DZ)
     (void)block_scan_u64(la, s_u64, &A);
-    if (threadIdx.x == 0) { ctr->n_cut = R; ctr->n_active = A; }
+    Z = A >> 32;
+    A &= 0xffffffffull;
+    if (threadIdx.x == 0) { ctr->n_cut = R; ctr->n_active = A; ctr->n_points = Z * 64ull; }
   }
   // This is the mesh's last kernel: its first workgroup hands the counters to the host itself (pinned, device-mapped memory;
   // visible when the kernel has completed) -- the D2H copy that used to follow cost 4 us plus the gap in front of it.
@@ -1022,6 +1093,7 @@ __global__ void __launch_bounds__(BLOCK, 7) march_records_kernel(const uint32_t*
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_tris) / 8)) v = T;
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_cut) / 8)) v = R;
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_active) / 8)) v = A;
+      if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_points) / 8)) v = Z * 64ull;
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, overflow) / 8) && T > tri_cap) v = 1ull;
       dst[k] = v;
     }
@@ -1188,7 +1260,7 @@ __global__ void __launch_bounds__(1024) scan_groups_kernel(const unsigned long l
   unsigned long long lr = 0, lt = 0, la = 0;
   for (uint64_t e = e0; e < e1; e++) {
     const unsigned long long v = psum[e];
-    lr += PSUM_REC(v); lt += PSUM_TRI(v); la += PSUM_ACT(v);
+    lr += PSUM_REC(v); lt += PSUM_TRI(v); la += (unsigned long long)PSUM_ACT(v) | ((unsigned long long)PSUM_ROWS(v) << 32);  // (rows evaluated in the high half)
   }
   unsigned long long ir = lr, it = lt, ia = la;  // wave inclusive scans (only the records' is needed per thread; the others as totals)
 #pragma unroll
@@ -1205,6 +1277,8 @@ __global__ void __launch_bounds__(1024) scan_groups_kernel(const unsigned long l
     if (w < wave) before += s_r[w];
     R += s_r[w]; T += s_t[w]; A += s_a[w];
   }
+  const unsigned long long Z = A >> 32;  // z rows evaluated (DZ)
+  A &= 0xffffffffull;
   unsigned long long acc = before + ir - lr;
   for (uint64_t e = e0; e < e1; e++) {
     grp_base[e] = acc;
@@ -1217,7 +1291,7 @@ __global__ void __launch_bounds__(1024) scan_groups_kernel(const unsigned long l
     for (unsigned long long k = tid; k < ((nch + 1ull) & ~1ull); k += 1024) chunk_tri[k] = 0u;  // (+ the padding word)
   }
   if (tid == 0) {
-    ctr->n_cut = R; ctr->n_tris = T; ctr->n_active = A;
+    ctr->n_cut = R; ctr->n_tris = T; ctr->n_active = A; ctr->n_points = Z * 64ull;
     if (!fits) ctr->overflow = 1ull;  // the host learns the exact size and reruns
   }
   if (host_ctr != nullptr) {
@@ -1228,6 +1302,7 @@ __global__ void __launch_bounds__(1024) scan_groups_kernel(const unsigned long l
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_tris) / 8)) v = T;
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_cut) / 8)) v = R;
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_active) / 8)) v = A;
+      if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_points) / 8)) v = Z * 64ull;
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, overflow) / 8) && !fits) v = 1ull;
       dst[k] = v;
     }

@@ -212,7 +212,8 @@ class SDFHIP:
         buf = C.create_string_buffer(512)
         _check(lib().gsdf_hip_program_kernels(self._h, buf, 512))
         kern = dict(kv.split("=") for kv in buf.value.decode().split())
-        return {"code_words": a.value, "lds_slots": b.value, "specialized": bool(sp), "specialize_s": t.value, "kernels": kern}
+        leaf_k = int(kern["leaf"].split("<")[1].split(",")[0]) if "leaf" in kern else 0  # points per lane of the leaf phase
+        return {"code_words": a.value, "lds_slots": b.value, "specialized": bool(sp), "specialize_s": t.value, "kernels": kern, "leaf_k": leaf_k}
 
     def specialize(self):
         """Build (hiprtc) and switch to kernels specialised for this tree: same bits, no fetch/decode. Returns self."""

@@ -169,7 +169,11 @@ typedef struct gsdf_mesh_opts {
   void* stream;       /* hipStream_t to run on; NULL = the program's stream */
   int share_corners;  /* 0 (default): every leaf evaluates its own 8 corners like the reference (8 evals/leaf);
                          1: each bitwise-distinct lattice point of a 4x4x4-leaf brick is evaluated once (identical
-                         triangles, ~1.5x fewer evaluations, ~9% less time at npt-flange resdiv 1600) */
+                         triangles, ~1.5x fewer evaluations; an older, fused kernel: slower than the default today);
+                         2: the bitwise-distinct z rows of a brick once each (a brick's eight rows of corners are five to eight
+                         distinct planes: row 2k-1 = (O + res (i-1)) + res and row 2k = O + res i are the same float on most planes)
+                         -- the default's kernels, a quarter fewer evaluations, identical distances, records and triangles.
+                         stats.evals then counts the evaluations performed, not the reference's 8 per leaf. */
   int host_output;    /* 1: the triangle buffer is pinned, device-mapped HOST memory and the mesher writes it across PCIe
                          while it runs (gsdf_hip_mesh_host_tris then returns that buffer: mesh + transfer 4.x ms instead
                          of 1.7 + 4.4 ms at npt-flange resdiv 1600). For results that are consumed on the host only:

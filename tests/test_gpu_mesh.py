@@ -52,6 +52,21 @@ def test_scene_mesh_identical_to_oracle(gpu, scene, key):
     shared = gpu.OctreeHIP(sdf, res, share_corners=True)   # exact corner sharing: same triangles, fewer evaluations
     assert (_sorted(shared.RenderAll()).view(np.uint32) == tg.view(np.uint32)).all()
     assert shared.stats.evals <= oc.stats.evals             # strictly fewer when the 4-points-per-lane brick kernel applies
+    # distinct z rows (share_corners = 2): the default's kernels, every bitwise-distinct row of a brick evaluated once -- same
+    # records, same triangles, same statistics, fewer evaluations; as triangles and as packed records marched afterwards
+    rows = gpu.OctreeHIP(sdf, res, share_corners=2)
+    assert (_sorted(rows.RenderAll()).view(np.uint32) == tg.view(np.uint32)).all()
+    assert rows.TotalPruned() == oc.TotalPruned()
+    assert [int(getattr(rows.stats, k)) for k in ("n_tris", "leaf_cubes", "active_leaves", "cut_leaves", "evals_prune")] == \
+           [int(getattr(oc.stats, k)) for k in ("n_tris", "leaf_cubes", "active_leaves", "cut_leaves", "evals_prune")]
+    assert 5 * int(rows.stats.leaf_cubes) <= int(rows.stats.evals_leaf) <= int(oc.stats.evals_leaf) == 8 * int(oc.stats.leaf_cubes)
+    if sdf.info()["leaf_k"] == 4:
+        assert rows.stats.evals_leaf < oc.stats.evals_leaf   # (a brick has 5..8 distinct rows; all eight only where every plane's two floats differ)
+    rrec = gpu.OctreeHIP(sdf, res, share_corners=2, payload=gpu.PAYLOAD_RECORDS)
+    assert rrec.payload()[0] == gpu.PAYLOAD_RECORDS and rrec.payload()[1] == int(oc.stats.cut_leaves)
+    rrec.march()
+    assert (_sorted(rrec.RenderAll()).view(np.uint32) == tg.view(np.uint32)).all()
+    assert int(rrec.stats.evals_leaf) == int(rows.stats.evals_leaf)
     # pruning must not change the surface (flat renderer == octree renderer in the reference's README)
     if key != "npt_flange_resdiv400":
         assert gpu.OctreeHIP(sdf, res, prune=False).n_tris() == g["n_tris"]

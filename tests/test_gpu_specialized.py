@@ -58,6 +58,15 @@ def test_specialised_mesh_identical(gpu, scene, key):
         assert gpu.OctreeHIP(sdf, res, prune=False).n_tris() == g["n_tris"]
     # the corner-sharing kernel (interpreter build) still works on a specialised handle
     assert (_sorted(gpu.OctreeHIP(sdf, res, share_corners=True).RenderAll()).view(np.uint32) == tg.view(np.uint32)).all()
+    # distinct z rows through the specialised kernels (built on first use): same set, fewer evaluations, whole and in shards
+    rows = gpu.OctreeHIP(sdf, res, share_corners=2)
+    assert (_sorted(rows.RenderAll()).view(np.uint32) == tg.view(np.uint32)).all()
+    assert rows.stats.evals <= oc.stats.evals and rows.stats.active_leaves == oc.stats.active_leaves
+    if sdf.info()["leaf_k"] == 4:
+        assert rows.stats.evals < oc.stats.evals
+    parts = [gpu.OctreeHIP(sdf, res, shard_rank=r, shard_count=2, share_corners=2) for r in range(2)]
+    assert (_sorted(np.concatenate([q.RenderAll() for q in parts])).view(np.uint32) == tg.view(np.uint32)).all()
+    assert sum(int(q.stats.evals_leaf) for q in parts) == int(rows.stats.evals_leaf)
 
 
 def test_specialised_full_size_npt_flange(gpu):
@@ -69,6 +78,9 @@ def test_specialised_full_size_npt_flange(gpu):
     oc = gpu.OctreeHIP(sdf, res)
     assert oc.n_tris() == g["n_tris"]
     assert hashlib.sha256(_sorted(oc.RenderAll()).tobytes()).hexdigest() == g["sha256_sorted"]
+    rows = gpu.OctreeHIP(sdf, res, share_corners=2)   # distinct z rows of every brick once: the same set from fewer evaluations
+    assert rows.n_tris() == g["n_tris"] and rows.stats.evals < oc.stats.evals
+    assert hashlib.sha256(_sorted(rows.RenderAll()).tobytes()).hexdigest() == g["sha256_sorted"]
 
 
 def test_specialise_is_idempotent_and_counts_evaluations(gpu):
