@@ -309,6 +309,7 @@ def main():
                          "finished inside the timed region)")
     ap.add_argument("--no-gather-pipeline", action="store_true",
                     help="N > 1: wait for a mesh's gather before meshing the next (default: the payload of mesh i moves while mesh i+1 is made)")
+    ap.add_argument("--no-distinct-rows", action="store_true", help="skip the share_corners = 2 measurement that follows the timed loop (profiles of the headline's kernels alone)")
     ap.add_argument("--share-corners", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2],
                     help="0: every corner of every leaf, as the reference (headline); 1: each bitwise-distinct lattice corner of a brick once (older fused kernel); "
                          "2: the bitwise-distinct z rows of a brick once each (same kernels, same triangles, a quarter fewer evaluations)")
@@ -586,11 +587,11 @@ def main():
                                         "note": "one blocking mesh at a time (measured after the timed loop): the kernel with the GPU to itself"}
             out["roofline"]["note"] += ("; the timed loop keeps two meshes in flight on two streams, so kernel_ms / achieved / frac above are the kernel's "
                                         "duration while it shares the CUs with the other mesh's kernels -- 'alone' is the same kernel by itself")
-        if mesh_pipeline and not dc and args.share_corners == 0:
+        if mesh_pipeline and not dc and args.share_corners == 0 and not args.no_distinct_rows:
             # Beside the headline, not in it: the same mesh with every bitwise-distinct z row of a brick evaluated once
             # (gsdf_mesh_opts.share_corners = 2; the triangle set is bit-identical, tests/test_gpu_mesh.py) -- time to mesh for a
             # caller who does not need the reference's evaluation count. Same pipelined loop, after the timed region.
-            run_meshes(5, sc=2)
+            run_meshes(max(5, args.preheat // 2), sc=2)  # (its own kernels; the clocks have relaxed during the blocking meshes above)
             dacc = {"evals": 0, "tris": 0}
             torch.cuda.synchronize()
             t1 = time.perf_counter()

@@ -198,7 +198,9 @@ void spec_aux(gsdf_program* p) {
 
 // leaf_eval_kernel with distinct z rows (kernels_octree.h: DZ) for a specialised handle whose leaf phase runs four points per
 // lane: the one-body form at the occupancy the handle's evaluating kernel has, then at four workgroups per CU, then the two-site
-// form; the first that builds without scratch is taken. Failure leaves the interpreter's DZ kernel in use.
+// form; the first that builds without scratch is taken. If none does (knurled-cylinder with hipcc 7.2: three variants of the
+// second pass in one body want more than 128 registers; at three workgroups per CU the option costs more than it saves), a
+// specialised handle keeps evaluating every row with its specialised kernel.
 void spec_leaf_dz(gsdf_program* p) {
   if (!p->spec_mod || p->spec_dz_tried || p->prog.is2d) return;
   p->spec_dz_tried = true;
@@ -248,22 +250,22 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
   if (!p->prog.is2d) {
     names.push_back("prune_kernel");
     names.push_back("prune_spec_kernel");
-    names.push_back(std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(lw) + (fused_leaf() ? ">" : (p->leaf_nt_in_lds() ? ", true, true, false>" : ", true, false, false>")));
+    names.push_back(std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(lw) + (fused_leaf() ? ">" : (p->leaf_nt_in_lds() ? ", true, true, false, false>" : ", true, false, false, false>")));
     // a fifth workgroup per CU where the LDS has room for it (npt-flange's 7 slots): the 96-register build is taken if the
     // compiler reaches it without scratch (-3 % on the evaluating kernel); built beside the 128-register one, same process
-    if (!fused_leaf() && lk == 4 && lw == 4 && 5 * lds_m <= (size_t)160 * 1024) names.push_back("leaf_eval_kernel<4, 5, true, true, false>");
+    if (!fused_leaf() && lk == 4 && lw == 4 && 5 * lds_m <= (size_t)160 * 1024) names.push_back("leaf_eval_kernel<4, 5, true, true, false, false>");
     // both passes of a column brick in one body -- taken, ahead of the others, if the compiler reaches it without scratch: -7 %
     // where much of the program depends on x and y alone (an atan2, several hypots: npt-flange), -1..2 % elsewhere
     static const bool both_off = [] { const char* e = getenv("GSDF_HIP_NO_BOTH_PASSES"); return e && atoi(e) != 0; }();  // developer knob (A/B timing)
     static const int both_min = [] { const char* e = getenv("GSDF_HIP_BOTH_MIN_WEIGHT"); return e ? atoi(e) : 0; }();  // developer knob. 0: always -- programs without x,y-only work gain 1-2 % too (bolt 1.029 -> 1.007 ms, knurled-cylinder 3.19 -> 3.16: one body of eight points schedules a little better than two of four)
     if (!fused_leaf() && !both_off && lk == 4 && gsdf_dev::spec_xy_shared_weight(p->prog) >= both_min) {
       both_at = (int)names.size();
-      names.push_back(std::string("leaf_eval_kernel<4, ") + std::to_string(lw) + (p->leaf_nt_in_lds() ? ", true, true, true>" : ", true, false, true>"));
+      names.push_back(std::string("leaf_eval_kernel<4, ") + std::to_string(lw) + (p->leaf_nt_in_lds() ? ", true, true, true, false>" : ", true, false, true, false>"));
       // ... and at five workgroups per CU (96 registers) where the LDS has room: taken if it builds without scratch
       static const bool both5_off = [] { const char* e = getenv("GSDF_HIP_NO_BOTH5"); return e && atoi(e) != 0; }();  // developer knob (A/B timing)
       if (!both5_off && lw == 4 && 5 * lds_m <= (size_t)160 * 1024) {
         both5_at = (int)names.size();
-        names.push_back(std::string("leaf_eval_kernel<4, 5") + (p->leaf_nt_in_lds() ? ", true, true, true>" : ", true, false, true>"));
+        names.push_back(std::string("leaf_eval_kernel<4, 5") + (p->leaf_nt_in_lds() ? ", true, true, true, false>" : ", true, false, true, false>"));
       }
     }
   }
@@ -320,7 +322,7 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
     for (int w2 = lw - 1; !okl && w2 >= 2; w2--) {
       std::vector<hipFunction_t> fl;
       hipModule_t m2 = nullptr;
-      const std::string nl = std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(w2) + (fused_leaf() ? ">" : (p->leaf_nt_in_lds() ? ", true, true, false>" : ", true, false, false>"));
+      const std::string nl = std::string(fused_leaf() ? "leaf_kernel<" : "leaf_eval_kernel<") + std::to_string(lk) + ", " + std::to_string(w2) + (fused_leaf() ? ">" : (p->leaf_nt_in_lds() ? ", true, true, false, false>" : ", true, false, false, false>"));
       if (spec_build(p, {nl}, &m2, fl, &p->spec_compile_s) != GSDF_OK) break;
       okl = fn_scratch_bytes(fl[0]) == 0;
       spec_report("specialised", nl, fl[0], okl);
@@ -391,7 +393,7 @@ extern "C" int gsdf_hip_specialize_check(const gsdf_tree* tree, size_t* code_obj
     std::vector<std::string> low;
     std::string log;
     const std::vector<std::string> names = pr.is2d ? std::vector<std::string>{"eval_kernel<2, 4, 4>"}
-                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "prune_spec_kernel", "leaf_eval_kernel<4, 4, true, true, false>", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
+                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "prune_spec_kernel", "leaf_eval_kernel<4, 4, true, true, false, false>", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
     if (!gsdf_dev::spec_compile(pr, "gfx950", names, co, low, log)) return fail(GSDF_ERR_HIP, "specialised build failed:\n" + log);
     if (code_object_bytes) *code_object_bytes = co.size();
     return GSDF_OK;

@@ -217,6 +217,7 @@ int gsdf_mesh_job::enqueue() {
         // share_corners = 2: the distinct z rows of a brick once each (kernels_octree.h: DZ) -- column bricks at four points per lane
         used_dz = opts.share_corners == 2 && lq == 3 && lk == 4;
         if (used_dz) spec_leaf_dz(p);
+        if (used_dz && !p->f_leaf_dz && p->f_leaf && p->spec_leaf_k == lk) used_dz = false;  // no scratch-free build of it for this tree: every row, through the specialised kernel
 #define LAUNCH_LEAF_EVAL_U(KK, WW, UU, NN, LDS)                                                                                    \
   hipLaunchKernelGGL((leaf_eval_kernel<KK, WW, UU, NN>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), LDS, s, p->d_code, \
                      (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res, d_hdr,   \

@@ -359,7 +359,7 @@ __device__ __forceinline__ void smooth_h(const float (&num)[K], float k, float r
 template <int K, int SHARE = 0, bool LIP = false>
 __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)[K],
                                          float* __restrict__ lds /* already offset by tid */, const uint32_t nthreads,
-                                         const bool brick = false /* wave-uniform; see xy_shared */,
+                                         const bool brick = false /* wave-uniform: the wave is spatially compact (polygon edge culling pays, poly_cull); with SHARE = 2 also: point kp has the same z in every lane; see xy_shared */,
                                          const float lip_h = 0.0f, const uint32_t lip_base = 0u) {
   using namespace dm;
   static_assert(!LIP || (K == 2 && SHARE == 0), "interval mode: two points per lane, lower and upper bound");
@@ -729,7 +729,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         bool neg[K];
         bool done = false;
         uint64_t keepd = ~0ull, keeps = ~0ull;
-        if (SHARE != 0 && brick && nv >= 6u && nv <= 64u) poly_cull<K>(code, q0, nv, pv, keepd, keeps);  // one wave = one 4x4x4-leaf brick
+        if (brick && nv >= 6u && nv <= 64u) poly_cull<K>(code, q0, nv, pv, keepd, keeps);  // a spatially compact wave: a 4x4x4-leaf brick, a patch of lattice cells, a run of kept cubes
         if (hdr >> 31) done = poly_edges<K, true>(code, q0, nv, v0x, v0y, pv, d, neg, keepd, keeps);
         if (!done) poly_edges<K, false>(code, q0, nv, v0x, v0y, pv, d, neg, keepd, keeps);
         KLOOP {

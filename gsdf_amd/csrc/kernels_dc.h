@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __r
 #pragma unroll
       for (int kp = 0; kp < K; kp++) d[kp] = 3.0e38f;
     } else {
-      gsdf_dev::sdf_eval<K, 2>(code, p, d, lds, BLOCK);  // COLUMN mode: the lane's K cells are one x,y column (z = wave + 4 kp)
+      gsdf_dev::sdf_eval<K, 2>(code, p, d, lds, BLOCK, /*brick=*/true);  // COLUMN mode: the lane's K cells are one x,y column (z = wave + 4 kp: the same in every lane of the wave); a wave = an 8 x 8 patch of columns: polygon edge culling pays (a glyph outline of 30 edges keeps 3-6)
 #pragma unroll
       for (int kp = 0; kp < K; kp++) {  // count the lattice cells (tiles overhang the lattice edge)
         const unsigned long long vm = __ballot(valid[kp]);
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_edges_kernel(const uint32_t* __re
     const float x0 = ox + res * (float)c.x, y0 = oy + res * (float)c.y, z0 = oz + res * (float)c.z;
     P3 p[4] = {{x0, y0, z0}, {x0 + res, y0 + 0.f, z0 + 0.f}, {x0 + 0.f, y0 + res, z0 + 0.f}, {x0 + 0.f, y0 + 0.f, z0 + res}};
     float d[4];
-    gsdf_dev::sdf_eval<4>(code, p, d, lds, BLOCK);
+    gsdf_dev::sdf_eval<4>(code, p, d, lds, BLOCK, /*brick=*/true);  // (kept cubes arrive tile by tile: a wave's 64 cubes are neighbours -- edge culling on)
     if (valid) {
       dists[i] = make_float4(d[0], d[1], d[2], d[3]);
       fv[3 * i] = x0; fv[3 * i + 1] = y0; fv[3 * i + 2] = z0;
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_normals_kernel(const uint32_t* __
       P3 ab[2] = {{px + (dim == 0 ? h : 0.f), py + (dim == 1 ? h : 0.f), pz + (dim == 2 ? h : 0.f)},
                   {px - (dim == 0 ? h : 0.f), py - (dim == 1 ? h : 0.f), pz - (dim == 2 ? h : 0.f)}};
       float dd[2];
-      gsdf_dev::sdf_eval<2>(code, ab, dd, lds, BLOCK);
+      gsdf_dev::sdf_eval<2>(code, ab, dd, lds, BLOCK, /*brick=*/true);  // (active edges in the order of their cubes: neighbours -- edge culling on)
       const float v = dd[0] - dd[1];
       if (dim == 0) out[0] = v; else if (dim == 1) out[1] = v; else out[2] = v;
     }

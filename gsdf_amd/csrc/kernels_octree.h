@@ -775,6 +775,9 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
           mism |= (__float_as_uint(far) != __float_as_uint(near) ? 1u : 0u) << (k - 1u);
         }
         mism = __builtin_amdgcn_readfirstlane(mism);
+#ifdef GSDF_EXP_DZ_FORCE  // developer experiment (GSDF_HIP_SPEC_FLAGS=-DGSDF_EXP_DZ_FORCE=0 / 7): every brick with 5 / 8 rows (timing only, wrong meshes)
+        mism = GSDF_EXP_DZ_FORCE;
+#endif
         rowmask = 0xabu | ((mism & 1u) << 2) | ((mism & 2u) << 3) | ((mism & 4u) << 4);  // rows 0, 1, 3, 5, 7 always; 2, 4, 6 where they differ
         nrows = (unsigned)__builtin_popcount(rowmask);
         zrows = nrows;
@@ -821,8 +824,13 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
         }
 #undef GSDF_ROWS_PASS
       } else if (BOTH) {
+#ifdef GSDF_EXP_ROWS  // developer experiment (GSDF_HIP_SPEC_FLAGS=-DGSDF_EXP_ROWS=4): only the first rows of a brick -- what a row costs (timing only, wrong meshes)
+#pragma unroll
+        for (unsigned c0 = 0; c0 < GSDF_EXP_ROWS; c0 += K) GSDF_COLUMN_PASS
+#else
 #pragma unroll
         for (unsigned c0 = 0; c0 < 8; c0 += K) GSDF_COLUMN_PASS
+#endif
       } else {
 #pragma unroll 1
         for (unsigned c0 = 0; c0 < 8; c0 += K) GSDF_COLUMN_PASS

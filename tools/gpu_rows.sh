@@ -8,7 +8,7 @@ mkdir -p $OUT
 if [ -z "$SKIP_TESTS" ]; then
 timeout 1500 python -m pytest tests/test_gpu_mesh.py tests/test_gpu_specialized.py -m gpu -x -q -k "identical or full_size" > $OUT/pytest_rows.log 2>&1; tail -4 $OUT/pytest_rows.log
 fi
-for sc in ${SCENES:-"npt-flange 1600" "bolt 2000" "knurled-cylinder 2000"}; do set -- $sc
+for sc in ${SCENES:-npt-flange:1600 bolt:2000 knurled-cylinder:2000}; do set -- ${sc/:/ }
   GSDF_HIP_DEBUG=1 timeout 600 python bench.py --scene $1 --resdiv $2 --steps 20 --warmup 2 --no-cpu-baseline --no-evaluate-dropin 2>$OUT/err_$1.txt | tail -1 > $OUT/bench_$1.json
   grep "rows\|true, true>" $OUT/err_$1.txt | tail -6
   python - $OUT/bench_$1.json <<'PY'
