@@ -588,24 +588,29 @@ def main():
             out["roofline"]["note"] += ("; the timed loop keeps two meshes in flight on two streams, so kernel_ms / achieved / frac above are the kernel's "
                                         "duration while it shares the CUs with the other mesh's kernels -- 'alone' is the same kernel by itself")
         if mesh_pipeline and not dc and args.share_corners == 0 and not args.no_distinct_rows:
-            # Beside the headline, not in it: the same mesh with every bitwise-distinct z row of a brick evaluated once
-            # (gsdf_mesh_opts.share_corners = 2; the triangle set is bit-identical, tests/test_gpu_mesh.py) -- time to mesh for a
-            # caller who does not need the reference's evaluation count. Same pipelined loop, after the timed region.
-            run_meshes(max(5, args.preheat // 2), sc=2)  # (its own kernels; the clocks have relaxed during the blocking meshes above)
-            dacc = {"evals": 0, "tris": 0}
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            run_meshes(args.steps, lambda o: (dacc.__setitem__("evals", dacc["evals"] + o.stats.evals), dacc.__setitem__("tris", dacc["tris"] + o.stats.n_tris)), sc=2)
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t1
-            al2 = [hip.OctreeHIP(sdf, res, share_corners=2).stats for _ in range(8)][2:]
-            out["distinct_rows"] = {"ms_per_step": dt2 / args.steps * 1e3, "triangles_per_s": dacc["tris"] / dt2, "triangles_per_step": dacc["tris"] / args.steps,
-                                    "evals_performed_per_step": dacc["evals"] / args.steps, "evals_performed_per_s": dacc["evals"] / dt2,
-                                    "reference_evals_per_s": evals_all / dt2,
-                                    "kernel": sdf.info()["kernels"].get("leaf_rows"),
-                                    "alone": {"kernel_ms": sum(a.ms_march for a in al2) / len(al2), "ms_per_mesh_device": sum(a.ms_total for a in al2) / len(al2)},
-                                    "note": "gsdf_mesh_opts.share_corners = 2: rows 2k-1 and 2k of a brick's eight z rows of corners are the same plane and mostly the same float; "
-                                            "each distinct row is evaluated once. Bit-identical triangle set; not the headline, which performs every evaluation the reference performs"}
+            # Beside the headline, not in it: the same mesh with the evaluations the reference repeats left out (gsdf_mesh_opts.share_corners;
+            # the triangle set is bit-identical, tests/test_gpu_mesh.py) -- time to mesh for a caller who does not need the reference's
+            # evaluation count. Same pipelined loop, after the timed region. 2: every bitwise-distinct z row of a brick once (the
+            # headline's kernels); 1: every bitwise-distinct lattice point of a brick once (leaf_dense_kernel: no column sharing).
+            def shared(sc, key):
+                run_meshes(max(5, args.preheat // 2), sc=sc)  # (its own kernels; the clocks have relaxed during the blocking meshes above)
+                dacc = {"evals": 0, "tris": 0}
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                run_meshes(args.steps, lambda o: (dacc.__setitem__("evals", dacc["evals"] + o.stats.evals), dacc.__setitem__("tris", dacc["tris"] + o.stats.n_tris)), sc=sc)
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t1
+                al2 = [hip.OctreeHIP(sdf, res, share_corners=sc).stats for _ in range(8)][2:]
+                return {"ms_per_step": dt2 / args.steps * 1e3, "triangles_per_s": dacc["tris"] / dt2, "triangles_per_step": dacc["tris"] / args.steps,
+                        "evals_performed_per_step": dacc["evals"] / args.steps, "evals_performed_per_s": dacc["evals"] / dt2,
+                        "reference_evals_per_s": evals_all / dt2, "kernel": sdf.info()["kernels"].get(key),
+                        "alone": {"kernel_ms": sum(a.ms_march for a in al2) / len(al2), "ms_per_mesh_device": sum(a.ms_total for a in al2) / len(al2)}}
+            out["distinct_rows"] = shared(2, "leaf_rows")
+            out["distinct_rows"]["note"] = ("gsdf_mesh_opts.share_corners = 2: rows 2k-1 and 2k of a brick's eight z rows of corners are the same plane and mostly the same float; "
+                                            "each distinct row is evaluated once. Bit-identical triangle set; not the headline, which performs every evaluation the reference performs")
+            out["distinct_points"] = shared(1, "leaf_dense")
+            out["distinct_points"]["note"] = ("gsdf_mesh_opts.share_corners = 1: every bitwise-distinct lattice point of a brick once (5..8 coordinates per axis instead of 8), packed "
+                                              "four to a lane, no (x, y) column sharing; evals_performed counts lane slots. Bit-identical triangle set; not the headline")
         if comm is not None and gstat["n"]:
             n = gstat["n"]
             g_ms = (gstat["ms_counts"] + gstat["ms_payload"]) / n

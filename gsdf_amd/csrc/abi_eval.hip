@@ -228,6 +228,25 @@ void spec_leaf_dz(gsdf_program* p) {
   }
 }
 
+// leaf_dense_kernel (share_corners = 1: every bitwise-distinct lattice point of a brick once) for a specialised handle, at the most
+// workgroups per CU its LDS allows for which the compiler needs no scratch. Failure leaves the interpreter's kernel in use.
+void spec_leaf_dense(gsdf_program* p) {
+  if (!p->spec_mod || p->spec_dense_tried || p->prog.is2d || fused_leaf()) return;
+  p->spec_dense_tried = true;
+  std::vector<std::string> names;
+  std::vector<int> ws;
+  for (int w = 5; w >= 3; w--)
+    if ((size_t)w * p->lds_dense() <= (size_t)160 * 1024) { names.push_back("leaf_dense_kernel<" + std::to_string(w) + ", true, true>"); ws.push_back(w); }
+  if (names.empty()) return;
+  std::vector<hipFunction_t> f;
+  if (spec_build(p, names, &p->spec_mod_dense, f, &p->spec_compile_s) != GSDF_OK) return;
+  for (size_t i = 0; i < names.size(); i++) {
+    const bool ok = fn_scratch_bytes(f[i]) == 0;
+    spec_report("specialised", names[i], f[i], ok && !p->f_leaf_dense);
+    if (ok && !p->f_leaf_dense) { p->f_leaf_dense = f[i]; p->spec_leaf_dense_w = ws[i]; }
+  }
+}
+
 // Compile and load kernels specialised for this handle's program (specialize.cpp): eval, prune and leaf kernels of
 // the configuration the mesher would pick. Afterwards gsdf_hip_eval*/gsdf_hip_mesh_octree launch them instead of the
 // interpreter kernels; results are bit-identical (same statements, same compiler flags). Idempotent.
@@ -357,6 +376,8 @@ extern "C" int gsdf_hip_program_kernels(const gsdf_program* p, char* dst, size_t
     snprintf(buf, sizeof buf, "eval=eval_kernel<3,%d,%d>:%s leaf=%s<%d,%d%s>:%s prune=prune_kernel:%s", ek, ew, se ? "specialised" : "interpreter",
              fused_leaf() ? "leaf_kernel" : "leaf_eval_kernel", lk, sl ? p->spec_leaf_w : aw, sl && p->spec_leaf_both ? ",both" : "", sl ? "specialised" : "interpreter",
              p->f_prune ? "specialised" : "interpreter");
+  if (p->f_leaf_dense && strlen(buf) + 64 < sizeof buf)  // the evaluating kernel of share_corners = 1, once it has been built
+    snprintf(buf + strlen(buf), sizeof buf - strlen(buf), " leaf_dense=leaf_dense_kernel<%d>:specialised", p->spec_leaf_dense_w);
   if (p->f_leaf_dz && strlen(buf) + 64 < sizeof buf)  // the evaluating kernel of share_corners = 2, once it has been built
     snprintf(buf + strlen(buf), sizeof buf - strlen(buf), " leaf_rows=leaf_eval_kernel<4,%d%s,rows>:specialised", p->spec_leaf_dz_w, p->spec_leaf_dz_both ? ",both" : "");
   if (p->spec_mod && strlen(buf) + 32 < sizeof buf) { strcat(buf, " compiler="); strcat(buf, p->spec_compiler.c_str()); }
@@ -448,6 +469,7 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (p->spec_mod3) (void)hipModuleUnload(p->spec_mod3);
   if (p->spec_mod4) (void)hipModuleUnload(p->spec_mod4);
   if (p->spec_mod_dz) (void)hipModuleUnload(p->spec_mod_dz);
+  if (p->spec_mod_dense) (void)hipModuleUnload(p->spec_mod_dense);
   p->q0.release(); p->q1.release(); p->ctr.release();
   p->rec.release(); p->hdr.release(); p->grp.release();
   p->b_q0.release(); p->b_q1.release(); p->b_ctr.release(); p->b_spec_pass.release(); p->b_rec.release(); p->b_hdr.release(); p->b_grp.release();

@@ -46,7 +46,7 @@ struct gsdf_mesh_job {
   uint64_t qcap = 0, want = 0, want_rec_n = 0;  // capacities of the next attempt
   // the attempt in flight
   int attempt = 0, slot;
-  bool used_brick = false, two_kernel = false, ctr_on_host = false, used_dz = false;
+  bool used_brick = false, two_kernel = false, ctr_on_host = false, used_dz = false, used_dense = false;
   int chain_first = 0;  // levels <= chain_first were tested by prune_kernel (one launch per level), the ones above speculatively
   uint64_t nblk = 0;
   size_t clear_bytes = 0;
@@ -69,6 +69,7 @@ struct gsdf_mesh_job {
 int gsdf_mesh_job::enqueue() {
     ctr_on_host = false;
     used_dz = false;
+    used_dense = false;
     MeshCounters& hc = *hcp;
     (void)hc;
     HIP_TRYM(w.q0.ensure(qcap * sizeof(Cube)));
@@ -117,7 +118,7 @@ int gsdf_mesh_job::enqueue() {
     nblk = p->rec_blocks ? p->rec_blocks : kRecBlocks0;
     if (nblk > nblk_q) nblk = nblk_q;
     const uint64_t ngrp = (nblk + MARCH_GROUP - 1) / MARCH_GROUP;
-    bool want_two = !fused_leaf() && !(lq == 3 && lk == 4 && opts.share_corners == 1);
+    bool want_two = !fused_leaf();
     if (want_two && (w.hdr.ensure(nblk * sizeof(uint32_t)) != hipSuccess || w.rec.ensure(nblk * (size_t)REC_BLOCK * sizeof(uint32_t)) != hipSuccess)) {
       (void)hipGetLastError();  // no room for the records: the fused kernel needs none
       w.hdr.release(); w.rec.release();
@@ -214,6 +215,9 @@ int gsdf_mesh_job::enqueue() {
         uint32_t* d_hdr = (uint32_t*)w.hdr.p;
         uint32_t* d_rec = (uint32_t*)w.rec.p;
         unsigned long long* d_psum = (unsigned long long*)((char*)w.ctr.p + kCtrBytes);  // cleared with the counters
+        // share_corners = 1: every bitwise-distinct lattice point of a brick once (kernels_octree.h: leaf_dense_kernel)
+        used_dense = opts.share_corners == 1 && lq == 3 && lk == 4;
+        if (used_dense) spec_leaf_dense(p);
         // share_corners = 2: the distinct z rows of a brick once each (kernels_octree.h: DZ) -- column bricks at four points per lane
         used_dz = opts.share_corners == 2 && lq == 3 && lk == 4;
         if (used_dz) spec_leaf_dz(p);
@@ -234,7 +238,19 @@ int gsdf_mesh_job::enqueue() {
   hipLaunchKernelGGL((leaf_eval_kernel<4, WW, true, NN, false, true>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), lds_m, s, p->d_code, \
                      (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res, d_hdr,   \
                      d_rec, d_psum, (unsigned long long)nblk, d_ctr)
-        if (used_dz && p->f_leaf_dz) {
+        if (used_dense) {
+          const size_t lds_d = p->lds_dense();
+          if (p->f_leaf_dense) {
+            HIP_TRYM(launch_fn(p->f_leaf_dense, grid_for(bound, p->num_cu, leaf_bpc), BLOCK, lds_d, s, (const uint32_t*)p->d_code, (const Cube*)q[lq & 1]->p,
+                               (unsigned long long)capq[lq & 1], (int)p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec, d_psum, (unsigned long long)nblk, d_ctr));
+          } else if (3 * lds_d <= (size_t)160 * 1024) {  // the interpreter's kernels: scratch-free occupancies only, passes of four points per lane
+            hipLaunchKernelGGL((leaf_dense_kernel<3, true, false>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), lds_d, s, p->d_code, (const Cube*)q[lq & 1]->p,
+                               (unsigned long long)capq[lq & 1], p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec, d_psum, (unsigned long long)nblk, d_ctr);
+          } else {
+            hipLaunchKernelGGL((leaf_dense_kernel<2, true, false>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), lds_d, s, p->d_code, (const Cube*)q[lq & 1]->p,
+                               (unsigned long long)capq[lq & 1], p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec, d_psum, (unsigned long long)nblk, d_ctr);
+          }
+        } else if (used_dz && p->f_leaf_dz) {
           HIP_TRYM(launch_fn(p->f_leaf_dz, grid_for(bound, p->num_cu, leaf_bpc), BLOCK, lds_m, s, (const uint32_t*)p->d_code, (const Cube*)q[lq & 1]->p,
                              (unsigned long long)capq[lq & 1], (int)lq, (int)p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec, d_psum,
                              (unsigned long long)nblk, d_ctr));
@@ -367,7 +383,7 @@ int gsdf_mesh_job::stats() {
     if (hc.n_items[level]) pruned += (hc.n_items[level] - passed) << (3 * (level - 1));  // DecomposesTo(1) = 8^(level-1)
   }
   const uint64_t n_leaves = hc.n_level[lq] << (3 * (lq - 1));
-  const uint64_t evals_leaf = used_brick || (used_dz && two_kernel) ? hc.n_points  // distinct lattice points (share_corners = 1) / distinct z rows of the bricks (= 2) evaluated once each
+  const uint64_t evals_leaf = used_brick || ((used_dz || used_dense) && two_kernel) ? hc.n_points  // distinct lattice points (share_corners = 1) / distinct z rows of the bricks (= 2) evaluated once each
                                          : n_leaves * (uint64_t)lk + (uint64_t)(8 - lk) * (two_kernel && lq == 3 ? n_leaves : hc.n_cont);  // evaluations actually executed (a column brick always evaluates all eight rows: leaf_eval_kernel counts nothing)
   m->st.n_tris = hc.n_tris;
   m->st.evals = evals_prune + evals_leaf;
@@ -408,8 +424,8 @@ extern "C" int gsdf_hip_mesh_octree_start(gsdf_program* p, float res, const gsdf
   if (opts.payload != GSDF_PAYLOAD_TRIANGLES && opts.payload != GSDF_PAYLOAD_RECORDS) return fail(GSDF_ERR_BAD_ARGUMENT, "bad payload kind");
   const bool want_recs = opts.payload == GSDF_PAYLOAD_RECORDS;
   if (opts.share_corners < 0 || opts.share_corners > 2) return fail(GSDF_ERR_BAD_ARGUMENT, "share_corners is 0 (every corner of every leaf, as the reference), 1 (distinct lattice points of a brick) or 2 (distinct z rows of a brick)");
-  if (want_recs && (opts.host_output || opts.share_corners == 1 || opts.max_tris || fused_leaf()))
-    return fail(GSDF_ERR_BAD_ARGUMENT, "payload = records goes with the two-kernel leaf phase only (no host_output, share_corners = 1, max_tris, fused leaf kernel)");
+  if (want_recs && (opts.host_output || opts.max_tris || fused_leaf()))
+    return fail(GSDF_ERR_BAD_ARGUMENT, "payload = records goes with the two-kernel leaf phase only (no host_output, max_tris, fused leaf kernel)");
   HIP_TRY(hipSetDevice(p->device));
 
   // Octree.Reset (octreerenderer.go:71-128) + makeICube (:222-235)

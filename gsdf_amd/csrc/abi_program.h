@@ -73,6 +73,12 @@ struct gsdf_program {
   hipFunction_t f_leaf_dz = nullptr;
   bool spec_dz_tried = false, spec_leaf_dz_both = false;
   int spec_leaf_dz_w = 0;
+  // distinct lattice points (share_corners = 1; kernels_octree.h: leaf_dense_kernel): likewise built on first use (spec_leaf_dense)
+  hipModule_t spec_mod_dense = nullptr;
+  hipFunction_t f_leaf_dense = nullptr;
+  bool spec_dense_tried = false;
+  int spec_leaf_dense_w = 0;
+  size_t lds_dense() const { return (size_t)(prog.nslots * 4 > 8 ? prog.nslots * 4 : 8) * BLOCK * sizeof(float) + 256 + 4 * 512 * sizeof(float) + 4 * 24 * sizeof(float) + 16; }
   double spec_compile_s = 0;
   std::string spec_compiler;  // hipcc | hiprtc | cache: what built the specialised kernels
   std::string spec_key;       // key of that build (specialize.cpp: build_key)
@@ -155,6 +161,7 @@ inline unsigned grid_for(uint64_t n, int num_cu, int blocks_per_cu) {
 void spec_aux(gsdf_program* p);
 // The evaluating kernel with distinct z rows for a specialised handle, built on first use: abi_eval.hip.
 void spec_leaf_dz(gsdf_program* p);
+void spec_leaf_dense(gsdf_program* p);
 
 namespace {
 // ms3.Box.ScaleCentered(1.01) = NewCenteredBox(Center(), MulElem(scale, Size())) [external]; float32, unfused.

@@ -941,6 +941,159 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// leaf_dense_kernel (gsdf_mesh_opts.share_corners = 1, two-kernel leaf phase): every BITWISE-DISTINCT lattice point of a brick once.
+// A brick's 512 corner evaluations are the product of eight x, eight y and eight z coordinates of which, per axis, rows 2k-1 and
+// 2k -- (O + res (i-1)) + res and O + res i -- are the same plane and mostly the same float (see DZ above): nx x ny x nz distinct
+// points, 5..8 per axis, ~250 of 512 on average. The wave evaluates exactly those, packed four to a lane (unrelated points: no
+// column sharing -- this pays where the field costs more per point than per (x, y) column: threads, knurls, transformed parts; a
+// part that is mostly axisymmetric loses more through the sharing it gives up), the tail in a pass of
+// one or two points per lane (TAILS; the interpreter build rounds up to passes of four), into 512 floats of LDS per wave; every
+// leaf then reads its eight corners where its coordinates' values sit, and from there on the kernel is leaf_eval_kernel: the same
+// records, headers and group sums for march_records_kernel / the packing kernels. Same distances on the same points, same bits.
+// LDS: [max(nslots * 4, 8) columns of BLOCK floats | 256 B case counts if NTLDS | 4 x 512 distances | 4 x 24 coordinates | 4 words].
+template <int WAVES, bool NTLDS, bool TAILS>
+__global__ void __launch_bounds__(BLOCK, WAVES) leaf_dense_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
+                                                                  unsigned long long cube_cap, int nslots, float ox, float oy, float oz, float res,
+                                                                  uint32_t* __restrict__ hdr, uint32_t* __restrict__ rec,
+                                                                  unsigned long long* __restrict__ psum, unsigned long long n_blocks_cap,
+                                                                  MeshCounters* __restrict__ ctr) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  const size_t cols = (size_t)(nslots * 4 > 8 ? nslots * 4 : 8) * BLOCK;
+  uint8_t* s_nt = (uint8_t*)(g_smem + cols);
+  float* s_D = g_smem + cols + (NTLDS ? 64 : 0);
+  float* s_val = s_D + 4 * 512;
+  unsigned* s_pts = (unsigned*)(s_val + 4 * 24);
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  float* D = s_D + wave * 512;
+  float* val = s_val + wave * 24;
+  if (NTLDS) s_nt[threadIdx.x] = GSDF_MC_NTRI[threadIdx.x];
+  unsigned long long n_cubes = uniform_u64(ctr->n_level[3]);  // survivors of the last prune level (device-side count)
+  if (NTLDS) __syncthreads();
+  if (n_cubes > cube_cap) n_cubes = cube_cap;  // queue overflowed: host reruns with larger queues
+  const float cubeDiag = 2 * 1.73205080757f * res;  // marchcubes.go:19
+  const float org[3] = {ox, oy, oz};
+  unsigned my_points = 0;  // wave-uniform
+  const uint64_t step = (uint64_t)gridDim.x * 4;
+  for (uint64_t brick = (uint64_t)blockIdx.x * 4 + wave; brick < n_cubes; brick += step) {  // wave-uniform; no barrier inside
+    const unsigned long long cw = uniform_u64(*(const unsigned long long*)(cubes + brick));
+    const unsigned pidx[3] = {(unsigned)(cw & 0xffffu), (unsigned)((cw >> 16) & 0xffffu), (unsigned)((cw >> 32) & 0xffffu)};
+    // per axis: planes 1..3 with two distinct floats (bits, not ==: -0 and +0 are different points to an evaluator)
+    unsigned mb[3], nax[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+      const unsigned i0 = pidx[ax] * 4u;
+      unsigned m = 0;
+#pragma unroll
+      for (unsigned k = 1; k < 4; k++) {
+        const float far = (org[ax] + res * (float)(uint16_t)(i0 + k - 1u)) + res, near = org[ax] + res * (float)(uint16_t)(i0 + k);
+        m |= (__float_as_uint(far) != __float_as_uint(near) ? 1u : 0u) << (k - 1u);
+      }
+      mb[ax] = __builtin_amdgcn_readfirstlane(m);
+      nax[ax] = 5u + (unsigned)__builtin_popcount(mb[ax]);
+    }
+    if (lane < 12u) {  // coordinate table: lane (axis, a) writes A_a and A_a + res at their distinct-value slots (a merged plane is written twice, with equal bits)
+      const unsigned ax = lane >> 2, a = lane & 3u;
+      const unsigned mm = ax == 0 ? mb[0] : (ax == 1 ? mb[1] : mb[2]);
+      const float oo = ax == 0 ? ox : (ax == 1 ? oy : oz);
+      const unsigned pi = ax == 0 ? pidx[0] : (ax == 1 ? pidx[1] : pidx[2]);
+      const float Aa = oo + res * (float)(uint16_t)(pi * 4u + a);
+      const unsigned u = a + (unsigned)__builtin_popcount(mm & ((1u << a) - 1u));
+      val[ax * 8u + u] = Aa;
+      val[ax * 8u + u + 1u] = Aa + res;  // Box max = origin + size
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned nx = nax[0], nxy = nax[0] * nax[1], N = nxy * nax[2];
+    const float inx = 1.0f / (float)nx, inxy = 1.0f / (float)nxy;
+#define GSDF_DENSE_PASS(KK, T0)                                                                  \
+  {                                                                                               \
+    P3 pk[KK];                                                                                    \
+    float dk[KK];                                                                                 \
+    _Pragma("unroll") for (int kp = 0; kp < KK; kp++) {                                           \
+      unsigned t = (T0) + (unsigned)kp * 64u + lane;                                              \
+      if (t >= N) t = N - 1u; /* idle slots re-evaluate the last point (result discarded) */      \
+      const unsigned uz = (unsigned)(((float)t + 0.5f) * inxy);                                   \
+      const unsigned r = t - uz * nxy;                                                            \
+      const unsigned uy = (unsigned)(((float)r + 0.5f) * inx);                                    \
+      const unsigned ux = r - uy * nx;                                                            \
+      pk[kp] = P3{val[ux], val[8u + uy], val[16u + uz]};                                          \
+    }                                                                                             \
+    gsdf_dev::sdf_eval<KK>(code, pk, dk, lds, BLOCK, /*brick=*/true);                             \
+    _Pragma("unroll") for (int kp = 0; kp < KK; kp++) {                                           \
+      const unsigned t = (T0) + (unsigned)kp * 64u + lane;                                        \
+      if (t < N) D[t] = dk[kp];                                                                   \
+    }                                                                                             \
+    my_points += (unsigned)(KK) * 64u;                                                            \
+  }
+    unsigned t0 = 0;
+    if (TAILS) {
+#pragma unroll 1
+      for (; t0 + 192u < N; t0 += 256u) GSDF_DENSE_PASS(4, t0)  // (a remainder of more than three rows of lanes: four points per lane)
+      if (t0 + 64u >= N) { if (t0 < N) GSDF_DENSE_PASS(1, t0) }
+      else if (t0 + 128u >= N) GSDF_DENSE_PASS(2, t0)
+      else if (t0 < N) GSDF_DENSE_PASS(4, t0)
+    } else {
+#pragma unroll 1
+      for (; t0 < N; t0 += 256u) GSDF_DENSE_PASS(4, t0)
+    }
+#undef GSDF_DENSE_PASS
+    __builtin_amdgcn_wave_barrier();
+    // this lane's leaf (a, b, c) and its corner 0 in the distinct-point lattice
+    const unsigned la = lane & 3u, lb = (lane >> 2) & 3u, lc = lane >> 4;
+    const unsigned ux0 = la + (unsigned)__builtin_popcount(mb[0] & ((1u << la) - 1u));
+    const unsigned uy0 = lb + (unsigned)__builtin_popcount(mb[1] & ((1u << lb) - 1u));
+    const unsigned uz0 = lc + (unsigned)__builtin_popcount(mb[2] & ((1u << lc) - 1u));
+    const unsigned tb = ux0 + nx * uy0 + nxy * uz0;
+    float dc[8];
+    unsigned index = 0;
+#pragma unroll
+    for (unsigned c = 0; c < 8; c++) {
+      dc[c] = D[tb + ((c ^ (c >> 1)) & 1u) + nx * ((c >> 1) & 1u) + nxy * ((c >> 2) & 1u)];
+      index |= (nb::lt0(dc[c]) ? 1u : 0u) << c;
+    }
+    __builtin_amdgcn_wave_barrier();  // (the next brick rewrites D and the table)
+    const bool pass = nb::abs_le(dc[0], cubeDiag);
+    const unsigned nact = (unsigned)__builtin_popcountll(__ballot(pass));
+    const bool cut = pass && index != 0u && index != 255u;
+    const unsigned long long cm = __ballot(cut);
+    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+    const uint64_t blk = brick;  // block = brick = 64 consecutive leaves of the queue's order
+    if (blk < n_blocks_cap) {
+      unsigned ntri = 0;
+      if (cm != 0ull) {  // wave-uniform
+        unsigned nt = 0u;  // 0..5
+        if (NTLDS) { if (cut) nt = (unsigned)s_nt[index]; }
+        else { if (cut) nt = (unsigned)GSDF_MC_NTRI[index]; }
+        ntri = (unsigned)__builtin_popcountll(__ballot((nt & 1u) != 0u)) + 2u * (unsigned)__builtin_popcountll(__ballot((nt & 2u) != 0u)) +
+               4u * (unsigned)__builtin_popcountll(__ballot((nt & 4u) != 0u));
+      }
+      if (lane == 0u) {
+        const uint32_t nrec = (uint32_t)__builtin_popcountll(cm);
+        hdr[blk] = nrec | (ntri << 8);
+        if (nact) atomicAdd(&psum[blk / MARCH_GROUP], PSUM_PACK(nrec, ntri, nact, 0u));
+      }
+      if (cut) {
+        const uint32_t lx = (pidx[0] << 2) + la, ly = (pidx[1] << 2) + lb, lz = (pidx[2] << 2) + lc;
+        uint2* w = (uint2*)(rec + blk * REC_BLOCK + rank * REC_WORDS);  // 40-byte records: five 8-byte stores
+        w[0] = make_uint2(__float_as_uint(dc[0]), __float_as_uint(dc[1]));
+        w[1] = make_uint2(__float_as_uint(dc[2]), __float_as_uint(dc[3]));
+        w[2] = make_uint2(__float_as_uint(dc[4]), __float_as_uint(dc[5]));
+        w[3] = make_uint2(__float_as_uint(dc[6]), __float_as_uint(dc[7]));
+        w[4] = make_uint2((lx & 0xffffu) | ((ly & 0xffffu) << 16), (lz & 0xffffu) | (index << 16));
+      }
+    }
+  }
+  // statistics: the points evaluated (lane slots, idle ones included), one atomic per workgroup
+  __syncthreads();
+  if (lane == 0u) s_pts[wave] = my_points;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = (unsigned long long)s_pts[0] + s_pts[1] + s_pts[2] + s_pts[3];
+    if (t) atomicAdd(&ctr->n_points, t);
+  }
+}
+
 // Inclusive prefix sum over the workgroup (thread order) of a 64-bit value; *total = the workgroup's sum. s_w: 4 words of LDS.
 __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long v, unsigned long long* s_w, unsigned long long* total) {
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1089,7 +1242,7 @@ __global__ void __launch_bounds__(BLOCK, 7) march_records_kernel(const uint32_t*
     (void)block_scan_u64(la, s_u64, &A);
     Z = A >> 32;
     A &= 0xffffffffull;
-    if (threadIdx.x == 0) { ctr->n_cut = R; ctr->n_active = A; ctr->n_points = Z * 64ull; }
+    if (threadIdx.x == 0) { ctr->n_cut = R; ctr->n_active = A; if (Z) ctr->n_points = Z * 64ull; }  // (leaf_dense_kernel counts its points itself)
   }
   // This is the mesh's last kernel: its first workgroup hands the counters to the host itself (pinned, device-mapped memory;
   // visible when the kernel has completed) -- the D2H copy that used to follow cost 4 us plus the gap in front of it.
@@ -1101,7 +1254,7 @@ __global__ void __launch_bounds__(BLOCK, 7) march_records_kernel(const uint32_t*
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_tris) / 8)) v = T;
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_cut) / 8)) v = R;
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_active) / 8)) v = A;
-      if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_points) / 8)) v = Z * 64ull;
+      if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_points) / 8) && Z) v = Z * 64ull;
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, overflow) / 8) && T > tri_cap) v = 1ull;
       dst[k] = v;
     }
@@ -1299,7 +1452,7 @@ __global__ void __launch_bounds__(1024) scan_groups_kernel(const unsigned long l
     for (unsigned long long k = tid; k < ((nch + 1ull) & ~1ull); k += 1024) chunk_tri[k] = 0u;  // (+ the padding word)
   }
   if (tid == 0) {
-    ctr->n_cut = R; ctr->n_tris = T; ctr->n_active = A; ctr->n_points = Z * 64ull;
+    ctr->n_cut = R; ctr->n_tris = T; ctr->n_active = A; if (Z) ctr->n_points = Z * 64ull;
     if (!fits) ctr->overflow = 1ull;  // the host learns the exact size and reruns
   }
   if (host_ctr != nullptr) {
@@ -1310,7 +1463,7 @@ __global__ void __launch_bounds__(1024) scan_groups_kernel(const unsigned long l
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_tris) / 8)) v = T;
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_cut) / 8)) v = R;
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_active) / 8)) v = A;
-      if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_points) / 8)) v = Z * 64ull;
+      if (k == (unsigned)(__builtin_offsetof(MeshCounters, n_points) / 8) && Z) v = Z * 64ull;
       if (k == (unsigned)(__builtin_offsetof(MeshCounters, overflow) / 8) && !fits) v = 1ull;
       dst[k] = v;
     }

@@ -49,8 +49,14 @@ def test_random_trees_distances_and_meshes(gpu, seed):
         m = ref.render_octree(res, 4096, True)
         assert oc.n_tris() == m.n_tris, (seed, k)
         if m.n_tris:
-            assert (_sorted(oc.RenderAll()).view(np.uint32) == _sorted(m.tris).view(np.uint32)).all(), (seed, k)
+            want = _sorted(m.tris).view(np.uint32)
+            assert (_sorted(oc.RenderAll()).view(np.uint32) == want).all(), (seed, k)
             meshed += 1
+            # the evaluations the reference repeats left out: distinct lattice points (1) / distinct z rows (2) of a brick once each
+            for sc in (1, 2):
+                sh_ = gpu.OctreeHIP(sdf, res, share_corners=sc)
+                assert sh_.n_tris() == m.n_tris and sh_.stats.evals <= oc.stats.evals, (seed, k, sc)
+                assert (_sorted(sh_.RenderAll()).view(np.uint32) == want).all(), (seed, k, sc)
         # flat renderer: the PAIRED lattice pass (two planes per lane) against the oracle's FlatRenderer
         if k % 2 == 0:
             fl = gpu.FlatHIP(sdf, res)

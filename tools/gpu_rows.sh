@@ -15,7 +15,8 @@ for sc in ${SCENES:-npt-flange:1600 bolt:2000 knurled-cylinder:2000}; do set -- 
 import json,sys
 d=json.loads(open(sys.argv[1]).read())
 print(d['config']['workload'][:40], 'ms/mesh', round(d['ms_per_step'],4), 'alone', {k:round(v,4) for k,v in d['roofline']['alone'].items() if isinstance(v,float)})
-r=d.get('distinct_rows')
-if r: print('  rows: ms/mesh', round(r['ms_per_step'],4), 'evals performed', r['evals_performed_per_step'], 'of', d['evals_per_step'], 'alone', r['alone'], r['kernel'])
+for nm in ('distinct_rows','distinct_points'):
+  r=d.get(nm)
+  if r: print('  '+nm+': ms/mesh', round(r['ms_per_step'],4), 'evals performed', r['evals_performed_per_step'], 'of', d['evals_per_step'], 'alone', r['alone'], r['kernel'])
 PY
 done
