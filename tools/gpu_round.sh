@@ -30,7 +30,10 @@ open(out + "/pmc_summary.json", "wb").write(s)
 print(s.decode()[:1500])
 PY
 find $OUT -name "*stats.csv" | head
-# keep only small summaries (gpurun_out merge limit)
-find $OUT -name "*kernel_trace.csv" -size +4M -delete
-find $OUT -name "*counter_collection.csv" -size +16M -delete
+# keep only the summaries (gpurun_out's merge limit is 64 MiB for everything a call writes): the per-dispatch CSVs are what
+# pmc_summary.json and *_kernel_stats.csv were made from
+cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
+find $OUT -name "*kernel_trace.csv" -delete
+find $OUT -name "*counter_collection.csv" -delete
+find $OUT -name "*agent_info.csv" -delete
 du -sh $OUT
