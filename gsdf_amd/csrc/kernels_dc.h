@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_normals_kernel(const uint32_t* __
       P3 ab[2] = {{px + (dim == 0 ? h : 0.f), py + (dim == 1 ? h : 0.f), pz + (dim == 2 ? h : 0.f)},
                   {px - (dim == 0 ? h : 0.f), py - (dim == 1 ? h : 0.f), pz - (dim == 2 ? h : 0.f)}};
       float dd[2];
-      gsdf_dev::sdf_eval<2>(code, ab, dd, lds, BLOCK, /*brick=*/true);  // (active edges in the order of their cubes: neighbours -- edge culling on)
+      gsdf_dev::sdf_eval<2>(code, ab, dd, lds, BLOCK);  // (no edge culling here: two points per lane do not pay for its reductions -- text plate 0.255 -> 0.31 ms with it)
       const float v = dd[0] - dd[1];
       if (dim == 0) out[0] = v; else if (dim == 1) out[1] = v; else out[2] = v;
     }
