@@ -228,6 +228,21 @@ void spec_leaf_dz(gsdf_program* p) {
   }
 }
 
+// eval_kernel<D, 1, 4> for a specialised handle: one point per lane, what host-mapped Evaluate calls run (eval_dev). Built at the
+// first such call, in a module of its own (the first group's build key -- the handle's code identity -- stays what it is).
+void spec_eval_k1(gsdf_program* p) {
+  static std::mutex mu;  // host-buffer calls may come from several threads
+  std::lock_guard<std::mutex> lk(mu);
+  if (!p->spec_mod || p->spec_k1_tried || p->batch_k() == 1) return;
+  p->spec_k1_tried = true;
+  std::vector<hipFunction_t> f;
+  const std::string name = std::string("eval_kernel<") + (p->prog.is2d ? "2" : "3") + ", 1, 4>";
+  if (spec_build(p, {name}, &p->spec_mod_k1, f, &p->spec_compile_s) != GSDF_OK) return;
+  const bool ok = fn_scratch_bytes(f[0]) == 0;
+  spec_report("specialised", name, f[0], ok);
+  if (ok) p->f_eval_k1 = f[0];
+}
+
 // leaf_dense_kernel (share_corners = 1: every bitwise-distinct lattice point of a brick once) for a specialised handle, at the most
 // workgroups per CU its LDS allows for which the compiler needs no scratch. Failure leaves the interpreter's kernel in use.
 void spec_leaf_dense(gsdf_program* p) {
@@ -469,6 +484,7 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (p->spec_mod3) (void)hipModuleUnload(p->spec_mod3);
   if (p->spec_mod4) (void)hipModuleUnload(p->spec_mod4);
   if (p->spec_mod_dz) (void)hipModuleUnload(p->spec_mod_dz);
+  if (p->spec_mod_k1) (void)hipModuleUnload(p->spec_mod_k1);
   if (p->spec_mod_dense) (void)hipModuleUnload(p->spec_mod_dense);
   p->q0.release(); p->q1.release(); p->ctr.release();
   p->rec.release(); p->hdr.release(); p->grp.release();
@@ -496,9 +512,15 @@ extern "C" int gsdf_hip_program_info(const gsdf_program* p, uint32_t* code_words
 }
 extern "C" uint64_t gsdf_hip_evaluations(const gsdf_program* p) { return p ? p->evals + p->evals_host.load() : 0; }
 
-static int eval_dev(gsdf_program* p, int dim, const void* d_pos, size_t stride_bytes, float* d_dist, size_t n, hipStream_t s, bool count = true) {
+// host_mapped: the buffers are pinned host memory the kernel reaches across PCIe (the host-buffer API's small and registered calls).
+// Such a call is bound by the reads' latency and bandwidth, not by the evaluation: ONE point per lane puts four times as many
+// workgroups on the bus at once (32 768 points: 128 workgroups instead of 32) -- 24.6 -> 19.6 us per blocking call from registered
+// buffers, 31.4 -> 26.1 us from pageable ones (tools/gpu_dropin_k.sh).
+static int eval_dev(gsdf_program* p, int dim, const void* d_pos, size_t stride_bytes, float* d_dist, size_t n, hipStream_t s, bool count = true, bool host_mapped = false) {
   if (stride_bytes % 4 != 0 || stride_bytes < (size_t)dim * 4) return fail(GSDF_ERR_BAD_ARGUMENT, "bad position stride");
-  const int k = p->batch_k();
+  static const bool k1_off = [] { const char* e = getenv("GSDF_HIP_NO_EVAL_K1"); return e && atoi(e) != 0; }();  // developer knob (A/B timing)
+  const bool latency = host_mapped && !k1_off && (p->f_eval_k1 != nullptr || p->f_eval == nullptr);  // (a specialised handle without a K = 1 build keeps its specialised kernel)
+  const int k = latency ? 1 : p->batch_k();
   static const int eval_bpc = [] { const char* e = getenv("GSDF_HIP_EVAL_BPC"); return e ? atoi(e) : 64; }();  // tuning knob: finer grids drain evenly (8 -> 64 per CU: +10 % on npt-flange)
   const unsigned grid = grid_for((n + k - 1) / k, p->num_cu, eval_bpc);
   const uint32_t sf = (uint32_t)(stride_bytes / 4);
@@ -506,7 +528,9 @@ static int eval_dev(gsdf_program* p, int dim, const void* d_pos, size_t stride_b
   const uint64_t nn = (uint64_t)n;
   const int w = p->sweep_waves(k);
 #define LAUNCH_EVAL(D, KK, WW) hipLaunchKernelGGL((eval_kernel<D, KK, WW>), dim3(grid), dim3(BLOCK), p->lds_bytes(KK), s, p->d_code, q, sf, d_dist, nn)
-  if (p->f_eval && p->spec_eval_k == k) {  // whichever W the specialised kernel was built for: same launch
+  if (latency && p->f_eval_k1) {
+    HIP_TRY(launch_fn(p->f_eval_k1, grid, BLOCK, p->lds_bytes(1), s, (const uint32_t*)p->d_code, q, sf, d_dist, nn));
+  } else if (p->f_eval && p->spec_eval_k == k) {  // whichever W the specialised kernel was built for: same launch
     HIP_TRY(launch_fn(p->f_eval, grid, BLOCK, p->lds_bytes(k), s, (const uint32_t*)p->d_code, q, sf, d_dist, nn));
   } else
   if (dim == 3) {
@@ -615,7 +639,8 @@ static int eval_submit(gsdf_program* p, int dim, const void* pos, size_t stride,
     std::memcpy(sl.h_pos, pos, pbytes);
     if (hipHostGetDevicePointer(&dp, sl.h_pos, 0) != hipSuccess || hipHostGetDevicePointer(&dd, sl.h_dist, 0) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipHostGetDevicePointer failed"));
   }
-  rc = eval_dev(p, dim, dp, stride, (float*)dd, n_pos, sl.s, /*count=*/false);
+  if (p->spec_mod && !p->spec_k1_tried) spec_eval_k1(p);
+  rc = eval_dev(p, dim, dp, stride, (float*)dd, n_pos, sl.s, /*count=*/false, /*host_mapped=*/true);
   if (rc) return bail(rc);
   // completion flag behind the kernel (eval_wait polls it; hipStreamSynchronize remains the fallback)
   // (hipStreamWriteValue32 instead of the one-thread kernel was tried: slower, 38.7 vs 29.9 us per blocking pageable call)

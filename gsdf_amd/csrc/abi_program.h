@@ -63,6 +63,9 @@ struct gsdf_program {
   uint64_t last_dc_cubes = 0;  // kept cubes of the previous dual contouring pass: sizes the next queues
   // run-time specialised kernels for this program (gsdf_hip_program_specialize): hiprtc module, else interpreter
   hipModule_t spec_mod = nullptr, spec_mod2 = nullptr, spec_mod3 = nullptr, spec_mod4 = nullptr;  // spec_mod4: leaf kernel rebuilt with a larger register budget; spec_mod2: second group, built on first use (see spec_aux); spec_mod3: eval kernel rebuilt for 3 workgroups per CU
+  hipFunction_t f_eval_k1 = nullptr;  // eval_kernel<D, 1, 4>: one point per lane, for host-mapped calls (abi_eval.hip: eval_dev, spec_eval_k1)
+  hipModule_t spec_mod_k1 = nullptr;
+  bool spec_k1_tried = false;
   hipFunction_t f_eval = nullptr, f_prune = nullptr, f_prune_spec = nullptr, f_leaf = nullptr;
   hipFunction_t f_dc_origin = nullptr, f_dc_edges = nullptr, f_dc_normals = nullptr, f_normals = nullptr, f_image = nullptr, f_flat_grid = nullptr;
   bool spec_aux_tried = false;
