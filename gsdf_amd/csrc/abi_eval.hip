@@ -429,7 +429,7 @@ extern "C" int gsdf_hip_specialize_check(const gsdf_tree* tree, size_t* code_obj
     std::vector<std::string> low;
     std::string log;
     const std::vector<std::string> names = pr.is2d ? std::vector<std::string>{"eval_kernel<2, 4, 4>"}
-                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "prune_spec_kernel", "leaf_eval_kernel<4, 4, true, true, false, false>", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
+                                                   : std::vector<std::string>{"eval_kernel<3, 4, 4>", "prune_kernel", "prune_spec_kernel", "leaf_eval_kernel<4, 4, true, true, false, false>", "leaf_eval_kernel<4, 4, true, true, true, true>", "leaf_dense_kernel<4, true, true>", "leaf_kernel<4, 4>", "flat_grid_kernel<4, 4>"};
     if (!gsdf_dev::spec_compile(pr, "gfx950", names, co, low, log)) return fail(GSDF_ERR_HIP, "specialised build failed:\n" + log);
     if (code_object_bytes) *code_object_bytes = co.size();
     return GSDF_OK;
