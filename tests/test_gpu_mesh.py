@@ -68,6 +68,10 @@ def test_scene_mesh_identical_to_oracle(gpu, scene, key):
         rrec.march()
         assert (_sorted(rrec.RenderAll()).view(np.uint32) == tg.view(np.uint32)).all()
         assert int(rrec.stats.evals_leaf) == int(rows.stats.evals_leaf)
+        prec = gpu.OctreeHIP(sdf, res, share_corners=1, payload=gpu.PAYLOAD_RECORDS)   # distinct lattice points + packed records
+        assert prec.payload()[1] == int(oc.stats.cut_leaves) and int(prec.stats.evals_leaf) == int(shared.stats.evals_leaf)
+        prec.march()
+        assert (_sorted(prec.RenderAll()).view(np.uint32) == tg.view(np.uint32)).all()
     # pruning must not change the surface (flat renderer == octree renderer in the reference's README)
     if key != "npt_flange_resdiv400":
         assert gpu.OctreeHIP(sdf, res, prune=False).n_tris() == g["n_tris"]
