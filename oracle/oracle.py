@@ -15,7 +15,8 @@ _LIB = None
 class _Mesh(C.Structure):
     _fields_ = [("tris", C.POINTER(C.c_float)), ("n_tris", C.c_uint64), ("cap", C.c_uint64), ("evals", C.c_uint64),
                 ("pruned", C.c_uint64), ("levels", C.c_int), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
-                ("t_eval_s", C.c_double), ("t_march_s", C.c_double)]
+                ("t_eval_s", C.c_double), ("t_march_s", C.c_double),
+                ("evals_rows", C.c_uint64), ("evals_points", C.c_uint64), ("evals_points_tails", C.c_uint64), ("evals_points_256", C.c_uint64)]
 
 
 PRUNE_ASSUME_SDF = 1 << 30  # orc_eval.h: ORC_PRUNE_ASSUME_SDF
@@ -72,6 +73,9 @@ class MeshResult:
         self.grid = (int(m.nx), int(m.ny), int(m.nz))
         self.t_eval_s = float(m.t_eval_s)
         self.t_march_s = float(m.t_march_s)
+        # octree: corner evaluations of the leaf phase under the device's share_corners options (orc_eval.h)
+        self.evals_rows, self.evals_points = int(m.evals_rows), int(m.evals_points)
+        self.evals_points_tails, self.evals_points_256 = int(m.evals_points_tails), int(m.evals_points_256)
 
 
 class OracleSDF:

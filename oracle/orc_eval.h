@@ -42,6 +42,11 @@ typedef struct orc_mesh {
   int nx, ny, nz;  /* flat grid cubes per axis */
   double t_eval_s; /* seconds in SDF evaluation (flat: evalGrid) */
   double t_march_s;
+  /* octree only; not reference quantities -- what the device's share_corners options must report (include/gsdf_hip.h): over the
+   * surviving Level-3 cubes (bricks of 4x4x4 leaves), the corner evaluations left when every bitwise-distinct z row of a brick
+   * is evaluated once (rows: 64 columns x 5..8 rows), every bitwise-distinct lattice point once (points), and the latter in lane
+   * slots of a 64-wide wave: passes of 256 with a tail of 64 / 128 / 256 (points_tails), passes of 256 only (points_256) */
+  uint64_t evals_rows, evals_points, evals_points_tails, evals_points_256;
 } orc_mesh;
 void orc_mesh_free(orc_mesh* m);
 

@@ -256,6 +256,32 @@ static void cv_push(CubeVec* cv, Cube c) {
   cv->v[cv->n++] = c;
 }
 
+/* A surviving Level-3 cube as the device's share_corners options see it (gsdf_amd/csrc/kernels_octree.h: DZ, leaf_dense_kernel):
+ * per axis the eight corner coordinates of its four leaves, A_k = O + res*float(i0+k) and A_k + res, of which (A_{k-1} + res) and
+ * A_k are the same plane -- and one point to an evaluator iff they are the same float (bits: -0 and +0 differ). */
+static void count_brick(orc_mesh* out, Cube c, V3 origin, float res) {
+  const float org[3] = {origin.x, origin.y, origin.z};
+  const int32_t i0[3] = {c.x, c.y, c.z};
+  unsigned n[3];
+  for (int ax = 0; ax < 3; ax++) {
+    n[ax] = 5;
+    for (int k = 1; k < 4; k++) {
+      const float far = (org[ax] + res * (float)(i0[ax] + k - 1)) + res, near = org[ax] + res * (float)(i0[ax] + k);
+      uint32_t a, b;
+      memcpy(&a, &far, 4); memcpy(&b, &near, 4);
+      if (a != b) n[ax]++;
+    }
+  }
+  const unsigned N = n[0] * n[1] * n[2];
+  out->evals_rows += 64u * n[2];
+  out->evals_points += N;
+  out->evals_points_256 += (N + 255u) & ~255u;
+  unsigned t0 = 0, slots = 0;
+  for (; t0 + 192u < N; t0 += 256u) slots += 256u;
+  if (t0 < N) { const unsigned rem = N - t0; slots += rem <= 64u ? 64u : (rem <= 128u ? 128u : 256u); }
+  out->evals_points_tails += slots;
+}
+
 int orc_render_octree(const orc_sdf* s, float res, int batch, int prune, orc_mesh* out) {
   memset(out, 0, sizeof(*out));
   if (batch < 64) return -1; /* :46-48 */
@@ -314,6 +340,7 @@ int orc_render_octree(const orc_sdf* s, float res, int batch, int prune, orc_mes
             /* children in corner order (i3.Cube octree decomposition [external]) */
             const int ox[8] = {0, 1, 1, 0, 0, 1, 1, 0}, oy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, oz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
             for (int k = 0; k < 8; k++) { Cube ch = {c.x + ox[k] * h, c.y + oy[k] * h, c.z + oz[k] * h, level - 1}; cv_push(&nxt, ch); }
+            if (level == 3) count_brick(out, c, origin, res);
           } else {
             out->pruned += (uint64_t)1 << (3 * (level - 1)); /* DecomposesTo(1) = 8^(level-1) :279 */
           }
@@ -325,6 +352,7 @@ int orc_render_octree(const orc_sdf* s, float res, int batch, int prune, orc_mes
         int h = 1 << (level - 2);
         const int ox[8] = {0, 1, 1, 0, 0, 1, 1, 0}, oy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, oz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
         for (int k = 0; k < 8; k++) { Cube ch = {c.x + ox[k] * h, c.y + oy[k] * h, c.z + oz[k] * h, level - 1}; cv_push(&nxt, ch); }
+        if (level == 3) count_brick(out, c, origin, res);
       }
     }
     CubeVec t = cur; cur = nxt; nxt = t;

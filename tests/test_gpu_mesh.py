@@ -61,7 +61,12 @@ def test_scene_mesh_identical_to_oracle(gpu, scene, key):
            [int(getattr(oc.stats, k)) for k in ("n_tris", "leaf_cubes", "active_leaves", "cut_leaves", "evals_prune")]
     assert 5 * int(rows.stats.leaf_cubes) <= int(rows.stats.evals_leaf) <= int(oc.stats.evals_leaf) == 8 * int(oc.stats.leaf_cubes)
     if sdf.info()["leaf_k"] == 4 and not os.environ.get("GSDF_HIP_FUSED_LEAF"):
-        assert rows.stats.evals_leaf < oc.stats.evals_leaf   # (a brick has 5..8 distinct rows; all eight only where every plane's two floats differ)
+        assert rows.stats.evals_leaf < oc.stats.evals_leaf
+        # ... and exactly what the oracle counts for the surviving bricks: 64 columns x the distinct z rows of each; every distinct
+        # lattice point in passes of 256 lane slots (the interpreter's build of leaf_dense_kernel has no tail passes)
+        assert int(rows.stats.evals_leaf) == ref.evals_rows and int(shared.stats.evals_leaf) == ref.evals_points_256
+    elif sdf.info()["leaf_k"] == 4:
+        assert int(shared.stats.evals_leaf) == ref.evals_points   # (the fused leaf_brick_kernel counts points, not lane slots)   # (a brick has 5..8 distinct rows; all eight only where every plane's two floats differ)
     if not os.environ.get("GSDF_HIP_FUSED_LEAF"):   # (packed records are the two-kernel leaf phase's; the fused kernel of tools/gpu_variants*.sh has none)
         rrec = gpu.OctreeHIP(sdf, res, share_corners=2, payload=gpu.PAYLOAD_RECORDS)
         assert rrec.payload()[0] == gpu.PAYLOAD_RECORDS and rrec.payload()[1] == int(oc.stats.cut_leaves)

@@ -63,7 +63,10 @@ def test_specialised_mesh_identical(gpu, scene, key):
     assert (_sorted(rows.RenderAll()).view(np.uint32) == tg.view(np.uint32)).all()
     assert rows.stats.evals <= oc.stats.evals and rows.stats.active_leaves == oc.stats.active_leaves
     if sdf.info()["kernels"].get("leaf_rows"):   # (a tree whose distinct-rows kernel does not build without scratch keeps every row)
-        assert rows.stats.evals < oc.stats.evals
+        assert rows.stats.evals < oc.stats.evals and int(rows.stats.evals_leaf) == ref.evals_rows   # the oracle's count for the surviving bricks
+    dense = gpu.OctreeHIP(sdf, res, share_corners=1)
+    if sdf.info()["leaf_k"] == 4:   # lane slots: passes of 256 + a tail of 64 / 128 / 256 in the specialised build, passes of 256 in the interpreter's
+        assert int(dense.stats.evals_leaf) == (ref.evals_points_tails if sdf.info()["kernels"].get("leaf_dense") else ref.evals_points_256)
     parts = [gpu.OctreeHIP(sdf, res, shard_rank=r, shard_count=2, share_corners=2) for r in range(2)]
     assert (_sorted(np.concatenate([q.RenderAll() for q in parts])).view(np.uint32) == tg.view(np.uint32)).all()
     assert sum(int(q.stats.evals_leaf) for q in parts) == int(rows.stats.evals_leaf)
