@@ -29,6 +29,14 @@ for seed in range(lo, hi):
             oc = hip.OctreeHIP(sdf, res)
             e2 = (oc.n_tris() != m.n_tris) or (m.n_tris and not (srt(oc.RenderAll()).view(np.uint32) == srt(m.tris).view(np.uint32)).all())
             e3 = mism(sdf.Evaluate(pos), d)
+            # the share_corners options: same set, and exactly the evaluations the oracle counts for the surviving bricks
+            kern = sdf.info()["kernels"]; k4 = sdf.info()["leaf_k"] == 4 and m.levels >= 3
+            for sc in (1, 2):
+                o2 = hip.OctreeHIP(sdf, res, share_corners=sc)
+                e2 = e2 or (o2.n_tris() != m.n_tris) or (m.n_tris and not (srt(o2.RenderAll()).view(np.uint32) == srt(m.tris).view(np.uint32)).all())
+                kern = sdf.info()["kernels"]
+                if k4 and sc == 2 and (kern.get("leaf_rows") or not sdf.info()["specialized"]): e2 = e2 or int(o2.stats.evals_leaf) != m.evals_rows
+                if k4 and sc == 1: e2 = e2 or int(o2.stats.evals_leaf) != (m.evals_points_tails if kern.get("leaf_dense") else m.evals_points_256)
             fl = hip.FlatHIP(sdf, res)   # flat renderer: COLUMN-mode lattice pass + balanced marching pass
             mf = ref.render_flat(res, 4096, 2)
             e4 = (fl.n_tris() != mf.n_tris) or (fl.Evaluations() != mf.evals) or (mf.n_tris and not (srt(fl.RenderAll()).view(np.uint32) == srt(mf.tris).view(np.uint32)).all())
