@@ -310,7 +310,7 @@ def main():
     ap.add_argument("--no-gather-pipeline", action="store_true",
                     help="N > 1: wait for a mesh's gather before meshing the next (default: the payload of mesh i moves while mesh i+1 is made)")
     ap.add_argument("--no-distinct-rows", action="store_true", help="skip the share_corners = 2 measurement that follows the timed loop (profiles of the headline's kernels alone)")
-    ap.add_argument("--share-corners", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2],
+    ap.add_argument("--share-corners", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2, 3],
                     help="0: every corner of every leaf, as the reference (headline); 1: each bitwise-distinct lattice corner of a brick once (older fused kernel); "
                          "2: the bitwise-distinct z rows of a brick once each (same kernels, same triangles, a quarter fewer evaluations)")
     args = ap.parse_args()
@@ -404,7 +404,7 @@ def main():
     gmode = {"all": hip.GATHER_ALL, "root": hip.GATHER_ROOT, "none": hip.GATHER_NONE}[args.gather]
     pipeline = comm is not None and not args.no_gather_pipeline
     # what moves in the gather: packed cut-leaf records by default (marching cubes then runs on the receiving ranks)
-    records = (comm is not None and args.payload == "records" and args.gather != "none" and args.renderer == "octree" and args.share_corners != 1)
+    records = (comm is not None and args.payload == "records" and args.gather != "none" and args.renderer == "octree")
     payload = hip.PAYLOAD_RECORDS if records else hip.PAYLOAD_TRIANGLES
     gstat = {"n": 0, "ms_counts": 0.0, "ms_payload": 0.0, "ms_march": 0.0, "bytes_received": 0, "bytes_sent": 0}
     pending = []  # at most one gather in flight: (PendingGather)
@@ -551,7 +551,8 @@ def main():
                                     + ((", gather of " + ("packed cut-leaf records (marching cubes after the gather)" if records else "triangles") + " inside the library over " + comm.transport() + " (gsdf_hip_mesh_gatherv_start/_wait): mode " + args.gather
                                         + (", payload of mesh i overlapped with mesh i+1" if pipeline else ", not pipelined")) if comm is not None else ", RCCL all-gatherv of triangles through torch.distributed (fallback)")) if (world > 1 or comm is not None) else "single GPU",
                        "leaf_corners": {0: "8 per leaf (as the reference)", 1: "shared (distinct lattice points once)",
-                                        2: "the bitwise-distinct z rows of a brick once each (evals_per_step counts the evaluations performed)"}[args.share_corners],
+                                        2: "the bitwise-distinct z rows of a brick once each (evals_per_step counts the evaluations performed)",
+                                        3: "distinct lattice points or distinct z rows of a brick once each, chosen by the library for the tree (evals_per_step counts the evaluations performed)"}[args.share_corners],
                        "evaluator": spec_note, "code": code,
                        "setup": f"{args.preheat} untimed meshes before the warmup steps (clock ramp)",
                        "steps": ("meshes pipelined two deep on one handle (gsdf_hip_mesh_octree_start / _wait): mesh k+1's kernels are enqueued before mesh k "

@@ -423,7 +423,11 @@ extern "C" int gsdf_hip_mesh_octree_start(gsdf_program* p, float res, const gsdf
   if (opts.shard_count < 1 || opts.shard_rank < 0 || opts.shard_rank >= opts.shard_count) return fail(GSDF_ERR_BAD_ARGUMENT, "bad shard rank/count");
   if (opts.payload != GSDF_PAYLOAD_TRIANGLES && opts.payload != GSDF_PAYLOAD_RECORDS) return fail(GSDF_ERR_BAD_ARGUMENT, "bad payload kind");
   const bool want_recs = opts.payload == GSDF_PAYLOAD_RECORDS;
-  if (opts.share_corners < 0 || opts.share_corners > 2) return fail(GSDF_ERR_BAD_ARGUMENT, "share_corners is 0 (every corner of every leaf, as the reference), 1 (distinct lattice points of a brick) or 2 (distinct z rows of a brick)");
+  if (opts.share_corners < 0 || opts.share_corners > 3) return fail(GSDF_ERR_BAD_ARGUMENT, "share_corners is 0 (every corner of every leaf, as the reference), 1 (distinct lattice points of a brick), 2 (distinct z rows of a brick) or 3 (1 or 2, whichever suits the tree)");
+  // 3: by the program's share of work that depends on x and y alone (the column bricks of 0 and 2 compute it once per lane for all z
+  // rows, the packed points of 1 give that up): hypot / atan2 sharing instructions weighted as for the one-body leaf kernel. bolt (0)
+  // and knurled-cylinder (2) gain 9 % / 17 % from 1, npt-flange (7) loses 40 % with it and breaks even with 2.
+  if (opts.share_corners == 3) opts.share_corners = gsdf_dev::spec_xy_shared_weight(p->prog) < 3 ? 1 : 2;
   if (want_recs && (opts.host_output || opts.max_tris || fused_leaf()))
     return fail(GSDF_ERR_BAD_ARGUMENT, "payload = records goes with the two-kernel leaf phase only (no host_output, max_tris, fused leaf kernel)");
   HIP_TRY(hipSetDevice(p->device));

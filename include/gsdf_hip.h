@@ -173,7 +173,9 @@ typedef struct gsdf_mesh_opts {
                          2: the bitwise-distinct z rows of a brick once each (a brick's eight rows of corners are five to eight
                          distinct planes: row 2k-1 = (O + res (i-1)) + res and row 2k = O + res i are the same float on most planes)
                          -- the default's kernels, a quarter fewer evaluations, identical distances, records and triangles.
-                         stats.evals then counts the evaluations performed, not the reference's 8 per leaf. */
+                         stats.evals then counts the evaluations performed, not the reference's 8 per leaf;
+                         3: 1 or 2, chosen by how much of the tree's work depends on x and y alone (threads, knurls, transformed
+                         parts: 1; mostly axisymmetric parts: 2). */
   int host_output;    /* 1: the triangle buffer is pinned, device-mapped HOST memory and the mesher writes it across PCIe
                          while it runs (gsdf_hip_mesh_host_tris then returns that buffer: mesh + transfer 4.x ms instead
                          of 1.7 + 4.4 ms at npt-flange resdiv 1600). For results that are consumed on the host only:

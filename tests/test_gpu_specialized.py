@@ -65,6 +65,9 @@ def test_specialised_mesh_identical(gpu, scene, key):
     if sdf.info()["kernels"].get("leaf_rows"):   # (a tree whose distinct-rows kernel does not build without scratch keeps every row)
         assert rows.stats.evals < oc.stats.evals and int(rows.stats.evals_leaf) == ref.evals_rows   # the oracle's count for the surviving bricks
     dense = gpu.OctreeHIP(sdf, res, share_corners=1)
+    auto = gpu.OctreeHIP(sdf, res, share_corners=3)   # the library's choice between the two, by the tree: threads and knurls take the points
+    assert (_sorted(auto.RenderAll()).view(np.uint32) == tg.view(np.uint32)).all()
+    assert int(auto.stats.evals_leaf) == int((rows if scene == "npt-flange" else dense).stats.evals_leaf)
     if sdf.info()["leaf_k"] == 4:   # lane slots: passes of 256 + a tail of 64 / 128 / 256 in the specialised build, passes of 256 in the interpreter's
         assert int(dense.stats.evals_leaf) == (ref.evals_points_tails if sdf.info()["kernels"].get("leaf_dense") else ref.evals_points_256)
     parts = [gpu.OctreeHIP(sdf, res, shard_rank=r, shard_count=2, share_corners=2) for r in range(2)]
