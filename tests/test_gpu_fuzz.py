@@ -53,7 +53,7 @@ def test_random_trees_distances_and_meshes(gpu, seed):
             assert (_sorted(oc.RenderAll()).view(np.uint32) == want).all(), (seed, k)
             meshed += 1
             # the evaluations the reference repeats left out: distinct lattice points (1) / distinct z rows (2) of a brick once each
-            for sc in (1, 2):
+            for sc in ((1, 2) if k % 2 else ()):   # (every other tree: each option is a mesh and a sort of its own)
                 sh_ = gpu.OctreeHIP(sdf, res, share_corners=sc)
                 assert sh_.n_tris() == m.n_tris and sh_.stats.evals <= oc.stats.evals, (seed, k, sc)
                 assert (_sorted(sh_.RenderAll()).view(np.uint32) == want).all(), (seed, k, sc)

@@ -86,7 +86,14 @@ def test_specialised_full_size_npt_flange(gpu):
     assert hashlib.sha256(_sorted(oc.RenderAll()).tobytes()).hexdigest() == g["sha256_sorted"]
     rows = gpu.OctreeHIP(sdf, res, share_corners=2)   # distinct z rows of every brick once: the same set from fewer evaluations
     assert rows.n_tris() == g["n_tris"] and rows.stats.evals < oc.stats.evals
-    assert hashlib.sha256(_sorted(rows.RenderAll()).tobytes()).hexdigest() == g["sha256_sorted"]
+
+    def bag(t):   # order-independent fingerprint of a triangle multiset (a sort of 6.8 M triangles is 15 s; the default mesh above is sorted and hashed)
+        w = np.ascontiguousarray(t, np.float32).reshape(-1, 9).view(np.uint32).astype(np.uint64)
+        h = np.zeros(len(w), np.uint64)
+        for c in range(9):
+            h = (h * np.uint64(0x9E3779B97F4A7C15) + w[:, c]) ^ (h >> np.uint64(29))
+        return int(h.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(h))
+    assert bag(rows.RenderAll()) == bag(oc.RenderAll())
 
 
 def test_specialise_is_idempotent_and_counts_evaluations(gpu):
