@@ -141,6 +141,10 @@ int gsdf_mesh_job::enqueue() {
     // S dependent ones. GSDF_HIP_PRUNE_SPEC=0 keeps one launch per level (cross-check in the tests).
     int first_level = levels;  // first level of the per-level chain
     chain_first = levels;
+    // Brick masks (dev_ops.h: D_SKIP): valid when the last level of cubes, which the leaf kernels continue from, is a level-3 brick
+    // that was centre-tested by interval evaluation -- that test leaves, in every surviving cube's w field, which operand
+    // subtrees of the program cannot matter anywhere in the cube. GSDF_HIP_NO_BRICK_MASKS=1: no numbers in the program at all.
+    const bool masks_valid = lq == 3 && ptest == 1 && p->prog.n_skip_ids > 0 && (pmask == 1 || (pmask > 1 && ((pmask >> lq) & 1)));
     unsigned* spec_part = nullptr;  // statistics rows of the speculative top, for the first per-level launch to add up
     unsigned spec_rows = 0, spec_mask = 0;
     int spec_top_S = 0;
@@ -154,7 +158,13 @@ int gsdf_mesh_job::enqueue() {
       // launch -- if there is one (else the resolve stage issues its atomics itself)
       const unsigned rrows = (n_spec + SPEC_STAGE - 1) / SPEC_STAGE;
       const size_t part_off = ((size_t)n_spec + 63) & ~(size_t)63;
-      HIP_TRYM(w.spec_pass.ensure(part_off + (size_t)rrows * 16 * sizeof(unsigned)));
+      // brick masks of the block's last level, when that is the level the leaf kernels continue from (meshes of up to nine levels):
+      // two bytes per cube of that level, behind the statistics rows
+      const unsigned n_last = 1u << (3 * (S - 1));
+      const size_t mask_off_b = (part_off + (size_t)rrows * 16 * sizeof(unsigned) + 63) & ~(size_t)63;
+      const bool spec_masks = masks_valid && last_spec == lq;
+      HIP_TRYM(w.spec_pass.ensure(mask_off_b + (spec_masks ? (size_t)n_last * sizeof(uint16_t) : 0)));
+      uint16_t* d_mask16 = spec_masks ? (uint16_t*)((char*)w.spec_pass.p + mask_off_b) : nullptr;
       const bool chain_follows = last_spec - 1 >= lq;
       spec_part = chain_follows ? (unsigned*)((char*)w.spec_pass.p + part_off) : nullptr;
       spec_rows = rrows;
@@ -166,15 +176,17 @@ int gsdf_mesh_job::enqueue() {
       if (p->f_prune_spec) {
         HIP_TRYM(launch_fn(p->f_prune_spec, sgrid, BLOCK, lds_prune, s, (const uint32_t*)p->d_code, (int)levels, (unsigned)n_spec, (int)prune_cols,
                            (int)p->prog.nslots, ox, oy, oz, res, (unsigned)test_mask, (int)ptest, (int)shard_level, (unsigned)opts.shard_rank,
-                           (unsigned)opts.shard_count, (uint8_t*)w.spec_pass.p, (unsigned*)d_ctr, (unsigned)(clear_bytes / 4)));
+                           (unsigned)opts.shard_count, (uint8_t*)w.spec_pass.p, (unsigned*)d_ctr, (unsigned)(clear_bytes / 4), d_mask16,
+                           (unsigned)(n_spec - n_last)));
       } else {
         hipLaunchKernelGGL(prune_spec_kernel, dim3(sgrid), dim3(BLOCK), lds_prune, s, p->d_code, levels, n_spec, prune_cols, p->prog.nslots, ox, oy,
                            oz, res, test_mask, ptest, shard_level, (unsigned)opts.shard_rank, (unsigned)opts.shard_count, (uint8_t*)w.spec_pass.p,
-                           (unsigned*)d_ctr, (unsigned)(clear_bytes / 4));
+                           (unsigned*)d_ctr, (unsigned)(clear_bytes / 4), d_mask16, n_spec - n_last);
       }
       HIP_TRYM(hipGetLastError());
       hipLaunchKernelGGL(prune_resolve_kernel, dim3((n_spec + SPEC_STAGE - 1) / SPEC_STAGE), dim3(BLOCK), 0, s, (const uint8_t*)w.spec_pass.p, levels, S,
-                         n_spec, test_mask, (Cube*)q[last_spec & 1]->p, (unsigned long long)capq[last_spec & 1], d_ctr, spec_part);
+                         n_spec, test_mask, (Cube*)q[last_spec & 1]->p, (unsigned long long)capq[last_spec & 1], d_ctr, spec_part,
+                         (const uint16_t*)d_mask16);
       HIP_TRYM(hipGetLastError());
       first_level = last_spec - 1;
       chain_first = first_level;
@@ -225,7 +237,7 @@ int gsdf_mesh_job::enqueue() {
 #define LAUNCH_LEAF_EVAL_U(KK, WW, UU, NN, LDS)                                                                                    \
   hipLaunchKernelGGL((leaf_eval_kernel<KK, WW, UU, NN>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), LDS, s, p->d_code, \
                      (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res, d_hdr,   \
-                     d_rec, d_psum, (unsigned long long)nblk, d_ctr)
+                     d_rec, d_psum, (unsigned long long)nblk, d_ctr, (unsigned)(masks_valid ? 1u : 0u))
         // lq == 3 (three levels or more): a wave pass is one level-3 cube (column bricks, scalar prefetched cube load), its
         // case-count table in LDS unless that costs a workgroup per CU; else a few leaves (occupancy is no concern: table in LDS)
 #define LAUNCH_LEAF_EVAL(KK, WW)                                                             \
@@ -237,30 +249,30 @@ int gsdf_mesh_job::enqueue() {
 #define LAUNCH_LEAF_EVAL_DZ(WW, NN)                                                                                                 \
   hipLaunchKernelGGL((leaf_eval_kernel<4, WW, true, NN, false, true>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), lds_m, s, p->d_code, \
                      (const Cube*)q[lq & 1]->p, (unsigned long long)capq[lq & 1], lq, p->prog.nslots, ox, oy, oz, res, d_hdr,   \
-                     d_rec, d_psum, (unsigned long long)nblk, d_ctr)
+                     d_rec, d_psum, (unsigned long long)nblk, d_ctr, (unsigned)(masks_valid ? 1u : 0u))
         if (used_dense) {
           const size_t lds_d = p->lds_dense();
           if (p->f_leaf_dense) {
             HIP_TRYM(launch_fn(p->f_leaf_dense, grid_for(bound, p->num_cu, leaf_bpc), BLOCK, lds_d, s, (const uint32_t*)p->d_code, (const Cube*)q[lq & 1]->p,
-                               (unsigned long long)capq[lq & 1], (int)p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec, d_psum, (unsigned long long)nblk, d_ctr));
+                               (unsigned long long)capq[lq & 1], (int)p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec, d_psum, (unsigned long long)nblk, d_ctr, (unsigned)(masks_valid ? 1u : 0u)));
           } else if (3 * lds_d <= (size_t)160 * 1024) {  // the interpreter's kernels: scratch-free occupancies only, passes of four points per lane
             hipLaunchKernelGGL((leaf_dense_kernel<3, true, false>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), lds_d, s, p->d_code, (const Cube*)q[lq & 1]->p,
-                               (unsigned long long)capq[lq & 1], p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec, d_psum, (unsigned long long)nblk, d_ctr);
+                               (unsigned long long)capq[lq & 1], p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec, d_psum, (unsigned long long)nblk, d_ctr, (unsigned)(masks_valid ? 1u : 0u));
           } else {
             hipLaunchKernelGGL((leaf_dense_kernel<2, true, false>), dim3(grid_for(bound, p->num_cu, leaf_bpc)), dim3(BLOCK), lds_d, s, p->d_code, (const Cube*)q[lq & 1]->p,
-                               (unsigned long long)capq[lq & 1], p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec, d_psum, (unsigned long long)nblk, d_ctr);
+                               (unsigned long long)capq[lq & 1], p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec, d_psum, (unsigned long long)nblk, d_ctr, (unsigned)(masks_valid ? 1u : 0u));
           }
         } else if (used_dz && p->f_leaf_dz) {
           HIP_TRYM(launch_fn(p->f_leaf_dz, grid_for(bound, p->num_cu, leaf_bpc), BLOCK, lds_m, s, (const uint32_t*)p->d_code, (const Cube*)q[lq & 1]->p,
                              (unsigned long long)capq[lq & 1], (int)lq, (int)p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec, d_psum,
-                             (unsigned long long)nblk, d_ctr));
+                             (unsigned long long)nblk, d_ctr, (unsigned)(masks_valid ? 1u : 0u)));
         } else if (used_dz) {  // the interpreter's kernels (scratch-free occupancies only, as below)
           if (p->leaf_nt_in_lds()) { if (lw == 2) LAUNCH_LEAF_EVAL_DZ(2, true); else LAUNCH_LEAF_EVAL_DZ(3, true); }
           else { if (lw == 2) LAUNCH_LEAF_EVAL_DZ(2, false); else LAUNCH_LEAF_EVAL_DZ(3, false); }
         } else if (p->f_leaf && p->spec_leaf_k == lk && lq == 3) {
           HIP_TRYM(launch_fn(p->f_leaf, grid_for(bound, p->num_cu, leaf_bpc), BLOCK, lds_m, s, (const uint32_t*)p->d_code, (const Cube*)q[lq & 1]->p,
                              (unsigned long long)capq[lq & 1], (int)lq, (int)p->prog.nslots, ox, oy, oz, res, d_hdr, d_rec, d_psum,
-                             (unsigned long long)nblk, d_ctr));
+                             (unsigned long long)nblk, d_ctr, (unsigned)(masks_valid ? 1u : 0u)));
         } else {
           // ahead-of-time kernels exist at the scratch-free occupancies only (tests/test_kernel_resources.py)
           if (lk == 4) { if (lw == 2) LAUNCH_LEAF_EVAL(4, 2); else LAUNCH_LEAF_EVAL(4, 3); }

@@ -47,6 +47,19 @@ struct Ctx {
   int lip_depth = 0, max_lip_depth = 0;  // nesting of the position maps that stretch (interval stack of D_LIP_PUSH / _POP)
   int lip_push() { const int d = lip_depth++; if (lip_depth > max_lip_depth) max_lip_depth = lip_depth; op(D_LIP_PUSH, d); return d; }
   void lip_pop(int d) { op(D_LIP_POP, d); lip_depth--; }
+  // Brick masks (dev_ops.h: D_SKIP / D_LIP_DOM). discont > 0: inside a position map that jumps (array cell, circular sector, screw
+  // sawtooth) -- no numbers there. The lowering runs twice: the first run lists the candidate operand subtrees in emission order
+  // with their costs, the 16 most expensive get a number, the second run emits them.
+  int discont = 0;
+  bool numbering = false;          // second run
+  std::vector<double> cand_cost;   // first run: cost of candidate i
+  std::vector<int> cand_id;        // second run: number of candidate i, or -1
+  size_t cand_next = 0;
+  int candidate(double cost) {
+    const size_t i = cand_next++;
+    if (!numbering) { cand_cost.push_back(cost); return -1; }
+    return i < cand_id.size() ? cand_id[i] : -1;
+  }
   size_t max_code;
   std::vector<int8_t> clob;  // memo: -1 unknown, 0/1
   struct Table { size_t patch; float angle; int n; };
@@ -674,12 +687,50 @@ void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int dept
     c.u((uint32_t)(ub.size() / (is2d ? 4 : 6)));
     for (float v : ub) c.f(v);
   }
+  // Brick masks: which operands of this frame may carry a number (dev_ops.h: D_SKIP). kind = D_LIP_DOM's.
+  int dom_kind = -1;
+  switch (comb) {
+    case D_COMBINE_MIN: dom_kind = 0; break;
+    case D_COMBINE_MAX: dom_kind = 1; break;
+    case D_COMBINE_DIFF: dom_kind = 2; break;
+    case D_COMBINE_SUNION: if (n.p[0] > 0) dom_kind = 3; break;
+    case D_COMBINE_SDIFF: if (n.p[0] > 0) dom_kind = 4; break;
+    case D_COMBINE_SINTER: if (n.p[0] > 0) dom_kind = 5; break;
+    default: break;
+  }
+  if (c.discont > 0) dom_kind = -1;
+  std::vector<int> sid(n.nchild, -1);  // by child number
+  if (dom_kind >= 0)
+    for (uint32_t k = 0; k < n.nchild; k++) sid[order[k]] = c.candidate(cost[order[k]]);  // (emission order)
+  bool any_id = false;
+  for (int v : sid) any_id = any_id || v >= 0;
+  // the frame's entry position magnitude for D_LIP_DOM's padding: interval stack[depth], second column (D_LIP_PUSH stores it)
+  int dom_depth = -1;
+  if (any_id) { dom_depth = c.lip_depth++; if (c.lip_depth > c.max_lip_depth) c.max_lip_depth = c.lip_depth; c.op(D_LIP_PUSH, dom_depth); }
+  auto subst_of = [&](uint32_t ck) -> float {  // the side of the combine on which a dominated operand lies
+    const bool a_role = ck == 0;
+    switch (dom_kind) {
+      case 0: case 3: return GSDF_SKIP_BIG;
+      case 1: case 5: return -GSDF_SKIP_BIG;
+      default: return a_role ? -GSDF_SKIP_BIG : GSDF_SKIP_BIG;  // (smooth) difference: minuend far below, subtrahend far above
+    }
+  };
   bool dirty = false;
   for (uint32_t k = 0; k < n.nchild; k++) {
     if (k > 0 && dirty) { c.load_saved(slotP, is2d); dirty = false; }
     const uint32_t ck = order[k];
     uint32_t ch = c.child(n, ck);
     long skip_at = -1, gate_pc = -1;
+    long bskip_pc = -1, bskip_at = -1;
+    const uint32_t bs_xyver = c.xyver, bs_hxy = c.hxyver;
+    if (sid[ck] >= 0) {
+      bskip_pc = (long)c.code.size();
+      c.op(D_SKIP | c.shxy_flag(), 0);
+      c.u((uint32_t)sid[ck]);
+      c.f(subst_of(ck));
+      bskip_at = (long)c.code.size();
+      c.u(0);  // patched below: words to the end of the subtree
+    }
     if (worth[ck] && (k > 0 || bounded)) {
       const Region& g = reg[ck];
       const bool minus = comb == D_COMBINE_DIFF || comb == D_COMBINE_SDIFF;  // compare with -a
@@ -706,7 +757,7 @@ void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int dept
       c.f(ctx ? outer.ok : 0.0f);
       c.f(ctx && comb == D_COMBINE_SDIFF ? 0.25f * n.p[0] * 1.0001f : 0.0f);
       skip_at = (long)c.code.size();
-      c.u(0);  // patched below: words from this instruction to the child's combine instruction
+      c.u(0);  // patched below: words from this instruction to the child's combine instruction | (brick-mask number + 1) << 24
     }
     const uint32_t hxy_before = c.hxyver;
     // a (smooth) difference whose subtrahend is already in slotD hands its minuend the context (k == 1: evaluated second)
@@ -720,13 +771,37 @@ void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int dept
     // a child that may be skipped at run time may not have refreshed the hypot(x,y) register: forget what it cached
     if (skip_at >= 0 && c.hxyver != hxy_before) c.hxyver = 0;
     dirty = dirty || clobbers(c, ch);
-    if (skip_at >= 0) c.code[(size_t)skip_at] = (uint32_t)((long)c.code.size() - gate_pc);
-    if (k > 0 || bounded) { c.op(comb | ((asym && swapped) ? D_FLAG_SWAP : 0u), slotD); if (has_k) { c.f(n.p[0]); c.f(recip_for(n.p[0])); } }
+    if (skip_at >= 0) c.code[(size_t)skip_at] = (uint32_t)((long)c.code.size() - gate_pc) | ((uint32_t)(sid[ck] + 1) << 24);
+    if (bskip_at >= 0) {
+      c.code[(size_t)bskip_at] = (uint32_t)((long)c.code.size() - bskip_pc);
+      // the subtree left hypot(x, y) of ITS ENTRY position in the register (a primitive right under the frame): the skip path
+      // computes the same value; anything else it may have cached is forgotten
+      if (c.hxyver != bs_hxy) {
+        if (c.hxyver == bs_xyver) c.code[(size_t)bskip_pc] |= D_FLAG_HXY;
+        else c.hxyver = 0;
+      }
+    }
+    if (k > 0 || bounded) {
+      const uint32_t swapf = (asym && swapped) ? D_FLAG_SWAP : 0u;
+      const int first_id = (k == 1 && !bounded) ? sid[order[0]] : -1, second_id = sid[ck];
+      if (first_id >= 0 || second_id >= 0) {
+        const int ida = swapf ? second_id : first_id, idb = swapf ? first_id : second_id;
+        c.op(D_LIP_DOM | swapf, slotD);
+        c.u((uint32_t)dom_kind);
+        c.u(ida >= 0 ? (uint32_t)ida : 0xffu);
+        c.u(idb >= 0 ? (uint32_t)idb : 0xffu);
+        c.f(has_k ? 1.002f * n.p[0] : 0.0f);
+        c.u((uint32_t)dom_depth | (is2d ? 0x10000u : 0u));
+      }
+      c.op(comb | swapf, slotD);
+      if (has_k) { c.f(n.p[0]); c.f(recip_for(n.p[0])); }
+    }
     if (k + 1 < n.nchild) {
       if (slotD < 0) slotD = c.alloc(1);
       c.op(D_SAVER, slotD);
     }
   }
+  if (dom_depth >= 0) c.lip_depth--;
   if (slotD >= 0) c.release(1);
   if (own_save) { c.live.pop_back(); c.release(is2d ? 2 : 3); }
 }
@@ -785,7 +860,7 @@ void gen(Ctx& c, uint32_t i, int depth) {
         c.f((float)ii); c.f((float)j); c.f((float)k);
         c.f(P[0]); c.f(P[1]); c.f(P[2]);
         c.f(P[3] + -1); c.f(P[4] + -1); c.f(P[5] + -1);
-        gen(c, c.child(n, 0), depth + 1);
+        c.discont++; gen(c, c.child(n, 0), depth + 1); c.discont--;
         c.op(D_COMBINE_MIN, slotD);
         if (!(k == 1 && j == 1 && ii == 1)) c.op(D_SAVER, slotD);
       }
@@ -862,6 +937,7 @@ void gen(Ctx& c, uint32_t i, int depth) {
         cg = o;
       }
       if (sector_gate) { c.op(D_CIRC_ORDER, slotP); for (int j = 0; j < 6; j++) c.f(cg.b[j]); }
+      c.discont++;  // a sector's copy of the child is evaluated where the point's fold puts it: no brick-level numbers inside
       gen(c, c.child(n, 0), depth + 1);  // pos1 first (or whichever D_CIRC_ORDER put there)
       c.op(D_SAVER, slotD);
       c.load_saved(slotP, is2d);
@@ -877,6 +953,7 @@ void gen(Ctx& c, uint32_t i, int depth) {
         c.u(0);
       }
       gen(c, c.child(n, 0), depth + 1);  // pos0
+      c.discont--;
       if (skip_at >= 0) {
         if (c.hxyver != hxy_before) c.hxyver = 0;  // a child that may be skipped may not have refreshed the hypot register
         c.code[(size_t)skip_at] = (uint32_t)((long)c.code.size() - gate_pc);
@@ -913,7 +990,7 @@ void gen(Ctx& c, uint32_t i, int depth) {
       c.bump();
       c.f(P[0]); c.f(P[1]); c.f(P[2]); c.f(gsdf::tanf32(P[3])); c.f(P[0] / 2); c.f(recip_for(P[0]));
       c.op(D_LIP_WRAP); c.f(P[0] / 2); c.f(lip_screw_seam(*c.t, c.child(n, 0), P[0]));
-      gen(c, c.child(n, 0), depth + 1);
+      c.discont++; gen(c, c.child(n, 0), depth + 1); c.discont--;  // (the profile coordinate is a sawtooth of the axial one)
       c.lip_pop(lipd);
       c.op(D_MAXR_SLOT, s);
       c.release(1);
@@ -1006,7 +1083,7 @@ void gen(Ctx& c, uint32_t i, int depth) {
         c.op(D_ARRAY2D_PRE, slotP);
         c.bump();
         c.f((float)ii); c.f((float)j); c.f(P[0]); c.f(P[1]); c.f(P[2] + -1); c.f(P[3] + -1);
-        gen(c, c.child(n, 0), depth + 1);
+        c.discont++; gen(c, c.child(n, 0), depth + 1); c.discont--;
         c.op(D_COMBINE_MIN, slotD);
         if (!(j == 1 && ii == 1)) c.op(D_SAVER, slotD);
       }
@@ -1116,10 +1193,32 @@ int region_of(const gsdf_tree& t, uint32_t node, float params[8]) {
 
 Program compile(const gsdf_tree& t, size_t max_code_words) {
   validate(t);
+  // first run: the candidate operand subtrees of the brick masks, in emission order, with their costs
+  std::vector<int> cand_id;
+  {
+    Ctx c0;
+    c0.t = &t;
+    c0.max_code = max_code_words;
+    c0.clob.assign(t.n_nodes, -1);
+    gen(c0, t.root, 0);
+    static const bool masks_off = [] { const char* e = getenv("GSDF_HIP_NO_BRICK_MASKS"); return e && atoi(e) != 0; }();  // developer knob (A/B timing, cross-check in the tests)
+    cand_id.assign(c0.cand_cost.size(), -1);
+    if (!masks_off) {
+      std::vector<size_t> idx(c0.cand_cost.size());
+      for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
+      std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return c0.cand_cost[x] > c0.cand_cost[y]; });
+      std::vector<char> take(idx.size(), 0);
+      for (size_t i = 0; i < idx.size() && i < 16; i++) take[idx[i]] = 1;
+      int next = 0;
+      for (size_t i = 0; i < take.size(); i++) if (take[i]) cand_id[i] = next++;
+    }
+  }
   Ctx c;
   c.t = &t;
   c.max_code = max_code_words;
   c.clob.assign(t.n_nodes, -1);
+  c.numbering = true;
+  c.cand_id = cand_id;
   gen(c, t.root, 0);
   c.op(D_END);
   for (const Ctx::Table& tb : c.tables) {
@@ -1135,6 +1234,8 @@ Program compile(const gsdf_tree& t, size_t max_code_words) {
   p.code = std::move(c.code);
   p.nslots = c.max_slots;
   p.lip_depth = c.max_lip_depth;
+  p.n_skip_ids = 0;
+  for (int v : cand_id) if (v >= 0) p.n_skip_ids++;
   p.is2d = gsdf_op_is2d(t.nodes[t.root].op);
   p.has_exact_bb = exact_box(c, t.root, p.exact_bb);
   std::memcpy(p.bb, t.bb, sizeof(p.bb));

@@ -12,6 +12,7 @@ struct Program {
   std::vector<uint32_t> code;  // dev_ops.h stream, terminated by D_END
   int nslots = 0;              // LDS scratch slots per lane
   int lip_depth = 0;           // slots of the interval stack (dev_ops.h: D_LIP_PUSH / _POP); prune_kernel's columns = nslots + lip_depth
+  int n_skip_ids = 0;          // operand subtrees that carry a brick-mask number (dev_ops.h: D_SKIP); 0: the leaf kernels get no masks
   bool is2d = false;           // root takes 2D positions
   float bb[6] = {0};
   // Set when the whole field is known to be >= the Euclidean distance to `exact_bb` (exact-distance primitives under

@@ -95,7 +95,8 @@ enum DevOp : uint32_t {
   //      1e-3 (L + |a|) + 2e-6 (|x| + |y| + |z|), a thousand times the rounding of either side), the child's value b >= L
   //      leaves the combine's result unchanged bit for bit (see gen_combine): R = L and the program counter advances
   //      by `skip` words to the child's combine instruction, which runs on (a, L). Wave-uniform forward branch -- the one
-  //      non-straight-line instruction of the stream.
+  //      non-straight-line instruction of the stream. The skip word's top byte holds the child's brick-mask number + 1
+  //      (0: none; see D_SKIP below).
   //      Context of ONE enclosing combine (oslot != 0xffff; differences only): the gated child b is the subtrahend of
   //      X = (smooth) max(a, -b), and X is itself the minuend of an enclosing (smooth) difference max(X, -c) whose other
   //      operand c was evaluated first and sits in lds[oslot]. With U = max(a, -L) + k4 >= X (k4 = a quarter of the inner
@@ -139,11 +140,42 @@ enum DevOp : uint32_t {
   //      child is >= L(centre) - lipR everywhere in the ball; the test runs on that against both ends of `a` (the two points),
   //      and the substitute (both ends = L - lipR) leaves the combine's interval what the ungated evaluation gives, bit for
   //      bit (min / max select a's ends; a clamped blend weight multiplies the substitute by 0) -- the oracle has no gates.
-  D_LIP_PUSH,   // (slot = nesting depth)  interval stack[depth] <- lipR           (before a map that stretches)
+  D_LIP_PUSH,   // (slot = nesting depth)  interval stack[depth] <- lipR, |P.x| + |P.y| + |P.z|  (before a map that stretches; at the entry of a combine frame with numbered operands)
   D_LIP_POP,    // (slot = nesting depth)  lipR <- interval stack[depth]           (after its subtree)
   D_LIP_MUL,    // f : lipR *= f  (non-rigid D_TRANSFORM / D_ROT2D: largest singular value, rounded up)
   D_LIP_WRAP,   // halfpitch seam : after D_SCREW_PRE; if |P.x| + lipR >= halfpitch (the image may reach a seam of the
                 // sawtooth) lipR += seam (what the profile's field can jump by there; compile.cpp: lip_screw_seam)
+  // ---- brick masks (round 5). The last level of centre tests evaluates the field in interval mode over the bounding ball of
+  //      every level-3 cube -- exactly the brick (4 x 4 x 4 leaves, 512 corner evaluations) one wave of the leaf kernels then
+  //      evaluates point by point. What the intervals prove for the whole ball holds for every corner of the brick, so the
+  //      centre test hands the leaf kernel a 16-bit mask with the cube (Cube.w): bit i = "operand subtree i cannot influence
+  //      its combine anywhere in this brick". Up to 16 operand subtrees of combine frames (compile.cpp: the most expensive
+  //      ones that sit under continuous position maps only -- array cells, circular sectors and screw sawteeth jump, and a
+  //      copy's decision at the centre says nothing about the same instruction for a point across the seam) carry a number.
+  //      D_SKIP (first instruction of such a subtree): if the wave's brick mask has the bit, R <- subst and the program counter
+  //      advances to the end of the subtree (the D_SAVER or combine that follows), a wave-uniform forward branch decided by a
+  //      scalar bit test -- no per-point gate test at all. subst = +-1e30, the side of the combine on which the operand
+  //      provably lies: min / max then select the other operand, a smooth combine's weight clamps to exactly 0 or 1 and subst
+  //      enters times 0 with the sign the true value would have had (a zero result keeps its sign): same bits as evaluating the
+  //      subtree. D_FLAG_HXY on D_SKIP: the subtree would have left hypot(P.x, P.y) of the entry position in the register for
+  //      code behind it -- the skip path computes it instead. Elsewhere (no brick: Evaluate, lattices, dual contouring; interval
+  //      mode itself) the mask is 0 and D_SKIP falls through.
+  //      D_LIP_DOM (in front of a combine, interval mode only): records, per lane = per cube, which operand of the combine
+  //      dominates over the whole ball, with a = the formula's first operand, b its second (D_FLAG_SWAP: b was evaluated first
+  //      and sits in lds[slot], a is in R), kk = 1.002 k for the smooth combines, m = kk + 1e-3 (|u| + |v|) + pad:
+  //        kind 0 min(a, b)        : b.lo > a.hi + m -> skip b (+)      a.lo > b.hi + m -> skip a (+)
+  //        kind 1 max(a, b)        : b.hi < a.lo - m -> skip b (-)      a.hi < b.lo - m -> skip a (-)
+  //        kind 2 max(a, -b)       : b.lo > -a.lo + m -> skip b (+)     a.hi < -b.hi - m -> skip a (-)
+  //        kind 3 smooth union     : b.lo - a.hi > m -> skip b (+)      a.lo - b.hi > m -> skip a (+)
+  //        kind 4 smooth difference: b.lo + a.lo > m -> skip b (+)      b.hi + a.hi < -m -> skip a (-)
+  //        kind 5 smooth intersect.: a.lo - b.hi > m -> skip b (-)      b.lo - a.hi > m -> skip a (-)
+  //      ((+) / (-): the sign of the D_SKIP's subst.) pad = 2e-6 (|x| + |y| + |z| + 4 lipR) of the frame's entry position
+  //      (pinfo: the depth of the interval stack where the frame's D_LIP_PUSH left it). A D_GATE* in interval mode records its child's bit the same way
+  //      (the child's bound outside its region in place of b.lo) for every lane that passes, whether or not the wave as a
+  //      whole skips; a gate whose child carries a number is not tested per point by a wave that holds a valid brick mask
+  //      (bit 31 of the mask): the brick-level decision replaces it.
+  D_SKIP,       // id subst skip|flags<<24 : words from this instruction to the end of the subtree
+  D_LIP_DOM,    // kind ida idb kk pinfo   (slot = the combine's; ida / idb = 0xff: none; pinfo = interval-stack depth | is2d << 16)
   D_OP_COUNT
 };
 
@@ -161,4 +193,9 @@ static const uint8_t kDevOpParams[D_OP_COUNT] = {
     /*MIN*/ 0, /*MAX*/ 0, /*DIFF*/ 0, /*XOR*/ 0, /*SUNION*/ 2, /*SDIFF*/ 2, /*SINTER*/ 2,
     /*GATE2D*/ 10, /*GATE3D*/ 12, /*GATEZC*/ 13, /*UBOUND2D*/ 1, /*UBOUND3D*/ 1, /*GATEOB*/ 14, /*CIRC_ORDER*/ 6,
     /*LIP_PUSH*/ 0, /*LIP_POP*/ 0, /*LIP_MUL*/ 1, /*LIP_WRAP*/ 2,
+    /*SKIP*/ 3, /*LIP_DOM*/ 5,
 };
+#define GSDF_GATE_SKIP(w) ((w) & 0x00ffffffu)  // a gate's (and D_SKIP's) last parameter word: words to skip | (number + 1) << 24 (D_SKIP: flags << 24)
+#define GSDF_GATE_ID1(w) ((w) >> 24)
+#define GSDF_BRICK_MASK_VALID 0x80000000u      // brick mask handed to sdf_eval: bits 0..15 subtree numbers, bit 31 "a centre test produced it"
+#define GSDF_SKIP_BIG 1.0e30f

@@ -278,22 +278,31 @@ __device__ __forceinline__ void region_lb_obox(const P3 (&pv)[K], float cx, floa
 // child cannot change its own combine), or -- with the context of the enclosing difference, c = its other operand -- the
 // upper bound U = max(a, -L) + k4 of the inner result is negative and c + U <= -ok by the margin (the enclosing combine
 // discards the inner result).
-template <int K, int DIM>
+// LIP (interval mode: the lane's two points are the two ends of `a` and `c` over one ball): the lane passes if BOTH ends pass the
+// first test or BOTH ends pass the second -- each test is monotone in (a, c), so its holding at the two extreme corners is its
+// holding for every pair of values in between; one end by one test and the other end by the other test says nothing about
+// the values in between. *lane_good (optional) = this lane's own verdict, whatever the rest of the wave says (D_LIP_DOM's
+// gate form: the brick mask is per cube).
+template <int K, int DIM, bool LIP = false>
 __device__ __forceinline__ bool gate_far(const P3 (&pv)[K], const float (&a)[K], const float (&L)[K], float sg, float kk,
-                                         const float (&c)[K], bool has_outer, float ok, float k4) {
+                                         const float (&c)[K], bool has_outer, float ok, float k4, bool* lane_good = nullptr) {
   using namespace dm;
-  bool far = true;
+  bool far = true, far2 = true;
   KLOOP {
     float S = absf(pv[kp].x) + absf(pv[kp].y);
     if (DIM == 3) S += absf(pv[kp].z);
     const float pad = 2e-6f * S;
-    bool good = (L[kp] > 0.0f) && (L[kp] > sg * a[kp] + kk + (1e-3f * (L[kp] + absf(a[kp])) + pad));
+    const bool g1 = (L[kp] > 0.0f) && (L[kp] > sg * a[kp] + kk + (1e-3f * (L[kp] + absf(a[kp])) + pad));
+    bool g2 = false;
     if (has_outer) {
       const float U = maxf(a[kp], -L[kp]) + k4;
-      good = good || ((U < 0.0f) && (c[kp] + U <= -ok - (1e-3f * (absf(c[kp]) + absf(U)) + pad)));
+      g2 = (U < 0.0f) && (c[kp] + U <= -ok - (1e-3f * (absf(c[kp]) + absf(U)) + pad));
     }
-    far = far && good;
+    if (LIP) { far = far && g1; far2 = far2 && g2; }
+    else far = far && (g1 || g2);
   }
+  if (LIP) far = far || (has_outer && far2);
+  if (lane_good != nullptr) *lane_good = far;
   return __all(far) != 0;
 }
 
@@ -355,12 +364,72 @@ __device__ __forceinline__ void smooth_h(const float (&num)[K], float k, float r
 #define LIP_HI (K - 1)
 // value -+ radius: an exact distance (or any other 1-Lipschitz term of the current frame) over the ball
 #define LIP_WIDEN(lo, hi) { lo = lo - lipR; hi = hi + lipR; }
+// D_LIP_DOM (dev_ops.h): which operand of the combine that follows dominates over the whole ball, per lane = per cube. One text for
+// the interpreter (below, in the dispatch's default branch) and the specialised build (specialize.cpp emits the macro).
+#define GSDF_LIP_DOM_BODY \
+        if (LIP) {                                                                                                                     \
+          if (lip_fired != nullptr) {                                                                                                  \
+            const uint32_t kind = PU(0), ida = PU(1), idb = PU(2), pinfo = PU(4);                                                      \
+            const float kk = PF(3);                                                                                                    \
+            /* first evaluated operand: lds[slot]; second: R. swap_ab: the formula's second operand b was evaluated first. */          \
+            const float f_lo = lds[((slot) * K + LIP_LO) * nthreads], f_hi = lds[((slot) * K + LIP_HI) * nthreads];                    \
+            const float alo = swap_ab ? Rv[LIP_LO] : f_lo, ahi = swap_ab ? Rv[LIP_HI] : f_hi;                                          \
+            const float blo = swap_ab ? f_lo : Rv[LIP_LO], bhi = swap_ab ? f_hi : Rv[LIP_HI];                                          \
+            /* |x| + |y| + |z| of the frame's entry position (the centre): D_LIP_PUSH left it on the interval stack, second column */  \
+            const float S = lds[((lip_base + (pinfo & 0xffffu)) * K + LIP_HI) * nthreads];                                             \
+            const float pad = kk + 2e-6f * (S + 4.0f * lipR);                                                                          \
+            auto GSDF_DOM_M = [&](float u, float v) { return pad + 1e-3f * (absf(u) + absf(v)); };                                     \
+            bool sa = false, sb = false;                                                                                               \
+            switch (kind) {                                                                                                            \
+              case 0u: sb = blo > ahi + GSDF_DOM_M(blo, ahi); sa = alo > bhi + GSDF_DOM_M(alo, bhi); break;                            \
+              case 1u: sb = bhi < alo - GSDF_DOM_M(bhi, alo); sa = ahi < blo - GSDF_DOM_M(ahi, blo); break;                            \
+              case 2u: sb = blo > -alo + GSDF_DOM_M(blo, alo); sa = ahi < -bhi - GSDF_DOM_M(ahi, bhi); break;                          \
+              case 3u: sb = blo - ahi > GSDF_DOM_M(blo, ahi); sa = alo - bhi > GSDF_DOM_M(alo, bhi); break;                            \
+              case 4u: sb = blo + alo > GSDF_DOM_M(blo, alo); sa = bhi + ahi < -GSDF_DOM_M(bhi, ahi); break;                           \
+              case 5u: sb = alo - bhi > GSDF_DOM_M(alo, bhi); sa = blo - ahi > GSDF_DOM_M(blo, ahi); break;                            \
+              default: break;                                                                                                          \
+            }                                                                                                                          \
+            if (sa && ida < 32u) *lip_fired |= 1u << ida;                                                                              \
+            if (sb && idb < 32u) *lip_fired |= 1u << idb;                                                                              \
+          }                                                                                                                            \
+        }                                                                                                                              \
+
+// The test of a D_GATE* instruction (dev_ops.h), shared by the interpreter's four cases and the specialised build's generated
+// text: REGION fills L[] from the gate's region parameters; I0 = index of the `sg` parameter (then kk, oslot, ok, k4, skip word).
+// Leaves far_ (wave-uniform: the child is skipped) and L (the substitute) in scope.
+#define GSDF_GATE_TEST(REGION, DIM, I0)                                                                                      \
+  float L[K];                                                                                                               \
+  bool far_ = false;                                                                                                        \
+  {                                                                                                                         \
+    const uint32_t gid1 = GSDF_GATE_ID1(PU((I0) + 5));                                                                      \
+    /* a numbered child under a valid brick mask: the centre test decided for the whole brick (D_SKIP), no per-point test */ \
+    const bool untested = !LIP && gid1 != 0u && (bmask & GSDF_BRICK_MASK_VALID) != 0u;                                      \
+    if (!untested) {                                                                                                        \
+      float a[K], cc[K];                                                                                                    \
+      const uint32_t oslot = PU((I0) + 2);                                                                                  \
+      const bool has_outer = oslot != 0xffffu; /* wave-uniform */                                                           \
+      KLOOP { a[kp] = LDSF(slot); cc[kp] = has_outer ? LDSF(oslot) : 0.0f; }                                                \
+      REGION;                                                                                                               \
+      if (LIP) KLOOP L[kp] = L[kp] - lipR; /* interval mode: the bound over the whole ball (L is 1-Lipschitz), against both ends of a */ \
+      bool lane_good = false;                                                                                               \
+      far_ = gate_far<K, DIM, LIP>(pv, a, L, PF(I0), PF((I0) + 1), cc, has_outer, PF((I0) + 3), PF((I0) + 4), &lane_good);  \
+      if (LIP && gid1 != 0u && lip_fired != nullptr && lane_good) *lip_fired |= 1u << (gid1 - 1u);                          \
+    }                                                                                                                       \
+  }
+// the skipped child's value: its lower bound (interval mode: the valid interval [bound, "no upper bound"])
+#define GSDF_GATE_TAKEN                                                       \
+  {                                                                           \
+    if (LIP) { Rv[LIP_LO] = L[LIP_LO]; Rv[LIP_HI] = GSDF_SKIP_BIG; }          \
+    else { KLOOP Rv[kp] = L[kp]; }                                            \
+  }
 #ifndef GSDF_SPECIALIZED
 template <int K, int SHARE = 0, bool LIP = false>
 __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)[K],
                                          float* __restrict__ lds /* already offset by tid */, const uint32_t nthreads,
                                          const bool brick = false /* wave-uniform: the wave is spatially compact (polygon edge culling pays, poly_cull); with SHARE = 2 also: point kp has the same z in every lane; see xy_shared */,
-                                         const float lip_h = 0.0f, const uint32_t lip_base = 0u) {
+                                         const float lip_h = 0.0f, const uint32_t lip_base = 0u,
+                                         const uint32_t bmask = 0u /* wave-uniform: the brick mask of the cube this wave evaluates (dev_ops.h: D_SKIP); 0 where a wave is no brick */,
+                                         uint32_t* lip_fired = nullptr /* interval mode: this lane's brick mask is OR-ed in here */) {
   using namespace dm;
   static_assert(!LIP || (K == 2 && SHARE == 0), "interval mode: two points per lane, lower and upper bound");
   [[maybe_unused]] float lipR = lip_h;
@@ -1192,63 +1261,23 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       case D_GATE2D: {
-        float a[K], L[K], cc[K];
-        const uint32_t oslot = PU(6);
-        const bool has_outer = oslot != 0xffffu;  // wave-uniform
-        KLOOP { a[kp] = LDSF(slot); cc[kp] = has_outer ? LDSF(oslot) : 0.0f; }
-        region_lb_box<K, 2>(pv, PF(0), PF(1), 0.f, PF(2), PF(3), 0.f, L);
-        if (LIP) KLOOP L[kp] = L[kp] - lipR;  // interval mode: the bound over the whole ball (L is 1-Lipschitz), against both ends of a
-        if (gate_far<K, 2>(pv, a, L, PF(4), PF(5), cc, has_outer, PF(7), PF(8))) {
-          KLOOP Rv[kp] = L[kp];
-          pc += PU(9);
-        } else {
-          pc += 11;
-        }
+        GSDF_GATE_TEST((region_lb_box<K, 2>(pv, PF(0), PF(1), 0.f, PF(2), PF(3), 0.f, L)), 2, 4)
+        if (far_) { GSDF_GATE_TAKEN pc += GSDF_GATE_SKIP(PU(9)); } else { pc += 11; }
         break;
       }
       case D_GATE3D: {
-        float a[K], L[K], cc[K];
-        const uint32_t oslot = PU(8);
-        const bool has_outer = oslot != 0xffffu;
-        KLOOP { a[kp] = LDSF(slot); cc[kp] = has_outer ? LDSF(oslot) : 0.0f; }
-        region_lb_box<K, 3>(pv, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5), L);
-        if (LIP) KLOOP L[kp] = L[kp] - lipR;
-        if (gate_far<K, 3>(pv, a, L, PF(6), PF(7), cc, has_outer, PF(9), PF(10))) {
-          KLOOP Rv[kp] = L[kp];
-          pc += PU(11);
-        } else {
-          pc += 13;
-        }
+        GSDF_GATE_TEST((region_lb_box<K, 3>(pv, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5), L)), 3, 6)
+        if (far_) { GSDF_GATE_TAKEN pc += GSDF_GATE_SKIP(PU(11)); } else { pc += 13; }
         break;
       }
       case D_GATEZC: {
-        float a[K], L[K], cc[K];
-        const uint32_t oslot = PU(9);
-        const bool has_outer = oslot != 0xffffu;
-        KLOOP { a[kp] = LDSF(slot); cc[kp] = has_outer ? LDSF(oslot) : 0.0f; }
-        region_lb_zcyl<K>(pv, hxy, use_hxy, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5), PF(6), L);
-        if (LIP) KLOOP L[kp] = L[kp] - lipR;
-        if (gate_far<K, 3>(pv, a, L, PF(7), PF(8), cc, has_outer, PF(10), PF(11))) {
-          KLOOP Rv[kp] = L[kp];
-          pc += PU(12);
-        } else {
-          pc += 14;
-        }
+        GSDF_GATE_TEST((region_lb_zcyl<K>(pv, hxy, use_hxy, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5), PF(6), L)), 3, 7)
+        if (far_) { GSDF_GATE_TAKEN pc += GSDF_GATE_SKIP(PU(12)); } else { pc += 14; }
         break;
       }
       case D_GATEOB: {
-        float a[K], L[K], cc[K];
-        const uint32_t oslot = PU(10);
-        const bool has_outer = oslot != 0xffffu;
-        KLOOP { a[kp] = LDSF(slot); cc[kp] = has_outer ? LDSF(oslot) : 0.0f; }
-        region_lb_obox<K, 3>(pv, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5), PF(6), PF(7), L);
-        if (LIP) KLOOP L[kp] = L[kp] - lipR;
-        if (gate_far<K, 3>(pv, a, L, PF(8), PF(9), cc, has_outer, PF(11), PF(12))) {
-          KLOOP Rv[kp] = L[kp];
-          pc += PU(13);
-        } else {
-          pc += 15;
-        }
+        GSDF_GATE_TEST((region_lb_obox<K, 3>(pv, PF(0), PF(1), PF(2), PF(3), PF(4), PF(5), PF(6), PF(7), L)), 3, 8)
+        if (far_) { GSDF_GATE_TAKEN pc += GSDF_GATE_SKIP(PU(13)); } else { pc += 15; }
         break;
       }
       case D_CIRC_ORDER: {
@@ -1272,11 +1301,37 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         break;
       }
       // ------------------------------------------------ interval mode bookkeeping (no-ops elsewhere)
-      case D_LIP_PUSH: { if (LIP) lds[((lip_base + slot) * K) * nthreads] = lipR; pc += 1; break; }
+      case D_LIP_PUSH: {
+        if (LIP) {  // second column: the magnitude of the position here (D_LIP_DOM pads its comparisons by it)
+          lds[((lip_base + slot) * K) * nthreads] = lipR;
+          lds[((lip_base + slot) * K + LIP_HI) * nthreads] = absf(pv[0].x) + absf(pv[0].y) + absf(pv[0].z);
+        }
+        pc += 1;
+        break;
+      }
       case D_LIP_POP: { if (LIP) lipR = lds[((lip_base + slot) * K) * nthreads]; pc += 1; break; }
       case D_LIP_MUL: { if (LIP) lipR = minf(lipR * PF(0), GSDF_LIP_BIG); pc += 2; break; }
       case D_LIP_WRAP: { if (LIP) { if (absf(pv[0].x) + lipR >= PF(0)) lipR = lipR + PF(1); } pc += 3; break; }
+      // ------------------------------------------------ brick masks (dev_ops.h: D_SKIP, D_LIP_DOM). Not cases of their own: two
+      // more entries in the dispatch tree cost the ahead-of-time kernels that sit exactly at their register budget four spilled
+      // VGPRs (flat_grid_kernel<4, 4>, dc_origin_kernel<2, 4>: tests/test_kernel_resources.py), and a kernel with scratch is not used.
       default:
+        if (op == D_SKIP) {
+        const uint32_t sw = PU(2);
+        if (!LIP && ((bmask >> (PU(0) & 31u)) & 1u) != 0u) {  // wave-uniform: the centre test proved this operand irrelevant for the whole brick
+          if (use_hxy) xy_shared<K>(pv, hxy, sh_xy, brick, [](float x, float y) { return dm::hypotf_(x, y); }, sh_col);  // (flag on D_SKIP: code behind the subtree reuses the hypot the subtree would have left)
+          KLOOP Rv[kp] = PF(1);
+          pc += GSDF_GATE_SKIP(sw);
+        } else {
+          pc += 4;
+        }
+          break;
+        }
+        if (op == D_LIP_DOM) {
+          GSDF_LIP_DOM_BODY
+          pc += 6;
+          break;
+        }
         KLOOP Rv[kp] = __builtin_nanf("");
         return;
     }
@@ -1300,5 +1355,8 @@ namespace gsdf_dev {
 #undef LIP_WIDEN
 #undef LIP_LO
 #undef LIP_HI
+#undef GSDF_GATE_TEST
+#undef GSDF_GATE_TAKEN
+#undef GSDF_LIP_DOM_BODY
 
 }  // namespace gsdf_dev

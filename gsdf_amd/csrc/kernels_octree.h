@@ -97,8 +97,12 @@ __global__ void __launch_bounds__(BLOCK) prune_kernel(const uint32_t* __restrict
         gsdf_dev::sdf_eval<2>(code, pv, dv, lds, BLOCK);
         keep = valid && !nb::abs_ge(dv[0], maxDist);
       } else {
-        gsdf_dev::sdf_eval<2, 0, true>(code, pv, dv, lds, BLOCK, false, maxDist, (uint32_t)lip_base);
+        // interval evaluation over the cube's bounding ball; `fired` = this cube's brick mask (dev_ops.h: D_SKIP), handed on in
+        // Cube.w: the leaf kernels read it at the last level (there the cube IS the brick a wave evaluates), the levels above ignore it
+        uint32_t fired = 0u;
+        gsdf_dev::sdf_eval<2, 0, true>(code, pv, dv, lds, BLOCK, false, maxDist, (uint32_t)lip_base, 0u, &fired);
         keep = valid && !(nb::ge0(dv[0]) || nb::le0(dv[1]));
+        c.w = (uint16_t)fired;
       }
     }
     const unsigned long long pm = __ballot(keep);
@@ -166,7 +170,9 @@ __device__ __forceinline__ Cube spec_cube(unsigned j, unsigned k) {
 __global__ void __launch_bounds__(BLOCK) prune_spec_kernel(const uint32_t* __restrict__ code_g, int top, unsigned n_spec, int ncols,
                                                            int lip_base, float ox, float oy, float oz, float res, unsigned test_mask,
                                                            int ptest, int shard_level, unsigned shard_rank, unsigned shard_count,
-                                                           uint8_t* __restrict__ pass, unsigned* __restrict__ clear_p, unsigned clear_words) {
+                                                           uint8_t* __restrict__ pass, unsigned* __restrict__ clear_p, unsigned clear_words,
+                                                           uint16_t* __restrict__ mask16 /* brick masks of the block's last level (by number within the level), or null */,
+                                                           unsigned mask_off /* first cube of that level */) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
   (void)ncols;
@@ -196,8 +202,10 @@ __global__ void __launch_bounds__(BLOCK) prune_spec_kernel(const uint32_t* __res
       gsdf_dev::sdf_eval<2>(code, pv, dv, lds, BLOCK);
       keep = !nb::abs_ge(dv[0], maxDist);
     } else {
-      gsdf_dev::sdf_eval<2, 0, true>(code, pv, dv, lds, BLOCK, false, maxDist, (uint32_t)lip_base);  // (maxDist differs from lane to lane: fine, it is the lane's own radius)
+      uint32_t fired = 0u;
+      gsdf_dev::sdf_eval<2, 0, true>(code, pv, dv, lds, BLOCK, false, maxDist, (uint32_t)lip_base, 0u, &fired);  // (maxDist differs from lane to lane: fine, it is the lane's own radius)
       keep = !(nb::ge0(dv[0]) || nb::le0(dv[1]));
+      if (mask16 != nullptr && valid && tested && i >= mask_off) mask16[i - mask_off] = (uint16_t)fired;
     }
     if (!tested) keep = true;
     const bool own = level != shard_level || brick_owner(c.x, c.y, c.z, shard_count) == shard_rank;
@@ -213,7 +221,8 @@ __global__ void __launch_bounds__(BLOCK) prune_spec_kernel(const uint32_t* __res
 #define SPEC_STAGE 2048
 __global__ void __launch_bounds__(BLOCK) prune_resolve_kernel(const uint8_t* __restrict__ pass, int top, int S, unsigned n_spec,
                                                               unsigned test_mask, Cube* __restrict__ out, unsigned long long out_cap,
-                                                              MeshCounters* __restrict__ ctr, unsigned* __restrict__ part) {
+                                                              MeshCounters* __restrict__ ctr, unsigned* __restrict__ part,
+                                                              const uint16_t* __restrict__ mask16 /* brick masks of level top - (S - 1), by number within the level; or null */) {
   __shared__ Cube s_q[SPEC_STAGE];
   __shared__ unsigned s_n, s_items[8], s_pass[8];
   __shared__ unsigned long long s_base;
@@ -241,7 +250,11 @@ __global__ void __launch_bounds__(BLOCK) prune_resolve_kernel(const uint8_t* __r
       if (me & 1u) atomicAdd(&s_pass[j], 1u);
       if (me == 3u && (int)j == S - 1) {
         const unsigned slot = atomicAdd(&s_n, 1u);
-        if (slot < SPEC_STAGE) s_q[slot] = spec_cube(j, k);
+        if (slot < SPEC_STAGE) {
+          Cube c = spec_cube(j, k);
+          if (mask16 != nullptr) c.w = mask16[k];
+          s_q[slot] = c;
+        }
       }
     }
   }
@@ -673,7 +686,8 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
                                                           unsigned long long cube_cap, int lq, int nslots, float ox, float oy, float oz,
                                                           float res, uint32_t* __restrict__ hdr, uint32_t* __restrict__ rec,
                                                           unsigned long long* __restrict__ psum, unsigned long long n_blocks_cap,
-                                                          MeshCounters* __restrict__ ctr) {
+                                                          MeshCounters* __restrict__ ctr,
+                                                          unsigned mask_valid /* the cubes' w fields are brick masks of the last centre-test level (dev_ops.h: D_SKIP) */) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
   // triangles per marching-cubes case, behind the interpreter's columns (256 B)
@@ -747,6 +761,8 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
       const unsigned bx = ((unsigned)(cw & 0xffffu)) << 2, by = ((unsigned)((cw >> 16) & 0xffffu)) << 2, bz = ((unsigned)((cw >> 32) & 0xffffu)) << 2;
       const float xa = ox + res * (float)(uint16_t)(bx + ((lane & 7u) >> 1)), ya = oy + res * (float)(uint16_t)(by + (lane >> 4));
       const float px = (lane & 1u) ? xa + res : xa, py = (lane & 8u) ? ya + res : ya;
+      // what the last centre test proved for this whole brick: operand subtrees that cannot matter anywhere in it (scalar)
+      const uint32_t bmask = mask_valid ? (__builtin_amdgcn_readfirstlane((uint32_t)(cw >> 48)) | GSDF_BRICK_MASK_VALID) : 0u;
       float dall[8];  // distances of rows 0..7; static shift register
 #pragma unroll
       for (int j = 0; j < 8; j++) dall[j] = 0.f;
@@ -761,7 +777,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
       pk[kp].y = py;                                                         \
       pk[kp].z = (r & 1u) ? za + res : za;                                   \
     }                                                                        \
-    gsdf_dev::sdf_eval<K, 2>(code, pk, dk, lds, BLOCK, /*brick=*/true);      \
+    gsdf_dev::sdf_eval<K, 2>(code, pk, dk, lds, BLOCK, /*brick=*/true, 0.0f, 0u, bmask); \
     _Pragma("unroll") for (int j = 0; j < 8 - K; j++) dall[j] = dall[j + K]; \
     _Pragma("unroll") for (int kp = 0; kp < K; kp++) dall[8 - K + kp] = dk[kp]; \
   }
@@ -800,7 +816,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
       pk[kp].y = py;                                                                         \
       pk[kp].z = (r & 1u) ? za + res : za;                                                   \
     }                                                                                        \
-    gsdf_dev::sdf_eval<KK, 2>(code, pk, dk, lds, BLOCK, /*brick=*/true);                     \
+    gsdf_dev::sdf_eval<KK, 2>(code, pk, dk, lds, BLOCK, /*brick=*/true, 0.0f, 0u, bmask);    \
     _Pragma("unroll") for (int kp = 0; kp < KK; kp++) dall[(D0) + kp] = dk[kp];              \
   }
         if (BOTH) {  // one body: what depends on x and y alone is computed once for all the rows
@@ -957,7 +973,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_dense_kernel(const uint32_t
                                                                   unsigned long long cube_cap, int nslots, float ox, float oy, float oz, float res,
                                                                   uint32_t* __restrict__ hdr, uint32_t* __restrict__ rec,
                                                                   unsigned long long* __restrict__ psum, unsigned long long n_blocks_cap,
-                                                                  MeshCounters* __restrict__ ctr) {
+                                                                  MeshCounters* __restrict__ ctr, unsigned mask_valid /* see leaf_eval_kernel */) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
   const size_t cols = (size_t)(nslots * 4 > 8 ? nslots * 4 : 8) * BLOCK;
@@ -979,6 +995,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_dense_kernel(const uint32_t
   for (uint64_t brick = (uint64_t)blockIdx.x * 4 + wave; brick < n_cubes; brick += step) {  // wave-uniform; no barrier inside
     const unsigned long long cw = uniform_u64(*(const unsigned long long*)(cubes + brick));
     const unsigned pidx[3] = {(unsigned)(cw & 0xffffu), (unsigned)((cw >> 16) & 0xffffu), (unsigned)((cw >> 32) & 0xffffu)};
+    const uint32_t bmask = mask_valid ? ((uint32_t)(cw >> 48) | GSDF_BRICK_MASK_VALID) : 0u;  // the brick's mask from the last centre test (scalar)
     // per axis: planes 1..3 with two distinct floats (bits, not ==: -0 and +0 are different points to an evaluator)
     unsigned mb[3], nax[3];
 #pragma unroll
@@ -1019,7 +1036,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_dense_kernel(const uint32_t
       const unsigned ux = r - uy * nx;                                                            \
       pk[kp] = P3{val[ux], val[8u + uy], val[16u + uz]};                                          \
     }                                                                                             \
-    gsdf_dev::sdf_eval<KK>(code, pk, dk, lds, BLOCK, /*brick=*/true);                             \
+    gsdf_dev::sdf_eval<KK>(code, pk, dk, lds, BLOCK, /*brick=*/true, 0.0f, 0u, bmask);            \
     _Pragma("unroll") for (int kp = 0; kp < KK; kp++) {                                           \
       const unsigned t = (T0) + (unsigned)kp * 64u + lane;                                        \
       if (t < N) D[t] = dk[kp];                                                                   \

@@ -39,6 +39,19 @@ def decode(code):
     return out
 
 
+def at(ins, target, field=0):
+    """The instruction a gate's skip lands on: the child's combine (an interval-mode-only D_LIP_DOM in front of it is stepped over)."""
+    k = [j for j, i in enumerate(ins) if i[4] == target]
+    assert len(k) == 1, target
+    j = k[0] + (1 if ins[k[0]][0] == "D_LIP_DOM" else 0)
+    return [ins[j][field]]
+
+
+def skipw(code, at_):
+    """A gate's skip distance (the word's top byte is the child's brick-mask number + 1)."""
+    return int(code[at_]) & 0xffffff
+
+
 def test_opcode_table_is_consistent():
     assert len(NAMES) == len(NPAR)
     assert NAMES[0] == "D_END"
@@ -68,10 +81,14 @@ def test_npt_flange_program():
     f = code.view(np.float32)
     g0, g1 = gates[0][4], gates[1][4]
     assert f[g0 + 7] == 1.0 and abs(f[g0 + 8] - 1.002 * 0.2) < 1e-6 and f[g1 + 8] == -1.0 and f[g1 + 9] == 0.0
-    assert int(code[g0 + 9]) == 0xffff and int(code[g1 + 10]) == 0xffff            # no enclosing-difference context here
-    t0, t1 = g0 + int(code[g0 + 12]), g1 + int(code[g1 + 13])
-    assert [i[0] for i in ins if i[4] == t0] == ["D_COMBINE_SUNION"] and [i[0] for i in ins if i[4] == t1] == ["D_COMBINE_DIFF"]
-    assert [i[3] for i in ins if i[4] == t0] == [gates[0][3]] and [i[3] for i in ins if i[4] == t1] == [gates[1][3]]
+    assert skipw(code, g0 + 9) == 0xffff and skipw(code, g1 + 10) == 0xffff            # no enclosing-difference context here
+    # (the skip word's top byte carries the child's brick-mask number + 1; the skip lands on the combine, or on the
+    # interval-mode-only D_LIP_DOM in front of it)
+    t0, t1 = g0 + (int(code[g0 + 12]) & 0xffffff), g1 + (int(code[g1 + 13]) & 0xffffff)
+    assert [i[0] for i in ins if i[4] in (t0, t0 + 6)] == ["D_LIP_DOM", "D_COMBINE_SUNION"]
+    assert [i[0] for i in ins if i[4] in (t1, t1 + 6)] == ["D_LIP_DOM", "D_COMBINE_DIFF"]
+    assert at(ins, t0 + 6, 3) == [gates[0][3]] and at(ins, t1 + 6, 3) == [gates[1][3]]
+    assert int(code[g0 + 12]) >> 24 and int(code[g1 + 13]) >> 24      # both gated children carry a number
     # polygon edge records start on a 32-byte boundary
     poly = [i for i in ins if i[0] == "D_POLY2D"][0]
     assert ((poly[4] + 4 + 7) & ~7) % 8 == 0
@@ -142,9 +159,9 @@ def test_far_child_skip_in_wide_unions():
     skips = [i for i in gates if i[3] == ub[0][3]]           # those testing against the slot the bound was stored in
     assert len(skips) == 24                                  # every glyph, the first one included
     for k, (name, _, _, slot, pc) in enumerate(skips):
-        target = pc + int(code[pc + 10])
-        assert [i[0] for i in ins if i[4] == target] == ["D_COMBINE_MIN"]   # lands on the child's combine ...
-        assert [i[3] for i in ins if i[4] == target] == [slot]              # ... of the same running-minimum slot
+        target = pc + skipw(code, pc + 10)
+        assert at(ins, target, 0) == ["D_COMBINE_MIN"]   # lands on the child's combine ...
+        assert at(ins, target, 3) == [slot]              # ... of the same running-minimum slot
         x0, y0, x1, y1 = f[pc + 1:pc + 5]
         assert x1 - x0 == 6.0 and y1 - y0 == 10.0            # glyph cell of the scene (threads.hpp: 6 x 10)
         assert f[pc + 5] == 1.0 and f[pc + 6] == 0.0         # union: compare with +a, no blend width
@@ -153,9 +170,9 @@ def test_far_child_skip_in_wide_unions():
     inner = [i for i in gates if i[3] != ub[0][3]]
     assert len(inner) == 6
     for (name, _, _, slot, pc) in inner:
-        target = pc + int(code[pc + 10])
-        assert [i[0] for i in ins if i[4] == target] == ["D_COMBINE_DIFF"] and f[pc + 5] == -1.0 and f[pc + 6] == 0.0
-        assert [i[2] for i in ins if i[4] == target] == [False]   # never with swapped operands: only a subtrahend can be skipped
+        target = pc + skipw(code, pc + 10)
+        assert at(ins, target, 0) == ["D_COMBINE_DIFF"] and f[pc + 5] == -1.0 and f[pc + 6] == 0.0
+        assert at(ins, target, 2) == [False]   # never with swapped operands: only a subtrahend can be skipped
     # children without a lower-bound claim are never skipped: approximate primitives
     def mk(child):
         return b.Union2D(b.NewCircle(1), b.Translate2D(b.NewCircle(1), 3, 0), b.Translate2D(b.NewCircle(1), 6, 0), child)
@@ -218,8 +235,8 @@ def test_gates_of_binary_combines():
     assert len(g) == 1 and g[0][0] == "D_GATE3D" and f[g[0][4] + 7] == 1.0 and f[g[0][4] + 8] == 0.0
     names = [i[0] for i in ins]
     assert names.index("D_SPHERE") < names.index("D_POLY2D")
-    tgt = g[0][4] + int(code[g[0][4] + 12])
-    assert [i[0] for i in ins if i[4] == tgt] == ["D_COMBINE_MIN"]
+    tgt = g[0][4] + skipw(code, g[0][4] + 12)
+    assert at(ins, tgt, 0) == ["D_COMBINE_MIN"]
     # difference sphere - extrusion: the subtrahend is gated with sg = -1; extrusion - sphere: nothing (the minuend is the
     # result, and the sphere is not worth a test)
     ins, g, f, code = gate(b.Difference(sph(), ext()))
@@ -230,13 +247,13 @@ def test_gates_of_binary_combines():
     for sh in (b.SmoothUnion(0.3, ext(), sph()), b.SmoothUnion(0.3, sph(), ext())):
         ins, g, f, code = gate(sh)
         assert len(g) == 1 and f[g[0][4] + 7] == 1.0 and abs(f[g[0][4] + 8] - 1.002 * 0.3) < 1e-6
-        assert [i[0] for i in ins if i[4] == g[0][4] + int(code[g[0][4] + 12])] == ["D_COMBINE_SUNION"]
+        assert at(ins, g[0][4] + skipw(code, g[0][4] + 12), 0) == ["D_COMBINE_SUNION"]
     ins, g, f, code = gate(b.SmoothDifference(0.3, sph(), ext()))
     assert len(g) == 1 and f[g[0][4] + 7] == -1.0 and abs(f[g[0][4] + 8] - 1.002 * 0.3) < 1e-6
     assert gate(b.SmoothDifference(0.3, ext(), sph()))[1] == []
     # a smooth union's own region is the hull of its operands grown by k / 4
     ins, g, f, code = gate(b.Union(b.Translate(b.SmoothUnion(0.4, ext(), b.NewSphere(1)), 10, 0, 0), sph()))
-    outer = [q for q in g if [i[0] for i in ins if i[4] == q[4] + int(code[q[4] + 12])] == ["D_COMBINE_MIN"]]
+    outer = [q for q in g if at(ins, q[4] + skipw(code, q[4] + 12), 0) == ["D_COMBINE_MIN"]]
     assert len(outer) == 1
     x0, y0, z0, x1, y1, z1 = f[outer[0][4] + 1:outer[0][4] + 7]
     assert abs(x0 - (10 - 1 - 0.1)) < 1e-3 and abs(x1 - (10 + 2.5 + 0.1)) < 1e-3 and abs(z0 - (-1 - 0.1)) < 1e-3 and abs(y1 - (2.5 + 0.1)) < 1e-3
@@ -257,7 +274,7 @@ def test_gate_regions_of_screws_and_rotational_ops():
     pc = zc[0][4]
     cx, cy, r, z0, z1, rs, rin, sg, kk = f[pc + 1:pc + 10]
     assert cx == 0 and cy == 0 and 1.5 < r < 1.56 and abs((z1 - z0) - 8.0) < 1e-3 and 0.99999 < rs < 1.0 and rin == 0 and sg == 1.0 and kk == 0.0
-    assert [i[0] for i in ins if i[4] == pc + int(code[pc + 13])] == ["D_COMBINE_MIN"]
+    assert at(ins, pc + skipw(code, pc + 13), 0) == ["D_COMBINE_MIN"]
     # npt-flange: tapered thread -> rs = 1 / (1 + 1/32)
     code, _ = hip.lower(b.Scene("npt-flange"))
     f = code.view(np.float32)
@@ -279,13 +296,13 @@ def test_gate_regions_of_screws_and_rotational_ops():
     f = code.view(np.float32)
     ins = decode(code)
     gz = [i for i in ins if i[0] == "D_GATEZC"]
-    ctx = [i for i in gz if int(code[i[4] + 10]) != 0xffff]
+    ctx = [i for i in gz if skipw(code, i[4] + 10) != 0xffff]
     assert len(ctx) == 1
     pc = ctx[0][4]
     hole = [i for i in ins if i[0] == "D_SAVER"][0]                                 # the hole cylinder's value is saved first
-    assert int(code[pc + 10]) == hole[3] and f[pc + 8] == -1.0 and abs(f[pc + 9] - 1.002) < 1e-6
+    assert skipw(code, pc + 10) == hole[3] and f[pc + 8] == -1.0 and abs(f[pc + 9] - 1.002) < 1e-6
     assert abs(f[pc + 11] - 1.002) < 1e-6 and abs(f[pc + 12] - 0.25) < 1e-4 and 8.9 < f[pc + 7] < 8.94
-    assert [i[0] for i in ins if i[4] == pc + int(code[pc + 13])] == ["D_COMBINE_SDIFF"]
+    assert at(ins, pc + skipw(code, pc + 13), 0) == ["D_COMBINE_SDIFF"]
 
 
 def test_hxy_not_reused_across_xy_changes():
@@ -357,10 +374,75 @@ def test_sector_gate_of_circular_arrays():
             cx, cy, c, s, hx, hy, z0, z1, sg, kk = f[pc + 1:pc + 11]
             assert abs(cx - 6) < 1e-4 and cy == 0 and abs(c - np.cos(0.5)) < 1e-5 and abs(abs(s) - np.sin(0.5)) < 1e-5   # the tooth's box, turned by 0.5 rad
             assert 1.0 < hx < 1.3 and 1.0 < hy < 1.3 and abs(z0 + 1.5) < 0.01 and abs(z1 - 1.5) < 0.01
-            assert sg == 1.0 and kk == 0.0 and int(code[pc + 11]) == 0xffff
-            assert [j[0] for j in ins if j[4] == pc + int(code[pc + 14])] == ["D_COMBINE_MIN"]
+            assert sg == 1.0 and kk == 0.0 and skipw(code, pc + 11) == 0xffff
+            assert at(ins, pc + skipw(code, pc + 14), 0) == ["D_COMBINE_MIN"]
             assert ins[k - 1][0] == "D_LOADP3" and ins[k - 2][0] == "D_SAVER" and ins[k - 2][3] == i[3]  # a = the first copy's value
     # cheaper children (knurled-cylinder's cutter: a turned box, 95 instructions) or children without a box (a torus) get neither
     for tree in (b.Scene("knurled-cylinder"), b.CircularArray(b.Translate(b.NewTorus(1.0, 0.3), 3, 0, 0), 8, 8)):
         nm = [i[0] for i in decode(hip.lower(tree)[0])]
         assert "D_CIRC_ORDER" not in nm and "D_GATEOB" not in nm
+
+
+def test_brick_mask_numbering():
+    """Brick masks (dev_ops.h: D_SKIP / D_LIP_DOM): operand subtrees of combine frames under continuous position maps carry a
+    number -- a D_SKIP in front of the subtree whose skip ends exactly where the subtree ends (the D_SAVER or, through an
+    interval-mode-only D_LIP_DOM, the combine), a substitute on the side of the combine where a dominated operand lies, and a
+    D_LIP_DOM that names both operands of its combine by role."""
+    b = Builder()
+    BIG = np.float32(1e30)
+    for scene in ("npt-flange", "bolt", "knurled-cylinder"):
+        code, _ = hip.lower(b.Scene(scene))
+        ins = decode(code)
+        f = code.view(np.float32)
+        by_pc = {i[4]: k for k, i in enumerate(ins)}
+        skips = [i for i in ins if i[0] == "D_SKIP"]
+        ids = [int(code[i[4] + 1]) for i in skips]
+        assert sorted(ids) == list(range(len(ids))) and 0 < len(ids) <= 16, (scene, ids)
+        for i in skips:
+            pc = i[4]
+            assert abs(f[pc + 2]) == BIG
+            end = pc + skipw(code, pc + 3)
+            assert end in by_pc, (scene, pc)                      # an instruction boundary
+            assert ins[by_pc[end]][0] in ("D_SAVER", "D_LIP_DOM") or ins[by_pc[end]][0].startswith("D_COMBINE"), (scene, ins[by_pc[end]][0])
+            # a gate right behind a D_SKIP guards the same subtree and carries the same number
+            nxt = ins[by_pc[pc] + 1]
+            if nxt[0].startswith("D_GATE"):
+                n = NPAR[NAMES.index(nxt[0])]
+                w = int(code[nxt[4] + n])
+                assert (w >> 24) - 1 == int(code[pc + 1]) and nxt[4] + (w & 0xffffff) == end
+        # every D_LIP_DOM sits right in front of its combine, on the combine's slot, and names numbers that exist
+        kinds = {"D_COMBINE_MIN": 0, "D_COMBINE_MAX": 1, "D_COMBINE_DIFF": 2, "D_COMBINE_SUNION": 3, "D_COMBINE_SDIFF": 4, "D_COMBINE_SINTER": 5}
+        doms = [i for i in ins if i[0] == "D_LIP_DOM"]
+        assert doms
+        for i in doms:
+            comb = ins[by_pc[i[4]] + 1]
+            assert kinds[comb[0]] == int(code[i[4] + 1]) and comb[3] == i[3] and comb[2] == i[2]      # kind, slot, swap flag
+            for q in (2, 3):
+                v = int(code[i[4] + q])
+                assert v == 0xff or v in ids
+            # substitutes: a union's / smooth union's operands far above (+), an intersection's far below (-), a (smooth)
+            # difference's minuend far below (-) and subtrahend far above (+)
+            k = int(code[i[4] + 1])
+            for role, q in (("a", 2), ("b", 3)):
+                v = int(code[i[4] + q])
+                if v == 0xff:
+                    continue
+                sub = f[[s[4] for s in skips if int(code[s[4] + 1]) == v][0] + 2]
+                want = {0: BIG, 3: BIG, 1: -BIG, 5: -BIG}.get(k, -BIG if role == "a" else BIG)
+                assert sub == want, (scene, k, role, sub)
+    # nothing is numbered inside a position map that jumps: array cells, circular sectors, screw profiles
+    two = lambda: b.Union(b.NewSphere(1), b.Translate(b.NewBox(1, 1, 1, 0), 1.5, 0, 0))
+    for sh in (b.Array(two(), 4, 4, 4, 3, 3, 3), b.CircularArray(b.Translate(two(), 5, 0, 0), 6, 6)):
+        names = [i[0] for i in decode(hip.lower(sh)[0])]
+        assert names.count("D_SKIP") == 0 and names.count("D_LIP_DOM") == 0, names
+    # ... and the frame around such a map is numbered as usual
+    names = [i[0] for i in decode(hip.lower(b.Union(b.Array(two(), 4, 4, 4, 3, 3, 3), b.Translate(b.NewSphere(1), 20, 0, 0)))[0])]
+    assert names.count("D_SKIP") == 2 and names.count("D_LIP_DOM") == 1
+    # more than 16 candidates: the 16 most expensive ones
+    wide = b.Union(*[b.Translate(b.NewSphere(1) if k % 2 else b.NewBox(1, 1, 1, 0.1), 3.0 * k, 0, 0) for k in range(24)])
+    code = hip.lower(wide)[0]
+    ins = decode(code)
+    sk = [i for i in ins if i[0] == "D_SKIP"]
+    assert len(sk) == 16
+    follow = [ins[[j[4] for j in ins].index(i[4]) + 1:][:4] for i in sk]
+    assert sum(any(j[0] == "D_BOX" for j in fl) for fl in follow) == 12   # all twelve boxes (45) before any sphere (25 + translate)

@@ -30,11 +30,17 @@ def test_generated_source_follows_the_program():
     assert words == [int(w) for w in code]
     # one block per instruction, in program order, named after the interpreter's cases; no D_END block, no dispatch loop
     blocks = re.findall(r"\{  // (\d+) (D_[A-Z0-9_]+)", src)
-    assert [n for _, n in blocks] == ["D_LIP_PUSH", "D_SCALE_PRE", "D_CYL0", "D_SAVER", "D_SAVEP3", "D_TRANSLATE", "D_CYLR", "D_SAVER", "D_LOADP3",
-                                      "D_GATE3D", "D_CYL0", "D_SAVER", "D_GATEZC", "D_LIP_PUSH", "D_SCREW_PRE", "D_LIP_WRAP", "D_POLY2D", "D_LIP_POP", "D_MAXR_SLOT",
-                                      "D_COMBINE_DIFF", "D_COMBINE_SUNION", "D_COMBINE_DIFF", "D_MULR", "D_LIP_POP"]
-    # the two gates are structured ifs around their children: `if (gate_far) R = L; else { child }`, closed before the combine
-    assert src.count("if (gate_far<K, 3>(") == 2 and src.count("if (LIP) KLOOP L[kp] = L[kp] - lipR;") == 2 and src.count("}}  // end of gated child") == 2
+    # (brick masks, dev_ops.h: every operand subtree of the four combine frames carries a number -- a D_SKIP in front of it, a
+    # D_LIP_PUSH at the frame's entry and a D_LIP_DOM in front of the combine, both for the interval mode of the centre tests)
+    assert [n for _, n in blocks] == ["D_LIP_PUSH", "D_SCALE_PRE", "D_LIP_PUSH", "D_SKIP", "D_CYL0", "D_SAVER", "D_SKIP", "D_SAVEP3", "D_LIP_PUSH", "D_SKIP",
+                                      "D_TRANSLATE", "D_CYLR", "D_SAVER", "D_LOADP3", "D_SKIP", "D_GATE3D", "D_LIP_PUSH", "D_SKIP", "D_CYL0", "D_SAVER",
+                                      "D_SKIP", "D_GATEZC", "D_LIP_PUSH", "D_SCREW_PRE", "D_LIP_WRAP", "D_POLY2D", "D_LIP_POP", "D_MAXR_SLOT",
+                                      "D_LIP_DOM", "D_COMBINE_DIFF", "D_LIP_DOM", "D_COMBINE_SUNION", "D_LIP_DOM", "D_COMBINE_DIFF", "D_MULR", "D_LIP_POP"]
+    # the two gates are structured ifs around their children: `if (far_) R = L; else { child }`, closed before the combine -- the
+    # interpreter's own test (interp.h: GSDF_GATE_TEST); the six numbered subtrees likewise: `if (mask bit) R = subst; else { subtree }`
+    assert src.count("GSDF_GATE_TEST((region_lb_") == 2 and src.count("if (far_) GSDF_GATE_TAKEN else {") == 2
+    assert src.count("if (!LIP && ((bmask >> (PU(0) & 31u)) & 1u) != 0u) {") == 6 and src.count("}}  // end of gated child") == 8
+    assert src.count("GSDF_LIP_DOM_BODY") == 3
     assert src.index("// end of gated child") < src.index("D_COMBINE_DIFF")
     assert [int(p) for p, _ in blocks] == sorted(int(p) for p, _ in blocks)
     assert "switch (op)" not in src and "readfirstlane" not in src

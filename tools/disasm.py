@@ -31,6 +31,18 @@ def listing(code):
             nb = int(code[pc + 1]); out.append(f"{pc:5d} {name}{fl} slot={slot} boxes={nb}"); pc += 2 + (4 if name == "D_UBOUND2D" else 6) * nb
         elif name == "D_LINES2D":
             ns = int(code[pc + 1]); out.append(f"{pc:5d} {name}{fl} ns={ns}"); pc += 3 + 5 * ns
+        elif name == "D_SKIP":
+            sw = int(code[pc + 3])
+            out.append(f"{pc:5d} {name}{fl} id={int(code[pc+1])} subst={f[pc+2]:.3g} -> {pc + (sw & 0xffffff)}"); pc += 4
+        elif name == "D_LIP_DOM":
+            k, ia, ib, pi = (int(code[pc + 1 + i]) for i in (0, 1, 2, 4))
+            kinds = ["min", "max", "diff", "sunion", "sdiff", "sinter"]
+            out.append(f"{pc:5d} {name}{fl} slot={slot} {kinds[k]} ida={ia if ia != 255 else '-'} idb={ib if ib != 255 else '-'} kk={f[pc+4]:.6g} depth={pi & 0xffff}{' 2d' if pi & 0x10000 else ''}"); pc += 6
+        elif name.startswith("D_GATE"):
+            n = nparams[op]
+            sw = int(code[pc + n])
+            out.append(f"{pc:5d} {name}{fl} slot={slot} " + " ".join(f"{f[pc+1+i]:.6g}" for i in range(n - 1)) + f" -> {pc + (sw & 0xffffff)}" + (f" id={(sw >> 24) - 1}" if sw >> 24 else ""))
+            pc += 1 + n
         else:
             n = nparams[op]
             out.append(f"{pc:5d} {name}{fl} slot={slot} " + " ".join(f"{f[pc+1+i]:.6g}" for i in range(n)))
