@@ -199,8 +199,17 @@ def valu_roofline(kernel_evals_per_s, workload, code=None):
     if not per_eval:
         return None
     ach = per_eval * kernel_evals_per_s
-    return {"lane_instr_per_eval": per_eval, "counters_from": pm.get("source"), "achieved": ach / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-instr/s",
-            "frac": ach / VALU_PEAK_LANE_OPS}
+    out = {"lane_instr_per_eval": per_eval, "counters_from": pm.get("source"), "achieved": ach / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-instr/s",
+           "frac": ach / VALU_PEAK_LANE_OPS}
+    mix = pm.get("valu_mix")
+    if mix and mix.get("cycles_per_instr_by_class"):
+        # what the kernel's own instruction mix allows: classes priced by their measured issue cost in real shader cycles, at the
+        # clock VALU-dense code runs at (tools/ubench/class_rate.hip; the peak assumes 2 cycles for every instruction at 2.4 GHz)
+        roof = 256 * 4 * 64 * mix.get("clock_ghz", 2.4) * 1e9 / mix["cycles_per_instr_by_class"]  # lanes x (clock under load) / (cycles per wave-instruction of the mix)
+        out["mix"] = {k: v for k, v in mix.items() if k not in ("kernel_ms", "frac_of_mix_roof", "roof_ms")}
+        out["mix_roof"] = roof / 1e12
+        out["mix_roof_frac"] = ach / roof
+    return out
 
 
 def eval_mode(args, torch, np, hip, shader, sdf, res, dev):
@@ -591,11 +600,33 @@ def main():
                 m_ms = sum(a.ms_emit for a in alone) / len(alone)
                 m_gbs = e_bytes / (m_ms * 1e-3) / 1e9
                 out["roofline_march"]["alone"] = {"kernel_ms": m_ms, "achieved": m_gbs, "frac": m_gbs / HBM_PEAK_GBS}
-            out["roofline"]["valu_alone"] = valu_roofline((march_evals / max(1, args.steps)) / (a_ms * 1e-3), workload, code)
-            out["roofline"]["alone"] = {"kernel_ms": a_ms, "achieved": a_gbs, "frac": a_gbs / HBM_PEAK_GBS, "ms_per_mesh_device": sum(a.ms_total for a in alone) / len(alone),
-                                        "note": "one blocking mesh at a time (measured after the timed loop): the kernel with the GPU to itself"}
-            out["roofline"]["note"] += ("; the timed loop keeps two meshes in flight on two streams, so kernel_ms / achieved / frac above are the kernel's "
-                                        "duration while it shares the CUs with the other mesh's kernels -- 'alone' is the same kernel by itself")
+            va = valu_roofline((march_evals / max(1, args.steps)) / (a_ms * 1e-3), workload, code)
+            # The line's face: the BINDING roof of the dominant kernel -- VALU issue -- for the kernel ALONE (kernel_ms <= ms_per_step
+            # holds on the face of the line). The HBM figures of SURVEY 8(d) are notional by construction (positions are generated in
+            # registers, distances stay on the CU) and move under `hbm_notional`; the span the kernel takes while it shares the CUs
+            # with the other mesh in flight stays as kernel_span_overlapped_ms.
+            rf = out["roofline"]
+            rf["hbm_notional"] = {"bound": "hbm", "algorithmic_gb_per_launch": rf["algorithmic_gb_per_launch"], "traffic": rf["traffic"], "traffic_unit": rf["traffic_unit"],
+                                  "achieved_alone": a_gbs, "frac_alone": a_gbs / HBM_PEAK_GBS, "achieved_overlapped": rf["achieved"], "frac_overlapped": rf["frac"],
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "note": "16 B per evaluation + 40 B per cut-leaf record, as SURVEY 8(d) counts them: the kernel moves 6 % of that (PMC traffic)"}
+            rf["kernel_span_overlapped_ms"] = rf["kernel_ms"]
+            rf["valu_overlapped"] = rf.pop("valu")
+            rf["kernel_ms"] = a_ms
+            rf["kernel_evals_per_s"] = (march_evals / max(1, args.steps)) / (a_ms * 1e-3)
+            rf["ms_per_mesh_device_alone"] = sum(a.ms_total for a in alone) / len(alone)
+            rf["bound"] = "valu"
+            rf["unit"] = "T lane-instr/s"
+            rf["peak"] = VALU_PEAK_LANE_OPS / 1e12
+            rf["achieved"] = va["achieved"] if va else None
+            rf["frac"] = va["frac"] if va else None
+            rf["valu"] = va
+            rf["note"] = ("bound by VALU issue (SURVEY 8(d)): achieved = SQ_INSTS_VALU x 64 lanes per evaluation (PMC summary under profiles/ whose code key equals the running "
+                          "kernels', else null) x the kernel's evaluations per second with the GPU to itself (blocking meshes after the timed loop); peak = 256 CUs x 4 SIMDs x "
+                          "32 lanes x 2.4 GHz; valu.mix_roof_frac prices the same rate against what the kernel's own instruction mix allows on gfx950 "
+                          "(tools/ubench/class_rate.hip); the timed loop keeps two meshes in flight, kernel_span_overlapped_ms is the kernel's event-to-event span there")
+            for k in ("traffic", "traffic_unit", "algorithmic_gb_per_launch"):
+                rf.pop(k, None)
         if mesh_pipeline and not dc and args.share_corners == 0 and not args.no_distinct_rows:
             # Beside the headline, not in it: the same mesh with the evaluations the reference repeats left out (gsdf_mesh_opts.share_corners;
             # the triangle set is bit-identical, tests/test_gpu_mesh.py) -- time to mesh for a caller who does not need the reference's

@@ -366,6 +366,79 @@ extern "C" int gsdf_hip_program_specialize(gsdf_program* p) {
   }
   return GSDF_OK;
 }
+// ---- specialisation in the background -----------------------------------------------------------------------------------------
+// Every example of the reference is one tree -> one mesh -> one file (examples/npt-flange/flange.go:61-98): a caller that waits for
+// a compiler before its only mesh has gained nothing. _async starts the build (and the module load) on a thread of its own and
+// returns; the handle keeps meshing and evaluating through the interpreter kernels and switches to the specialised ones at the
+// first entry-point call after they are ready -- same bits either way (same statements, same flags), so a mesh may even change
+// kernels between its attempts. With GSDF_HIP_CACHE_DIR set and the tree seen before, "ready" is a file read away.
+void spec_adopt_slow(gsdf_program* p) {
+  std::lock_guard<std::mutex> lk(p->spec_async_mu);
+  if (p->spec_async.load(std::memory_order_acquire) != 2) return;  // another thread of the caller was faster
+  if (p->spec_thread.joinable()) p->spec_thread.join();
+  gsdf_program* q = p->spec_shadow;
+  p->spec_shadow = nullptr;
+  if (q && !p->spec_mod) {
+    p->spec_compile_s += q->spec_compile_s; p->spec_compiler = q->spec_compiler; p->spec_key = q->spec_key;
+    p->spec_eval_k = q->spec_eval_k; p->spec_eval_w = q->spec_eval_w; p->spec_leaf_k = q->spec_leaf_k; p->spec_leaf_w = q->spec_leaf_w;
+    p->spec_leaf_both = q->spec_leaf_both;
+    p->spec_mod3 = q->spec_mod3; p->spec_mod4 = q->spec_mod4;
+    std::atomic_thread_fence(std::memory_order_release);  // (the configuration before the functions: a reader that sees a function sees what it was built for)
+    p->f_prune = q->f_prune; p->f_prune_spec = q->f_prune_spec; p->f_leaf = q->f_leaf; p->f_eval = q->f_eval;
+    p->spec_mod = q->spec_mod;
+    q->spec_mod = q->spec_mod3 = q->spec_mod4 = nullptr;
+  }
+  if (q) gsdf_hip_program_destroy(q);
+  p->spec_async.store(0, std::memory_order_release);
+}
+
+extern "C" int gsdf_hip_program_specialize_async(gsdf_program* p) {
+  if (!p) return fail(GSDF_ERR_BAD_ARGUMENT, "null program");
+  std::lock_guard<std::mutex> lk(p->spec_async_mu);
+  if (p->spec_mod || p->spec_async.load() != 0) return GSDF_OK;  // specialised already, or a build is under way / waiting to be adopted
+  if (gsdf_dev::spec_instruction_count(p->prog) > 4000)
+    return fail(GSDF_ERR_BAD_TREE, "program too large to specialise (more than 4000 instructions): the interpreter kernels stay in use");
+  gsdf_program* q = new (std::nothrow) gsdf_program;
+  if (!q) return fail(GSDF_ERR_CAPACITY, "out of memory");
+  q->prog = p->prog; q->device = p->device; q->num_cu = p->num_cu;  // all a build reads (no streams, no device memory)
+  p->spec_shadow = q;
+  p->spec_async_err.clear();
+  p->spec_async.store(1, std::memory_order_release);
+  try {
+    p->spec_thread = std::thread([p, q] {
+      const int rc = gsdf_hip_program_specialize(q);
+      if (rc != GSDF_OK) p->spec_async_err = gsdf_hip_last_error();  // (the error text is the building thread's)
+      p->spec_async.store(rc == GSDF_OK ? 2 : 3, std::memory_order_release);
+    });
+  } catch (...) {
+    p->spec_shadow = nullptr;
+    gsdf_hip_program_destroy(q);
+    p->spec_async.store(0);
+    return fail(GSDF_ERR_CAPACITY, "cannot start the build thread");
+  }
+  return GSDF_OK;
+}
+
+/* 1: the handle runs specialised kernels now; 0: the build is still under way (wait = 0) or none was started; a negative status if
+ * the build failed (the interpreter kernels stay in use; gsdf_hip_last_error has the compiler's words). wait != 0 blocks until the
+ * build has finished. */
+extern "C" int gsdf_hip_program_specialize_poll(gsdf_program* p, int wait) {
+  if (!p) return fail(GSDF_ERR_BAD_ARGUMENT, "null program");
+  if (wait) {
+    std::unique_lock<std::mutex> lk(p->spec_async_mu);
+    if (p->spec_async.load() == 1 && p->spec_thread.joinable()) p->spec_thread.join();
+  }
+  spec_adopt(p);
+  if (p->spec_async.load(std::memory_order_acquire) == 3) {
+    std::lock_guard<std::mutex> lk(p->spec_async_mu);
+    if (p->spec_thread.joinable()) p->spec_thread.join();
+    if (p->spec_shadow) { gsdf_hip_program_destroy(p->spec_shadow); p->spec_shadow = nullptr; }
+    p->spec_async.store(0);
+    return fail(GSDF_ERR_HIP, "background specialisation failed: " + p->spec_async_err);
+  }
+  return p->spec_mod ? 1 : 0;
+}
+
 /* 1 if the handle runs specialised kernels; compile_seconds (optional) = what the build took */
 extern "C" int gsdf_hip_program_is_specialized(const gsdf_program* p, double* compile_seconds) {
   if (compile_seconds) *compile_seconds = p ? p->spec_compile_s : 0.0;
@@ -468,6 +541,8 @@ extern "C" int gsdf_hip_lower_region(const gsdf_tree* tree, uint32_t node, int* 
 
 extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   if (!p) return;
+  if (p->spec_thread.joinable()) p->spec_thread.join();  // a build under way finishes first (its thread writes into this handle)
+  if (p->spec_shadow) { gsdf_hip_program_destroy(p->spec_shadow); p->spec_shadow = nullptr; }
   if (p->d_code) (void)hipFree(p->d_code);
   if (p->d_pos) (void)hipFree(p->d_pos);
   if (p->d_dist) (void)hipFree(p->d_dist);
@@ -518,6 +593,7 @@ extern "C" uint64_t gsdf_hip_evaluations(const gsdf_program* p) { return p ? p->
 // buffers, 31.4 -> 26.1 us from pageable ones (tools/gpu_dropin_k.sh).
 static int eval_dev(gsdf_program* p, int dim, const void* d_pos, size_t stride_bytes, float* d_dist, size_t n, hipStream_t s, bool count = true, bool host_mapped = false) {
   if (stride_bytes % 4 != 0 || stride_bytes < (size_t)dim * 4) return fail(GSDF_ERR_BAD_ARGUMENT, "bad position stride");
+  spec_adopt(p);  // (a background build that has finished: its kernels from here on)
   static const bool k1_off = [] { const char* e = getenv("GSDF_HIP_NO_EVAL_K1"); return e && atoi(e) != 0; }();  // developer knob (A/B timing)
   const bool latency = host_mapped && !k1_off && (p->f_eval_k1 != nullptr || p->f_eval == nullptr);  // (a specialised handle without a K = 1 build keeps its specialised kernel)
   const int k = latency ? 1 : p->batch_k();

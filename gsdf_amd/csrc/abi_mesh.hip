@@ -303,7 +303,7 @@ int gsdf_mesh_job::enqueue() {
         } else {
         // one wave of workgroups: each takes an equal share of the records (computed on device from the group sums)
         static const int march_bpc = [] { const char* e = getenv("GSDF_HIP_MARCH_BPC"); return e ? atoi(e) : 4; }();  // tuning knob (7 fit a CU; 4 leave LDS and wave slots to the other mesh in flight: 0.503 -> 0.495 ms per mesh, and a blocking mesh loses nothing)
-        const size_t lds_march = (size_t)11 * BLOCK * 4 + 5 * BLOCK * 4 + 256 * 16 + (BLOCK + 1) * 4 + 8 * 4 + 8 + 14 * 8;
+        const size_t lds_march = MARCH_LDS_BYTES;
         hipLaunchKernelGGL(march_records_kernel, dim3(grid_for(nblk_q, p->num_cu, march_bpc)), dim3(BLOCK), lds_march, s, d_hdr, d_rec,
                            d_psum, (unsigned long long)nblk, lq, ox, oy, oz, res, m->d_tris, (uint64_t)tcap, d_ctr,
                            ctr_from_kernel ? hcp : (MeshCounters*)nullptr);
@@ -427,6 +427,7 @@ static void job_release(gsdf_mesh_job* j) {
 extern "C" int gsdf_hip_mesh_octree_start(gsdf_program* p, float res, const gsdf_mesh_opts* opts_in, gsdf_mesh_job** out) {
   if (!p || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
   *out = nullptr;
+  spec_adopt(p);  // (a background build that has finished: its kernels from here on)
   if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
   if (!(res > 0) || std::isnan(res) || std::isinf(res)) return fail(GSDF_ERR_RESOLUTION, "invalid renderer cube resolution");
   gsdf_mesh_opts opts{};
@@ -565,7 +566,7 @@ int mesh_march_dense(const uint8_t* d_buf, const gsdf_dense_part* parts, int npa
   HIP_TRY(hipMemcpyAsync(d_parts, &h, sizeof h, hipMemcpyHostToDevice, s));
   static const int march_bpc = [] { const char* e = getenv("GSDF_HIP_MARCH_BPC"); return e ? atoi(e) : 4; }();  // tuning knob (7 fit a CU; 4 leave LDS and wave slots to the other mesh in flight: 0.503 -> 0.495 ms per mesh, and a blocking mesh loses nothing)
   const uint64_t gmax = (uint64_t)num_cu * (uint64_t)(march_bpc > 0 ? march_bpc : 4);
-  const size_t lds = (size_t)11 * BLOCK * 4 + 5 * BLOCK * 4 + 256 * 16 + 8 * 4 + 8 + 4 * 8;
+  const size_t lds = MARCH_DENSE_LDS_BYTES;
   hipLaunchKernelGGL(march_dense_kernel, dim3((unsigned)(chunks < gmax ? chunks : gmax)), dim3(BLOCK), lds, s, d_buf, (const DenseParts*)d_parts, ox, oy, oz, res, d_tris);
   HIP_TRY(hipGetLastError());
   return GSDF_OK;
@@ -621,6 +622,7 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
                                          gsdf_mesh** out) {
   if (!p || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
   *out = nullptr;
+  spec_adopt(p);  // (a background build that has finished: its kernels from here on)
   if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
   if (!(res > 0) || std::isnan(res) || std::isinf(res)) return fail(GSDF_ERR_RESOLUTION, "invalid renderer cube resolution");
   if (shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return fail(GSDF_ERR_BAD_ARGUMENT, "bad shard rank/count");
@@ -792,6 +794,7 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
 extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, int shard_count, void* stream, gsdf_mesh** out) {
   if (!p || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
   *out = nullptr;
+  spec_adopt(p);  // (a background build that has finished: its kernels from here on)
   if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
   if (!(res > 0) || std::isnan(res) || std::isinf(res)) return fail(GSDF_ERR_RESOLUTION, "invalid renderer cube resolution");
   if (shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return fail(GSDF_ERR_BAD_ARGUMENT, "bad shard rank/count");

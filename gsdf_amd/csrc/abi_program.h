@@ -3,6 +3,7 @@
 #pragma once
 #include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "abi_host.h"
@@ -83,6 +84,14 @@ struct gsdf_program {
   int spec_leaf_dense_w = 0;
   size_t lds_dense() const { return (size_t)(prog.nslots * 4 > 8 ? prog.nslots * 4 : 8) * BLOCK * sizeof(float) + 256 + 4 * 512 * sizeof(float) + 4 * 24 * sizeof(float) + 16; }
   double spec_compile_s = 0;
+  // Specialisation in the background (gsdf_hip_program_specialize_async): a thread builds and loads the kernels on a shadow handle
+  // (this program, this device, nothing else) while the interpreter kernels serve; the entry points adopt the result at their
+  // next call (abi_eval.hip: spec_adopt). 0 idle | 1 building | 2 built, to be adopted | 3 failed (spec_async_err)
+  std::atomic<int> spec_async{0};
+  std::thread spec_thread;
+  gsdf_program* spec_shadow = nullptr;
+  std::mutex spec_async_mu;
+  std::string spec_async_err;
   std::string spec_compiler;  // hipcc | hiprtc | cache: what built the specialised kernels
   std::string spec_key;       // key of that build (specialize.cpp: build_key)
   // leaf kernel batching: K = 4 while 3 workgroups still fit the CU's LDS (<= 11 slots); 12..15 slots run K = 2 at 4
@@ -162,6 +171,10 @@ inline unsigned grid_for(uint64_t n, int num_cu, int blocks_per_cu) {
 // Second group of a specialised handle (dual contouring, normals, flat lattice pass, image renderer), built on first use:
 // abi_eval.hip.
 void spec_aux(gsdf_program* p);
+// A background build (gsdf_hip_program_specialize_async) that has finished is taken over here: called at the top of the entry
+// points that launch evaluating kernels. One relaxed load when there is nothing to adopt.
+void spec_adopt_slow(gsdf_program* p);
+inline void spec_adopt(gsdf_program* p) { if (p->spec_async.load(std::memory_order_acquire) == 2) spec_adopt_slow(p); }
 // The evaluating kernel with distinct z rows for a specialised handle, built on first use: abi_eval.hip.
 void spec_leaf_dz(gsdf_program* p);
 void spec_leaf_dense(gsdf_program* p);

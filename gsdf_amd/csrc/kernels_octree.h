@@ -1111,6 +1111,18 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_dense_kernel(const uint32_t
   }
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave by DPP row shifts and row broadcasts: six v_add_u32 with a DPP operand (the
+// compiler folds the move into the integer add) -- __shfl_up goes through ds_bpermute, an LDS round trip per step.
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // Inclusive prefix sum over the workgroup (thread order) of a 64-bit value; *total = the workgroup's sum. s_w: 4 words of LDS.
 __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long v, unsigned long long* s_w, unsigned long long* total) {
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1128,17 +1140,73 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
   return incl + (wave > 0 ? a : 0ull) + (wave > 1 ? b : 0ull) + (wave > 2 ? c : 0ull);
 }
 
+// ---- the marching kernels' vertex -----------------------------------------------------------------------------------------
+// The two corners of a marching-cubes edge differ in ONE coordinate. mcInterpolate (marchcubes.go:76-98) forms every coordinate
+// as a + t (b - a); on the two axes where a = b that is a + t * (+0) = a + (t * 0), and only the third needs the subtraction,
+// the product and the choice between the snapped endpoints. Same float operations on the same values as mc_interp above --
+// also for a NaN or infinite t, which reaches the unchanged coordinates through t * 0 -- at a third of the arithmetic.
+// Edge word (the kernels' LDS table: one 16-bit entry per triangle corner): ca | cb << 3 | axis << 6 | pa << 8, pa bit 0 / 1 / 2 =
+// corner a sits at the max of the leaf's box in x / y / z (Box{origin, origin + size}: max = min + res).
+constexpr __host__ __device__ __forceinline__ uint32_t march_edge_word(unsigned e) {
+  const unsigned ca = GSDF_MC_PAIR_A(e), cb = GSDF_MC_PAIR_B(e);
+  const unsigned pa = ((ca ^ (ca >> 1)) & 1u) | (((ca >> 1) & 1u) << 1) | (((ca >> 2) & 1u) << 2);
+  const unsigned pb = ((cb ^ (cb >> 1)) & 1u) | (((cb >> 1) & 1u) << 1) | (((cb >> 2) & 1u) << 2);
+  const unsigned d = pa ^ pb;  // exactly one bit
+  const unsigned axis = d == 1u ? 0u : (d == 2u ? 1u : 2u);
+  return ca | (cb << 3) | (axis << 6) | (pa << 8);
+}
+// col: the record's 8 corner distances + leaf origin (11 floats)
+__device__ __forceinline__ void march_vertex(uint32_t ed, const float* col, float res, float& rx, float& ry, float& rz) {
+  const float x0 = col[8], y0 = col[9], z0 = col[10];
+  const float v1 = col[ed & 7u], v2 = col[(ed >> 3) & 7u];
+  const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;  // Box max = origin + size
+  const float px = (ed & 0x100u) ? x1 : x0, py = (ed & 0x200u) ? y1 : y0, pz = (ed & 0x400u) ? z1 : z0;  // corner a
+  const unsigned axis = (ed >> 6) & 3u;
+  const bool on_x = axis == 0u, on_y = axis == 1u;
+  const float c0 = on_x ? x0 : (on_y ? y0 : z0), c1 = on_x ? x1 : (on_y ? y1 : z1);
+  const bool a_max = ((ed >> (8u + axis)) & 1u) != 0u;
+  const float ac = a_max ? c1 : c0, bc = a_max ? c0 : c1;
+  const float eps = 1e-12f;
+  const bool k1 = dm::absf(0.f - v1) < eps, k2 = dm::absf(0.f - v2) < eps;
+  float t = 0.5f;
+  if (!k1 || !k2) t = (0.f - v1) / (v2 - v1);
+  float rv = ac + t * (bc - ac);
+  if (k1 && !k2) rv = ac;
+  if (k2 && !k1) rv = bc;
+  const float z = (k1 != k2) ? 0.0f : t * 0.0f;  // a snapped endpoint's coordinates are the corner's own; else a + t * (a - a)
+  const float fx = px + z, fy = py + z, fz = pz + z;
+  rx = on_x ? rv : fx;
+  ry = on_y ? rv : fy;
+  rz = (axis == 2u) ? rv : fz;
+}
+
+// The triangle table as the marching kernels keep it in LDS: [256][16] 16-bit entries -- entries 0..14 the EDGE WORDS of the
+// row's triangle corners (march_edge_word: what a vertex needs of its edge, without a second lookup), entry 15 the row's
+// triangle count.
+static __device__ __constant__ const uint16_t GSDF_MARCH_EDGE_WORD[16] = {
+    (uint16_t)march_edge_word(0), (uint16_t)march_edge_word(1), (uint16_t)march_edge_word(2),  (uint16_t)march_edge_word(3),
+    (uint16_t)march_edge_word(4), (uint16_t)march_edge_word(5), (uint16_t)march_edge_word(6),  (uint16_t)march_edge_word(7),
+    (uint16_t)march_edge_word(8), (uint16_t)march_edge_word(9), (uint16_t)march_edge_word(10), (uint16_t)march_edge_word(11), 0, 0, 0, 0};
+__device__ __forceinline__ void march_load_table(uint16_t* s_tri) {
+  for (int k = threadIdx.x; k < 256 * 16; k += BLOCK) {
+    const int e = GSDF_MC_TRI[k >> 4][k & 15];
+    s_tri[k] = (k & 15) == 15 ? (uint16_t)GSDF_MC_NTRI[k >> 4] : (e >= 0 ? GSDF_MARCH_EDGE_WORD[e & 15] : (uint16_t)0);
+  }
+}
+
+struct __attribute__((packed, aligned(4))) MarchV3 { float x, y, z; };
+
 // One chunk of at most BLOCK cut-leaf records, one per lane (rw: the lane's record, `has`: it has one), marched into triangles
-// number out, out + 1, ...: returns the chunk's triangle count (block-uniform). Shared by march_records_kernel (records where
-// leaf_eval_kernel left them) and march_dense_kernel (packed records, after a gather). `prefetch` runs once the lane's record is
-// in LDS -- the caller's load of its NEXT record, in flight while this chunk is marched (a dependent global load is ~2 us).
+// number out, out + 1, ...: returns the chunk's triangle count (block-uniform). march_dense_kernel's chunk body (packed records,
+// after a gather). `prefetch` runs once the lane's record is in LDS -- the caller's load of its NEXT record, in flight while this
+// chunk is marched (a dependent global load is ~2 us).
 // Ends with a barrier: the caller may rewrite the columns, the owner list and s_misc.
 //   s_col [BLOCK][11]: 8 distances + origin (odd stride: one record's values, read together by neighbouring lanes, sit in 11 banks)
 //   s_own [5 * BLOCK]: triangle -> table offset (index*16 + 3*number) | record << 12
-//   s_tri: the triangle table, a row's spare byte 15 = its triangle count;  s_misc[0..3]: wave sums
+//   s_tri: the table of edge words (march_load_table);  s_misc[0..3]: wave sums
 template <typename Prefetch>
 __device__ __forceinline__ unsigned march_chunk_emit(const uint32_t (&rw)[10], bool has, Prefetch prefetch, float ox, float oy, float oz,
-                                                     float res, float* s_col, uint32_t* s_own, const int8_t* s_tri, unsigned* s_misc,
+                                                     float res, float* s_col, uint32_t* s_own, const uint16_t* s_tri, unsigned* s_misc,
                                                      float* __restrict__ tris, unsigned long long out) {
   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   unsigned index = 0;
@@ -1153,7 +1221,7 @@ __device__ __forceinline__ unsigned march_chunk_emit(const uint32_t (&rw)[10], b
     s_col[threadIdx.x * 11u + 10u] = oz + res * (float)(zi & 0xffffu);
   }
   prefetch();
-  // owner list: prefix sum of the records' triangle counts (the table's spare byte holds the row's count)
+  // owner list: prefix sum of the records' triangle counts
   const unsigned nt = index ? (unsigned)s_tri[index * 16 + 15] : 0u;
   unsigned ti = nt;
 #pragma unroll
@@ -1171,76 +1239,120 @@ __device__ __forceinline__ unsigned march_chunk_emit(const uint32_t (&rw)[10], b
   for (unsigned k = 0; k < nt; k++) s_own[first + k] = (index * 16u + 3u * k) | (threadIdx.x << 12);
   __syncthreads();
   // one output VERTEX per lane: a wave's store is 768 contiguous bytes
-  struct __attribute__((packed, aligned(4))) V3 { float x, y, z; };
-  V3* dst = (V3*)(tris + out * 9);
+  MarchV3* dst = (MarchV3*)(tris + out * 9);
   const unsigned n3 = total * 3u;
 #pragma unroll 2
   for (unsigned k = threadIdx.x; k < n3; k += BLOCK) {
     const unsigned t = k / 3u, j = k - 3u * t;
     const uint32_t o = s_own[t];
-    const float* col = s_col + (o >> 12) * 11u;
-    const int e = s_tri[(o & 4095u) + (2u - j)];  // reversed winding (marchcubes.go:64-68)
-    const unsigned ca = GSDF_MC_PAIR_A(e), cb = GSDF_MC_PAIR_B(e);
-    const float x0 = col[8], y0 = col[9], z0 = col[10];
-    const float x1 = x0 + res, y1 = y0 + res, z1 = z0 + res;  // Box max = origin + size
-    const bool ax = ((ca ^ (ca >> 1)) & 1u) != 0u, ay = ((ca >> 1) & 1u) != 0u, az = ((ca >> 2) & 1u) != 0u;
-    const bool bx = ((cb ^ (cb >> 1)) & 1u) != 0u, by = ((cb >> 1) & 1u) != 0u, bz = ((cb >> 2) & 1u) != 0u;
-    V3 r;
-    mc_interp(ax ? x1 : x0, ay ? y1 : y0, az ? z1 : z0, bx ? x1 : x0, by ? y1 : y0, bz ? z1 : z0, col[ca], col[cb], r.x, r.y, r.z);
+    MarchV3 r;
+    march_vertex(s_tri[(o & 4095u) + (2u - j)], s_col + (o >> 12) * 11u, res, r.x, r.y, r.z);  // reversed winding (marchcubes.go:64-68)
+    dst[k] = r;
+  }
+  __syncthreads();  // the next chunk rewrites the columns, the owner list and s_misc
+  return total;
+}
+
+// The same for ONE WAVE and at most 64 records, with no workgroup barrier: the wave's own columns, owner list and output range
+// (march_records_kernel: the four waves of a workgroup work through their own shares at their own pace -- the barriers of the
+// workgroup-wide form made every chunk wait for its slowest wave: half of the kernel's wave cycles were waits, round 4's PMC).
+// A wave's LDS operations execute in order: a wave_barrier only pins the compiler's schedule.
+//   wcol [64][11], wown [5 * 64]: as above, for the wave's records; owner entries carry the lane (record) << 12
+template <typename Prefetch>
+__device__ __forceinline__ unsigned march_chunk_emit_wave(const uint32_t (&rw)[10], bool has, Prefetch prefetch, float ox, float oy, float oz,
+                                                          float res, float* wcol, uint32_t* wown, const uint16_t* s_tri,
+                                                          float* __restrict__ tris, unsigned long long out) {
+  const unsigned lane = threadIdx.x & 63u;
+  unsigned index = 0;
+  if (has) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) wcol[lane * 11u + c] = __uint_as_float(rw[c]);
+    const uint32_t xy = rw[8], zi = rw[9];
+    index = zi >> 16;
+    wcol[lane * 11u + 8u] = ox + res * (float)(xy & 0xffffu);  // the leaf origin exactly as the evaluating kernel formed it
+    wcol[lane * 11u + 9u] = oy + res * (float)(xy >> 16);
+    wcol[lane * 11u + 10u] = oz + res * (float)(zi & 0xffffu);
+  }
+  prefetch();
+  const unsigned nt = index ? (unsigned)s_tri[index * 16 + 15] : 0u;
+  const unsigned ti = wave_incl_scan_u32(nt);
+  const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)ti, 63);
+  const unsigned first = ti - nt;
+  for (unsigned k = 0; k < nt; k++) wown[first + k] = (index * 16u + 3u * k) | (lane << 12);
+  __builtin_amdgcn_wave_barrier();
+#ifdef GSDF_EXP_MARCH_TRIANGLE_PER_LANE
+  // (developer experiment, measured and not kept: ONE TRIANGLE PER LANE -- the record's origin and the table row fetched once
+  // for the three vertices, half the instructions per vertex, but the 36 bytes of a triangle leave as three 12-byte stores at a
+  // 36-byte stride: 0.141 ms against 0.120 for one vertex per lane, whose store instructions are 768 contiguous bytes each. The
+  // kernel pays for its output stream, not for its arithmetic.)
+  MarchV3* dst = (MarchV3*)(tris + out * 9);
+  for (unsigned t = lane; t < total; t += 64u) {
+    const uint32_t o = wown[t];
+    const float* col = wcol + (o >> 12) * 11u;
+    const uint16_t* row = s_tri + (o & 4095u);
+    MarchV3 r0, r1, r2;
+    march_vertex(row[2], col, res, r0.x, r0.y, r0.z);  // reversed winding (marchcubes.go:64-68)
+    march_vertex(row[1], col, res, r1.x, r1.y, r1.z);
+    march_vertex(row[0], col, res, r2.x, r2.y, r2.z);
+    dst[3u * t] = r0;
+    dst[3u * t + 1u] = r1;
+    dst[3u * t + 2u] = r2;
+  }
+#else
+  MarchV3* dst = (MarchV3*)(tris + out * 9);
+  const unsigned n3 = total * 3u;
+  // (not unrolled: two vertices side by side make the compiler pack their f32 operations into v_pk_* -- no faster on gfx950 than
+  // the scalar pairs, plus the moves that form the register pairs; the other waves of the SIMD fill the latencies)
+#pragma unroll 1
+  for (unsigned k = lane; k < n3; k += 64u) {  // one output vertex per lane: a store is 768 contiguous bytes
+    const unsigned t = k / 3u, j = k - 3u * t;
+    const uint32_t o = wown[t];
+    MarchV3 r;
+    march_vertex(s_tri[(o & 4095u) + (2u - j)], wcol + (o >> 12) * 11u, res, r.x, r.y, r.z);  // reversed winding (marchcubes.go:64-68)
 #ifdef GSDF_EXP_MARCH_NO_STORE  // developer experiment (library built with -D...): the kernel without its output stream (timing only)
     if (r.x == 1.2345678e-30f) dst[k] = r;
 #else
     dst[k] = r;
 #endif
   }
-  __syncthreads();  // the next chunk rewrites the columns, the owner list and s_misc
+#endif
+  __builtin_amdgcn_wave_barrier();  // (the next chunk rewrites the columns and the owner list)
   return total;
 }
 
-// The triangle table as the marching kernels keep it in LDS: by dwords, a row's spare byte 15 takes its triangle count.
-__device__ __forceinline__ void march_load_table(int8_t* s_tri) {
-  for (int k = threadIdx.x; k < 256 * 4; k += BLOCK) {
-    uint32_t w = ((const uint32_t*)&GSDF_MC_TRI[0][0])[k];
-    if ((k & 3) == 3) w = (w & 0x00ffffffu) | ((uint32_t)GSDF_MC_NTRI[k >> 2] << 24);
-    ((uint32_t*)s_tri)[k] = w;
-  }
-}
-
-// Marching cubes over the cut-leaf records. NO atomic, NO staging.
+// Marching cubes over the cut-leaf records. NO atomic, NO staging, NO workgroup barrier in the loop.
 //  * Where things go: the evaluating kernel left, per group of MARCH_GROUP blocks, the number of records and of triangles
 //    (psum); every workgroup sums those (a few KB from L2), takes an equal share of the RECORDS -- a contiguous range of
-//    blocks, cut at block granularity -- and knows from the same sums where its first triangle goes. Triangles appear in
-//    block order, record order, table order (a pure function of the survivor queue's order).
-//  * Who computes what: records are taken 256 at a time (one per lane, 8 distances + origin into LDS columns); a prefix sum of
-//    their triangle counts gives an owner list (triangle -> record, table row); then ONE OUTPUT VERTEX PER LANE: lane k of a
-//    round computes vertex k % 3 of triangle k / 3 and stores its 12 bytes at out*36 + 12 k -- one store instruction of a wave
-//    is 768 contiguous bytes, nothing is staged, and the rounds of a chunk are independent of each other (no barrier between
-//    them). (One output FLOAT per lane -- 256-byte stores, the edge parameter computed three times -- was slower: 0.127 ms.)
-//  (History: the first version appended LDS stages of 896 triangles through the one counter word, ~88 appends/us: three
-//  workgroups per CU, and a static deal of 256-block passes of which a workgroup got one or two -- it ran for two pass times
-//  with half its slots idle in the second: 0.158 ms. Known offsets + equal shares + a 512-triangle stage: 0.115 ms.)
-// LDS: [11 record columns of BLOCK floats | owner list 5*BLOCK u32 | tri table | prefix BLOCK+1 | misc] = 21.7 KB: 7 workgroups per CU
-__global__ void __launch_bounds__(BLOCK, 7) march_records_kernel(const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ rec,
+//    blocks, cut at block granularity -- splits it into four equal parts, one per WAVE, and knows from the same sums where
+//    every part's first triangle goes. Triangles appear in block order, record order, table order (a pure function of the
+//    survivor queue's order).
+//  * Who computes what: a wave takes its blocks 64 at a time (a wave-level prefix of their record counts), their records 64 at a
+//    time (one per lane, 8 distances + origin into the wave's LDS columns); a prefix sum of the records' triangle counts gives an
+//    owner list (triangle -> record, table row); then ONE OUTPUT VERTEX PER LANE: lane k of a round computes vertex k % 3 of
+//    triangle k / 3 -- one interpolation, on the axis its edge runs along (march_vertex) -- and stores its 12 bytes at
+//    out*36 + 12 k: one store instruction of a wave is 768 contiguous bytes. The next chunk's record and the next pass's block
+//    counts are in flight while a chunk is marched.
+//  (History: round 1 appended LDS stages of 896 triangles through one counter word: 0.158 ms. Known offsets + equal shares,
+//  workgroup-wide chunks of 256 records between barriers, three interpolations and two 64-bit shifts per vertex: 0.100-0.115 ms,
+//  33.5 M wave-instructions and half of the wave cycles waiting -- rounds 2-4. This form: round 5.)
+// LDS: [table 256 x 16 u16 | per wave: 11 record columns of 64 floats, owner list 5 x 64, block prefix 66 | scratch] = 25.9 KB: 6 workgroups per CU
+#define MARCH_WAVE_WORDS (64 * 11 + 5 * 64 + 66)
+#define MARCH_LDS_BYTES (256 * 16 * 2 + 4 * MARCH_WAVE_WORDS * 4 + 8 + 24 * 8)
+__global__ void __launch_bounds__(BLOCK, 6) march_records_kernel(const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ rec,
                                                               const unsigned long long* __restrict__ psum,
                                                               unsigned long long n_blocks_cap, int lq, float ox, float oy, float oz,
                                                               float res, float* __restrict__ tris, uint64_t tri_cap,
                                                               MeshCounters* __restrict__ ctr, MeshCounters* __restrict__ host_ctr) {
-  float* s_col = g_smem;                                       // [BLOCK][11]: 8 distances + origin of the chunk's records (odd stride:
-                                                               // the values of one record, read together by neighbouring lanes, sit in 11 banks)
-  uint32_t* s_own = (uint32_t*)(s_col + 11 * BLOCK);           // [5 * BLOCK] triangle -> table offset (index*16 + 3*number) | record << 12
-  int8_t* s_tri = (int8_t*)(s_own + 5 * BLOCK);
-  unsigned* s_pre = (unsigned*)(s_tri + 256 * 16);             // [BLOCK + 1] exclusive prefix of the pass's record counts
-  unsigned* s_misc = s_pre + BLOCK + 1;                        // [0..3] wave sums of the triangle counts, [4..7] of the record counts
-  unsigned long long* s_u64 = (unsigned long long*)(((uintptr_t)(s_misc + 8) + 7) & ~(uintptr_t)7);  // [0..3] scan, [4..9] found, [10..13] result
+  uint16_t* s_tri = (uint16_t*)g_smem;
+  float* s_wave = (float*)(s_tri + 256 * 16);
+  unsigned long long* s_u64 = (unsigned long long*)(((uintptr_t)(s_wave + 4 * MARCH_WAVE_WORDS) + 7) & ~(uintptr_t)7);  // [0..3] scan, [4..18] found (five cut points x 3)
+  const unsigned long long n_cubes_l = ctr->n_level[lq];  // (needed only once the group sums are in: the two trips to memory overlap)
   march_load_table(s_tri);
-  unsigned long long n_cubes = uniform_u64(ctr->n_level[lq]);
-  const uint64_t n_leaves = n_cubes << (3 * (lq - 1));
-  uint64_t n_blocks = (n_leaves + 63) >> 6;
-  if (n_blocks > n_blocks_cap) n_blocks = n_blocks_cap;  // (the cube queue overflowed: the host reruns)
   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 
-  // ---- this workgroup's share of the records, and where its triangles go
-  const uint64_t n_grp = (n_blocks + MARCH_GROUP - 1) / MARCH_GROUP;
+  // ---- this workgroup's share of the records, and where its triangles go. The sums run over the groups of the arena's CAPACITY:
+  // the words behind the live blocks' groups were cleared with the counters and add nothing.
+  const uint64_t n_grp = (n_blocks_cap + MARCH_GROUP - 1) / MARCH_GROUP;
   const uint64_t per = (n_grp + BLOCK - 1) / BLOCK;  // groups per thread (contiguous)
   uint64_t e0 = (uint64_t)threadIdx.x * per, e1 = e0 + per;
   if (e0 > n_grp) e0 = n_grp;
@@ -1255,6 +1367,10 @@ __global__ void __launch_bounds__(BLOCK, 7) march_records_kernel(const uint32_t*
   }
   unsigned long long R, T, A = 0, Z = 0;
   const unsigned long long br = block_scan_u64(lr, s_u64, &R) - lr, bt = block_scan_u64(lt, s_u64, &T) - lt;
+  const unsigned long long n_cubes = uniform_u64(n_cubes_l);
+  const uint64_t n_leaves = n_cubes << (3 * (lq - 1));
+  uint64_t n_blocks = (n_leaves + 63) >> 6;
+  if (n_blocks > n_blocks_cap) n_blocks = n_blocks_cap;  // (the cube queue overflowed: the host reruns)
   if (blockIdx.x == 0) {  // the statistics the evaluating kernel sent along: cut leaves = records, active leaves, z rows evaluated (DZ)
     (void)block_scan_u64(la, s_u64, &A);
     Z = A >> 32;
@@ -1284,10 +1400,13 @@ __global__ void __launch_bounds__(BLOCK, 7) march_records_kernel(const uint32_t*
   if (T > tri_cap) return;
   const unsigned long long X0 = R * blockIdx.x / gridDim.x, X1 = R * (blockIdx.x + 1ull) / gridDim.x;  // records [X0, X1)
   if (X0 == X1) return;
+  // five cut points: the workgroup's share in four parts, wave w takes records [Xc(w), Xc(w + 1)) -- like the shares themselves,
+  // cut at block granularity by the same rule, so the parts tile the share and the shares tile the mesh
+  auto cut = [&](unsigned w) -> unsigned long long { return X0 + (X1 - X0) * w / 4ull; };
   // the group in which the running record count reaches X (X > 0): found by the one thread whose groups straddle it
-#pragma unroll
-  for (int w = 0; w < 2; w++) {
-    const unsigned long long X = w ? X1 : X0;
+#pragma unroll 1
+  for (unsigned w = 0; w < 5u; w++) {
+    const unsigned long long X = cut(w);
     if (br < X && X <= br + lr) {
       unsigned long long acc = br, tacc = bt;
       for (uint64_t e = e0; e < e1; e++) {
@@ -1301,87 +1420,85 @@ __global__ void __launch_bounds__(BLOCK, 7) march_records_kernel(const uint32_t*
       }
     }
   }
-  __syncthreads();
-  // first block whose exclusive record prefix is >= X, and the triangles before it (waves 0 and 1: X0 and X1)
-  if (wave < 2) {
-    const unsigned long long X = wave ? X1 : X0;
-    unsigned long long B = 0, tb = 0;
-    if (X != 0ull) {
-      const unsigned long long e = s_u64[4 + 3 * wave], acc = s_u64[5 + 3 * wave], tacc = s_u64[6 + 3 * wave];
-      const uint64_t b = e * MARCH_GROUP + lane;
-      const uint32_t h = b < n_blocks ? hdr[b] : 0u;
-      const unsigned nr = h & 255u, ntr = h >> 8;
-      unsigned ir = nr, it = ntr;
+  __syncthreads();  // (the last one: from here on every wave is on its own)
+  // first block whose exclusive record prefix is >= X, and the triangles before it -- for the wave's own begin (cut w) and end
+  // (cut w + 1): the 64 header words of the two groups are loaded together (two dependent trips to memory would be ~2 us each)
+  const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+  unsigned long long cutX[2], cutE[2], cutAcc[2], cutT[2];
+  uint32_t cutH[2];
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const unsigned ur = __shfl_up(ir, off, 64), ut = __shfl_up(it, off, 64);
-        if (lane >= (unsigned)off) { ir += ur; it += ut; }
-      }
-      const unsigned long long m = __ballot(acc + (ir - nr) >= X);
+  for (int i = 0; i < 2; i++) {
+    const unsigned w = wave_u + (unsigned)i;
+    cutX[i] = cut(w);
+    cutE[i] = uniform_u64(s_u64[4 + 3 * w]); cutAcc[i] = uniform_u64(s_u64[5 + 3 * w]); cutT[i] = uniform_u64(s_u64[6 + 3 * w]);
+    const uint64_t b = cutE[i] * MARCH_GROUP + lane;
+    cutH[i] = (cutX[i] != 0ull && b < n_blocks) ? hdr[b] : 0u;
+  }
+  unsigned long long cutB[2], cutTb[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    unsigned long long B = 0, tb = 0;
+    if (cutX[i] != 0ull) {
+      const unsigned nr = cutH[i] & 255u, ntr = cutH[i] >> 8;
+      const unsigned ir = wave_incl_scan_u32(nr), it = wave_incl_scan_u32(ntr);
+      const unsigned long long m = __ballot(cutAcc[i] + (ir - nr) >= cutX[i]);
       if (m != 0ull) {
         const int j = __builtin_ctzll(m);
-        B = e * MARCH_GROUP + (unsigned)j;
-        tb = tacc + (unsigned)__shfl(it - ntr, j, 64);
+        B = cutE[i] * MARCH_GROUP + (unsigned)j;
+        tb = cutT[i] + (unsigned)__builtin_amdgcn_readlane((int)(it - ntr), j);
       } else {
-        B = (e + 1) * MARCH_GROUP;
-        tb = tacc + (unsigned)__shfl(it, 63, 64);
+        B = (cutE[i] + 1) * MARCH_GROUP;
+        tb = cutT[i] + (unsigned)__builtin_amdgcn_readlane((int)it, 63);
       }
     }
-    if (lane == 0) { s_u64[10 + 2 * wave] = B; s_u64[11 + 2 * wave] = tb; }
+    cutB[i] = uniform_u64(B); cutTb[i] = uniform_u64(tb);
   }
-  __syncthreads();
-  const uint64_t b_begin = uniform_u64(s_u64[10]);
-  uint64_t b_end = uniform_u64(s_u64[12]);
+  const unsigned long long b_begin = cutB[0];
+  unsigned long long b_end = cutB[1], out = cutTb[0];
   if (b_end > n_blocks) b_end = n_blocks;
-  unsigned long long out = uniform_u64(s_u64[11]);
 
-  for (uint64_t b0 = b_begin; b0 < b_end; b0 += BLOCK) {  // block-uniform
-    // exclusive prefix of the record counts of blocks b0 .. b0+255
-    const uint64_t b = b0 + threadIdx.x;
-    const unsigned nr = b < b_end ? (hdr[b] & 255u) : 0u;
-    unsigned incl = nr;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned u = __shfl_up(incl, off, 64);
-      if (lane >= (unsigned)off) incl += u;
+  float* wcol = s_wave + wave_u * MARCH_WAVE_WORDS;
+  uint32_t* wown = (uint32_t*)(wcol + 64 * 11);
+  unsigned* wpre = (unsigned*)(wown + 5 * 64);  // [65] exclusive prefix of the pass's record counts, [64] = their sum
+  unsigned nr_next = (b_begin + lane < b_end) ? (hdr[b_begin + lane] & 255u) : 0u;
+#ifdef GSDF_EXP_MARCH_STARTUP_ONLY  // developer experiment: what the kernel costs before its first record (timing only)
+  if (nr_next != 0xffffffffu) return;
+#endif
+  for (uint64_t b0 = b_begin; b0 < b_end; b0 += 64) {  // wave-uniform
+    const unsigned nr = nr_next;
+    {  // the next pass's counts: a dependent global load (~2 us) in flight while this pass is marched
+      const uint64_t bn = b0 + 64 + lane;
+      nr_next = bn < b_end ? (hdr[bn] & 255u) : 0u;
     }
-    if (lane == 63) s_misc[4 + wave] = incl;
-    __syncthreads();
-    const unsigned p0 = s_misc[4], p1 = s_misc[5], p2 = s_misc[6], p3 = s_misc[7];
-    const unsigned wpre = (wave > 0 ? p0 : 0u) + (wave > 1 ? p1 : 0u) + (wave > 2 ? p2 : 0u);
-    s_pre[threadIdx.x] = wpre + incl - nr;
-    const unsigned Rp = __builtin_amdgcn_readfirstlane(p0 + p1 + p2 + p3);  // records of this pass (block-uniform)
-    if (threadIdx.x == 0) s_pre[BLOCK] = Rp;
-    __syncthreads();
-    // One record per lane in chunks of 256. The next chunk's record is fetched into registers BEFORE the current chunk is
-    // marched: a dependent global load is ~2 us.
+    const unsigned incl = wave_incl_scan_u32(nr);
+    wpre[lane] = incl - nr;
+    const unsigned Rp = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);  // records of this pass (wave-uniform)
+    __builtin_amdgcn_wave_barrier();
+    // One record per lane in chunks of 64. The next chunk's record is fetched into registers BEFORE the current chunk is marched.
     uint32_t rw[REC_WORDS];
     auto fetch = [&](unsigned q) {
 #pragma unroll
       for (int c = 0; c < REC_WORDS; c++) rw[c] = 0u;
       if (q < Rp) {
-        // the block holding record q: largest j with s_pre[j] <= q (blocks without records share their successor's prefix)
-        unsigned lo = 0, hi = BLOCK;
+        // the block holding record q: largest j with wpre[j] <= q (blocks without records share their successor's prefix)
+        unsigned lo = 0, hi = 64;
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
+        for (int it = 0; it < 6; it++) {
           const unsigned mid = (lo + hi) >> 1;
-          if (s_pre[mid] <= q) lo = mid; else hi = mid;
+          if (wpre[mid] <= q) lo = mid; else hi = mid;
         }
         struct __attribute__((packed, aligned(8))) Rec { uint32_t w[REC_WORDS]; };  // 40 bytes, 8-byte aligned: wide loads
-#ifdef GSDF_EXP_MARCH_ONE_LINE  // developer experiment: every lane reads the FIRST record of its block (a third of the record traffic)
-        const Rec v = *(const Rec*)(rec + (b0 + lo) * REC_BLOCK);
-#else
-        const Rec v = *(const Rec*)(rec + (b0 + lo) * REC_BLOCK + (q - s_pre[lo]) * REC_WORDS);
-#endif
+        const Rec v = *(const Rec*)(rec + (b0 + lo) * REC_BLOCK + (q - wpre[lo]) * REC_WORDS);
 #pragma unroll
         for (int c = 0; c < REC_WORDS; c++) rw[c] = v.w[c];
       }
     };
-    fetch(threadIdx.x);
-    for (unsigned q0 = 0; q0 < Rp; q0 += BLOCK) {  // block-uniform
-      const unsigned q = q0 + threadIdx.x;
-      out += march_chunk_emit(rw, q < Rp, [&] { fetch(q + BLOCK); }, ox, oy, oz, res, s_col, s_own, s_tri, s_misc, tris, out);
+    fetch(lane);
+    for (unsigned q0 = 0; q0 < Rp; q0 += 64u) {  // wave-uniform
+      const unsigned q = q0 + lane;
+      out += march_chunk_emit_wave(rw, q < Rp, [&] { fetch(q + 64u); }, ox, oy, oz, res, wcol, wown, s_tri, tris, out);
     }
+    __builtin_amdgcn_wave_barrier();  // (the next pass rewrites the prefix)
   }
 }
 
@@ -1549,12 +1666,13 @@ __global__ void __launch_bounds__(BLOCK) pack_records_kernel(const uint32_t* __r
 // where its first triangle goes (the part's tri0 + the counts of the part's chunks before it: a few KB from L2). Triangles
 // come out part-major, in record order. The chunk body is march_records_kernel's (march_chunk_emit): one record per lane, the
 // next chunk's record in flight while this one is marched, one output vertex per lane.
-// LDS: [11 record columns | owner list | tri table | misc] = 20.7 KB: 7 workgroups per CU.
-__global__ void __launch_bounds__(BLOCK, 7) march_dense_kernel(const uint8_t* __restrict__ buf, const DenseParts* __restrict__ parts, float ox, float oy, float oz,
+// LDS: [11 record columns | owner list | table of edge words 8 KB | misc] = 24.7 KB: 6 workgroups per CU.
+#define MARCH_DENSE_LDS_BYTES (11 * BLOCK * 4 + 5 * BLOCK * 4 + 256 * 16 * 2 + 8 * 4 + 8 + 4 * 8)
+__global__ void __launch_bounds__(BLOCK, 6) march_dense_kernel(const uint8_t* __restrict__ buf, const DenseParts* __restrict__ parts, float ox, float oy, float oz,
                                                                float res, float* __restrict__ tris) {
   float* s_col = g_smem;
   uint32_t* s_own = (uint32_t*)(s_col + 11 * BLOCK);
-  int8_t* s_tri = (int8_t*)(s_own + 5 * BLOCK);
+  uint16_t* s_tri = (uint16_t*)(s_own + 5 * BLOCK);
   unsigned* s_misc = (unsigned*)(s_tri + 256 * 16);
   unsigned long long* s_u64 = (unsigned long long*)(((uintptr_t)(s_misc + 8) + 7) & ~(uintptr_t)7);
   march_load_table(s_tri);

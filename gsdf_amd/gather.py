@@ -3,7 +3,7 @@ transfers instead of the library's own RCCL communicator.
 
 The product's multi-GPU exchange is gsdf_hip_mesh_gatherv_start / _wait: RCCL called directly inside libgsdfhip.so, which
 runs exactly the list of copies / sends / receives that gsdf_hip_gather_plan returns for the ranks' payload sizes. This module
-runs THE SAME LIST with dist.isend / dist.irecv -- on gloo for the CPU tests of the schedule and the rank-major layout
+runs THE SAME LIST as one dist.batch_isend_irecv -- on gloo for the CPU tests of the schedule and the rank-major layout
 (tests/test_gather_gloo.py, world sizes 2 and 3, ragged and empty ranks, all three modes), and on torch's RCCL process group
 as bench.py's fallback when the library's communicator cannot be had. Nothing is padded: the counts are exchanged (one
 all_gather of world int64) and every transfer has its exact size.
@@ -41,16 +41,21 @@ def run_plan(payload, mode=hip.GATHER_ALL, root=0, group=None):
     sizes_l = [int(c) for c in sizes.tolist()]
     ops, total = hip.gather_plan(sizes_l, rank, mode, root)
     out = torch.empty(total, dtype=torch.uint8, device=dev)
-    reqs = []
+    # The sends and receives run as ONE batch (dist.batch_isend_irecv): on torch's RCCL process group that is one
+    # ncclGroupStart / End around all of them, like the library's own executor. Issued one by one, both ranks of a pair would
+    # enqueue their send in front of their receive on the pair's communicator, and a payload beyond the eager limit (a mesh
+    # is tens of MB) then waits for a receive that sits behind the peer's own send. gloo takes the same batch.
+    p2p = []
     for kind, peer, src_off, dst_off, nbytes in ops:
         if kind == hip.GOP_COPY:
             out[dst_off:dst_off + nbytes] = payload[src_off:src_off + nbytes]
         elif kind == hip.GOP_SEND:
-            reqs.append(dist.isend(payload[src_off:src_off + nbytes].contiguous(), peer, group=group))
+            p2p.append(dist.P2POp(dist.isend, payload[src_off:src_off + nbytes].contiguous(), peer, group))
         else:
-            reqs.append(dist.irecv(out[dst_off:dst_off + nbytes], peer, group=group))
-    for r in reqs:
-        r.wait()
+            p2p.append(dist.P2POp(dist.irecv, out[dst_off:dst_off + nbytes], peer, group))
+    if p2p:
+        for r in dist.batch_isend_irecv(p2p):
+            r.wait()
     return out, sizes_l, ops
 
 

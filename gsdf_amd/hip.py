@@ -21,7 +21,7 @@ ErrMismatchBufferLength = "position and distance buffer length mismatch"
 
 # every symbol include/gsdf_hip.h declares
 SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "gsdf_hip_program_destroy",
-           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_lower_region", "gsdf_hip_eval3_submit", "gsdf_hip_eval_wait", "gsdf_hip_host_alloc", "gsdf_hip_host_register", "gsdf_hip_host_release", "gsdf_hip_comm_unique_id", "gsdf_hip_comm_create", "gsdf_hip_comm_rank", "gsdf_hip_comm_world", "gsdf_hip_comm_allreduce_sum_u64", "gsdf_hip_mesh_gatherv", "gsdf_hip_mesh_gatherv_start", "gsdf_hip_mesh_gatherv_wait", "gsdf_hip_comm_destroy", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_selftest_circ", "gsdf_hip_blockcache_create", "gsdf_hip_blockcache_reset", "gsdf_hip_blockcache_eval3", "gsdf_hip_blockcache_hits", "gsdf_hip_blockcache_evaluations", "gsdf_hip_blockcache_destroy", "gsdf_hip_program_specialize", "gsdf_hip_program_is_specialized", "gsdf_hip_program_kernels", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
+           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_lower_region", "gsdf_hip_eval3_submit", "gsdf_hip_eval_wait", "gsdf_hip_host_alloc", "gsdf_hip_host_register", "gsdf_hip_host_release", "gsdf_hip_comm_unique_id", "gsdf_hip_comm_create", "gsdf_hip_comm_rank", "gsdf_hip_comm_world", "gsdf_hip_comm_allreduce_sum_u64", "gsdf_hip_mesh_gatherv", "gsdf_hip_mesh_gatherv_start", "gsdf_hip_mesh_gatherv_wait", "gsdf_hip_comm_destroy", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_selftest_circ", "gsdf_hip_blockcache_create", "gsdf_hip_blockcache_reset", "gsdf_hip_blockcache_eval3", "gsdf_hip_blockcache_hits", "gsdf_hip_blockcache_evaluations", "gsdf_hip_blockcache_destroy", "gsdf_hip_program_specialize", "gsdf_hip_program_specialize_async", "gsdf_hip_program_specialize_poll", "gsdf_hip_program_is_specialized", "gsdf_hip_program_kernels", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
            "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3", "gsdf_hip_image2",
            "gsdf_hip_mesh_octree", "gsdf_hip_mesh_dualcontour", "gsdf_hip_mesh_flat", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
            "gsdf_hip_mesh_stl", "gsdf_hip_mesh_host_tris", "gsdf_hip_mesh_host_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner", "gsdf_hip_slab_range",
@@ -118,6 +118,8 @@ def lib():
         L.gsdf_hip_blockcache_destroy.argtypes = [C.c_void_p]
         L.gsdf_hip_program_specialize.argtypes = [C.c_void_p]
         L.gsdf_hip_program_is_specialized.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.gsdf_hip_program_specialize_async.argtypes = [C.c_void_p]
+        L.gsdf_hip_program_specialize_poll.argtypes = [C.c_void_p, C.c_int]
         L.gsdf_hip_program_kernels.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         L.gsdf_hip_specialize_source.argtypes = [C.POINTER(GsdfTree), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.gsdf_hip_specialize_check.argtypes = [C.POINTER(GsdfTree), C.POINTER(C.c_size_t)]
@@ -219,6 +221,19 @@ class SDFHIP:
         """Build (hiprtc) and switch to kernels specialised for this tree: same bits, no fetch/decode. Returns self."""
         _check(lib().gsdf_hip_program_specialize(self._h))
         return self
+
+    def specialize_async(self):
+        """Start the same build on a thread of the library's own and return: the handle works through the interpreter kernels until
+        the specialised ones are ready and switches at its next call (gsdf_hip_program_specialize_async). Returns self."""
+        _check(lib().gsdf_hip_program_specialize_async(self._h))
+        return self
+
+    def specialize_poll(self, wait=False):
+        """True once the handle runs specialised kernels (wait=True: block until the background build has finished)."""
+        rc = lib().gsdf_hip_program_specialize_poll(self._h, 1 if wait else 0)
+        if rc < 0:
+            _check(rc)
+        return rc == 1
 
     def Evaluate(self, pos, dist=None, userData=None):
         """pos: (n,3)|(n,4)|(n,2) float32 host array (row stride = position stride); dist: (n,) float32."""

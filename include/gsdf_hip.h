@@ -84,6 +84,14 @@ int gsdf_hip_selftest_circ(float ncirc, uint64_t* mismatches, uint64_t* fast_pat
  * architecture, options, hiprtc version), so the next process that specialises the same tree reads a file instead. */
 int gsdf_hip_program_specialize(gsdf_program* p);
 int gsdf_hip_program_is_specialized(const gsdf_program* p, double* compile_seconds);
+/* The same build on a thread of its own: returns at once, the handle keeps working through the interpreter kernels and switches to
+ * the specialised ones at its first entry-point call after they are ready (bit-identical results either way). For the callers the
+ * reference actually has -- one tree, one mesh, one file (examples/npt-flange/flange.go:61-98; gsdfaux.RenderShader3D,
+ * gsdfaux/gsdfaux.go:93-171, compiles its shader and then renders once): the first mesh does not wait for a compiler.
+ * _poll: 1 = specialised kernels in use, 0 = still building or never started (wait != 0: block until the build has finished),
+ * negative status = the build failed (the interpreter kernels stay in use). Destroying the handle waits for a build under way. */
+int gsdf_hip_program_specialize_async(gsdf_program* p);
+int gsdf_hip_program_specialize_poll(gsdf_program* p, int wait);
 /* Names of the kernels this handle launches, as a profiler shows them: "eval=eval_kernel<3,4,4>:specialised
  * leaf=leaf_eval_kernel<4,4>:specialised prune=prune_kernel:specialised compiler=hipcc code=<32 hex digits>" (":interpreter" =
  * the ahead-of-time kernels; compiler = what built the specialised ones: the installed hipcc out of process, or the process's

@@ -1,6 +1,9 @@
 // Micro-benchmark: issue rate of VALU instruction CLASSES on gfx950 -- what the evaluating kernel's instruction mix costs.
-// 16 independent chains per lane, 4 waves per SIMD (the leaf kernel's occupancy) and 8; cycles at 2.4 GHz per wave-instruction
-// per SIMD. (leaf_eval_kernel on npt-flange: 47 % of its VALU instructions are f32 add / mul / fma, f64, conversions or integer
+// 16 independent chains per lane, 4 waves per SIMD (the leaf kernel's occupancy) and 8. Cycles per wave-instruction per SIMD are
+// REAL shader-clock cycles: every wave brackets its loop with s_memtime (the shader clock counter) and s_memrealtime (a constant
+// 100 MHz), the longest wave of the launch is what is reported, and the clock the loop actually ran at is printed beside it
+// (round 4's table converted wall time at an assumed 2.4 GHz and read 2.66 "cycles" for v_fma_f32: the part runs VALU-dense
+// code below its peak clock, see profiles/r5_valu_class_rates.txt). (leaf_eval_kernel on npt-flange: 47 % of its VALU instructions are f32 add / mul / fma, f64, conversions or integer
 // arithmetic by the SQ_INSTS_VALU_* counters; the rest are moves, selects, compares, min / max, logic.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -9,7 +12,7 @@
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 template <int OP>
-__global__ void __launch_bounds__(256) k(float* out, int iters, float a, float b) {
+__global__ void __launch_bounds__(256) k(float* out, int iters, float a, float b, unsigned long long* tm) {
   float s[16];
   double d[8];
   typedef float v2f __attribute__((ext_vector_type(2)));
@@ -18,6 +21,7 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, float a, float b
   for (int i = 0; i < 8; i++) { d[i] = (double)s[i]; p[i] = v2f{s[2 * i], s[2 * i + 1]}; }
   v2f aa = v2f{a, a}, bb = v2f{b, b};
   double da = a, db = b;
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; it++) {
 #define F(i)                                                                                                                  \
   if (OP == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(s[i]) : "v"(a), "v"(b));                                        \
@@ -85,6 +89,8 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, float a, float b
     REP16(G)
 #undef G
   }
+  const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) { atomicMax(&tm[0], c1 - c0); atomicMax(&tm[1], r1 - r0); }
   float r = 0;
   for (int i = 0; i < 16; i++) r += s[i];
   for (int i = 0; i < 8; i++) r += (float)d[i] + p[i].x + p[i].y;
@@ -100,7 +106,9 @@ int main() {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  struct Row { const char* name; void (*fn)(float*, int, float, float); };
+  struct Row { const char* name; void (*fn)(float*, int, float, float, unsigned long long*); };
+  unsigned long long* dtm;
+  (void)hipMalloc(&dtm, 16);
 #define ROW(n, op) Row{n, k<op>}
   std::vector<Row> rows = {ROW("v_fma_f32", 0), ROW("v_add_f32", 1), ROW("v_sub_f32", 25), ROW("v_mul_f32", 2), ROW("v_max_f32", 3), ROW("v_min_f32", 4), ROW("v_med3_f32", 5),
                            ROW("v_max3_f32", 19), ROW("v_mov_b32", 6), ROW("v_cndmask_b32 vcc", 7), ROW("v_cndmask_b32 sgpr pair", 29), ROW("v_cmp_gt_f32 -> vcc", 8),
@@ -117,15 +125,20 @@ int main() {
     for (const Row& r : rows) {
       const int grid = cus * wps;
       float ms = 0;
+      unsigned long long tm[2] = {0, 0};
       for (int rep = 0; rep < 2; rep++) {
+        (void)hipMemset(dtm, 0, 16);
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL(r.fn, dim3(grid), dim3(256), 0, 0, dmem, iters, 1.0001f, 0.5f);
+        hipLaunchKernelGGL(r.fn, dim3(grid), dim3(256), 0, 0, dmem, iters, 1.0001f, 0.5f, dtm);
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipMemcpy(tm, dtm, 16, hipMemcpyDeviceToHost);
       }
-      const double per_simd = (double)wps * iters * 32;
-      printf("%-28s %6.2f cycles per wave-instruction per SIMD\n", r.name, ms * 1e6 / per_simd * 2.4);
+      const double per_simd = (double)wps * iters * 32;  // wave-instructions a SIMD issues: its waves x iterations x 32 per iteration
+      const double ghz = tm[1] ? (double)tm[0] / ((double)tm[1] * 10.0) : 0.0;  // s_memrealtime ticks are 10 ns
+      printf("%-28s %6.2f cycles per wave-instruction per SIMD (s_memtime)   clock %.2f GHz   [wall time at an assumed 2.4 GHz: %.2f]\n", r.name,
+             (double)tm[0] / per_simd, ghz, ms * 1e6 / per_simd * 2.4);
     }
   }
   return 0;
