@@ -132,3 +132,39 @@ def test_specialised_dualcontour_normals_image(gpu):
     s2, p2 = gpu.SDF2HIP(sh2).specialize(), gpu.SDF2HIP(sh2)
     ia, ib = s2.render_image(96, 64), p2.render_image(96, 64)
     assert all((np.asarray(x).view(np.uint8) == np.asarray(y).view(np.uint8)).all() for x, y in zip(ia, ib))
+
+
+def test_background_specialisation(gpu, tmp_path, monkeypatch):
+    """gsdf_hip_program_specialize_async: the handle meshes through the interpreter kernels while the build runs and through the
+    specialised ones once it is adopted -- the same triangles, bit for bit, at every moment; a warm code-object cache makes the
+    second handle's build a file read; destroying a handle waits for a build under way."""
+    monkeypatch.setenv("GSDF_HIP_CACHE_DIR", str(tmp_path))
+    s = Builder().Scene("bolt")
+    g = GOLD["bolt_resdiv150"]
+    res = np.uint32(g["res_bits"]).view(np.float32)
+    sdf = gpu.SDF3HIP(s)
+    assert not sdf.info()["specialized"]
+    sdf.specialize_async()
+    sdf.specialize_async()                                   # idempotent while a build is under way
+    first = gpu.OctreeHIP(sdf, res)                          # at once: whichever kernels are ready (with a cold cache, the interpreter's)
+    assert first.n_tris() == g["n_tris"] and hashlib.sha256(_sorted(first.RenderAll()).tobytes()).hexdigest() == g["sha256_sorted"]
+    pos = corpus.sample_points(s)
+    d0 = sdf.Evaluate(pos)
+    assert sdf.specialize_poll(wait=True) and sdf.info()["specialized"]
+    assert "specialised" in sdf.info()["kernels"]["leaf"]
+    later = gpu.OctreeHIP(sdf, res)
+    assert later.n_tris() == g["n_tris"] and hashlib.sha256(_sorted(later.RenderAll()).tobytes()).hexdigest() == g["sha256_sorted"]
+    assert _mismatch(sdf.Evaluate(pos), d0) == 0 and _mismatch(d0, OracleSDF(s.tree()).Evaluate(pos)) == 0
+    sdf.specialize_async()                                   # nothing left to do
+    assert sdf.specialize_poll()
+    # a second handle of the same tree: the cache holds the code object now
+    import time
+    t0 = time.perf_counter()
+    sdf2 = gpu.SDF3HIP(s).specialize_async()
+    assert sdf2.specialize_poll(wait=True)
+    assert time.perf_counter() - t0 < 1.0 and sdf2.info()["kernels"].get("compiler") == "cache"
+    # a handle closed while its build runs (a fresh tree, nothing cached): close() returns after the build, nothing leaks or crashes
+    other = gpu.SDF3HIP(Builder().Scene("knurled-cylinder")).specialize_async()
+    other.close()
+    # poll on a handle that never asked for a build
+    assert gpu.SDF3HIP(s).specialize_poll() is False

@@ -9,7 +9,7 @@ if [ -n "$T" ]; then timeout 2400 python -m pytest $T -x -q -m gpu 2>&1 | tail -
 for knob in 0 1; do
 echo "GSDF_HIP_NO_BRICK_MASKS=$knob"
 for sc in "npt-flange 1600" "bolt 2000" "knurled-cylinder 2000"; do set -- $sc
-GSDF_HIP_NO_BRICK_MASKS=$knob timeout 600 python bench.py --scene $1 --resdiv $2 --steps 20 --no-cpu-baseline --no-evaluate-dropin --no-distinct-rows > $OUT/bench_$1_$knob.json 2>$OUT/bench_$1_$knob.err || tail -5 $OUT/bench_$1_$knob.err
+GSDF_HIP_NO_BRICK_MASKS=$knob timeout 600 python bench.py --scene $1 --resdiv $2 --steps 20 --no-cpu-baseline --no-evaluate-dropin --no-distinct-rows --no-one-shot > $OUT/bench_$1_$knob.json 2>$OUT/bench_$1_$knob.err || tail -5 $OUT/bench_$1_$knob.err
 python - $OUT/bench_$1_$knob.json <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

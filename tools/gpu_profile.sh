@@ -11,7 +11,7 @@ for sc in "$@"; do set -- $sc
   ARGS="--scene $1 --resdiv $2"
   timeout 900 python bench.py $ARGS --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err || tail -3 $OUT/bench.err
   # counters from blocking meshes (the kernel with the GPU to itself), as the line's roofline is
-  P="python $GRAFT_REPO_ROOT/bench.py $ARGS --steps 5 --warmup 1 --preheat 4 --no-cpu-baseline --no-evaluate-dropin --no-distinct-rows --no-mesh-pipeline"
+  P="python $GRAFT_REPO_ROOT/bench.py $ARGS --steps 5 --warmup 1 --preheat 4 --no-cpu-baseline --no-evaluate-dropin --no-distinct-rows --no-one-shot --no-mesh-pipeline"
   ( cd /tmp
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $P > $OUT/trace.log 2>&1
     timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_BRANCH --output-format csv -d $OUT/p1 -- $P > $OUT/p1.log 2>&1

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 cp gsdf_amd/csrc/libgsdfhip.so /tmp/lib_orig.so
 for v in $1; do
 cp tools/variants/lib_$v.so gsdf_amd/csrc/libgsdfhip.so
-timeout 600 python bench.py ${2:---scene npt-flange --resdiv 1600} --steps 20 --no-cpu-baseline --no-evaluate-dropin --no-distinct-rows > /tmp/b_$v.json 2>/tmp/b_$v.err || tail -3 /tmp/b_$v.err
+timeout 600 python bench.py ${2:---scene npt-flange --resdiv 1600} --steps 20 --no-cpu-baseline --no-evaluate-dropin --no-distinct-rows --no-one-shot > /tmp/b_$v.json 2>/tmp/b_$v.err || tail -3 /tmp/b_$v.err
 python - /tmp/b_$v.json $v <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
