@@ -411,8 +411,15 @@ def main():
     dist = None
     comm = None
     torch_gather = False
-    torch.cuda.set_device(local_rank if world > 1 else 0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    # one rank per GPU; on a box with fewer GPUs than ranks (GSDF_HIP_COMM=ipc: the library's inter-process transport for ranks that
+    # share a device -- RCCL refuses those) the ranks go round the devices there are: the whole N > 1 path on one GPU, no scaling claim
+    ndev = max(1, torch.cuda.device_count())
+    shared_device = world > ndev
+    if shared_device and os.environ.get("GSDF_HIP_COMM") != "ipc":
+        raise SystemExit(f"{world} ranks on {ndev} GPU(s): set GSDF_HIP_COMM=ipc (ranks sharing a device cannot use RCCL)")
+    dev_index = (local_rank % ndev) if world > 1 else 0
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     hip.init(dev.index)
     # (developer knobs, used by tools/gpu_dist1.sh to run the N > 1 code path on the one GPU a gpurun box has:
     # GSDF_BENCH_FORCE_DIST=1 takes it at world size 1, GSDF_BENCH_FORCE_TORCH_GATHER=1 also forces its fallback)
@@ -655,6 +662,9 @@ def main():
             "stages": dc_stages,
             "phase_ms_rank0": {"prune": st.ms_prune, "leaf": st.ms_leaf, "eval_kernel": st.ms_march, "march_kernel": st.ms_emit, "total_device": st.ms_total},
         }
+        if shared_device:
+            out["config"]["devices"] = (f"{world} ranks on {ndev} GPU(s): ranks share a device over the library's inter-process transport (GSDF_HIP_COMM=ipc) -- "
+                                        "the N > 1 code path end to end, not a scaling measurement")
         if mesh_pipeline and not dc:
             # The two chains in flight share the CUs: the evaluating kernel's event-to-event time above includes what the other
             # chain's centre tests and marching kernel took from it. Its duration ALONE, from blocking meshes after the timed loop:

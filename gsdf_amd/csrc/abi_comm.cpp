@@ -15,7 +15,15 @@
 // is a device-to-device copy ordered by events) with which the whole path -- counts, plan, transfers, marching -- runs at world
 // sizes 2..64 on a one-GPU box (tests/test_gpu_gather.py); only librccl's own send/recv is not exercised by it.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <thread>
 
 #include <condition_variable>
 #include <cstdlib>
@@ -280,6 +288,208 @@ bool loopback_requested() {
   const char* e = getenv("GSDF_HIP_COMM");
   return e && !strcmp(e, "loopback");
 }
+
+// ---- ipc: the ranks are PROCESSES of one node that may share a device ------------------------------------------------------------
+// RCCL refuses two ranks on one GPU ("duplicate GPU"), so on a one-GPU box the N > 1 path of a multi-process caller -- bench.py under
+// torch.distributed.run: a rendezvous of the 128-byte id, one HIP context per process, barriers, the counts, the plan, marching what
+// arrived -- could not run at all. GSDF_HIP_COMM=ipc gives it a transport: a POSIX shared-memory segment named by the id holds a
+// barrier, a board for the small collectives and one mailbox per (sender, receiver); a send posts the hipIpcMemHandle of its source
+// allocation (+ offset, size) once the sender's stream has produced the data, the matching receive maps it (hipIpcOpenMemHandle,
+// cached), copies device to device on its own stream and marks the mailbox taken, and the sender's group_end returns when its
+// mailboxes are: ncclSend / ncclRecv ordering with the host in the loop (no interprocess events: a transfer has completed when
+// group_end returns, so a _start overlaps nothing -- a test transport for what one GPU can show, not a fast one). Works between
+// devices of one node as well. Every wait gives up after GSDF_HIP_IPC_TIMEOUT_S (default 120) seconds with an error.
+struct IpcShm {
+  static constexpr int kMaxWorld = 64;
+  std::atomic<uint32_t> magic;      // set last by the creator
+  std::atomic<uint32_t> world;
+  std::atomic<uint32_t> bar_count;  // sense-reversing barrier
+  std::atomic<uint32_t> bar_gen;
+  std::atomic<uint32_t> failed;     // a rank gave up: everybody stops waiting
+  uint32_t pad[11];
+  unsigned long long board[kMaxWorld][16];
+  struct Box {
+    std::atomic<uint32_t> state;    // 0 empty, 1 posted, 2 taken
+    int32_t rc;
+    uint64_t off, bytes;
+    hipIpcMemHandle_t h;
+  } box[kMaxWorld][kMaxWorld];      // [sender][receiver]
+};
+const char kIpcMagic[8] = {'G', 'S', 'D', 'F', 'I', 'P', 'C', '1'};
+bool ipc_requested() {
+  const char* e = getenv("GSDF_HIP_COMM");
+  return e && !strcmp(e, "ipc");
+}
+double ipc_timeout_s() {
+  const char* e = getenv("GSDF_HIP_IPC_TIMEOUT_S");
+  const double v = e ? atof(e) : 0.0;
+  return v > 0 ? v : 120.0;
+}
+
+struct IpcTransport final : Transport {
+  IpcShm* shm = nullptr;
+  std::string shm_name;
+  bool creator = false;
+  int rank = 0, world = 0;
+  struct PendingRecv { void* dst; size_t bytes; int peer; };
+  std::vector<int> sent_to;
+  std::vector<PendingRecv> recvs;
+  struct Mapped { hipIpcMemHandle_t h; void* p; };
+  std::vector<Mapped> mapped;  // peers' allocations this process has opened (closed with the communicator)
+  ~IpcTransport() override {
+    for (Mapped& m : mapped) (void)hipIpcCloseMemHandle(m.p);
+    if (shm) munmap(shm, sizeof(IpcShm));
+    if (creator) shm_unlink(shm_name.c_str());
+  }
+  template <typename F>
+  int wait_until(F done, const char* what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (!done()) {
+      if (shm->failed.load(std::memory_order_acquire)) return fail(GSDF_ERR_HIP, std::string("ipc: another rank gave up while this one waited for ") + what);
+      if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+      if ((spins & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > ipc_timeout_s()) {
+        shm->failed.store(1, std::memory_order_release);
+        return fail(GSDF_ERR_HIP, std::string("ipc: timed out waiting for ") + what);
+      }
+    }
+    return GSDF_OK;
+  }
+  int barrier() {
+    const uint32_t gen = shm->bar_gen.load(std::memory_order_acquire);
+    if (shm->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)world) {
+      shm->bar_count.store(0, std::memory_order_relaxed);
+      shm->bar_gen.fetch_add(1, std::memory_order_acq_rel);
+      return GSDF_OK;
+    }
+    return wait_until([&] { return shm->bar_gen.load(std::memory_order_acquire) != gen; }, "the other ranks at a barrier");
+  }
+  int exchange(const std::vector<unsigned long long>& mine, std::vector<std::vector<unsigned long long>>& all) {
+    if (mine.size() > 16) return fail(GSDF_ERR_BAD_ARGUMENT, "ipc: a small collective carries at most 16 words per rank");
+    for (size_t i = 0; i < mine.size(); i++) shm->board[rank][i] = mine[i];
+    if (int rc = barrier()) return rc;
+    all.assign((size_t)world, std::vector<unsigned long long>(mine.size()));
+    for (int r = 0; r < world; r++) for (size_t i = 0; i < mine.size(); i++) all[(size_t)r][i] = shm->board[r][i];
+    return barrier();  // nobody rewrites the board before everybody has read it
+  }
+  int all_gather_u64(const unsigned long long* d_send, unsigned long long* d_recv, size_t n, hipStream_t s) override {
+    std::vector<unsigned long long> mine(n);
+    HIP_TRY(hipMemcpyAsync(mine.data(), d_send, n * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<std::vector<unsigned long long>> all;
+    if (int rc = exchange(mine, all)) return rc;
+    std::vector<unsigned long long> flat;
+    for (const auto& v : all) flat.insert(flat.end(), v.begin(), v.end());
+    HIP_TRY(hipMemcpyAsync(d_recv, flat.data(), flat.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return GSDF_OK;
+  }
+  int all_reduce_sum_u64(unsigned long long* d_buf, size_t n, hipStream_t s) override {
+    std::vector<unsigned long long> mine(n);
+    HIP_TRY(hipMemcpyAsync(mine.data(), d_buf, n * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<unsigned long long> sum(n, 0);
+    for (size_t o = 0; o < n; o += 16) {  // in pieces of the board's 16 words per rank
+      const size_t k = n - o < 16 ? n - o : 16;
+      std::vector<std::vector<unsigned long long>> all;
+      if (int rc = exchange(std::vector<unsigned long long>(mine.begin() + (long)o, mine.begin() + (long)(o + k)), all)) return rc;
+      for (const auto& v : all) for (size_t i = 0; i < k; i++) sum[o + i] += v[i];
+    }
+    HIP_TRY(hipMemcpyAsync(d_buf, sum.data(), n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return GSDF_OK;
+  }
+  int group_start() override { sent_to.clear(); recvs.clear(); return GSDF_OK; }
+  int send(const void* d, size_t bytes, int peer, hipStream_t s) override {
+    if (peer < 0 || peer >= world || peer == rank) return fail(GSDF_ERR_BAD_ARGUMENT, "ipc: bad peer");
+    HIP_TRY(hipStreamSynchronize(s));  // the payload is complete before its handle leaves the process
+    void* base = nullptr;
+    size_t size = 0;
+    HIP_TRY(hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)d));
+    IpcShm::Box& b = shm->box[rank][peer];
+    if (int rc = wait_until([&] { return b.state.load(std::memory_order_acquire) == 0u; }, "a mailbox to empty")) return rc;
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, base));
+    b.h = h; b.off = (uint64_t)((const char*)d - (const char*)base); b.bytes = bytes; b.rc = GSDF_OK;
+    b.state.store(1u, std::memory_order_release);
+    sent_to.push_back(peer);
+    return GSDF_OK;
+  }
+  int recv(void* d, size_t bytes, int peer, hipStream_t) override { recvs.push_back({d, bytes, peer}); return GSDF_OK; }
+  void* map(const hipIpcMemHandle_t& h) {
+    for (const Mapped& m : mapped) if (!std::memcmp(&m.h, &h, sizeof h)) return m.p;
+    if (mapped.size() >= 32) { (void)hipIpcCloseMemHandle(mapped.front().p); mapped.erase(mapped.begin()); }  // (pool buffers come and go)
+    void* p = nullptr;
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    mapped.push_back({h, p});
+    return p;
+  }
+  int group_end(hipStream_t s) override {
+    int rc = GSDF_OK;
+    for (const PendingRecv& r : recvs) {
+      IpcShm::Box& b = shm->box[r.peer][rank];
+      int mrc = wait_until([&] { return b.state.load(std::memory_order_acquire) == 1u; }, "a peer's send");
+      if (mrc) { if (!rc) rc = mrc; break; }
+      if (b.bytes != r.bytes) mrc = fail(GSDF_ERR_BAD_ARGUMENT, "ipc: a receive's size differs from the matching send's");
+      else {
+        void* src = map(b.h);
+        if (!src) mrc = fail(GSDF_ERR_HIP, "ipc: hipIpcOpenMemHandle failed (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)");
+        else if (hipMemcpyAsync(r.dst, (const char*)src + b.off, r.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+          mrc = fail(GSDF_ERR_HIP, "ipc: device-to-device copy from a peer's allocation failed");
+      }
+      b.rc = mrc;
+      b.state.store(2u, std::memory_order_release);
+      if (mrc && !rc) rc = mrc;
+    }
+    for (int peer : sent_to) {  // the source stays untouched until the receiver has copied it
+      IpcShm::Box& b = shm->box[rank][peer];
+      const int wrc = wait_until([&] { return b.state.load(std::memory_order_acquire) == 2u; }, "a peer to take a send");
+      if (wrc) { if (!rc) rc = wrc; continue; }
+      if (b.rc && !rc) rc = fail(GSDF_ERR_HIP, "ipc: the receiving rank failed");
+      b.state.store(0u, std::memory_order_release);
+    }
+    sent_to.clear();
+    recvs.clear();
+    return rc;
+  }
+  const char* name() const override { return "ipc"; }
+  // rank 0 creates the segment, the others wait for it
+  int attach(const uint8_t* id, int rank_, int world_) {
+    rank = rank_; world = world_;
+    uint64_t token = 0;
+    std::memcpy(&token, id + 8, 8);
+    char nm[64];
+    snprintf(nm, sizeof nm, "/gsdf_ipc_%016llx", (unsigned long long)token);
+    shm_name = nm;
+    int fd = -1;
+    if (rank == 0) {
+      (void)shm_unlink(nm);
+      fd = shm_open(nm, O_CREAT | O_EXCL | O_RDWR, 0600);
+      if (fd < 0 || ftruncate(fd, (off_t)sizeof(IpcShm)) != 0) { if (fd >= 0) close(fd); return fail(GSDF_ERR_HIP, std::string("ipc: cannot create the shared-memory segment ") + nm); }
+      creator = true;
+    } else {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (;;) {
+        fd = shm_open(nm, O_RDWR, 0600);
+        struct stat st;
+        if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(IpcShm)) break;
+        if (fd >= 0) { close(fd); fd = -1; }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > ipc_timeout_s()) return fail(GSDF_ERR_HIP, std::string("ipc: rank 0 never created ") + nm);
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+      }
+    }
+    void* p = mmap(nullptr, sizeof(IpcShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return fail(GSDF_ERR_HIP, "ipc: mmap of the shared-memory segment failed");
+    shm = (IpcShm*)p;  // (a fresh segment is zero-filled: counters 0, mailboxes empty)
+    if (rank == 0) { shm->world.store((uint32_t)world); shm->magic.store(0x43504947u, std::memory_order_release); }
+    else {
+      if (int rc = wait_until([&] { return shm->magic.load(std::memory_order_acquire) == 0x43504947u; }, "rank 0 to publish the segment")) return rc;
+      if (shm->world.load() != (uint32_t)world) return fail(GSDF_ERR_BAD_ARGUMENT, "ipc: ranks disagree about the world size");
+    }
+    return barrier();  // everybody is attached (rank 0 may unlink the name only at the end: late joiners of a rerun get a fresh one)
+  }
+};
 }  // namespace
 
 struct gsdf_comm {
@@ -316,6 +526,15 @@ extern "C" int gsdf_hip_comm_unique_id(uint8_t id[GSDF_COMM_ID_BYTES]) {
     std::memcpy(id + 8, &idx, 8);
     return GSDF_OK;
   }
+  if (ipc_requested()) {  // a random token names the shared-memory segment
+    uint64_t token = 0;
+    int fd = open("/dev/urandom", O_RDONLY);
+    if (fd >= 0) { if (read(fd, &token, 8) != 8) token = 0; close(fd); }
+    if (!token) token = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((uint64_t)getpid() << 32);
+    std::memcpy(id, kIpcMagic, 8);
+    std::memcpy(id + 8, &token, 8);
+    return GSDF_OK;
+  }
   RcclApi* R = rccl();
   if (!R->err.empty()) return fail(GSDF_ERR_HIP, R->err);
   static_assert(sizeof(ncclUniqueId) <= GSDF_COMM_ID_BYTES, "ncclUniqueId larger than GSDF_COMM_ID_BYTES");
@@ -342,8 +561,8 @@ extern "C" int gsdf_hip_comm_create(const uint8_t id[GSDF_COMM_ID_BYTES], int ra
   *out = nullptr;
   if (world < 1 || rank < 0 || rank >= world) return fail(GSDF_ERR_BAD_ARGUMENT, "bad rank / world size");
   if (world > kDenseMaxParts) return fail(GSDF_ERR_BAD_ARGUMENT, "world size above 64");
-  const bool loop = std::memcmp(id, kLoopMagic, 8) == 0;
-  RcclApi* R = loop ? nullptr : rccl();
+  const bool loop = std::memcmp(id, kLoopMagic, 8) == 0, ipc = std::memcmp(id, kIpcMagic, 8) == 0;
+  RcclApi* R = (loop || ipc) ? nullptr : rccl();
   if (R && !R->err.empty()) return fail(GSDF_ERR_HIP, R->err);
   gsdf_comm* c = new (std::nothrow) gsdf_comm();
   if (!c) return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory");
@@ -373,6 +592,10 @@ extern "C" int gsdf_hip_comm_create(const uint8_t id[GSDF_COMM_ID_BYTES], int ra
     }
     auto t = std::make_unique<LoopTransport>();
     t->w = w; t->rank = rank;
+    c->t = std::move(t);
+  } else if (ipc) {
+    auto t = std::make_unique<IpcTransport>();
+    if (int rc = t->attach(id, rank, world)) return bail(rc);
     c->t = std::move(t);
   } else {
     auto t = std::make_unique<RcclTransport>(R);

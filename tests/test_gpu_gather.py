@@ -271,3 +271,48 @@ def test_gather_rejects_mixed_payloads(gpu):
         return True
 
     assert _loopback_world(gpu, 2, work) == [True, True]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gatherv_across_processes_sharing_a_device(gpu, world, tmp_path):
+    """The N > 1 path with the ranks as PROCESSES -- each its own HIP context on device 0 -- over the library's inter-process
+    transport (GSDF_HIP_COMM=ipc: RCCL refuses two ranks on one GPU): the id travels through a file, every rank meshes its shard and
+    the ranks gather in all three modes with both payloads, then pipelined as bench.py does. The gathered mesh is the whole mesh, bit
+    for bit, on every receiving rank (tests/ipc_rank.py is one rank)."""
+    import hashlib
+    import json
+    import subprocess
+    import sys
+    b = Builder()
+    sh = b.Scene("npt-flange")
+    res = np.float32(float(sh.Diagonal()) / 260)
+    whole = gpu.OctreeHIP(gpu.SDF3HIP(sh), res)
+    want = hashlib.sha256(_srt(whole.RenderAll()).tobytes()).hexdigest()
+    want_tris, want_evals = whole.n_tris(), int(whole.stats.evals_leaf)
+    env = dict(os.environ, GSDF_HIP_COMM="ipc", HSA_ENABLE_IPC_MODE_LEGACY="0", GSDF_HIP_IPC_TIMEOUT_S="90")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ipc_rank.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hangs")
+        logs.append(o.decode(errors="replace")[-3000:])
+    assert all(pr.returncode == 0 for pr in procs), "\n----\n".join(logs)
+    for r in range(world):
+        j = json.load(open(tmp_path / f"rank{r}.json"))
+        assert len(j["modes"]) == 6
+        for row in j["modes"]:
+            assert row["total"] == [want_tris, want_evals] and sum(row["counts"]) == want_tris and row["counts"][r] == row["own"]
+            recv = row["mode"] == gpu.GATHER_ALL or (row["mode"] == gpu.GATHER_ROOT and r == row["root"])
+            assert row["received"] == recv
+            if recv:
+                assert row["n_tris"] == want_tris and row["sha256_sorted"] == want
+                if row["payload"] == gpu.PAYLOAD_TRIANGLES:
+                    assert row["bytes_received"] == 36 * (want_tris - row["own"])
+            if row["mode"] == gpu.GATHER_NONE:
+                assert row["bytes_sent"] == 0 and row["bytes_received"] == 0
+        assert j["pipelined"] == [want] * 3
