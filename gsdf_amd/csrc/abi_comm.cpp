@@ -674,6 +674,8 @@ extern "C" int gsdf_hip_mesh_gatherv_start(const gsdf_mesh* m_in, gsdf_comm* c, 
   p->counts = ntri;
   (void)hipEventElapsedTime(&p->ms_counts, c->ev[0], c->ev[1]);
   auto bail = [&](int code) {
+    (void)hipStreamSynchronize(c->stream);  // transfers or a marching kernel may already be enqueued: nothing goes back to the pool under them
+    (void)hipGetLastError();
     if (p->g) gsdf_hip_mesh_destroy(p->g);
     if (p->d_recv) pool_give(c->device, (float*)p->d_recv, p->recv_cap36);
     for (hipEvent_t e : {p->ev_payload0, p->ev_payload1, p->ev_march1}) if (e) (void)hipEventDestroy(e);
@@ -721,6 +723,7 @@ extern "C" int gsdf_hip_mesh_gatherv_start(const gsdf_mesh* m_in, gsdf_comm* c, 
   for (hipEvent_t* e : {&p->ev_payload0, &p->ev_payload1, &p->ev_march1})
     if (hipEventCreate(e) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipEventCreate failed"));
   m->inflight.fetch_add(1);
+  m->refs.fetch_add(1);
   p->src = m;
   if (hipEventRecord(p->ev_payload0, c->stream) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipEventRecord failed"));
   // 3. the payload: one grouped launch of the plan
@@ -753,7 +756,7 @@ extern "C" int gsdf_hip_mesh_gatherv_start(const gsdf_mesh* m_in, gsdf_comm* c, 
       off += bytes[(size_t)r];
       t0 += ntri[(size_t)r];
     }
-    if (int rc = mesh_march_dense(p->d_recv, parts.data(), (int)parts.size(), p->g->d_tris + total_tris * 9, m->st.origin[0], m->st.origin[1], m->st.origin[2],
+    if (int rc = mesh_march_dense(p->d_recv, parts.data(), (int)parts.size(), dense_parts_at(p->g->d_tris, total_tris), m->st.origin[0], m->st.origin[1], m->st.origin[2],
                                   m->st.res, p->g->d_tris, c->num_cu, c->stream)) return bail(rc);
   }
   if (hipEventRecord(p->ev_march1, c->stream) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipEventRecord failed"));

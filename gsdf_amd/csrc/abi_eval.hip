@@ -183,11 +183,11 @@ void spec_aux(gsdf_program* p) {
       p->f_image = ok ? f[0] : nullptr;
     }
   } else {
-    if (spec_build(p, {"dc_origin_kernel<" + kw + ">", "dc_edges_kernel", "dc_normals_kernel", "normals_kernel", "flat_grid_kernel<" + kw + ">"},
+    if (spec_build(p, {"dc_origin_kernel<" + kw + ">", "dc_edges_kernel", "dc_normals_kernel", "normals_kernel", "flat_grid_kernel<" + kw + ">", "dc_block_test_kernel"},
                    &p->spec_mod2, f, &p->spec_compile_s) == GSDF_OK) {
-      const char* nm[5] = {"dc_origin_kernel", "dc_edges_kernel", "dc_normals_kernel", "normals_kernel", "flat_grid_kernel"};
-      hipFunction_t* dst[5] = {&p->f_dc_origin, &p->f_dc_edges, &p->f_dc_normals, &p->f_normals, &p->f_flat_grid};
-      for (int i = 0; i < 5; i++) {
+      const char* nm[6] = {"dc_origin_kernel", "dc_edges_kernel", "dc_normals_kernel", "normals_kernel", "flat_grid_kernel", "dc_block_test_kernel"};
+      hipFunction_t* dst[6] = {&p->f_dc_origin, &p->f_dc_edges, &p->f_dc_normals, &p->f_normals, &p->f_flat_grid, &p->f_dc_block_test};
+      for (int i = 0; i < 6; i++) {
         const bool ok = fn_scratch_bytes(f[(size_t)i]) == 0;
         spec_report("specialised", nm[i], f[(size_t)i], ok);
         *dst[i] = ok ? f[(size_t)i] : nullptr;
@@ -565,7 +565,7 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   p->rec.release(); p->hdr.release(); p->grp.release();
   p->b_q0.release(); p->b_q1.release(); p->b_ctr.release(); p->b_spec_pass.release(); p->b_rec.release(); p->b_hdr.release(); p->b_grp.release();
   if (p->stream_b) (void)hipStreamDestroy(p->stream_b);
-  p->flat_grid.release(); p->flat_bits.release(); p->flat_list.release(); p->dc_grid.release(); p->dc_dist.release(); p->dc_fv.release(); p->dc_nrm.release(); p->dc_edge.release();
+  p->flat_grid.release(); p->flat_bits.release(); p->flat_list.release(); p->dc_tile.release(); p->dc_grid.release(); p->dc_dist.release(); p->dc_fv.release(); p->dc_nrm.release(); p->dc_edge.release();
   for (auto e : p->ev) if (e) (void)hipEventDestroy(e);
   for (auto e : p->ev_b) if (e) (void)hipEventDestroy(e);
   if (p->h_ctr) (void)hipHostFree(p->h_ctr);

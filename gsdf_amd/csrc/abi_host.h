@@ -51,8 +51,11 @@ struct gsdf_mesh {
   const char* stage_name[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // A gather in flight reads this mesh's buffers on the communicator's stream (gsdf_hip_mesh_gatherv_start .. _wait): a
   // destroy in between is deferred to the gather's end instead of handing the buffers to the next mesh under it.
-  std::atomic<int> inflight{0};
-  std::atomic<bool> zombie{false};
+  // ONE count of references: the owner's (dropped by gsdf_hip_mesh_destroy) + one per gather in flight (dropped by
+  // mesh_inflight_done); whoever drops the last one frees the mesh -- destroy and a gather's end may run on different threads, and
+  // two separate flags let both of them free it.
+  std::atomic<int> refs{1};
+  std::atomic<int> inflight{0};  // gathers in flight (what gsdf_hip_mesh_march asks about); the lifetime is decided by refs
 };
 void mesh_inflight_done(gsdf_mesh* m);  // abi_mesh.hip: one gather fewer; destroys a mesh whose owner already let go
 
@@ -63,6 +66,7 @@ inline uint64_t dense_bytes(uint64_t n_recs) { return n_recs * 40ull + ((((n_rec
 // Marching cubes over them into d_tris (room for the parts' triangles: the last part's tri0 + its own), on stream s.
 // d_parts: device scratch of at least dense_parts_bytes() that stays valid until the work on s has run.
 size_t dense_parts_bytes();
+void* dense_parts_at(float* d_tris, uint64_t n_tris);  // where the table goes behind n_tris triangles (8-byte aligned)
 int mesh_march_dense(const uint8_t* d_buf, const gsdf_dense_part* parts, int nparts, void* d_parts, float ox, float oy, float oz, float res,
                      float* d_tris, int num_cu, hipStream_t s);
 

@@ -1,8 +1,8 @@
 // kernels.h -- every gfx950 kernel of the MI355X SDF backend (device code only), by phase: kernels_common.h, kernels_eval.h,
 // kernels_octree.h, kernels_flat.h, kernels_dc.h, kernels_stl.h.
 //
-// Compiled twice: ahead of time by hipcc as part of gsdf_hip.hip (evaluator = the wave-uniform interpreter of
-// interp.h), and at run time by hiprtc for one lowered program (GSDF_SPECIALIZED: interp.h then takes sdf_eval from
+// Compiled twice: ahead of time by hipcc as part of abi_eval.hip and abi_mesh.hip (evaluator = the wave-uniform interpreter of
+// interp.h), and at run time -- by the installed hipcc out of process, else hiprtc -- for one lowered program (GSDF_SPECIALIZED: interp.h then takes sdf_eval from
 // the generated gsdf_spec_gen.h, the same instruction bodies laid out straight-line with every parameter a literal).
 // Nothing here may depend on host headers.
 //

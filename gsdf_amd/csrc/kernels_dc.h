@@ -13,6 +13,46 @@ struct DCCounters {
   unsigned long long n_origin_evals;  // lattice cells whose origin was actually evaluated (the rest were outside the exact box)
 };
 
+// Stage 0 (round 5): which blocks of the origin sweep can hold a kept cube at all. The sweep's work item is a wave's block of
+// 8 x 8 x K cell origins; a cube is kept iff |d(origin)| < 2 res, and the reference evaluates every origin of its cubic lattice
+// to find that out (dual_contour.go:26-83). Here one lane per block evaluates the field in INTERVAL mode (interp.h: LIP, what the
+// octree's centre tests run) over the ball that holds the block's origins: bounds that exclude (-2 res, 2 res) by the margin prove
+// "nothing kept here" for all 64 K origins at the price of two evaluations, and the sweep skips the block -- same kept cubes, same
+// grid, a fraction of the evaluations (the kept cubes hug the surface; the sweep covers the part's whole box).
+// The same evaluation proves more than that: which operand subtrees of the program cannot matter anywhere in the block -- its BRICK
+// MASK (dev_ops.h: D_SKIP), which the sweep hands its evaluator as the octree's last centre test does for the leaf kernels.
+// flags[T * 4 + w]: bit 31 = block w of tile T must be evaluated, bits 0..15 = its brick mask. LDS: [2 * ncols floats per lane] as prune_kernel.
+__global__ void __launch_bounds__(BLOCK) dc_block_test_kernel(const uint32_t* __restrict__ code_g, int ncols, int lip_base, int K, float ox, float oy, float oz,
+                                                              float res, unsigned zlo, unsigned tx0, unsigned ty0, unsigned tz0, unsigned ntx, unsigned nty,
+                                                              unsigned ntz, uint32_t* __restrict__ flags) {
+  code_ptr code = as_code(code_g);
+  float* lds = g_smem + threadIdx.x;
+  (void)ncols;
+  const uint64_t nblk = (uint64_t)ntx * nty * ntz * 4ull;
+  const float kf = (float)(K - 1);
+  // the block's origins span 7 x 7 x (K - 1) cells: half its diagonal, a little more for the rounding of the coordinates
+  const float radius = 0.5f * res * dm::sqrtf_(98.0f + kf * kf) * 1.0001f;
+  const float keepDist = res * 2 * 1.001f;
+  for (uint64_t b0 = (uint64_t)blockIdx.x * BLOCK; b0 < nblk; b0 += (uint64_t)gridDim.x * BLOCK) {  // block-uniform trip count
+    const uint64_t b = b0 + threadIdx.x;
+    const bool valid = b < nblk;
+    const uint64_t T = (valid ? b : 0ull) >> 2;
+    const unsigned w = (unsigned)(b & 3ull);
+    const unsigned tx = tx0 + (unsigned)(T % ntx), ty = ty0 + (unsigned)((T / ntx) % nty), tz = tz0 + (unsigned)(T / ((uint64_t)ntx * nty));
+    P3 c;
+    c.x = ox + res * ((float)(tx * 8u) + 3.5f);
+    c.y = oy + res * ((float)(ty * 8u) + 3.5f);
+    c.z = oz + res * ((float)(zlo + tz * (4u * (unsigned)K) + w * (unsigned)K) + 0.5f * kf);
+    P3 pv[2] = {c, c};
+    float dv[2];
+    uint32_t fired = 0u;
+    gsdf_dev::sdf_eval<2, 0, true>(code, pv, dv, lds, BLOCK, false, radius, (uint32_t)lip_base, 0u, &fired);
+    const float pad = 4e-6f * (dm::absf(c.x) + dm::absf(c.y) + dm::absf(c.z) + radius);
+    const bool none = dv[0] >= keepDist + pad || dv[1] <= -(keepDist + pad);  // (NaN bounds: false, the block is evaluated)
+    if (valid) flags[b] = none ? 0u : (0x80000000u | (fired & 0xffffu));
+  }
+}
+
 // Stage 1 (Reset :26-83): evaluate every cube origin; keep iff |d| < 2*size (octreePrunea szMult=2, origin).
 template <int K, int W = 3>
 __global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __restrict__ code_g, int nslots, int nshift, float ox, float oy,
@@ -20,14 +60,15 @@ __global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __r
                                                              unsigned long long cube_cap, unsigned zlo, unsigned zhi,
                                                              int use_box, float bx0, float by0, float bz0, float bx1, float by1,
                                                              float bz1, unsigned tx0, unsigned ty0, unsigned tz0, unsigned ntx,
-                                                             unsigned nty, unsigned ntz, DCCounters* __restrict__ ctr) {
+                                                             unsigned nty, unsigned ntz, DCCounters* __restrict__ ctr,
+                                                             const uint32_t* __restrict__ block_keep /* dc_block_test_kernel's verdicts and brick masks, or null: every block is evaluated */) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
   unsigned* s_w = (unsigned*)(g_smem + (size_t)(nslots > 0 ? nslots : 1) * K * BLOCK);  // 4 wave totals
   unsigned long long* s_base = (unsigned long long*)(s_w + 4);
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // multi-GPU: this rank evaluates the z-slab [zlo, zhi) of the lattice (its own slab plus a one-cube halo).
-  // Work tile = a compact 8 x 8 x 4K brick of cells (a wave = one 8x8 patch at K z-levels), not a K*256-long row:
+  // Work tile = a compact 8 x 8 x 4K brick of cells (a wave = a block of 8 x 8 x K of them: an x,y column of K z per lane), not a K*256-long row:
   // spatially coherent waves are what lets D_SKIPFAR* drop the far children of a wide union for the whole wave.
   // The host hands over the range of tiles to sweep: all of the slab, or -- for trees with an exact box -- the tiles
   // that can hold a kept cube or a neighbour of one (box grown by the keep radius and two cells); cells outside that
@@ -47,7 +88,8 @@ __global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __r
       const unsigned j = (unsigned)kp * BLOCK + threadIdx.x;
       cx[kp] = tx * 8u + (j & 7u);
       cy[kp] = ty * 8u + ((j >> 3) & 7u);
-      cz[kp] = zlo + tz * (4u * K) + (j >> 6);
+      cz[kp] = zlo + tz * (4u * K) + wave * (unsigned)K + (unsigned)kp;  // (j >> 6 = 4 kp + wave until round 4: the wave's K levels four apart)
+      (void)j;
       valid[kp] = cx[kp] < n && cy[kp] < n && cz[kp] < zhi;
       p[kp] = P3{ox + res * (float)cx[kp], oy + res * (float)cy[kp], oz + res * (float)cz[kp]};  // CubeOrigin, size = res
     }
@@ -61,11 +103,15 @@ __global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __r
                                dm::maxf(bz0 - p[kp].z, p[kp].z - bz1));
       far = far && (!valid[kp] || L > maxDist * 1.001f);
     }
-    if (__all(far)) {
+    // ... and a wave whose block the interval test cleared (dc_block_test_kernel): nothing of it is within the keep radius
+    const uint32_t bflag = block_keep != nullptr ? (uint32_t)__builtin_amdgcn_readfirstlane((int)block_keep[T * 4ull + wave]) : 0x80000000u;
+    const bool cleared = (bflag >> 31) == 0u;
+    const uint32_t bmask = block_keep != nullptr ? ((bflag & 0xffffu) | GSDF_BRICK_MASK_VALID) : 0u;  // (no test, no mask: the gates are tested per wave)
+    if (cleared || __all(far)) {
 #pragma unroll
       for (int kp = 0; kp < K; kp++) d[kp] = 3.0e38f;
     } else {
-      gsdf_dev::sdf_eval<K, 2>(code, p, d, lds, BLOCK, /*brick=*/true);  // COLUMN mode: the lane's K cells are one x,y column (z = wave + 4 kp: the same in every lane of the wave); a wave = an 8 x 8 patch of columns: polygon edge culling pays (a glyph outline of 30 edges keeps 3-6)
+      gsdf_dev::sdf_eval<K, 2>(code, p, d, lds, BLOCK, /*brick=*/true, 0.0f, 0u, bmask);  // COLUMN mode: the lane's K cells are one x,y column (z = K wave + kp: the same in every lane of the wave); a wave = an 8 x 8 patch of columns: polygon edge culling pays (a glyph outline of 30 edges keeps 3-6)
 #pragma unroll
       for (int kp = 0; kp < K; kp++) {  // count the lattice cells (tiles overhang the lattice edge)
         const unsigned long long vm = __ballot(valid[kp]);

@@ -355,7 +355,7 @@ class OctreeHIP:
         self._mesh = None
         self._cursor = 0
         # share_corners: False / 0 every corner of every leaf (the reference's evaluations), True / 1 the distinct lattice points
-        # of a brick (older fused kernel), 2 the distinct z rows of a brick (same kernels, same triangles, fewer evaluations)
+        # of a brick (leaf_dense_kernel), 2 the distinct z rows of a brick (same kernels, same triangles, fewer evaluations)
         # prune: True / False, or an int bit mask of the octree levels to centre-test (bit L = Level L >= 3);
         # assume_sdf: the reference's predicate verbatim instead of the field's bounds over the cube (gsdf_hip.h)
         self._opts = MeshOpts(int(prune) | (PRUNE_ASSUME_SDF if assume_sdf else 0), shard_rank, shard_count, max_tris, stream, int(share_corners), int(host_output), int(payload), 0)

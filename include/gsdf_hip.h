@@ -177,11 +177,15 @@ typedef struct gsdf_mesh_opts {
   void* stream;       /* hipStream_t to run on; NULL = the program's stream */
   int share_corners;  /* 0 (default): every leaf evaluates its own 8 corners like the reference (8 evals/leaf);
                          1: each bitwise-distinct lattice point of a 4x4x4-leaf brick is evaluated once (identical
-                         triangles, ~1.5x fewer evaluations; an older, fused kernel: slower than the default today);
+                         triangles, 1.2-2.2x fewer evaluations; leaf_dense_kernel in the default two-kernel leaf phase -- it
+                         gives up the column sharing of the default, so it pays where the field costs more per point than per
+                         (x, y) column: threads, knurls, transformed parts);
                          2: the bitwise-distinct z rows of a brick once each (a brick's eight rows of corners are five to eight
                          distinct planes: row 2k-1 = (O + res (i-1)) + res and row 2k = O + res i are the same float on most planes)
                          -- the default's kernels, a quarter fewer evaluations, identical distances, records and triangles.
-                         stats.evals then counts the evaluations performed, not the reference's 8 per leaf;
+                         stats.evals then counts the evaluations performed, not the reference's 8 per leaf: for 2, distinct rows
+                         x 64 lanes (a second pass rounds the rows it executes up to its width: lane slots that repeat a row
+                         are not counted; 1 counts every lane slot of its passes);
                          3: 1 or 2, chosen by how much of the tree's work depends on x and y alone (threads, knurls, transformed
                          parts: 1; mostly axisymmetric parts: 2). */
   int host_output;    /* 1: the triangle buffer is pinned, device-mapped HOST memory and the mesher writes it across PCIe
