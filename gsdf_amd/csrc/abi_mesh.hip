@@ -738,6 +738,11 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
         else hipLaunchKernelGGL(dc_block_test_kernel, dim3(gt), dim3(BLOCK), lds_t, s, p->d_code, cols, p->prog.nslots, lk, ox, oy, oz, res, zlo, t0[0], t0[1], t0[2], tn[0], tn[1],
                                 tn[2], (uint32_t*)p->dc_tile.p);
         HIP_TRYM(hipGetLastError());
+        // ... and the grid of the tile range cleared to "no cube": the sweep steps over the tiles the test cleared
+        const uint64_t crows = (uint64_t)tn[1] * 8 * (uint64_t)tn[2] * tzk;
+        hipLaunchKernelGGL(dc_grid_clear_kernel, dim3(grid_for(crows * 64, p->num_cu, 16)), dim3(BLOCK), 0, s, (int*)grid.p, nshift, t0[0] * 8u, tn[0] * 8u, t0[1] * 8u, tn[1] * 8u,
+                           zlo + t0[2] * tzk, tn[2] * tzk);
+        HIP_TRYM(hipGetLastError());
         d_keep = (const uint32_t*)p->dc_tile.p;
       } else {
         (void)hipGetLastError();
@@ -801,6 +806,7 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
   }
   p->last_dc_cubes = hc.n_cubes;
   m->st.n_tris = 2 * hc.n_tris;  // quads -> 2 triangles
+  for (int k = 0; k < 64; k++) hc.n_origin_evals += hc.n_origin_part[k * 8];
   m->st.evals = hc.n_origin_evals + 4 * hc.n_cubes + 6 * hc.n_edges;
   m->st.evals_prune = hc.n_origin_evals;  // of the nslab lattice cells; the rest lay outside the exact box by > 2 res
   m->st.evals_leaf = 4 * hc.n_cubes + 6 * hc.n_edges;

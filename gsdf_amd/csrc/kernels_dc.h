@@ -10,8 +10,28 @@
 // =================================================================================================
 struct DCCounters {
   unsigned long long n_cubes, n_edges, n_tris, q_overflow, t_overflow;
-  unsigned long long n_origin_evals;  // lattice cells whose origin was actually evaluated (the rest were outside the exact box)
+  unsigned long long n_origin_evals;  // lattice cells whose origin was actually evaluated (the rest were outside the exact box) -- the host's total of:
+  // the same count in 64 parts, one cache line each: every workgroup of the origin sweep adds its count once, and 8 192 adds to ONE
+  // word were 0.3 of the sweep's 0.43 ms (a word takes ~88 atomics per microsecond; round 5, rocprofv3: dc_origin_kernel 425 us for
+  // 8.7 M evaluations)
+  unsigned long long n_origin_part[64 * 8];
 };
+
+// The index grid of the sweep's tile range <- -1 ("no cube here"), row by row (a row of the range is contiguous in x): the origin
+// sweep then writes only the tiles it evaluates and steps over the ones the block test cleared without touching their cells.
+__global__ void __launch_bounds__(BLOCK) dc_grid_clear_kernel(int* __restrict__ grid, int nshift, unsigned x0, unsigned nx, unsigned y0, unsigned ny, unsigned z0,
+                                                              unsigned nz) {
+  const uint64_t rows = (uint64_t)ny * nz;
+  const unsigned n = 1u << nshift;
+  if (x0 >= n) return;
+  if (x0 + nx > n) nx = n - x0;
+  for (uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (uint64_t)gridDim.x * 4) {  // a wave per row
+    const unsigned y = y0 + (unsigned)(r % ny), z = z0 + (unsigned)(r / ny);
+    if (y >= n || z >= n) continue;
+    int* row = grid + ((uint64_t)x0 + ((uint64_t)y << nshift) + ((uint64_t)z << (2 * nshift)));
+    for (unsigned x = threadIdx.x & 63u; x < nx; x += 64u) row[x] = -1;
+  }
+}
 
 // Stage 0 (round 5): which blocks of the origin sweep can hold a kept cube at all. The sweep's work item is a wave's block of
 // 8 x 8 x K cell origins; a cube is kept iff |d(origin)| < 2 res, and the reference evaluates every origin of its cubic lattice
@@ -78,6 +98,11 @@ __global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __r
   const float maxDist = res * 2;
   unsigned long long my_evals = 0;
   for (uint64_t T = blockIdx.x; T < ntiles; T += gridDim.x) {  // block-uniform trip count
+    // a tile whose four blocks the interval test cleared: nothing kept, nothing to write (the grid of the range was cleared to -1)
+    if (block_keep != nullptr) {
+      const uint4 f = *(const uint4*)(block_keep + T * 4ull);  // (block-uniform: a scalar load)
+      if (((f.x | f.y | f.z | f.w) >> 31) == 0u) continue;
+    }
     const unsigned tx = tx0 + (unsigned)(T % ntx), ty = ty0 + (unsigned)((T / ntx) % nty), tz = tz0 + (unsigned)(T / ((uint64_t)ntx * nty));
     P3 p[K];
     float d[K];
@@ -166,7 +191,15 @@ __global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __r
       }
     }
   }
-  if (lane == 0 && my_evals) atomicAdd(&ctr->n_origin_evals, my_evals);
+  {  // statistics: one add per workgroup, spread over 64 words on 64 cache lines
+    __syncthreads();
+    unsigned long long* s_ev = (unsigned long long*)s_base;  // (the append's word is idle now)
+    if (threadIdx.x == 0) *s_ev = 0ull;
+    __syncthreads();
+    if (lane == 0 && my_evals) atomicAdd(s_ev, my_evals);
+    __syncthreads();
+    if (threadIdx.x == 0 && *s_ev) atomicAdd(&ctr->n_origin_part[(blockIdx.x & 63u) * 8u], *s_ev);
+  }
 }
 
 // Stage 2 (RenderAll :85-108): origin, +x, +y, +z distances of every kept cube (one 4-point pass per

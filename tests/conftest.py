@@ -23,6 +23,20 @@ def _native_libs():
         subprocess.check_call([sys.executable, os.path.join(ROOT, "__graft_entry__.py")])
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _code_object_cache(tmp_path_factory):
+    """One code-object cache for the whole run (GSDF_HIP_CACHE_DIR, specialize.cpp): the example scenes are specialised by many
+    tests, and each build is an out-of-process compiler run of seconds -- after the first, a file read. Tests of the cache itself set
+    their own directory."""
+    if os.environ.get("GSDF_HIP_CACHE_DIR"):
+        yield
+        return
+    d = tmp_path_factory.mktemp("gsdf_code_objects")
+    os.environ["GSDF_HIP_CACHE_DIR"] = str(d)
+    yield
+    os.environ.pop("GSDF_HIP_CACHE_DIR", None)
+
+
 @pytest.fixture(scope="session")
 def gpu():
     # Tests that hand device buffers to torch (the RCCL gather) need torch's bundled HIP runtime initialised BEFORE the

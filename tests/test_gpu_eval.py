@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from par import pmap
+
 import corpus
 from scaffold.builder import Builder
 from oracle.oracle import OracleSDF
@@ -222,6 +224,7 @@ def test_circular_array_points_on_sector_boundaries(gpu):
     waves take both paths and the hand-over is exact; interpreter and specialised kernels, 3-D and 2-D arrays."""
     b = Builder()
     rng = np.random.default_rng(5)
+    cases = []
     for div in (3, 4, 7, 24, 45):
         n = max(1, div - 1)
         sh3 = b.CircularArray(b.Translate(b.NewBox(0.6, 0.4, 0.5, 0.05), 1.5, 0, 0), n, div)
@@ -240,12 +243,16 @@ def test_circular_array_points_on_sector_boundaries(gpu):
         xy = np.concatenate([xy, far])
         z = (rng.standard_normal(len(xy)) * 0.4).astype(np.float32)
         for shape, pos in ((sh3, np.concatenate([xy, z[:, None]], 1)), (sh2, xy)):
-            pos = np.ascontiguousarray(pos, np.float32)
-            ref = OracleSDF(shape.tree()).Evaluate(pos)
-            sdf = gpu.SDFHIP(shape)
-            assert _mismatch(sdf.Evaluate(pos), ref) == 0, (div, pos.shape)
-            sdf.specialize()
-            assert _mismatch(sdf.Evaluate(pos), ref) == 0, (div, pos.shape, "specialised")
+            cases.append((div, shape, np.ascontiguousarray(pos, np.float32)))
+
+    def check(case):                                          # (ten builds: side by side, tests/par.py)
+        div, shape, pos = case
+        ref = OracleSDF(shape.tree()).Evaluate(pos)
+        sdf = gpu.SDFHIP(shape)
+        assert _mismatch(sdf.Evaluate(pos), ref) == 0, (div, pos.shape)
+        sdf.specialize()
+        assert _mismatch(sdf.Evaluate(pos), ref) == 0, (div, pos.shape, "specialised")
+    pmap(check, cases, workers=10)
 
 
 def test_sqrt_unit_range_exhaustive(gpu):

@@ -5,6 +5,7 @@ import pytest
 
 import fuzz_trees
 from oracle.oracle import OracleSDF
+from par import pmap
 
 pytestmark = pytest.mark.gpu
 
@@ -32,11 +33,12 @@ def test_random_trees_distances_and_meshes(gpu, seed):
     _, shapes = fuzz_trees.random_shapes(seed, 14, depth=4)
     assert len(shapes) == 14
     rng = np.random.default_rng(100 + seed)
-    meshed = 0
-    for k, sh in enumerate(shapes):
+    points = [_points(sh, rng) for sh in shapes]              # (drawn in tree order, whatever order the trees are checked in)
+
+    def check(k):                                             # one tree: its builds are compiler runs of seconds -- side by side (tests/par.py)
+        sh, pos, meshed = shapes[k], points[k], 0
         ref = OracleSDF(sh.tree())
         sdf = gpu.SDF3HIP(sh)
-        pos = _points(sh, rng)
         dref = ref.Evaluate(pos)
         assert not np.isnan(dref).any(), (seed, k)   # trees the constructors accept, finite positions: no NaN, so _mismatch masks nothing (the NaN relation: tests/test_gpu_nan.py)
         assert _mismatch(sdf.Evaluate(pos), dref) == 0, (seed, k, "interpreter")
@@ -64,6 +66,8 @@ def test_random_trees_distances_and_meshes(gpu, seed):
             assert fl.Evaluations() == mf.evals and fl.n_tris() == mf.n_tris, (seed, k, "flat")
             if mf.n_tris:
                 assert (_sorted(fl.RenderAll()).view(np.uint32) == _sorted(mf.tris).view(np.uint32)).all(), (seed, k, "flat")
+        return meshed
+    meshed = sum(pmap(check, range(len(shapes)), workers=7))
     assert meshed >= 8
 
 
@@ -71,25 +75,32 @@ def test_random_2d_trees(gpu):
     _, shapes = fuzz_trees.random_shapes2d(7, 24, depth=3)
     assert len(shapes) == 24
     rng = np.random.default_rng(70)
-    for k, sh in enumerate(shapes):
+    points = []
+    for sh in shapes:
         bb = np.asarray(sh.Bounds(), np.float32)
         lo, hi = bb[[0, 1]], bb[[3, 4]]
         c, h = (lo + hi) / 2, (hi - lo) / 2 * np.float32(1.2)
         pos = (c + (rng.random((5000, 2), np.float32) * 2 - 1) * h).astype(np.float32)
-        pos = np.concatenate([pos, np.float32(0.125) * rng.integers(-12, 13, (1000, 2)).astype(np.float32)])
+        points.append(np.concatenate([pos, np.float32(0.125) * rng.integers(-12, 13, (1000, 2)).astype(np.float32)]))
+
+    def check(k):
+        sh, pos = shapes[k], points[k]
         dref = OracleSDF(sh.tree()).Evaluate(pos)
         sdf = gpu.SDF2HIP(sh)
         assert _mismatch(sdf.Evaluate(pos), dref) == 0, (k, "interpreter")
         if k % 4 == 0:
             assert _mismatch(sdf.specialize().Evaluate(pos), dref) == 0, (k, "specialised")
+    pmap(check, range(len(shapes)), workers=6)
 
 
 def test_random_trees_dual_contouring_and_normals(gpu):
     """Dual contouring (all five stages incl. the fp64 QR) and central-difference normals of random trees."""
     _, shapes = fuzz_trees.random_shapes(11, 8, depth=3)
     rng = np.random.default_rng(110)
-    done = 0
-    for k, sh in enumerate(shapes):
+    points = [_points(sh, rng, 2000) for sh in shapes]
+
+    def check(k):
+        sh = shapes[k]
         ref = OracleSDF(sh.tree())
         sdf = gpu.SDF3HIP(sh)
         if k % 2 == 0:
@@ -98,14 +109,17 @@ def test_random_trees_dual_contouring_and_normals(gpu):
         try:
             m = ref.render_dualcontour(res, False)
         except Exception:
-            continue                                  # lattice too large / degenerate for the oracle's renderer
+            return 0                                  # lattice too large / degenerate for the oracle's renderer
+        done = 0
         a = gpu.DualContourHIP(sdf, res).RenderAll()
         assert a.shape[0] == m.n_tris, (k, a.shape[0], m.n_tris)
         if m.n_tris:
             assert (_sorted(a).view(np.uint32) == _sorted(m.tris).view(np.uint32)).all(), k
-            done += 1
-        pos = _points(sh, rng, 2000)
+            done = 1
+        pos = points[k]
         assert _mismatch(sdf.normals(pos, 1e-3), ref.normals_central_diff(pos, 1e-3)) == 0, k
+        return done
+    done = sum(pmap(check, range(len(shapes)), workers=4))
     assert done >= 4
 
 

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import corpus
+from par import pmap
 from scaffold.builder import Builder
 from oracle.oracle import OracleSDF
 
@@ -29,13 +30,17 @@ def _sorted(t):
 def test_corpus_specialised_bit_exact(gpu, which):
     """All 53 node types: specialised Evaluate == oracle == committed golden distances, bit for bit."""
     gold = np.load(os.path.join(GOLDDIR, "corpus_distances.npz"))
+    gold = {k: gold[k] for k in gold.files}
     _, shapes = (corpus.shapes3d if which == "3d" else corpus.shapes2d)()
-    for name, sh in shapes:
+
+    def check(item):                                          # (one build per shape: side by side, tests/par.py)
+        name, sh = item
         sdf = gpu.SDFHIP(sh).specialize()
         assert sdf.info()["specialized"]
         pos = corpus.sample_points(sh)
         assert _mismatch(sdf.Evaluate(pos), OracleSDF(sh.tree()).Evaluate(pos)) == 0, name
         assert _mismatch(sdf.Evaluate(gold["pos_" + name]), gold["dist_" + name]) == 0, name
+    pmap(check, shapes, workers=12)
 
 
 @pytest.mark.parametrize("scene,key", [("npt-flange", "npt_flange_resdiv400"), ("bolt", "bolt_resdiv150"),
