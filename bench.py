@@ -250,6 +250,34 @@ def pmc_summary(workload, code=None):
     return {}
 
 
+def pmc_dc_stages(workload, code=None):
+    """Per-stage counters of the dual contouring kernels from the newest committed PMC summary of THIS workload and THIS code
+    (tools/gpu_dc_prof.sh): {stage: {...}} or {}."""
+    import glob
+    import re
+    key = re.match(r"examples/(\S+) resdiv (\d+)", workload or "")
+    if not key:
+        return {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        k2 = re.match(r"examples/(\S+) resdiv (\d+)", j.get("workload", ""))
+        if not (k2 and k2.groups() == key.groups() and "dc_origin_kernel" in j and "dual contouring" in j.get("workload", "")):
+            continue
+        if code is not None and j.get("code") != code:
+            continue
+        out = {}
+        for st in ("dc_block_test", "dc_origin", "dc_edges", "dc_normals", "dc_place", "dc_quads"):
+            d = j.get(st + "_kernel")
+            if d:
+                out[st] = {k: d[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "hbm_traffic_gb_per_launch", "wave_wait_any_frac", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE") if k in d}
+                out[st]["counters_from"] = os.path.basename(f)
+        return out
+    return {}
+
+
 def pmc_traffic_gb(workload, code=None):
     """HBM bytes per leaf_kernel launch: 2*FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE, KB -> GB."""
     return pmc_summary(workload, code).get("hbm_traffic_gb_per_launch")
@@ -662,6 +690,12 @@ def main():
             "stages": dc_stages,
             "phase_ms_rank0": {"prune": st.ms_prune, "leaf": st.ms_leaf, "eval_kernel": st.ms_march, "march_kernel": st.ms_emit, "total_device": st.ms_total},
         }
+        if dc and dc_stages:  # counters of the same kernels, if a summary under profiles/ carries this workload and this code key
+            for k, v in pmc_dc_stages(workload, code).items():
+                if k in dc_stages:
+                    dc_stages[k]["pmc"] = v
+                else:
+                    dc_stages[k] = {"pmc": v}
         if shared_device:
             out["config"]["devices"] = (f"{world} ranks on {ndev} GPU(s): ranks share a device over the library's inter-process transport (GSDF_HIP_COMM=ipc) -- "
                                         "the N > 1 code path end to end, not a scaling measurement")

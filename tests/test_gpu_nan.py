@@ -21,6 +21,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from par import pmap
+
 import corpus
 from gsdf_amd._ctypes_common import GsdfNode, GsdfTree, OP
 from oracle.oracle import OracleSDF
@@ -115,7 +117,7 @@ def test_non_finite_positions_differ_only_where_the_reference_is_not_finite(gpu)
     rng = np.random.default_rng(43)
     b3, s3 = corpus.shapes3d()
     shapes = list(s3) + [(n, b3.Scene(n)) for n in ("npt-flange", "bolt", "knurled-cylinder")]
-    total, checked, failures = 0, 0, []
+    cases = []
     for k, (name, sh) in enumerate(shapes):
         t = sh.tree()
         ops, todo = set(), [t.root]
@@ -127,6 +129,11 @@ def test_non_finite_positions_differ_only_where_the_reference_is_not_finite(gpu)
         bad = rng.integers(0, len(pos), 600)
         vals = np.float32([np.nan, np.inf, -np.inf, 0.0, -0.0])   # (not 3e38: finite, but squares overflow differently along the two paths)
         pos[bad, rng.integers(0, 3, 600)] = vals[rng.integers(0, len(vals), 600)]
+        cases.append((k, name, t, ops, pos))
+
+    def check(case):                                        # (every fourth tree is also built: side by side, tests/par.py)
+        k, name, t, ops, pos = case
+        failures = []
         dref = OracleSDF(t).Evaluate(pos)
         sdf = gpu.SDFHIP(t)
         builds = [("interpreter", sdf.Evaluate(pos))]
@@ -138,9 +145,10 @@ def test_non_finite_positions_differ_only_where_the_reference_is_not_finite(gpu)
             if differ.any() and not (ops & SIGN_OF_NAN):
                 i = int(np.flatnonzero(differ)[0])
                 failures.append((name, what, int(differ.sum()), pos[i].tolist(), float(dev[i]), float(dref[i])))
-        if not (ops & SIGN_OF_NAN):
-            checked += 1
-        total += int((~np.isfinite(dref)).sum())
+        return failures, (0 if (ops & SIGN_OF_NAN) else 1), int((~np.isfinite(dref)).sum())
+    res = pmap(check, cases, workers=8)
+    failures = [f for r in res for f in r[0]]
+    checked, total = sum(r[1] for r in res), sum(r[2] for r in res)
     assert not failures, failures
     assert total > 1000 and checked >= 25
 

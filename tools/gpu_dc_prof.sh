@@ -16,7 +16,8 @@ for sc in "text-plate 800" "npt-flange 800"; do set -- $sc
     timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_BRANCH SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_mix -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/pmc_mix.log 2>&1
     timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1
     timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/pmc_write.log 2>&1 )
-  python tools/pmc_summarize.py $OUT --command "python bench.py $ARGS" --workload "$(python -c "import json;print(json.load(open('$OUT/bench.json'))['config']['workload'])")" > $OUT/pmc_summary.json
+  python tools/pmc_summarize.py $OUT --command "python bench.py $ARGS" --workload "$(python -c "import json;print(json.load(open('$OUT/bench.json'))['config']['workload'])")" \
+    --code "$(python -c "import json;print(json.load(open('$OUT/bench.json'))['config'].get('code') or '')")" > $OUT/pmc_summary.json
   cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
   find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
   head -12 $OUT/kernel_stats.csv | cut -c1-160

@@ -20,7 +20,7 @@ ap.add_argument("--clock-ghz", type=float, default=2.1, help="shader clock under
 ap.add_argument("--command", default="python bench.py --steps 5 --warmup 1 --no-cpu-baseline")
 a = ap.parse_args()
 
-KERNELS = ("leaf_eval_kernel", "leaf_dense_kernel", "march_records_kernel", "march_dense_kernel", "leaf_kernel", "prune_kernel", "prune_spec_kernel", "prune_resolve_kernel", "dc_origin_kernel", "dc_edges_kernel", "dc_normals_kernel", "dc_place_kernel", "dc_quads_kernel", "stl_kernel", "leaf_brick_kernel", "eval_kernel", "flat_grid_kernel", "flat_march_kernel", "flat_cut_scan_kernel", "flat_march_list_kernel")
+KERNELS = ("leaf_eval_kernel", "leaf_dense_kernel", "march_records_kernel", "march_dense_kernel", "leaf_kernel", "prune_kernel", "prune_spec_kernel", "prune_resolve_kernel", "dc_block_test_kernel", "dc_grid_clear_kernel", "dc_origin_kernel", "dc_edges_kernel", "dc_normals_kernel", "dc_place_kernel", "dc_quads_kernel", "stl_kernel", "leaf_brick_kernel", "eval_kernel", "flat_grid_kernel", "flat_march_kernel", "flat_cut_scan_kernel", "flat_march_list_kernel")
 acc = {k: defaultdict(lambda: [0.0, 0]) for k in KERNELS}
 for f in glob.glob(os.path.join(a.dir, "**", "*counter_collection.csv"), recursive=True):
     per = defaultdict(float)
