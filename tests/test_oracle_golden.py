@@ -267,3 +267,33 @@ def test_block_cached_wrapper_semantics():
     import pytest
     with pytest.raises(ValueError):
         c.Reset(sdf, 0.0, 1.0, 1.0)
+
+
+def test_reference_octree_schedule_near_pin():
+    """The evaluation counts the reference prints for its OCTREE renderer (README.md:116: npt-flange at resdiv 400, 46,148,745
+    evaluations, 95.7 % of the leaf cubes pruned; README.md:152: fibonacci-showerhead at resdiv 350, 14,646,431 / 89.08 %) come
+    from its schedule, not from the field: Octree.Reset sizes a prune buffer of 8 + 64 + 512 + 4096 = 4680 cubes
+    (octreerenderer.go:94-105), the first ReadTriangles call decomposes the top cube breadth-first into it (ms3.Octree.DecomposeBFS,
+    :140) -- four levels down: 4096 cubes of Level top - 4 -- and prune() centre-tests exactly that frontier (:180-202, :270-273);
+    what survives goes down to the leaves depth-first. That much of the schedule is restated here through the oracle's level
+    mask (test Level top - 4 only, the reference's predicate verbatim):
+        npt-flange   4096 tests + 8 x 32768 leaves x 176 surviving Level-6 cubes = 46,141,440 (README - 7,305, 0.016 %), 95.703 % pruned
+        showerhead   4096 tests + 8 x 4096 leaves x 448 surviving Level-5 cubes  = 14,684,160 (README + 37,729, 0.26 %),  89.062 % pruned
+    The printed percentages are reproduced to their last digit but one. The residue is the one external semantic this tree cannot
+    pin: when the prune buffer runs empty, the next ReadTriangles call decomposes the first Level >= 3 cube still on the depth-first
+    stack (octreerenderer.go:136-146) and tests a deeper frontier -- which cube that is depends on the order in which
+    ms3.Octree.SafeSpread / SafeMove (soypat/geometry, not vendored) hand the survivors back and on the caller's triangle buffer."""
+    b = Builder()
+    ASSUME = 1 << 30
+    s = b.Scene("npt-flange")
+    res = np.float32(float(s.Diagonal()) / 400)
+    m = OracleSDF(s.tree()).render_octree(res, 4096, (1 << 6) | ASSUME)
+    assert m.levels == 10 and m.n_tris == 423852
+    assert m.evals == 46141440 == 4096 + 8 * 32768 * 176
+    assert abs(m.evals - 46148745) == 7305 and f"{100.0 * m.pruned / 8 ** (m.levels - 1):.1f}" == "95.7"
+    s = b.Scene("fibonacci-showerhead")
+    res = np.float32(float(s.Diagonal()) / 350)
+    m = OracleSDF(s.tree()).render_octree(res, 4096, (1 << 5) | ASSUME)
+    assert m.levels == 9 and m.n_tris == 309872
+    assert m.evals == 14684160 == 4096 + 8 * 4096 * 448
+    assert abs(m.evals - 14646431) == 37729 and abs(100.0 * m.pruned / 8 ** (m.levels - 1) - 89.08) < 0.02
