@@ -684,12 +684,41 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
   uint64_t ccap = p->last_dc_cubes ? p->last_dc_cubes + p->last_dc_cubes / 8 + 4096 : (uint64_t)12 << (2 * nshift);
   if (ccap < (1u << 20)) ccap = 1u << 20;
   DCCounters hc{};
+  uint64_t n_cubes = 0, n_edges = 0, n_cube_runs = 0, n_edge_runs = 0, last_cap = 0;
   const float h = (chiseled ? (float)1e-4 : (float)2e-8) * 0.5f;  // NormalsCentralDiff: step *= 0.5
   const float sqrtLambda = chiseled ? (float)(std::sqrt(1e-5) * 1e-4) : (float)std::sqrt(1e-5);
+  spec_aux(p);
+  const int ub = p->prog.has_exact_bb ? 1 : 0;
+  const float* eb = p->prog.exact_bb;
+  // tile range of the origin sweep (8 x 8 x 4K cells per tile, z tiles counted from zlo)
+  const unsigned ncell1 = 1u << nshift, tzk = 4u * (unsigned)lk;
+  unsigned t0[3] = {0, 0, 0}, tn[3] = {(ncell1 + 7u) >> 3, (ncell1 + 7u) >> 3, (zhi - zlo + tzk - 1u) / tzk};
+  if (ub) {
+    const float org[3] = {ox, oy, oz}, grow = res * 2 * 1.001f + 2 * res;
+    const unsigned lo_lim[3] = {0, 0, zlo}, hi_lim[3] = {ncell1, ncell1, zhi}, tsz[3] = {8, 8, tzk};
+    for (int a = 0; a < 3; a++) {
+      double c0 = std::floor(((double)eb[a] - grow - org[a]) / res) - 1, c1 = std::ceil(((double)eb[a + 3] + grow - org[a]) / res) + 2;
+      if (c0 < lo_lim[a]) c0 = lo_lim[a];
+      if (c1 > hi_lim[a]) c1 = hi_lim[a];
+      if (c1 <= c0) { c0 = lo_lim[a]; c1 = lo_lim[a]; }  // nothing of the box in this slab
+      const unsigned first = ((unsigned)c0 - lo_lim[a]) / tsz[a], last = ((unsigned)c1 - lo_lim[a] + tsz[a] - 1) / tsz[a];
+      t0[a] = first;
+      tn[a] = last > first ? last - first : 0;
+    }
+  }
+  const uint64_t ntiles = (uint64_t)tn[0] * tn[1] * tn[2];  // of the origin sweep
   for (int attempt = 0;; attempt++) {
-    if (ccap > nslab) ccap = nslab;
+    // the lists are kept in DC_PARTS parts (kernels_dc.h), an equal share of the arrays each; a part cannot hold more than the cells
+    // of the tiles that go to it
+    const uint64_t cmax = DC_PARTS * ((ntiles + DC_PARTS - 1) / DC_PARTS) * (uint64_t)(256 * lk);
+    if (ccap > cmax) ccap = cmax;
+    ccap = (ccap + DC_PARTS - 1) / DC_PARTS * DC_PARTS;
+    if (ccap < DC_PARTS) ccap = DC_PARTS;
     const uint64_t ecap = 3 * ccap, tcap = 2 * ecap;
-    HIP_TRYM(p->q0.ensure(ccap * sizeof(Cube)));
+    // run descriptors (kernels_dc.h: DC_DESC): the origin sweep's follow the cubes in q0, the edge stage's have an arena of their own
+    const uint64_t crun_cap = DC_PARTS * dc_cube_run_seg(ntiles), erun_cap = DC_PARTS * dc_edge_run_seg(ccap, ntiles);
+    HIP_TRYM(p->q0.ensure((ccap + crun_cap) * sizeof(Cube)));
+    HIP_TRYM(p->dc_erun.ensure(erun_cap * sizeof(unsigned long long)));
     HIP_TRYM(d2.ensure(ccap * sizeof(float4)));
     HIP_TRYM(f2.ensure(ccap * 12));
     HIP_TRYM(n2.ensure(ccap * 36));
@@ -702,27 +731,10 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(DCCounters), s));
     if (shard_count > 1) HIP_TRYM(hipMemsetAsync(grid.p, 0xff, ncell * sizeof(int), s));  // cells outside the slab read as empty
     HIP_TRYM(hipEventRecord(p->ev[0], s));
-    const unsigned g1 = grid_for((nslab + lk - 1) / lk, p->num_cu, 32);
+    static const int origin_grid = [] { const char* e = getenv("GSDF_HIP_DC_ORIGIN_GRID"); return e ? atoi(e) : 0; }();  // developer knob: workgroups of the origin sweep (1 = tiles strictly in order)
+    unsigned g1 = origin_grid > 0 ? (unsigned)origin_grid : grid_for((nslab + lk - 1) / lk, p->num_cu, 32);
+    g1 = (g1 + DC_PARTS - 1) / DC_PARTS * DC_PARTS;  // tile T goes to workgroup T % g1, hence to part T % DC_PARTS: what bounds a part's run descriptors (dc_cube_run_seg)
 #define LAUNCH_O(KK, WW) hipLaunchKernelGGL((dc_origin_kernel<KK, WW>), dim3(g1), dim3(BLOCK), p->lds_bytes(KK) + 32, s, p->d_code, p->prog.nslots, nshift, ox, oy, oz, res, (int*)grid.p, (Cube*)p->q0.p, (unsigned long long)ccap, zlo, zhi, ub, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], t0[0], t0[1], t0[2], tn[0], tn[1], tn[2], d_ctr, d_keep)
-    spec_aux(p);
-    const int ub = p->prog.has_exact_bb ? 1 : 0;
-    const float* eb = p->prog.exact_bb;
-    // tile range of the origin sweep (8 x 8 x 4K cells per tile, z tiles counted from zlo)
-    const unsigned ncell1 = 1u << nshift, tzk = 4u * (unsigned)lk;
-    unsigned t0[3] = {0, 0, 0}, tn[3] = {(ncell1 + 7u) >> 3, (ncell1 + 7u) >> 3, (zhi - zlo + tzk - 1u) / tzk};
-    if (ub) {
-      const float org[3] = {ox, oy, oz}, grow = res * 2 * 1.001f + 2 * res;
-      const unsigned lo_lim[3] = {0, 0, zlo}, hi_lim[3] = {ncell1, ncell1, zhi}, tsz[3] = {8, 8, tzk};
-      for (int a = 0; a < 3; a++) {
-        double c0 = std::floor(((double)eb[a] - grow - org[a]) / res) - 1, c1 = std::ceil(((double)eb[a + 3] + grow - org[a]) / res) + 2;
-        if (c0 < lo_lim[a]) c0 = lo_lim[a];
-        if (c1 > hi_lim[a]) c1 = hi_lim[a];
-        if (c1 <= c0) { c0 = lo_lim[a]; c1 = lo_lim[a]; }  // nothing of the box in this slab
-        const unsigned first = ((unsigned)c0 - lo_lim[a]) / tsz[a], last = ((unsigned)c1 - lo_lim[a] + tsz[a] - 1) / tsz[a];
-        t0[a] = first;
-        tn[a] = last > first ? last - first : 0;
-      }
-    }
     // Stage 0: the interval test of the sweep's blocks (kernels_dc.h: dc_block_test_kernel), one lane per block of 8 x 8 x K origins.
     // GSDF_HIP_NO_DC_BLOCK_TEST=1: every block is evaluated (developer knob: A/B timing, cross-check in the tests).
     static const bool block_test_off = [] { const char* e = getenv("GSDF_HIP_NO_DC_BLOCK_TEST"); return e && atoi(e) != 0; }();
@@ -758,17 +770,17 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     HIP_TRYM(hipEventRecord(p->ev_b[0], s));  // origin sweep done
     if (p->lds_bytes(4) > 150 * 1024) return bail(fail(GSDF_ERR_BAD_TREE, "tree needs too much LDS scratch for the dual contouring edge pass"));
     if (p->f_dc_edges) HIP_TRYM(launch_fn(p->f_dc_edges, grid_for(ccap, p->num_cu, 8), BLOCK, p->lds_bytes(4), s, (const uint32_t*)p->d_code, (const Cube*)p->q0.p,
-                       (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, d_ctr));
+                       (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, (unsigned long long*)p->dc_erun.p, (unsigned long long)ntiles, d_ctr));
     else
     hipLaunchKernelGGL(dc_edges_kernel, dim3(grid_for(ccap, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(4), s, p->d_code, (const Cube*)p->q0.p,
-                       (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, d_ctr);
+                       (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, (unsigned long long*)p->dc_erun.p, (unsigned long long)ntiles, d_ctr);
     HIP_TRYM(hipGetLastError());
     HIP_TRYM(hipEventRecord(p->ev_b[1], s));  // edges done
     if (p->f_dc_normals) HIP_TRYM(launch_fn(p->f_dc_normals, grid_for(ecap, p->num_cu, 8), BLOCK, p->lds_bytes(2), s, (const uint32_t*)p->d_code, (const Cube*)p->q0.p,
-                       (const float4*)d2.p, (const unsigned*)e2.p, (unsigned long long)ecap, ox, oy, oz, res, h, (float*)n2.p, d_ctr));
+                       (const float4*)d2.p, (const unsigned*)e2.p, (const unsigned long long*)p->dc_erun.p, (unsigned long long)ccap, (unsigned long long)ntiles, ox, oy, oz, res, h, (float*)n2.p, d_ctr));
     else
     hipLaunchKernelGGL(dc_normals_kernel, dim3(grid_for(ecap, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(2), s, p->d_code, (const Cube*)p->q0.p,
-                       (const float4*)d2.p, (const unsigned*)e2.p, (unsigned long long)ecap, ox, oy, oz, res, h, (float*)n2.p, d_ctr);
+                       (const float4*)d2.p, (const unsigned*)e2.p, (const unsigned long long*)p->dc_erun.p, (unsigned long long)ccap, (unsigned long long)ntiles, ox, oy, oz, res, h, (float*)n2.p, d_ctr);
     HIP_TRYM(hipGetLastError());
     HIP_TRYM(hipEventRecord(p->ev_b[2], s));  // normals done
     hipLaunchKernelGGL(dc_place_kernel, dim3(grid_for(ccap * 4, p->num_cu, 16)), dim3(DC_BLOCK), 0, s, (const Cube*)p->q0.p,
@@ -783,12 +795,21 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     HIP_TRYM(hipEventRecord(p->ev[1], s));
     HIP_TRYM(hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, s));
     HIP_TRYM(hipStreamSynchronize(s));
-    if (hc.q_overflow || hc.t_overflow) {
-      if (attempt >= 8 || ccap >= nslab) return bail(fail(GSDF_ERR_CAPACITY, "dual contouring queue capacity exceeded"));
-      // the origin pass keeps counting past the capacity, so the exact number of kept cubes is known
-      ccap = hc.n_cubes > ccap ? hc.n_cubes + hc.n_cubes / 16 + 4096 : ccap * 2;
+    n_cubes = n_edges = n_cube_runs = n_edge_runs = 0;
+    uint64_t max_part = 0;  // the fullest part of the cubes' list: what the capacity has to hold DC_PARTS times
+    for (int k = 0; k < DC_PARTS; k++) {
+      const uint64_t c = DC_W_COUNT(hc.cubes_w[k * DC_WORD_STRIDE]);
+      n_cubes += c; n_edges += DC_W_COUNT(hc.edges_w[k * DC_WORD_STRIDE]);
+      n_cube_runs += DC_W_RUNS(hc.cubes_w[k * DC_WORD_STRIDE]); n_edge_runs += DC_W_RUNS(hc.edges_w[k * DC_WORD_STRIDE]);
+      if (c > max_part) max_part = c;
+    }
+    if (hc.q_overflow || hc.t_overflow || max_part > ccap / DC_PARTS) {
+      if (attempt >= 8 || ccap >= cmax) return bail(fail(GSDF_ERR_CAPACITY, "dual contouring queue capacity exceeded"));
+      // the origin pass keeps counting past the capacity, so the exact number of kept cubes is known (part by part)
+      ccap = max_part > ccap / DC_PARTS ? DC_PARTS * (max_part + max_part / 16 + 512) : ccap * 2;
       continue;
     }
+    last_cap = DC_PARTS * max_part;
     break;
   }
   float ms = 0;
@@ -804,15 +825,20 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
       m->stage_name[k] = names[k];
     }
   }
-  p->last_dc_cubes = hc.n_cubes;
+  {
+    static const bool dbg = [] { const char* e = getenv("GSDF_HIP_DC_DEBUG"); return e && atoi(e) != 0; }();  // developer knob
+    if (dbg) fprintf(stderr, "dc: cubes %llu in %llu runs, edges %llu in %llu runs\n", (unsigned long long)n_cubes, (unsigned long long)n_cube_runs,
+                     (unsigned long long)n_edges, (unsigned long long)n_edge_runs);
+  }
+  p->last_dc_cubes = last_cap;  // (DC_PARTS times the fullest part: what the next mesh of this handle sizes its arrays by)
   m->st.n_tris = 2 * hc.n_tris;  // quads -> 2 triangles
   for (int k = 0; k < 64; k++) hc.n_origin_evals += hc.n_origin_part[k * 8];
-  m->st.evals = hc.n_origin_evals + 4 * hc.n_cubes + 6 * hc.n_edges;
+  m->st.evals = hc.n_origin_evals + 4 * n_cubes + 6 * n_edges;
   m->st.evals_prune = hc.n_origin_evals;  // of the nslab lattice cells; the rest lay outside the exact box by > 2 res
-  m->st.evals_leaf = 4 * hc.n_cubes + 6 * hc.n_edges;
-  m->st.pruned_leaves = nslab - hc.n_cubes;
-  m->st.leaf_cubes = hc.n_cubes;
-  m->st.active_leaves = hc.n_edges;
+  m->st.evals_leaf = 4 * n_cubes + 6 * n_edges;
+  m->st.pruned_leaves = nslab - n_cubes;
+  m->st.leaf_cubes = n_cubes;
+  m->st.active_leaves = n_edges;
   m->st.ms_total = ms;
   p->evals += m->st.evals;
   *out = m;

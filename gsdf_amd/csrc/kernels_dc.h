@@ -8,14 +8,72 @@
 // int32 index grid in HBM (levels <= 11 -> <= 4.3 GB, trivial against 288 GB), so neighbour lookups
 // are single loads and every stage is one lane per cube / per active edge.
 // =================================================================================================
+// The lists (kept cubes, active edges) are appended to with returning atomics, one per workgroup pass -- and ONE counter word
+// serves only so many of them: ~88 per microsecond with the device to itself, 15-30 ns each when thousands of passes queue on it
+// (round 5, npt-flange at resdiv 800: a second, idle atomic per pass on the same word took the origin sweep from 0.43 to 0.75 ms
+// and the edge stage from 0.42 to 0.58 -- 10.8 K passes each; the text plate's 3.1 K did not notice). So each list is kept in
+// DC_PARTS PARTS, every part with a counter word on a cache line of its own and its own eighth of the arrays; a workgroup appends
+// to part (blockIdx.x % DC_PARTS), readers walk the parts one after the other (dc_flat_to_part).
+#define DC_PARTS 8
+#define DC_WORD_STRIDE 16  // unsigned long longs between two parts' counter words (128 bytes)
 struct DCCounters {
-  unsigned long long n_cubes, n_edges, n_tris, q_overflow, t_overflow;
+  // kept cubes / active edges AND the runs they were appended in (DC_DESC below), one word per part: entries in the low 36 bits,
+  // runs above them -- a pass reserves its entries and its run descriptor(s) with one atomic
+  unsigned long long cubes_w[DC_PARTS * DC_WORD_STRIDE], edges_w[DC_PARTS * DC_WORD_STRIDE];
+  unsigned long long n_tris, q_overflow, t_overflow;
   unsigned long long n_origin_evals;  // lattice cells whose origin was actually evaluated (the rest were outside the exact box) -- the host's total of:
   // the same count in 64 parts, one cache line each: every workgroup of the origin sweep adds its count once, and 8 192 adds to ONE
-  // word were 0.3 of the sweep's 0.43 ms (a word takes ~88 atomics per microsecond; round 5, rocprofv3: dc_origin_kernel 425 us for
-  // 8.7 M evaluations)
+  // word were 0.3 of the sweep's 0.43 ms (round 5, rocprofv3: dc_origin_kernel 425 us for 8.7 M evaluations)
   unsigned long long n_origin_part[64 * 8];
 };
+#define DC_W_COUNT(w) ((w) & 0xfffffffffull)
+#define DC_W_RUNS(w) ((w) >> 36)
+
+// A RUN = cubes (edges) that one workgroup pass appended: contiguous in the list and neighbours in space (one 8 x 8 x 4K tile of the
+// origin sweep; the edges of the passes over such a tile). The lists themselves are in the order the passes' atomics arrived -- runs
+// from all over the part interleave -- and a wave that takes 64 consecutive entries straddles two or three runs from different
+// places: every far-child gate of a wide union (dev_ops.h: D_GATE*) then stays shut for it and the polygon edge culling keeps most
+// edges. (Round 5, text plate at resdiv 800: the normals stage issued ~2 500 lane instructions per evaluation, four glyph outlines
+// in full; the edge stage 570.) So the evaluating stages take their work run by run: descriptor = first entry << 13 | entries
+// (<= 1024 cubes of a tile; edge runs are cut into wave-sized pieces of <= 64). Every part has its own run arrays.
+#define DC_DESC(first, count) (((unsigned long long)(first) << 13) | (unsigned long long)(count))
+#define DC_DESC_FIRST(d) ((d) >> 13)
+#define DC_DESC_COUNT(d) ((unsigned)((d) & 8191ull))
+
+// Sizes of a part's share of the arrays, from the kernels' capacity arguments (the host sizes the arenas with the same functions).
+//   cubes, distances, vertices, normals : cube_cap / DC_PARTS entries (cube_cap is a multiple of DC_PARTS)
+//   cube runs                            : one per tile the part's workgroups sweep: tile T goes to workgroup T % gridDim and the grid
+//                                          is a multiple of DC_PARTS, so to part T % DC_PARTS
+//   edges                                : 3 per cube; edge runs: one per 64 edges and one more per cube run (its last, ragged one)
+__host__ __device__ __forceinline__ unsigned long long dc_cube_run_seg(unsigned long long ntiles) { return (ntiles + DC_PARTS - 1) / DC_PARTS + 1; }
+__host__ __device__ __forceinline__ unsigned long long dc_edge_run_seg(unsigned long long cube_cap, unsigned long long ntiles) {
+  return 3 * (cube_cap / DC_PARTS) / 64 + dc_cube_run_seg(ntiles) + 8;
+}
+// Entry g of a list read as one (parts one after the other) -> its part and its place there; false past the end. n[] = entries per part.
+__device__ __forceinline__ bool dc_flat_to_part(unsigned long long g, const unsigned long long (&n)[DC_PARTS], unsigned& part, unsigned long long& k) {
+  unsigned p = 0;
+  unsigned long long np = n[0];
+#pragma unroll
+  for (int q = 0; q < DC_PARTS - 1; q++) {
+    if (p == (unsigned)q && g >= n[q]) { g -= n[q]; p = (unsigned)q + 1u; np = n[q + 1]; }
+  }
+  part = p; k = g;
+  return g < np;
+}
+// the parts' counts (entries or runs) as block-uniform values, clipped to a part's capacity; their sum
+template <bool RUNS>
+__device__ __forceinline__ unsigned long long dc_part_counts(const unsigned long long* __restrict__ words, unsigned long long cap, unsigned long long (&n)[DC_PARTS]) {
+  unsigned long long total = 0;
+#pragma unroll
+  for (int q = 0; q < DC_PARTS; q++) {
+    const unsigned long long w = uniform_u64(words[q * DC_WORD_STRIDE]);
+    unsigned long long v = RUNS ? DC_W_RUNS(w) : DC_W_COUNT(w);
+    if (v > cap) v = cap;
+    n[q] = v;
+    total += v;
+  }
+  return total;
+}
 
 // The index grid of the sweep's tile range <- -1 ("no cube here"), row by row (a row of the range is contiguous in x): the origin
 // sweep then writes only the tiles it evaluates and steps over the ones the block test cleared without touching their cells.
@@ -94,9 +152,14 @@ __global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __r
   // that can hold a kept cube or a neighbour of one (box grown by the keep radius and two cells); cells outside that
   // range are neither written here nor read by the later stages.
   const unsigned n = 1u << nshift;
-  const uint64_t ntiles = (uint64_t)ntx * nty * ntz;
   const float maxDist = res * 2;
   unsigned long long my_evals = 0;
+  const uint64_t ntiles = (uint64_t)ntx * nty * ntz;
+  // this workgroup's part of the lists (DC_PARTS): its counter word, its share of the cubes' array and of the run descriptors behind it
+  const unsigned part = blockIdx.x % DC_PARTS;
+  unsigned long long* const my_word = &ctr->cubes_w[part * DC_WORD_STRIDE];
+  const unsigned long long cseg = cube_cap / DC_PARTS, cfirst = (unsigned long long)part * cseg;
+  unsigned long long* const my_runs = (unsigned long long*)(cubes + cube_cap) + (unsigned long long)part * dc_cube_run_seg(ntiles);
   for (uint64_t T = blockIdx.x; T < ntiles; T += gridDim.x) {  // block-uniform trip count
     // a tile whose four blocks the interval test cleared: nothing kept, nothing to write (the grid of the range was cleared to -1)
     if (block_keep != nullptr) {
@@ -143,8 +206,7 @@ __global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __r
         if (lane == 0) my_evals += (unsigned long long)__builtin_popcountll(vm);
       }
     }
-    // Block-wide append: ONE global atomic per workgroup pass (K*256 cells) instead of one per wave and point --
-    // at ~88 atomics/us on a single word the per-wave form was a co-bottleneck for cheap trees (1e9 cells / 64).
+    // Block-wide append: ONE global atomic per workgroup pass (K*256 cells) instead of one per wave and point.
     bool keep[K];
     unsigned mine = 0;
 #pragma unroll
@@ -170,17 +232,27 @@ __global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __r
     if (lane == 63) s_w[wave] = incl;
     __syncthreads();
     const unsigned w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
-    const unsigned total = w0 + w1 + w2 + w3;
-    if (threadIdx.x == 0 && total) *s_base = atomicAdd(&ctr->n_cubes, (unsigned long long)total);
+    const unsigned total = w0 + w1 + w2 + w3;  // (> 0 here)
+    if (threadIdx.x == 0) {
+      const unsigned long long w = atomicAdd(my_word, (unsigned long long)total | (1ull << 36));
+#ifdef GSDF_EXP_DC_EXTRA_ATOMIC  // experiment: what a second returning atomic on the same word costs the stage
+      if (atomicAdd(my_word, 0ull) == 0x123456789abcull) ctr->t_overflow = 1ull;
+#endif
+      const unsigned long long b = DC_W_COUNT(w);
+      *s_base = b;
+      // this pass's run (a run past the part's capacity has no entries: the mesh is repeated with more room)
+      const unsigned long long room = b < cseg ? cseg - b : 0ull;
+      my_runs[DC_W_RUNS(w)] = DC_DESC(cfirst + b, room < total ? room : total);
+    }
     __syncthreads();
-    unsigned long long slot = (total ? *s_base : 0ull) + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + (incl - mine);
+    unsigned long long slot = *s_base + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + (incl - mine);  // (within the part)
 #pragma unroll
     for (int kp = 0; kp < K; kp++) {
       const uint64_t c = (uint64_t)cx[kp] + ((uint64_t)cy[kp] << nshift) + ((uint64_t)cz[kp] << (2 * nshift));
       if (keep[kp]) {
-        if (slot < cube_cap) {
-          cubes[slot] = Cube{(uint16_t)cx[kp], (uint16_t)cy[kp], (uint16_t)cz[kp], 0};
-          grid[c] = (int)slot;
+        if (slot < cseg) {
+          cubes[cfirst + slot] = Cube{(uint16_t)cx[kp], (uint16_t)cy[kp], (uint16_t)cz[kp], 0};
+          grid[c] = (int)(cfirst + slot);
         } else {
           ctr->q_overflow = 1ull;
           grid[c] = -1;
@@ -204,45 +276,117 @@ __global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __r
 
 // Stage 2 (RenderAll :85-108): origin, +x, +y, +z distances of every kept cube (one 4-point pass per
 // lane); default FinalVertex = cube origin; active edges (sign BIT differs, :261-269) are compacted.
+// Work item = a run of the origin sweep (DC_DESC): the cubes of one tile, 256 per pass; a wave without a cube of the run
+// skips the evaluation, lanes past the run's end repeat its last cube (a dummy position would stretch the wave's bounding box).
+// The edges are appended once per run (DC_EDGE_PASSES passes = the 1024 cells of the largest tile: one atomic); until then a pass's active edges wait in
+// LDS as 16 bits per lane (which of the cube's three, where they go within the pass's part of the append).
+#define DC_EDGE_PASSES 4  // (2 KB of LDS: npt-flange keeps its five workgroups per CU)
 __global__ void __launch_bounds__(BLOCK, 3) dc_edges_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
                                                             unsigned long long cube_cap, float ox, float oy, float oz, float res,
                                                             float4* __restrict__ dists, float* __restrict__ fv,
                                                             unsigned* __restrict__ edges, unsigned long long edge_cap,
+                                                            unsigned long long* __restrict__ edge_runs, unsigned long long ntiles /* of the origin sweep */,
                                                             DCCounters* __restrict__ ctr) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
-  unsigned long long n = uniform_u64(ctr->n_cubes);
-  if (n > cube_cap) n = cube_cap;
-  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {
-    const uint64_t i = base + threadIdx.x;
-    const bool valid = i < n;
-    Cube c = {0, 0, 0, 0};
-    if (valid) c = cubes[i];
-    const float x0 = ox + res * (float)c.x, y0 = oy + res * (float)c.y, z0 = oz + res * (float)c.z;
-    P3 p[4] = {{x0, y0, z0}, {x0 + res, y0 + 0.f, z0 + 0.f}, {x0 + 0.f, y0 + res, z0 + 0.f}, {x0 + 0.f, y0 + 0.f, z0 + res}};
-    float d[4];
-    gsdf_dev::sdf_eval<4>(code, p, d, lds, BLOCK, /*brick=*/true);  // (kept cubes arrive tile by tile: a wave's 64 cubes are neighbours -- edge culling on)
-    if (valid) {
-      dists[i] = make_float4(d[0], d[1], d[2], d[3]);
-      fv[3 * i] = x0; fv[3 * i + 1] = y0; fv[3 * i + 2] = z0;
-    }
-    const unsigned s0 = __float_as_uint(d[0]) >> 31;
-    bool act[3];
-    unsigned mine = 0;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      act[a] = valid && ((__float_as_uint(d[1 + a]) >> 31) != s0);
-      mine += act[a] ? 1u : 0u;
-    }
-    unsigned long long slot = block_append_n(mine, &ctr->n_edges);  // one atomic per workgroup pass (was: three per wave)
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      if (act[a]) {
-        if (slot < edge_cap) edges[slot] = ((unsigned)i << 2) | (unsigned)a;
-        else ctr->q_overflow = 1ull;
-        slot++;
+  __shared__ uint16_t s_pend[DC_EDGE_PASSES][BLOCK];
+  __shared__ unsigned s_tot[DC_EDGE_PASSES], s_off[DC_EDGE_PASSES], s_w[4];
+  __shared__ unsigned long long s_word;
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned long long* __restrict__ cube_runs = (const unsigned long long*)(cubes + cube_cap);
+  const unsigned long long crseg = dc_cube_run_seg(ntiles);
+  unsigned long long nr[DC_PARTS];
+  const unsigned long long nruns = dc_part_counts<true>(ctr->cubes_w, crseg, nr);  // the cube runs of all parts, one after the other
+  // this workgroup's part of the edge list (DC_PARTS): its counter word, its share of the edges' array and of the edge runs
+  const unsigned part = blockIdx.x % DC_PARTS;
+  unsigned long long* const my_word = &ctr->edges_w[part * DC_WORD_STRIDE];
+  const unsigned long long eseg = edge_cap / DC_PARTS, efirst = (unsigned long long)part * eseg;
+  unsigned long long* const my_runs = edge_runs + (unsigned long long)part * dc_edge_run_seg(cube_cap, ntiles);
+  auto run_at = [&](unsigned long long g) -> unsigned long long {  // (block-uniform)
+    unsigned pp = 0;
+    unsigned long long kk = 0;
+    return dc_flat_to_part(g, nr, pp, kk) ? uniform_u64(cube_runs[(unsigned long long)pp * crseg + kk]) : 0ull;
+  };
+  unsigned long long dsc_next = run_at(blockIdx.x);
+  for (unsigned long long r = blockIdx.x; r < nruns; r += gridDim.x) {  // block-uniform trip counts
+    const unsigned long long dsc = dsc_next;
+    dsc_next = run_at(r + gridDim.x);  // (its latency under this run's evaluation)
+    const unsigned long long first = DC_DESC_FIRST(dsc);
+    const unsigned cnt = DC_DESC_COUNT(dsc);  // (0: a run past the cubes' capacity -- the mesh is repeated with more room)
+    // Which wave takes which 64 of a pass's 256 changes from run to run: a run's last pass fills one or two waves, and with a fixed
+    // order those would always be waves 0 and 1.
+    const unsigned rot = (unsigned)__builtin_popcountll(r) & 3u;
+    const unsigned jt = (((threadIdx.x >> 6) - rot) & 3u) * 64u + lane;  // this thread's place in a pass
+    unsigned npend = 0;  // block-uniform
+    for (unsigned off = 0; off < cnt; off += BLOCK) {
+      const unsigned j = off + jt;
+      const bool valid = j < cnt;
+      const uint64_t i = first + (valid ? j : cnt - 1u);
+      const Cube c = cubes[i];
+      const float x0 = ox + res * (float)c.x, y0 = oy + res * (float)c.y, z0 = oz + res * (float)c.z;
+      P3 p[4] = {{x0, y0, z0}, {x0 + res, y0 + 0.f, z0 + 0.f}, {x0 + 0.f, y0 + res, z0 + 0.f}, {x0 + 0.f, y0 + 0.f, z0 + res}};
+      float d[4] = {0.f, 0.f, 0.f, 0.f};
+      if (__builtin_amdgcn_ballot_w64(valid) != 0ull)  // (wave-uniform)
+        gsdf_dev::sdf_eval<4>(code, p, d, lds, BLOCK, /*brick=*/true);  // (a wave's cubes are neighbours within one tile: edge culling on)
+      if (valid) {
+        dists[i] = make_float4(d[0], d[1], d[2], d[3]);
+        fv[3 * i] = x0; fv[3 * i + 1] = y0; fv[3 * i + 2] = z0;
       }
+      const unsigned s0 = __float_as_uint(d[0]) >> 31;
+      unsigned act = 0, mine = 0;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const bool on = valid && ((__float_as_uint(d[1 + a]) >> 31) != s0);
+        act |= on ? (1u << a) : 0u;
+        mine += on ? 1u : 0u;
+      }
+      unsigned incl = mine;  // where this pass's edges go among themselves: a block-wide scan (thread order)
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(incl, o, 64);
+        if (lane >= (unsigned)o) incl += v;
+      }
+      __syncthreads();  // the previous pass's (or flush's) readers are done with s_w, s_pend, s_tot
+      if (lane == 63u) s_w[wave] = incl;
+      __syncthreads();
+      const unsigned w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+      s_pend[npend][threadIdx.x] = (uint16_t)(act | (((wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + (incl - mine)) << 3));  // (< 768 ahead of it)
+      if (threadIdx.x == 0) { s_tot[npend] = w0 + w1 + w2 + w3; s_off[npend] = off; }
+      npend++;
+      if (npend < DC_EDGE_PASSES && off + BLOCK < cnt) continue;
+      // ---- the append of the passes that wait: one atomic for their edges and the runs of <= 64 they are handed to the normals stage in
+      __syncthreads();
+      unsigned sum = 0;
+      for (unsigned q = 0; q < npend; q++) sum += s_tot[q];
+      if (sum != 0u) {  // (block-uniform)
+        if (threadIdx.x == 0) s_word = atomicAdd(my_word, (unsigned long long)sum | ((unsigned long long)((sum + 63u) >> 6) << 36));
+#ifdef GSDF_EXP_DC_EXTRA_ATOMIC
+        if (threadIdx.x == 0 && atomicAdd(my_word, 0ull) == 0x123456789abcull) ctr->t_overflow = 1ull;
+#endif
+        __syncthreads();
+        const unsigned long long wd = s_word;
+        const unsigned long long ebase = DC_W_COUNT(wd);  // (within the part)
+        unsigned long long base = ebase;
+        for (unsigned q = 0; q < npend; q++) {
+          const unsigned pend = s_pend[q][threadIdx.x];
+          const unsigned cube = (unsigned)(first + s_off[q] + jt);
+          unsigned long long slot = base + (pend >> 3);
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            if ((pend >> a) & 1u) {
+              if (slot < eseg) edges[efirst + slot] = (cube << 2) | (unsigned)a;
+              else ctr->q_overflow = 1ull;
+              slot++;
+            }
+          }
+          base += s_tot[q];
+        }
+        const unsigned long long room = ebase < eseg ? eseg - ebase : 0ull;
+        const unsigned n = room < sum ? (unsigned)room : sum, nsub = (sum + 63u) >> 6;
+        for (unsigned k = threadIdx.x; k < nsub; k += BLOCK)
+          my_runs[DC_W_RUNS(wd) + k] = DC_DESC(efirst + ebase + 64u * k, 64u * k >= n ? 0u : (n - 64u * k < 64u ? n - 64u * k : 64u));
+      }
+      npend = 0;
     }
   }
 }
@@ -251,42 +395,46 @@ __device__ __forceinline__ float dc_isect(float o, float e) { return -o / (e - o
 
 // Stage 3 (PlaceVertices :28-50 + gleval.NormalsCentralDiff): raw central-difference normals at the
 // linear intersection of every ACTIVE edge (inactive edges' normals are never read by the reference).
+// Work item = a wave-sized run of edges from one pass of the edge stage (DC_DESC), a wave each: no workgroup-level step here.
 __global__ void __launch_bounds__(BLOCK, 3) dc_normals_kernel(const uint32_t* __restrict__ code_g, const Cube* __restrict__ cubes,
                                                               const float4* __restrict__ dists, const unsigned* __restrict__ edges,
-                                                              unsigned long long edge_cap, float ox, float oy, float oz, float res,
-                                                              float h, float* __restrict__ nrm, DCCounters* __restrict__ ctr) {
+                                                              const unsigned long long* __restrict__ edge_runs, unsigned long long cube_cap,
+                                                              unsigned long long ntiles, float ox, float oy, float oz,
+                                                              float res, float h, float* __restrict__ nrm, DCCounters* __restrict__ ctr) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
-  unsigned long long n = uniform_u64(ctr->n_edges);
-  if (n > edge_cap) n = edge_cap;
-  const uint64_t step = (uint64_t)gridDim.x * BLOCK;
-  for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {
-    const uint64_t i = base + threadIdx.x;
-    const bool valid = i < n;
-    float px = 0, py = 0, pz = 0;
-    unsigned e = 0;
-    if (valid) {
-      e = edges[i];
-      const unsigned ci = e >> 2, a = e & 3u;
-      const Cube c = cubes[ci];
-      const float4 d = dists[ci];
-      const float t = res * dc_isect(d.x, a == 0 ? d.y : (a == 1 ? d.z : d.w));
-      px = (ox + res * (float)c.x) + (a == 0 ? t : 0.f);
-      py = (oy + res * (float)c.y) + (a == 1 ? t : 0.f);
-      pz = (oz + res * (float)c.z) + (a == 2 ? t : 0.f);
-    }
+  const unsigned long long erseg = dc_edge_run_seg(cube_cap, ntiles);
+  unsigned long long nr[DC_PARTS];
+  const unsigned long long nruns = dc_part_counts<true>(ctr->edges_w, erseg, nr);  // the edge runs of all parts, one after the other
+  const unsigned lane = threadIdx.x & 63u;
+  for (unsigned long long r = uniform_u64((unsigned long long)blockIdx.x * 4u + (threadIdx.x >> 6)); r < nruns; r += (unsigned long long)gridDim.x * 4u) {  // wave-uniform
+    unsigned pp = 0;
+    unsigned long long kk = 0;
+    dc_flat_to_part(r, nr, pp, kk);
+    const unsigned long long dsc = uniform_u64(edge_runs[(unsigned long long)pp * erseg + kk]);
+    const unsigned cnt = DC_DESC_COUNT(dsc);  // 1 .. 64 (0: past the edges' capacity)
+    if (cnt == 0u) continue;
+    const bool valid = lane < cnt;
+    const unsigned e = edges[DC_DESC_FIRST(dsc) + (valid ? lane : cnt - 1u)];  // (lanes past the end repeat the last edge: see dc_edges_kernel)
+    const unsigned ci = e >> 2, a = e & 3u;
+    const Cube c = cubes[ci];
+    const float4 d = dists[ci];
+    const float t = res * dc_isect(d.x, a == 0 ? d.y : (a == 1 ? d.z : d.w));
+    const float px = (ox + res * (float)c.x) + (a == 0 ? t : 0.f);
+    const float py = (oy + res * (float)c.y) + (a == 1 ? t : 0.f);
+    const float pz = (oz + res * (float)c.z) + (a == 2 ? t : 0.f);
     float out[3];
 #pragma unroll 1
     for (int dim = 0; dim < 3; dim++) {
       P3 ab[2] = {{px + (dim == 0 ? h : 0.f), py + (dim == 1 ? h : 0.f), pz + (dim == 2 ? h : 0.f)},
                   {px - (dim == 0 ? h : 0.f), py - (dim == 1 ? h : 0.f), pz - (dim == 2 ? h : 0.f)}};
       float dd[2];
-      gsdf_dev::sdf_eval<2>(code, ab, dd, lds, BLOCK);  // (no edge culling here: two points per lane do not pay for its reductions -- text plate 0.255 -> 0.31 ms with it)
+      gsdf_dev::sdf_eval<2>(code, ab, dd, lds, BLOCK, /*brick=*/true);  // (the wave's edges lie within one tile: edge culling on. Round 4, waves that straddled runs from different places: 0.255 -> 0.31 ms with it)
       const float v = dd[0] - dd[1];
       if (dim == 0) out[0] = v; else if (dim == 1) out[1] = v; else out[2] = v;
     }
     if (valid) {
-      const size_t o = ((size_t)(e >> 2) * 3 + (e & 3u)) * 3;
+      const size_t o = ((size_t)ci * 3 + a) * 3;
       nrm[o] = out[0]; nrm[o + 1] = out[1]; nrm[o + 2] = out[2];
     }
   }
@@ -309,14 +457,17 @@ __global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restri
                                                             DCCounters* __restrict__ ctr) {
   __shared__ float sA[DC_ROWS][3][DC_BLOCK];
   __shared__ float sB[DC_ROWS][DC_BLOCK];
-  unsigned long long n = uniform_u64(ctr->n_cubes);
-  if (n > cube_cap) n = cube_cap;
+  const unsigned long long cseg = cube_cap / DC_PARTS;
+  unsigned long long np[DC_PARTS];
+  const unsigned long long n = dc_part_counts<false>(ctr->cubes_w, cseg, np);  // the cubes of all parts, one after the other
   const int nn = 1 << nshift;
   const unsigned t = threadIdx.x;
   const uint64_t step = (uint64_t)gridDim.x * DC_BLOCK;
   for (uint64_t base = (uint64_t)blockIdx.x * DC_BLOCK; base < n; base += step) {
-    const uint64_t i = base + t;
-    if (i >= n) continue;  // no block-level sync below: each lane owns column t of the LDS arrays
+    unsigned pp = 0;
+    unsigned long long kk = 0;
+    if (!dc_flat_to_part(base + t, np, pp, kk)) continue;  // no block-level sync below: each lane owns column t of the LDS arrays
+    const uint64_t i = (uint64_t)pp * cseg + kk;
     const Cube c = cubes[i];
     if (c.z >= zplace_hi) continue;  // top halo layer: only its distances/normals are needed
     const float cox = ox + res * (float)c.x, coy = oy + res * (float)c.y, coz = oz + res * (float)c.z;
@@ -433,17 +584,19 @@ __global__ void __launch_bounds__(BLOCK) dc_quads_kernel(const Cube* __restrict_
                                                          const int* __restrict__ grid, const float* __restrict__ fv, int nshift,
                                                          unsigned zown_lo, unsigned zown_hi, float* __restrict__ tris,
                                                          unsigned long long tri_cap, DCCounters* __restrict__ ctr) {
-  unsigned long long n = uniform_u64(ctr->n_edges);
-  if (n > edge_cap) n = edge_cap;
+  const unsigned long long eseg = edge_cap / DC_PARTS;
+  unsigned long long np[DC_PARTS];
+  const unsigned long long n = dc_part_counts<false>(ctr->edges_w, eseg, np);  // the edges of all parts, one after the other
   const int nn = 1 << nshift;
   const uint64_t step = (uint64_t)gridDim.x * BLOCK;
   for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < n; base += step) {
-    const uint64_t i = base + threadIdx.x;
-    bool ok = i < n;
+    unsigned pp = 0;
+    unsigned long long kk = 0;
+    bool ok = dc_flat_to_part(base + threadIdx.x, np, pp, kk);
     int q[4] = {-1, -1, -1, -1};
     bool flip = false;
     if (ok) {
-      const unsigned e = edges[i];
+      const unsigned e = edges[(uint64_t)pp * eseg + kk];
       const unsigned ci = e >> 2, a = e & 3u;
       const Cube c = cubes[ci];
       const float4 d = dists[ci];
