@@ -40,6 +40,15 @@ __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi
 // smallest/largest |numerator|; it returns false (wave-uniform) if some lane left the proven-exact range.
 // keepd / keeps (wave-uniform bit per edge, from poly_cull): edges whose distance part / winding part can matter for some
 // point of this wave; the others are provably irrelevant and skipped.
+// a wave-uniform value held in a vector register (see poly_edges)
+template <bool ON>
+__device__ __forceinline__ float in_vgpr(float s) {
+  if (!ON) return s;
+  float v;
+  asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+  return v;
+}
+
 template <int K, bool FAST>
 __device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t nv, float v0x, float v0y, const P3 (&pv)[K],
                                            float (&d)[K], bool (&neg)[K], const uint64_t keepd = ~0ull,
@@ -61,7 +70,11 @@ __device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t n
     if (!kd && !ks) continue;
     const f4ptr er = (f4ptr)(code + q);
     const v4f e0 = er[0], e1 = er[1];
-    const float v1x = e0.x, v1y = e0.y, ex = e0.z, ey = e0.w, n2e = e1.x, v2y = e1.y, rn2e = e1.z;
+    // The edge's constants arrive in scalar registers, and on gfx950 a float add / multiply / fma with a scalar-register operand
+    // issues at 4.2 cycles instead of 2.4 (tools/ubench/class_rate.hip: "sgpr src0"): with two or more points per lane the thirteen
+    // such operations per point are worth six moves to vector registers per edge. Same values, same operations.
+    const float v1x = in_vgpr<(K >= 2)>(e0.x), v1y = in_vgpr<(K >= 2)>(e0.y), ex = in_vgpr<(K >= 2)>(e0.z), ey = in_vgpr<(K >= 2)>(e0.w),
+                n2e = in_vgpr<(K >= 2)>(e1.x), v2y = e1.y, rn2e = in_vgpr<(K >= 2)>(e1.z);
     KLOOP {
       const float px = pv[kp].x, py = pv[kp].y;
       const float wx = px - v1x, wy = py - v1y;
