@@ -750,10 +750,9 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
         else hipLaunchKernelGGL(dc_block_test_kernel, dim3(gt), dim3(BLOCK), lds_t, s, p->d_code, cols, p->prog.nslots, lk, ox, oy, oz, res, zlo, t0[0], t0[1], t0[2], tn[0], tn[1],
                                 tn[2], (uint32_t*)p->dc_tile.p);
         HIP_TRYM(hipGetLastError());
-        // ... and the grid of the tile range cleared to "no cube": the sweep steps over the tiles the test cleared
-        const uint64_t crows = (uint64_t)tn[1] * 8 * (uint64_t)tn[2] * tzk;
-        hipLaunchKernelGGL(dc_grid_clear_kernel, dim3(grid_for(crows * 64, p->num_cu, 16)), dim3(BLOCK), 0, s, (int*)grid.p, nshift, t0[0] * 8u, tn[0] * 8u, t0[1] * 8u, tn[1] * 8u,
-                           zlo + t0[2] * tzk, tn[2] * tzk);
+        // ... and "no cube here" in the cleared tiles next to evaluated ones: the cells the later stages read and the sweep does not write
+        hipLaunchKernelGGL(dc_grid_clear_kernel, dim3(grid_for((uint64_t)((tn[0] + 3) / 4) * ((tn[1] + 3) / 4) * ((tn[2] + 3) / 4) * BLOCK, p->num_cu, 16)), dim3(BLOCK), 0, s, (int*)grid.p, nshift, lk, zlo, zhi, t0[0], t0[1], t0[2], tn[0], tn[1],
+                           tn[2], (const uint32_t*)p->dc_tile.p);
         HIP_TRYM(hipGetLastError());
         d_keep = (const uint32_t*)p->dc_tile.p;
       } else {

@@ -1251,7 +1251,17 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
             m2[kp] = minf(m2[kp], dx * dx + dy * dy);
           }
         }
-        KLOOP LDSF(slot) = LIP ? 3.0e38f : 1.001f * sqrtf_(m2[kp]) + 1e-30f;  // (a bound at the centre says nothing about the cube)
+        if (LIP) {
+          // interval mode: the bound over the whole ball (the distance to a box's farthest corner is 1-Lipschitz in the point, so is
+          // the minimum over the boxes), above every value the per-point form can take there -- 1.002 against its 1.001 and the
+          // rounding of its sums, which is below 1e-6 of the coordinates' magnitudes. BOTH columns: the running minimum of the
+          // union never exceeds it anywhere in the ball, and the children the gates now skip from the first one on (each proven
+          // above it over the whole ball, D_GATE*) cannot lower the interval's lower end below what the evaluated ones give.
+          const float u = 1.002f * (sqrtf_(m2[0]) + lipR) + 2e-6f * (absf(pv[0].x) + absf(pv[0].y)) + 1e-30f;
+          KLOOP LDSF(slot) = u;
+        } else {
+          KLOOP LDSF(slot) = 1.001f * sqrtf_(m2[kp]) + 1e-30f;
+        }
         pc = q;
         break;
       }
@@ -1269,7 +1279,12 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
             m2[kp] = minf(m2[kp], dx * dx + dy * dy + dz * dz);
           }
         }
-        KLOOP LDSF(slot) = LIP ? 3.0e38f : 1.001f * sqrtf_(m2[kp]) + 1e-30f;
+        if (LIP) {  // (see D_UBOUND2D)
+          const float u = 1.002f * (sqrtf_(m2[0]) + lipR) + 2e-6f * (absf(pv[0].x) + absf(pv[0].y) + absf(pv[0].z)) + 1e-30f;
+          KLOOP LDSF(slot) = u;
+        } else {
+          KLOOP LDSF(slot) = 1.001f * sqrtf_(m2[kp]) + 1e-30f;
+        }
         pc = q;
         break;
       }

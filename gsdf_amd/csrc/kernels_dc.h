@@ -75,19 +75,69 @@ __device__ __forceinline__ unsigned long long dc_part_counts(const unsigned long
   return total;
 }
 
-// The index grid of the sweep's tile range <- -1 ("no cube here"), row by row (a row of the range is contiguous in x): the origin
-// sweep then writes only the tiles it evaluates and steps over the ones the block test cleared without touching their cells.
-__global__ void __launch_bounds__(BLOCK) dc_grid_clear_kernel(int* __restrict__ grid, int nshift, unsigned x0, unsigned nx, unsigned y0, unsigned ny, unsigned z0,
-                                                              unsigned nz) {
-  const uint64_t rows = (uint64_t)ny * nz;
+// The index grid's cells that are READ but not written by the origin sweep <- -1 ("no cube here"). The sweep writes every cell of
+// the tiles it evaluates and steps over the tiles the block test cleared; the later stages look at the cells around kept cubes only
+// (one cell either way: dc_place_kernel, dc_quads_kernel), i.e. at evaluated tiles and their 26 neighbours. So a cleared tile is
+// filled iff one of its neighbours is evaluated -- the rest of the range is never read. (Until round 5 the whole range was filled:
+// 213 MB and 39 us for npt-flange at resdiv 800.) flags: dc_block_test_kernel's, four per tile.
+// A workgroup takes a block of 4 x 4 x 4 tiles, a tile per thread of its first wave: which tiles of the block and of the shell around it
+// are evaluated goes through LDS (one load per thread; 27 dependent trips to memory per tile took 30 us whatever the lattice's size),
+// the tiles to fill are listed, and the waves fill them side by side, a row of 8 cells (32 bytes) per lane and store pair.
+__global__ void __launch_bounds__(BLOCK) dc_grid_clear_kernel(int* __restrict__ grid, int nshift, int K, unsigned zlo, unsigned zhi, unsigned tx0, unsigned ty0,
+                                                              unsigned tz0, unsigned ntx, unsigned nty, unsigned ntz, const uint32_t* __restrict__ flags) {
+  __shared__ unsigned char s_ev[6 * 6 * 6];
+  __shared__ unsigned s_n;
+  __shared__ unsigned s_list[64];
   const unsigned n = 1u << nshift;
-  if (x0 >= n) return;
-  if (x0 + nx > n) nx = n - x0;
-  for (uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (uint64_t)gridDim.x * 4) {  // a wave per row
-    const unsigned y = y0 + (unsigned)(r % ny), z = z0 + (unsigned)(r / ny);
-    if (y >= n || z >= n) continue;
-    int* row = grid + ((uint64_t)x0 + ((uint64_t)y << nshift) + ((uint64_t)z << (2 * nshift)));
-    for (unsigned x = threadIdx.x & 63u; x < nx; x += 64u) row[x] = -1;
+  const unsigned nbx = (ntx + 3u) >> 2, nby = (nty + 3u) >> 2, nbz = (ntz + 3u) >> 2;
+  const unsigned nblocks = nbx * nby * nbz;
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (unsigned B = blockIdx.x; B < nblocks; B += gridDim.x) {  // block-uniform trip count
+    const int bx = (int)(B % nbx) * 4, by = (int)((B / nbx) % nby) * 4, bz = (int)(B / (nbx * nby)) * 4;
+    if (threadIdx.x < 216u) {
+      const unsigned e = threadIdx.x;
+      const int ux = bx + (int)(e % 6u) - 1, uy = by + (int)((e / 6u) % 6u) - 1, uz = bz + (int)(e / 36u) - 1;
+      unsigned ev = 0u;
+      if (ux >= 0 && uy >= 0 && uz >= 0 && ux < (int)ntx && uy < (int)nty && uz < (int)ntz) {
+        const uint4 f = *(const uint4*)(flags + ((uint64_t)ux + (uint64_t)ntx * ((uint64_t)uy + (uint64_t)nty * (uint64_t)uz)) * 4ull);
+        ev = (f.x | f.y | f.z | f.w) >> 31;
+      }
+      s_ev[e] = (unsigned char)ev;
+    }
+    if (threadIdx.x == 0) s_n = 0u;
+    __syncthreads();
+    if (threadIdx.x < 64u) {
+      const unsigned lx = threadIdx.x & 3u, ly = (threadIdx.x >> 2) & 3u, lz = threadIdx.x >> 4;
+      const unsigned x = (unsigned)bx + lx, y = (unsigned)by + ly, z = (unsigned)bz + lz;
+      if (x < ntx && y < nty && z < ntz && s_ev[(lz + 1u) * 36u + (ly + 1u) * 6u + lx + 1u] == 0u) {  // (an evaluated tile is written by the sweep)
+        unsigned near = 0u;
+#pragma unroll
+        for (unsigned dz = 0; dz < 3u; dz++)
+#pragma unroll
+          for (unsigned dy = 0; dy < 3u; dy++)
+#pragma unroll
+            for (unsigned dx = 0; dx < 3u; dx++) near |= s_ev[(lz + dz) * 36u + (ly + dy) * 6u + lx + dx];
+        if (near != 0u) s_list[atomicAdd(&s_n, 1u)] = x | (y << 10) | (z << 20);  // (tile coordinates are below 2^10: 2^11 cells / 8, / 4)
+      }
+    }
+    __syncthreads();
+    // a wave per tile found: 8 x 4K rows of 8 cells, a row per lane and step (the rows start on 32-byte boundaries: two 16-byte stores)
+    const unsigned cnt = s_n;
+    for (unsigned q = wave; q < cnt; q += 4u) {
+      const unsigned F = s_list[q];
+      const unsigned x = F & 1023u, y = (F >> 10) & 1023u, z = F >> 20;
+      const unsigned cx = (tx0 + x) * 8u;
+      if (cx >= n) continue;  // (n is a multiple of 8: a row lies in the lattice or it does not)
+      for (unsigned r = lane; r < 32u * (unsigned)K; r += 64u) {
+        const unsigned cy = (ty0 + y) * 8u + (r & 7u), cz = zlo + (tz0 + z) * (4u * (unsigned)K) + (r >> 3);
+        if (cy < n && cz < zhi) {
+          int4* row = (int4*)(grid + ((uint64_t)cx + ((uint64_t)cy << nshift) + ((uint64_t)cz << (2 * nshift))));
+          row[0] = make_int4(-1, -1, -1, -1);
+          row[1] = make_int4(-1, -1, -1, -1);
+        }
+      }
+    }
+    __syncthreads();  // (s_ev and s_list are rewritten by the next pass)
   }
 }
 
@@ -114,9 +164,9 @@ __global__ void __launch_bounds__(BLOCK) dc_block_test_kernel(const uint32_t* __
   for (uint64_t b0 = (uint64_t)blockIdx.x * BLOCK; b0 < nblk; b0 += (uint64_t)gridDim.x * BLOCK) {  // block-uniform trip count
     const uint64_t b = b0 + threadIdx.x;
     const bool valid = b < nblk;
-    const uint64_t T = (valid ? b : 0ull) >> 2;
+    const unsigned T = (unsigned)((valid ? b : 0ull) >> 2);  // (tile counts stay below 2^32: 32-bit divisions)
     const unsigned w = (unsigned)(b & 3ull);
-    const unsigned tx = tx0 + (unsigned)(T % ntx), ty = ty0 + (unsigned)((T / ntx) % nty), tz = tz0 + (unsigned)(T / ((uint64_t)ntx * nty));
+    const unsigned tx = tx0 + T % ntx, ty = ty0 + (T / ntx) % nty, tz = tz0 + T / (ntx * nty);
     P3 c;
     c.x = ox + res * ((float)(tx * 8u) + 3.5f);
     c.y = oy + res * ((float)(ty * 8u) + 3.5f);
