@@ -512,17 +512,17 @@ __global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restri
   const unsigned long long n = dc_part_counts<false>(ctr->cubes_w, cseg, np);  // the cubes of all parts, one after the other
   const int nn = 1 << nshift;
   const unsigned t = threadIdx.x;
-  const uint64_t step = (uint64_t)gridDim.x * DC_BLOCK;
-  for (uint64_t base = (uint64_t)blockIdx.x * DC_BLOCK; base < n; base += step) {
-    unsigned pp = 0;
-    unsigned long long kk = 0;
-    if (!dc_flat_to_part(base + t, np, pp, kk)) continue;  // no block-level sync below: each lane owns column t of the LDS arrays
-    const uint64_t i = (uint64_t)pp * cseg + kk;
+  // Two cubes in five are placed (the ones with an active edge among the twelve of their cell; the kept cubes are a band four cells
+  // thick around the surface), and taken 64 at a time in list order the least-squares solve ran with that share of its lanes. So the
+  // workgroup -- one wave -- first ASKS which of its next 64 cubes are placed and queues those (a ring of 128 indices in LDS); the
+  // solve runs whenever 64 are waiting, on full waves.
+  __shared__ unsigned s_q[128];
+  unsigned head = 0, tail = 0;  // (wave-uniform)
+  auto place = [&](const uint64_t i) {
     const Cube c = cubes[i];
-    if (c.z >= zplace_hi) continue;  // top halo layer: only its distances/normals are needed
     const float cox = ox + res * (float)c.x, coy = oy + res * (float)c.y, coz = oz + res * (float)c.z;
     const float invRes = 1.0f / res;
-    int nr = 0, nnb = 0;
+    int nr = 0;
     float mx = 0.f, my = 0.f, mz = 0.f;
     auto add_row = [&](float bx, float by, float bz, float nx, float ny, float nz) {
       const float qx = invRes * (bx - cox), qy = invRes * (by - coy), qz = invRes * (bz - coz);
@@ -539,9 +539,15 @@ __global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restri
       const size_t o = ((size_t)ci * 3 + (size_t)a) * 3;
       add_row(ux + (a == 0 ? tt : 0.f), uy + (a == 1 ? tt : 0.f), uz + (a == 2 ? tt : 0.f), nrm[o], nrm[o + 1], nrm[o + 2]);
     };
-    // neighbour records first decide whether this cube is placed at all (len(cube.Neighbors) == 0 -> skip)
-    unsigned contrib[12];
-    unsigned char caxis[12];
+    // (whether the cube is placed at all -- len(cube.Neighbors) != 0 -- was decided when it was queued)
+    {
+      const float4 d = dists[i];
+      const unsigned s0 = __float_as_uint(d.x) >> 31;
+      if ((__float_as_uint(d.y) >> 31) != s0) edge_row((unsigned)i, 0);
+      if ((__float_as_uint(d.z) >> 31) != s0) edge_row((unsigned)i, 1);
+      if ((__float_as_uint(d.w) >> 31) != s0) edge_row((unsigned)i, 2);
+    }
+    // the active edges of the cell, in lattice order (z, y, x) and axis order
     for (int dz = 0; dz < 2; dz++)
       for (int dy = 0; dy < 2; dy++)
         for (int dx = 0; dx < 2; dx++) {
@@ -551,19 +557,10 @@ __global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restri
           if (ui < 0) continue;
           const float4 d = dists[ui];
           const unsigned s0 = __float_as_uint(d.x) >> 31;
-          if (dx == 0 && ((__float_as_uint(d.y) >> 31) != s0)) { contrib[nnb] = (unsigned)ui; caxis[nnb++] = 0; }
-          if (dy == 0 && ((__float_as_uint(d.z) >> 31) != s0)) { contrib[nnb] = (unsigned)ui; caxis[nnb++] = 1; }
-          if (dz == 0 && ((__float_as_uint(d.w) >> 31) != s0)) { contrib[nnb] = (unsigned)ui; caxis[nnb++] = 2; }
+          if (dx == 0 && ((__float_as_uint(d.y) >> 31) != s0)) edge_row((unsigned)ui, 0);
+          if (dy == 0 && ((__float_as_uint(d.z) >> 31) != s0)) edge_row((unsigned)ui, 1);
+          if (dz == 0 && ((__float_as_uint(d.w) >> 31) != s0)) edge_row((unsigned)ui, 2);
         }
-    if (nnb == 0) continue;
-    {
-      const float4 d = dists[i];
-      const unsigned s0 = __float_as_uint(d.x) >> 31;
-      if ((__float_as_uint(d.y) >> 31) != s0) edge_row((unsigned)i, 0);
-      if ((__float_as_uint(d.z) >> 31) != s0) edge_row((unsigned)i, 1);
-      if ((__float_as_uint(d.w) >> 31) != s0) edge_row((unsigned)i, 2);
-    }
-    for (int k = 0; k < nnb; k++) edge_row(contrib[k], caxis[k]);
     const float im = 1.f / (float)nr;
     const float bsx = invRes * (im * mx - cox), bsy = invRes * (im * my - coy), bsz = invRes * (im * mz - coz);
     sA[nr][0][t] = sqrtLambda; sA[nr][1][t] = 0.0f; sA[nr][2][t] = 0.0f; sB[nr][t] = sqrtLambda * bsx; nr++;
@@ -625,6 +622,45 @@ __global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restri
     }
     const float xf = dm::clampf((float)x[0], -0.1f, 1.1f), yf = dm::clampf((float)x[1], -0.1f, 1.1f), zf = dm::clampf((float)x[2], -0.1f, 1.1f);
     fv[3 * i] = res * xf + cox; fv[3 * i + 1] = res * yf + coy; fv[3 * i + 2] = res * zf + coz;
+  };
+  auto drain = [&](unsigned count) {  // the cubes at the ring's head, a lane each (each lane owns column t of the LDS arrays)
+    __syncthreads();  // (one wave: the queue's writes are in LDS)
+    if (t < count) place((uint64_t)s_q[(head + t) & 127u]);
+    head += count;
+  };
+  const uint64_t step = (uint64_t)gridDim.x * DC_BLOCK;
+  for (uint64_t base = (uint64_t)blockIdx.x * DC_BLOCK;; base += step) {  // wave-uniform trip count; past the list's end: what is left in the queue
+    const bool more = base < n;
+    unsigned pp = 0;
+    unsigned long long kk = 0;
+    bool placed = false;
+    unsigned idx = 0;
+    if (more && dc_flat_to_part(base + t, np, pp, kk)) {
+      const uint64_t i = (uint64_t)pp * cseg + kk;
+      idx = (unsigned)i;
+      const Cube c = cubes[i];
+      if (c.z < zplace_hi) {  // (top halo layer: only its distances/normals are needed)
+        // len(cube.Neighbors) != 0: an active edge among the cell's twelve (the same walk as place()'s, which lists them)
+        for (int dz = 0; dz < 2; dz++)
+          for (int dy = 0; dy < 2; dy++)
+            for (int dx = 0; dx < 2; dx++) {
+              const int ux = c.x + dx, uy = c.y + dy, uz = c.z + dz;
+              if (ux >= nn || uy >= nn || uz >= nn) continue;
+              const int ui = grid[((size_t)uz * nn + uy) * nn + ux];
+              if (ui < 0) continue;
+              const float4 d = dists[ui];
+              const unsigned s0 = __float_as_uint(d.x) >> 31;
+              placed = placed || (dx == 0 && ((__float_as_uint(d.y) >> 31) != s0)) || (dy == 0 && ((__float_as_uint(d.z) >> 31) != s0)) ||
+                       (dz == 0 && ((__float_as_uint(d.w) >> 31) != s0));
+            }
+      }
+    }
+    const unsigned long long m = __ballot(placed);
+    if (placed) s_q[(tail + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))) & 127u] = idx;
+    tail += (unsigned)__builtin_popcountll(m);
+    const unsigned waiting = tail - head;
+    if (waiting >= 64u || (!more && waiting != 0u)) drain(waiting < 64u ? waiting : 64u);  // (the solve's only call site: it is inlined once)
+    if (!more && tail == head) break;
   }
 }
 
