@@ -719,6 +719,7 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     const uint64_t crun_cap = DC_PARTS * dc_cube_run_seg(ntiles), erun_cap = DC_PARTS * dc_edge_run_seg(ccap, ntiles);
     HIP_TRYM(p->q0.ensure((ccap + crun_cap) * sizeof(Cube)));
     HIP_TRYM(p->dc_erun.ensure(erun_cap * sizeof(unsigned long long)));
+    HIP_TRYM(p->dc_flag.ensure(ccap));  // "this cube is placed", a byte per cube: set by the edge stage, read by the placement stage
     HIP_TRYM(d2.ensure(ccap * sizeof(float4)));
     HIP_TRYM(f2.ensure(ccap * 12));
     HIP_TRYM(n2.ensure(ccap * 36));
@@ -729,6 +730,7 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
       if (!m->d_tris) { HIP_TRYM(hipMalloc((void**)&m->d_tris, tcap * 36)); m->cap = tcap; }
     }
     HIP_TRYM(hipMemsetAsync(d_ctr, 0, sizeof(DCCounters), s));
+    HIP_TRYM(hipMemsetAsync(p->dc_flag.p, 0, ccap, s));
     if (shard_count > 1) HIP_TRYM(hipMemsetAsync(grid.p, 0xff, ncell * sizeof(int), s));  // cells outside the slab read as empty
     HIP_TRYM(hipEventRecord(p->ev[0], s));
     static const int origin_grid = [] { const char* e = getenv("GSDF_HIP_DC_ORIGIN_GRID"); return e ? atoi(e) : 0; }();  // developer knob: workgroups of the origin sweep (1 = tiles strictly in order)
@@ -769,10 +771,10 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     HIP_TRYM(hipEventRecord(p->ev_b[0], s));  // origin sweep done
     if (p->lds_bytes(4) > 150 * 1024) return bail(fail(GSDF_ERR_BAD_TREE, "tree needs too much LDS scratch for the dual contouring edge pass"));
     if (p->f_dc_edges) HIP_TRYM(launch_fn(p->f_dc_edges, grid_for(ccap, p->num_cu, 8), BLOCK, p->lds_bytes(4), s, (const uint32_t*)p->d_code, (const Cube*)p->q0.p,
-                       (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, (unsigned long long*)p->dc_erun.p, (unsigned long long)ntiles, d_ctr));
+                       (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, (unsigned long long*)p->dc_erun.p, (unsigned long long)ntiles, (const int*)grid.p, (int)nshift, (unsigned char*)p->dc_flag.p, d_ctr));
     else
     hipLaunchKernelGGL(dc_edges_kernel, dim3(grid_for(ccap, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(4), s, p->d_code, (const Cube*)p->q0.p,
-                       (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, (unsigned long long*)p->dc_erun.p, (unsigned long long)ntiles, d_ctr);
+                       (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, (unsigned long long*)p->dc_erun.p, (unsigned long long)ntiles, (const int*)grid.p, (int)nshift, (unsigned char*)p->dc_flag.p, d_ctr);
     HIP_TRYM(hipGetLastError());
     HIP_TRYM(hipEventRecord(p->ev_b[1], s));  // edges done
     if (p->f_dc_normals) HIP_TRYM(launch_fn(p->f_dc_normals, grid_for(ecap, p->num_cu, 8), BLOCK, p->lds_bytes(2), s, (const uint32_t*)p->d_code, (const Cube*)p->q0.p,
@@ -784,7 +786,7 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     HIP_TRYM(hipEventRecord(p->ev_b[2], s));  // normals done
     hipLaunchKernelGGL(dc_place_kernel, dim3(grid_for(ccap * 4, p->num_cu, 16)), dim3(DC_BLOCK), 0, s, (const Cube*)p->q0.p,
                        (unsigned long long)ccap, (const float4*)d2.p, (const int*)grid.p, (const float*)n2.p, nshift, ox, oy, oz, res,
-                       sqrtLambda, (float*)f2.p, zown_hi, d_ctr);
+                       sqrtLambda, (float*)f2.p, zown_hi, (const unsigned char*)p->dc_flag.p, d_ctr);
     HIP_TRYM(hipGetLastError());
     HIP_TRYM(hipEventRecord(p->ev_b[3], s));  // placement done
     hipLaunchKernelGGL(dc_quads_kernel, dim3(grid_for(ecap, p->num_cu, 8)), dim3(BLOCK), 0, s, (const Cube*)p->q0.p, (const float4*)d2.p,

@@ -50,7 +50,7 @@ struct gsdf_program {
       return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-  } q0, q1, ctr, spec_pass, dc_tile, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, dc_erun, flat_grid, flat_bits, flat_list, rec, hdr, grp, b_q0, b_q1, b_ctr, b_spec_pass, b_rec, b_hdr, b_grp;  // b_*: the octree mesher's second workspace (its second chain in flight runs on stream_b, beside the first: gsdf_hip_mesh_octree_start)  // flat_bits: sign and near-surface bit planes of the flat renderer's lattice (flat_grid_kernel -> flat_cut_scan_kernel), flat_list: the cut cubes (-> flat_march_list_kernel)  // rec / hdr: cut-leaf records and block headers of the two-kernel leaf phase (the group sums follow the counters in ctr)  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
+  } q0, q1, ctr, spec_pass, dc_tile, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, dc_erun, dc_flag, flat_grid, flat_bits, flat_list, rec, hdr, grp, b_q0, b_q1, b_ctr, b_spec_pass, b_rec, b_hdr, b_grp;  // b_*: the octree mesher's second workspace (its second chain in flight runs on stream_b, beside the first: gsdf_hip_mesh_octree_start)  // flat_bits: sign and near-surface bit planes of the flat renderer's lattice (flat_grid_kernel -> flat_cut_scan_kernel), flat_list: the cut cubes (-> flat_march_list_kernel)  // rec / hdr: cut-leaf records and block headers of the two-kernel leaf phase (the group sums follow the counters in ctr)  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_b[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // second set: the octree mesher has up to two chains in flight (gsdf_hip_mesh_octree_start)
   static constexpr int kJobs = 2;

@@ -336,6 +336,7 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_edges_kernel(const uint32_t* __re
                                                             float4* __restrict__ dists, float* __restrict__ fv,
                                                             unsigned* __restrict__ edges, unsigned long long edge_cap,
                                                             unsigned long long* __restrict__ edge_runs, unsigned long long ntiles /* of the origin sweep */,
+                                                            const int* __restrict__ grid, int nshift, unsigned char* __restrict__ placed /* one per cube, cleared: <- 1 for the cubes around an active edge */,
                                                             DCCounters* __restrict__ ctr) {
   code_ptr code = as_code(code_g);
   float* lds = g_smem + threadIdx.x;
@@ -430,6 +431,31 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_edges_kernel(const uint32_t* __re
             }
           }
           base += s_tot[q];
+          // The cubes this cube's active edges belong to -- itself and, per edge, the three at -1 along the other two axes
+          // (EdgeNeighborsX/Y/Z, dual_contour.go:271-287) -- are the ones the placement stage solves for (len(cube.Neighbors) != 0,
+          // dual_contour_vertexplacement.go:52-60): marked here, three grid lookups per active edge, instead of every kept cube
+          // walking the eight cubes of its cell there (22 M lookups against 2.5 M for npt-flange at resdiv 800).
+          if ((pend & 7u) != 0u) {
+            const Cube c = cubes[cube];
+            placed[cube] = 1;
+            const int nn = 1 << nshift;
+            (void)nn;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+              if ((pend >> a) & 1u) {
+                const int b1 = (a + 1) % 3, b2 = (a + 2) % 3;
+#pragma unroll
+                for (int k = 1; k < 4; k++) {
+                  int o[3] = {0, 0, 0};
+                  o[b1] = -(k & 1); o[b2] = -(k >> 1);
+                  const int x = (int)c.x + o[0], y = (int)c.y + o[1], z = (int)c.z + o[2];
+                  if (x < 0 || y < 0 || z < 0) continue;
+                  const int ui = grid[((size_t)z << (2 * nshift)) + ((size_t)y << nshift) + (size_t)x];
+                  if (ui >= 0) placed[ui] = 1;
+                }
+              }
+            }
+          }
         }
         const unsigned long long room = ebase < eseg ? eseg - ebase : 0ull;
         const unsigned n = room < sum ? (unsigned)room : sum, nsub = (sum + 63u) >> 6;
@@ -504,7 +530,7 @@ __global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restri
                                                             const float4* __restrict__ dists, const int* __restrict__ grid,
                                                             const float* __restrict__ nrm, int nshift, float ox, float oy, float oz,
                                                             float res, float sqrtLambda, float* __restrict__ fv, unsigned zplace_hi,
-                                                            DCCounters* __restrict__ ctr) {
+                                                            const unsigned char* __restrict__ placed_flag /* dc_edges_kernel's marks */, DCCounters* __restrict__ ctr) {
   __shared__ float sA[DC_ROWS][3][DC_BLOCK];
   __shared__ float sB[DC_ROWS][DC_BLOCK];
   const unsigned long long cseg = cube_cap / DC_PARTS;
@@ -514,8 +540,8 @@ __global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restri
   const unsigned t = threadIdx.x;
   // Two cubes in five are placed (the ones with an active edge among the twelve of their cell; the kept cubes are a band four cells
   // thick around the surface), and taken 64 at a time in list order the least-squares solve ran with that share of its lanes. So the
-  // workgroup -- one wave -- first ASKS which of its next 64 cubes are placed and queues those (a ring of 128 indices in LDS); the
-  // solve runs whenever 64 are waiting, on full waves.
+  // workgroup -- one wave -- first asks which of its next 64 cubes are placed (a byte per cube, set by the edge stage) and queues those
+  // (a ring of 128 indices in LDS); the solve runs whenever 64 are waiting, on full waves.
   __shared__ unsigned s_q[128];
   unsigned head = 0, tail = 0;  // (wave-uniform)
   auto place = [&](const uint64_t i) {
@@ -638,22 +664,9 @@ __global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restri
     if (more && dc_flat_to_part(base + t, np, pp, kk)) {
       const uint64_t i = (uint64_t)pp * cseg + kk;
       idx = (unsigned)i;
-      const Cube c = cubes[i];
-      if (c.z < zplace_hi) {  // (top halo layer: only its distances/normals are needed)
-        // len(cube.Neighbors) != 0: an active edge among the cell's twelve (the same walk as place()'s, which lists them)
-        for (int dz = 0; dz < 2; dz++)
-          for (int dy = 0; dy < 2; dy++)
-            for (int dx = 0; dx < 2; dx++) {
-              const int ux = c.x + dx, uy = c.y + dy, uz = c.z + dz;
-              if (ux >= nn || uy >= nn || uz >= nn) continue;
-              const int ui = grid[((size_t)uz * nn + uy) * nn + ux];
-              if (ui < 0) continue;
-              const float4 d = dists[ui];
-              const unsigned s0 = __float_as_uint(d.x) >> 31;
-              placed = placed || (dx == 0 && ((__float_as_uint(d.y) >> 31) != s0)) || (dy == 0 && ((__float_as_uint(d.z) >> 31) != s0)) ||
-                       (dz == 0 && ((__float_as_uint(d.w) >> 31) != s0));
-            }
-      }
+      // len(cube.Neighbors) != 0: an active edge among the cell's twelve -- the edge stage marked those cubes (top halo layer of a
+      // z-slab: only its distances / normals are needed)
+      placed = placed_flag[i] != 0 && cubes[i].z < zplace_hi;
     }
     const unsigned long long m = __ballot(placed);
     if (placed) s_q[(tail + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))) & 127u] = idx;
