@@ -689,6 +689,8 @@ def main():
                 "note": "marching cubes over the cut-leaf records: 40 B read per record + 36 B written per triangle"},
             "stages": dc_stages,
             "phase_ms_rank0": {"prune": st.ms_prune, "leaf": st.ms_leaf, "eval_kernel": st.ms_march, "march_kernel": st.ms_emit, "total_device": st.ms_total},
+            "phase_note": ("event-to-event spans of the timed loop's LAST mesh" + (": it shares the device with the other mesh in flight, so the spans overlap the other chain's kernels "
+                           "(a mesh with the device to itself: roofline.ms_per_mesh_device_alone)" if mesh_pipeline else "")),
         }
         if dc and dc_stages:  # counters of the same kernels, if a summary under profiles/ carries this workload and this code key
             for k, v in pmc_dc_stages(workload, code).items():
