@@ -507,6 +507,10 @@ extern "C" int gsdf_hip_mesh_octree_start(gsdf_program* p, float res, const gsdf
   if ((opts.prune & GSDF_PRUNE_ASSUME_SDF) && j->pmask == 0) j->pmask = 1;
   j->ptest = (opts.prune & GSDF_PRUNE_ASSUME_SDF) ? 2 : 1;
   p->leaf_config(&j->lk, &j->lw, &j->lds_m);
+  {
+    static const size_t lds_pad = [] { const char* e = getenv("GSDF_HIP_LEAF_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();  // developer knob: LDS a leaf workgroup asks for beyond its need (occupancy experiments)
+    j->lds_m += lds_pad;
+  }
   j->qcap = j->w.q0.cap / sizeof(Cube);
   {
     // 1 M cubes (8 MB) per queue to start with; GSDF_HIP_QCAP_MIN lowers it so that tests can drive the
