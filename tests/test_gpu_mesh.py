@@ -383,6 +383,22 @@ def test_cube_queue_overflow_grows_and_reruns(gpu, monkeypatch):
         assert _digest(oc.RenderAll()) == g["sha256_sorted"]
 
 
+def test_dualcontour_lists_regrow(gpu):
+    """The cube and edge lists are sized from the handle's previous dual-contouring mesh (a floor of 2^20 cubes, in eight parts): a
+    fine mesh after a coarse one on the same handle overflows its parts, learns their exact sizes from the counters and repeats --
+    the same triangles as on a fresh handle, whose first guess is ample."""
+    b = Builder()
+    s = b.Scene("npt-flange")
+    res = np.float32(float(s.Diagonal()) / 800)
+    used = gpu.SDF3HIP(s)
+    assert gpu.DualContourHIP(used, np.float32(float(s.Diagonal()) / 60)).n_tris() > 0
+    again = gpu.DualContourHIP(used, res)
+    fresh = gpu.DualContourHIP(gpu.SDF3HIP(s), res)
+    assert again.stats.leaf_cubes == fresh.stats.leaf_cubes > (1 << 20)          # (more kept cubes than the floor: the first attempt overflowed)
+    assert again.n_tris() == fresh.n_tris() and again.stats.evals == fresh.stats.evals
+    assert _digest(again.RenderAll()) == _digest(fresh.RenderAll())
+
+
 def test_dualcontour_exact_box_early_out(gpu):
     """A long thin exact-distance part fills a few percent of the reference's cubic lattice: cells farther than 2*res
     outside the part's box are decided without evaluation -- identical mesh, a fraction of the evaluations. The same
