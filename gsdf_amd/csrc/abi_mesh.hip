@@ -721,7 +721,7 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     const uint64_t ecap = 3 * ccap, tcap = 2 * ecap;
     // run descriptors (kernels_dc.h: DC_DESC): the origin sweep's follow the cubes in q0, the edge stage's have an arena of their own
     const uint64_t crun_cap = DC_PARTS * dc_cube_run_seg(ntiles), erun_cap = DC_PARTS * dc_edge_run_seg(ccap, ntiles);
-    HIP_TRYM(p->q0.ensure((ccap + crun_cap) * sizeof(Cube)));
+    HIP_TRYM(p->q0.ensure((ccap + crun_cap) * sizeof(Cube) + ccap * sizeof(float)));  // (+ the sweep's distance of every kept cube, behind the descriptors)
     HIP_TRYM(p->dc_erun.ensure(erun_cap * sizeof(unsigned long long)));
     HIP_TRYM(p->dc_flag.ensure(ccap));  // "this cube is placed", a byte per cube: set by the edge stage, read by the placement stage
     HIP_TRYM(d2.ensure(ccap * sizeof(float4)));
@@ -774,10 +774,10 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     HIP_TRYM(hipGetLastError());
     HIP_TRYM(hipEventRecord(p->ev_b[0], s));  // origin sweep done
     if (p->lds_bytes(4) > 150 * 1024) return bail(fail(GSDF_ERR_BAD_TREE, "tree needs too much LDS scratch for the dual contouring edge pass"));
-    if (p->f_dc_edges) HIP_TRYM(launch_fn(p->f_dc_edges, grid_for(ccap, p->num_cu, 8), BLOCK, p->lds_bytes(4), s, (const uint32_t*)p->d_code, (const Cube*)p->q0.p,
+    if (p->f_dc_edges) HIP_TRYM(launch_fn(p->f_dc_edges, grid_for(ccap, p->num_cu, 8), BLOCK, p->lds_bytes(3), s, (const uint32_t*)p->d_code, (const Cube*)p->q0.p,
                        (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, (unsigned long long*)p->dc_erun.p, (unsigned long long)ntiles, (const int*)grid.p, (int)nshift, (unsigned char*)p->dc_flag.p, d_ctr));
     else
-    hipLaunchKernelGGL(dc_edges_kernel, dim3(grid_for(ccap, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(4), s, p->d_code, (const Cube*)p->q0.p,
+    hipLaunchKernelGGL(dc_edges_kernel, dim3(grid_for(ccap, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(3), s, p->d_code, (const Cube*)p->q0.p,
                        (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, (unsigned long long*)p->dc_erun.p, (unsigned long long)ntiles, (const int*)grid.p, (int)nshift, (unsigned char*)p->dc_flag.p, d_ctr);
     HIP_TRYM(hipGetLastError());
     HIP_TRYM(hipEventRecord(p->ev_b[1], s));  // edges done
@@ -838,9 +838,9 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
   p->last_dc_cubes = last_cap;  // (DC_PARTS times the fullest part: what the next mesh of this handle sizes its arrays by)
   m->st.n_tris = 2 * hc.n_tris;  // quads -> 2 triangles
   for (int k = 0; k < 64; k++) hc.n_origin_evals += hc.n_origin_part[k * 8];
-  m->st.evals = hc.n_origin_evals + 4 * n_cubes + 6 * n_edges;
+  m->st.evals = hc.n_origin_evals + 3 * n_cubes + 6 * n_edges;  // (performed: a kept cube's origin is the sweep's evaluation, not repeated by the edge stage)
   m->st.evals_prune = hc.n_origin_evals;  // of the nslab lattice cells; the rest lay outside the exact box by > 2 res
-  m->st.evals_leaf = 4 * n_cubes + 6 * n_edges;
+  m->st.evals_leaf = 3 * n_cubes + 6 * n_edges;
   m->st.pruned_leaves = nslab - n_cubes;
   m->st.leaf_cubes = n_cubes;
   m->st.active_leaves = n_edges;

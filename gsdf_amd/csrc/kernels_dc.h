@@ -46,6 +46,8 @@ struct DCCounters {
 //                                          is a multiple of DC_PARTS, so to part T % DC_PARTS
 //   edges                                : 3 per cube; edge runs: one per 64 edges and one more per cube run (its last, ragged one)
 __host__ __device__ __forceinline__ unsigned long long dc_cube_run_seg(unsigned long long ntiles) { return (ntiles + DC_PARTS - 1) / DC_PARTS + 1; }
+// The origin sweep's distances of the kept cubes (one float each) wait for the edge stage behind the cubes' run descriptors.
+__host__ __device__ __forceinline__ unsigned long long dc_origin_dist_offset_words(unsigned long long ntiles) { return DC_PARTS * dc_cube_run_seg(ntiles); }
 __host__ __device__ __forceinline__ unsigned long long dc_edge_run_seg(unsigned long long cube_cap, unsigned long long ntiles) {
   return 3 * (cube_cap / DC_PARTS) / 64 + dc_cube_run_seg(ntiles) + 8;
 }
@@ -210,6 +212,7 @@ __global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __r
   unsigned long long* const my_word = &ctr->cubes_w[part * DC_WORD_STRIDE];
   const unsigned long long cseg = cube_cap / DC_PARTS, cfirst = (unsigned long long)part * cseg;
   unsigned long long* const my_runs = (unsigned long long*)(cubes + cube_cap) + (unsigned long long)part * dc_cube_run_seg(ntiles);
+  float* const origin_dist = (float*)((unsigned long long*)(cubes + cube_cap) + dc_origin_dist_offset_words(ntiles));  // [cube]: the edge stage's first point is this one
   for (uint64_t T = blockIdx.x; T < ntiles; T += gridDim.x) {  // block-uniform trip count
     // a tile whose four blocks the interval test cleared: nothing kept, nothing to write (the grid of the range was cleared to -1)
     if (block_keep != nullptr) {
@@ -302,6 +305,7 @@ __global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __r
       if (keep[kp]) {
         if (slot < cseg) {
           cubes[cfirst + slot] = Cube{(uint16_t)cx[kp], (uint16_t)cy[kp], (uint16_t)cz[kp], 0};
+          origin_dist[cfirst + slot] = d[kp];
           grid[c] = (int)(cfirst + slot);
         } else {
           ctr->q_overflow = 1ull;
@@ -324,8 +328,8 @@ __global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __r
   }
 }
 
-// Stage 2 (RenderAll :85-108): origin, +x, +y, +z distances of every kept cube (one 4-point pass per
-// lane); default FinalVertex = cube origin; active edges (sign BIT differs, :261-269) are compacted.
+// Stage 2 (RenderAll :85-108): origin, +x, +y, +z distances of every kept cube (one 3-point pass per
+// lane + the sweep's value of the origin); default FinalVertex = cube origin; active edges (sign BIT differs, :261-269) are compacted.
 // Work item = a run of the origin sweep (DC_DESC): the cubes of one tile, 256 per pass; a wave without a cube of the run
 // skips the evaluation, lanes past the run's end repeat its last cube (a dummy position would stretch the wave's bounding box).
 // The edges are appended once per run (DC_EDGE_PASSES passes = the 1024 cells of the largest tile: one atomic); until then a pass's active edges wait in
@@ -345,6 +349,7 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_edges_kernel(const uint32_t* __re
   __shared__ unsigned long long s_word;
   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const unsigned long long* __restrict__ cube_runs = (const unsigned long long*)(cubes + cube_cap);
+  const float* __restrict__ origin_dist = (const float*)(cube_runs + dc_origin_dist_offset_words(ntiles));
   const unsigned long long crseg = dc_cube_run_seg(ntiles);
   unsigned long long nr[DC_PARTS];
   const unsigned long long nruns = dc_part_counts<true>(ctr->cubes_w, crseg, nr);  // the cube runs of all parts, one after the other
@@ -375,10 +380,14 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_edges_kernel(const uint32_t* __re
       const uint64_t i = first + (valid ? j : cnt - 1u);
       const Cube c = cubes[i];
       const float x0 = ox + res * (float)c.x, y0 = oy + res * (float)c.y, z0 = oz + res * (float)c.z;
-      P3 p[4] = {{x0, y0, z0}, {x0 + res, y0 + 0.f, z0 + 0.f}, {x0 + 0.f, y0 + res, z0 + 0.f}, {x0 + 0.f, y0 + 0.f, z0 + res}};
-      float d[4] = {0.f, 0.f, 0.f, 0.f};
+      // The cube's own origin was evaluated by the sweep -- the same float position (O + res * i, formed the same way), hence the same
+      // bits: it is read back; the three points a cell further along x, y, z are evaluated here (the reference forms them as
+      // origin + res, not as the neighbour's O + res * (i + 1): they are not the neighbours' origins bit for bit).
+      P3 p[3] = {{x0 + res, y0 + 0.f, z0 + 0.f}, {x0 + 0.f, y0 + res, z0 + 0.f}, {x0 + 0.f, y0 + 0.f, z0 + res}};
+      float d3[3] = {0.f, 0.f, 0.f};
       if (__builtin_amdgcn_ballot_w64(valid) != 0ull)  // (wave-uniform)
-        gsdf_dev::sdf_eval<4>(code, p, d, lds, BLOCK, /*brick=*/true);  // (a wave's cubes are neighbours within one tile: edge culling on)
+        gsdf_dev::sdf_eval<3>(code, p, d3, lds, BLOCK, /*brick=*/true);  // (a wave's cubes are neighbours within one tile: edge culling on)
+      const float d[4] = {origin_dist[i], d3[0], d3[1], d3[2]};
       if (valid) {
         dists[i] = make_float4(d[0], d[1], d[2], d[3]);
         fv[3 * i] = x0; fv[3 * i + 1] = y0; fv[3 * i + 2] = z0;
