@@ -807,16 +807,29 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
         const uint32_t nv = hdr & 0x7fffffffu;
         const float v0x = PF(1), v0y = PF(2);
         const uint32_t q0 = (pc + 4u + 7u) & ~7u;
-        float d[K];
-        bool neg[K];
-        bool done = false;
-        uint64_t keepd = ~0ull, keeps = ~0ull;
-        if (brick && nv >= 6u && nv <= 64u) poly_cull<K>(code, q0, nv, pv, keepd, keeps);  // a spatially compact wave: a 4x4x4-leaf brick, a patch of lattice cells, a run of kept cubes
-        if (hdr >> 31) done = poly_edges<K, true>(code, q0, nv, v0x, v0y, pv, d, neg, keepd, keeps);
-        if (!done) poly_edges<K, false>(code, q0, nv, v0x, v0y, pv, d, neg, keepd, keeps);
-        KLOOP {
-          float sd = sqrtf_(d[kp]);
-          Rv[kp] = neg[kp] ? -sd : sd;  // s * sqrt(d), s = +-1
+        if (LIP) {
+          // interval mode: the lane's two points are the same centre (bit for bit: every position instruction treats them alike) --
+          // the polygon once, the value into both columns (the primitives' widening by the radius follows below)
+          const P3 p1[1] = {pv[0]};
+          float d1[1];
+          bool neg1[1];
+          bool done1 = false;
+          if (hdr >> 31) done1 = poly_edges<1, true>(code, q0, nv, v0x, v0y, p1, d1, neg1);
+          if (!done1) poly_edges<1, false>(code, q0, nv, v0x, v0y, p1, d1, neg1);
+          const float sd = sqrtf_(d1[0]);
+          KLOOP Rv[kp] = neg1[0] ? -sd : sd;
+        } else {
+          float d[K];
+          bool neg[K];
+          bool done = false;
+          uint64_t keepd = ~0ull, keeps = ~0ull;
+          if (brick && nv >= 6u && nv <= 64u) poly_cull<K>(code, q0, nv, pv, keepd, keeps);  // a spatially compact wave: a 4x4x4-leaf brick, a patch of lattice cells, a run of kept cubes
+          if (hdr >> 31) done = poly_edges<K, true>(code, q0, nv, v0x, v0y, pv, d, neg, keepd, keeps);
+          if (!done) poly_edges<K, false>(code, q0, nv, v0x, v0y, pv, d, neg, keepd, keeps);
+          KLOOP {
+            float sd = sqrtf_(d[kp]);
+            Rv[kp] = neg[kp] ? -sd : sd;  // s * sqrt(d), s = +-1
+          }
         }
         pc = q0 + 8u * nv;
         break;
