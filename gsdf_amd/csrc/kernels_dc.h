@@ -529,19 +529,16 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_normals_kernel(const uint32_t* __
 #define DC_BLOCK 64
 // Stage 4 (PlaceVertices :52-141, leastSquaresMGS64 :152-223): per cube, rows = own active edges, then the
 // edges of the (up to 12) contributing cubes in lattice order (z,y,x) and axis order, 3 regularisation rows;
-// float64 modified Gram-Schmidt over rows staged in LDS ([row][col][lane]; zero rows are exact no-ops). Every entry of the
-// system is a float32 value (normals, products formed in float32), so the rows are STORED as float32 -- 16 bytes per row and
-// lane instead of 32 -- and the orthonormalised columns the reference keeps in place (A[k][j] -= dot * A[k][i]; A[k][j] *= inv)
+// float64 modified Gram-Schmidt. Every entry of the system is a float32 value (normals, products formed in float32), so the rows
+// are KEPT as float32 and the orthonormalised columns the reference keeps in place (A[k][j] -= dot * A[k][i]; A[k][j] *= inv)
 // are recomputed from them wherever they are read: the same float64 operations on the same operands in the same order, hence
-// the same bits, for a few more multiply-adds in a kernel that waits on occupancy (36.9 -> 18.4 KB of LDS per 64 lanes:
-// 8 workgroups per CU instead of 4).
+// the same bits. Since round 5 the rows are in registers at fixed places (see place() below; until then in LDS, [row][col][lane],
+// 18.4 KB per 64 lanes).
 __global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restrict__ cubes, unsigned long long cube_cap,
                                                             const float4* __restrict__ dists, const int* __restrict__ grid,
                                                             const float* __restrict__ nrm, int nshift, float ox, float oy, float oz,
                                                             float res, float sqrtLambda, float* __restrict__ fv, unsigned zplace_hi,
                                                             const unsigned char* __restrict__ placed_flag /* dc_edges_kernel's marks */, DCCounters* __restrict__ ctr) {
-  __shared__ float sA[DC_ROWS][3][DC_BLOCK];
-  __shared__ float sB[DC_ROWS][DC_BLOCK];
   const unsigned long long cseg = cube_cap / DC_PARTS;
   unsigned long long np[DC_PARTS];
   const unsigned long long n = dc_part_counts<false>(ctr->cubes_w, cseg, np);  // the cubes of all parts, one after the other
@@ -557,68 +554,85 @@ __global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restri
     const Cube c = cubes[i];
     const float cox = ox + res * (float)c.x, coy = oy + res * (float)c.y, coz = oz + res * (float)c.z;
     const float invRes = 1.0f / res;
+    // The system's rows live in REGISTERS, one fixed place per edge of the cell: 0..2 the cube's own edges, 3..14 the cell's twelve in
+    // lattice order (z, y, x) and axis order -- the order the reference appends them in -- 15..17 the regularisation rows; an edge
+    // that is not active leaves its row zero, and a zero row adds +-0 to sums that start at +0: an exact no-op (the sums never
+    // hold -0: they start at +0 and a cancellation gives +0). Every loop over the rows is unrolled: no LDS, no row count in the
+    // loops' bounds -- the kernel had 18.4 KB of LDS per wave (two waves per SIMD) and a trip to LDS for every operand.
+    float A0[DC_ROWS], A1[DC_ROWS], A2[DC_ROWS], Bv[DC_ROWS];
+#pragma unroll
+    for (int k = 0; k < DC_ROWS; k++) { A0[k] = 0.f; A1[k] = 0.f; A2[k] = 0.f; Bv[k] = 0.f; }
     int nr = 0;
     float mx = 0.f, my = 0.f, mz = 0.f;
-    auto add_row = [&](float bx, float by, float bz, float nx, float ny, float nz) {
-      const float qx = invRes * (bx - cox), qy = invRes * (by - coy), qz = invRes * (bz - coz);
-      sA[nr][0][t] = nx; sA[nr][1][t] = ny; sA[nr][2][t] = nz;
-      sB[nr][t] = nx * qx + ny * qy + nz * qz;
-      mx = mx + bx; my = my + by; mz = mz + bz;
-      nr++;
-    };
-    auto edge_row = [&](unsigned ci, int a) {
+    auto edge_row = [&](const int slot, unsigned ci, int a) {  // (slot: a constant after unrolling)
       const Cube u = cubes[ci];
       const float4 d = dists[ci];
       const float tt = res * dc_isect(d.x, a == 0 ? d.y : (a == 1 ? d.z : d.w));
       const float ux = ox + res * (float)u.x, uy = oy + res * (float)u.y, uz = oz + res * (float)u.z;
       const size_t o = ((size_t)ci * 3 + (size_t)a) * 3;
-      add_row(ux + (a == 0 ? tt : 0.f), uy + (a == 1 ? tt : 0.f), uz + (a == 2 ? tt : 0.f), nrm[o], nrm[o + 1], nrm[o + 2]);
+      const float bx = ux + (a == 0 ? tt : 0.f), by = uy + (a == 1 ? tt : 0.f), bz = uz + (a == 2 ? tt : 0.f);
+      const float nx = nrm[o], ny = nrm[o + 1], nz = nrm[o + 2];
+      const float qx = invRes * (bx - cox), qy = invRes * (by - coy), qz = invRes * (bz - coz);
+      A0[slot] = nx; A1[slot] = ny; A2[slot] = nz;
+      Bv[slot] = nx * qx + ny * qy + nz * qz;
+      mx = mx + bx; my = my + by; mz = mz + bz;
+      nr++;
     };
     // (whether the cube is placed at all -- len(cube.Neighbors) != 0 -- was decided when it was queued)
     {
       const float4 d = dists[i];
       const unsigned s0 = __float_as_uint(d.x) >> 31;
-      if ((__float_as_uint(d.y) >> 31) != s0) edge_row((unsigned)i, 0);
-      if ((__float_as_uint(d.z) >> 31) != s0) edge_row((unsigned)i, 1);
-      if ((__float_as_uint(d.w) >> 31) != s0) edge_row((unsigned)i, 2);
+      if ((__float_as_uint(d.y) >> 31) != s0) edge_row(0, (unsigned)i, 0);
+      if ((__float_as_uint(d.z) >> 31) != s0) edge_row(1, (unsigned)i, 1);
+      if ((__float_as_uint(d.w) >> 31) != s0) edge_row(2, (unsigned)i, 2);
     }
     // the active edges of the cell, in lattice order (z, y, x) and axis order
-    for (int dz = 0; dz < 2; dz++)
-      for (int dy = 0; dy < 2; dy++)
-        for (int dx = 0; dx < 2; dx++) {
-          const int ux = c.x + dx, uy = c.y + dy, uz = c.z + dz;
-          if (ux >= nn || uy >= nn || uz >= nn) continue;
-          const int ui = grid[((size_t)uz * nn + uy) * nn + ux];
-          if (ui < 0) continue;
-          const float4 d = dists[ui];
-          const unsigned s0 = __float_as_uint(d.x) >> 31;
-          if (dx == 0 && ((__float_as_uint(d.y) >> 31) != s0)) edge_row((unsigned)ui, 0);
-          if (dy == 0 && ((__float_as_uint(d.z) >> 31) != s0)) edge_row((unsigned)ui, 1);
-          if (dz == 0 && ((__float_as_uint(d.w) >> 31) != s0)) edge_row((unsigned)ui, 2);
-        }
+    {
+      int slot = 3;
+#pragma unroll
+      for (int dz = 0; dz < 2; dz++)
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+          for (int dx = 0; dx < 2; dx++) {
+            const int s_x = slot, s_y = slot + (dx == 0 ? 1 : 0), s_z = s_y + (dy == 0 ? 1 : 0);  // this neighbour's places: x, y, z edges as far as it has them
+            slot = s_z + (dz == 0 ? 1 : 0);
+            const int ux = c.x + dx, uy = c.y + dy, uz = c.z + dz;
+            if (ux >= nn || uy >= nn || uz >= nn) continue;
+            const int ui = grid[((size_t)uz * nn + uy) * nn + ux];
+            if (ui < 0) continue;
+            const float4 d = dists[ui];
+            const unsigned s0 = __float_as_uint(d.x) >> 31;
+            if (dx == 0 && ((__float_as_uint(d.y) >> 31) != s0)) edge_row(s_x, (unsigned)ui, 0);
+            if (dy == 0 && ((__float_as_uint(d.z) >> 31) != s0)) edge_row(s_y, (unsigned)ui, 1);
+            if (dz == 0 && ((__float_as_uint(d.w) >> 31) != s0)) edge_row(s_z, (unsigned)ui, 2);
+          }
+    }
     const float im = 1.f / (float)nr;
     const float bsx = invRes * (im * mx - cox), bsy = invRes * (im * my - coy), bsz = invRes * (im * mz - coz);
-    sA[nr][0][t] = sqrtLambda; sA[nr][1][t] = 0.0f; sA[nr][2][t] = 0.0f; sB[nr][t] = sqrtLambda * bsx; nr++;
-    sA[nr][0][t] = 0.0f; sA[nr][1][t] = sqrtLambda; sA[nr][2][t] = 0.0f; sB[nr][t] = sqrtLambda * bsy; nr++;
-    sA[nr][0][t] = 0.0f; sA[nr][1][t] = 0.0f; sA[nr][2][t] = sqrtLambda; sB[nr][t] = sqrtLambda * bsz; nr++;
-    const int K = nr;
+    A0[15] = sqrtLambda; Bv[15] = sqrtLambda * bsx;
+    A1[16] = sqrtLambda; Bv[16] = sqrtLambda * bsy;
+    A2[17] = sqrtLambda; Bv[17] = sqrtLambda * bsz;
     double R[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     // leastSquaresMGS64 :152-223, column by column; qJ(k) = what the reference's A[k][J] holds once column J is done
     // column 0: normalise
     double nsq = 0;
-    for (int k = 0; k < K; k++) { const double a = (double)sA[k][0][t]; nsq += a * a; }
+#pragma unroll
+    for (int k = 0; k < DC_ROWS; k++) { const double a = (double)A0[k]; nsq += a * a; }
     const double norm0 = __builtin_sqrt(nsq);
     R[0][0] = norm0;
     const bool have0 = norm0 > 1e-14;
     const double inv0 = 1.0 / norm0;
-#define DC_Q0(k) (have0 ? (double)sA[k][0][t] * inv0 : (double)sA[k][0][t])
+#define DC_Q0(k) (have0 ? (double)A0[k] * inv0 : (double)A0[k])
     // column 1: minus its projection on q0, then normalise
     double dot01 = 0;
-    for (int k = 0; k < K; k++) dot01 += DC_Q0(k) * (double)sA[k][1][t];
+#pragma unroll
+    for (int k = 0; k < DC_ROWS; k++) dot01 += DC_Q0(k) * (double)A1[k];
     R[0][1] = dot01;
-#define DC_V1(k) ((double)sA[k][1][t] - dot01 * DC_Q0(k))
+#define DC_V1(k) ((double)A1[k] - dot01 * DC_Q0(k))
     nsq = 0;
-    for (int k = 0; k < K; k++) { const double v = DC_V1(k); nsq += v * v; }
+#pragma unroll
+    for (int k = 0; k < DC_ROWS; k++) { const double v = DC_V1(k); nsq += v * v; }
     const double norm1 = __builtin_sqrt(nsq);
     R[1][1] = norm1;
     const bool have1 = norm1 > 1e-14;
@@ -626,23 +640,29 @@ __global__ void __launch_bounds__(DC_BLOCK) dc_place_kernel(const Cube* __restri
 #define DC_Q1(k) (have1 ? DC_V1(k) * inv1 : DC_V1(k))
     // column 2: minus its projections on q0 and (what is left) on q1, then normalise
     double dot02 = 0;
-    for (int k = 0; k < K; k++) dot02 += DC_Q0(k) * (double)sA[k][2][t];
+#pragma unroll
+    for (int k = 0; k < DC_ROWS; k++) dot02 += DC_Q0(k) * (double)A2[k];
     R[0][2] = dot02;
-#define DC_W2(k) ((double)sA[k][2][t] - dot02 * DC_Q0(k))
+#define DC_W2(k) ((double)A2[k] - dot02 * DC_Q0(k))
     double dot12 = 0;
-    for (int k = 0; k < K; k++) dot12 += DC_Q1(k) * DC_W2(k);
+#pragma unroll
+    for (int k = 0; k < DC_ROWS; k++) dot12 += DC_Q1(k) * DC_W2(k);
     R[1][2] = dot12;
 #define DC_V2(k) (DC_W2(k) - dot12 * DC_Q1(k))
     nsq = 0;
-    for (int k = 0; k < K; k++) { const double v = DC_V2(k); nsq += v * v; }
+#pragma unroll
+    for (int k = 0; k < DC_ROWS; k++) { const double v = DC_V2(k); nsq += v * v; }
     const double norm2 = __builtin_sqrt(nsq);
     R[2][2] = norm2;
     const bool have2 = norm2 > 1e-14;
     const double inv2 = 1.0 / norm2;
     double Qtb[3] = {0, 0, 0};
-    for (int k = 0; k < K; k++) Qtb[0] += DC_Q0(k) * (double)sB[k][t];
-    for (int k = 0; k < K; k++) Qtb[1] += DC_Q1(k) * (double)sB[k][t];
-    for (int k = 0; k < K; k++) { const double v = DC_V2(k); Qtb[2] += (have2 ? v * inv2 : v) * (double)sB[k][t]; }
+#pragma unroll
+    for (int k = 0; k < DC_ROWS; k++) Qtb[0] += DC_Q0(k) * (double)Bv[k];
+#pragma unroll
+    for (int k = 0; k < DC_ROWS; k++) Qtb[1] += DC_Q1(k) * (double)Bv[k];
+#pragma unroll
+    for (int k = 0; k < DC_ROWS; k++) { const double v = DC_V2(k); Qtb[2] += (have2 ? v * inv2 : v) * (double)Bv[k]; }
 #undef DC_Q0
 #undef DC_V1
 #undef DC_Q1
