@@ -246,7 +246,9 @@ typedef struct gsdf_mesh_job gsdf_mesh_job;
 int gsdf_hip_mesh_octree_start(gsdf_program* p, float res, const gsdf_mesh_opts* opts, gsdf_mesh_job** job);
 int gsdf_hip_mesh_octree_wait(gsdf_mesh_job* job, gsdf_mesh** out);
 /* Dual contouring (least-squares vertex placement; chiseled = DualContourLeastSquares.Chiseled). The result is a
- * gsdf_mesh like the octree mesher's (stats: leaf_cubes = kept cubes, active_leaves = active edges). Multi-GPU: rank
+ * gsdf_mesh like the octree mesher's (stats: leaf_cubes = kept cubes, active_leaves = active edges; evals = the evaluations
+ * performed -- fewer than the reference's: lattice blocks an interval evaluation proves empty are not swept, and a kept cube's own
+ * origin is evaluated once, by the sweep, not again with its three edge ends). Multi-GPU: rank
  * shard_rank of shard_count emits the quads of its z-slab of the lattice (one-cube halo recomputed, nothing exchanged). */
 int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chiseled, int shard_rank, int shard_count, void* stream,
                               gsdf_mesh** out);
