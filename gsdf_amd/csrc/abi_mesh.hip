@@ -774,10 +774,13 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
     HIP_TRYM(hipGetLastError());
     HIP_TRYM(hipEventRecord(p->ev_b[0], s));  // origin sweep done
     if (p->lds_bytes(4) > 150 * 1024) return bail(fail(GSDF_ERR_BAD_TREE, "tree needs too much LDS scratch for the dual contouring edge pass"));
-    if (p->f_dc_edges) HIP_TRYM(launch_fn(p->f_dc_edges, grid_for(ccap, p->num_cu, 8), BLOCK, p->lds_bytes(3), s, (const uint32_t*)p->d_code, (const Cube*)p->q0.p,
+    // (a multiple of DC_PARTS like the sweep's grid: run r goes to workgroup r % grid, hence to the edge list's part r % DC_PARTS --
+    // what bounds a part's edge-run descriptors, dc_edge_run_seg)
+    const unsigned g_edges = (grid_for(ccap, p->num_cu, 8) + DC_PARTS - 1) / DC_PARTS * DC_PARTS;
+    if (p->f_dc_edges) HIP_TRYM(launch_fn(p->f_dc_edges, g_edges, BLOCK, p->lds_bytes(3), s, (const uint32_t*)p->d_code, (const Cube*)p->q0.p,
                        (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, (unsigned long long*)p->dc_erun.p, (unsigned long long)ntiles, (const int*)grid.p, (int)nshift, (unsigned char*)p->dc_flag.p, d_ctr));
     else
-    hipLaunchKernelGGL(dc_edges_kernel, dim3(grid_for(ccap, p->num_cu, 8)), dim3(BLOCK), p->lds_bytes(3), s, p->d_code, (const Cube*)p->q0.p,
+    hipLaunchKernelGGL(dc_edges_kernel, dim3(g_edges), dim3(BLOCK), p->lds_bytes(3), s, p->d_code, (const Cube*)p->q0.p,
                        (unsigned long long)ccap, ox, oy, oz, res, (float4*)d2.p, (float*)f2.p, (unsigned*)e2.p, (unsigned long long)ecap, (unsigned long long*)p->dc_erun.p, (unsigned long long)ntiles, (const int*)grid.p, (int)nshift, (unsigned char*)p->dc_flag.p, d_ctr);
     HIP_TRYM(hipGetLastError());
     HIP_TRYM(hipEventRecord(p->ev_b[1], s));  // edges done

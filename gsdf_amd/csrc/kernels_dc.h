@@ -295,7 +295,8 @@ __global__ void __launch_bounds__(BLOCK, W) dc_origin_kernel(const uint32_t* __r
       *s_base = b;
       // this pass's run (a run past the part's capacity has no entries: the mesh is repeated with more room)
       const unsigned long long room = b < cseg ? cseg - b : 0ull;
-      my_runs[DC_W_RUNS(w)] = DC_DESC(cfirst + b, room < total ? room : total);
+      if (DC_W_RUNS(w) < dc_cube_run_seg(ntiles)) my_runs[DC_W_RUNS(w)] = DC_DESC(cfirst + b, room < total ? room : total);  // (one run per tile of the part at most: the bound holds by construction, the test keeps a wrong launch from writing elsewhere)
+      else ctr->q_overflow = 1ull;
     }
     __syncthreads();
     unsigned long long slot = *s_base + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + (incl - mine);  // (within the part)
@@ -468,8 +469,12 @@ __global__ void __launch_bounds__(BLOCK, 3) dc_edges_kernel(const uint32_t* __re
         }
         const unsigned long long room = ebase < eseg ? eseg - ebase : 0ull;
         const unsigned n = room < sum ? (unsigned)room : sum, nsub = (sum + 63u) >> 6;
-        for (unsigned k = threadIdx.x; k < nsub; k += BLOCK)
-          my_runs[DC_W_RUNS(wd) + k] = DC_DESC(efirst + ebase + 64u * k, 64u * k >= n ? 0u : (n - 64u * k < 64u ? n - 64u * k : 64u));
+        const unsigned long long erseg = dc_edge_run_seg(cube_cap, ntiles);
+        for (unsigned k = threadIdx.x; k < nsub; k += BLOCK) {
+          // (a part whose edges overflow its share of the array -- the mesh is repeated then -- may also run out of descriptors)
+          if (DC_W_RUNS(wd) + k < erseg) my_runs[DC_W_RUNS(wd) + k] = DC_DESC(efirst + ebase + 64u * k, 64u * k >= n ? 0u : (n - 64u * k < 64u ? n - 64u * k : 64u));
+          else ctr->q_overflow = 1ull;
+        }
       }
       npend = 0;
     }
