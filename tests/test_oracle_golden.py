@@ -297,3 +297,23 @@ def test_reference_octree_schedule_near_pin():
     assert m.levels == 9 and m.n_tris == 309872
     assert m.evals == 14684160 == 4096 + 8 * 4096 * 448
     assert abs(m.evals - 14646431) == 37729 and abs(100.0 * m.pruned / 8 ** (m.levels - 1) - 89.08) < 0.02
+
+
+def test_reference_octree_schedule_simulated():
+    """What the level mask above leaves over is the reference's own bookkeeping, and its own files state it (tests/refsched.py):
+    every ReadTriangles call centre-tests whatever is still in the prune buffer AGAIN (octreerenderer.go:147-153), and corners
+    evaluated but not marched when RenderAll's 4096-triangle buffer fills up stay in the position buffer and are evaluated again
+    (:155-176, marchcubes.go:22-33). Simulated call by call over the oracle's evaluator -- 104 calls, 423,852 triangles -- the count
+    lands within 0.004 % of the README's 46,148,745 under 19 of 24 assumed forms of the external ms3.Octree operations (-490 ...
+    +1,695; the other five prune one more big cube in the tail: -35 K ... -196 K; tools/refsched_grid.py), and within 0.001 %
+    under the form asserted here; the
+    showerhead's 14,646,431 within 0.02 % under the same form (+2,703; -14 K ... +44 K over the forms: its tail decompositions
+    depend on the order SafeSpread / SafeMove hand cubes back in). The last digits are the external semantics', not the field's."""
+    from refsched import RefSchedule
+    b = Builder()
+    s = b.Scene("npt-flange")
+    res = np.float32(float(s.Diagonal()) / 400)
+    r = RefSchedule(OracleSDF(s.tree()), res, move_from="front", spread_from="front", spread_append=True, margin=2).render_all()
+    assert r.levels == 10 and r.tris == 423852 and r.calls == 104
+    assert r.evals == 46148745 - 398
+    assert f"{100.0 * 8 * r.pruned / (r.evals + 8 * r.pruned):.1f}" == "95.7"
