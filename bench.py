@@ -228,59 +228,81 @@ def evaluate_dropin(hip, sdf, shader, n=32768, calls=300):
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, one wave64 VALU op per 2 cycles, 2.4 GHz
 
 
-def pmc_summary(workload, code=None):
-    """Latest committed rocprofv3 PMC summary of THIS workload AND THIS code (profiles/*_pmc_summary.json carry the bench
-    line's config.workload and config.code they were collected under; the match is on scene, resdiv and the kernels' code key,
-    gsdf_hip_program_kernels). {} if there is none: a line never carries another workload's counters, nor those of kernels
-    that have since been edited."""
+def _pmc_files(workload, want):
+    """Committed rocprofv3 PMC summaries (profiles/*_pmc_summary.json) of THIS workload (scene and resdiv), newest first; `want(j)` picks
+    the kind (octree / dual contouring)."""
     import glob
     import re
     key = re.match(r"examples/(\S+) resdiv (\d+)", workload or "")
     if not key:
-        return {}
+        return
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
         try:
             j = json.load(open(f))
         except Exception:
             continue
         k2 = re.match(r"examples/(\S+) resdiv (\d+)", j.get("workload", ""))
-        d = j.get("leaf_eval_kernel") or j.get("leaf_kernel")
-        if d and k2 and k2.groups() == key.groups() and (code is None or j.get("code") == code):  # summaries of other commands (eval mode, flat renderer) carry no leaf_kernel entry
-            return dict(d, source=os.path.basename(f))
-    return {}
+        if k2 and k2.groups() == key.groups() and want(j):
+            yield f, j
+
+
+def pmc_summary(workload, code=None):
+    """Counters of the evaluating kernel for THIS workload from the committed profiles: the newest summary whose code key
+    (gsdf_hip_program_kernels: a hash of the kernels' sources and the program) equals the running kernels' -> code_match True;
+    failing that the newest one of the workload with code_match False (the line says so: roofline.counters). A line never carries
+    another workload's counters. {} if there is none."""
+    first = None
+    for f, j in _pmc_files(workload, lambda j: j.get("leaf_eval_kernel") or j.get("leaf_kernel")):
+        d = dict(j.get("leaf_eval_kernel") or j.get("leaf_kernel"), source=os.path.basename(f))
+        if code is None or j.get("code") == code:
+            return dict(d, code_match=True)
+        first = first or dict(d, code_match=False)
+    return first or {}
 
 
 def pmc_dc_stages(workload, code=None):
-    """Per-stage counters of the dual contouring kernels from the newest committed PMC summary of THIS workload and THIS code
-    (tools/gpu_dc_prof.sh): {stage: {...}} or {}."""
-    import glob
-    import re
-    key = re.match(r"examples/(\S+) resdiv (\d+)", workload or "")
-    if not key:
-        return {}
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
-        try:
-            j = json.load(open(f))
-        except Exception:
-            continue
-        k2 = re.match(r"examples/(\S+) resdiv (\d+)", j.get("workload", ""))
-        if not (k2 and k2.groups() == key.groups() and "dc_origin_kernel" in j and "dual contouring" in j.get("workload", "")):
-            continue
-        if code is not None and j.get("code") != code:
-            continue
+    """Per-stage counters of the dual contouring kernels, chosen like pmc_summary: ({stage: {...}}, code_match)."""
+    first = None
+    for f, j in _pmc_files(workload, lambda j: "dc_origin_kernel" in j and "dual contouring" in j.get("workload", "")):
         out = {}
         for st in ("dc_block_test", "dc_origin", "dc_edges", "dc_normals", "dc_place", "dc_quads"):
             d = j.get(st + "_kernel")
             if d:
                 out[st] = {k: d[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "hbm_traffic_gb_per_launch", "wave_wait_any_frac", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE") if k in d}
                 out[st]["counters_from"] = os.path.basename(f)
-        return out
-    return {}
+        if code is None or j.get("code") == code:
+            return out, True
+        first = first or (out, False)
+    return first or ({}, None)
 
 
-def pmc_traffic_gb(workload, code=None):
-    """HBM bytes per leaf_kernel launch: 2*FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE, KB -> GB."""
-    return pmc_summary(workload, code).get("hbm_traffic_gb_per_launch")
+def counters_note(source, match):
+    """Where a line's instruction / traffic counters come from -- never measured by bench.py itself (PMC needs rocprofv3)."""
+    if not source:
+        return "none: no committed PMC summary of this workload (achieved / frac / traffic are null)"
+    return (f"read from profiles/{source} (rocprofv3 --pmc passes of this workload, tools/gpu_profile.sh), not measured in this run; "
+            + ("its code key equals the running kernels'" if match else "its code key DIFFERS from the running kernels': the kernels were edited after that profile"))
+
+
+def copy_rate_gbs(rbytes, wbytes):
+    """Live: GB/s a plain HIP copy kernel (16 B per lane, best of plain / nontemporal variants and grid sizes) reaches on this box
+    for a stream of `rbytes` read + `wbytes` written (tools/ubench/copy_rate.hip, built by __graft_entry__.build()). None if unbuilt."""
+    import ctypes as C
+    so = os.path.join(ROOT, "tools", "ubench", "libcopyrate.so")
+    if not os.path.exists(so):
+        return None
+    L = C.CDLL(so)
+    L.copy_rate_ms.restype = C.c_float
+    L.copy_rate_ms.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int]
+    best = None
+    for v, name in ((0, "plain"), (1, "nt-store"), (2, "nt-load+store")):
+        for bpc in (4, 8, 16):
+            ms = L.copy_rate_ms(int(rbytes), int(wbytes), v, 30, bpc)
+            if ms > 0 and (best is None or ms < best[0]):
+                best = (ms, name, bpc)
+    if best is None:
+        return None
+    return {"gb_per_s": (rbytes + wbytes) / (best[0] * 1e-3) / 1e9, "ms": best[0], "variant": best[1], "workgroups_per_cu": best[2]}
 
 
 def valu_roofline(kernel_evals_per_s, workload, code=None):
@@ -291,7 +313,7 @@ def valu_roofline(kernel_evals_per_s, workload, code=None):
     if not per_eval:
         return None
     ach = per_eval * kernel_evals_per_s
-    out = {"lane_instr_per_eval": per_eval, "counters_from": pm.get("source"), "achieved": ach / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-instr/s",
+    out = {"lane_instr_per_eval": per_eval, "counters_from": pm.get("source"), "code_match": pm.get("code_match"), "achieved": ach / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-instr/s",
            "frac": ach / VALU_PEAK_LANE_OPS}
     mix = pm.get("valu_mix")
     if mix and mix.get("cycles_per_instr_by_class"):
@@ -371,18 +393,52 @@ def flat_mode(args, torch, np, hip, shader, sdf, res, spec_note):
     g_ms /= args.steps
     m_ms /= args.steps
     alg_gb = (4.0 * ev + 36.0 * nt) / 1e9
-    achieved = alg_gb / (m_ms * 1e-3)
+    # dominant kernel: the lattice pass (flat_grid_kernel, 80 % of a mesh), VALU-bound like the octree's leaf kernel; its instruction
+    # count from the newest committed PMC summary of the flat renderer (tools/gpu_profile.sh ... --mode flat), if any
+    import glob
+    vi = src = match = None
+    code = sdf.info()["kernels"].get("code")
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_flat_pmc_summary.json")), reverse=True):
+        j = json.load(open(f))
+        if args.scene in j.get("workload", "") and str(args.resdiv) in j.get("workload", "") and "flat_grid_kernel" in j and (vi is None or j.get("code") == code):
+            vi, src, match = j["flat_grid_kernel"].get("SQ_INSTS_VALU"), os.path.basename(f), (j.get("code") == code)  # the newest, or the one of this code
+            traffic = j["flat_grid_kernel"].get("hbm_traffic_gb_per_launch")
+            if match:
+                break
+    ach = vi * 64 / (g_ms * 1e-3) if vi else None
     print(json.dumps({
+        "schema": 6,
         "metric": "sdf_evals_per_s", "value": ev * args.steps / dt, "unit": "evals/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"FlatRenderer on device: {args.scene} resdiv {args.resdiv}, {ev} lattice corners, {nt} triangles; {spec_note}"},
+        "config": {"workload": f"FlatRenderer on device: {args.scene} resdiv {args.resdiv}, {ev} lattice corners, {nt} triangles; {spec_note}", "code": code},
         "triangles": nt, "triangles_per_s": nt * args.steps / dt,
-        "lattice_pass": {"kernel": "flat_grid_kernel<K>", "kernel_ms": g_ms, "evals_per_s": ev / (g_ms * 1e-3)},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "flat_march_kernel" if streaming else "flat_cut_scan_kernel + flat_march_list_kernel",
-                     "kernel_ms": m_ms, "algorithmic_gb_per_launch": alg_gb,
-                     "note": "marching phase (both kernels); notional for the bit-plane pass, whose measured HBM traffic is in profiles/*_flat_pmc_summary.json"}}), flush=True)
+        "roofline": {"bound": "valu", "kernel": "flat_grid_kernel<K>", "kernel_ms": g_ms, "kernel_evals_per_s": ev / (g_ms * 1e-3),
+                     "achieved": ach / 1e12 if ach else None, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-instr/s", "frac": ach / VALU_PEAK_LANE_OPS if ach else None,
+                     "traffic": traffic if vi else None, "traffic_unit": "GB per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)", "counters": counters_note(src, match),
+                     "hbm_notional": {"algorithmic_gb_per_launch": 16.0 * ev / 1e9, "gb_per_s": 16.0 * ev / 1e9 / (g_ms * 1e-3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "note": "16 B per lattice corner as SURVEY 8(d) counts an evaluation; the kernel writes the 4-B distance and two sign bits, positions are generated in registers"}},
+        "roofline_march": {"bound": "hbm", "kernel": "flat_march_kernel" if streaming else "flat_cut_scan_kernel + flat_march_list_kernel",
+                           "kernel_ms": m_ms, "algorithmic_gb_per_launch": alg_gb, "notional_gb_per_s": alg_gb / (m_ms * 1e-3),
+                           "note": "marching phase (both kernels) priced as SURVEY 8(d) counts it, 4 B per corner + 36 B per triangle -- NOTIONAL: the bit-plane pass reads two bits per "
+                                   "corner and the eight distances of the cut cubes only (measured HBM traffic: profiles/*_flat_pmc_summary.json), so no fraction of the peak is formed"}}), flush=True)
+
+
+def self_launch(n):
+    """Re-execute this command line as N ranks: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port <a free one> bench.py <the same arguments>. The launched form keeps working as before (WORLD_SIZE set)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL and hipIpcGetMemHandle need on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench: --gpus %d without a launcher: starting %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -423,7 +479,14 @@ def main():
     ap.add_argument("--share-corners", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2, 3],
                     help="0: every corner of every leaf, as the reference (headline); 1: each bitwise-distinct lattice corner of a brick once (older fused kernel); "
                          "2: the bitwise-distinct z rows of a brick once each (same kernels, same triangles, a quarter fewer evaluations)")
+    ap.add_argument("--no-gather-modes", action="store_true",
+                    help="N > 1: skip the two extra timed loops (the gather modes other than --gather) that follow the headline loop")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver starts the N = 1 line: become the launcher -- one rank per GPU under
+        # torch.distributed.run on this node -- and pass the ranks' output through (rank 0 prints the one JSON line)
+        raise SystemExit(self_launch(args.gpus))
 
     import numpy as np
     import torch
@@ -434,8 +497,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, or without a launcher")
     dist = None
     comm = None
     torch_gather = False
@@ -518,11 +580,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    gmode = {"all": hip.GATHER_ALL, "root": hip.GATHER_ROOT, "none": hip.GATHER_NONE}[args.gather]
+    GM = {"all": hip.GATHER_ALL, "root": hip.GATHER_ROOT, "none": hip.GATHER_NONE}
     pipeline = comm is not None and not args.no_gather_pipeline
-    # what moves in the gather: packed cut-leaf records by default (marching cubes then runs on the receiving ranks)
-    records = (comm is not None and args.payload == "records" and args.gather != "none" and args.renderer == "octree")
-    payload = hip.PAYLOAD_RECORDS if records else hip.PAYLOAD_TRIANGLES
+    dc = args.renderer == "dualcontour"
+    G = {}  # the gather of the loop being run (use_gather): mode, what moves, the payload constant
+
+    def use_gather(mode):
+        # what moves in the gather: packed cut-leaf records by default (marching cubes then runs on the receiving ranks)
+        G["mode"] = mode
+        G["records"] = (comm is not None and args.payload == "records" and mode != "none" and not dc)
+        G["payload"] = hip.PAYLOAD_RECORDS if G["records"] else hip.PAYLOAD_TRIANGLES
+    use_gather(args.gather)
     gstat = {"n": 0, "ms_counts": 0.0, "ms_payload": 0.0, "ms_march": 0.0, "bytes_received": 0, "bytes_sent": 0}
     pending = []  # at most one gather in flight: (PendingGather)
 
@@ -539,15 +607,15 @@ def main():
         return g
 
     def step():
-        if args.renderer == "dualcontour":  # BASELINE configs[4]: dual contouring, z-slabs of the lattice per rank
+        if dc:  # BASELINE configs[4]: dual contouring, z-slabs of the lattice per rank
             oc = hip.DualContourHIP(sdf, res, shard_rank=rank, shard_count=world)
         else:
-            oc = hip.OctreeHIP(sdf, res, shard_rank=rank, shard_count=world, share_corners=args.share_corners, payload=payload)
+            oc = hip.OctreeHIP(sdf, res, shard_rank=rank, shard_count=world, share_corners=args.share_corners, payload=G["payload"])
         gathered = None
         if comm is not None:
             # the counts are exchanged and the payload enqueued on the communicator's stream; with the pipeline on, the
             # previous mesh's payload is awaited only now, i.e. it moved while this mesh was made
-            pg = oc.gatherv_start(comm, gmode, 0)
+            pg = oc.gatherv_start(comm, GM[G["mode"]], 0)
             gathered = finish()
             pending.append(pg)
             if not pipeline:
@@ -559,7 +627,7 @@ def main():
 
     # Setup, untimed: bring the GPU out of its idle clock state before the W warmup steps. The first ~20 meshes after
     # start-up run 5 % slower (1.70 vs 1.61 ms leaf kernel), and with the contract's small W they would be the ones timed.
-    mesh_pipeline = (comm is None and not torch_gather and args.renderer == "octree" and not args.no_mesh_pipeline)
+    mesh_pipeline = (comm is None and not torch_gather and not dc and not args.no_mesh_pipeline)
 
     def run_meshes(n, account=None, sc=None):
         """n meshes, every one started and finished inside this call. Pipelined (N = 1): mesh k + 1 is started -- its chain of kernels
@@ -581,57 +649,109 @@ def main():
             pend = nxt
         return last
 
+    def timed_loop():
+        """The contract's loop for the gather in use: W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides;
+        the time is the maximum over the ranks, evaluations and triangles the sums."""
+        run_meshes(args.warmup)
+        finish()
+        for k in gstat:
+            gstat[k] = 0
+        acc = {"evals": 0, "tris": 0, "march_ms": 0.0, "march_evals": 0.0, "march_tris": 0.0, "emit_ms": 0.0, "cut": 0.0}
+
+        def account(oc):
+            st = oc.stats
+            acc["evals"] += st.evals
+            acc["tris"] += st.n_tris
+            acc["march_ms"] += st.ms_march
+            acc["march_evals"] += st.evals_leaf
+            acc["march_tris"] += st.n_tris
+            acc["emit_ms"] += st.ms_emit
+            acc["cut"] += st.cut_leaves
+
+        barrier()
+        t0 = time.perf_counter()
+        last = run_meshes(args.steps, account)
+        gl = finish()  # the last mesh's gather belongs to the timed region too
+        if gl is not None:
+            last = (last[0], gl)
+        barrier()
+        dt = time.perf_counter() - t0
+        tot = torch.tensor([float(acc["evals"]), float(acc["tris"]), dt], dtype=torch.float64, device=dev if torch_gather else "cpu")
+        evals_minmax = None
+        if dist is not None:
+            tmax = tot.clone()
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax[2])
+            # load balance of the brick partition: evaluations per step of the least and the most loaded rank
+            lo = torch.tensor([float(acc["evals"])], dtype=torch.float64, device=tot.device)
+            hi = lo.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            evals_minmax = (float(lo[0]) / args.steps, float(hi[0]) / args.steps)
+        r = {"last": last, "acc": acc, "dt": dt, "evals_all": float(tot[0]), "tris_all": float(tot[1]), "evals_minmax": evals_minmax,
+             "gstat": dict(gstat), "mode": G["mode"], "records": G["records"]}
+        if dist is not None and rank == 0 and last[1] is not None:
+            ng = last[1].n_tris() if hasattr(last[1], "n_tris") else int(last[1].shape[0])
+            assert ng == int(r["tris_all"] / args.steps), "gathered triangle count differs from the sum of the ranks'"
+        return r
+
+    def gather_report(r):
+        """One timed loop's gather as the line reports it (rank 0's HIP events on the communicator's stream)."""
+        gs, n = r["gstat"], max(1, r["gstat"]["n"])
+        step_ms = r["dt"] / args.steps * 1e3
+        g_ms = (gs["ms_counts"] + gs["ms_payload"] + gs["ms_march"]) / n
+        st = r["last"][0].stats
+        return {"mode": r["mode"], "pipelined": pipeline, "payload": "records" if r["records"] else "triangles",
+                "transport": comm.transport(), "ms_per_step": step_ms, "evals_per_s": r["evals_all"] / r["dt"], "triangles_per_s": r["tris_all"] / r["dt"],
+                "bytes_received_per_rank": gs["bytes_received"] / n, "bytes_sent_per_rank": gs["bytes_sent"] / n, "ms": g_ms,
+                "ms_counts": gs["ms_counts"] / n, "ms_payload": gs["ms_payload"] / n, "ms_march_after_gather": gs["ms_march"] / n,
+                "evals_per_step_min_max_over_ranks": r["evals_minmax"],
+                # how much of the shorter of the two (meshing on the device, gather on the wire) hid behind the other
+                "overlap_frac": max(0.0, min(1.0, (st.ms_total + g_ms - step_ms) / max(1e-9, min(st.ms_total, g_ms))))}
+
     run_meshes(args.preheat)
-    run_meshes(args.warmup)
-    finish()
-    for k in gstat:
-        gstat[k] = 0
-    acc = {"evals": 0, "tris": 0, "march_ms": 0.0, "march_evals": 0.0, "march_tris": 0.0, "emit_ms": 0.0, "cut": 0.0}
+    H = timed_loop()  # the headline: the gather mode --gather names (default all)
+    gather_modes = None
+    if comm is not None:
+        # Beside the headline, after it: the SAME loop with the other two gather modes, so that one N > 1 run separates what the
+        # compute scales to (none: every rank keeps its shard) from what the wire allows (root, all) -- xGMI is one ~60 GB/s link per
+        # peer, one GPU emits triangles at 400 GB/s (DESIGN.md section 7)
+        gather_modes = {args.gather: gather_report(H)}
+        if not args.no_gather_modes:
+            for mode in ("all", "root", "none"):
+                if mode != args.gather:
+                    use_gather(mode)
+                    gather_modes[mode] = gather_report(timed_loop())
+            use_gather(args.gather)
+    last, dt, evals_all, tris_all = H["last"], H["dt"], H["evals_all"], H["tris_all"]
+    evals, tris, march_ms, march_evals, march_tris, emit_ms, cut = (H["acc"][k] for k in ("evals", "tris", "march_ms", "march_evals", "march_tris", "emit_ms", "cut"))
+    records = H["records"]
 
-    def account(oc):
-        st = oc.stats
-        acc["evals"] += st.evals
-        acc["tris"] += st.n_tris
-        acc["march_ms"] += st.ms_march
-        acc["march_evals"] += st.evals_leaf
-        acc["march_tris"] += st.n_tris
-        acc["emit_ms"] += st.ms_emit
-        acc["cut"] += st.cut_leaves
-
+    # The dominant kernel ALONE, after the timed loops: blocking meshes of rank 0's shard with the device to itself (the other
+    # ranks wait at the barrier -- they may share rank 0's device), no gather. Every line takes its roofline from these.
     barrier()
-    t0 = time.perf_counter()
-    last = run_meshes(args.steps, account)
-    evals, tris, march_ms, march_evals, march_tris, emit_ms, cut = (acc[k] for k in ("evals", "tris", "march_ms", "march_evals", "march_tris", "emit_ms", "cut"))
-    gl = finish()  # the last mesh's gather belongs to the timed region too
-    if gl is not None:
-        last = (last[0], gl)
+    alone = None
+    if rank == 0 and not dc:
+        alone = [hip.OctreeHIP(sdf, res, shard_rank=rank, shard_count=world, share_corners=args.share_corners).stats for _ in range(8)][2:]
+    elif rank == 0:
+        alone = [hip.DualContourHIP(sdf, res, shard_rank=rank, shard_count=world) for _ in range(4)][1:]
+        alone_stage_ms = [a.stage_ms() for a in alone]
     barrier()
-    dt = time.perf_counter() - t0
-
-    tot = torch.tensor([float(evals), float(tris), dt], dtype=torch.float64, device=dev if torch_gather else "cpu")
-    if dist is not None:
-        tmax = tot.clone()
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax[2])
-    evals_all, tris_all = float(tot[0]), float(tot[1])
-    evals_minmax = None
-    if dist is not None:  # load balance of the brick partition: evaluations per step of the least and the most loaded rank
-        lo = torch.tensor([float(evals)], dtype=torch.float64, device=tot.device)
-        hi = lo.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        evals_minmax = (float(lo[0]) / args.steps, float(hi[0]) / args.steps)
 
     if rank == 0:
         oc, g = last
         st = oc.stats
-        # dominant kernel: leaf_eval_kernel (fused mode: leaf_kernel). ALGORITHMIC bytes per launch = 16 B per evaluation it performs
-        # (12 B position + 4 B distance; positions are generated on device but counted) + 36 B per triangle.
-        dc = args.renderer == "dualcontour"
+        workload = (f"examples/{args.scene} resdiv {args.resdiv}: "
+                    + ("dual contouring (least-squares vertex placement) on device " if dc else "octree prune + marching cubes on device ")
+                    + f"(res {float(res):.7f}, {st.levels} levels)")
+        kern = sdf.info()["kernels"]
+        code = kern.get("code")
         dc_stages = None
-        if dc:  # five stages, timed apart by HIP events (gsdf_hip_mesh_stage_ms): the roofline line is the longest one's
-            sm = oc.stage_ms()
+        two_kernel = emit_ms > 0 or (alone is not None and not dc and alone[0].ms_emit > 0)  # leaf phase = leaf_eval_kernel (dominant) + march_records_kernel
+        if dc:
+            # five stages, timed apart by HIP events (gsdf_hip_mesh_stage_ms): the roofline is the longest one's
+            sm = {k: sum(a[k] for a in alone_stage_ms) / len(alone_stage_ms) for k in alone_stage_ms[0]}
             nc, ne, nq, no = float(st.leaf_cubes), float(st.active_leaves), float(st.n_tris) / 2, float(st.evals_prune)
             alg = {"dc_origin": 16.0 * no + 4.0 * no,            # position + distance per evaluated cell, + its index-grid word
                    "dc_edges": 16.0 * 4 * nc + 8.0 * nc + 28.0 * nc + 4.0 * ne,  # 4 evaluations per kept cube, its cube word in, distances + default vertex out, an edge word per active edge
@@ -640,24 +760,47 @@ def main():
                    "dc_quads": 72.0 * nq + 4.0 * ne + 4 * 12.0 * nq}  # two triangles out per quad, four vertices + an edge word in
             dc_stages = {k: {"ms": v, "algorithmic_gb": alg[k] / 1e9, "gb_per_s": alg[k] / 1e9 / (v * 1e-3) if v > 0 else 0.0} for k, v in sm.items()}
             kmax = max(sm, key=sm.get)
-            march_ms, march_evals, march_tris = sm[kmax] * args.steps, float(st.evals) * args.steps, float(st.n_tris) * args.steps
-        k_ms = march_ms / max(1, args.steps)
-        two_kernel = emit_ms > 0  # leaf phase = leaf_eval_kernel (dominant) + march_records_kernel
-        # ALGORITHMIC bytes of the dominant kernel: 16 B per evaluation; the fused kernel also emits the
-        # triangles (36 B each), the evaluating kernel of the two-kernel phase hands 40-byte cut-leaf records on instead
-        k_bytes = (march_evals * 16.0 + (cut * 40.0 if two_kernel else march_tris * 36.0)) / max(1, args.steps)
-        if dc:
-            k_bytes = dc_stages[kmax]["algorithmic_gb"] * 1e9
-        e_ms = emit_ms / max(1, args.steps)
-        e_bytes = (cut * 40.0 + march_tris * 36.0) / max(1, args.steps)
-        achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        kernel_rate = (march_evals / max(1, args.steps)) / (k_ms * 1e-3) if k_ms > 0 else 0.0
-        workload = (f"examples/{args.scene} resdiv {args.resdiv}: "
-                    + ("dual contouring (least-squares vertex placement) on device " if dc else "octree prune + marching cubes on device ")
-                    + f"(res {float(res):.7f}, {st.levels} levels)")
-        kern = sdf.info()["kernels"]
-        code = kern.get("code")
+            pm_st, pm_match = pmc_dc_stages(workload, code)
+            for k, v in pm_st.items():  # counters of the same kernels, if a summary under profiles/ carries this workload
+                dc_stages.setdefault(k, {})["pmc"] = v
+            vi = (pm_st.get(kmax) or {}).get("SQ_INSTS_VALU")
+            ach = (vi * 64 / (sm[kmax] * 1e-3)) if (vi and world == 1) else None
+            rf = {"bound": "valu", "kernel": kmax + "_kernel (the longest of the five stages; all of them under 'stages')", "kernel_ms": sm[kmax],
+                  "achieved": ach / 1e12 if ach else None, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-instr/s",
+                  "frac": ach / VALU_PEAK_LANE_OPS if ach else None, "traffic": (pm_st.get(kmax) or {}).get("hbm_traffic_gb_per_launch"),
+                  "traffic_unit": "GB per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
+                  "counters": counters_note((pm_st.get(kmax) or {}).get("counters_from"), pm_match),
+                  "hbm_notional": {"algorithmic_gb_per_launch": alg[kmax] / 1e9, "gb_per_s": dc_stages[kmax]["gb_per_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+                  "note": "stage times of blocking meshes after the timed loop; achieved = SQ_INSTS_VALU x 64 lanes of that stage's kernel (PMC summary) / its time"}
+        else:
+            # ALGORITHMIC bytes of the dominant kernel: 16 B per evaluation it performs (12 B position + 4 B distance;
+            # positions are generated on device but counted); the evaluating kernel of the two-kernel leaf phase hands 40-byte
+            # cut-leaf records on, the fused kernel emits the triangles (36 B each). Notional by construction: the kernel moves 6 %
+            # of that (PMC traffic) -- so it is reported as bytes and GB/s, never as a fraction of the HBM peak.
+            a_ms = sum(a.ms_march for a in alone) / len(alone)
+            a_ev = sum(a.evals_leaf for a in alone) / len(alone)
+            a_cut = sum(a.cut_leaves for a in alone) / len(alone)
+            a_tri = sum(a.n_tris for a in alone) / len(alone)
+            k_bytes = a_ev * 16.0 + (a_cut * 40.0 if two_kernel else a_tri * 36.0)
+            kernel_rate = a_ev / (a_ms * 1e-3) if a_ms > 0 else 0.0
+            va = valu_roofline(kernel_rate, workload, code)
+            pm = pmc_summary(workload, code)
+            rf = {"bound": "valu", "kernel": kern.get("leaf", "leaf_kernel"), "kernel_ms": a_ms,
+                  "achieved": va["achieved"] if va else None, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-instr/s",
+                  "frac": va["frac"] if va else None, "traffic": pm.get("hbm_traffic_gb_per_launch"), "traffic_unit": "GB per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
+                  "counters": counters_note(pm.get("source"), pm.get("code_match")),
+                  "kernel_evals_per_s": kernel_rate, "kernel_span_in_loop_ms": march_ms / max(1, args.steps),
+                  "ms_per_mesh_device_alone": sum(a.ms_total for a in alone) / len(alone), "valu": va,
+                  "hbm_notional": {"algorithmic_gb_per_launch": k_bytes / 1e9, "gb_per_s_alone": k_bytes / (a_ms * 1e-3) / 1e9 if a_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "note": "16 B per evaluation + 40 B per cut-leaf record, as SURVEY 8(d) counts them; positions are generated in registers and distances never "
+                                           "leave the CU, so these bytes do not cross HBM (roofline.traffic does) and no fraction of the HBM peak is formed from them"},
+                  "note": ("bound by VALU issue (SURVEY 8(d)): achieved = SQ_INSTS_VALU x 64 lanes per evaluation (PMC summary under profiles/, see `counters`) x the kernel's "
+                           "evaluations per second with the GPU to itself (blocking meshes of rank 0's shard after the timed loop, HIP events on the launching stream); peak = 256 CUs x "
+                           "4 SIMDs x 32 lanes x 2.4 GHz; valu.mix_roof_frac prices the same rate against what the kernel's own instruction mix allows on gfx950 "
+                           "(tools/ubench/class_rate.hip); kernel_span_in_loop_ms is the kernel's event-to-event span inside the timed loop"
+                           + (", where it shares the CUs with the other mesh in flight" if mesh_pipeline else ""))}
         out = {
+            "schema": 6,
             "metric": "sdf_evals_per_s", "value": evals_all / dt, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -676,68 +819,29 @@ def main():
                                  "is waited for; all K started and finished inside the timed region") if mesh_pipeline else "one blocking mesh call per step"},
             "triangles_per_s": tris_all / dt,
             "triangles_per_step": tris_all / args.steps, "evals_per_step": evals_all / args.steps,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if dc else pmc_traffic_gb(workload, code), "traffic_unit": "GB per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
-                         "algorithmic_gb_per_launch": k_bytes / 1e9,
-                         "kernel": (kmax + "_kernel (the longest of the five stages; all of them under 'stages')") if dc else kern.get("leaf", "leaf_kernel"), "kernel_ms": k_ms,
-                         "kernel_evals_per_s": kernel_rate, "valu": None if dc else valu_roofline(kernel_rate, workload, code),
-                         "note": "path is fp32-VALU bound (SURVEY 8(d)): algorithmic HBM bytes are tiny by construction; "
-                                 "'valu' prices the same kernel against the VALU issue peak"},
-            "roofline_march": None if (dc or not two_kernel or records) else {
-                "bound": "hbm", "kernel": "march_records_kernel", "kernel_ms": e_ms, "algorithmic_gb_per_launch": e_bytes / 1e9,
-                "achieved": e_bytes / (e_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": e_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": "marching cubes over the cut-leaf records: 40 B read per record + 36 B written per triangle"},
+            "roofline": rf,
             "stages": dc_stages,
             "phase_ms_rank0": {"prune": st.ms_prune, "leaf": st.ms_leaf, "eval_kernel": st.ms_march, "march_kernel": st.ms_emit, "total_device": st.ms_total},
             "phase_note": ("event-to-event spans of the timed loop's LAST mesh" + (": it shares the device with the other mesh in flight, so the spans overlap the other chain's kernels "
                            "(a mesh with the device to itself: roofline.ms_per_mesh_device_alone)" if mesh_pipeline else "")),
         }
-        if dc and dc_stages:  # counters of the same kernels, if a summary under profiles/ carries this workload and this code key
-            for k, v in pmc_dc_stages(workload, code).items():
-                if k in dc_stages:
-                    dc_stages[k]["pmc"] = v
-                else:
-                    dc_stages[k] = {"pmc": v}
+        if not dc and two_kernel:
+            # march_records_kernel alone (the same blocking meshes): its two streams against the HBM peak and against what a plain
+            # HIP copy kernel of as many bytes reaches on this part (tools/ubench/copy_rate.hip; profiles/r6_copy_rate.txt)
+            m_ms = sum(a.ms_emit for a in alone) / len(alone)
+            e_bytes = a_cut * 40.0 + a_tri * 36.0
+            m_gbs = e_bytes / (m_ms * 1e-3) / 1e9 if m_ms > 0 else 0.0
+            cr = guarded(copy_rate_gbs, a_cut * 40.0, a_tri * 36.0)
+            cr_gbs = (cr or {}).get("gb_per_s")
+            out["roofline_march"] = {"bound": "hbm", "kernel": "march_records_kernel", "kernel_ms": m_ms, "algorithmic_gb_per_launch": e_bytes / 1e9,
+                                     "achieved": m_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": m_gbs / HBM_PEAK_GBS,
+                                     "frac_of_copy": m_gbs / cr_gbs if cr_gbs else None, "copy": cr,
+                                     "kernel_span_in_loop_ms": emit_ms / max(1, args.steps),
+                                     "note": "marching cubes over the cut-leaf records, kernel alone: 40 B read per record + 36 B written per triangle; frac_of_copy = against the "
+                                             "rate a 16-B-per-lane HIP copy kernel reading and writing the same byte counts reaches on this box in this run (tools/ubench/copy_rate.hip)"}
         if shared_device:
             out["config"]["devices"] = (f"{world} ranks on {ndev} GPU(s): ranks share a device over the library's inter-process transport (GSDF_HIP_COMM=ipc) -- "
                                         "the N > 1 code path end to end, not a scaling measurement")
-        if mesh_pipeline and not dc:
-            # The two chains in flight share the CUs: the evaluating kernel's event-to-event time above includes what the other
-            # chain's centre tests and marching kernel took from it. Its duration ALONE, from blocking meshes after the timed loop:
-            alone = [hip.OctreeHIP(sdf, res, share_corners=args.share_corners).stats for _ in range(8)][2:]
-            a_ms = sum(a.ms_march for a in alone) / len(alone)
-            a_gbs = k_bytes / (a_ms * 1e-3) / 1e9
-            if out.get("roofline_march"):
-                m_ms = sum(a.ms_emit for a in alone) / len(alone)
-                m_gbs = e_bytes / (m_ms * 1e-3) / 1e9
-                out["roofline_march"]["alone"] = {"kernel_ms": m_ms, "achieved": m_gbs, "frac": m_gbs / HBM_PEAK_GBS}
-            va = valu_roofline((march_evals / max(1, args.steps)) / (a_ms * 1e-3), workload, code)
-            # The line's face: the BINDING roof of the dominant kernel -- VALU issue -- for the kernel ALONE (kernel_ms <= ms_per_step
-            # holds on the face of the line). The HBM figures of SURVEY 8(d) are notional by construction (positions are generated in
-            # registers, distances stay on the CU) and move under `hbm_notional`; the span the kernel takes while it shares the CUs
-            # with the other mesh in flight stays as kernel_span_overlapped_ms.
-            rf = out["roofline"]
-            rf["hbm_notional"] = {"bound": "hbm", "algorithmic_gb_per_launch": rf["algorithmic_gb_per_launch"], "traffic": rf["traffic"], "traffic_unit": rf["traffic_unit"],
-                                  "achieved_alone": a_gbs, "frac_alone": a_gbs / HBM_PEAK_GBS, "achieved_overlapped": rf["achieved"], "frac_overlapped": rf["frac"],
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "note": "16 B per evaluation + 40 B per cut-leaf record, as SURVEY 8(d) counts them: the kernel moves 6 % of that (PMC traffic)"}
-            rf["kernel_span_overlapped_ms"] = rf["kernel_ms"]
-            rf["valu_overlapped"] = rf.pop("valu")
-            rf["kernel_ms"] = a_ms
-            rf["kernel_evals_per_s"] = (march_evals / max(1, args.steps)) / (a_ms * 1e-3)
-            rf["ms_per_mesh_device_alone"] = sum(a.ms_total for a in alone) / len(alone)
-            rf["bound"] = "valu"
-            rf["unit"] = "T lane-instr/s"
-            rf["peak"] = VALU_PEAK_LANE_OPS / 1e12
-            rf["achieved"] = va["achieved"] if va else None
-            rf["frac"] = va["frac"] if va else None
-            rf["valu"] = va
-            rf["note"] = ("bound by VALU issue (SURVEY 8(d)): achieved = SQ_INSTS_VALU x 64 lanes per evaluation (PMC summary under profiles/ whose code key equals the running "
-                          "kernels', else null) x the kernel's evaluations per second with the GPU to itself (blocking meshes after the timed loop); peak = 256 CUs x 4 SIMDs x "
-                          "32 lanes x 2.4 GHz; valu.mix_roof_frac prices the same rate against what the kernel's own instruction mix allows on gfx950 "
-                          "(tools/ubench/class_rate.hip); the timed loop keeps two meshes in flight, kernel_span_overlapped_ms is the kernel's event-to-event span there")
-            for k in ("traffic", "traffic_unit", "algorithmic_gb_per_launch"):
-                rf.pop(k, None)
         if mesh_pipeline and not dc and args.share_corners == 0 and not args.no_distinct_rows:
             # Beside the headline, not in it: the same mesh with the evaluations the reference repeats left out (gsdf_mesh_opts.share_corners;
             # the triangle set is bit-identical, tests/test_gpu_mesh.py) -- time to mesh for a caller who does not need the reference's
@@ -765,37 +869,27 @@ def main():
                                             "each distinct row is evaluated once. Bit-identical triangle set; not the headline, which performs every evaluation the reference performs")
             out["distinct_points"]["note"] = ("gsdf_mesh_opts.share_corners = 1: every bitwise-distinct lattice point of a brick once (5..8 coordinates per axis instead of 8), packed "
                                               "four to a lane, no (x, y) column sharing; evals_performed counts lane slots. Bit-identical triangle set; not the headline")
-        if comm is not None and gstat["n"]:
-            n = gstat["n"]
-            g_ms = (gstat["ms_counts"] + gstat["ms_payload"]) / n
-            step_ms = dt / args.steps * 1e3
-            out["phase_ms_rank0"]["gather_counts"] = gstat["ms_counts"] / n
-            out["phase_ms_rank0"]["gather"] = gstat["ms_payload"] / n
-            out["phase_ms_rank0"]["gather_march"] = gstat["ms_march"] / n
-            g_ms += gstat["ms_march"] / n
-            out["gather"] = {"mode": args.gather, "pipelined": pipeline, "payload": "records" if records else "triangles",
-                             "transport": comm.transport(), "bytes_received_per_rank": gstat["bytes_received"] / n,
-                             "bytes_sent_per_rank": gstat["bytes_sent"] / n, "ms": g_ms, "ms_march_after_gather": gstat["ms_march"] / n,
-                             "evals_per_step_min_max_over_ranks": evals_minmax,
-                             # how much of the shorter of the two (meshing on the device, gather on the wire) hid behind the other
-                             "overlap_frac": max(0.0, min(1.0, (st.ms_total + g_ms - step_ms) / max(1e-9, min(st.ms_total, g_ms)))),
-                             "note": "rank 0, HIP events on the communicator's stream; a step = one mesh + its gather"}
+        if gather_modes:
+            gh = gather_modes[args.gather]
+            out["phase_ms_rank0"]["gather_counts"] = gh["ms_counts"]
+            out["phase_ms_rank0"]["gather"] = gh["ms_payload"]
+            out["phase_ms_rank0"]["gather_march"] = gh["ms_march_after_gather"]
+            out["gather"] = dict(gh, note="rank 0, HIP events on the communicator's stream; a step = one mesh + its gather")
+            out["gather_modes"] = dict(gather_modes, note="the same K-step loop once per mode, one after the other in this run; the headline (`value`, `ms_per_step`) is mode "
+                                       + args.gather + "; `none` is what the compute scales to, `root` / `all` add the wire")
         if world == 1 and not args.no_cpu_baseline and not dc:
             threads = max(1, (os.cpu_count() or 2) - 1)  # GOMAXPROCS-1 (gsdfaux/gsdfaux.go:162-164)
             # bounded sample of the SAME workload: full resdiv 1600 lattice (420 M evals) on big hosts, coarser on small ones
             cpu_rd = args.cpu_resdiv or (args.resdiv if threads >= 64 else (1000 if threads >= 16 else 600))
             out["cpu_baseline"] = guarded(cpu_baseline, shader, args.scene, cpu_rd, threads)
-        if world == 1 and not dc:
+        if world == 1 and comm is None and not dc:
             out["host_inclusive"] = guarded(host_inclusive, hip, sdf, res)
-        if world == 1 and not dc and not args.no_evaluate_dropin and args.scene != "text-plate":
+        if world == 1 and comm is None and not dc and not args.no_evaluate_dropin and args.scene != "text-plate":
             out["evaluate_dropin"] = guarded(evaluate_dropin, hip, sdf, shader)
-        if world == 1 and not dc and not args.no_one_shot and not args.interpreter:
+        if world == 1 and comm is None and not dc and not args.no_one_shot and not args.interpreter:
             out["one_shot"] = guarded(one_shot, hip, shader, res)
         print(json.dumps(out), flush=True)
     if dist is not None:
-        if rank == 0 and last[1] is not None:
-            ng = last[1].n_tris() if hasattr(last[1], "n_tris") else int(last[1].shape[0])
-            assert ng == int(tris_all / args.steps), "gathered triangle count differs from the sum of the ranks'"
         dist.barrier()
         if comm is not None:
             comm.close()

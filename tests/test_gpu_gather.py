@@ -316,3 +316,33 @@ def test_gatherv_across_processes_sharing_a_device(gpu, world, tmp_path):
             if row["mode"] == gpu.GATHER_NONE:
                 assert row["bytes_sent"] == 0 and row["bytes_received"] == 0
         assert j["pipelined"] == [want] * 3
+
+
+def test_bench_self_launches_two_ranks_on_one_gpu(gpu):
+    """`GSDF_HIP_COMM=ipc python3 bench.py --gpus 2` with NO launcher -- the form the driver starts the N = 1 line in -- must start its
+    own ranks (torch.distributed.run, one process per rank) and print the one JSON line: VALU roofline like the N = 1 line, the three
+    gather modes timed in the same run, the gathered count equal to the whole mesh's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GSDF_HIP_COMM="ipc", HSA_ENABLE_IPC_MODE_LEGACY="0", GSDF_HIP_IPC_TIMEOUT_S="120")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--preheat", "3", "--resdiv", "400"]
+    pr = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in pr.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["schema"] == 6
+    assert d["triangles_per_step"] == 423852                         # README.md:116,130 -- the two shards together are the whole mesh
+    rf = d["roofline"]
+    assert rf["bound"] == "valu" and rf["kernel_ms"] > 0 and "leaf_eval_kernel" in rf["kernel"]
+    assert rf["frac"] is None or 0 < rf["frac"] <= 1
+    assert "frac" not in rf["hbm_notional"]
+    gm = d["gather_modes"]
+    assert set(gm) >= {"all", "root", "none"}
+    for mode in ("all", "root", "none"):
+        assert gm[mode]["ms_per_step"] > 0 and gm[mode]["mode"] == mode
+    assert gm["none"]["bytes_received_per_rank"] == 0 and gm["all"]["bytes_received_per_rank"] > 0
+    assert d["gather"]["mode"] == "all" and "ranks share a device" in d["config"]["devices"]
