@@ -102,6 +102,27 @@ extern "C" int gsdf_hip_selftest_circ(float ncirc, uint64_t* mismatches, uint64_
   return rc;
 }
 
+// Test hook: dm::atan2_fast (float32 of math.Atan2 without the reference's float64 operation sequence, accepted only where the
+// rounding is decided) against dm::atan2_ref, over 2^log2n pairs of `mode` (kernels_eval.h: atan2_selftest_kernel).
+extern "C" int gsdf_hip_selftest_atan2(int mode, int log2n, uint64_t* mismatches, uint64_t* fast_path_points) {
+  if (mismatches) *mismatches = 0;
+  if (fast_path_points) *fast_path_points = 0;
+  if (mode < 0 || mode > 2 || log2n < 0 || log2n > 40) return fail(GSDF_ERR_BAD_ARGUMENT, "mode in 0..2, log2n in 0..40");
+  unsigned long long* d_c = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_c, 16));
+  int rc = GSDF_OK;
+  do {
+    if (hipMemset(d_c, 0, 16) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "memset failed"); break; }
+    hipLaunchKernelGGL(atan2_selftest_kernel, dim3(4096), dim3(BLOCK), 0, nullptr, mode, log2n, d_c, d_c + 1);
+    unsigned long long h[2] = {0, 0};
+    if (hipMemcpy(h, d_c, 16, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "selftest kernel failed"); break; }
+    if (mismatches) *mismatches = h[0];
+    if (fast_path_points) *fast_path_points = h[1];
+  } while (0);
+  (void)hipFree(d_c);
+  return rc;
+}
+
 // Test hook: dm::sqrt_1to2 against sqrtf for all 8,388,609 floats in [1, 2].
 extern "C" int gsdf_hip_selftest_sqrt(uint64_t* mismatches) {
   unsigned long long* d_c = nullptr;

@@ -238,7 +238,8 @@ DM_INL bool circ_sector_fast(float x, float y, float inv_angle, float m, float& 
   return l == h;
 }
 
-DM_INL float atan2f_(float yf, float xf) {
+// math.Atan2 as the reference evaluates it: Go's float64 Cephes routine, rounded once (the arithmetic contract).
+DM_INL float atan2_ref(float yf, float xf) {
   double y = (double)yf, x = (double)xf;
   double r;
   if (y == 0.0) {
@@ -250,6 +251,65 @@ DM_INL float atan2f_(float yf, float xf) {
     r = x < 0.0 ? (q <= 0.0 ? q + DM_PI : q - DM_PI) : q;
   }
   return (float)r;
+}
+
+// The same float32 WITHOUT the reference's operation sequence, where that is provably enough (round 6). atan2_ref costs ~115
+// instructions: three IEEE float64 divisions, Cephes' rational function in unfused multiplies and adds, 64-bit selects. What the
+// contract needs is only float32(g), g = Go's float64 result, and g is within 2^-50 (relative) of the true angle theta (Cephes
+// atan: peak relative error 1.8e-16; the quotient's rounding adds 2^-53). So: compute r within e_r of theta by the cheapest
+// float64 route --
+//   t = lo / hi in [0, 1]  (|y|, |x| sorted; the reciprocal from v_rcp_f32 -- 1 ulp: |1 - hi r0| <= 2^-23 -- and ONE Newton step
+//       in float64: relative error e^2 <= 2^-46)
+//   atan t = t P(t^2), P of degree 15 fitted to atan(sqrt u)/sqrt u on [0, 1]: relative error 2^-44.28 with the coefficients
+//       rounded to binary64 (tools/gen/atan_poly.py; 16 FMAs, 2^-53 each)
+//   theta = k pi/2 +- atan t by octant (one FMA: k in {0, 1, 2} times pi/2 is exact up to the constant's own 2^-54), sign of y
+// -- e_r <= 2^-43.8 -- and accept when every float64 within ETA = 2^-40 (relative) of r rounds to the same float32:
+// float32(r (1 + ETA)) == float32(r (1 - ETA)) bit for bit. Then float32(g) is that float32 too (|g - r| <= (2^-50 + 2^-43.8) |theta|
+// < ETA |r|, a 13-fold margin). Rejected: one point in ~2^15 (r within 2^-16 ulp of a rounding boundary) and the inputs the route
+// does not cover (hi outside [2^-100, 2^100]: zeros, infinities, NaN, where v_rcp_f32 would leave the normal range) -- the caller
+// votes and evaluates atan2_ref for the wave. ~46 instructions. Checked on device against atan2_ref: gsdf_hip_selftest_atan2
+// (2^32 hashed pairs of every magnitude and sign, 2^30 pairs searched towards rounding boundaries, lattice-shaped pairs).
+DM_INL float atan2_fast(float yf, float xf, bool& ok) {
+  const float ax = absf(xf), ay = absf(yf);
+  const float hi = maxf(ax, ay), lo = minf(ax, ay);
+  const bool swap = ay > ax;
+  ok = (__float_as_uint(hi) - 0x0D800000u) < (0x71800000u - 0x0D800000u);  // 2^-100 <= hi < 2^100 (also: not 0, Inf, NaN)
+  const double hid = (double)hi, lod = (double)lo;
+  double rr = (double)__builtin_amdgcn_rcpf(hi);
+  rr = __builtin_fma(rr, __builtin_fma(-hid, rr, 1.0), rr);
+  const double t = lod * rr, u = t * t;
+  double p = -0x1.cb482a6cb5224p-14;
+  p = __builtin_fma(p, u, 0x1.05217b419a6d7p-10);
+  p = __builtin_fma(p, u, -0x1.17ce579499acep-8);
+  p = __builtin_fma(p, u, 0x1.7bef9c85ccda5p-7);
+  p = __builtin_fma(p, u, -0x1.756cd8238c9c5p-6);
+  p = __builtin_fma(p, u, 0x1.22637d152cb30p-5);
+  p = __builtin_fma(p, u, -0x1.81111fde7ae21p-5);
+  p = __builtin_fma(p, u, 0x1.d185bc23a2f84p-5);
+  p = __builtin_fma(p, u, -0x1.0ee3841b8af57p-4);
+  p = __builtin_fma(p, u, 0x1.3aa7733d3ec56p-4);
+  p = __builtin_fma(p, u, -0x1.744e578217a19p-4);
+  p = __builtin_fma(p, u, 0x1.c71b1bf660394p-4);
+  p = __builtin_fma(p, u, -0x1.24923fb1fa2b1p-3);
+  p = __builtin_fma(p, u, 0x1.99999952cd8edp-3);
+  p = __builtin_fma(p, u, -0x1.55555554ebae1p-2);
+  p = __builtin_fma(p, u, 0x1.ffffffffffe5ap-1);
+  const double a = t * p;  // atan(lo / hi) in [0, pi/4]
+  // octants: x >= 0: a | pi/2 - a (swapped);  x < 0: pi - a | pi/2 + a (swapped);  x's sign by its bit (atan2(y, -0) = +-pi)
+  const uint32_t xneg = __float_as_uint(xf) >> 31, sw = swap ? 1u : 0u;
+  const uint32_t k = swap ? 1u : (xneg << 1);
+  const double sa = __longlong_as_double(__double_as_longlong(a) ^ ((long long)(sw ^ xneg) << 63));
+  double r = __builtin_fma((double)k, DM_PI / 2, sa);  // >= +0
+  r = __longlong_as_double(__double_as_longlong(r) | ((long long)(__float_as_uint(yf) >> 31) << 63));  // copysign(r, y)
+  const float f1 = (float)__builtin_fma(r, 0x1p-40, r), f2 = (float)__builtin_fma(r, -0x1p-40, r);
+  ok = ok && (__float_as_uint(f1) == __float_as_uint(f2));
+  return f1;
+}
+// (single points: selftests, code outside the interpreter's voted call sites)
+DM_INL float atan2f_(float yf, float xf) {
+  bool ok;
+  const float f = atan2_fast(yf, xf, ok);
+  return ok ? f : atan2_ref(yf, xf);
 }
 
 DM_INL double trig_poly_sin(double z, double zz) {

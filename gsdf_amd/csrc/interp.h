@@ -234,6 +234,21 @@ __device__ __forceinline__ void xy_shared(const P3 (&pv)[K], float (&out)[K], bo
   if (shared) { KLOOP if (kp & 1) out[kp] = out[kp ? kp - 1 : 0]; }
   else { KLOOP if (kp & 1) out[kp] = f(pv[kp].x, pv[kp].y); }
 }
+// math.Atan2 of the points' (y, x) with xy_shared's sharing: dm::atan2_fast for every point, one wave vote, the reference's own
+// sequence (dm::atan2_ref) for the whole wave where a point's result is not decided by the fast route (one wave in ~100).
+template <int K>
+__device__ __forceinline__ void atan2_shared(const P3 (&pv)[K], float (&out)[K], bool shared, bool brick, bool column) {
+#ifndef GSDF_NO_ATAN2_FAST
+  // (one angle per lane for all of its points -- a column brick under an axis-aligned frame, npt-flange's thread -- is cheap either
+  // way, and the short route's float64 temporaries cost that build its fifth workgroup per CU: the reference's sequence there)
+  if (!(shared && column)) {  // (wave-uniform: instruction flags)
+    bool ok = true;
+    xy_shared<K>(pv, out, shared, brick, [&ok](float x, float y) { bool o; const float v = dm::atan2_fast(y, x, o); ok = ok && o; return v; }, column);
+    if (__all(ok)) return;
+  }
+#endif
+  xy_shared<K>(pv, out, shared, brick, [](float x, float y) { return dm::atan2_ref(y, x); }, column);
+}
 
 // hypot(P.x,P.y) of every point into hxy[] unless the cache is valid
 #define ENSURE_HXY() \
@@ -968,7 +983,7 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_SCREW_PRE: {
         float th[K];  // atan2(P.y, P.x): a function of x,y only
-        xy_shared<K>(pv, th, sh_xy, brick, [](float x, float y) { return dm::atan2f_(y, x); }, sh_col);
+        atan2_shared<K>(pv, th, sh_xy, brick, sh_col);
         ENSURE_HXY();
         {
           // z' = z + lead*theta/2pi ; sawTooth(z', pitch): both divisors are wave-uniform -> exact reciprocal form
@@ -1062,8 +1077,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
           fast = __builtin_amdgcn_ballot_w64(!fast) == 0ull;  // wave-uniform
         }
         if (!fast) {
-          float th[K];  // atan2(P.y, P.x): a function of x,y only
-          xy_shared<K>(pv, th, sh_xy, brick, [](float x, float y) { return dm::atan2f_(y, x); }, sh_col);
+          float th[K];  // atan2(P.y, P.x): a function of x,y only (a rare path -- a point on a sector boundary: the reference's sequence)
+          xy_shared<K>(pv, th, sh_xy, brick, [](float x, float y) { return dm::atan2_ref(y, x); }, sh_col);
           KLOOP idv[kp] = floorf_(th[kp] / PF(0));
         }
         KLOOP {

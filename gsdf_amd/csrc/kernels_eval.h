@@ -114,8 +114,72 @@ __global__ void __launch_bounds__(BLOCK) circ_selftest_kernel(float angle, unsig
     float id;
     if (dm::circ_sector_fast(x, y, inv_angle, m, id)) {
       nf++;
-      const float ref = dm::floorf_(dm::atan2f_(y, x) / angle);
+      const float ref = dm::floorf_(dm::atan2_ref(y, x) / angle);
       if (__float_as_uint(id) != __float_as_uint(ref) && !(id == 0.f && ref == 0.f)) nb++;
+    }
+  }
+  if (nb) atomicAdd(bad, nb);
+  if (nf) atomicAdd(fast_count, nf);
+}
+
+// Self-test of dm::atan2_fast against dm::atan2_ref (float32 of Go's float64 math.Atan2): wherever the fast route ACCEPTS, its
+// float32 must be the reference's, bit for bit. 2^log2n points per call:
+//   mode 0  both coordinates from a hash: every sign, exponents 2^-60 .. 2^60 apart by up to 2^+-40, plus zeros of both signs
+//   mode 1  searched towards rounding boundaries: a hashed pair, then of the 8 float32 neighbours y + j ulp the one whose float64
+//           angle lies nearest to the midpoint of two float32 values (where a wrong accept would show first)
+//   mode 2  lattice-shaped pairs, as a renderer produces them: x = ox + i res, y = oy + j res with small integers, |x| == |y|,
+//           points on the axes, ratios near the octant boundaries
+// bad: accepted and different; fast_count: accepted.
+__global__ void __launch_bounds__(BLOCK) atan2_selftest_kernel(int mode, int log2n, unsigned long long* __restrict__ bad,
+                                                               unsigned long long* __restrict__ fast_count) {
+  unsigned long long nb = 0, nf = 0;
+  auto hash = [](unsigned v) { v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16; return v; };
+  const unsigned long long n = 1ull << log2n;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * BLOCK) {
+    const unsigned h1 = hash((unsigned)i ^ (unsigned)(i >> 32) * 0x85ebca6bu), h2 = hash(h1 ^ 0x9e3779b9u), h3 = hash(h2 + 0x7f4a7c15u);
+    float x, y;
+    if (mode == 2) {
+      const float res = __uint_as_float(0x3c000000u + (h3 & 0x03ffffffu)) ;  // 2^-7 .. 2^0 (a lattice step)
+      const float ox = (float)((int)(h1 & 0xffffu) - 32768) * 1.52587890625e-05f * 40.f, oy = (float)((int)(h1 >> 16) - 32768) * 1.52587890625e-05f * 40.f;
+      x = ox + res * (float)((int)(h2 & 0x7ffu) - 1024);
+      y = oy + res * (float)((int)((h2 >> 11) & 0x7ffu) - 1024);
+      const unsigned sel = h2 >> 28;
+      if (sel == 0u) y = x;
+      if (sel == 1u) y = -x;
+      if (sel == 2u) y = (h3 >> 31) ? 0.f : -0.f;
+      if (sel == 3u) x = (h3 >> 31) ? 0.f : -0.f;
+      if (sel == 4u) y = x * 0.41421357f;   // tan(pi/8): the old routine's range boundary
+      if (sel == 5u) y = x * 2.4142137f;
+      if (sel == 6u) y = __uint_as_float(__float_as_uint(x) + ((h3 & 7u) - 3u));  // |y| within 4 ulp of |x|
+    } else {
+      // sign | exponent 67..187 | 23 mantissa bits for x; y's exponent within +-40 of x's; one in 64 is a zero
+      const unsigned ex = 67u + (h1 >> 8) % 121u;
+      int ey = (int)ex + (int)((h2 >> 8) % 81u) - 40;
+      ey = ey < 1 ? 1 : (ey > 254 ? 254 : ey);
+      x = __uint_as_float((h1 & 0x80000000u) | (ex << 23) | (h2 & 0x7fffffu));
+      y = __uint_as_float((h2 & 0x80000000u) | ((unsigned)ey << 23) | (h3 & 0x7fffffu));
+      if ((h1 & 63u) == 0u) x = (h2 & 1u) ? 0.f : -0.f;
+      if ((h2 & 63u) == 1u) y = (h1 & 1u) ? 0.f : -0.f;
+      if (mode == 1 && y != 0.f && x != 0.f) {
+        float best = y;
+        double bestd = 1.0;
+        for (int j = -4; j < 4; j++) {
+          const float yj = __uint_as_float(__float_as_uint(y) + (unsigned)j);
+          const double g = dm::atan64((double)yj / (double)x);  // (the octant constant does not move the low bits' distance much; good enough to steer)
+          const float f = (float)g;
+          const float f2 = __uint_as_float(__float_as_uint(f) + (((double)f < g) ? 1u : 0xffffffffu));  // the float32 on the other side of g
+          const double mid = 0.5 * ((double)f + (double)f2);
+          const double d = __builtin_fabs(g - mid) / __builtin_fabs((double)f - (double)f2);
+          if (d < bestd) { bestd = d; best = yj; }
+        }
+        y = best;
+      }
+    }
+    bool ok;
+    const float a = dm::atan2_fast(y, x, ok);
+    if (ok) {
+      nf++;
+      if (__float_as_uint(a) != __float_as_uint(dm::atan2_ref(y, x))) nb++;
     }
   }
   if (nb) atomicAdd(bad, nb);

@@ -1260,7 +1260,7 @@ __device__ __forceinline__ unsigned march_chunk_emit(const uint32_t (&rw)[10], b
 //   wcol [64][11], wown [5 * 64]: as above, for the wave's records; owner entries carry the lane (record) << 12
 template <typename Prefetch>
 __device__ __forceinline__ unsigned march_chunk_emit_wave(const uint32_t (&rw)[10], bool has, Prefetch prefetch, float ox, float oy, float oz,
-                                                          float res, float* wcol, uint32_t* wown, const uint16_t* s_tri,
+                                                          float res, float* wcol, uint32_t* wown, float* wstage, const uint16_t* s_tri,
                                                           float* __restrict__ tris, unsigned long long out) {
   const unsigned lane = threadIdx.x & 63u;
   unsigned index = 0;
@@ -1280,40 +1280,58 @@ __device__ __forceinline__ unsigned march_chunk_emit_wave(const uint32_t (&rw)[1
   const unsigned first = ti - nt;
   for (unsigned k = 0; k < nt; k++) wown[first + k] = (index * 16u + 3u * k) | (lane << 12);
   __builtin_amdgcn_wave_barrier();
-#ifdef GSDF_EXP_MARCH_TRIANGLE_PER_LANE
-  // (developer experiment, measured and not kept: ONE TRIANGLE PER LANE -- the record's origin and the table row fetched once
-  // for the three vertices, half the instructions per vertex, but the 36 bytes of a triangle leave as three 12-byte stores at a
-  // 36-byte stride: 0.141 ms against 0.120 for one vertex per lane, whose store instructions are 768 contiguous bytes each. The
-  // kernel pays for its output stream, not for its arithmetic.)
-  MarchV3* dst = (MarchV3*)(tris + out * 9);
-  for (unsigned t = lane; t < total; t += 64u) {
-    const uint32_t o = wown[t];
-    const float* col = wcol + (o >> 12) * 11u;
-    const uint16_t* row = s_tri + (o & 4095u);
-    MarchV3 r0, r1, r2;
-    march_vertex(row[2], col, res, r0.x, r0.y, r0.z);  // reversed winding (marchcubes.go:64-68)
-    march_vertex(row[1], col, res, r1.x, r1.y, r1.z);
-    march_vertex(row[0], col, res, r2.x, r2.y, r2.z);
-    dst[3u * t] = r0;
-    dst[3u * t + 1u] = r1;
-    dst[3u * t + 2u] = r2;
+#ifndef GSDF_MARCH_VERTEX_PER_LANE
+  // ONE TRIANGLE PER LANE, its 36 bytes handed to the neighbours through LDS so that the wave's stores are 16 bytes per lane and
+  // contiguous (round 6). Round 5 measured the two plain forms against each other -- a vertex per lane (768-byte store
+  // instructions, twice the instructions per vertex: the record's origin, the owner word and the table row are fetched per
+  // vertex) 0.120 ms, a triangle per lane with its three 12-byte stores at a 36-byte stride 0.141 ms -- and concluded that the
+  // kernel pays for its output stream. It paid for the SHAPE of it: a HIP copy kernel moving the same bytes (136 MB in, 245 MB out)
+  // with 16-byte nontemporal stores runs at 6.9 TB/s on this part, with plain 16-byte stores at 5.2-5.5 (tools/ubench/copy_rate.hip,
+  // profiles/r6a_copy_rate.txt). So: the triangle's arithmetic once per lane, nine floats into the wave's staging rows (stride 9:
+  // conflict-free), and the wave writes the round's 64 x 36 bytes as three 1024-byte nontemporal store instructions (dword-
+  // aligned: a triangle is 36 bytes) -- the triangles are written once and never read again by this mesh.
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef float f4a __attribute__((ext_vector_type(4)));
+  for (unsigned t0 = 0; t0 < total; t0 += 64u) {  // wave-uniform
+    const unsigned t = t0 + lane;
+    if (t < total) {
+      const uint32_t o = wown[t];
+      const float* col = wcol + (o >> 12) * 11u;
+      const uint16_t* row = s_tri + (o & 4095u);
+      float* st = wstage + lane * 9u;
+      march_vertex(row[2], col, res, st[0], st[1], st[2]);  // reversed winding (marchcubes.go:64-68)
+      march_vertex(row[1], col, res, st[3], st[4], st[5]);
+      march_vertex(row[0], col, res, st[6], st[7], st[8]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned nd = (total - t0 < 64u ? total - t0 : 64u) * 9u;  // dwords of this round (wave-uniform)
+    float* gdst = tris + (out + t0) * 9ull;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const unsigned idx = 4u * lane + 256u * (unsigned)r;
+      if (idx + 4u <= nd) {
+        const f4u v = *(const f4a*)(wstage + idx);
+#ifdef GSDF_EXP_MARCH_NO_STORE  // developer experiment (library built with -D...): the kernel without its output stream (timing only)
+        if (v.x == 1.2345678e-30f)
+#endif
+        __builtin_nontemporal_store(v, (f4u*)(gdst + idx));
+      } else {
+        for (unsigned j = idx; j < nd; j++) __builtin_nontemporal_store(wstage[j], gdst + j);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // (the next round rewrites the staging rows)
   }
 #else
   MarchV3* dst = (MarchV3*)(tris + out * 9);
   const unsigned n3 = total * 3u;
-  // (not unrolled: two vertices side by side make the compiler pack their f32 operations into v_pk_* -- no faster on gfx950 than
-  // the scalar pairs, plus the moves that form the register pairs; the other waves of the SIMD fill the latencies)
+  // (the round-5 form: one output vertex per lane, a store is 768 contiguous bytes)
 #pragma unroll 1
-  for (unsigned k = lane; k < n3; k += 64u) {  // one output vertex per lane: a store is 768 contiguous bytes
+  for (unsigned k = lane; k < n3; k += 64u) {
     const unsigned t = k / 3u, j = k - 3u * t;
     const uint32_t o = wown[t];
     MarchV3 r;
     march_vertex(s_tri[(o & 4095u) + (2u - j)], wcol + (o >> 12) * 11u, res, r.x, r.y, r.z);  // reversed winding (marchcubes.go:64-68)
-#ifdef GSDF_EXP_MARCH_NO_STORE  // developer experiment (library built with -D...): the kernel without its output stream (timing only)
-    if (r.x == 1.2345678e-30f) dst[k] = r;
-#else
     dst[k] = r;
-#endif
   }
 #endif
   __builtin_amdgcn_wave_barrier();  // (the next chunk rewrites the columns and the owner list)
@@ -1336,9 +1354,9 @@ __device__ __forceinline__ unsigned march_chunk_emit_wave(const uint32_t (&rw)[1
 //  workgroup-wide chunks of 256 records between barriers, three interpolations and two 64-bit shifts per vertex: 0.100-0.115 ms,
 //  33.5 M wave-instructions and half of the wave cycles waiting -- rounds 2-4. This form: round 5.)
 // LDS: [table 256 x 16 u16 | per wave: 11 record columns of 64 floats, owner list 5 x 64, block prefix 66 | scratch] = 25.9 KB: 6 workgroups per CU
-#define MARCH_WAVE_WORDS (64 * 11 + 5 * 64 + 66)
+#define MARCH_WAVE_WORDS (64 * 11 + 5 * 64 + 68 + 64 * 9)
 #define MARCH_LDS_BYTES (256 * 16 * 2 + 4 * MARCH_WAVE_WORDS * 4 + 8 + 24 * 8)
-__global__ void __launch_bounds__(BLOCK, 6) march_records_kernel(const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ rec,
+__global__ void __launch_bounds__(BLOCK, 4) march_records_kernel(const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ rec,
                                                               const unsigned long long* __restrict__ psum,
                                                               unsigned long long n_blocks_cap, int lq, float ox, float oy, float oz,
                                                               float res, float* __restrict__ tris, uint64_t tri_cap,
@@ -1358,7 +1376,7 @@ __global__ void __launch_bounds__(BLOCK, 6) march_records_kernel(const uint32_t*
   if (e0 > n_grp) e0 = n_grp;
   if (e1 > n_grp) e1 = n_grp;
   unsigned long long lr = 0, lt = 0, la = 0;
-#pragma unroll 4
+#pragma unroll 8
   for (uint64_t e = e0; e < e1; e++) {
     const unsigned long long v = psum[e];
     lr += PSUM_REC(v);
@@ -1403,20 +1421,32 @@ __global__ void __launch_bounds__(BLOCK, 6) march_records_kernel(const uint32_t*
   // five cut points: the workgroup's share in four parts, wave w takes records [Xc(w), Xc(w + 1)) -- like the shares themselves,
   // cut at block granularity by the same rule, so the parts tile the share and the shares tile the mesh
   auto cut = [&](unsigned w) -> unsigned long long { return X0 + (X1 - X0) * w / 4ull; };
-  // the group in which the running record count reaches X (X > 0): found by the one thread whose groups straddle it
-#pragma unroll 1
-  for (unsigned w = 0; w < 5u; w++) {
-    const unsigned long long X = cut(w);
-    if (br < X && X <= br + lr) {
+  // the group in which the running record count reaches X (X > 0): found by the one thread whose groups straddle it. ONE walk over
+  // the thread's groups serves all five cut points, eight group sums in flight at a time (round 6: the walk used to run once per
+  // cut point with an early exit, i.e. one dependent load per group -- up to 5 x 24 trips to the cache in front of the first record)
+  {
+    unsigned long long Xc[5];
+    bool mine = false;
+#pragma unroll
+    for (unsigned w = 0; w < 5u; w++) {
+      Xc[w] = cut(w);
+      mine = mine || (br < Xc[w] && Xc[w] <= br + lr);
+    }
+    if (mine) {
       unsigned long long acc = br, tacc = bt;
-      for (uint64_t e = e0; e < e1; e++) {
-        const unsigned long long v = psum[e];
-        if (acc + PSUM_REC(v) >= X) {
-          s_u64[4 + 3 * w] = e; s_u64[5 + 3 * w] = acc; s_u64[6 + 3 * w] = tacc;
-          break;
+      for (uint64_t e = e0; e < e1; e += 8) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (e + u < e1) ? psum[e + u] : 0ull;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const unsigned long long nr_ = PSUM_REC(v[u]);
+#pragma unroll
+          for (unsigned w = 0; w < 5u; w++)
+            if (acc < Xc[w] && Xc[w] <= acc + nr_) { s_u64[4 + 3 * w] = e + u; s_u64[5 + 3 * w] = acc; s_u64[6 + 3 * w] = tacc; }
+          acc += nr_;
+          tacc += PSUM_TRI(v[u]);
         }
-        acc += PSUM_REC(v);
-        tacc += PSUM_TRI(v);
       }
     }
   }
@@ -1460,6 +1490,7 @@ __global__ void __launch_bounds__(BLOCK, 6) march_records_kernel(const uint32_t*
   float* wcol = s_wave + wave_u * MARCH_WAVE_WORDS;
   uint32_t* wown = (uint32_t*)(wcol + 64 * 11);
   unsigned* wpre = (unsigned*)(wown + 5 * 64);  // [65] exclusive prefix of the pass's record counts, [64] = their sum
+  float* wstage = (float*)(wpre + 68);          // [64][9]: a round's triangles on their way out (16-byte aligned)
   unsigned nr_next = (b_begin + lane < b_end) ? (hdr[b_begin + lane] & 255u) : 0u;
 #ifdef GSDF_EXP_MARCH_STARTUP_ONLY  // developer experiment: what the kernel costs before its first record (timing only)
   if (nr_next != 0xffffffffu) return;
@@ -1496,7 +1527,7 @@ __global__ void __launch_bounds__(BLOCK, 6) march_records_kernel(const uint32_t*
     fetch(lane);
     for (unsigned q0 = 0; q0 < Rp; q0 += 64u) {  // wave-uniform
       const unsigned q = q0 + lane;
-      out += march_chunk_emit_wave(rw, q < Rp, [&] { fetch(q + 64u); }, ox, oy, oz, res, wcol, wown, s_tri, tris, out);
+      out += march_chunk_emit_wave(rw, q < Rp, [&] { fetch(q + 64u); }, ox, oy, oz, res, wcol, wown, wstage, s_tri, tris, out);
     }
     __builtin_amdgcn_wave_barrier();  // (the next pass rewrites the prefix)
   }

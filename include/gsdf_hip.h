@@ -75,6 +75,11 @@ int gsdf_hip_selftest_sqrt(uint64_t* mismatches);
 /* Test hook (needs a GPU): the circular array's sector index from a float32 angle estimate (taken only where it provably
  * decides floor(atan2(y, x) / angle), cpu_evaluators.go:1047-1056) against that expression, over 2^32 points. */
 int gsdf_hip_selftest_circ(float ncirc, uint64_t* mismatches, uint64_t* fast_path_points);
+/* Test hook (needs a GPU): float32(math.Atan2(y, x)) by the short float64 route of the evaluator's screw / circular-array
+ * instructions (forge/threads/threads.go:160, cpu_evaluators.go:1060), which is taken only where it provably rounds like the
+ * reference's own operation sequence, against that sequence: 2^log2n pairs; mode 0 hashed pairs of every sign and magnitude,
+ * 1 pairs searched towards float32 rounding boundaries, 2 lattice-shaped pairs. mismatches must come back 0. */
+int gsdf_hip_selftest_atan2(int mode, int log2n, uint64_t* mismatches, uint64_t* fast_path_points);
 /* Run-time specialisation (no reference counterpart; the reference's GPU path compiles GLSL per tree at
  * gleval/gpu.go:35-54, this is the same step for the HIP backend): builds, with hiprtc, eval / prune / leaf kernels in
  * which this program's instructions are laid out straight-line with literal parameters, and makes the handle launch

@@ -218,6 +218,19 @@ def test_circular_array_sector_index_without_the_angle(gpu):
         assert bad.value == 0 and nfast.value > 1_500_000_000, (ncirc, bad.value, nfast.value)
 
 
+def test_atan2_short_route_rounds_like_the_reference(gpu):
+    """dm::atan2_fast -- float32(math.Atan2) from a 16-FMA float64 polynomial instead of Go's Cephes sequence, accepted only where
+    every float64 within 2^-40 of its result rounds to the same float32 -- against the reference's sequence (dm::atan2_ref): 2^32
+    hashed pairs of every sign and magnitude, 2^30 pairs steered towards float32 rounding boundaries, 2^30 lattice-shaped pairs
+    (equal magnitudes, axes, signed zeros, the old routine's range boundaries). No accepted result may differ; nearly all are accepted."""
+    import ctypes as C
+    for mode, log2n in ((0, 32), (1, 30), (2, 30)):
+        bad, nfast = C.c_uint64(1), C.c_uint64(0)
+        assert gpu.lib().gsdf_hip_selftest_atan2(mode, log2n, C.byref(bad), C.byref(nfast)) == 0
+        assert bad.value == 0, (mode, bad.value, nfast.value)
+        assert nfast.value > 0.95 * 2.0 ** log2n, (mode, nfast.value / 2.0 ** log2n)   # (zeros are one pair in 32: they take the reference's route)
+
+
 def test_circular_array_points_on_sector_boundaries(gpu):
     """The sector index comes from a float32 angle estimate unless some point of the wave is too close to a sector boundary:
     points ON the boundaries (angle k * 2 pi / n to the last bit, the axes, +-0, the origin) mixed with ordinary ones, so that
