@@ -231,8 +231,8 @@ func (o *MeshHIP) GatherStart(c *HIPComm, mode, root int) (*PendingGatherHIP, er
 func (p *PendingGatherHIP) Wait() (*MeshHIP, []uint64, error) {
 	counts := make([]uint64, p.world)
 	var all *C.gsdf_mesh
-	var st C.gsdf_gather_stats
-	if rc := C.gsdf_hip_mesh_gatherv_wait(p.g, &all, (*C.uint64_t)(unsafe.Pointer(&counts[0])), &st); rc != 0 {
+	var gst C.gsdf_gather_stats
+	if rc := C.gsdf_hip_mesh_gatherv_wait(p.g, &all, (*C.uint64_t)(unsafe.Pointer(&counts[0])), &gst); rc != 0 {
 		return nil, nil, hipErr(rc)
 	}
 	if all == nil {
