@@ -473,6 +473,8 @@ def main():
                     help="N = 1: one blocking gsdf_hip_mesh_octree call per step (default: gsdf_hip_mesh_octree_start / _wait, the next mesh's "
                          "chain of kernels is enqueued before the previous mesh is waited for; every one of the K meshes is started and "
                          "finished inside the timed region)")
+    ap.add_argument("--mesh-depth", type=int, default=3, choices=[1, 2, 3],
+                    help="N = 1, pipelined: meshes in flight on the handle (it has three workspaces and streams; 3 measured best: tools/gpu_pipe_depth.py)")
     ap.add_argument("--no-gather-pipeline", action="store_true",
                     help="N > 1: wait for a mesh's gather before meshing the next (default: the payload of mesh i moves while mesh i+1 is made)")
     ap.add_argument("--no-distinct-rows", action="store_true", help="skip the share_corners = 2 measurement that follows the timed loop (profiles of the headline's kernels alone)")
@@ -630,8 +632,8 @@ def main():
     mesh_pipeline = (comm is None and not torch_gather and not dc and not args.no_mesh_pipeline)
 
     def run_meshes(n, account=None, sc=None):
-        """n meshes, every one started and finished inside this call. Pipelined (N = 1): mesh k + 1 is started -- its chain of kernels
-        enqueued, on the handle's other workspace and stream -- before mesh k is waited for."""
+        """n meshes, every one started and finished inside this call. Pipelined (N = 1): up to --mesh-depth meshes are in flight -- the
+        chains of kernels of meshes k + 1 (and k + 2) are enqueued, on the handle's other workspaces and streams, before mesh k is waited for."""
         last = None
         sc = args.share_corners if sc is None else sc
         if not mesh_pipeline:
@@ -640,13 +642,15 @@ def main():
                 if account:
                     account(last[0])
             return last
-        pend = hip.OctreeHIP.start(sdf, res, share_corners=sc) if n > 0 else None
+        inflight = []  # args.mesh_depth meshes in flight: the handle's workspaces and streams (three)
+        started = 0
         for k in range(n):
-            nxt = hip.OctreeHIP.start(sdf, res, share_corners=sc) if k + 1 < n else None
-            last = (pend.wait(), None)
+            while started < n and len(inflight) < args.mesh_depth:
+                inflight.append(hip.OctreeHIP.start(sdf, res, share_corners=sc))
+                started += 1
+            last = (inflight.pop(0).wait(), None)
             if account:
                 account(last[0])
-            pend = nxt
         return last
 
     def timed_loop():
@@ -815,7 +819,7 @@ def main():
                                         3: "distinct lattice points or distinct z rows of a brick once each, chosen by the library for the tree (evals_per_step counts the evaluations performed)"}[args.share_corners],
                        "evaluator": spec_note, "code": code,
                        "setup": f"{args.preheat} untimed meshes before the warmup steps (clock ramp)",
-                       "steps": ("meshes pipelined two deep on one handle (gsdf_hip_mesh_octree_start / _wait): mesh k+1's kernels are enqueued before mesh k "
+                       "steps": (f"meshes pipelined {args.mesh_depth} deep on one handle (gsdf_hip_mesh_octree_start / _wait): the kernels of the next meshes are enqueued before mesh k "
                                  "is waited for; all K started and finished inside the timed region") if mesh_pipeline else "one blocking mesh call per step"},
             "triangles_per_s": tris_all / dt,
             "triangles_per_step": tris_all / args.steps, "evals_per_step": evals_all / args.steps,

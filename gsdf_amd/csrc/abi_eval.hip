@@ -585,10 +585,13 @@ extern "C" void gsdf_hip_program_destroy(gsdf_program* p) {
   p->q0.release(); p->q1.release(); p->ctr.release();
   p->rec.release(); p->hdr.release(); p->grp.release();
   p->b_q0.release(); p->b_q1.release(); p->b_ctr.release(); p->b_spec_pass.release(); p->b_rec.release(); p->b_hdr.release(); p->b_grp.release();
+  p->c_q0.release(); p->c_q1.release(); p->c_ctr.release(); p->c_spec_pass.release(); p->c_rec.release(); p->c_hdr.release(); p->c_grp.release();
   if (p->stream_b) (void)hipStreamDestroy(p->stream_b);
+  if (p->stream_c) (void)hipStreamDestroy(p->stream_c);
   p->flat_grid.release(); p->flat_bits.release(); p->flat_list.release(); p->dc_tile.release(); p->dc_grid.release(); p->dc_dist.release(); p->dc_fv.release(); p->dc_nrm.release(); p->dc_edge.release(); p->dc_erun.release(); p->dc_flag.release();
   for (auto e : p->ev) if (e) (void)hipEventDestroy(e);
   for (auto e : p->ev_b) if (e) (void)hipEventDestroy(e);
+  for (auto e : p->ev_c) if (e) (void)hipEventDestroy(e);
   if (p->h_ctr) (void)hipHostFree(p->h_ctr);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;

@@ -59,7 +59,8 @@ struct gsdf_mesh_job {
   Ws w;
   explicit gsdf_mesh_job(gsdf_program* pp, int sl)
       : p(pp), slot(sl), w(sl == 0 ? Ws{pp->q0, pp->q1, pp->ctr, pp->spec_pass, pp->rec, pp->hdr, pp->grp}
-                                   : Ws{pp->b_q0, pp->b_q1, pp->b_ctr, pp->b_spec_pass, pp->b_rec, pp->b_hdr, pp->b_grp}) {}
+                           : sl == 1 ? Ws{pp->b_q0, pp->b_q1, pp->b_ctr, pp->b_spec_pass, pp->b_rec, pp->b_hdr, pp->b_grp}
+                                     : Ws{pp->c_q0, pp->c_q1, pp->c_ctr, pp->c_spec_pass, pp->c_rec, pp->c_hdr, pp->c_grp}) {}
 
   int enqueue();            // one attempt: the whole chain onto the stream, nothing waited for
   int finish(bool* again);  // waits for it; *again: a capacity was short -- enqueue() once more (nothing was dropped silently)
@@ -459,18 +460,19 @@ extern "C" int gsdf_hip_mesh_octree_start(gsdf_program* p, float res, const gsdf
 
   int slot = -1;
   for (int k = 0; k < gsdf_program::kJobs; k++) if (!p->job_busy[k]) { slot = k; break; }
-  if (slot < 0) return fail(GSDF_ERR_BAD_ARGUMENT, "two meshes of this program are in flight already: wait for one (gsdf_hip_mesh_octree_wait)");
+  if (slot < 0) return fail(GSDF_ERR_BAD_ARGUMENT, "three meshes of this program are in flight already: wait for one (gsdf_hip_mesh_octree_wait)");
   // Each slot has a workspace and a stream of its own: two chains in flight run beside each other (a caller's stream takes both).
   // Measured at npt-flange resdiv 1600, per mesh: one blocking call at a time 0.59 ms; two chains back to back on ONE stream 0.58;
   // on TWO streams 0.50 -- the centre tests and the marching kernel of one mesh (latency- and HBM-bound) run under the evaluating
   // kernel of the other. Tried and dropped: one stream for the evaluating kernels of all meshes and side streams for the stages
   // around them, ordered by events (a three-stage pipeline): 0.54, and a blocking call 0.61 -- every cross-stream event wait is
   // ~10 us on this runtime.
-  if (slot == 1 && !opts.stream && !p->stream_b && hipStreamCreateWithFlags(&p->stream_b, hipStreamNonBlocking) != hipSuccess) {
+  hipStream_t* own = slot == 1 ? &p->stream_b : (slot == 2 ? &p->stream_c : nullptr);
+  if (own && !opts.stream && !*own && hipStreamCreateWithFlags(own, hipStreamNonBlocking) != hipSuccess) {
     (void)hipGetLastError();
     return fail(GSDF_ERR_HIP, "hipStreamCreate failed");
   }
-  hipStream_t s = opts.stream ? (hipStream_t)opts.stream : (slot == 0 ? p->stream : p->stream_b);
+  hipStream_t s = opts.stream ? (hipStream_t)opts.stream : (own ? *own : p->stream);
   gsdf_mesh_job* j = new (std::nothrow) gsdf_mesh_job(p, slot);
   gsdf_mesh* m = new (std::nothrow) gsdf_mesh();
   if (!j || !m) { delete j; delete m; return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory"); }
@@ -486,13 +488,11 @@ extern "C" int gsdf_hip_mesh_octree_start(gsdf_program* p, float res, const gsdf
   m->st.origin[0] = j->ox; m->st.origin[1] = j->oy; m->st.origin[2] = j->oz;
   auto bail = [&](int code) { job_release(j); return code; };
   static_assert(sizeof(MeshCounters) <= 2048, "counters: a 2 KB slot of the pinned block each (slot 1: DCCounters of dual contouring)");
-  if (!p->h_ctr && hipHostMalloc(&p->h_ctr, 8192, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return bail(fail(GSDF_ERR_HIP, "hipHostMalloc of the counter block failed")); }
-  j->hcp = (MeshCounters*)((char*)p->h_ctr + (slot == 0 ? 0 : 4096));
-  for (auto& e : p->ev)
-    if (!e && hipEventCreate(&e) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipEventCreate failed"));
-  for (auto& e : p->ev_b)
-    if (slot == 1 && !e && hipEventCreate(&e) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipEventCreate failed"));
-  hipEvent_t* evs = slot == 0 ? p->ev : p->ev_b;
+  if (!p->h_ctr && hipHostMalloc(&p->h_ctr, 16384, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return bail(fail(GSDF_ERR_HIP, "hipHostMalloc of the counter block failed")); }
+  j->hcp = (MeshCounters*)((char*)p->h_ctr + (size_t)slot * 4096);
+  hipEvent_t* evs = slot == 0 ? p->ev : (slot == 1 ? p->ev_b : p->ev_c);
+  for (int k = 0; k < 5; k++)
+    if (!evs[k] && hipEventCreate(&evs[k]) != hipSuccess) return bail(fail(GSDF_ERR_HIP, "hipEventCreate failed"));
   j->ev0 = evs[0]; j->ev1 = evs[1]; j->ev2 = evs[2]; j->ev3 = evs[3]; j->evr = evs[4];
 
   // ---- level-synchronous descent from the top cube to level lq = min(levels, 3). The whole chain

@@ -16,6 +16,7 @@ struct gsdf_program {
   uint32_t* d_code = nullptr;
   hipStream_t stream = nullptr;
   hipStream_t stream_b = nullptr;  // the octree mesher's second chain in flight (created on first use)
+  hipStream_t stream_c = nullptr;  // its third
   std::atomic<uint64_t> evals{0};  // (atomic: host-buffer calls of several threads and a mesher may count at the same time)
   // staging for the host-buffer API
   void* d_pos = nullptr;
@@ -50,13 +51,17 @@ struct gsdf_program {
       return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-  } q0, q1, ctr, spec_pass, dc_tile, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, dc_erun, dc_flag, flat_grid, flat_bits, flat_list, rec, hdr, grp, b_q0, b_q1, b_ctr, b_spec_pass, b_rec, b_hdr, b_grp;  // b_*: the octree mesher's second workspace (its second chain in flight runs on stream_b, beside the first: gsdf_hip_mesh_octree_start)  // flat_bits: sign and near-surface bit planes of the flat renderer's lattice (flat_grid_kernel -> flat_cut_scan_kernel), flat_list: the cut cubes (-> flat_march_list_kernel)  // rec / hdr: cut-leaf records and block headers of the two-kernel leaf phase (the group sums follow the counters in ctr)  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
+  } q0, q1, ctr, spec_pass, dc_tile, dc_grid, dc_dist, dc_fv, dc_nrm, dc_edge, dc_erun, dc_flag, flat_grid, flat_bits, flat_list, rec, hdr, grp, b_q0, b_q1, b_ctr, b_spec_pass, b_rec, b_hdr, b_grp, c_q0, c_q1, c_ctr, c_spec_pass, c_rec, c_hdr, c_grp;  // b_* / c_*: the octree mesher's second and third workspace (its further chains in flight run on stream_b / stream_c, beside the first: gsdf_hip_mesh_octree_start)  // flat_bits: sign and near-surface bit planes of the flat renderer's lattice (flat_grid_kernel -> flat_cut_scan_kernel), flat_list: the cut cubes (-> flat_march_list_kernel)  // rec / hdr: cut-leaf records and block headers of the two-kernel leaf phase (the group sums follow the counters in ctr)  // dc_*: dual contouring workspace (index grid: 4 B per lattice cell); flat_grid: FlatRenderer distances
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_b[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // second set: the octree mesher has up to two chains in flight (gsdf_hip_mesh_octree_start)
-  static constexpr int kJobs = 2;
-  bool job_busy[kJobs] = {false, false};
-  hipStream_t job_stream[kJobs] = {nullptr, nullptr};
-  bool mesh_in_flight() const { return job_busy[0] || job_busy[1]; }
+  hipEvent_t ev_b[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // second set: the octree mesher has up to three chains in flight (gsdf_hip_mesh_octree_start)
+  hipEvent_t ev_c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // third set
+  // Three chains: measured at npt-flange resdiv 1600 with one, two, three, four and six meshes in flight (tools/gpu_pipe_depth.py,
+  // round 6): 0.452, 0.365-0.369, 0.340, 0.374, 0.358 ms per mesh -- a third chain fills what two leave idle around the evaluating
+  // kernel (the five dependent launches of the centre tests, the marching kernel's latency-bound passes), a fourth only adds contention.
+  static constexpr int kJobs = 3;
+  bool job_busy[kJobs] = {false, false, false};
+  hipStream_t job_stream[kJobs] = {nullptr, nullptr, nullptr};
+  bool mesh_in_flight() const { return job_busy[0] || job_busy[1] || job_busy[2]; }
   void* h_ctr = nullptr;  // pinned host copy of the device counters (a pageable destination makes the D2H copy a staged, blocking one)
   uint64_t last_tris = 0;  // triangle count of the previous mesh on this handle: sizes the next output buffer
   uint64_t last_recs = 0;  // cut leaves of the previous mesh with payload = records: sizes the next payload buffer

@@ -378,7 +378,7 @@ class OctreeHIP:
 
     @classmethod
     def start(cls, sdf, res, **kw):
-        """gsdf_hip_mesh_octree_start: enqueue the mesh and return a PendingMesh; .wait() gives the OctreeHIP. Up to two per
+        """gsdf_hip_mesh_octree_start: enqueue the mesh and return a PendingMesh; .wait() gives the OctreeHIP. Up to three per
         program in flight -- start the next one before waiting for the previous one and the GPU never idles between meshes."""
         self = cls.__new__(cls)
         self.sdf, self._mesh, self._cursor = sdf, None, 0

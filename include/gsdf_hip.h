@@ -241,11 +241,12 @@ GSDF_ABI_ASSERT(GSDF_ERR_EMPTY_BUFFERS == -1 && GSDF_ERR_LENGTH_MISMATCH == -2 &
 
 int gsdf_hip_mesh_octree(gsdf_program* p, float res, const gsdf_mesh_opts* opts, gsdf_mesh** out);
 /* The same in two halves, for a caller with several meshes to make (a part at several resolutions, a batch of parts on one
- * program): _start enqueues the whole chain of kernels and returns; _wait blocks until that mesh is complete. Up to two meshes
- * of a program may be in flight, each with a workspace and a stream of its own (opts.stream, if given, takes both): the ~30 us a
+ * program): _start enqueues the whole chain of kernels and returns; _wait blocks until that mesh is complete. Up to three meshes
+ * of a program may be in flight, each with a workspace and a stream of its own (opts.stream, if given, takes them all): the ~30 us a
  * blocking call spends between a mesh's last kernel and the next mesh's first (completion wake-up, the caller's bookkeeping,
  * launch latency) pass under a busy GPU, and the latency-bound top and tail of one mesh (centre tests, marching cubes over the
- * records) run beside the other's evaluating kernel: 0.41-0.43 instead of 0.53-0.55 ms per mesh at npt-flange resdiv 1600.
+ * records) run beside the others' evaluating kernel: 0.34 ms per mesh with three in flight, 0.37 with two, 0.45 one at a time
+ * (npt-flange resdiv 1600).
  * gsdf_hip_mesh_octree is _start followed by _wait. No other mesher call on the program while a job is in flight. */
 typedef struct gsdf_mesh_job gsdf_mesh_job;
 int gsdf_hip_mesh_octree_start(gsdf_program* p, float res, const gsdf_mesh_opts* opts, gsdf_mesh_job** job);

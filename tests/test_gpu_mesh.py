@@ -643,35 +643,37 @@ def test_example_render_stl(gpu, tmp_path):
     assert (_sorted(tris).view(np.uint32) == _sorted(ref.tris).view(np.uint32)).all()
 
 
-def test_octree_start_wait_two_in_flight(gpu):
-    """gsdf_hip_mesh_octree_start / _wait: the next mesh's chain of kernels is enqueued while the previous mesh runs (two per
-    program, back to back on its stream, one shared workspace). Same meshes as the blocking call, at mixed resolutions and
-    payloads, through capacity reruns (first meshes of a handle), interpreter and specialised; a third job and the other meshers
-    are refused while jobs are in flight."""
+def test_octree_start_wait_three_in_flight(gpu):
+    """gsdf_hip_mesh_octree_start / _wait: the next meshes' chains of kernels are enqueued while the previous mesh runs (three per
+    program, a workspace and a stream each). Same meshes as the blocking call, at mixed resolutions and payloads, through capacity
+    reruns (first meshes of a handle), interpreter and specialised; a fourth job and the other meshers are refused while jobs are in
+    flight."""
     b = Builder()
     sh = b.Scene("npt-flange")
     for spec in (False, True):
         sdf = gpu.SDF3HIP(sh)
         if spec:
             sdf.specialize()
-        rds = [90, 260, 140, 260, 400, 90]
+        rds = [90, 260, 140, 260, 400, 90, 140]
         ress = [np.float32(float(sh.Diagonal()) / rd) for rd in rds]
         want = [gpu.OctreeHIP(gpu.SDF3HIP(sh), r) for r in ress[:3]]
         want = {float(r): (w.n_tris(), w.TotalPruned(), int(w.stats.evals), _digest(w.RenderAll())) for r, w in zip(ress[:3], want)}
         want[float(ress[4])] = (423852, None, None, None)
-        pend, got = None, []
+        pend, got = [], []
         for k, r in enumerate(ress):
-            nxt = gpu.OctreeHIP.start(sdf, r, payload=gpu.PAYLOAD_RECORDS if k == 3 else gpu.PAYLOAD_TRIANGLES)
-            if pend is not None:
-                if k == 2:                                            # two in flight: a third is refused, so are the other meshers
+            pend.append(gpu.OctreeHIP.start(sdf, r, payload=gpu.PAYLOAD_RECORDS if k == 3 else gpu.PAYLOAD_TRIANGLES))
+            if len(pend) == 3:
+                if k == 2:                                            # three in flight: a fourth is refused, so are the other meshers
                     with pytest.raises(gpu.HipError):
                         gpu.OctreeHIP.start(sdf, r)
                     with pytest.raises(gpu.HipError):
                         gpu.FlatHIP(sdf, r)
                     with pytest.raises(gpu.HipError):
                         gpu.DualContourHIP(sdf, r)
-                got.append(pend.wait())
-            pend = nxt
+                got.append(pend.pop(0).wait())
+        while len(pend) > 1:
+            got.append(pend.pop(0).wait())
+        pend = pend[0]
         got.append(pend.wait())
         assert got[3].payload()[0] == gpu.PAYLOAD_RECORDS
         got[3].march()
