@@ -334,10 +334,7 @@ struct IpcTransport final : Transport {
   struct PendingRecv { void* dst; size_t bytes; int peer; };
   std::vector<int> sent_to;
   std::vector<PendingRecv> recvs;
-  struct Mapped { hipIpcMemHandle_t h; void* p; };
-  std::vector<Mapped> mapped;  // peers' allocations this process has opened (closed with the communicator)
   ~IpcTransport() override {
-    for (Mapped& m : mapped) (void)hipIpcCloseMemHandle(m.p);
     if (shm) munmap(shm, sizeof(IpcShm));
     if (creator) shm_unlink(shm_name.c_str());
   }
@@ -416,12 +413,12 @@ struct IpcTransport final : Transport {
     return GSDF_OK;
   }
   int recv(void* d, size_t bytes, int peer, hipStream_t) override { recvs.push_back({d, bytes, peer}); return GSDF_OK; }
+  // A peer's allocation is mapped for ONE copy and unmapped again (round 6; the mappings used to be cached by handle bytes: a
+  // pool buffer the peer had returned stayed pinned here, and a recycled address with the same handle bytes would have been read
+  // through the stale mapping). A test transport: the reopen costs nothing that matters.
   void* map(const hipIpcMemHandle_t& h) {
-    for (const Mapped& m : mapped) if (!std::memcmp(&m.h, &h, sizeof h)) return m.p;
-    if (mapped.size() >= 32) { (void)hipIpcCloseMemHandle(mapped.front().p); mapped.erase(mapped.begin()); }  // (pool buffers come and go)
     void* p = nullptr;
     if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    mapped.push_back({h, p});
     return p;
   }
   int group_end(hipStream_t s) override {
@@ -434,8 +431,11 @@ struct IpcTransport final : Transport {
       else {
         void* src = map(b.h);
         if (!src) mrc = fail(GSDF_ERR_HIP, "ipc: hipIpcOpenMemHandle failed (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)");
-        else if (hipMemcpyAsync(r.dst, (const char*)src + b.off, r.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-          mrc = fail(GSDF_ERR_HIP, "ipc: device-to-device copy from a peer's allocation failed");
+        else {
+          if (hipMemcpyAsync(r.dst, (const char*)src + b.off, r.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+            mrc = fail(GSDF_ERR_HIP, "ipc: device-to-device copy from a peer's allocation failed");
+          (void)hipIpcCloseMemHandle(src);
+        }
       }
       b.rc = mrc;
       b.state.store(2u, std::memory_order_release);
@@ -487,7 +487,9 @@ struct IpcTransport final : Transport {
       if (int rc = wait_until([&] { return shm->magic.load(std::memory_order_acquire) == 0x43504947u; }, "rank 0 to publish the segment")) return rc;
       if (shm->world.load() != (uint32_t)world) return fail(GSDF_ERR_BAD_ARGUMENT, "ipc: ranks disagree about the world size");
     }
-    return barrier();  // everybody is attached (rank 0 may unlink the name only at the end: late joiners of a rerun get a fresh one)
+    const int brc = barrier();  // everybody is attached: the name can go now -- the segment lives on in the mappings, and a rank 0
+    if (creator) { shm_unlink(shm_name.c_str()); creator = false; }  // that dies later leaves nothing behind in /dev/shm
+    return brc;
   }
 };
 }  // namespace

@@ -619,7 +619,15 @@ static int eval_dev(gsdf_program* p, int dim, const void* d_pos, size_t stride_b
   if (stride_bytes % 4 != 0 || stride_bytes < (size_t)dim * 4) return fail(GSDF_ERR_BAD_ARGUMENT, "bad position stride");
   spec_adopt(p);  // (a background build that has finished: its kernels from here on)
   static const bool k1_off = [] { const char* e = getenv("GSDF_HIP_NO_EVAL_K1"); return e && atoi(e) != 0; }();  // developer knob (A/B timing)
-  const bool latency = host_mapped && !k1_off && (p->f_eval_k1 != nullptr || p->f_eval == nullptr);  // (a specialised handle without a K = 1 build keeps its specialised kernel)
+  // This entry runs on several host threads at once (the host-buffer calls): the kernel it launches and what that kernel was built
+  // for are read as ONE snapshot under the mutex an adopting thread holds while it swaps them (spec_adopt_slow).
+  hipFunction_t f_eval = nullptr, f_eval_k1 = nullptr;
+  int spec_eval_k = 0;
+  {
+    std::lock_guard<std::mutex> lk(p->spec_async_mu);
+    f_eval = p->f_eval; f_eval_k1 = p->f_eval_k1; spec_eval_k = p->spec_eval_k;
+  }
+  const bool latency = host_mapped && !k1_off && (f_eval_k1 != nullptr || f_eval == nullptr);  // (a specialised handle without a K = 1 build keeps its specialised kernel)
   const int k = latency ? 1 : p->batch_k();
   static const int eval_bpc = [] { const char* e = getenv("GSDF_HIP_EVAL_BPC"); return e ? atoi(e) : 64; }();  // tuning knob: finer grids drain evenly (8 -> 64 per CU: +10 % on npt-flange)
   const unsigned grid = grid_for((n + k - 1) / k, p->num_cu, eval_bpc);
@@ -628,10 +636,10 @@ static int eval_dev(gsdf_program* p, int dim, const void* d_pos, size_t stride_b
   const uint64_t nn = (uint64_t)n;
   const int w = p->sweep_waves(k);
 #define LAUNCH_EVAL(D, KK, WW) hipLaunchKernelGGL((eval_kernel<D, KK, WW>), dim3(grid), dim3(BLOCK), p->lds_bytes(KK), s, p->d_code, q, sf, d_dist, nn)
-  if (latency && p->f_eval_k1) {
-    HIP_TRY(launch_fn(p->f_eval_k1, grid, BLOCK, p->lds_bytes(1), s, (const uint32_t*)p->d_code, q, sf, d_dist, nn));
-  } else if (p->f_eval && p->spec_eval_k == k) {  // whichever W the specialised kernel was built for: same launch
-    HIP_TRY(launch_fn(p->f_eval, grid, BLOCK, p->lds_bytes(k), s, (const uint32_t*)p->d_code, q, sf, d_dist, nn));
+  if (latency && f_eval_k1) {
+    HIP_TRY(launch_fn(f_eval_k1, grid, BLOCK, p->lds_bytes(1), s, (const uint32_t*)p->d_code, q, sf, d_dist, nn));
+  } else if (f_eval && spec_eval_k == k) {  // whichever W the specialised kernel was built for: same launch
+    HIP_TRY(launch_fn(f_eval, grid, BLOCK, p->lds_bytes(k), s, (const uint32_t*)p->d_code, q, sf, d_dist, nn));
   } else
   if (dim == 3) {
     if (k == 4) { if (w == 4) LAUNCH_EVAL(3, 4, 4); else LAUNCH_EVAL(3, 4, 3); }
@@ -869,6 +877,7 @@ extern "C" int gsdf_hip_normals3(gsdf_program* p, const float* pos, float* norma
   if (n == 0) return fail(GSDF_ERR_EMPTY_BUFFERS, "empty buffers");
   if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
   HIP_TRY(hipSetDevice(p->device));
+  spec_adopt(p);  // (a background build that has finished: its kernels from here on)
   float *d_p = nullptr, *d_n = nullptr;
   HIP_TRY(hipMalloc((void**)&d_p, n * 12));
   if (hipMalloc((void**)&d_n, n * 12) != hipSuccess) { (void)hipFree(d_p); return fail(GSDF_ERR_HIP, "hipMalloc failed"); }
@@ -897,6 +906,7 @@ extern "C" int gsdf_hip_image2(gsdf_program* p, int w, int h, float* dist_out, u
   if (!p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 3D, image2 called");
   if (w <= 0 || h <= 0) return fail(GSDF_ERR_BAD_ARGUMENT, "bad image size");
   HIP_TRY(hipSetDevice(p->device));
+  spec_adopt(p);  // (a background build that has finished: its kernels from here on)
   const size_t n = (size_t)w * (size_t)h;
   // image.go:82-88: dx = sz.X/dxi ; bb.Min += (dx/2, dy/2) ; y = bb.Max.Y - j*dy ; x = i*dx + bb.Min.X
   const float szx = p->prog.bb[3] - p->prog.bb[0], szy = p->prog.bb[4] - p->prog.bb[1];

@@ -54,11 +54,15 @@ struct Ctx {
   bool numbering = false;          // second run
   std::vector<double> cand_cost;   // first run: cost of candidate i
   std::vector<int> cand_id;        // second run: number of candidate i, or -1
+  std::vector<uint64_t> cand_key;  // first run: (node, child slot) of candidate i; the second run must meet the same subtree at the same place
   size_t cand_next = 0;
-  int candidate(double cost) {
+  bool cand_mismatch = false;      // second run: a candidate came up out of the first run's order (its numbers would name other subtrees)
+  int candidate(double cost, uint32_t node, uint32_t child_slot) {
     const size_t i = cand_next++;
-    if (!numbering) { cand_cost.push_back(cost); return -1; }
-    return i < cand_id.size() ? cand_id[i] : -1;
+    const uint64_t key = ((uint64_t)node << 32) | child_slot;
+    if (!numbering) { cand_cost.push_back(cost); cand_key.push_back(key); return -1; }
+    if (i >= cand_id.size() || cand_key[i] != key) { cand_mismatch = true; return -1; }
+    return cand_id[i];
   }
   size_t max_code;
   std::vector<int8_t> clob;  // memo: -1 unknown, 0/1
@@ -701,7 +705,7 @@ void gen_combine(Ctx& c, const gsdf_node& n, uint32_t comb, bool has_k, int dept
   if (c.discont > 0) dom_kind = -1;
   std::vector<int> sid(n.nchild, -1);  // by child number
   if (dom_kind >= 0)
-    for (uint32_t k = 0; k < n.nchild; k++) sid[order[k]] = c.candidate(cost[order[k]]);  // (emission order)
+    for (uint32_t k = 0; k < n.nchild; k++) sid[order[k]] = c.candidate(cost[order[k]], (uint32_t)(&n - c.t->nodes), order[k]);  // (emission order)
   bool any_id = false;
   for (int v : sid) any_id = any_id || v >= 0;
   // the frame's entry position magnitude for D_LIP_DOM's padding: interval stack[depth], second column (D_LIP_PUSH stores it)
@@ -1195,14 +1199,16 @@ Program compile(const gsdf_tree& t, size_t max_code_words) {
   validate(t);
   // first run: the candidate operand subtrees of the brick masks, in emission order, with their costs
   std::vector<int> cand_id;
+  std::vector<uint64_t> cand_key;
   {
     Ctx c0;
     c0.t = &t;
     c0.max_code = max_code_words;
     c0.clob.assign(t.n_nodes, -1);
     gen(c0, t.root, 0);
-    static const bool masks_off = [] { const char* e = getenv("GSDF_HIP_NO_BRICK_MASKS"); return e && atoi(e) != 0; }();  // developer knob (A/B timing, cross-check in the tests)
+    const bool masks_off = [] { const char* e = getenv("GSDF_HIP_NO_BRICK_MASKS"); return e && atoi(e) != 0; }();  // developer knob (A/B timing, cross-check in the tests), read at every compile
     cand_id.assign(c0.cand_cost.size(), -1);
+    cand_key = c0.cand_key;
     if (!masks_off) {
       std::vector<size_t> idx(c0.cand_cost.size());
       for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
@@ -1219,7 +1225,28 @@ Program compile(const gsdf_tree& t, size_t max_code_words) {
   c.clob.assign(t.n_nodes, -1);
   c.numbering = true;
   c.cand_id = cand_id;
+  c.cand_key = cand_key;
   gen(c, t.root, 0);
+  // The numbers were dealt by emission index: both runs must have met the same operand subtrees in the same order. If a decision
+  // of the lowering ever came to depend on what the second run emits (a D_SKIP moves the hypot cache's version), the numbers would
+  // name other subtrees -- a wrong mesh, silently. Then: lower once more without masks (always right, a third slower).
+  if (c.cand_mismatch || c.cand_next != cand_id.size()) {
+    bool any = false;
+    for (int v : cand_id) any = any || v >= 0;
+    if (any) {
+      Ctx c2;
+      c2.t = &t;
+      c2.max_code = max_code_words;
+      c2.clob.assign(t.n_nodes, -1);
+      c2.numbering = true;
+      c2.cand_id.assign(cand_id.size(), -1);
+      c2.cand_key = cand_key;
+      gen(c2, t.root, 0);
+      if (c2.cand_mismatch || c2.cand_next != cand_id.size()) throw std::runtime_error("lowering is not repeatable: candidate subtrees differ between runs");
+      c = std::move(c2);
+      std::fill(cand_id.begin(), cand_id.end(), -1);
+    }
+  }
   c.op(D_END);
   for (const Ctx::Table& tb : c.tables) {
     if (tb.n < 1 || tb.n > 4096) continue;  // offset stays 0: the device computes

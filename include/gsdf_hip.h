@@ -135,7 +135,9 @@ int gsdf_hip_eval2(gsdf_program* p, const void* pos, size_t pos_stride_bytes, si
 /* Thread safety of the host-buffer calls: gsdf_hip_eval3 / _eval2 may be called from several host threads on one program at
  * the same time (glrender.FlatRenderer evaluates from numParallel goroutines, flatrenderer.go:120-129): up to 4 calls are
  * in flight on their own streams and staging buffers, further callers wait for a slot. Everything else on a handle is one
- * caller at a time.
+ * caller at a time -- and while a background build is pending (gsdf_hip_program_specialize_async started, _poll not yet 1) not at
+ * the same time as those concurrent Evaluate calls either: whichever entry point first finds the build finished swaps the
+ * handle's kernels in (the Evaluate calls read theirs as one snapshot; a mesh being enqueued on another thread would not).
  * Pipelined form: submit returns at once with a ticket, wait blocks until that call's distances are in `dist` (batches of
  * up to 262144 points, any size in registered memory; at most 4 tickets outstanding per program). */
 int gsdf_hip_eval3_submit(gsdf_program* p, const void* pos, size_t pos_stride_bytes, size_t n_pos, float* dist, size_t n_dist, int* ticket);
