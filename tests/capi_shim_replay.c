@@ -219,19 +219,21 @@ int main(void) {
     CHECK(gsdf_hip_gather_plan(sizes, 3, 2, GSDF_GATHER_ALL, 0, ops, 8, &n_ops, &total) == 0 && total == 108 && n_ops == 4);
     CHECK(ops[0].kind == GSDF_GOP_COPY && ops[0].dst_off == 72 && ops[0].bytes == 36);
   }
-  /* two meshes of one program in flight (gsdf_hip_mesh_octree_start / _wait) */
+  /* three meshes of one program in flight (gsdf_hip_mesh_octree_start / _wait) */
   {
     gsdf_mesh_opts po;
     memset(&po, 0, sizeof po);
     po.prune = 1; po.shard_count = 1;
-    gsdf_mesh_job *ja = NULL, *jb = NULL, *jc = NULL;
+    gsdf_mesh_job *ja = NULL, *jb = NULL, *jc = NULL, *jd = NULL;
     CHECK(gsdf_hip_mesh_octree_start(s.h, 1.0f / 33, &po, &ja) == 0 && gsdf_hip_mesh_octree_start(s.h, 1.0f / 20, &po, &jb) == 0);
-    CHECK(gsdf_hip_mesh_octree_start(s.h, 1.0f / 20, &po, &jc) != 0); /* a third is refused */
-    gsdf_mesh *ma = NULL, *mb = NULL;
-    CHECK(gsdf_hip_mesh_octree_wait(ja, &ma) == 0 && gsdf_hip_mesh_octree_wait(jb, &mb) == 0);
+    CHECK(gsdf_hip_mesh_octree_start(s.h, 1.0f / 25, &po, &jc) == 0);
+    CHECK(gsdf_hip_mesh_octree_start(s.h, 1.0f / 20, &po, &jd) != 0); /* a fourth is refused */
+    gsdf_mesh *ma = NULL, *mb = NULL, *mc = NULL;
+    CHECK(gsdf_hip_mesh_octree_wait(ja, &ma) == 0 && gsdf_hip_mesh_octree_wait(jb, &mb) == 0 && gsdf_hip_mesh_octree_wait(jc, &mc) == 0);
     CHECK(gsdf_hip_mesh_stats_get(ma, &gst) == 0 && gst.n_tris == 41072);
     CHECK(gsdf_hip_mesh_stats_get(mb, &gst) == 0 && gst.n_tris > 1000);
-    gsdf_hip_mesh_destroy(ma); gsdf_hip_mesh_destroy(mb);
+    CHECK(gsdf_hip_mesh_stats_get(mc, &gst) == 0 && gst.n_tris > 1000);
+    gsdf_hip_mesh_destroy(ma); gsdf_hip_mesh_destroy(mb); gsdf_hip_mesh_destroy(mc);
   }
 
   /* the CSG program meshes too, through the specialised kernels, and pruning does not change its surface */
