@@ -881,17 +881,18 @@ def main():
             out["gather"] = dict(gh, note="rank 0, HIP events on the communicator's stream; a step = one mesh + its gather")
             out["gather_modes"] = dict(gather_modes, note="the same K-step loop once per mode, one after the other in this run; the headline (`value`, `ms_per_step`) is mode "
                                        + args.gather + "; `none` is what the compute scales to, `root` / `all` add the wire")
-        if world == 1 and not args.no_cpu_baseline and not dc:
-            threads = max(1, (os.cpu_count() or 2) - 1)  # GOMAXPROCS-1 (gsdfaux/gsdfaux.go:162-164)
-            # bounded sample of the SAME workload: full resdiv 1600 lattice (420 M evals) on big hosts, coarser on small ones
-            cpu_rd = args.cpu_resdiv or (args.resdiv if threads >= 64 else (1000 if threads >= 16 else 600))
-            out["cpu_baseline"] = guarded(cpu_baseline, shader, args.scene, cpu_rd, threads)
         if world == 1 and comm is None and not dc:
             out["host_inclusive"] = guarded(host_inclusive, hip, sdf, res)
         if world == 1 and comm is None and not dc and not args.no_evaluate_dropin and args.scene != "text-plate":
             out["evaluate_dropin"] = guarded(evaluate_dropin, hip, sdf, shader)
         if world == 1 and comm is None and not dc and not args.no_one_shot and not args.interpreter:
             out["one_shot"] = guarded(one_shot, hip, shader, res)
+        # (last: its 255 host threads leave the host's clocks and caches in a state the host-side measurements above should not see)
+        if world == 1 and not args.no_cpu_baseline and not dc:
+            threads = max(1, (os.cpu_count() or 2) - 1)  # GOMAXPROCS-1 (gsdfaux/gsdfaux.go:162-164)
+            # bounded sample of the SAME workload: full resdiv 1600 lattice (420 M evals) on big hosts, coarser on small ones
+            cpu_rd = args.cpu_resdiv or (args.resdiv if threads >= 64 else (1000 if threads >= 16 else 600))
+            out["cpu_baseline"] = guarded(cpu_baseline, shader, args.scene, cpu_rd, threads)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -335,6 +335,7 @@ struct IpcTransport final : Transport {
   std::vector<int> sent_to;
   std::vector<PendingRecv> recvs;
   ~IpcTransport() override {
+    for (Mapped& m : mapped) (void)hipIpcCloseMemHandle(m.p);
     if (shm) munmap(shm, sizeof(IpcShm));
     if (creator) shm_unlink(shm_name.c_str());
   }
@@ -413,12 +414,23 @@ struct IpcTransport final : Transport {
     return GSDF_OK;
   }
   int recv(void* d, size_t bytes, int peer, hipStream_t) override { recvs.push_back({d, bytes, peer}); return GSDF_OK; }
-  // A peer's allocation is mapped for ONE copy and unmapped again (round 6; the mappings used to be cached by handle bytes: a
-  // pool buffer the peer had returned stayed pinned here, and a recycled address with the same handle bytes would have been read
-  // through the stale mapping). A test transport: the reopen costs nothing that matters.
+  // Mappings of peers' allocations, by handle bytes, at most 32 (oldest closed first), all closed with the communicator. (Round 6 tried
+  // "map for one copy, unmap again" -- the advisor's point: a pool buffer the peer has returned stays pinned here, and a recycled
+  // address with the same handle bytes would be read through the stale mapping. With it hipIpcGetMemHandle on the SENDING side
+  // began to fail with "invalid argument" after a dozen gathers at npt-flange@1600 (profiles/r6g: tools/gpu_evidence.sh dist):
+  // re-exporting an allocation whose last import was closed is not something this runtime does reliably. The cache stays; the
+  // transport is for tests on one GPU and never a default. GSDF_HIP_IPC_CLOSE=1 selects the other behaviour for experiments.)
+  struct Mapped { hipIpcMemHandle_t h; void* p; };
+  std::vector<Mapped> mapped;
+  static bool close_after_copy() { static const bool v = [] { const char* e = getenv("GSDF_HIP_IPC_CLOSE"); return e && atoi(e) != 0; }(); return v; }
   void* map(const hipIpcMemHandle_t& h) {
+    if (!close_after_copy()) {
+      for (const Mapped& m : mapped) if (!std::memcmp(&m.h, &h, sizeof h)) return m.p;
+      if (mapped.size() >= 32) { (void)hipIpcCloseMemHandle(mapped.front().p); mapped.erase(mapped.begin()); }  // (pool buffers come and go)
+    }
     void* p = nullptr;
     if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (!close_after_copy()) mapped.push_back({h, p});
     return p;
   }
   int group_end(hipStream_t s) override {
@@ -434,7 +446,7 @@ struct IpcTransport final : Transport {
         else {
           if (hipMemcpyAsync(r.dst, (const char*)src + b.off, r.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
             mrc = fail(GSDF_ERR_HIP, "ipc: device-to-device copy from a peer's allocation failed");
-          (void)hipIpcCloseMemHandle(src);
+          if (close_after_copy()) (void)hipIpcCloseMemHandle(src);
         }
       }
       b.rc = mrc;

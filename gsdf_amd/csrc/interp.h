@@ -238,7 +238,9 @@ __device__ __forceinline__ void xy_shared(const P3 (&pv)[K], float (&out)[K], bo
 // sequence (dm::atan2_ref) for the whole wave where a point's result is not decided by the fast route (one wave in ~100).
 template <int K>
 __device__ __forceinline__ void atan2_shared(const P3 (&pv)[K], float (&out)[K], bool shared, bool brick, bool column) {
-#ifndef GSDF_NO_ATAN2_FAST
+  // (The short route is for the kernels built per tree. The interpreter holds every instruction's body in one function: the route's
+  // float64 temporaries beside the reference's pushed its one-point-per-lane builds into scratch, tests/test_kernel_resources.py.)
+#if defined(GSDF_SPECIALIZED) && !defined(GSDF_NO_ATAN2_FAST)
   // (one angle per lane for all of its points -- a column brick under an axis-aligned frame, npt-flange's thread -- is cheap either
   // way, and the short route's float64 temporaries cost that build its fifth workgroup per CU: the reference's sequence there)
   if (!(shared && column)) {  // (wave-uniform: instruction flags)
