@@ -173,3 +173,45 @@ def test_background_specialisation(gpu, tmp_path, monkeypatch):
     other.close()
     # poll on a handle that never asked for a build
     assert gpu.SDF3HIP(s).specialize_poll() is False
+
+
+def test_rotated_screws_through_the_short_atan2_route(gpu):
+    """A screw under a general rotation leaves no two points of a lane with equal x, y in its frame: every point takes math32.Atan2
+    on its own, which the specialised kernels evaluate by the short float64 route (dm::atan2_fast, accepted only where its float32 is
+    decided, the reference's sequence for the wave otherwise). Twelve seeded trees -- ISO, NPT (tapered) and buttress screws, rotated
+    about random axes, translated, some unioned with a second screw -- on 150 000 points each, a third of them on the lattice of a
+    renderer (shared coordinates, points on the screw's own axes): bit-identical to the oracle, octree meshes identical."""
+    rng = np.random.default_rng(61)
+
+    def make(seed):
+        r = np.random.default_rng(seed)
+        b = Builder()
+        kind = seed % 3
+        sc = (b.ScrewISO(1.0 + r.random(), 0.15 + 0.1 * r.random(), bool(seed & 1), 2.0) if kind == 0 else
+              b.ScrewNPT(0.5, 1.5) if kind == 1 else b.ScrewPlasticButtress(1.2, 0.25, 2.0))
+        axis = r.standard_normal(3)
+        s = b.Translate(b.Rotate(sc, float(r.uniform(0.2, 2.9)), tuple(float(a) for a in axis / np.linalg.norm(axis))),
+                        float(r.uniform(-1, 1)), float(r.uniform(-1, 1)), float(r.uniform(-1, 1)))
+        if seed % 4 == 0:
+            s = b.Union(s, b.Rotate(b.ScrewISO(0.8, 0.2, True, 1.5), 1.1, (1.0, 0.0, 0.0)))
+        return b, s
+
+    def check(seed):
+        b, s = make(seed)
+        sdf = gpu.SDF3HIP(s).specialize()
+        assert sdf.info()["specialized"]
+        bb = s.Bounds().astype(np.float64)
+        c, h = (bb[:3] + bb[3:]) / 2, (bb[3:] - bb[:3]) / 2 * 1.1
+        r = np.random.default_rng(seed + 1000)
+        pos = (c + (r.random((150000, 3)) * 2 - 1) * h).astype(np.float32)
+        res = np.float32(float(s.Diagonal()) / 257)
+        lat = (np.floor(pos[:50000] / res) * res).astype(np.float32)            # lattice-like: shared x, y, z values
+        lat[::7, 0] = 0.0
+        lat[::11, 1] = -0.0
+        pos[:50000] = lat
+        ref = OracleSDF(s.tree())
+        assert _mismatch(sdf.Evaluate(pos), ref.Evaluate(pos)) == 0, seed
+        oc = gpu.OctreeHIP(sdf, np.float32(float(s.Diagonal()) / 90))
+        want = ref.render_octree(np.float32(float(s.Diagonal()) / 90), 4096, True)
+        assert oc.n_tris() == want.n_tris and (_sorted(oc.RenderAll()).view(np.uint32) == _sorted(want.tris).view(np.uint32)).all(), seed
+    pmap(check, [int(x) for x in rng.integers(0, 10 ** 6, 12)], workers=12)
