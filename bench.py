@@ -475,6 +475,8 @@ def main():
                          "finished inside the timed region)")
     ap.add_argument("--mesh-depth", type=int, default=3, choices=[1, 2, 3],
                     help="N = 1, pipelined: meshes in flight on the handle (it has three workspaces and streams; 3 measured best: tools/gpu_pipe_depth.py)")
+    ap.add_argument("--dc-handles", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="N = 1, --renderer dualcontour: handles of the tree, each with one blocking mesh in flight on a host thread of its own")
     ap.add_argument("--no-gather-pipeline", action="store_true",
                     help="N > 1: wait for a mesh's gather before meshing the next (default: the payload of mesh i moves while mesh i+1 is made)")
     ap.add_argument("--no-distinct-rows", action="store_true", help="skip the share_corners = 2 measurement that follows the timed loop (profiles of the headline's kernels alone)")
@@ -571,6 +573,21 @@ def main():
             print("bench: specialised build unavailable, using the interpreter kernels: %s" % str(e)[:300], file=sys.stderr)
             spec_note = "interpreter kernels (specialised build failed)"
 
+    # Dual contouring's meshes are one blocking chain each, with host round trips between its stages (the octree's second and third
+    # workspace have no counterpart there): a caller with several meshes to make keeps the GPU busy the way a Go caller would --
+    # a second handle of the same tree and a host thread per handle (N = 1; --no-mesh-pipeline: one handle, one mesh at a time).
+    sdf_b = None  # (a list of the further handles, or None)
+    if args.mode == "mesh" and args.renderer == "dualcontour" and world == 1 and not args.no_mesh_pipeline and not force_dist and args.dc_handles > 1:
+        sdf_b = []
+        for _ in range(args.dc_handles - 1):
+            hb = hip.SDF3HIP(shader)
+            if not args.interpreter and "specialised" in spec_note:
+                try:
+                    hb.specialize()
+                except hip.HipError:
+                    pass  # (this handle keeps the interpreter kernels: same bits)
+            sdf_b.append(hb)
+
     if args.mode == "eval":
         return eval_mode(args, torch, np, hip, shader, sdf, res, dev)
     if args.mode == "flat":
@@ -636,6 +653,8 @@ def main():
         chains of kernels of meshes k + 1 (and k + 2) are enqueued, on the handle's other workspaces and streams, before mesh k is waited for."""
         last = None
         sc = args.share_corners if sc is None else sc
+        if dc and sdf_b is not None:
+            return run_dc_two_handles(n, account)
         if not mesh_pipeline:
             for _ in range(n):
                 last = step()
@@ -652,6 +671,32 @@ def main():
             if account:
                 account(last[0])
         return last
+
+    def run_dc_two_handles(n, account):
+        """n dual-contouring meshes, every one made inside this call: handle t of H makes meshes t, t + H, ... in its own host thread (the C calls
+        release the GIL); a mesh is accounted and let go as soon as it is done, the last one is kept."""
+        import threading
+        lock, keep, errs = threading.Lock(), {}, []
+        handles = [sdf] + list(sdf_b)
+
+        def worker(t):
+            try:
+                for i in range(t, n, len(handles)):
+                    oc = hip.DualContourHIP(handles[t], res, shard_rank=rank, shard_count=world)
+                    with lock:
+                        if account:
+                            account(oc)
+                        keep[i] = oc if i == n - 1 else None
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(len(handles))]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        if errs:
+            raise errs[0]
+        return (keep.get(n - 1), None) if n > 0 else None
 
     def timed_loop():
         """The contract's loop for the gather in use: W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides;
@@ -820,7 +865,10 @@ def main():
                        "evaluator": spec_note, "code": code,
                        "setup": f"{args.preheat} untimed meshes before the warmup steps (clock ramp)",
                        "steps": (f"meshes pipelined {args.mesh_depth} deep on one handle (gsdf_hip_mesh_octree_start / _wait): the kernels of the next meshes are enqueued before mesh k "
-                                 "is waited for; all K started and finished inside the timed region") if mesh_pipeline else "one blocking mesh call per step"},
+                                 "is waited for; all K started and finished inside the timed region") if mesh_pipeline else
+                                (f"{args.dc_handles} handles of the tree, a host thread and one blocking dual-contouring mesh in flight on each (a mesh is one chain with host round trips "
+                                 "between its stages); all K made inside the timed region; --no-mesh-pipeline: one handle, one mesh at a time") if (dc and sdf_b is not None)
+                                else "one blocking mesh call per step"},
             "triangles_per_s": tris_all / dt,
             "triangles_per_step": tris_all / args.steps, "evals_per_step": evals_all / args.steps,
             "roofline": rf,

@@ -518,6 +518,33 @@ def test_zero_copy_host_views(gpu):
         empty.stl_view()
 
 
+def test_dual_contouring_two_handles_of_one_tree_at_once(gpu):
+    """What bench.py --renderer dualcontour does at N = 1: two handles of the same tree, a host thread and one blocking dual-contouring
+    mesh in flight on each (a mesh is one chain with host round trips between its stages). Every mesh made that way is the mesh of a
+    sequential call, bit for bit; interpreter and specialised handles side by side."""
+    import threading
+    b = Builder()
+    s = b.Scene("npt-flange")
+    res = np.float32(float(s.Diagonal()) / 160)
+    want = _digest(gpu.DualContourHIP(gpu.SDF3HIP(s), res).RenderAll())
+    handles = [gpu.SDF3HIP(s), gpu.SDF3HIP(s).specialize()]
+    got, errs = [[], []], []
+
+    def work(t):
+        try:
+            for _ in range(6):
+                got[t].append(_digest(gpu.DualContourHIP(handles[t], res).RenderAll()))
+        except Exception as e:  # noqa: BLE001 - reported below, in the main thread
+            errs.append((t, repr(e)))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert got == [[want] * 6, [want] * 6]
+
+
 def test_concurrent_meshing_from_host_threads(gpu):
     """Handles are independent (own stream, own workspace; buffer pools are locked): four host threads meshing four
     different scenes at once get the results of the sequential runs."""
