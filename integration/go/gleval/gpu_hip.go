@@ -54,8 +54,6 @@ func hipErr(rc C.int) error {
 // NewComputeGPUSDF3 spends compiling GLSL (gpu.go:35-54) -- in the background; Wait blocks until it has landed.
 type HIPConfig struct{ Specialize, Wait bool }
 
-type hipProgram struct{ h *C.gsdf_program }
-
 func newHIPProgram(t HIPTree, bb [6]float32, cfg HIPConfig) (*C.gsdf_program, error) {
 	if len(t.Nodes) == 0 {
 		return nil, errors.New("gsdf_hip: empty tree")

@@ -126,6 +126,10 @@ def test_go_files_are_well_formed_and_tagged():
         for ch in code:
             depth += (ch == "{") - (ch == "}")
             assert depth >= 0, rel
+        # Go refuses unused imports: every imported package is named somewhere in the code
+        for imp in re.findall(r'^\s*"([\w./-]+)"\s*$', re.sub(r"/\*.*?\*/", " ", src, flags=re.S), re.M):
+            pkg = imp.split("/")[-1]
+            assert re.search(r"\b%s\." % re.escape(pkg), code), f"{rel}: import {imp} is never used"
         if 'import "C"' in src:
             assert src.startswith("//go:build cgo && hip\n\npackage "), rel
             assert re.search(r"\*/\nimport \"C\"\n", src), rel + ': import "C" must follow the preamble comment directly'
