@@ -13,6 +13,7 @@
 #include "kernels_flat.h"
 #include "kernels_dc.h"
 #include "kernels_stl.h"
+#include "kernels_minecraft.h"
 #include "abi_program.h"
 #include "host_math.h"
 
@@ -857,6 +858,76 @@ extern "C" int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chisele
 // glrender.FlatRenderer (flatrenderer.go:36-256) on device: Reset's lattice, evalGrid into a dense grid in HBM,
 // ReadTriangles as one marching-cubes pass over every cube. Multi-GPU: z-slabs of cubes like the reference's goroutines
 // (:120-122); a rank evaluates the planes its cubes touch (one shared plane per boundary is recomputed, nothing exchanged).
+// minecraftRender (glrender/dual_contour.go:297-403): the axis-aligned faces between cubes whose origins lie on different sides of
+// the surface. Unexported in the reference and used by one test; here for completeness of row a20. Three steps on the caller's
+// stream: the four positions of every level-1 cube to HBM, the program's ordinary Evaluate over them (gsdf_hip_eval3_dev: whatever
+// kernels the handle runs), one pass that counts the faces and one that writes them.
+extern "C" int gsdf_hip_mesh_minecraft(gsdf_program* p, float res, void* stream, gsdf_mesh** out) {
+  if (!p || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (p->prog.is2d) return fail(GSDF_ERR_DIMENSION, "program is 2D");
+  if (!(res > 0) || std::isnan(res) || std::isinf(res)) return fail(GSDF_ERR_RESOLUTION, "invalid renderer cube resolution");
+  if (p->mesh_in_flight()) return fail(GSDF_ERR_BAD_ARGUMENT, "an octree mesh of this program is in flight: wait for it first (shared workspace)");
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  // makeICube over the SDF's own bounds (dual_contour.go:298-299; glrender.go:222-235)
+  const float* bb = p->prog.bb;
+  const float longAxis = fmaxf(bb[3] - bb[0], fmaxf(bb[4] - bb[1], bb[5] - bb[2]));
+  const int levels = (int)std::ceil(gsdf::log2f32(longAxis / res)) + 1;
+  if (levels <= 1) return fail(GSDF_ERR_RESOLUTION, "resolution not fine enough for marching cubes");
+  if (levels > 9) return fail(GSDF_ERR_RESOLUTION, "minecraft render lattice too large: more than 9 octree levels (every cube of the lattice is evaluated)");
+  const int nshift = levels - 1;
+  const uint64_t n_cubes = (uint64_t)1 << (3 * nshift);
+  gsdf_mesh* m = new (std::nothrow) gsdf_mesh();
+  if (!m) return fail(GSDF_ERR_BAD_ARGUMENT, "out of memory");
+  m->device = p->device; m->stream = s;
+  m->st.levels = levels; m->st.res = res;
+  m->st.origin[0] = bb[0]; m->st.origin[1] = bb[1]; m->st.origin[2] = bb[2];
+  float* d_pos = nullptr;
+  float* d_dist = nullptr;
+  unsigned long long* d_ctr = nullptr;
+  auto bail = [&](int code) {
+    if (d_pos) (void)hipFree(d_pos);
+    if (d_dist) (void)hipFree(d_dist);
+    if (d_ctr) (void)hipFree(d_ctr);
+    gsdf_hip_mesh_destroy(m);
+    return code;
+  };
+#define HIP_TRYM(expr)                                                                                          \
+  do {                                                                                                          \
+    hipError_t _e = (expr);                                                                                     \
+    if (_e != hipSuccess) return bail(fail(GSDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
+  } while (0)
+  HIP_TRYM(hipMalloc((void**)&d_pos, n_cubes * 48));
+  HIP_TRYM(hipMalloc((void**)&d_dist, n_cubes * 16));
+  HIP_TRYM(hipMalloc((void**)&d_ctr, 8));
+  const unsigned grid = grid_for(n_cubes, p->num_cu, 16);
+  hipLaunchKernelGGL(mcr_positions_kernel, dim3(grid), dim3(BLOCK), 0, s, bb[0], bb[1], bb[2], res, nshift, n_cubes, d_pos);
+  HIP_TRYM(hipGetLastError());
+  if (int rc = gsdf_hip_eval3_dev(p, d_pos, 12, d_dist, (size_t)(4 * n_cubes), (void*)s)) return bail(rc);
+  unsigned long long n_tris = 0;
+  for (int pass = 0; pass < 2; pass++) {  // count, then emit into a buffer of exactly that size
+    HIP_TRYM(hipMemsetAsync(d_ctr, 0, 8, s));
+    hipLaunchKernelGGL(mcr_faces_kernel, dim3(grid), dim3(BLOCK), 0, s, (const float*)d_dist, bb[0], bb[1], bb[2], res, nshift, n_cubes,
+                       pass == 0 ? (float*)nullptr : m->d_tris, (unsigned long long)m->cap, d_ctr);
+    HIP_TRYM(hipGetLastError());
+    HIP_TRYM(hipMemcpyAsync(&n_tris, d_ctr, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRYM(hipStreamSynchronize(s));
+    if (pass == 0) {
+      if (n_tris == 0) break;
+      m->d_tris = pool_take(p->device, n_tris, &m->cap);
+      if (!m->d_tris) { HIP_TRYM(hipMalloc((void**)&m->d_tris, n_tris * 36)); m->cap = n_tris; }
+    }
+  }
+  m->st.n_tris = n_tris;
+  m->st.evals = 4 * n_cubes;
+  m->st.leaf_cubes = n_cubes;
+  (void)hipFree(d_pos); (void)hipFree(d_dist); (void)hipFree(d_ctr);
+#undef HIP_TRYM
+  *out = m;
+  return GSDF_OK;
+}
+
 extern "C" int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, int shard_count, void* stream, gsdf_mesh** out) {
   if (!p || !out) return fail(GSDF_ERR_BAD_ARGUMENT, "null argument");
   *out = nullptr;

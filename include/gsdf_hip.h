@@ -268,6 +268,11 @@ int gsdf_hip_mesh_dualcontour(gsdf_program* p, float res, int chiseled, int shar
  * pass, levels = 0. Multi-GPU: rank shard_rank of shard_count takes a z-slab of cubes (the reference's goroutine split,
  * :120-122), nothing exchanged. */
 int gsdf_hip_mesh_flat(gsdf_program* p, float res, int shard_rank, int shard_count, void* stream, gsdf_mesh** out);
+/* minecraftRender (glrender/dual_contour.go:297-403; unexported there, exercised by glrender_test.go:55-81): every level-1 cube of the
+ * top cube over Bounds() has its origin and its +x, +y, +z edge ends evaluated; an edge whose ends differ in sign contributes the
+ * square face across it, two triangles wound by which end is inside. Triangles in no particular order (the reference's is the order of
+ * its breadth-first decomposition); stats: n_tris, evals = 4 per cube, levels. At most 9 levels (every cube is evaluated). */
+int gsdf_hip_mesh_minecraft(gsdf_program* p, float res, void* stream, gsdf_mesh** out);
 int gsdf_hip_mesh_stats_get(const gsdf_mesh* m, gsdf_mesh_stats* st);
 /* Device time of the mesher's stages, where it records them (dual contouring: dc_origin, dc_edges, dc_normals, dc_place, dc_quads;
  * HIP events between the stages): *n = number of stages, ms / names (optional, cap entries) = milliseconds and kernel names. */

@@ -84,6 +84,16 @@ func NewDualContourRendererHIP(s *gleval.SDF3HIP, cubeResolution float32, chisel
 	return newMeshHIP(m), nil
 }
 
+// NewMinecraftRendererHIP: minecraftRender (dual_contour.go:297-403; unexported there) -- the axis-aligned faces between level-1
+// cubes whose origins lie on different sides of the surface.
+func NewMinecraftRendererHIP(s *gleval.SDF3HIP, cubeResolution float32) (*MeshHIP, error) {
+	var m *C.gsdf_mesh
+	if rc := C.gsdf_hip_mesh_minecraft(hipProgram(s), C.float(cubeResolution), nil, &m); rc != 0 {
+		return nil, hipErr(rc)
+	}
+	return newMeshHIP(m), nil
+}
+
 // ReadTriangles: the iterator contract of octreerenderer.go:131-134,154-157 -- len(dst) >= 5 or io.ErrShortBuffer,
 // (n, nil) while more remain, (n, io.EOF) at the end.
 func (o *MeshHIP) ReadTriangles(dst []ms3.Triangle, userData any) (int, error) {

@@ -47,6 +47,7 @@ def lib():
         L.orc_render_flat.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.POINTER(_Mesh)]
         L.orc_render_octree.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.POINTER(_Mesh)]
         L.orc_render_dualcontour.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(_Mesh)]
+        L.orc_render_minecraft.argtypes = [C.c_void_p, C.c_float, C.POINTER(_Mesh)]
         L.orc_lsq_mgs64.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_mesh_free.argtypes = [C.POINTER(_Mesh)]
         L.orc_stl_size.restype = C.c_size_t
@@ -156,6 +157,16 @@ class OracleSDF:
         err = self._L.orc_render_dualcontour(self._h, np.float32(res), int(chiseled), C.byref(m))
         if err:
             raise RuntimeError(f"oracle dual contour renderer error {err}")
+        r = MeshResult(m)
+        self._L.orc_mesh_free(C.byref(m))
+        return r
+
+    def render_minecraft(self, res):
+        """glrender.minecraftRender (dual_contour.go:297-403)."""
+        m = _Mesh()
+        err = self._L.orc_render_minecraft(self._h, np.float32(res), C.byref(m))
+        if err:
+            raise RuntimeError(f"oracle minecraft renderer error {err}")
         r = MeshResult(m)
         self._L.orc_mesh_free(C.byref(m))
         return r

@@ -61,6 +61,8 @@ int orc_render_flat(const orc_sdf* s, float res, int batch, int nthreads, orc_me
 int orc_render_octree(const orc_sdf* s, float res, int batch, int prune, orc_mesh* out);
 /* glrender.DualContourRenderer + DualContourLeastSquares (dual_contour.go, dual_contour_vertexplacement.go) */
 int orc_render_dualcontour(const orc_sdf* s, float res, int chiseled, orc_mesh* out);
+/* glrender/dual_contour.go:297-403 minecraftRender */
+int orc_render_minecraft(const orc_sdf* s, float res, orc_mesh* out);
 /* glrender.WriteBinarySTL (stl.go:15-62): writes 84+50*n bytes into dst (caller sized). */
 size_t orc_stl_size(uint64_t n_tris);
 int orc_write_stl(const float* tris, uint64_t n_tris, uint8_t* dst);

@@ -682,4 +682,75 @@ int orc_render_dualcontour(const orc_sdf* s, float res, int chiseled, orc_mesh* 
 }
 
 /* test access to leastSquaresMGS64 (rows x 3 floats, b rows floats) */
+/* ---------------- minecraftRender (glrender/dual_contour.go:297-403) ----------------
+ * Every level-1 cube of the top cube over the SDF's own Bounds(): origin and the ends of its +x, +y, +z edges evaluated (:323-335,
+ * ms3.Add adds the zero components too); an edge whose ends differ in sign bit (ActiveX/Y/Z :259-267) contributes the square face
+ * across it -- two triangles, first and third vertex exchanged when the far end is the smaller (FlipX/Y/Z :271-273). Cube order:
+ * x fastest (the reference's is its breadth-first decomposition's [external]; the mesh is compared as a set). */
+static inline V3 v3add(V3 a, float x, float y, float z) { V3 r = {a.x + x, a.y + y, a.z + z}; return r; }
+static void mcr_tri(orc_mesh* out, V3 a, V3 b, V3 c, int flip) {
+  mesh_reserve(out, 1);
+  float* t = out->tris + 9 * out->n_tris++;
+  if (flip) { V3 k = a; a = c; c = k; }
+  t[0] = a.x; t[1] = a.y; t[2] = a.z; t[3] = b.x; t[4] = b.y; t[5] = b.z; t[6] = c.x; t[7] = c.y; t[8] = c.z;
+}
+int orc_render_minecraft(const orc_sdf* s, float res, orc_mesh* out) {
+  memset(out, 0, sizeof(*out));
+  float bbf[6];
+  orc_sdf_bounds(s, bbf);
+  Box3 bb = {{bbf[0], bbf[1], bbf[2]}, {bbf[3], bbf[4], bbf[5]}};
+  int levels;
+  int err = make_icube(bb, res, &levels);
+  if (err) return err;
+  if (levels > 9) return -6;
+  out->levels = levels;
+  const V3 origin = bb.min;
+  const int n = 1 << (levels - 1);
+  const size_t N = (size_t)n * n * n;
+  orc_pool* vp = orc_pool_create(4096);
+  const size_t B = 1 << 14;
+  float* posbuf = (float*)malloc(sizeof(float) * 12 * B);
+  float* distbuf = (float*)malloc(sizeof(float) * 4 * B);
+  const float sz = cube_size(1, res);
+  for (size_t c0 = 0; c0 < N && !err; c0 += B) {
+    const size_t nb = N - c0 < B ? N - c0 : B;
+    for (size_t i = 0; i < nb; i++) {
+      const size_t c = c0 + i;
+      Cube cb = {(int)(c % n), (int)((c / n) % n), (int)(c / ((size_t)n * n)), 1};
+      const V3 o = cube_origin(cb, origin, sz);
+      const V3 q[4] = {o, v3add(o, sz, 0.0f, 0.0f), v3add(o, 0.0f, sz, 0.0f), v3add(o, 0.0f, 0.0f, sz)};
+      for (int k = 0; k < 4; k++) { posbuf[12 * i + 3 * k] = q[k].x; posbuf[12 * i + 3 * k + 1] = q[k].y; posbuf[12 * i + 3 * k + 2] = q[k].z; }
+    }
+    err = orc_eval3(s, vp, posbuf, distbuf, 4 * nb);
+    out->evals += 4 * nb;
+    for (size_t i = 0; i < nb && !err; i++) {
+      const size_t c = c0 + i;
+      Cube cb = {(int)(c % n), (int)((c / n) % n), (int)(c / ((size_t)n * n)), 1};
+      const V3 o = cube_origin(cb, origin, sz);
+      const float d0 = distbuf[4 * i], dx = distbuf[4 * i + 1], dy = distbuf[4 * i + 2], dz = distbuf[4 * i + 3];
+      if (dc_signbit(d0) != dc_signbit(dx)) {
+        const V3 xo = v3add(o, sz, 0.0f, 0.0f);
+        const int flip = dx - d0 < 0;
+        mcr_tri(out, xo, v3add(xo, 0.0f, sz, 0.0f), v3add(xo, 0.0f, sz, sz), flip);
+        mcr_tri(out, v3add(xo, 0.0f, sz, sz), v3add(xo, 0.0f, 0.0f, sz), xo, flip);
+      }
+      if (dc_signbit(d0) != dc_signbit(dy)) {
+        const V3 yo = v3add(o, 0.0f, sz, 0.0f);
+        const int flip = dy - d0 < 0;
+        mcr_tri(out, yo, v3add(yo, 0.0f, 0.0f, sz), v3add(yo, sz, 0.0f, sz), flip);
+        mcr_tri(out, v3add(yo, sz, 0.0f, sz), v3add(yo, sz, 0.0f, 0.0f), yo, flip);
+      }
+      if (dc_signbit(d0) != dc_signbit(dz)) {
+        const V3 zo = v3add(o, 0.0f, 0.0f, sz);
+        const int flip = dz - d0 < 0;
+        mcr_tri(out, zo, v3add(zo, sz, 0.0f, 0.0f), v3add(zo, sz, sz, 0.0f), flip);
+        mcr_tri(out, v3add(zo, sz, sz, 0.0f), v3add(zo, 0.0f, sz, 0.0f), zo, flip);
+      }
+    }
+  }
+  free(posbuf); free(distbuf);
+  orc_pool_destroy(vp);
+  return err;
+}
+
 void orc_lsq_mgs64(const float* A, const float* b, int K, float x[3]) { lsq_mgs64((const float(*)[3])A, b, K, x); }

@@ -711,3 +711,31 @@ def test_octree_start_wait_three_in_flight(gpu):
                 assert oc.TotalPruned() == pr and int(oc.stats.evals) == ev and _digest(oc.RenderAll()) == dg
         gpu.OctreeHIP.start(sdf, ress[0])                             # dropped without wait(): completed and released by its finaliser
         assert gpu.FlatHIP(sdf, ress[0]).n_tris() > 0                 # ... after which the handle is free again
+
+
+def test_minecraft_render_identical_to_oracle(gpu):
+    """gsdf_hip_mesh_minecraft (glrender.minecraftRender, dual_contour.go:297-403): the reference's own case (unit sphere, res 1/4,
+    glrender_test.go:55-81), a CSG part and a tree with negative coordinates throughout -- triangle sets bit-identical to the oracle's
+    (which tests/test_oracle_golden.py holds to an independent statement), evaluation counts equal, interpreter and specialised
+    evaluation kernels; errors like the other renderers'."""
+    b = Builder()
+    cases = [(b.NewSphere(1.0), np.float32(0.25)), (b.Scene("npt-flange"), None), (b.Translate(b.NewBox(1.0, 0.7, 0.5, 0.1), -3.0, -2.0, -1.5), np.float32(0.04))]
+    for sh, res in cases:
+        res = res if res is not None else np.float32(float(sh.Diagonal()) / 70)
+        want = OracleSDF(sh.tree()).render_minecraft(res)
+        for spec in (False, True):
+            sdf = gpu.SDF3HIP(sh)
+            if spec:
+                sdf.specialize()
+            m = gpu.MinecraftHIP(sdf, res)
+            assert m.n_tris() == want.n_tris > 0 and int(m.stats.evals) == want.evals and int(m.stats.levels) == want.levels
+            assert (_sorted(m.RenderAll()).view(np.uint32) == _sorted(want.tris).view(np.uint32)).all()
+            assert sdf.Evaluations() >= want.evals
+            assert len(m.WriteBinarySTL()) == 84 + 50 * want.n_tris
+    sdf = gpu.SDF3HIP(b.NewSphere(1.0))
+    with pytest.raises(gpu.HipError):
+        gpu.MinecraftHIP(sdf, np.float32(0))            # "invalid renderer cube resolution"
+    with pytest.raises(gpu.HipError):
+        gpu.MinecraftHIP(sdf, np.float32(8.0))          # "resolution not fine enough ..."
+    with pytest.raises(gpu.HipError):
+        gpu.MinecraftHIP(sdf, np.float32(1e-3))         # more than 9 levels: every cube of the lattice would be evaluated
