@@ -234,6 +234,16 @@ __device__ __forceinline__ void xy_shared(const P3 (&pv)[K], float (&out)[K], bo
   if (shared) { KLOOP if (kp & 1) out[kp] = out[kp ? kp - 1 : 0]; }
   else { KLOOP if (kp & 1) out[kp] = f(pv[kp].x, pv[kp].y); }
 }
+// What a lane keeps between the two passes of a column brick (kernels_octree.h: the 8 corners of a lane's (x, y) column are evaluated
+// four z rows at a time): the angle atan2(y, x) of an instruction whose points share x, y -- the same float in both passes, since the
+// column is the same and the instruction stream in front of it is -- keyed by the instruction's program counter (one entry: what a
+// program with one screw needs; another instruction overwrites it). The two passes sit behind their own wave-level gates, so the
+// compiler does not merge the two evaluations itself (round 6: the float64 sequence stood twice in npt-flange's kernel).
+struct XYCache {
+  float th = 0.0f;
+  uint32_t pc = 0xffffffffu;  // wave-uniform
+};
+
 // math.Atan2 of the points' (y, x) with xy_shared's sharing: dm::atan2_fast for every point, one wave vote, the reference's own
 // sequence (dm::atan2_ref) for the whole wave where a point's result is not decided by the fast route (one wave in ~100).
 template <int K>
@@ -459,7 +469,8 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
                                          const bool brick = false /* wave-uniform: the wave is spatially compact (polygon edge culling pays, poly_cull); with SHARE = 2 also: point kp has the same z in every lane; see xy_shared */,
                                          const float lip_h = 0.0f, const uint32_t lip_base = 0u,
                                          const uint32_t bmask = 0u /* wave-uniform: the brick mask of the cube this wave evaluates (dev_ops.h: D_SKIP); 0 where a wave is no brick */,
-                                         uint32_t* lip_fired = nullptr /* interval mode: this lane's brick mask is OR-ed in here */) {
+                                         uint32_t* lip_fired = nullptr /* interval mode: this lane's brick mask is OR-ed in here */,
+                                         XYCache* xyc = nullptr /* column bricks: what the lane's other pass already knows (see XYCache) */) {
   using namespace dm;
   static_assert(!LIP || (K == 2 && SHARE == 0), "interval mode: two points per lane, lower and upper bound");
   [[maybe_unused]] float lipR = lip_h;
@@ -985,7 +996,15 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
       }
       case D_SCREW_PRE: {
         float th[K];  // atan2(P.y, P.x): a function of x,y only
-        atan2_shared<K>(pv, th, sh_xy, brick, sh_col);
+#ifdef GSDF_NO_XYCACHE  // (A/B knob of the specialised build: GSDF_HIP_SPEC_FLAGS=-DGSDF_NO_XYCACHE)
+        xyc = nullptr;
+#endif
+        if (!LIP && xyc != nullptr && sh_xy && sh_col && xyc->pc == pc) {
+          KLOOP th[kp] = xyc->th;  // the column's other pass has it
+        } else {
+          atan2_shared<K>(pv, th, sh_xy, brick, sh_col);
+          if (!LIP && xyc != nullptr && sh_xy && sh_col) { xyc->th = th[0]; xyc->pc = pc; }
+        }
         ENSURE_HXY();
         {
           // z' = z + lead*theta/2pi ; sawTooth(z', pitch): both divisors are wave-uniform -> exact reciprocal form

@@ -766,6 +766,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
       float dall[8];  // distances of rows 0..7; static shift register
 #pragma unroll
       for (int j = 0; j < 8; j++) dall[j] = 0.f;
+      gsdf_dev::XYCache xyc;  // what this lane's column knows from its other pass (one brick: reset per brick)
 #define GSDF_COLUMN_PASS                                                     \
   {                                                                          \
     P3 pk[K];                                                                \
@@ -777,7 +778,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
       pk[kp].y = py;                                                         \
       pk[kp].z = (r & 1u) ? za + res : za;                                   \
     }                                                                        \
-    gsdf_dev::sdf_eval<K, 2>(code, pk, dk, lds, BLOCK, /*brick=*/true, 0.0f, 0u, bmask); \
+    gsdf_dev::sdf_eval<K, 2>(code, pk, dk, lds, BLOCK, /*brick=*/true, 0.0f, 0u, bmask, nullptr, &xyc); \
     _Pragma("unroll") for (int j = 0; j < 8 - K; j++) dall[j] = dall[j + K]; \
     _Pragma("unroll") for (int kp = 0; kp < K; kp++) dall[8 - K + kp] = dk[kp]; \
   }
@@ -816,7 +817,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES) leaf_eval_kernel(const uint32_t*
       pk[kp].y = py;                                                                         \
       pk[kp].z = (r & 1u) ? za + res : za;                                                   \
     }                                                                                        \
-    gsdf_dev::sdf_eval<KK, 2>(code, pk, dk, lds, BLOCK, /*brick=*/true, 0.0f, 0u, bmask);    \
+    gsdf_dev::sdf_eval<KK, 2>(code, pk, dk, lds, BLOCK, /*brick=*/true, 0.0f, 0u, bmask, nullptr, &xyc); \
     _Pragma("unroll") for (int kp = 0; kp < KK; kp++) dall[(D0) + kp] = dk[kp];              \
   }
         if (BOTH) {  // one body: what depends on x and y alone is computed once for all the rows
