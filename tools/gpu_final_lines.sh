@@ -2,7 +2,7 @@
 # Round 6, last pass on the final commit: the GPU suite's log, then the bench lines again now that profiles/ holds the PMC summaries of
 # THIS build (roofline.counters: "its code key equals the running kernels'") -> gpurun_out/<tag>_*
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-T=${1:-r6h}
+T=${1:-r6k}
 python -m pytest tests -m gpu -q > gpurun_out/${T}_gpu_suite.log 2>&1; grep -E "passed|failed|error" gpurun_out/${T}_gpu_suite.log | tail -3
 timeout 900 python bench.py --steps 20 --warmup 3 > gpurun_out/${T}_default_bench.json 2> gpurun_out/${T}_default_bench.err
 for sc in "npt-flange 1600" "bolt 2000" "knurled-cylinder 2000"; do set -- $sc
