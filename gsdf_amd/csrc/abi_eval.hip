@@ -123,6 +123,26 @@ extern "C" int gsdf_hip_selftest_atan2(int mode, int log2n, uint64_t* mismatches
   return rc;
 }
 
+// Test hook: dm::cossin_fast (float32 of math.Cos / math.Sin by FMAs, accepted only where the rounding is decided) against dm::cossinf_,
+// over every float32 argument.
+extern "C" int gsdf_hip_selftest_cossin(uint64_t* mismatches, uint64_t* fast_path_arguments) {
+  if (mismatches) *mismatches = 0;
+  if (fast_path_arguments) *fast_path_arguments = 0;
+  unsigned long long* d_c = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_c, 16));
+  int rc = GSDF_OK;
+  do {
+    if (hipMemset(d_c, 0, 16) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "memset failed"); break; }
+    hipLaunchKernelGGL(cossin_selftest_kernel, dim3(4096), dim3(BLOCK), 0, nullptr, d_c, d_c + 1);
+    unsigned long long h[2] = {0, 0};
+    if (hipMemcpy(h, d_c, 16, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(GSDF_ERR_HIP, "selftest kernel failed"); break; }
+    if (mismatches) *mismatches = h[0];
+    if (fast_path_arguments) *fast_path_arguments = h[1];
+  } while (0);
+  (void)hipFree(d_c);
+  return rc;
+}
+
 // Test hook: dm::sqrt_1to2 against sqrtf for all 8,388,609 floats in [1, 2].
 extern "C" int gsdf_hip_selftest_sqrt(uint64_t* mismatches) {
   unsigned long long* d_c = nullptr;

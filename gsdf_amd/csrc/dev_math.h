@@ -370,6 +370,54 @@ DM_INL void cossinf_(float xf, float& c_out, float& s_out) {
   c_out = (float)(csign ? -c : c);
   s_out = xs == 0.0 ? xf : (float)(ssign ? -sn : sn);  // Sin(+-0) = +-0
 }
+// math.Cos(x) and math.Sin(x) of a twist's angle WITHOUT the reference's operation sequence, where that provably rounds the same (round
+// 6; as atan2_fast). cossinf_ costs ~190 instructions: a float64 -> uint64 conversion, 64-bit integer octant logic, Cody-Waite and
+// both polynomials in unfused multiplies and adds, 64-bit selects. Here: |x| < 2^20 (else: the caller's fall-back), the octant as a
+// 32-bit integer, z = x - y pi/4 by three FMAs -- for y < 2^21 the reference's first two steps are exact (PI4A, PI4B carry 30 and 21
+// significant bits: exact products, exact differences) and its third rounds the same real this FMA rounds: the two z differ by at
+// most one ulp -- and the reference's own two polynomials (sin.go: _sin, _cos) in FMA Horner form: a few 2^-53 (relative) from the
+// unfused evaluation, no cancellation (|z| <= pi/4: the cosine form stays above 0.7, the sine form is z (1 + small)). So r is within
+// 2^-49 (relative) of Go's float64 g, and float32(g) is decided wherever every float64 within 2^-44 of r rounds to one float32:
+// float32(r (1 + 2^-44)) == float32(r (1 - 2^-44)), bit for bit, for both results. One value in ~2^19 is rejected. ~62 instructions.
+// Checked against cossinf_ on device for EVERY float32 argument (gsdf_hip_selftest_cossin: 2^32 bit patterns).
+DM_INL void cossin_fast(float xf, float& c_out, float& s_out, bool& ok) {
+  const double xs = (double)xf;
+  const double x = __builtin_fabs(xs);
+  ok = absf(xf) < 1048576.0f;  // 2^20 (NaN: false)
+  int j = (int)(x * (4.0 / DM_PI));  // truncates; < 1.34e6
+  j += j & 1;                        // "map zeros to origin": odd octants belong to the next even one
+  const double y = (double)j;
+  double z = __builtin_fma(-y, 7.85398125648498535156e-1, x);
+  z = __builtin_fma(-y, 3.77489470793079817668e-8, z);
+  z = __builtin_fma(-y, 2.69515142907905952645e-15, z);
+  const double zz = z * z;
+  double ps = 1.58962301576546568060e-10;
+  ps = __builtin_fma(ps, zz, -2.50507477628578072866e-8);
+  ps = __builtin_fma(ps, zz, 2.75573136213857245213e-6);
+  ps = __builtin_fma(ps, zz, -1.98412698295895385996e-4);
+  ps = __builtin_fma(ps, zz, 8.33333333332211858878e-3);
+  ps = __builtin_fma(ps, zz, -1.66666666666666307295e-1);
+  ps = __builtin_fma(z * zz, ps, z);
+  double pc = -1.13585365213876817300e-11;
+  pc = __builtin_fma(pc, zz, 2.08757008419747316778e-9);
+  pc = __builtin_fma(pc, zz, -2.75573141792967388112e-7);
+  pc = __builtin_fma(pc, zz, 2.48015872888517045348e-5);
+  pc = __builtin_fma(pc, zz, -1.38888888888730564116e-3);
+  pc = __builtin_fma(pc, zz, 4.16666666666665929218e-2);
+  pc = __builtin_fma(zz * zz, pc, __builtin_fma(-0.5, zz, 1.0));
+  const uint32_t j8 = (uint32_t)j & 7u, hi = j8 >> 2, j4 = j8 & 3u;  // octant mod 8; "j > 3: j -= 4, both signs flip"
+  const bool sw = j4 == 1u || j4 == 2u;                              // the sine series gives the cosine and the other way round
+  const uint32_t csign = hi ^ (j4 >> 1), ssign = hi ^ (xf < 0.0f ? 1u : 0u);
+  const double c0 = sw ? ps : pc, s0 = sw ? pc : ps;
+  const double c = __longlong_as_double(__double_as_longlong(c0) ^ ((long long)csign << 63));
+  const double sn = __longlong_as_double(__double_as_longlong(s0) ^ ((long long)ssign << 63));
+  const float c1 = (float)__builtin_fma(c, 0x1p-44, c), c2 = (float)__builtin_fma(c, -0x1p-44, c);
+  const float s1 = (float)__builtin_fma(sn, 0x1p-44, sn), s2 = (float)__builtin_fma(sn, -0x1p-44, sn);
+  ok = ok && __float_as_uint(c1) == __float_as_uint(c2) && __float_as_uint(s1) == __float_as_uint(s2);
+  c_out = c1;
+  s_out = xf == 0.0f ? xf : s1;  // Sin(+-0) = +-0
+}
+
 // math.Acos = Pi/2 - Asin (go/src/math/asin.go)
 DM_INL float acosf_(float xf) {
   double x = (double)xf;

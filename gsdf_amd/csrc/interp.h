@@ -262,6 +262,17 @@ __device__ __forceinline__ void atan2_shared(const P3 (&pv)[K], float (&out)[K],
   xy_shared<K>(pv, out, shared, brick, [](float x, float y) { return dm::atan2_ref(y, x); }, column);
 }
 
+// math.Cos / math.Sin of one angle per lane: dm::cossin_fast, one wave vote, the reference's sequence (dm::cossinf_) for the wave where
+// some lane's result is not decided by the short route. (Per-tree builds only, like the short atan2: see atan2_shared.)
+__device__ __forceinline__ void cossin_voted(float x, float& c, float& s) {
+#if defined(GSDF_SPECIALIZED) && !defined(GSDF_NO_COSSIN_FAST)
+  bool ok;
+  dm::cossin_fast(x, c, s, ok);
+  if (__all(ok)) return;
+#endif
+  dm::cossinf_(x, c, s);
+}
+
 // hypot(P.x,P.y) of every point into hxy[] unless the cache is valid
 #define ENSURE_HXY() \
   if (!use_hxy) xy_shared<K>(pv, hxy, sh_xy, brick, [](float x, float y) { return dm::hypotf_(x, y); }, sh_col)
@@ -943,15 +954,15 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
             float zs = pv[0].z;
             KLOOP if (sel == (uint32_t)kp) zs = pv[kp].z;
             float c1, s1;
-            cossinf_(k * zs, c1, s1);
+            cossin_voted(k * zs, c1, s1);
             KLOOP {
               tc[kp] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c1), kp));
               ts[kp] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s1), kp));
             }
           } else {
-            KLOOP if (kp < (K + 1) / 2) cossinf_(k * pv[kp].z, tc[kp], ts[kp]);
+            KLOOP if (kp < (K + 1) / 2) cossin_voted(k * pv[kp].z, tc[kp], ts[kp]);
             if (sh_z) { KLOOP if (kp >= (K + 1) / 2) { tc[kp] = tc[kp - K / 2]; ts[kp] = ts[kp - K / 2]; } }
-            else { KLOOP if (kp >= (K + 1) / 2) cossinf_(k * pv[kp].z, tc[kp], ts[kp]); }
+            else { KLOOP if (kp >= (K + 1) / 2) cossin_voted(k * pv[kp].z, tc[kp], ts[kp]); }
           }
         }
         KLOOP {

@@ -186,6 +186,26 @@ __global__ void __launch_bounds__(BLOCK) atan2_selftest_kernel(int mode, int log
   if (nf) atomicAdd(fast_count, nf);
 }
 
+// Exhaustive self-test of dm::cossin_fast against dm::cossinf_ (float32 of Go's float64 math.Cos / math.Sin): every float32 bit pattern;
+// wherever the short route accepts, both of its float32 results must be the reference's, bit for bit. bad: accepted and different;
+// fast_count: accepted.
+__global__ void __launch_bounds__(BLOCK) cossin_selftest_kernel(unsigned long long* __restrict__ bad, unsigned long long* __restrict__ fast_count) {
+  unsigned long long nb = 0, nf = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < (1ull << 32); i += (unsigned long long)gridDim.x * BLOCK) {
+    const float x = __uint_as_float((unsigned)i);
+    float c, s;
+    bool ok;
+    dm::cossin_fast(x, c, s, ok);
+    if (!ok) continue;
+    nf++;
+    float cr, sr;
+    dm::cossinf_(x, cr, sr);
+    if (__float_as_uint(c) != __float_as_uint(cr) || __float_as_uint(s) != __float_as_uint(sr)) nb++;
+  }
+  if (nb) atomicAdd(bad, nb);
+  if (nf) atomicAdd(fast_count, nf);
+}
+
 // Exhaustive self-test of dm::div_by_uniform: every float32 numerator against the IEEE division.
 __global__ void __launch_bounds__(BLOCK) div_selftest_kernel(float d, float r, unsigned long long* __restrict__ bad,
                                                              unsigned long long* __restrict__ fast_count) {

@@ -21,7 +21,7 @@ ErrMismatchBufferLength = "position and distance buffer length mismatch"
 
 # every symbol include/gsdf_hip.h declares
 SYMBOLS = ["gsdf_hip_last_error", "gsdf_hip_init", "gsdf_hip_program_create", "gsdf_hip_program_destroy",
-           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_lower_region", "gsdf_hip_eval3_submit", "gsdf_hip_eval_wait", "gsdf_hip_host_alloc", "gsdf_hip_host_register", "gsdf_hip_host_release", "gsdf_hip_comm_unique_id", "gsdf_hip_comm_create", "gsdf_hip_comm_rank", "gsdf_hip_comm_world", "gsdf_hip_comm_allreduce_sum_u64", "gsdf_hip_mesh_gatherv", "gsdf_hip_mesh_gatherv_start", "gsdf_hip_mesh_gatherv_wait", "gsdf_hip_comm_destroy", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_selftest_circ", "gsdf_hip_selftest_atan2", "gsdf_hip_mesh_minecraft", "gsdf_hip_blockcache_create", "gsdf_hip_blockcache_reset", "gsdf_hip_blockcache_eval3", "gsdf_hip_blockcache_hits", "gsdf_hip_blockcache_evaluations", "gsdf_hip_blockcache_destroy", "gsdf_hip_program_specialize", "gsdf_hip_program_specialize_async", "gsdf_hip_program_specialize_poll", "gsdf_hip_program_is_specialized", "gsdf_hip_program_kernels", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
+           "gsdf_hip_program_bounds", "gsdf_hip_program_is2d", "gsdf_hip_program_info", "gsdf_hip_evaluations", "gsdf_hip_lower", "gsdf_hip_lower_region", "gsdf_hip_eval3_submit", "gsdf_hip_eval_wait", "gsdf_hip_host_alloc", "gsdf_hip_host_register", "gsdf_hip_host_release", "gsdf_hip_comm_unique_id", "gsdf_hip_comm_create", "gsdf_hip_comm_rank", "gsdf_hip_comm_world", "gsdf_hip_comm_allreduce_sum_u64", "gsdf_hip_mesh_gatherv", "gsdf_hip_mesh_gatherv_start", "gsdf_hip_mesh_gatherv_wait", "gsdf_hip_comm_destroy", "gsdf_hip_selftest_div", "gsdf_hip_selftest_sqrt", "gsdf_hip_selftest_circ", "gsdf_hip_selftest_atan2", "gsdf_hip_selftest_cossin", "gsdf_hip_mesh_minecraft", "gsdf_hip_blockcache_create", "gsdf_hip_blockcache_reset", "gsdf_hip_blockcache_eval3", "gsdf_hip_blockcache_hits", "gsdf_hip_blockcache_evaluations", "gsdf_hip_blockcache_destroy", "gsdf_hip_program_specialize", "gsdf_hip_program_specialize_async", "gsdf_hip_program_specialize_poll", "gsdf_hip_program_is_specialized", "gsdf_hip_program_kernels", "gsdf_hip_specialize_source", "gsdf_hip_specialize_check",
            "gsdf_hip_eval3", "gsdf_hip_eval2", "gsdf_hip_eval3_dev", "gsdf_hip_eval2_dev", "gsdf_hip_normals3", "gsdf_hip_image2",
            "gsdf_hip_mesh_octree", "gsdf_hip_mesh_dualcontour", "gsdf_hip_mesh_flat", "gsdf_hip_mesh_stats_get", "gsdf_hip_mesh_read", "gsdf_hip_mesh_dev_tris",
            "gsdf_hip_mesh_stl", "gsdf_hip_mesh_host_tris", "gsdf_hip_mesh_host_stl", "gsdf_hip_mesh_destroy", "gsdf_hip_brick_owner", "gsdf_hip_slab_range",
@@ -108,6 +108,7 @@ def lib():
         L.gsdf_hip_selftest_sqrt.argtypes = [C.POINTER(C.c_uint64)]
         L.gsdf_hip_selftest_circ.argtypes = [C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.gsdf_hip_selftest_atan2.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.gsdf_hip_selftest_cossin.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.gsdf_hip_blockcache_create.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_void_p)]
         L.gsdf_hip_blockcache_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float]
         L.gsdf_hip_blockcache_eval3.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t]

@@ -80,6 +80,10 @@ int gsdf_hip_selftest_circ(float ncirc, uint64_t* mismatches, uint64_t* fast_pat
  * reference's own operation sequence, against that sequence: 2^log2n pairs; mode 0 hashed pairs of every sign and magnitude,
  * 1 pairs searched towards float32 rounding boundaries, 2 lattice-shaped pairs. mismatches must come back 0. */
 int gsdf_hip_selftest_atan2(int mode, int log2n, uint64_t* mismatches, uint64_t* fast_path_points);
+/* Test hook (needs a GPU): float32(math.Cos(x)), float32(math.Sin(x)) of a twist's angle (cpu_evaluators.go:1269-1270) by the short
+ * float64 route of the per-tree kernels, taken only where it provably rounds like the reference's own operation sequence, against that
+ * sequence over EVERY float32 argument. mismatches must come back 0. */
+int gsdf_hip_selftest_cossin(uint64_t* mismatches, uint64_t* fast_path_arguments);
 /* Run-time specialisation (no reference counterpart; the reference's GPU path compiles GLSL per tree at
  * gleval/gpu.go:35-54, this is the same step for the HIP backend): builds, with hiprtc, eval / prune / leaf kernels in
  * which this program's instructions are laid out straight-line with literal parameters, and makes the handle launch

@@ -231,6 +231,18 @@ def test_atan2_short_route_rounds_like_the_reference(gpu):
         assert nfast.value > 0.95 * 2.0 ** log2n, (mode, nfast.value / 2.0 ** log2n)   # (zeros are one pair in 32: they take the reference's route)
 
 
+def test_cossin_short_route_rounds_like_the_reference_for_every_float(gpu):
+    """dm::cossin_fast -- float32(math.Cos), float32(math.Sin) by FMAs on a 32-bit octant, accepted only where every float64 within 2^-44
+    of its results rounds to one float32 -- against the reference's sequence (dm::cossinf_) for EVERY float32 argument (2^32 bit patterns:
+    subnormals, both zeros, |x| up to the route's 2^20 limit; beyond it, infinities and NaN it declines). No accepted result may differ."""
+    import ctypes as C
+    bad, nfast = C.c_uint64(1), C.c_uint64(0)
+    assert gpu.lib().gsdf_hip_selftest_cossin(C.byref(bad), C.byref(nfast)) == 0
+    assert bad.value == 0, (bad.value, nfast.value)
+    # |x| < 2^20: exponents 0 .. 146 of 256, both signs: 2 * 147 * 2^23 arguments less the rejected one in ~2^19
+    assert 0.999 * 2 * 147 * 2 ** 23 < nfast.value <= 2 * 147 * 2 ** 23, nfast.value
+
+
 def test_circular_array_points_on_sector_boundaries(gpu):
     """The sector index comes from a float32 angle estimate unless some point of the wave is too close to a sector boundary:
     points ON the boundaries (angle k * 2 pi / n to the last bit, the axes, +-0, the origin) mixed with ordinary ones, so that
