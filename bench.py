@@ -717,9 +717,6 @@ def main():
             acc["emit_ms"] += st.ms_emit
             acc["cut"] += st.cut_leaves
 
-        import gc
-        gc.collect()
-        gc.disable()  # (the loop's host side is a few ctypes calls per mesh: a collection in the middle of K = 10 steps is a visible fraction of them)
         barrier()
         t0 = time.perf_counter()
         last = run_meshes(args.steps, account)
@@ -728,7 +725,6 @@ def main():
             last = (last[0], gl)
         barrier()
         dt = time.perf_counter() - t0
-        gc.enable()
         tot = torch.tensor([float(acc["evals"]), float(acc["tris"]), dt], dtype=torch.float64, device=dev if torch_gather else "cpu")
         evals_minmax = None
         if dist is not None:

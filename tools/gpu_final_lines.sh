@@ -3,7 +3,7 @@
 # THIS build (roofline.counters: "its code key equals the running kernels'") -> gpurun_out/<tag>_*
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 T=${1:-r6k}
-python -m pytest tests -m gpu -q > gpurun_out/${T}_gpu_suite.log 2>&1; grep -E "passed|failed|error" gpurun_out/${T}_gpu_suite.log | tail -3
+if [ "$2" != "nosuite" ]; then python -m pytest tests -m gpu -q > gpurun_out/${T}_gpu_suite.log 2>&1; grep -E "passed|failed|error" gpurun_out/${T}_gpu_suite.log | tail -3; fi
 timeout 900 python bench.py --steps 20 --warmup 3 > gpurun_out/${T}_default_bench.json 2> gpurun_out/${T}_default_bench.err
 for sc in "npt-flange 1600" "bolt 2000" "knurled-cylinder 2000"; do set -- $sc
   timeout 900 python bench.py --scene $1 --resdiv $2 --no-cpu-baseline 2>/dev/null | grep "^{" | tail -1 > gpurun_out/${T}_$1_bench.json; done
