@@ -717,6 +717,14 @@ def main():
             acc["emit_ms"] += st.ms_emit
             acc["cut"] += st.cut_leaves
 
+        import gc
+        gcmode = os.environ.get("GSDF_BENCH_GC", "")  # developer experiment (HISTORY round 6, item 18): "freeze" / "disable" / "collect"; default: nothing
+        if gcmode in ("freeze", "collect", "disable"):
+            gc.collect()
+        if gcmode == "freeze":
+            gc.freeze()
+        if gcmode == "disable":
+            gc.disable()
         barrier()
         t0 = time.perf_counter()
         last = run_meshes(args.steps, account)
@@ -725,6 +733,7 @@ def main():
             last = (last[0], gl)
         barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
         tot = torch.tensor([float(acc["evals"]), float(acc["tris"]), dt], dtype=torch.float64, device=dev if torch_gather else "cpu")
         evals_minmax = None
         if dist is not None:
