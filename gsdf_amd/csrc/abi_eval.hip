@@ -143,7 +143,7 @@ extern "C" int gsdf_hip_selftest_cossin(uint64_t* mismatches, uint64_t* fast_pat
   return rc;
 }
 
-// Test hook: dm::sqrt_1to2 against sqrtf for all 8,388,609 floats in [1, 2].
+// Test hook: dm::sqrt_1to2 against sqrtf for all 8,388,609 floats in [1, 2]; dm::sqrt_core against sqrtf for every float >= 2^-96.
 extern "C" int gsdf_hip_selftest_sqrt(uint64_t* mismatches) {
   unsigned long long* d_c = nullptr;
   HIP_TRY(hipMalloc((void**)&d_c, 8));

@@ -102,6 +102,46 @@ DM_INL float sqrt_1to2(float s) {
   return __uint_as_float(u);
 }
 
+// Correctly rounded sqrt of the K values of a lane where every value of the WAVE is at least 2^-96 (or NaN / +Inf): the compiler's
+// expansion of sqrtf without its range handling. That expansion is v_sqrt_f32 (1 ulp), the two neighbours r -+ 1 ulp, their residuals
+// s - r' r by FMA and two selects -- wrapped in a pre-scaling by 2^32 for arguments below 2^-96 (a multiply, a compare, a select; a
+// multiply and a select behind) and a class test that hands zeros and infinities through (a compare, a select): seven of its sixteen
+// instructions, all idle for a squared distance that is neither zero nor vanishing. Here: the wave's smallest argument decides
+// (two v_min3 for four values, a compare, a vote) between the nine-instruction core for everyone and the compiler's expansion for
+// everyone. The core is the expansion's own instruction sequence, so the bits are the same by construction wherever it runs: an
+// argument >= 2^-96 is not pre-scaled (the threshold is the expansion's own, 0x0f800000), and +Inf / NaN come out of the core as they
+// come out of v_sqrt_f32 (the neighbours' residuals are NaN, both selects keep r). Zero takes the compiler's path with its wave.
+// Per-tree kernels only, like the other short routes (interp.h: atan2_shared).
+DM_INL float sqrt_core(float s) {
+  const float r = __builtin_amdgcn_sqrtf(s);
+  const uint32_t u = __float_as_uint(r);
+  const float rm = __uint_as_float(u - 1u), rp = __uint_as_float(u + 1u);
+  const float em = __builtin_fmaf(-rm, r, s), ep = __builtin_fmaf(-rp, r, s);
+  float o = (em <= 0.0f) ? rm : r;
+  o = (ep > 0.0f) ? rp : o;
+  return o;
+}
+template <int K>
+DM_INL void sqrt_k(const float (&s)[K], float (&r)[K]) {
+#if defined(GSDF_SPECIALIZED) && !defined(GSDF_NO_SQRT_CORE)
+  float m = s[0];
+  if (K == 4) m = minf(minf(minf(s[0], s[K > 1 ? 1 : 0]), s[K > 2 ? 2 : 0]), s[K > 3 ? 3 : 0]);
+  else {
+#pragma unroll
+    for (int k = 1; k < K; k++) m = minf(m, s[k]);
+  }
+  // (v_min_f32 drops a NaN operand: a NaN argument beside ordinary ones takes the core, which returns what v_sqrt_f32 returns for it,
+  // as the expansion does; all NaN: the compare fails, the compiler's path)
+  if (__all(m >= 1.2621774483536189e-29f /* 2^-96 */)) {
+#pragma unroll
+    for (int k = 0; k < K; k++) r[k] = sqrt_core(s[k]);
+    return;
+  }
+#endif
+#pragma unroll
+  for (int k = 0; k < K; k++) r[k] = sqrtf_(s[k]);
+}
+
 // math32.Hypot (float32 port of go/src/math/hypot.go)
 DM_INL float hypotf_(float p, float q) {
   p = absf(p);

@@ -75,28 +75,36 @@ __device__ __forceinline__ bool poly_edges(code_ptr code, uint32_t q, uint32_t n
     // such operations per point are worth six moves to vector registers per edge. Same values, same operations.
     const float v1x = in_vgpr<(K >= 2)>(e0.x), v1y = in_vgpr<(K >= 2)>(e0.y), ex = in_vgpr<(K >= 2)>(e0.z), ey = in_vgpr<(K >= 2)>(e0.w),
                 n2e = in_vgpr<(K >= 2)>(e1.x), v2y = e1.y, rn2e = in_vgpr<(K >= 2)>(e1.z);
-    KLOOP {
-      const float px = pv[kp].x, py = pv[kp].y;
-      const float wx = px - v1x, wy = py - v1y;
-      if (kd) {
-        const float num = wx * ex + wy * ey;
-        float quo;
-        if (FAST) {
-          quo = div_by_uniform(num, n2e, rn2e);
-          nmin = minf(nmin, absf(num));
-          nmax = maxf(nmax, absf(num));
+    float wx[K], wy[K];
+    KLOOP { wx[kp] = pv[kp].x - v1x; wy[kp] = pv[kp].y - v1y; }
+    // The two parts under ONE wave-uniform branch each, over the K points (round 6: with the tests inside the point loop the compiler
+    // branched per point and carried the two uniform flags through vector registers -- four v_cndmask / v_cmp per edge, and a move
+    // behind every v_min), and the K numerators guarded together: nested minima / maxima fold into v_min3_f32 / v_max3_f32.
+    if (kd) {
+      float num[K];
+      KLOOP num[kp] = wx[kp] * ex + wy[kp] * ey;
+      if (FAST) {
+        if (K == 4) {
+          nmin = minf(minf(minf(nmin, absf(num[0])), absf(num[K > 1 ? 1 : 0])), minf(absf(num[K > 2 ? 2 : 0]), absf(num[K > 3 ? 3 : 0])));
+          nmax = maxf(maxf(maxf(nmax, absf(num[0])), absf(num[K > 1 ? 1 : 0])), maxf(absf(num[K > 2 ? 2 : 0]), absf(num[K > 3 ? 3 : 0])));
         } else {
-          quo = num / n2e;
+          KLOOP { nmin = minf(nmin, absf(num[kp])); nmax = maxf(nmax, absf(num[kp])); }
         }
+      }
+      KLOOP {
+        const float quo = FAST ? div_by_uniform(num[kp], n2e, rn2e) : num[kp] / n2e;
         // clamp(v,0,1) as med3: differs from the reference's if-chain only in the sign of a zero t, which cannot
         // reach d (t only scales e before the square)
         const float t = __builtin_amdgcn_fmed3f(quo, 0.f, 1.f);
-        const float bx = wx - t * ex, by = wy - t * ey;
+        const float bx = wx[kp] - t * ex, by = wy[kp] - t * ey;
         d[kp] = minf(d[kp], bx * bx + by * by);
       }
-      if (ks) {
+    }
+    if (ks) {
+      KLOOP {
+        const float py = pv[kp].y;
         const uint64_t b1 = __builtin_amdgcn_ballot_w64(py >= v1y), b2 = __builtin_amdgcn_ballot_w64(py < v2y),
-                       b3 = __builtin_amdgcn_ballot_w64(ex * wy > ey * wx);
+                       b3 = __builtin_amdgcn_ballot_w64(ex * wy[kp] > ey * wx[kp]);
         negm[kp] ^= ~((b1 ^ b2) | (b2 ^ b3));  // flip where all three are true or all three are false
       }
     }
@@ -173,9 +181,13 @@ __device__ __forceinline__ float wave_minmax(float v) {
   return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
 }
 
+// recip (wave-uniform: bit 31 of the polygon's header, every |e|^2 in [2^-30, 2^30] and its reciprocal in the record): the test's own
+// arithmetic may then be approximate -- the quotient as a product with the host's reciprocal (within 2^-23 of t in [0, 1]: 1.2e-7 |e| in
+// b), the two square roots as the bare v_sqrt_f32 (1 ulp; a subnormal argument costs at most 1.1e-19 absolute, against m >= 1e-5 *
+// 2^-15) -- each far inside the margin m below, which is what keeps a doubtful edge. 12 + 2 x 16 instructions become 1 + 2 x 1.
 template <int K>
 __device__ __forceinline__ void poly_cull(code_ptr code, uint32_t q0, uint32_t nv, const P3 (&pv)[K], uint64_t& keepd,
-                                          uint64_t& keeps) {
+                                          uint64_t& keeps, const bool recip = false) {
   using namespace dm;
   float x0 = pv[0].x, x1 = pv[0].x, y0 = pv[0].y, y1 = pv[0].y;
   KLOOP {
@@ -189,11 +201,19 @@ __device__ __forceinline__ void poly_cull(code_ptr code, uint32_t q0, uint32_t n
   const v4f r0 = rec[0], r1 = rec[1];
   const float v1x = r0.x, v1y = r0.y, ex = r0.z, ey = r0.w, n2e = r1.x, v2y = r1.y;
   const float cx = 0.5f * (x0 + x1), cy = 0.5f * (y0 + y1), hx = 0.5f * (x1 - x0), hy = 0.5f * (y1 - y0);
-  const float rb = sqrtf_(hx * hx + hy * hy);
+#ifdef GSDF_NO_CULL_APPROX
+  const bool approx = false;
+#else
+  const bool approx = recip;
+#endif
+  const float rb2 = hx * hx + hy * hy;
+  const float rb = approx ? __builtin_amdgcn_sqrtf(rb2) : sqrtf_(rb2);
   const float wx = cx - v1x, wy = cy - v1y;
-  const float t = __builtin_amdgcn_fmed3f((wx * ex + wy * ey) / n2e, 0.f, 1.f);
+  const float num = wx * ex + wy * ey;
+  const float t = __builtin_amdgcn_fmed3f(approx ? num * r1.z : num / n2e, 0.f, 1.f);
   const float bx = wx - t * ex, by = wy - t * ey;
-  const float dc = sqrtf_(bx * bx + by * by);
+  const float dc2 = bx * bx + by * by;
+  const float dc = approx ? __builtin_amdgcn_sqrtf(dc2) : sqrtf_(dc2);
   // Each edge pads its OWN interval by its OWN error bound: m = 1e-5 of the largest magnitude entering its sums, |w|, |e|, rb, |c|
   // in the 1-norm (no square roots; |c| too: the rounded centre may sit half an ulp of its own magnitude off the box's true
   // centre) -- the float error of dc -+ rb is below 1e-6 of that. Edge e is never the nearest one if its padded lower bound lies
@@ -862,13 +882,12 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
           bool neg[K];
           bool done = false;
           uint64_t keepd = ~0ull, keeps = ~0ull;
-          if (brick && nv >= 6u && nv <= 64u) poly_cull<K>(code, q0, nv, pv, keepd, keeps);  // a spatially compact wave: a 4x4x4-leaf brick, a patch of lattice cells, a run of kept cubes
+          if (brick && nv >= 6u && nv <= 64u) poly_cull<K>(code, q0, nv, pv, keepd, keeps, (hdr >> 31) != 0u);  // a spatially compact wave: a 4x4x4-leaf brick, a patch of lattice cells, a run of kept cubes
           if (hdr >> 31) done = poly_edges<K, true>(code, q0, nv, v0x, v0y, pv, d, neg, keepd, keeps);
           if (!done) poly_edges<K, false>(code, q0, nv, v0x, v0y, pv, d, neg, keepd, keeps);
-          KLOOP {
-            float sd = sqrtf_(d[kp]);
-            Rv[kp] = neg[kp] ? -sd : sd;  // s * sqrt(d), s = +-1
-          }
+          float sd[K];
+          sqrt_k<K>(d, sd);
+          KLOOP Rv[kp] = neg[kp] ? -sd[kp] : sd[kp];  // s * sqrt(d), s = +-1
         }
         pc = q0 + 8u * nv;
         break;
@@ -889,7 +908,9 @@ __device__ __forceinline__ void sdf_eval(code_ptr code, P3 (&pv)[K], float (&Rv)
             d[kp] = minf(d[kp], rx * rx + ry * ry);
           }
         }
-        KLOOP Rv[kp] = sqrtf_(d[kp]) - w2;
+        float sd[K];
+        sqrt_k<K>(d, sd);
+        KLOOP Rv[kp] = sd[kp] - w2;
         pc = q;
         break;
       }

@@ -75,12 +75,21 @@ __global__ void __launch_bounds__(BLOCK, 3) image2_kernel(const uint32_t* __rest
 // caller's mapped buffers are released at its end; PCIe keeps posted writes in order, so the host sees them before the flag.)
 __global__ void signal_kernel(unsigned* flag, unsigned v) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-// Exhaustive self-test of dm::sqrt_1to2 over every float in [1, 2].
+// Exhaustive self-test of dm::sqrt_1to2 over every float in [1, 2] ...
 __global__ void __launch_bounds__(BLOCK) sqrt_selftest_kernel(unsigned long long* __restrict__ bad) {
   unsigned long long nb = 0;
   for (unsigned i = 0x3f800000u + blockIdx.x * BLOCK + threadIdx.x; i <= 0x40000000u; i += gridDim.x * BLOCK) {
     const float s = __uint_as_float(i);
     if (__float_as_uint(dm::sqrt_1to2(s)) != __float_as_uint(__builtin_sqrtf(s))) nb++;
+  }
+  // ... and of dm::sqrt_core (dm::sqrt_k's route) over every float bit pattern it may be given: s >= 2^-96, +Inf, NaN (a NaN for a NaN)
+  for (unsigned long long j = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; j < (1ull << 32); j += (unsigned long long)gridDim.x * BLOCK) {
+    const float s = __uint_as_float((unsigned)j);
+    const unsigned sb = (unsigned)j;
+    if ((sb >> 31) != 0u || sb < 0x0f800000u) continue;  // (negatives, zeros, below 2^-96: the wave takes the compiler's expansion)
+    const unsigned a = __float_as_uint(dm::sqrt_core(s)), b = __float_as_uint(__builtin_sqrtf(s));
+    const bool an = (a & 0x7fffffffu) > 0x7f800000u, bn = (b & 0x7fffffffu) > 0x7f800000u;
+    if (an || bn ? an != bn : a != b) nb++;
   }
   if (nb) atomicAdd(bad, nb);
 }

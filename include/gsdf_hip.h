@@ -70,7 +70,8 @@ uint64_t gsdf_hip_evaluations(const gsdf_program* p);
 /* Test hook (needs a GPU): exhaustive check of the interpreter's exact division by a wave-uniform divisor d against
  * the IEEE division, over all 2^32 numerators. recip receives RN(1/d) (0: d not eligible, nothing to check). */
 int gsdf_hip_selftest_div(float d, uint64_t* mismatches, uint64_t* fast_path_numerators, float* recip);
-/* Test hook (needs a GPU): the interpreter's sqrt for hypot's [1,2] argument range against sqrtf, all floats in range. */
+/* Test hook (needs a GPU): the interpreter's sqrt for hypot's [1,2] argument range against sqrtf, all floats in range; and the
+ * per-tree kernels' sqrt without range handling (taken where a wave's arguments are all >= 2^-96) against sqrtf, every such float. */
 int gsdf_hip_selftest_sqrt(uint64_t* mismatches);
 /* Test hook (needs a GPU): the circular array's sector index from a float32 angle estimate (taken only where it provably
  * decides floor(atan2(y, x) / angle), cpu_evaluators.go:1047-1056) against that expression, over 2^32 points. */
