@@ -444,8 +444,10 @@ def self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # (default K: a step is a third of a millisecond and up to three are in flight -- with K = 10 the pipeline's fill and drain were 7 % of
+    # the timed region, 0.345-0.350 ms per step against 0.323-0.327 from K = 200 on; HISTORY.md round 6, item 20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--resdiv", type=int, default=1600)
     ap.add_argument("--scene", default="npt-flange")
     ap.add_argument("--cpu-resdiv", type=int, default=0, help="resdiv of the bounded CPU sample (0 = pick ~10-30 s of CPU work from the core count)")
