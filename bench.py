@@ -709,8 +709,12 @@ def main():
             gstat[k] = 0
         acc = {"evals": 0, "tris": 0, "march_ms": 0.0, "march_evals": 0.0, "march_tris": 0.0, "emit_ms": 0.0, "cut": 0.0}
 
+        trace = [] if os.environ.get("GSDF_BENCH_STEP_TRACE") else None  # developer: wall clock at every finished step -> the largest gaps on stderr
+
         def account(oc):
             st = oc.stats
+            if trace is not None:
+                trace.append(time.perf_counter())
             acc["evals"] += st.evals
             acc["tris"] += st.n_tris
             acc["march_ms"] += st.ms_march
@@ -736,6 +740,9 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         gc.enable()
+        if trace is not None and len(trace) > 2:
+            gaps = sorted(((trace[i + 1] - trace[i]) * 1e3, i) for i in range(len(trace) - 1))
+            print("bench: step trace: median gap %.4f ms, largest %s, gc counts %s" % (gaps[len(gaps) // 2][0], [(round(g, 3), i) for g, i in gaps[-6:]], gc.get_count()), file=sys.stderr)
         tot = torch.tensor([float(acc["evals"]), float(acc["tris"]), dt], dtype=torch.float64, device=dev if torch_gather else "cpu")
         evals_minmax = None
         if dist is not None:
