@@ -897,7 +897,7 @@ def main():
         }
         if not dc and two_kernel:
             # march_records_kernel alone (the same blocking meshes): its two streams against the HBM peak and against what a plain
-            # HIP copy kernel of as many bytes reaches on this part (tools/ubench/copy_rate.hip; profiles/r6_copy_rate.txt)
+            # HIP copy kernel of as many bytes reaches on this part (tools/ubench/copy_rate.hip; profiles/r6m_copy_rate.txt)
             m_ms = sum(a.ms_emit for a in alone) / len(alone)
             e_bytes = a_cut * 40.0 + a_tri * 36.0
             m_gbs = e_bytes / (m_ms * 1e-3) / 1e9 if m_ms > 0 else 0.0
