@@ -649,6 +649,7 @@ def main():
     # Setup, untimed: bring the GPU out of its idle clock state before the W warmup steps. The first ~20 meshes after
     # start-up run 5 % slower (1.70 vs 1.61 ms leaf kernel), and with the contract's small W they would be the ones timed.
     mesh_pipeline = (comm is None and not torch_gather and not dc and not args.no_mesh_pipeline)
+    rank_pipeline = (comm is not None and not dc and not args.no_mesh_pipeline)  # the N > 1 form of it (run_meshes)
 
     def run_meshes(n, account=None, sc=None):
         """n meshes, every one started and finished inside this call. Pipelined (N = 1): up to --mesh-depth meshes are in flight -- the
@@ -657,6 +658,25 @@ def main():
         sc = args.share_corners if sc is None else sc
         if dc and sdf_b is not None:
             return run_dc_two_handles(n, account)
+        if rank_pipeline:
+            # N > 1 over the library's gather: the same pipeline of meshes on every rank -- a rank's shard is an eighth of a third of a
+            # millisecond, a blocking mesh there is all latency (the replicated top levels, a dozen dependent launches) -- and the
+            # payload of mesh k moves on the communicator's stream while meshes k + 1 .. are made, as in step()
+            inflight, started = [], 0
+            for k in range(n):
+                while started < n and len(inflight) < args.mesh_depth:
+                    inflight.append(hip.OctreeHIP.start(sdf, res, shard_rank=rank, shard_count=world, share_corners=sc, payload=G["payload"]))
+                    started += 1
+                oc = inflight.pop(0).wait()
+                pg = oc.gatherv_start(comm, GM[G["mode"]], 0)
+                gathered = finish()
+                pending.append(pg)
+                if not pipeline:
+                    gathered = finish()
+                last = (oc, gathered)
+                if account:
+                    account(oc)
+            return last
         if not mesh_pipeline:
             for _ in range(n):
                 last = step()
@@ -886,6 +906,8 @@ def main():
                                  "is waited for; all K started and finished inside the timed region") if mesh_pipeline else
                                 (f"{args.dc_handles} handles of the tree, a host thread and one blocking dual-contouring mesh in flight on each (a mesh is one chain with host round trips "
                                  "between its stages); all K made inside the timed region; --no-mesh-pipeline: one handle, one mesh at a time") if (dc and sdf_b is not None)
+                                else (f"every rank: its shard's meshes pipelined {args.mesh_depth} deep on one handle (gsdf_hip_mesh_octree_start / _wait), the gather of mesh k started when "
+                                      "mesh k is done; all K started, finished and gathered inside the timed region") if rank_pipeline
                                 else "one blocking mesh call per step"},
             "triangles_per_s": tris_all / dt,
             "triangles_per_step": tris_all / args.steps, "evals_per_step": evals_all / args.steps,

@@ -419,7 +419,11 @@ struct IpcTransport final : Transport {
   // address with the same handle bytes would be read through the stale mapping. With it hipIpcGetMemHandle on the SENDING side
   // began to fail with "invalid argument" after a dozen gathers at npt-flange@1600 (profiles/r6g: tools/gpu_evidence.sh dist):
   // re-exporting an allocation whose last import was closed is not something this runtime does reliably. The cache stays; the
-  // transport is for tests on one GPU and never a default. GSDF_HIP_IPC_CLOSE=1 selects the other behaviour for experiments.)
+  // transport is for tests on one GPU and never a default. GSDF_HIP_IPC_CLOSE=1 selects the other behaviour for experiments.
+  // The stale-mapping case was then seen for real: with the triangle pool at four idle buffers and eight circulating per rank (three
+  // meshes in flight + a gather), every step freed a buffer, a recycled address reached a peer with the old handle bytes, and the copy
+  // faulted ("Memory access fault by GPU"). The pool keeps sixteen now (abi_host.cpp: pool_max) and nothing is freed in a steady loop;
+  // a caller that does free buffers a peer has mapped remains outside what this test transport supports.)
   struct Mapped { hipIpcMemHandle_t h; void* p; };
   std::vector<Mapped> mapped;
   static bool close_after_copy() { static const bool v = [] { const char* e = getenv("GSDF_HIP_IPC_CLOSE"); return e && atoi(e) != 0; }(); return v; }

@@ -3,6 +3,7 @@
 #include "abi_host.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -59,10 +60,18 @@ void hpool_give(void* p, size_t cap) {
   }
   g_hpool.push_back(HostBuf{p, cap});
 }
+// How many idle device buffers the pool keeps. Three meshes in flight per handle, a records payload each, a gather with its receive
+// buffer and the gathered mesh of the step before: eight buffers circulate on a rank of an N > 1 run (bench.py), and with room for
+// four every step freed one and allocated another -- hipFree waits for the device -- and, over the ipc test transport, a peer's
+// cached mapping of a freed buffer outlived it (a recycled address faulted: round 6, HISTORY item 21). GSDF_HIP_POOL_MAX overrides.
+static size_t pool_max() {
+  static const size_t v = [] { const char* e = getenv("GSDF_HIP_POOL_MAX"); const long n = e ? atol(e) : 16; return (size_t)(n < 1 ? 1 : n); }();
+  return v;
+}
 void pool_give(int device, float* p, uint64_t cap) {
   if (!p) return;
   std::lock_guard<std::mutex> lk(g_pool_mu);
-  if (g_pool.size() >= 4) {  // drop the smallest
+  if (g_pool.size() >= pool_max()) {  // drop the smallest
     size_t sm = 0;
     for (size_t i = 1; i < g_pool.size(); i++) if (g_pool[i].cap < g_pool[sm].cap) sm = i;
     if (g_pool[sm].cap < cap) { (void)hipFree(g_pool[sm].p); g_pool[sm] = TriBuf{device, p, cap}; }

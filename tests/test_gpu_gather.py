@@ -259,6 +259,39 @@ def test_pipelined_gathers_and_early_release_on_the_loopback_transport(gpu):
         assert oks == [True] * 5
 
 
+@pytest.mark.parametrize("payload_name", ["records", "triangles"])
+def test_gathers_under_three_meshes_in_flight_on_the_loopback_transport(gpu, payload_name):
+    """bench.py's N > 1 loop since round 6 (run_meshes: rank_pipeline) at world size 3: every rank keeps three meshes of its shard in flight
+    on ONE handle (gsdf_hip_mesh_octree_start / _wait), starts the gather of mesh k when mesh k is done and waits for the gather of
+    mesh k - 1 -- eight pooled buffers circulate per rank. Every gathered mesh is the whole mesh, bit for bit."""
+    payload = gpu.PAYLOAD_RECORDS if payload_name == "records" else gpu.PAYLOAD_TRIANGLES
+    b = Builder()
+    sh = b.Scene("npt-flange")
+    res = np.float32(float(sh.Diagonal()) / 300)
+    want = _srt(gpu.OctreeHIP(gpu.SDF3HIP(sh), res).RenderAll())
+    n = 9
+
+    def work(r, comm):
+        sdf = gpu.SDF3HIP(sh)
+        if r != 1:
+            sdf.specialize()
+        inflight, started, pend, got, keep = [], 0, None, [], None
+        for k in range(n):
+            while started < n and len(inflight) < 3:
+                inflight.append(gpu.OctreeHIP.start(sdf, res, shard_rank=r, shard_count=3, payload=payload))
+                started += 1
+            oc = inflight.pop(0).wait()
+            nxt = oc.gatherv_start(comm, gpu.GATHER_ALL, 0)
+            if pend is not None:
+                got.append(pend.wait()[0])
+            pend, keep = nxt, oc                                       # (the mesh before `oc` is released here, its gather waited for)
+        got.append(pend.wait()[0])
+        return [bool((_srt(g.RenderAll()).view(np.uint32) == want.view(np.uint32)).all()) for g in got]
+
+    for oks in _loopback_world(gpu, 3, work):
+        assert oks == [True] * n
+
+
 def test_gather_rejects_mixed_payloads(gpu):
     b = Builder()
     sh = b.NewSphere(1.0)
