@@ -301,6 +301,8 @@ int gsdf_hip_mesh_stl(const gsdf_mesh* m, uint8_t* dst, size_t dst_cap);
  * Valid until gsdf_hip_mesh_destroy; repeated calls return the same memory. */
 int gsdf_hip_mesh_host_tris(gsdf_mesh* m, const float** tris);
 int gsdf_hip_mesh_host_stl(gsdf_mesh* m, const uint8_t** stl, size_t* len);
+/* Releases the mesh. Its device buffers go to a per-process pool that the next meshes (and gathers) draw from -- up to 16 idle
+ * buffers are kept (environment: GSDF_HIP_POOL_MAX), beyond that the smallest is freed. */
 void gsdf_hip_mesh_destroy(gsdf_mesh* m);
 
 /* ---- multi-GPU (one process per GPU). The meshers shard with NO data-path collective (shard_rank / shard_count above); the
