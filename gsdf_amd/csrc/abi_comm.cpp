@@ -334,7 +334,9 @@ struct IpcTransport final : Transport {
   struct PendingRecv { void* dst; size_t bytes; int peer; };
   std::vector<int> sent_to;
   std::vector<PendingRecv> recvs;
+  IpcTransport() { pool_exporter_opened(); }
   ~IpcTransport() override {
+    pool_exporter_closed();
     for (Mapped& m : mapped) (void)hipIpcCloseMemHandle(m.p);
     if (shm) munmap(shm, sizeof(IpcShm));
     if (creator) shm_unlink(shm_name.c_str());
@@ -408,6 +410,7 @@ struct IpcTransport final : Transport {
     if (int rc = wait_until([&] { return b.state.load(std::memory_order_acquire) == 0u; }, "a mailbox to empty")) return rc;
     hipIpcMemHandle_t h;
     HIP_TRY(hipIpcGetMemHandle(&h, base));
+    pool_note_exported(base);  // the peer will cache its mapping: the pool keeps this allocation alive while a transport like this one exists
     b.h = h; b.off = (uint64_t)((const char*)d - (const char*)base); b.bytes = bytes; b.rc = GSDF_OK;
     b.state.store(1u, std::memory_order_release);
     sent_to.push_back(peer);
@@ -422,8 +425,8 @@ struct IpcTransport final : Transport {
   // transport is for tests on one GPU and never a default. GSDF_HIP_IPC_CLOSE=1 selects the other behaviour for experiments.
   // The stale-mapping case was then seen for real: with the triangle pool at four idle buffers and eight circulating per rank (three
   // meshes in flight + a gather), every step freed a buffer, a recycled address reached a peer with the old handle bytes, and the copy
-  // faulted ("Memory access fault by GPU"). The pool keeps sixteen now (abi_host.cpp: pool_max) and nothing is freed in a steady loop;
-  // a caller that does free buffers a peer has mapped remains outside what this test transport supports.)
+  // faulted ("Memory access fault by GPU"). The pool keeps sixteen now (abi_host.cpp: pool_max) and nothing is freed in a steady loop,
+  // and it never frees an allocation whose handle a send of this transport has posted (pool_note_exported) while such a transport lives.)
   struct Mapped { hipIpcMemHandle_t h; void* p; };
   std::vector<Mapped> mapped;
   static bool close_after_copy() { static const bool v = [] { const char* e = getenv("GSDF_HIP_IPC_CLOSE"); return e && atoi(e) != 0; }(); return v; }

@@ -68,14 +68,27 @@ static size_t pool_max() {
   static const size_t v = [] { const char* e = getenv("GSDF_HIP_POOL_MAX"); const long n = e ? atol(e) : 16; return (size_t)(n < 1 ? 1 : n); }();
   return v;
 }
+// Buffers whose hipIpcMemHandle has left the process (the ipc test transport, abi_comm.cpp): a peer keeps its mapping of such a buffer
+// cached, so the pool never frees one while a transport of that kind lives -- a recycled address would be read through the stale mapping.
+namespace {
+std::vector<void*> g_exported;
+int g_exporters = 0;
+bool exported_locked(const void* p) { return std::find(g_exported.begin(), g_exported.end(), p) != g_exported.end(); }
+}  // namespace
+void pool_exporter_opened() { std::lock_guard<std::mutex> lk(g_pool_mu); g_exporters++; }
+void pool_exporter_closed() { std::lock_guard<std::mutex> lk(g_pool_mu); if (--g_exporters <= 0) { g_exporters = 0; g_exported.clear(); } }
+void pool_note_exported(void* base) { std::lock_guard<std::mutex> lk(g_pool_mu); if (!exported_locked(base)) g_exported.push_back(base); }
 void pool_give(int device, float* p, uint64_t cap) {
   if (!p) return;
   std::lock_guard<std::mutex> lk(g_pool_mu);
-  if (g_pool.size() >= pool_max()) {  // drop the smallest
-    size_t sm = 0;
-    for (size_t i = 1; i < g_pool.size(); i++) if (g_pool[i].cap < g_pool[sm].cap) sm = i;
-    if (g_pool[sm].cap < cap) { (void)hipFree(g_pool[sm].p); g_pool[sm] = TriBuf{device, p, cap}; }
-    else (void)hipFree(p);
+  if (g_pool.size() >= pool_max()) {  // drop the smallest (of those no peer process may have mapped)
+    int sm = -1;
+    for (size_t i = 0; i < g_pool.size(); i++)
+      if (!exported_locked(g_pool[i].p) && (sm < 0 || g_pool[i].cap < g_pool[(size_t)sm].cap)) sm = (int)i;
+    const bool p_exported = exported_locked(p);
+    if (sm >= 0 && (p_exported || g_pool[(size_t)sm].cap < cap)) { (void)hipFree(g_pool[(size_t)sm].p); g_pool[(size_t)sm] = TriBuf{device, p, cap}; }
+    else if (!p_exported) (void)hipFree(p);
+    else g_pool.push_back(TriBuf{device, p, cap});  // (everything idle is exported: the pool grows past its limit rather than free one)
     return;
   }
   g_pool.push_back(TriBuf{device, p, cap});

@@ -73,6 +73,10 @@ int mesh_march_dense(const uint8_t* d_buf, const gsdf_dense_part* parts, int npa
 // Triangle buffers and pinned host buffers are recycled through small per-process pools (abi_host.cpp).
 float* pool_take(int device, uint64_t need, uint64_t* cap_out);
 void pool_give(int device, float* p, uint64_t cap);
+// the ipc test transport: a transport of that kind exists / is gone; the allocation at `base` has been exported to a peer process
+void pool_exporter_opened();
+void pool_exporter_closed();
+void pool_note_exported(void* base);
 void* hpool_take(size_t need, size_t* cap_out);
 void hpool_give(void* p, size_t cap);
 void big_memcpy(void* dst, const void* src, size_t n);
